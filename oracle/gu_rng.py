@@ -1,0 +1,128 @@
+"""Build-defined per-env counter RNG -- CPU restatement (test infrastructure).
+
+The reference has NO per-env RNG: its start choice
+draws from the process-global stdlib Mersenne Twister
+(core/envs/griduniverse_env.py:64,189) and random actions come from the caller
+(examples/griduniverse_env_examples.py:18, core/algorithms/monte_carlo.py:20).
+A batched engine needs a stream per env that does not depend on how the batch
+is sharded, so the build defines one and this file is its specification:
+
+    word(seed, env, stream, ctr) = MurmurHash3_x86_32 over the four 32-bit
+        little-endian words [seed_lo, seed_hi, env, (stream << 28) | ctr]
+        with hash seed 0x9747B28C   (Appleby's public-domain algorithm)
+
+    action(seed, env, t)      = (word(seed, env, 0, t >> 4) >> (2 * (t & 15))) & 3
+    start_index(seed, env, e) = (word(seed, env, 1, e) * n_starts) >> 32
+
+`env` is the GLOBAL env index (so a sharded run equals the single-GPU run),
+`t` the number of steps the env has taken since seeding, `e` its number of
+resets since seeding.  The HIP implementation is csrc/gu_rng.hpp; the parity
+tests drive the real reference with the numbers produced here.
+"""
+import numpy as np
+
+H0 = 0x9747B28C
+C1 = 0xCC9E2D51
+C2 = 0x1B873593
+M32 = 0xFFFFFFFF
+STREAM_ACTION = 0
+STREAM_START = 1
+CTR_MASK = 0x0FFFFFFF
+
+
+def _rotl(x, r):
+    return ((x << r) | (x >> (32 - r))) & M32
+
+
+def _block(h, k):
+    k = (k * C1) & M32
+    k = _rotl(k, 15)
+    k = (k * C2) & M32
+    h ^= k
+    h = _rotl(h, 13)
+    return (h * 5 + 0xE6546B64) & M32
+
+
+def _fmix(h):
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & M32
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & M32
+    h ^= h >> 16
+    return h
+
+
+def word(seed, env, stream, ctr):
+    """Scalar 32-bit output for (seed:uint64, env:uint32, stream:0..15, ctr:<2^28)."""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    h = H0
+    for k in (seed & M32, seed >> 32, int(env) & M32,
+              ((int(stream) & 0xF) << 28) | (int(ctr) & CTR_MASK)):
+        h = _block(h, k)
+    h ^= 16  # length in bytes
+    return _fmix(h)
+
+
+def action(seed, env, t):
+    return (word(seed, env, STREAM_ACTION, t >> 4) >> (2 * (t & 15))) & 3
+
+
+def start_index(seed, env, episode, n_starts):
+    return (word(seed, env, STREAM_START, episode) * int(n_starts)) >> 32
+
+
+# ---------------------------------------------------------------- vectorised
+def _vrotl(x, r):
+    return ((x << np.uint64(r)) | (x >> np.uint64(32 - r))) & np.uint64(M32)
+
+
+def _vblock(h, k):
+    k = (k * np.uint64(C1)) & np.uint64(M32)
+    k = _vrotl(k, 15)
+    k = (k * np.uint64(C2)) & np.uint64(M32)
+    h = h ^ k
+    h = _vrotl(h, 13)
+    return (h * np.uint64(5) + np.uint64(0xE6546B64)) & np.uint64(M32)
+
+
+def _vfmix(h):
+    h = h ^ (h >> np.uint64(16))
+    h = (h * np.uint64(0x85EBCA6B)) & np.uint64(M32)
+    h = h ^ (h >> np.uint64(13))
+    h = (h * np.uint64(0xC2B2AE35)) & np.uint64(M32)
+    h = h ^ (h >> np.uint64(16))
+    return h
+
+
+def word_v(seed, env, stream, ctr):
+    """Vectorised `word`: env and ctr broadcast; returns uint32 array."""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    env = np.asarray(env, dtype=np.uint64) & np.uint64(M32)
+    ctr = np.asarray(ctr, dtype=np.uint64) & np.uint64(CTR_MASK)
+    env, ctr = np.broadcast_arrays(env, ctr)
+    h = np.full(env.shape, H0, dtype=np.uint64)
+    h = _vblock(h, np.uint64(seed & M32))
+    h = _vblock(h, np.uint64(seed >> 32))
+    h = _vblock(h, env)
+    h = _vblock(h, (np.uint64((int(stream) & 0xF) << 28)) | ctr)
+    h = h ^ np.uint64(16)
+    return _vfmix(h).astype(np.uint32)
+
+
+def actions_v(seed, env, t):
+    """Vectorised `action`; env, t broadcast.  Returns int32 array in 0..3."""
+    t = np.asarray(t, dtype=np.uint64)
+    w = word_v(seed, env, STREAM_ACTION, t >> np.uint64(4)).astype(np.uint64)
+    return ((w >> (np.uint64(2) * (t & np.uint64(15)))) & np.uint64(3)).astype(np.int32)
+
+
+def start_index_v(seed, env, episode, n_starts):
+    w = word_v(seed, env, STREAM_START, episode).astype(np.uint64)
+    return ((w * np.uint64(int(n_starts))) >> np.uint64(32)).astype(np.int32)
+
+
+def action_stream(seed, env_ids, t0, T):
+    """[T, N] int32 uniform actions for global env ids `env_ids`, steps t0..t0+T-1."""
+    env_ids = np.asarray(env_ids, dtype=np.uint64)
+    t = (np.arange(T, dtype=np.uint64) + np.uint64(t0))[:, None]
+    return actions_v(seed, env_ids[None, :], t)

@@ -1,0 +1,141 @@
+"""Pins the batched C oracle (oracle/gu_oracle.c) and the DP restatements to the goldens
+captured from the real reference."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as C
+from oracle import dp as odp
+from oracle import gu_rng
+from oracle.ref_env import OracleGridUniverseEnv
+from tests import _golden as G
+
+
+def digest(obs, rew, don):
+    h = hashlib.sha256()
+    for a in (obs, rew, don):
+        h.update(np.ascontiguousarray(a, dtype='<i4').tobytes())
+    return h.hexdigest()
+
+
+def test_rng_c_equals_python():
+    lib = C.lib()
+    rs = np.random.RandomState(0)
+    for _ in range(300):
+        seed = int(rs.randint(0, 2 ** 63 - 1))
+        env = int(rs.randint(0, 2 ** 31 - 1)) * 2 + int(rs.randint(0, 2))
+        ctr = int(rs.randint(0, 2 ** 28))
+        for stream in (0, 1, 5):
+            assert lib.gu_oracle_rng_word(seed, env, stream, ctr) == gu_rng.word(seed, env, stream, ctr)
+        t = int(rs.randint(0, 2 ** 31 - 1))
+        assert lib.gu_oracle_rng_action(seed, env, t) == gu_rng.action(seed, env, t)
+        n = int(rs.randint(1, 5000))
+        assert lib.gu_oracle_rng_start(seed, env, ctr, n) == gu_rng.start_index(seed, env, ctr, n)
+    assert lib.gu_oracle_rng_word(2 ** 64 - 1, 2 ** 32 - 1, 15, 2 ** 28 - 1) == gu_rng.word(2 ** 64 - 1, 2 ** 32 - 1, 15, 2 ** 28 - 1)
+
+
+@pytest.mark.parametrize('name', G.traj_names())
+def test_trajectories_c_oracle(name):
+    meta, z = G.load_traj(name)
+    grid = C.Grid.from_lists(**meta)
+    T, N = z['actions'].shape
+    for use_rng_actions in (False, True):
+        if use_rng_actions and 'RandomState' in meta['note']:
+            continue  # that fixture's actions come from numpy, not from the build RNG
+        st = C.State(N, meta['env_id0'])
+        first = C.reset(grid, meta['seed'], st)
+        assert np.array_equal(first, z['first_state'])
+        out = C.rollout(grid, meta['seed'], st, T, meta['auto_reset'], None if use_rng_actions else z['actions'],
+                        stats=True)
+        for k in ('obs', 'reward', 'done'):
+            assert np.array_equal(out[k], z[k]), (name, k)
+        assert digest(out['obs'], out['reward'], out['done']) == meta['sha256']
+        assert np.array_equal(out['ret'], z['reward'].sum(0)) and np.array_equal(out['episodes'], z['done'].sum(0))
+        assert np.array_equal(st.pos, z['obs'][-1]) and np.array_equal(st.done, z['done'][-1])
+        assert np.all(st.tcount == T)
+
+
+def test_rollout_is_resumable():
+    meta, z = G.load_traj('rect25x30_busy')
+    grid = C.Grid.from_lists(**meta)
+    T, N = z['actions'].shape
+    st = C.State(N, meta['env_id0'])
+    C.reset(grid, meta['seed'], st)
+    parts = [C.rollout(grid, meta['seed'], st, n, True) for n in (1, 100, T - 101)]
+    for k in ('obs', 'reward', 'done'):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), z[k])
+
+
+@pytest.mark.parametrize('name', sorted(G.load_json('digests.json')))
+def test_large_digests(name):
+    """4096 envs x 1000 steps of the real reference, held as sha256."""
+    d = G.load_json('digests.json')[name]
+    grid = C.Grid.from_lists(**d)
+    st = C.State(d['N'])
+    C.reset(grid, d['seed'], st)
+    out = C.rollout(grid, d['seed'], st, d['T'], d['auto_reset'])
+    assert digest(out['obs'], out['reward'], out['done']) == d['sha256']
+    assert int(out['reward'].sum()) == d['sum_reward'] and int(out['done'].sum()) == d['sum_done']
+
+
+def test_look_step_ahead_table():
+    t = G.load_json('render_quirks.json')['quirks']['lsa_table_6x5']
+    grid = C.Grid.from_lists(**t['spec'])
+    s, a = np.meshgrid(np.arange(30), np.arange(4), indexing='ij')
+    for care in (True, False):
+        n, r, d = C.look_step_ahead(grid, s.ravel(), a.ravel(), care)
+        want = np.array(t['table'][str(care)], dtype=np.int64).reshape(-1, 3)
+        assert np.array_equal(np.stack([n, r, d], 1), want)
+
+
+def _oracle_env(meta):
+    return OracleGridUniverseEnv(grid_shape=(meta['W'], meta['H']), initial_state=list(meta['starts']),
+                                 goal_states=list(meta['goals']), lava_states=list(meta['lava']), walls=list(meta['walls']))
+
+
+@pytest.mark.parametrize('name', G.dp_names())
+def test_dp_c_oracle_bit_exact(name):
+    meta, z = G.load_dp(name)
+    grid = C.Grid.from_lists(**meta)
+    S, gamma = grid.S, meta['gamma']
+    pi0 = np.ones((S, 4)) / 4
+    v = np.zeros(S)
+    for k in range(1, 11):
+        v = C.policy_evaluation_sweep(grid, gamma, pi0, v)
+        if k in (1, 2, 10):
+            assert v.tobytes() == z['eval_v_%d' % k].tobytes(), (name, k)
+    assert C.greedy_policy(grid, gamma, v).tobytes() == z['greedy_pi_after_10'].tobytes()
+    v, pi = np.zeros(S), pi0.copy()
+    for k in range(1, meta['iters'] + 1):
+        v, pi, delta = C.value_iteration_step(grid, gamma, pi, v)
+        assert v.tobytes() == z['vi_v_%d' % k].tobytes(), (name, k)
+        assert pi.tobytes() == z['vi_pi_%d' % k].tobytes(), (name, k)
+        assert delta == meta['deltas'][k - 1]
+
+
+@pytest.mark.parametrize('name', [n for n in G.dp_names() if 'maze64' not in n and 'maze32' not in n])
+def test_dp_python_oracle_bit_exact(name):
+    meta, z = G.load_dp(name)
+    env = _oracle_env(meta)
+    S, gamma = env.world.size, meta['gamma']
+    v = np.zeros(S)
+    for k in range(1, 11):
+        v = odp.single_step_policy_evaluation(np.ones((S, 4)) / 4, env, discount_factor=gamma, value_function=v)
+        if k in (1, 2, 10):
+            assert v.tobytes() == z['eval_v_%d' % k].tobytes()
+    pi = odp.greedy_policy_from_value_function(np.ones((S, 4)) / 4, env, v, discount_factor=gamma)
+    assert pi.tobytes() == z['greedy_pi_after_10'].tobytes()
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        v3, pi3 = odp.value_iteration(np.ones((S, 4)) / 4, env, np.zeros(S), threshold=meta['driver_threshold'],
+                                      max_steps=meta['iters'], discount_factor=gamma)
+    assert v3.tobytes() == z['vi_driver_v'].tobytes() and pi3.tobytes() == z['vi_driver_pi'].tobytes()
+    assert (len(w) > 0) == meta['driver_warned']
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        v4, pi4 = odp.policy_iteration(np.ones((S, 4)) / 4, env, np.zeros(S), threshold=1e-3,
+                                       max_steps=meta['pi_driver_max_steps'], discount_factor=gamma)
+    assert v4.tobytes() == z['pi_driver_v'].tobytes() and pi4.tobytes() == z['pi_driver_pi'].tobytes()
+    assert (len(w) > 0) == meta['pi_driver_warned']

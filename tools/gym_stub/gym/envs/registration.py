@@ -1,0 +1,5 @@
+_registry = {}
+
+
+def register(id, entry_point=None, **kwargs):
+    _registry[id] = (entry_point, kwargs)

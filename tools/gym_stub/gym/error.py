@@ -1,0 +1,10 @@
+class Error(Exception):
+    pass
+
+
+class UnsupportedMode(Error):
+    pass
+
+
+class DependencyNotInstalled(Error):
+    pass

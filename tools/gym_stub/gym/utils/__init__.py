@@ -1,0 +1,5 @@
+from . import seeding  # noqa: F401
+
+
+def reraise(*a, **k):
+    raise

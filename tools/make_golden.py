@@ -1,0 +1,460 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REAL reference (TheMTank/GridUniverse).
+
+Runs only in the build container, where /root/reference is mounted.  It imports
+the reference under the stub `gym` in tools/gym_stub (the reference's only missing
+dependency; none of gym's arithmetic is on the path) and writes DATA fixtures
+(inputs + expected outputs) to tests/golden/.  Nothing of the reference's source
+is copied; the fixtures are what the oracle and the HIP kernels are pinned to.
+
+    python tools/make_golden.py            # regenerate everything (~2-3 min)
+
+Random-action streams come from the build's own counter RNG (oracle/gu_rng.py,
+a restatement of MurmurHash3) and are stored IN the fixtures, so the fixtures
+are self-contained.  Start states of multi-start levels are chosen by the same
+RNG (stream 1) and forced onto the reference instance right after its own
+`reset()`; the auto-reset policy is the reference harness's `if done: reset()`
+(examples/griduniverse_env_examples.py:22-24 breaks instead; monte_carlo.py:25).
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import random
+import sys
+import warnings
+
+os.environ.setdefault('MPLBACKEND', 'Agg')
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get('GU_REFERENCE', '/root/reference')
+sys.path[:0] = [os.path.join(HERE, 'gym_stub'), REF, REPO]
+
+import numpy as np  # noqa: E402
+
+if not hasattr(np, 'float'):
+    np.float = float  # utils.py:71 uses the alias numpy removed in 1.24
+
+import matplotlib.pyplot as pyplot  # noqa: E402
+from core.envs.griduniverse_env import GridUniverseEnv  # noqa: E402  (the reference)
+from core.algorithms import utils as ref_utils  # noqa: E402
+from core.algorithms import dynamic_programming as ref_dp  # noqa: E402
+from oracle import gu_rng  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+LEVELS = os.path.join(REF, 'core', 'envs', 'maze_text_files')
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+    pyplot.close('all')  # the generator leaks one figure per call (maze_generation.py:105)
+
+
+def ref_env(**kw):
+    with quiet():
+        return GridUniverseEnv(**kw)
+
+
+def seeded_maze_env(w, h, k):
+    random.seed(k)
+    np.random.seed(k)
+    return ref_env(grid_shape=(w, h), random_maze=True)
+
+
+def spec_of(env):
+    """Grid description as plain lists (what the build's engine is configured from)."""
+    return dict(W=int(env.x_max), H=int(env.y_max),
+                starts=[int(s) for s in env.starting_states],
+                goals=[int(s) for s in env.goal_states],
+                lava=[int(s) for s in env.lava_states],
+                walls=[int(s) for s in env.wall_indices],
+                reward=[int(r) for r in env.reward_matrix])
+
+
+def rollout(env, actions, seed, env_ids, auto_reset):
+    """Drive the reference step() for every env id (one instance, time-multiplexed).
+
+    Returns obs, reward, done as int32 [T, N] plus the start index used for every
+    episode start, in order, per env."""
+    T, N = actions.shape
+    obs = np.zeros((T, N), np.int32)
+    rew = np.zeros((T, N), np.int32)
+    don = np.zeros((T, N), np.int32)
+    starts = list(env.starting_states)
+    first_state = np.zeros(N, np.int32)
+    for j, gid in enumerate(env_ids):
+        episode = 0
+
+        def do_reset():
+            nonlocal episode
+            env.reset()
+            s = starts[gu_rng.start_index(seed, gid, episode, len(starts))]
+            env.current_state = env.previous_state = env.initial_state = s
+            episode += 1
+            return s
+        first_state[j] = do_reset()
+        done = False
+        for t in range(T):
+            if auto_reset and done:
+                do_reset()
+            o, r, done, _ = env.step(int(actions[t, j]))
+            obs[t, j], rew[t, j], don[t, j] = o, r, done
+    return obs, rew, don, first_state
+
+
+def digest(obs, rew, don):
+    h = hashlib.sha256()
+    for a in (obs, rew, don):
+        h.update(np.ascontiguousarray(a, dtype='<i4').tobytes())
+    return h.hexdigest()
+
+
+def save_traj(name, env, seed, N, T, auto_reset, actions=None, env_id0=0, note=''):
+    env_ids = list(range(env_id0, env_id0 + N))
+    if actions is None:
+        actions = gu_rng.action_stream(seed, env_ids, 0, T)
+    obs, rew, don, first = rollout(env, actions, seed, env_ids, auto_reset)
+    meta = dict(spec_of(env), seed=int(seed), N=N, T=T, auto_reset=bool(auto_reset), env_id0=env_id0, note=note,
+                sha256=digest(obs, rew, don))
+    np.savez_compressed(os.path.join(OUT, 'traj_%s.npz' % name), meta=json.dumps(meta),
+                        actions=actions.astype(np.int32), obs=obs, reward=rew, done=don, first_state=first)
+    print('traj', name, 'N', N, 'T', T, 'done-rate %.4f' % don.mean(), meta['sha256'][:16])
+    return meta
+
+
+def save_digest(store, name, env, seed, N, T, auto_reset):
+    env_ids = list(range(N))
+    actions = gu_rng.action_stream(seed, env_ids, 0, T)
+    obs, rew, don, _ = rollout(env, actions, seed, env_ids, auto_reset)
+    store[name] = dict(spec_of(env), seed=int(seed), N=N, T=T, auto_reset=bool(auto_reset),
+                       sha256=digest(obs, rew, don), sum_reward=int(rew.sum()), sum_done=int(don.sum()),
+                       sha256_final_obs=hashlib.sha256(obs[-1].astype('<i4').tobytes()).hexdigest())
+    print('digest', name, store[name]['sha256'][:16])
+
+
+def lava_column_32():
+    # examples/griduniverse_env_examples.py:80 column pattern scaled to 32x32
+    return [16 + 32 * r for r in range(24)]
+
+
+# ----------------------------------------------------------------------------- G1
+def capture_kats():
+    """The reference's own ten tests (tests/test_griduniverse.py) as data."""
+    kats = []
+
+    def run(name, kwargs, actions, reset_first=False, level=None):
+        kw = dict(kwargs)
+        if level:
+            kw['custom_world_fp'] = os.path.join(LEVELS, level)
+        results = []
+        # a level with several 'x' cells starts at a random one; the KAT must hold for each
+        for pick in (range(2) if level else [None]):
+            env = ref_env(**kw)
+            if reset_first:
+                env.reset()
+            if pick is not None:
+                env.current_state = env.previous_state = env.initial_state = env.starting_states[pick]
+            first = int(env.current_state)
+            steps = []
+            for a in actions:
+                o, r, d, _ = env.step(a)
+                steps.append([int(o), int(r), bool(d)])
+            results.append(dict(first_state=first, steps=steps))
+        kats.append(dict(name=name, kwargs=kwargs, level=level, actions=list(actions), runs=results))
+
+    run('wall_not_trespassed', dict(walls=[1]), [1])
+    run('default_completion_in_six_steps', {}, [1, 1, 1, 2, 2, 2])
+    run('large_completion_in_53_steps', dict(grid_shape=[25, 30]), [1] * 24 + [2] * 29)
+    run('custom_from_text_file', {}, [2, 2, 2, 2, 2, 2, 2, 1], level='test_env.txt')
+    run('each_boundary_within_default_env', {}, [3, 0, 1, 1, 1, 1, 2, 2, 3, 2, 2, 3, 3, 3], reset_first=True)
+    run('lava', dict(lava_states=[1]), [1])
+    run('lava_from_text_file', {}, [2, 2, 2, 1, 1], level='test_env.txt')
+    return kats
+
+
+# ----------------------------------------------------------------------------- G6
+def capture_errors():
+    cases = [
+        dict(goal_states=[16]), dict(goal_states=['a']), dict(goal_states=5.0), dict(lava_states='a'),
+        dict(walls='aaaa'), dict(grid_shape=[2, 2, 2]), dict(grid_shape='set'), dict(grid_shape=[2, 2.0]),
+        dict(grid_shape=2), dict(lava_states=[16]), dict(lava_states=['b']), dict(walls=[16]), dict(walls=[-1]),
+        dict(goal_states=[3.5]), dict(goal_states=[-17]), dict(lava_states=[-17]),
+    ]
+    out = []
+    for kw in cases:
+        real = dict(kw)
+        if real.get('grid_shape') == 'set':
+            real['grid_shape'] = set([2, 3])
+        try:
+            ref_env(**real)
+            out.append(dict(kwargs=kw, error=None))
+        except Exception as e:  # noqa: BLE001
+            out.append(dict(kwargs=kw, error=type(e).__name__, message=str(e)))
+    # loader errors (env:279,293,298,300)
+    for name, lines in [('not_rectangle', ['xo', 'oGo']), ('bad_char', ['xo', 'oT']),
+                        ('no_start', ['oo', 'oG']), ('no_goal', ['xo', 'oo'])]:
+        env = ref_env()
+        try:
+            with quiet():
+                env._create_custom_world_from_text(lines)
+            out.append(dict(lines=lines, name=name, error=None))
+        except Exception as e:  # noqa: BLE001
+            out.append(dict(lines=lines, name=name, error=type(e).__name__, message=str(e)))
+    # action domain (quirk 6)
+    env = ref_env()
+    for a in (4, -1, -4, -5):
+        env.reset()
+        env.current_state = 5
+        try:
+            o, r, d, _ = env.step(a)
+            out.append(dict(step_action=a, from_state=5, error=None, result=[int(o), int(r), bool(d)]))
+        except Exception as e:  # noqa: BLE001
+            out.append(dict(step_action=a, from_state=5, error=type(e).__name__))
+    return out
+
+
+# ----------------------------------------------------------------------------- G5/G7
+def capture_render_and_quirks():
+    out = {}
+    env = ref_env(walls=[1], lava_states=[2])
+    out['render_walls1_lava2'] = env.render(mode='ansi').getvalue()
+    env = ref_env()
+    frames = [env.render(mode='ansi').getvalue()]
+    for a in [1, 2, 2, 1, 1, 2]:
+        env.step(a)
+        frames.append(env.render(mode='ansi').getvalue())
+    out['render_default_walk'] = frames
+    env = ref_env(custom_world_fp=os.path.join(LEVELS, 'test_env.txt'))
+    env.current_state = env.starting_states[0]
+    out['render_test_env'] = env.render(mode='ansi').getvalue()
+    env = ref_env(grid_shape=(5, 3), goal_states=[14, 7], lava_states=[7, 3], walls=[6, 14])
+    out['render_5x3_overlaps'] = env.render(mode='ansi').getvalue()
+
+    quirks = {}
+    # 1 absorbing terminals
+    env = ref_env()
+    env.current_state = 11
+    quirks['absorbing'] = [[int(o), int(r), bool(d)] for o, r, d, _ in (env.step(a) for a in [2, 0, 3, 1])]
+    # 2 start on a wall, walk off, cannot walk back
+    env = ref_env(walls=[0])
+    quirks['start_on_wall'] = [[int(o), int(r), bool(d)] for o, r, d, _ in (env.step(a) for a in [1, 3, 2, 0])]
+    # 3 goal that is a wall: unreachable but terminal if you are placed on it
+    env = ref_env(goal_states=[5], walls=[5])
+    seq = [[int(o), int(r), bool(d)] for o, r, d, _ in (env.step(a) for a in [1, 2, 2, 0])]
+    env.current_state = 5
+    seq.append([int(x) if i < 2 else bool(x) for i, x in enumerate(env.step(1)[:3])])
+    quirks['goal_is_wall'] = seq
+    # 4 cell both goal and lava -> -10
+    env = ref_env(goal_states=[1, 15], lava_states=[1])
+    quirks['goal_and_lava'] = [[int(o), int(r), bool(d)] for o, r, d, _ in (env.step(a) for a in [1, 1])]
+    # 5 negative goal index: reward wraps, terminal test does not
+    env = ref_env(goal_states=[-1])
+    env.current_state = 14
+    quirks['negative_goal'] = dict(reward=[int(r) for r in env.reward_matrix], goal_states=[-1],
+                                   steps=[[int(o), int(r), bool(d)] for o, r, d, _ in (env.step(a) for a in [1, 1, 3])])
+    # 7 stale observation_space after loading
+    env = ref_env(custom_world_fp=os.path.join(LEVELS, 'test_env.txt'))
+    quirks['stale_observation_space'] = dict(n=int(env.observation_space.n), world_size=int(env.world.size))
+    # 8 return types
+    env = ref_env()
+    o, r, d, i = env.step(1)
+    quirks['types'] = [type(o).__name__, type(r).__name__, type(d).__name__, type(i).__name__]
+    # care_about_terminal=False (only user: maze_solving.py:48)
+    env = ref_env(lava_states=[1])
+    quirks['care_about_terminal_false'] = [
+        [int(x) if k < 2 else bool(x) for k, x in enumerate(env.look_step_ahead(s, a, c))]
+        for (s, a, c) in [(1, 1, True), (1, 1, False), (15, 3, True), (15, 3, False), (1, 2, False), (0, 1, False)]]
+    # look_step_ahead over the whole (state, action) table of a busy grid
+    env = ref_env(grid_shape=(6, 5), goal_states=[29, 8], lava_states=[13, 8], walls=[7, 14, 20, 29],
+                  initial_state=[0, 3])
+    table = {}
+    for care in (True, False):
+        table[str(care)] = [[[int(x) if k < 2 else bool(x) for k, x in enumerate(env.look_step_ahead(s, a, care))]
+                             for a in range(4)] for s in range(30)]
+    quirks['lsa_table_6x5'] = dict(spec=spec_of(env), table=table)
+    out['quirks'] = quirks
+    return out
+
+
+# ----------------------------------------------------------------------------- G3/G8
+def capture_mazes_and_levels():
+    mazes = {}
+    for (w, h) in [(8, 8), (11, 11), (7, 5), (5, 7), (32, 32), (64, 64), (21, 13)]:
+        for k in ([0, 1, 123] if w * h <= 1024 else [5, 123]):
+            env = seeded_maze_env(w, h, k)
+            tail = [random.random(), float(np.random.random())]  # RNG positions after construction
+            rows = []
+            sp = spec_of(env)
+            for y in range(h):
+                row = ''
+                for x in range(w):
+                    s = y * w + x
+                    row += '#' if s in set(sp['walls']) else 'x' if s in sp['starts'] else 'G' if s in sp['goals'] else 'o'
+                rows.append(row)
+            mazes['%dx%d_seed%d' % (w, h, k)] = dict(W=w, H=h, seed=k, rows=rows, start=sp['starts'], goal=sp['goals'],
+                                                     n_walls=len(sp['walls']), initial_state=int(env.initial_state),
+                                                     rng_tail=tail)
+    levels = {}
+    os.makedirs(os.path.join(OUT, 'levels'), exist_ok=True)
+    for fn in sorted(os.listdir(LEVELS)):
+        random.seed(7)
+        env = ref_env(custom_world_fp=os.path.join(LEVELS, fn))
+        sp = spec_of(env)
+        del sp['reward']
+        sp['initial_state_seed7'] = int(env.initial_state)
+        sp['observation_space_n'] = int(env.observation_space.n)
+        levels[fn] = sp
+        # level text regenerated from the parsed grid (compact form, no blanks) so that the
+        # build's loader has the same level DATA to parse; expected parse = levels.json
+        wall, start, goal, lav = set(sp['walls']), set(sp['starts']), set(sp['goals']), set(sp['lava'])
+        with open(os.path.join(OUT, 'levels', fn), 'w') as f:
+            for y in range(sp['H']):
+                f.write(''.join('#' if (y * sp['W'] + x) in wall else 'x' if (y * sp['W'] + x) in start
+                                else 'G' if (y * sp['W'] + x) in goal else 'L' if (y * sp['W'] + x) in lav else 'o'
+                                for x in range(sp['W'])) + '\n')
+    return mazes, levels
+
+
+# ----------------------------------------------------------------------------- G4
+def capture_dp():
+    def uniform(env):
+        return np.ones([env.world.size, 4]) / 4
+
+    cases = [('maze8_s1', lambda: seeded_maze_env(8, 8, 1), 1.0, 12),
+             ('maze11_s3_g09', lambda: seeded_maze_env(11, 11, 3), 0.9, 15),
+             ('lava4x4_g095', lambda: ref_env(lava_states=[5, 6, 9]), 0.95, 12),
+             ('rect6x5_g1', lambda: ref_env(grid_shape=(6, 5), goal_states=[29, 8], lava_states=[13], walls=[7, 14, 20],
+                                            initial_state=[0, 3]), 1.0, 10),
+             ('maze32_s1', lambda: seeded_maze_env(32, 32, 1), 1.0, 12),
+             ('maze32_s1_g099', lambda: seeded_maze_env(32, 32, 1), 0.99, 8),
+             ('maze64_s5', lambda: seeded_maze_env(64, 64, 5), 1.0, 6),
+             ('maze64_s5_g097', lambda: seeded_maze_env(64, 64, 5), 0.97, 6)]
+    for name, make, gamma, iters in cases:
+        env = make()
+        S = env.world.size
+        arrays = {}
+        # (a) repeated V1 under the uniform policy (examples/griduniverse_alg_examples.py:31-35)
+        v = np.zeros(S)
+        pi0 = uniform(env)
+        for k in range(1, 11):
+            v = ref_utils.single_step_policy_evaluation(pi0, env, discount_factor=gamma, value_function=v)
+            if k in (1, 2, 10):
+                arrays['eval_v_%d' % k] = v.copy()
+        arrays['greedy_pi_after_10'] = ref_utils.greedy_policy_from_value_function(
+            uniform(env), env, v, discount_factor=gamma).copy()
+        # (b) value_iteration trace: one V1+V2 per iteration (dynamic_programming.py:15-20)
+        v = np.zeros(S)
+        pi = uniform(env)
+        deltas = []
+        for k in range(1, iters + 1):
+            v_new = ref_utils.single_step_policy_evaluation(pi, env, discount_factor=gamma, value_function=v)
+            deltas.append(float(np.max(v - v_new)))
+            v = v_new
+            pi = ref_utils.greedy_policy_from_value_function(pi, env, value_function=v, discount_factor=gamma)
+            arrays['vi_v_%d' % k] = v.copy()
+            arrays['vi_pi_%d' % k] = pi.copy()
+        # (c) the reference driver itself
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter('always')
+            v3, pi3 = ref_dp.value_iteration(uniform(env), env, np.zeros(S), threshold=1e-3, max_steps=iters,
+                                             discount_factor=gamma)
+        arrays['vi_driver_v'] = v3
+        arrays['vi_driver_pi'] = pi3
+        meta = dict(spec_of(env), gamma=gamma, iters=iters, deltas=deltas, driver_warned=len(wlist) > 0,
+                    driver_threshold=1e-3)
+        if S <= 1024:
+            with warnings.catch_warnings(record=True) as wlist:
+                warnings.simplefilter('always')
+                v4, pi4 = ref_dp.policy_iteration(uniform(env), env, np.zeros(S), threshold=1e-3, max_steps=60,
+                                                  discount_factor=gamma)
+            arrays['pi_driver_v'] = v4
+            arrays['pi_driver_pi'] = pi4
+            meta['pi_driver_warned'] = len(wlist) > 0
+            meta['pi_driver_max_steps'] = 60
+        np.savez_compressed(os.path.join(OUT, 'dp_%s.npz' % name), meta=json.dumps(meta), **arrays)
+        print('dp', name, 'S', S, 'gamma', gamma, 'deltas[-1]', deltas[-1])
+
+
+# ----------------------------------------------------------------------------- G2
+def capture_trajectories():
+    digests = {}
+    # C1: run_default_griduniverse() shape -- 1 env, 1000 random steps, reset on done
+    env = ref_env()
+    acts = np.random.RandomState(0).randint(0, 4, size=(1000, 1)).astype(np.int32)
+    save_traj('c1_default4x4', env, 11, 1, 1000, True, actions=acts, note='actions = RandomState(0).randint(0,4,1000)')
+    # C2: default 8x8
+    env = ref_env(grid_shape=(8, 8))
+    save_traj('c2_open8x8', env, 2, 64, 256, True)
+    save_traj('c2_open8x8_absorbing', env, 3, 64, 256, False)
+    save_digest(digests, 'c2_open8x8_4096x1000', env, 2, 4096, 1000, True)
+    # C3: 32x32 generator maze, seed 123
+    env = seeded_maze_env(32, 32, 123)
+    save_traj('c3_maze32', env, 123, 64, 512, True)
+    save_digest(digests, 'c3_maze32_4096x1000', env, 123, 4096, 1000, True)
+    # C4: 32x32 open grid with the lava column
+    env = ref_env(grid_shape=(32, 32), lava_states=lava_column_32())
+    save_traj('c4_lava32', env, 4, 64, 256, True)
+    save_traj('c4_lava32_absorbing', env, 4, 64, 256, False)
+    save_traj('c4_lava32_shard1', env, 4, 64, 256, True, env_id0=32768, note='env ids of the second of 8 shards of 262144')
+    save_digest(digests, 'c4_lava32_4096x1000', env, 4, 4096, 1000, True)
+    # C5: 64x64 generator maze, seed 5
+    env = seeded_maze_env(64, 64, 5)
+    save_traj('c5_maze64', env, 5, 64, 512, True)
+    # multi-start level (2 starts, lava, walls), short episodes
+    env = ref_env(custom_world_fp=os.path.join(LEVELS, 'test_env.txt'))
+    save_traj('multistart_test_env', env, 77, 64, 192, True)
+    # non-square, several goals / lava / walls / starts incl. a terminal start and a wall start
+    rs = np.random.RandomState(9)
+    W, H = 25, 30
+    cells = rs.permutation(W * H)
+    env = ref_env(grid_shape=(W, H), initial_state=[int(c) for c in cells[:5]] + [int(cells[40])] + [int(cells[100])],
+                  goal_states=[int(c) for c in cells[30:41]], lava_states=[int(c) for c in cells[38:60]],
+                  walls=[int(c) for c in cells[100:260]])
+    save_traj('rect25x30_busy', env, 99, 64, 384, True)
+    # wider than one 32-bit row word
+    W, H = 40, 12
+    cells = rs.permutation(W * H)
+    env = ref_env(grid_shape=(W, H), initial_state=[int(cells[0]), int(cells[1])], goal_states=[int(c) for c in cells[2:6]],
+                  lava_states=[int(c) for c in cells[6:20]], walls=[int(c) for c in cells[20:120]])
+    save_traj('wide40x12', env, 40, 64, 256, True)
+    # the 101x101 level: long corridors, 4 words per row
+    env = ref_env(custom_world_fp=os.path.join(LEVELS, 'maze_101x101.txt'))
+    save_traj('maze101', env, 101, 16, 2048, True)
+    # 1x1 and 1xN / Nx1 degenerate grids
+    env = ref_env(grid_shape=(1, 1))
+    save_traj('grid1x1', env, 1, 4, 8, True)
+    env = ref_env(grid_shape=(1, 9), walls=[4])
+    save_traj('grid1x9', env, 1, 8, 64, True)
+    env = ref_env(grid_shape=(9, 1), lava_states=[6])
+    save_traj('grid9x1', env, 1, 8, 64, True)
+    return digests
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    random.seed(0)
+    np.random.seed(0)
+    what = set(sys.argv[1:]) or {'kat', 'err', 'render', 'maze', 'dp', 'traj'}
+    if 'kat' in what:
+        json.dump(capture_kats(), open(os.path.join(OUT, 'kat.json'), 'w'), indent=1)
+    if 'err' in what:
+        json.dump(capture_errors(), open(os.path.join(OUT, 'errors.json'), 'w'), indent=1)
+    if 'render' in what:
+        json.dump(capture_render_and_quirks(), open(os.path.join(OUT, 'render_quirks.json'), 'w'), indent=1)
+    if 'maze' in what:
+        mazes, levels = capture_mazes_and_levels()
+        json.dump(mazes, open(os.path.join(OUT, 'mazes.json'), 'w'), indent=1)
+        json.dump(levels, open(os.path.join(OUT, 'levels.json'), 'w'), indent=1)
+    if 'dp' in what:
+        capture_dp()
+    if 'traj' in what:
+        json.dump(capture_trajectories(), open(os.path.join(OUT, 'digests.json'), 'w'), indent=1)
+    assert not any('__pycache__' in d for d, _, _ in os.walk(REF)), 'bytecode was written into the reference'
+
+
+if __name__ == '__main__':
+    main()

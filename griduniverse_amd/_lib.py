@@ -1,0 +1,127 @@
+"""ctypes binding of libgu.so (include/gu.h) -- the only door to the HIP kernels.
+
+There is deliberately NO fallback: if the library is missing, or no MI355X is
+visible, every compute entry point raises `GuError`.  Host-only logic (argument
+validation, level loading, maze generation, ASCII rendering) never touches this
+module, so it keeps working on a machine without a GPU.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libgu.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+GU_OK = 0
+ERR_NAMES = {-1: 'GU_ERR_INVALID', -2: 'GU_ERR_HIP', -3: 'GU_ERR_NOMEM', -4: 'GU_ERR_STATE',
+             -5: 'GU_ERR_COMM', -6: 'GU_ERR_UNSUPPORTED'}
+
+F_AUTO_RESET, F_TRAJECTORY, F_STATS = 1, 2, 4
+POLICY_UNIFORM, POLICY_STREAM, POLICY_GREEDY = 0, 1, 2
+COMM_ID_BYTES = 128
+
+_c = ctypes
+_vp, _i32, _i64, _u32, _u64, _f64 = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint32, _c.c_uint64, _c.c_double
+
+# name -> argtypes (restype is int everywhere).  Must list every symbol of include/gu.h;
+# tests/test_abi.py cross-checks this table against the header and the built library.
+SIGNATURES = {
+    'gu_version': [],
+    'gu_last_error': [_c.c_char_p, _c.c_size_t],
+    'gu_device_count': [_c.POINTER(_c.c_int)],
+    'gu_create': [_c.c_int, _i64, _i64, _c.POINTER(_vp)],
+    'gu_destroy': [_vp],
+    'gu_set_grid': [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32],
+    'gu_seed': [_vp, _u64],
+    'gu_reset': [_vp, _vp, _vp, _vp],
+    'gu_reset_done': [_vp],
+    'gu_step': [_vp, _vp, _u32, _vp, _vp, _vp],
+    'gu_upload_actions': [_vp, _vp, _i64],
+    'gu_step_device': [_vp, _i64, _u32],
+    'gu_step_graph': [_vp, _i64, _i64, _u32],
+    'gu_read_outputs': [_vp, _vp, _vp, _vp],
+    'gu_reserve_trajectory': [_vp, _i64],
+    'gu_rollout': [_vp, _i64, _i32, _u32],
+    'gu_read_trajectory': [_vp, _i64, _i64, _vp, _vp, _vp],
+    'gu_read_stats': [_vp, _vp, _vp],
+    'gu_get_state': [_vp, _vp, _vp, _vp, _vp],
+    'gu_set_state': [_vp, _vp, _vp, _vp, _vp],
+    'gu_done_indices': [_vp, _vp, _vp],
+    'gu_look_step_ahead': [_vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp],
+    'gu_vi_set': [_vp, _vp, _vp],
+    'gu_vi_sweep': [_vp, _f64, _i32, _i32, _vp],
+    'gu_vi_greedy': [_vp, _f64],
+    'gu_vi_get': [_vp, _vp, _vp],
+    'gu_vi_sweep_step': [_vp, _f64, _u32, _vp],
+    'gu_sync': [_vp],
+    'gu_timer_begin': [_vp],
+    'gu_timer_end': [_vp, _c.POINTER(_c.c_float)],
+    'gu_comm_unique_id': [_vp],
+    'gu_comm_init': [_vp, _i32, _i32, _vp],
+    'gu_comm_destroy': [_vp],
+    'gu_allgather_view': [_vp, _vp, _vp, _vp],
+}
+
+
+class GuError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__('{} ({}): {}'.format(ERR_NAMES.get(code, 'GU_ERR'), code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libgu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ['make', '-C', CSRC] + ([] if verbose else ['-s'])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    """dlopen libgu.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GuError(-2, 'libgu.so not found at {}; build it with `python -c "import __graft_entry__ as g; '
+                              'g.build()"` or `make -C griduniverse_amd/csrc`'.format(LIB_PATH))
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    load().gu_last_error(buf, 512)
+    return buf.value.decode('utf-8', 'replace')
+
+
+def check(rc):
+    if rc != GU_OK:
+        raise GuError(rc, last_error())
+
+
+def device_count():
+    """Number of visible HIP devices; 0 when there is none (does not raise)."""
+    n = ctypes.c_int(0)
+    rc = load().gu_device_count(ctypes.byref(n))
+    return n.value if rc == GU_OK else 0
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def as_array(a, dtype, shape=None, name='array'):
+    out = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(out.shape) != tuple(shape):
+        raise ValueError('{} must have shape {}, got {}'.format(name, tuple(shape), tuple(out.shape)))
+    return out

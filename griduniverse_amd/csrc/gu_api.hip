@@ -1,0 +1,556 @@
+// gu_api.hip -- C ABI of libgu.so (see include/gu.h for the contract and the reference
+// interfaces each entry point replaces).
+#include "gu_internal.hpp"
+#include "gu_rng.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+// ---------------------------------------------------------------------------------- errors
+static thread_local std::string g_last_error;
+
+void gu_set_error(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int gu_fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+int gu_use_device(gu_engine *h)
+{
+    GU_REQUIRE(h != nullptr, GU_ERR_INVALID, "null handle");
+    GU_HIP(hipSetDevice(h->device));
+    return GU_OK;
+}
+
+int gu_ensure_scratch(gu_engine *h, size_t bytes)
+{
+    if (bytes <= h->scratch_bytes) return GU_OK;
+    if (h->d_scratch) {
+        GU_HIP(hipStreamSynchronize(h->stream));
+        GU_HIP(hipFree(h->d_scratch));
+        h->d_scratch = nullptr;
+        h->scratch_bytes = 0;
+    }
+    GU_HIP(hipMalloc(&h->d_scratch, bytes));
+    h->scratch_bytes = bytes;
+    return GU_OK;
+}
+
+#define GU_ENTER(h)                                  \
+    do {                                             \
+        int _rc = gu_use_device(h);                  \
+        if (_rc != GU_OK) return _rc;                \
+    } while (0)
+
+#define GU_NEED_GRID(h) GU_REQUIRE((h)->has_grid, GU_ERR_STATE, "no grid set: call gu_set_grid first")
+
+extern "C" {
+
+int gu_version(void) { return GU_ABI_VERSION; }
+
+int gu_last_error(char *buf, size_t len)
+{
+    if (buf && len) {
+        size_t n = g_last_error.size() < len - 1 ? g_last_error.size() : len - 1;
+        memcpy(buf, g_last_error.data(), n);
+        buf[n] = 0;
+    }
+    return (int)g_last_error.size();
+}
+
+int gu_device_count(int *count)
+{
+    GU_REQUIRE(count != nullptr, GU_ERR_INVALID, "count is NULL");
+    *count = 0;
+    GU_HIP(hipGetDeviceCount(count));
+    return GU_OK;
+}
+
+// ---------------------------------------------------------------------------------- lifetime
+int gu_create(int device_id, int64_t num_envs, int64_t env_id0, gu_handle *out)
+{
+    GU_REQUIRE(out != nullptr, GU_ERR_INVALID, "out handle is NULL");
+    *out = nullptr;
+    GU_REQUIRE(num_envs > 0 && num_envs <= 0x7FFFFFFF, GU_ERR_INVALID, "num_envs %lld out of range", (long long)num_envs);
+    GU_REQUIRE(env_id0 >= 0 && env_id0 + num_envs <= 0xFFFFFFFFLL, GU_ERR_INVALID, "global env ids must fit 32 bits");
+    int n_dev = 0;
+    GU_HIP(hipGetDeviceCount(&n_dev));
+    GU_REQUIRE(device_id >= 0 && device_id < n_dev, GU_ERR_HIP, "device %d not present (%d visible)", device_id, n_dev);
+    gu_engine *h = new (std::nothrow) gu_engine();
+    GU_REQUIRE(h != nullptr, GU_ERR_NOMEM, "host allocation failed");
+    h->device = device_id;
+    h->N = num_envs;
+    h->env_id0 = env_id0;
+    h->seed = 0;
+    h->seed_prefix = gu_rng_seed_prefix(0);
+    int rc = GU_OK;
+    auto body = [&]() -> int {
+        GU_HIP(hipSetDevice(device_id));
+        GU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        GU_HIP(hipEventCreate(&h->ev_begin));
+        GU_HIP(hipEventCreate(&h->ev_end));
+        const size_t n = (size_t)num_envs;
+        GU_HIP(hipMalloc(&h->d_out3, 3 * n * sizeof(int32_t)));
+        GU_HIP(hipMalloc(&h->d_episode, n * sizeof(uint32_t)));
+        GU_HIP(hipMalloc(&h->d_tcount, n * sizeof(uint32_t)));
+        GU_HIP(hipMalloc(&h->d_ret, n * sizeof(int32_t)));
+        GU_HIP(hipMalloc(&h->d_episodes_fin, n * sizeof(int32_t)));
+        GU_HIP(hipMalloc(&h->d_done_bits, ((n + 63) / 64) * sizeof(uint64_t)));
+        GU_HIP(hipMalloc(&h->d_done_idx, n * sizeof(int32_t)));
+        GU_HIP(hipMalloc(&h->d_done_count, sizeof(int32_t)));
+        GU_HIP(hipHostMalloc(&h->h_pin, 4 * n * sizeof(int32_t), hipHostMallocDefault));
+        GU_HIP(hipMemsetAsync(h->d_out3, 0, 3 * n * sizeof(int32_t), h->stream));
+        GU_HIP(hipMemsetAsync(h->d_episode, 0, n * sizeof(uint32_t), h->stream));
+        GU_HIP(hipMemsetAsync(h->d_tcount, 0, n * sizeof(uint32_t), h->stream));
+        GU_HIP(hipStreamSynchronize(h->stream));
+        return GU_OK;
+    };
+    rc = body();
+    if (rc != GU_OK) {
+        std::string keep = g_last_error;
+        gu_destroy(h);
+        g_last_error = keep;
+        return rc;
+    }
+    *out = h;
+    return GU_OK;
+}
+
+int gu_destroy(gu_handle h)
+{
+    if (!h) return GU_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    gu_comm_free(h);
+    gu_vi_free(h);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    void *bufs[] = {h->d_cell, h->d_cell_raw, h->d_starts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions,
+                    h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_done_idx, h->d_done_count,
+                    h->d_scratch, h->d_greedy};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return GU_OK;
+}
+
+// ---------------------------------------------------------------------------------- grid
+static inline bool plane_bit(const uint32_t *rows, int32_t wpr, int32_t x, int32_t y)
+{
+    return rows && ((rows[(size_t)y * wpr + (x >> 5)] >> (x & 31)) & 1u);
+}
+
+int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row, const uint32_t *wall_rows,
+                const uint32_t *goal_rows, const uint32_t *lava_rows, const uint32_t *rplus_rows,
+                const uint32_t *rminus_rows, const int32_t *starts, int32_t n_starts)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(W > 0 && H > 0 && (int64_t)W * H <= (1 << 30), GU_ERR_INVALID, "bad grid shape %d x %d", W, H);
+    GU_REQUIRE(words_per_row == (W + 31) / 32, GU_ERR_INVALID, "words_per_row must be ceil(W/32)");
+    GU_REQUIRE(wall_rows && goal_rows && lava_rows, GU_ERR_INVALID, "wall/goal/lava planes are required");
+    GU_REQUIRE((rplus_rows == nullptr) == (rminus_rows == nullptr), GU_ERR_INVALID, "give both reward planes or neither");
+    GU_REQUIRE(starts && n_starts > 0, GU_ERR_INVALID, "at least one starting state is required");
+    const int32_t S = W * H;
+    for (int32_t i = 0; i < n_starts; ++i)
+        GU_REQUIRE(starts[i] >= 0 && starts[i] < S, GU_ERR_INVALID, "starting state %d outside the grid", starts[i]);
+
+    const int32_t cell_bytes = (S + 15) & ~15;
+    std::vector<uint8_t> cell((size_t)cell_bytes, 0), raw((size_t)cell_bytes, 0);
+    auto wall = [&](int32_t x, int32_t y) { return plane_bit(wall_rows, words_per_row, x, y); };
+    for (int32_t y = 0; y < H; ++y) {
+        for (int32_t x = 0; x < W; ++x) {
+            const bool lava = plane_bit(lava_rows, words_per_row, x, y);
+            const bool goal = plane_bit(goal_rows, words_per_row, x, y);
+            const bool term = lava || goal;                                          // env:163-168
+            const bool rminus = rminus_rows ? plane_bit(rminus_rows, words_per_row, x, y) : lava;   // env:86-88
+            const bool rplus = rplus_rows ? plane_bit(rplus_rows, words_per_row, x, y) : (goal && !lava);
+            uint8_t blocked = 0;
+            if (y == 0 || wall(x, y - 1)) blocked |= 1u;        // UP    env:51, env:149
+            if (x == W - 1 || wall(x + 1, y)) blocked |= 2u;    // RIGHT env:52
+            if (y == H - 1 || wall(x, y + 1)) blocked |= 4u;    // DOWN  env:53
+            if (x == 0 || wall(x - 1, y)) blocked |= 8u;        // LEFT  env:54
+            uint8_t info = (term ? GU_CELL_TERM : 0) | (rplus ? GU_CELL_RPLUS : 0) | (rminus ? GU_CELL_RMINUS : 0);
+            raw[(size_t)y * W + x] = blocked | info;
+            cell[(size_t)y * W + x] = (term ? 0x0Fu : blocked) | info;                // env:145-146 absorbing
+        }
+    }
+    GU_HIP(hipStreamSynchronize(h->stream));
+    for (void *p : {(void *)h->d_cell, (void *)h->d_cell_raw, (void *)h->d_starts, (void *)h->d_greedy})
+        if (p) GU_HIP(hipFree(p));
+    h->d_cell = h->d_cell_raw = h->d_greedy = nullptr;
+    h->d_starts = nullptr;
+    h->has_grid = false;
+    gu_vi_free(h);
+    GU_HIP(hipMalloc(&h->d_cell, cell_bytes));
+    GU_HIP(hipMalloc(&h->d_cell_raw, cell_bytes));
+    GU_HIP(hipMalloc(&h->d_greedy, cell_bytes));
+    GU_HIP(hipMalloc(&h->d_starts, (size_t)n_starts * sizeof(int32_t)));
+    GU_HIP(hipMemcpy(h->d_cell, cell.data(), cell_bytes, hipMemcpyHostToDevice));
+    GU_HIP(hipMemcpy(h->d_cell_raw, raw.data(), cell_bytes, hipMemcpyHostToDevice));
+    GU_HIP(hipMemset(h->d_greedy, 0, cell_bytes));
+    GU_HIP(hipMemcpy(h->d_starts, starts, (size_t)n_starts * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->h_cell.swap(cell);
+    h->h_cell_raw.swap(raw);
+    h->h_starts.assign(starts, starts + n_starts);
+    h->W = W;
+    h->H = H;
+    h->S = S;
+    h->cell_bytes = cell_bytes;
+    h->n_starts = n_starts;
+    h->has_grid = true;
+    h->greedy_valid = false;
+    if (h->graph_exec) {
+        (void)hipGraphExecDestroy(h->graph_exec);
+        h->graph_exec = nullptr;
+    }
+    // every env starts at starts[0] until the caller resets (pos must always be a valid cell)
+    std::vector<int32_t> init((size_t)h->N, starts[0]);
+    GU_HIP(hipMemcpy(h->pos(), init.data(), (size_t)h->N * sizeof(int32_t), hipMemcpyHostToDevice));
+    GU_HIP(hipMemset(h->reward(), 0, 2 * (size_t)h->N * sizeof(int32_t)));
+    return GU_OK;
+}
+
+// ---------------------------------------------------------------------------------- RNG
+int gu_seed(gu_handle h, uint64_t seed)
+{
+    GU_ENTER(h);
+    h->seed = seed;
+    h->seed_prefix = gu_rng_seed_prefix(seed);
+    h->steps_taken = 0;
+    GU_HIP(hipMemsetAsync(h->d_episode, 0, (size_t)h->N * sizeof(uint32_t), h->stream));
+    GU_HIP(hipMemsetAsync(h->d_tcount, 0, (size_t)h->N * sizeof(uint32_t), h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    return GU_OK;
+}
+
+// ---------------------------------------------------------------------------------- reset
+int gu_reset(gu_handle h, const uint8_t *mask, const int32_t *start_choice, int32_t *obs_out)
+{
+    GU_ENTER(h);
+    GU_NEED_GRID(h);
+    const size_t n = (size_t)h->N;
+    uint8_t *d_mask = nullptr;
+    int32_t *d_choice = nullptr;
+    if (mask || start_choice) {
+        int rc = gu_ensure_scratch(h, n * 5 + 16);
+        if (rc != GU_OK) return rc;
+        if (start_choice) {
+            for (size_t i = 0; i < n; ++i)
+                if (!mask || mask[i])
+                    GU_REQUIRE(start_choice[i] >= 0 && start_choice[i] < h->n_starts, GU_ERR_INVALID,
+                               "start_choice[%zu]=%d outside [0,%d)", i, start_choice[i], h->n_starts);
+            d_choice = (int32_t *)h->d_scratch;
+            GU_HIP(hipMemcpyAsync(d_choice, start_choice, n * 4, hipMemcpyHostToDevice, h->stream));
+        }
+        if (mask) {
+            d_mask = (uint8_t *)h->d_scratch + n * 4;
+            GU_HIP(hipMemcpyAsync(d_mask, mask, n, hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    int rc = gu_launch_reset(h, d_mask, d_choice, false);
+    if (rc != GU_OK) return rc;
+    if (obs_out) GU_HIP(hipMemcpyAsync(obs_out, h->pos(), n * 4, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    return GU_OK;
+}
+
+int gu_reset_done(gu_handle h)
+{
+    GU_ENTER(h);
+    GU_NEED_GRID(h);
+    return gu_launch_reset(h, nullptr, nullptr, true);
+}
+
+// ---------------------------------------------------------------------------------- step
+int gu_step(gu_handle h, const int32_t *actions, uint32_t flags, int32_t *obs, int32_t *reward, int32_t *done)
+{
+    GU_ENTER(h);
+    GU_NEED_GRID(h);
+    GU_REQUIRE(actions != nullptr, GU_ERR_INVALID, "actions is NULL");
+    GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_step accepts only GU_F_AUTO_RESET");
+    const size_t n = (size_t)h->N;
+    for (size_t i = 0; i < n; ++i)
+        GU_REQUIRE((uint32_t)actions[i] < 4u, GU_ERR_INVALID, "action %d of env %zu outside 0..3", actions[i], i);
+    int rc = gu_ensure_scratch(h, n * 5 + 16);
+    if (rc != GU_OK) return rc;
+    int32_t *d_act = (int32_t *)h->d_scratch;
+    memcpy(h->h_pin, actions, n * 4);  // pinned staging keeps the H2D copy asynchronous
+    GU_HIP(hipMemcpyAsync(d_act, h->h_pin, n * 4, hipMemcpyHostToDevice, h->stream));
+    rc = gu_launch_step(h, d_act, flags);
+    if (rc != GU_OK) return rc;
+    if (obs || reward || done)
+        GU_HIP(hipMemcpyAsync(h->h_pin + n, h->d_out3, 3 * n * 4, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (obs) memcpy(obs, h->h_pin + n, n * 4);
+    if (reward) memcpy(reward, h->h_pin + 2 * n, n * 4);
+    if (done) memcpy(done, h->h_pin + 3 * n, n * 4);
+    return GU_OK;
+}
+
+int gu_upload_actions(gu_handle h, const int32_t *actions, int64_t T)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(actions != nullptr && T > 0, GU_ERR_INVALID, "actions NULL or T <= 0");
+    const size_t count = (size_t)T * (size_t)h->N;
+    for (size_t i = 0; i < count; ++i)
+        GU_REQUIRE((uint32_t)actions[i] < 4u, GU_ERR_INVALID, "action %d at flat index %zu outside 0..3", actions[i], i);
+    if (T > h->actions_T) {
+        GU_HIP(hipStreamSynchronize(h->stream));
+        if (h->d_actions) GU_HIP(hipFree(h->d_actions));
+        h->d_actions = nullptr;
+        h->actions_T = 0;
+        GU_HIP(hipMalloc(&h->d_actions, count * sizeof(int32_t)));
+        h->actions_T = T;
+        if (h->graph_exec) {
+            (void)hipGraphExecDestroy(h->graph_exec);
+            h->graph_exec = nullptr;
+        }
+    }
+    GU_HIP(hipMemcpy(h->d_actions, actions, count * sizeof(int32_t), hipMemcpyHostToDevice));
+    return GU_OK;
+}
+
+int gu_step_device(gu_handle h, int64_t t, uint32_t flags)
+{
+    GU_ENTER(h);
+    GU_NEED_GRID(h);
+    GU_REQUIRE(h->d_actions && t >= 0 && t < h->actions_T, GU_ERR_STATE, "row %lld not in the uploaded action stream", (long long)t);
+    GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_step_device accepts only GU_F_AUTO_RESET");
+    return gu_launch_step(h, h->d_actions + t * h->N, flags);
+}
+
+int gu_step_graph(gu_handle h, int64_t t0, int64_t T, uint32_t flags)
+{
+    GU_ENTER(h);
+    GU_NEED_GRID(h);
+    GU_REQUIRE(h->d_actions && t0 >= 0 && T > 0 && t0 + T <= h->actions_T, GU_ERR_STATE, "rows [%lld,%lld) not in the uploaded action stream",
+               (long long)t0, (long long)(t0 + T));
+    GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_step_graph accepts only GU_F_AUTO_RESET");
+    if (!h->graph_exec || h->graph_t0 != t0 || h->graph_T != T || h->graph_flags != flags) {
+        if (h->graph_exec) {
+            (void)hipGraphExecDestroy(h->graph_exec);
+            h->graph_exec = nullptr;
+        }
+        const uint32_t saved = h->steps_taken;
+        hipGraph_t graph = nullptr;
+        GU_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        int rc = GU_OK;
+        for (int64_t t = t0; t < t0 + T && rc == GU_OK; ++t) rc = gu_launch_step(h, h->d_actions + t * h->N, flags);
+        hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        h->steps_taken = saved;  // capture launched nothing
+        if (rc != GU_OK) return rc;
+        GU_HIP(e);
+        e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        GU_HIP(e);
+        h->graph_t0 = t0;
+        h->graph_T = T;
+        h->graph_flags = flags;
+    }
+    GU_HIP(hipGraphLaunch(h->graph_exec, h->stream));
+    h->steps_taken += (uint32_t)T;
+    return GU_OK;
+}
+
+int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done)
+{
+    GU_ENTER(h);
+    const size_t n = (size_t)h->N;
+    GU_HIP(hipMemcpyAsync(h->h_pin, h->d_out3, 3 * n * 4, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (obs) memcpy(obs, h->h_pin, n * 4);
+    if (reward) memcpy(reward, h->h_pin + n, n * 4);
+    if (done) memcpy(done, h->h_pin + 2 * n, n * 4);
+    return GU_OK;
+}
+
+// ---------------------------------------------------------------------------------- rollout
+int gu_reserve_trajectory(gu_handle h, int64_t T)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(T > 0, GU_ERR_INVALID, "T <= 0");
+    if (T == h->traj_T) return GU_OK;
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (h->d_traj) GU_HIP(hipFree(h->d_traj));
+    h->d_traj = nullptr;
+    h->traj_T = 0;
+    GU_HIP(hipMalloc(&h->d_traj, 3 * (size_t)T * (size_t)h->N * sizeof(int32_t)));
+    h->traj_T = T;
+    return GU_OK;
+}
+
+int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
+{
+    GU_ENTER(h);
+    GU_NEED_GRID(h);
+    GU_REQUIRE(T > 0 && T <= 100000000, GU_ERR_INVALID, "T %lld out of range", (long long)T);
+    GU_REQUIRE((flags & ~(GU_F_AUTO_RESET | GU_F_TRAJECTORY | GU_F_STATS)) == 0, GU_ERR_INVALID, "unknown flags 0x%x", flags);
+    if (flags & GU_F_TRAJECTORY)
+        GU_REQUIRE(h->d_traj && T <= h->traj_T, GU_ERR_STATE, "trajectory buffer holds %lld rows, need %lld: call gu_reserve_trajectory",
+                   (long long)h->traj_T, (long long)T);
+    if (policy_kind == GU_POLICY_STREAM)
+        GU_REQUIRE(h->d_actions && T <= h->actions_T, GU_ERR_STATE, "action stream holds %lld rows, need %lld", (long long)h->actions_T, (long long)T);
+    if (policy_kind == GU_POLICY_GREEDY) {
+        GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no policy table: call gu_vi_set first");
+        if (!h->greedy_valid) {
+            int rc = gu_launch_greedy_table(h);
+            if (rc != GU_OK) return rc;
+        }
+    }
+    int rc = gu_launch_rollout(h, T, policy_kind, flags);
+    if (rc == GU_OK) h->stats_valid = (flags & GU_F_STATS) != 0;
+    return rc;
+}
+
+int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(h->d_traj && t0 >= 0 && T > 0 && t0 + T <= h->traj_T, GU_ERR_STATE, "rows [%lld,%lld) not in the trajectory buffer",
+               (long long)t0, (long long)(t0 + T));
+    const size_t n = (size_t)h->N, rows = (size_t)h->traj_T * n, count = (size_t)T * n;
+    GU_HIP(hipStreamSynchronize(h->stream));
+    int32_t *dst[3] = {obs, reward, done};
+    for (int k = 0; k < 3; ++k)
+        if (dst[k]) GU_HIP(hipMemcpy(dst[k], h->d_traj + k * rows + (size_t)t0 * n, count * 4, hipMemcpyDeviceToHost));
+    return GU_OK;
+}
+
+int gu_read_stats(gu_handle h, int64_t *reward_sum, int32_t *episodes)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(h->stats_valid, GU_ERR_STATE, "the last rollout did not run with GU_F_STATS");
+    const size_t n = (size_t)h->N;
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (reward_sum) {
+        std::vector<int32_t> tmp(n);
+        GU_HIP(hipMemcpy(tmp.data(), h->d_ret, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) reward_sum[i] = tmp[i];
+    }
+    if (episodes) GU_HIP(hipMemcpy(episodes, h->d_episodes_fin, n * 4, hipMemcpyDeviceToHost));
+    return GU_OK;
+}
+
+// ---------------------------------------------------------------------------------- state
+int gu_get_state(gu_handle h, int32_t *pos, int32_t *done, uint32_t *episode, uint32_t *tcount)
+{
+    GU_ENTER(h);
+    const size_t n = (size_t)h->N;
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (pos) GU_HIP(hipMemcpy(pos, h->pos(), n * 4, hipMemcpyDeviceToHost));
+    if (done) GU_HIP(hipMemcpy(done, h->done(), n * 4, hipMemcpyDeviceToHost));
+    if (episode) GU_HIP(hipMemcpy(episode, h->d_episode, n * 4, hipMemcpyDeviceToHost));
+    if (tcount) {
+        GU_HIP(hipMemcpy(tcount, h->d_tcount, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) tcount[i] += h->steps_taken;
+    }
+    return GU_OK;
+}
+
+int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uint32_t *episode, const uint32_t *tcount)
+{
+    GU_ENTER(h);
+    GU_NEED_GRID(h);
+    const size_t n = (size_t)h->N;
+    if (pos)
+        for (size_t i = 0; i < n; ++i)
+            GU_REQUIRE(pos[i] >= 0 && pos[i] < h->S, GU_ERR_INVALID, "pos[%zu]=%d outside the grid", i, pos[i]);
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (pos) GU_HIP(hipMemcpy(h->pos(), pos, n * 4, hipMemcpyHostToDevice));
+    if (done) {
+        std::vector<int32_t> d(done, done + n);
+        for (auto &x : d) x = x ? 1 : 0;
+        GU_HIP(hipMemcpy(h->done(), d.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    if (episode) GU_HIP(hipMemcpy(h->d_episode, episode, n * 4, hipMemcpyHostToDevice));
+    if (tcount) {
+        std::vector<uint32_t> t(tcount, tcount + n);
+        for (auto &x : t) x -= h->steps_taken;  // stored as an offset to the lock-step counter
+        GU_HIP(hipMemcpy(h->d_tcount, t.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    return GU_OK;
+}
+
+int gu_done_indices(gu_handle h, int32_t *idx, int32_t *count)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(count != nullptr, GU_ERR_INVALID, "count is NULL");
+    int rc = gu_launch_done_compact(h);
+    if (rc != GU_OK) return rc;
+    GU_HIP(hipMemcpyAsync(count, h->d_done_count, 4, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (idx && *count > 0) GU_HIP(hipMemcpy(idx, h->d_done_idx, (size_t)*count * 4, hipMemcpyDeviceToHost));
+    return GU_OK;
+}
+
+// ---------------------------------------------------------------------------------- look_step_ahead
+int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int32_t *actions, int32_t care_about_terminal,
+                       int32_t *next, int32_t *reward, int32_t *done)
+{
+    GU_ENTER(h);
+    GU_NEED_GRID(h);
+    GU_REQUIRE(n > 0 && states && actions, GU_ERR_INVALID, "n <= 0 or NULL inputs");
+    for (int64_t i = 0; i < n; ++i) {
+        GU_REQUIRE(states[i] >= 0 && states[i] < h->S, GU_ERR_INVALID, "state %d outside the grid", states[i]);
+        GU_REQUIRE((uint32_t)actions[i] < 4u, GU_ERR_INVALID, "action %d outside 0..3", actions[i]);
+    }
+    const size_t bytes = (size_t)n * 4;
+    int rc = gu_ensure_scratch(h, 5 * bytes);
+    if (rc != GU_OK) return rc;
+    int32_t *d = (int32_t *)h->d_scratch;
+    GU_HIP(hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, h->stream));
+    GU_HIP(hipMemcpyAsync(d + n, actions, bytes, hipMemcpyHostToDevice, h->stream));
+    rc = gu_launch_lookahead(h, n, d, d + n, care_about_terminal != 0, d + 2 * n, d + 3 * n, d + 4 * n);
+    if (rc != GU_OK) return rc;
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (next) GU_HIP(hipMemcpy(next, d + 2 * n, bytes, hipMemcpyDeviceToHost));
+    if (reward) GU_HIP(hipMemcpy(reward, d + 3 * n, bytes, hipMemcpyDeviceToHost));
+    if (done) GU_HIP(hipMemcpy(done, d + 4 * n, bytes, hipMemcpyDeviceToHost));
+    return GU_OK;
+}
+
+// ---------------------------------------------------------------------------------- stream / timing
+int gu_sync(gu_handle h)
+{
+    GU_ENTER(h);
+    GU_HIP(hipStreamSynchronize(h->stream));
+    return GU_OK;
+}
+
+int gu_timer_begin(gu_handle h)
+{
+    GU_ENTER(h);
+    GU_HIP(hipEventRecord(h->ev_begin, h->stream));
+    return GU_OK;
+}
+
+int gu_timer_end(gu_handle h, float *milliseconds)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(milliseconds != nullptr, GU_ERR_INVALID, "milliseconds is NULL");
+    GU_HIP(hipEventRecord(h->ev_end, h->stream));
+    GU_HIP(hipEventSynchronize(h->ev_end));
+    GU_HIP(hipEventElapsedTime(milliseconds, h->ev_begin, h->ev_end));
+    return GU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// gu_internal.hpp -- engine object shared by the translation units of libgu.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gu.h"
+
+// ---- per-cell record (one byte per grid cell, staged in LDS by every kernel) --------
+// Compiled on the host from the row bit-planes handed to gu_set_grid().  It encodes the
+// reference transition core/envs/griduniverse_env.py:136-155 for a cell:
+//   bits 0..3  move a (UP,RIGHT,DOWN,LEFT; env:51-56) leaves the agent in place:
+//              grid edge (env:51-54), wall at the candidate cell (env:149), or -- in the
+//              "absorbing" map only -- the cell itself is terminal (env:145-146)
+//   bit  4     is_terminal(cell)            (env:163-168)
+//   bit  5     reward_matrix[cell] == +10   (env:80-90)
+//   bit  6     reward_matrix[cell] == -10
+#define GU_CELL_TERM 0x10u
+#define GU_CELL_RPLUS 0x20u
+#define GU_CELL_RMINUS 0x40u
+
+#define GU_MAX_LDS_CELLS 65536 /* grids up to 64 KiB of records are LDS-resident; larger ones read L2 */
+
+struct gu_engine {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+    int64_t N = 0;        // envs on this device
+    int64_t env_id0 = 0;  // global id of env 0
+
+    // grid
+    bool has_grid = false;
+    int32_t W = 0, H = 0, S = 0;
+    int32_t cell_bytes = 0;          // S rounded up to 16
+    uint8_t *d_cell = nullptr;       // absorbing-aware records   [cell_bytes]
+    uint8_t *d_cell_raw = nullptr;   // care_about_terminal=False [cell_bytes]
+    int32_t *d_starts = nullptr;
+    int32_t n_starts = 0;
+    std::vector<uint8_t> h_cell, h_cell_raw;
+    std::vector<int32_t> h_starts;
+
+    // SoA env state
+    int32_t *d_out3 = nullptr;  // pos[N] | reward[N] | done[N]
+    uint32_t *d_episode = nullptr;
+    uint32_t *d_tcount = nullptr;  // per-env step-count OFFSET; effective count = offset + steps_taken
+    uint32_t steps_taken = 0;      // lock-step counter since gu_seed (all envs step together)
+    uint64_t seed = 0;
+    uint32_t seed_prefix = 0;
+
+    // device-resident action stream
+    int32_t *d_actions = nullptr;
+    int64_t actions_T = 0;
+
+    // trajectory buffers obs|reward|done, each [traj_T][N]
+    int32_t *d_traj = nullptr;
+    int64_t traj_T = 0;
+
+    // rollout stats
+    int32_t *d_ret = nullptr;
+    int32_t *d_episodes_fin = nullptr;
+    bool stats_valid = false;
+
+    // done compaction
+    uint64_t *d_done_bits = nullptr;
+    int32_t *d_done_idx = nullptr;
+    int32_t *d_done_count = nullptr;
+
+    // scratch for masks / start choices / look_step_ahead
+    void *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    // pinned host staging (4*N int32)
+    int32_t *h_pin = nullptr;
+
+    // hipGraph cache for gu_step_graph
+    hipGraphExec_t graph_exec = nullptr;
+    int64_t graph_t0 = -1, graph_T = -1;
+    uint32_t graph_flags = 0;
+
+    // tabular DP
+    double *d_v[2] = {nullptr, nullptr};
+    double *d_pi[2] = {nullptr, nullptr};
+    int vi_cur = 0;
+    bool has_vi = false;
+    double *d_delta = nullptr;      // per-block maxima + final
+    uint8_t *d_greedy = nullptr;    // first-argmax action per state [cell_bytes]
+    bool greedy_valid = false;
+
+    // RCCL
+    void *comm = nullptr;  // ncclComm_t
+    int32_t nranks = 0, rank = 0;
+    int32_t *d_gather = nullptr;
+
+    int32_t *pos() const { return d_out3; }
+    int32_t *reward() const { return d_out3 + N; }
+    int32_t *done() const { return d_out3 + 2 * N; }
+};
+
+// ---- error plumbing --------------------------------------------------------------
+void gu_set_error(const char *fmt, ...);
+int gu_fail(int code, const char *fmt, ...);
+
+#define GU_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return gu_fail(_e == hipErrorOutOfMemory ? GU_ERR_NOMEM : GU_ERR_HIP, "%s failed: %s", \
+                           #expr, hipGetErrorString(_e));                                         \
+    } while (0)
+
+#define GU_REQUIRE(cond, code, ...) \
+    do {                            \
+        if (!(cond)) return gu_fail(code, __VA_ARGS__); \
+    } while (0)
+
+int gu_use_device(gu_engine *h);
+int gu_ensure_scratch(gu_engine *h, size_t bytes);
+
+// ---- kernel launchers (gu_kernels.hip) -------------------------------------------
+int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice, bool only_done);
+int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags);
+int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags);
+int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const int32_t *d_actions, bool care,
+                        int32_t *d_next, int32_t *d_reward, int32_t *d_done);
+int gu_launch_done_compact(gu_engine *h);
+
+// ---- tabular DP launchers (gu_vi.hip) --------------------------------------------
+int gu_vi_alloc(gu_engine *h);
+void gu_vi_free(gu_engine *h);
+int gu_launch_greedy_table(gu_engine *h);
+
+// ---- RCCL (gu_comm.hip) ----------------------------------------------------------
+void gu_comm_free(gu_engine *h);

@@ -1,0 +1,61 @@
+// gu_rng.hpp -- per-env counter RNG (device + host), gfx950.
+//
+// Specification: oracle/gu_rng.py (MurmurHash3_x86_32 over the four words
+// [seed_lo, seed_hi, global_env_id, (stream << 28) | counter], hash seed 0x9747B28C).
+// The reference has no per-env RNG (core/envs/griduniverse_env.py:64,189 use the
+// process-global stdlib RNG), so this is build-defined and
+// restated on the CPU by the oracle.
+//
+// The first three blocks depend only on (seed, env) and are hoisted out of the step
+// loop (`gu_rng_prefix`); one 32-bit word then costs one block + the finaliser and
+// feeds 16 two-bit actions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GU_RNG_STREAM_ACTION 0u
+#define GU_RNG_STREAM_START 1u
+
+__host__ __device__ __forceinline__ uint32_t gu_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__host__ __device__ __forceinline__ uint32_t gu_mm3_block(uint32_t h, uint32_t k)
+{
+    k *= 0xCC9E2D51u;
+    k = gu_rotl32(k, 15);
+    k *= 0x1B873593u;
+    h ^= k;
+    h = gu_rotl32(h, 13);
+    return h * 5u + 0xE6546B64u;
+}
+
+// state after hashing seed_lo, seed_hi (host side, once per gu_seed)
+__host__ __device__ __forceinline__ uint32_t gu_rng_seed_prefix(uint64_t seed)
+{
+    uint32_t h = 0x9747B28Cu;
+    h = gu_mm3_block(h, (uint32_t)seed);
+    return gu_mm3_block(h, (uint32_t)(seed >> 32));
+}
+
+// state after additionally hashing the global env id (once per lane per launch)
+__host__ __device__ __forceinline__ uint32_t gu_rng_prefix(uint32_t seed_prefix, uint32_t env)
+{
+    return gu_mm3_block(seed_prefix, env);
+}
+
+__host__ __device__ __forceinline__ uint32_t gu_rng_word(uint32_t prefix, uint32_t stream, uint32_t ctr)
+{
+    uint32_t h = gu_mm3_block(prefix, (stream << 28) | (ctr & 0x0FFFFFFFu));
+    h ^= 16u;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// index into starts[] for episode `ep` (multiply-shift range reduction)
+__host__ __device__ __forceinline__ uint32_t gu_rng_start_index(uint32_t prefix, uint32_t ep, uint32_t n_starts)
+{
+    return (uint32_t)(((uint64_t)gu_rng_word(prefix, GU_RNG_STREAM_START, ep) * (uint64_t)n_starts) >> 32);
+}

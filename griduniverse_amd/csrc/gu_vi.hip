@@ -1,0 +1,428 @@
+// gu_vi.hip -- tabular dynamic-programming sweeps on the engine's grid (config 5).
+//
+// Bit-exact float64 restatement of
+//   core/algorithms/utils.py:15-27   single_step_policy_evaluation        (V1)
+//   core/algorithms/utils.py:55-72   greedy_policy_from_value_function    (V2)
+//   core/algorithms/dynamic_programming.py:15-20  one value-iteration round (V1, delta, V2)
+// Every multiply and add is an explicit round-to-nearest f64 op (__dmul_rn/__dadd_rn):
+// the reference rounds after each Python-level operation, so FMA contraction is forbidden
+// (the library is also built with -ffp-contract=off).  Evaluation order is the reference's:
+//   v'[s]  = ((((0.0 + R[s]) + p0*(g*v[n0])) + p1*(g*v[n1])) + p2*(g*v[n2])) + p3*(g*v[n3])
+//   q[s,a] = 0.0 + (R[n_a] + g*v[n_a]);   ties: rint(q*1e8)/1e8 == rint(max*1e8)/1e8  (np.around(.,8))
+//   pi[s,a]= 1/|ties| on ties, else 0; all zeros if s is terminal
+// Walls and terminals are swept like any other state.
+//
+// One lane per state (S = 4096 at 64x64: latency-, not bandwidth-bound; v and pi live in
+// L2).  gu_vi_sweep_step_kernel additionally moves every agent one step greedily on the
+// policy of the SAME round; it gets pi'[pos] by re-evaluating v' at the four neighbour
+// states ("pull" evaluation), which needs no grid-wide barrier inside the launch.
+#include "gu_internal.hpp"
+#include "gu_rng.hpp"
+
+#include <cstring>
+
+#define VI_BLOCK 256
+
+__device__ __forceinline__ int32_t vi_delta(uint32_t a, int32_t W)
+{
+    const int32_t sign = (int32_t)(a & 2u) - 1;
+    return (a & 1u) ? -sign : sign * W;
+}
+
+__device__ __forceinline__ double vi_reward(uint32_t rec)
+{
+    return (rec & GU_CELL_RMINUS) ? -10.0 : ((rec & GU_CELL_RPLUS) ? 10.0 : -1.0);
+}
+
+__device__ __forceinline__ int32_t vi_next(const uint8_t *cell, int32_t s, uint32_t rec, uint32_t a, int32_t W)
+{
+    return ((rec >> a) & 1u) ? s : s + vi_delta(a, W);
+}
+
+// V1 for one state
+__device__ __forceinline__ double vi_eval_state(const uint8_t *cell, int32_t W, double gamma, const double *__restrict__ v,
+                                                const double *__restrict__ pi, int32_t s)
+{
+    const uint32_t rec = cell[s];
+    double acc = __dadd_rn(0.0, vi_reward(rec));
+#pragma unroll
+    for (uint32_t a = 0; a < 4; ++a) {
+        const int32_t n = vi_next(cell, s, rec, a, W);
+        acc = __dadd_rn(acc, __dmul_rn(pi[4 * s + a], __dmul_rn(gamma, v[n])));
+    }
+    return acc;
+}
+
+__device__ __forceinline__ double vi_around8(double x)
+{
+    return __ddiv_rn(rint(__dmul_rn(x, 100000000.0)), 100000000.0);
+}
+
+// V2 for one state given a functor returning v'(n)
+template <typename VNew>
+__device__ __forceinline__ void vi_greedy_state(const uint8_t *cell, int32_t W, double gamma, VNew vnew, int32_t s, double out[4])
+{
+    const uint32_t rec = cell[s];
+    double q[4];
+#pragma unroll
+    for (uint32_t a = 0; a < 4; ++a) {
+        const int32_t n = vi_next(cell, s, rec, a, W);
+        const double rn = vi_reward(cell[n]);
+        q[a] = __dadd_rn(0.0, __dadd_rn(rn, __dmul_rn(gamma, vnew(n))));
+    }
+    double qmax = q[0];
+#pragma unroll
+    for (int a = 1; a < 4; ++a) qmax = (q[a] > qmax) ? q[a] : qmax;
+    const double rmax = vi_around8(qmax);
+    bool tie[4];
+    int ties = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        tie[a] = vi_around8(q[a]) == rmax;
+        ties += tie[a];
+    }
+    const double share = (ties == 1) ? 1.0 : (ties == 2) ? 0.5 : (ties == 3) ? (1.0 / 3.0) : 0.25;
+    const bool term = rec & GU_CELL_TERM;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) out[a] = (tie[a] && !term) ? share : 0.0;
+}
+
+// order-preserving double -> uint64 key so that max(double) is an integer atomicMax
+__device__ __forceinline__ unsigned long long vi_key(double x)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ void vi_block_max_to_global(double mine, bool valid, unsigned long long *out)
+{
+    __shared__ unsigned long long wave_key[VI_BLOCK / 64];
+    unsigned long long k = valid ? vi_key(mine) : 0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_down(k, off);
+        k = o > k ? o : k;
+    }
+    if ((threadIdx.x & 63) == 0) wave_key[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) k = wave_key[w] > k ? wave_key[w] : k;
+        atomicMax(out, k);
+    }
+}
+
+__device__ __forceinline__ void vi_stage(const uint8_t *__restrict__ src, uint8_t *dst, int32_t bytes16)
+{
+    for (int32_t i = threadIdx.x * 16; i < bytes16; i += blockDim.x * 16)
+        *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
+}
+
+struct ViArgs {
+    const uint8_t *cell;
+    int32_t cell_bytes, W, S;
+    double gamma;
+    const double *v, *pi;     // old
+    double *v_new, *pi_new;   // new
+    unsigned long long *delta_key;
+};
+
+template <bool LDS>
+__global__ void __launch_bounds__(VI_BLOCK) gu_vi_eval_kernel(const ViArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint8_t *cell = a.cell;
+    if (LDS) {
+        vi_stage(a.cell, smem, a.cell_bytes);
+        __syncthreads();
+        cell = smem;
+    }
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = s < a.S;
+    double d = 0.0;
+    if (valid) {
+        const double vn = vi_eval_state(cell, a.W, a.gamma, a.v, a.pi, s);
+        a.v_new[s] = vn;
+        d = __dsub_rn(a.v[s], vn);  // signed, dynamic_programming.py:17
+    }
+    vi_block_max_to_global(d, valid, a.delta_key);
+}
+
+template <bool LDS>
+__global__ void __launch_bounds__(VI_BLOCK) gu_vi_greedy_kernel(const ViArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint8_t *cell = a.cell;
+    if (LDS) {
+        vi_stage(a.cell, smem, a.cell_bytes);
+        __syncthreads();
+        cell = smem;
+    }
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.S) return;
+    double row[4];
+    const double *vn = a.v_new;
+    vi_greedy_state(cell, a.W, a.gamma, [vn](int32_t n) { return vn[n]; }, s, row);
+    *reinterpret_cast<double4 *>(a.pi_new + 4 * s) = make_double4(row[0], row[1], row[2], row[3]);
+}
+
+// first-argmax action per state (np.argmax; examples/griduniverse_alg_examples.py:76)
+__global__ void __launch_bounds__(VI_BLOCK) gu_vi_argmax_kernel(const double *__restrict__ pi, int32_t S, uint8_t *__restrict__ greedy)
+{
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const double4 p = *reinterpret_cast<const double4 *>(pi + 4 * s);
+    uint32_t best = 0;
+    double m = p.x;
+    if (p.y > m) { m = p.y; best = 1; }
+    if (p.z > m) { m = p.z; best = 2; }
+    if (p.w > m) { m = p.w; best = 3; }
+    greedy[s] = (uint8_t)best;
+}
+
+// config 5: one V1+V2 round AND one greedy env step in one launch
+struct ViStepArgs {
+    ViArgs vi;
+    int32_t *pos, *reward, *done;
+    uint32_t *episode;
+    const int32_t *starts;
+    uint32_t n_starts, seed_prefix, env_id0;
+    int64_t N;
+    uint32_t flags;
+};
+
+template <bool LDS>
+__global__ void __launch_bounds__(VI_BLOCK) gu_vi_sweep_step_kernel(const ViStepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint8_t *cell = a.vi.cell;
+    if (LDS) {
+        vi_stage(a.vi.cell, smem, a.vi.cell_bytes);
+        __syncthreads();
+        cell = smem;
+    }
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t W = a.vi.W;
+    const double gamma = a.vi.gamma;
+    const double *v = a.vi.v, *pi = a.vi.pi;
+    auto vnew = [=](int32_t n) { return vi_eval_state(cell, W, gamma, v, pi, n); };
+
+    // (1) table round for state gid
+    const bool sweep = gid < a.vi.S;
+    double d = 0.0;
+    if (sweep) {
+        const int32_t s = (int32_t)gid;
+        const double vn = vnew(s);
+        a.vi.v_new[s] = vn;
+        d = __dsub_rn(v[s], vn);
+        double row[4];
+        vi_greedy_state(cell, W, gamma, vnew, s, row);
+        *reinterpret_cast<double4 *>(a.vi.pi_new + 4 * s) = make_double4(row[0], row[1], row[2], row[3]);
+    }
+    if (blockIdx.x * blockDim.x < a.vi.S) vi_block_max_to_global(d, sweep, a.vi.delta_key);  // block-uniform branch
+
+    // (2) agent gid acts greedily on the updated policy
+    if (gid >= a.N) return;
+    int32_t s = a.pos[gid];
+    if ((a.flags & GU_F_AUTO_RESET) && a.done[gid]) {
+        const uint32_t ep = a.episode[gid];
+        s = a.starts[gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)gid), ep, a.n_starts)];
+        a.episode[gid] = ep + 1;
+    }
+    double row[4];
+    vi_greedy_state(cell, W, gamma, vnew, s, row);
+    uint32_t act = 0;
+    double m = row[0];
+#pragma unroll
+    for (uint32_t k = 1; k < 4; ++k)
+        if (row[k] > m) { m = row[k]; act = k; }
+    uint32_t rec = cell[s];
+    s = vi_next(cell, s, rec, act, W);
+    rec = cell[s];
+    a.pos[gid] = s;
+    a.reward[gid] = (rec & GU_CELL_RMINUS) ? -10 : ((rec & GU_CELL_RPLUS) ? 10 : -1);
+    a.done[gid] = (rec & GU_CELL_TERM) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------ host side
+static inline unsigned vi_blocks(int64_t n) { return (unsigned)((n + VI_BLOCK - 1) / VI_BLOCK); }
+
+int gu_vi_alloc(gu_engine *h)
+{
+    if (h->d_v[0]) return GU_OK;
+    const size_t S = (size_t)h->S;
+    for (int k = 0; k < 2; ++k) {
+        GU_HIP(hipMalloc(&h->d_v[k], S * sizeof(double)));
+        GU_HIP(hipMalloc(&h->d_pi[k], 4 * S * sizeof(double)));
+    }
+    GU_HIP(hipMalloc(&h->d_delta, 4096 * sizeof(unsigned long long)));
+    return GU_OK;
+}
+
+void gu_vi_free(gu_engine *h)
+{
+    for (int k = 0; k < 2; ++k) {
+        if (h->d_v[k]) (void)hipFree(h->d_v[k]);
+        if (h->d_pi[k]) (void)hipFree(h->d_pi[k]);
+        h->d_v[k] = h->d_pi[k] = nullptr;
+    }
+    if (h->d_delta) (void)hipFree(h->d_delta);
+    h->d_delta = nullptr;
+    h->has_vi = false;
+    h->greedy_valid = false;
+}
+
+int gu_launch_greedy_table(gu_engine *h)
+{
+    hipLaunchKernelGGL(gu_vi_argmax_kernel, dim3(vi_blocks(h->S)), dim3(VI_BLOCK), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_greedy);
+    GU_HIP(hipGetLastError());
+    h->greedy_valid = true;
+    return GU_OK;
+}
+
+static double vi_unkey(unsigned long long k)
+{
+    unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    double x;
+    memcpy(&x, &b, sizeof x);
+    return x;
+}
+
+static ViArgs vi_args(gu_engine *h, double gamma, unsigned long long *delta_key)
+{
+    ViArgs a{};
+    a.cell = h->d_cell;
+    a.cell_bytes = h->cell_bytes;
+    a.W = h->W;
+    a.S = h->S;
+    a.gamma = gamma;
+    a.v = h->d_v[h->vi_cur];
+    a.pi = h->d_pi[h->vi_cur];
+    a.v_new = h->d_v[h->vi_cur ^ 1];
+    a.pi_new = h->d_pi[h->vi_cur ^ 1];
+    a.delta_key = delta_key;
+    return a;
+}
+
+extern "C" {
+
+int gu_vi_set(gu_handle h, const double *v, const double *pi)
+{
+    int rc = gu_use_device(h);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(h->has_grid, GU_ERR_STATE, "no grid set: call gu_set_grid first");
+    GU_REQUIRE(v && pi, GU_ERR_INVALID, "v or pi is NULL");
+    rc = gu_vi_alloc(h);
+    if (rc != GU_OK) return rc;
+    GU_HIP(hipStreamSynchronize(h->stream));
+    GU_HIP(hipMemcpy(h->d_v[h->vi_cur], v, (size_t)h->S * sizeof(double), hipMemcpyHostToDevice));
+    GU_HIP(hipMemcpy(h->d_pi[h->vi_cur], pi, 4 * (size_t)h->S * sizeof(double), hipMemcpyHostToDevice));
+    h->has_vi = true;
+    h->greedy_valid = false;
+    return GU_OK;
+}
+
+int gu_vi_get(gu_handle h, double *v, double *pi)
+{
+    int rc = gu_use_device(h);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (v) GU_HIP(hipMemcpy(v, h->d_v[h->vi_cur], (size_t)h->S * sizeof(double), hipMemcpyDeviceToHost));
+    if (pi) GU_HIP(hipMemcpy(pi, h->d_pi[h->vi_cur], 4 * (size_t)h->S * sizeof(double), hipMemcpyDeviceToHost));
+    return GU_OK;
+}
+
+int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update, double *deltas)
+{
+    int rc = gu_use_device(h);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
+    GU_REQUIRE(iters > 0 && iters <= 4096, GU_ERR_INVALID, "iters must be in 1..4096 per call");
+    GU_HIP(hipMemsetAsync(h->d_delta, 0, (size_t)iters * sizeof(unsigned long long), h->stream));
+    const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
+    const bool lds = h->S <= GU_MAX_LDS_CELLS;
+    const size_t smem = lds ? (size_t)h->cell_bytes : 0;
+    for (int32_t i = 0; i < iters; ++i) {
+        ViArgs a = vi_args(h, gamma, (unsigned long long *)h->d_delta + i);
+        if (lds) hipLaunchKernelGGL(gu_vi_eval_kernel<true>, grid, block, smem, h->stream, a);
+        else hipLaunchKernelGGL(gu_vi_eval_kernel<false>, grid, block, 0, h->stream, a);
+        if (greedy_update) {
+            if (lds) hipLaunchKernelGGL(gu_vi_greedy_kernel<true>, grid, block, smem, h->stream, a);
+            else hipLaunchKernelGGL(gu_vi_greedy_kernel<false>, grid, block, 0, h->stream, a);
+            h->vi_cur ^= 1;  // both tables advanced
+        } else {
+            // policy unchanged: only v advances; keep pi where it is by swapping v buffers only
+            double *t = h->d_v[0];
+            h->d_v[0] = h->d_v[1];
+            h->d_v[1] = t;
+        }
+    }
+    GU_HIP(hipGetLastError());
+    h->greedy_valid = false;
+    if (deltas) {
+        std::vector<unsigned long long> keys((size_t)iters);
+        GU_HIP(hipMemcpyAsync(keys.data(), h->d_delta, (size_t)iters * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        GU_HIP(hipStreamSynchronize(h->stream));
+        for (int32_t i = 0; i < iters; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
+    }
+    return GU_OK;
+}
+
+int gu_vi_greedy(gu_handle h, double gamma)
+{
+    int rc = gu_use_device(h);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
+    ViArgs a = vi_args(h, gamma, nullptr);
+    a.v_new = h->d_v[h->vi_cur];  // V2 reads the CURRENT value table ...
+    const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
+    if (h->S <= GU_MAX_LDS_CELLS)
+        hipLaunchKernelGGL(gu_vi_greedy_kernel<true>, grid, block, (size_t)h->cell_bytes, h->stream, a);
+    else
+        hipLaunchKernelGGL(gu_vi_greedy_kernel<false>, grid, block, 0, h->stream, a);
+    GU_HIP(hipGetLastError());
+    double *t = h->d_pi[0];  // ... and only the policy table advances
+    h->d_pi[0] = h->d_pi[1];
+    h->d_pi[1] = t;
+    h->greedy_valid = false;
+    return GU_OK;
+}
+
+int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta)
+{
+    int rc = gu_use_device(h);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
+    GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_vi_sweep_step accepts only GU_F_AUTO_RESET");
+    GU_HIP(hipMemsetAsync(h->d_delta, 0, sizeof(unsigned long long), h->stream));
+    ViStepArgs a{};
+    a.vi = vi_args(h, gamma, (unsigned long long *)h->d_delta);
+    a.pos = h->pos();
+    a.reward = h->reward();
+    a.done = h->done();
+    a.episode = h->d_episode;
+    a.starts = h->d_starts;
+    a.n_starts = (uint32_t)h->n_starts;
+    a.seed_prefix = h->seed_prefix;
+    a.env_id0 = (uint32_t)h->env_id0;
+    a.N = h->N;
+    a.flags = flags;
+    const int64_t threads = h->N > h->S ? h->N : h->S;
+    const dim3 grid(vi_blocks(threads)), block(VI_BLOCK);
+    if (h->S <= GU_MAX_LDS_CELLS)
+        hipLaunchKernelGGL(gu_vi_sweep_step_kernel<true>, grid, block, (size_t)h->cell_bytes, h->stream, a);
+    else
+        hipLaunchKernelGGL(gu_vi_sweep_step_kernel<false>, grid, block, 0, h->stream, a);
+    GU_HIP(hipGetLastError());
+    h->vi_cur ^= 1;
+    h->greedy_valid = false;
+    h->steps_taken += 1;
+    if (delta) {
+        unsigned long long key = 0;
+        GU_HIP(hipMemcpyAsync(&key, h->d_delta, sizeof key, hipMemcpyDeviceToHost, h->stream));
+        GU_HIP(hipStreamSynchronize(h->stream));
+        *delta = vi_unkey(key);
+    }
+    return GU_OK;
+}
+
+}  // extern "C"

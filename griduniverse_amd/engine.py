@@ -1,0 +1,210 @@
+"""Engine: numpy-facing wrapper of one libgu handle (one device, one HIP stream).
+
+Thin by design -- every method is one C-ABI call (include/gu.h) plus array
+marshalling; all grid / argument semantics of the reference live in
+`griduniverse_amd.envs` (host Python) and in the kernels (device).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ptr
+from .grid import GridSpec
+
+_POLICIES = {'uniform': _lib.POLICY_UNIFORM, 'stream': _lib.POLICY_STREAM, 'greedy': _lib.POLICY_GREEDY}
+
+
+class Engine(object):
+    def __init__(self, num_envs, spec, device=0, env_id0=0, seed=0):
+        if not isinstance(spec, GridSpec):
+            raise TypeError('spec must be a GridSpec')
+        self._h = ctypes.c_void_p()
+        self.lib = _lib.load()
+        self.N = int(num_envs)
+        self.env_id0 = int(env_id0)
+        self.device = int(device)
+        check(self.lib.gu_create(self.device, self.N, self.env_id0, ctypes.byref(self._h)))
+        self.spec = None
+        try:
+            self.set_grid(spec)
+            self.seed(seed)
+        except Exception:
+            self.close()
+            raise
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self.lib.gu_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ configuration
+    def set_grid(self, spec):
+        p = spec.planes()
+        starts = np.asarray(spec.starts, dtype=np.int32)
+        check(self.lib.gu_set_grid(self._h, spec.W, spec.H, spec.words_per_row, ptr(p['wall']), ptr(p['goal']),
+                                   ptr(p['lava']), ptr(p['rplus']), ptr(p['rminus']), ptr(starts), len(starts)))
+        self.spec = spec
+
+    def seed(self, seed):
+        self.seed_value = int(seed) & 0xFFFFFFFFFFFFFFFF
+        check(self.lib.gu_seed(self._h, self.seed_value))
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(self, mask=None, start_choice=None):
+        m = None if mask is None else _lib.as_array(np.asarray(mask).astype(bool), np.uint8, (self.N,), 'mask')
+        c = None if start_choice is None else _lib.as_array(start_choice, np.int32, (self.N,), 'start_choice')
+        obs = np.empty(self.N, np.int32)
+        check(self.lib.gu_reset(self._h, ptr(m), ptr(c), ptr(obs)))
+        return obs
+
+    def reset_done(self):
+        check(self.lib.gu_reset_done(self._h))
+
+    def step(self, actions, auto_reset=False):
+        a = _lib.as_array(actions, np.int32, (self.N,), 'actions')
+        obs, rew, don = (np.empty(self.N, np.int32) for _ in range(3))
+        check(self.lib.gu_step(self._h, ptr(a), _lib.F_AUTO_RESET if auto_reset else 0, ptr(obs), ptr(rew), ptr(don)))
+        return obs, rew, don
+
+    def upload_actions(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        if a.ndim != 2 or a.shape[1] != self.N:
+            raise ValueError('actions must have shape (T, {}), got {}'.format(self.N, a.shape))
+        check(self.lib.gu_upload_actions(self._h, ptr(a), a.shape[0]))
+
+    def step_device(self, t, auto_reset=False):
+        check(self.lib.gu_step_device(self._h, int(t), _lib.F_AUTO_RESET if auto_reset else 0))
+
+    def step_graph(self, t0, T, auto_reset=False):
+        check(self.lib.gu_step_graph(self._h, int(t0), int(T), _lib.F_AUTO_RESET if auto_reset else 0))
+
+    def read_outputs(self):
+        obs, rew, don = (np.empty(self.N, np.int32) for _ in range(3))
+        check(self.lib.gu_read_outputs(self._h, ptr(obs), ptr(rew), ptr(don)))
+        return obs, rew, don
+
+    # ------------------------------------------------------------------ rollout
+    def reserve_trajectory(self, T):
+        check(self.lib.gu_reserve_trajectory(self._h, int(T)))
+
+    def rollout(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
+        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_TRAJECTORY if trajectory else 0) | \
+                (_lib.F_STATS if stats else 0)
+        check(self.lib.gu_rollout(self._h, int(T), _POLICIES[policy], flags))
+
+    def read_trajectory(self, t0, T):
+        obs, rew, don = (np.empty((T, self.N), np.int32) for _ in range(3))
+        check(self.lib.gu_read_trajectory(self._h, int(t0), int(T), ptr(obs), ptr(rew), ptr(don)))
+        return dict(obs=obs, reward=rew, done=don)
+
+    def read_stats(self):
+        ret = np.empty(self.N, np.int64)
+        eps = np.empty(self.N, np.int32)
+        check(self.lib.gu_read_stats(self._h, ptr(ret), ptr(eps)))
+        return ret, eps
+
+    # ------------------------------------------------------------------ state
+    def get_state(self):
+        pos, don = np.empty(self.N, np.int32), np.empty(self.N, np.int32)
+        ep, tc = np.empty(self.N, np.uint32), np.empty(self.N, np.uint32)
+        check(self.lib.gu_get_state(self._h, ptr(pos), ptr(don), ptr(ep), ptr(tc)))
+        return dict(pos=pos, done=don, episode=ep, tcount=tc)
+
+    def set_state(self, pos=None, done=None, episode=None, tcount=None):
+        pos = None if pos is None else _lib.as_array(pos, np.int32, (self.N,), 'pos')
+        done = None if done is None else _lib.as_array(done, np.int32, (self.N,), 'done')
+        episode = None if episode is None else _lib.as_array(episode, np.uint32, (self.N,), 'episode')
+        tcount = None if tcount is None else _lib.as_array(tcount, np.uint32, (self.N,), 'tcount')
+        check(self.lib.gu_set_state(self._h, ptr(pos), ptr(done), ptr(episode), ptr(tcount)))
+
+    def done_indices(self):
+        idx = np.empty(self.N, np.int32)
+        count = ctypes.c_int32(0)
+        check(self.lib.gu_done_indices(self._h, ptr(idx), ctypes.byref(count)))
+        return idx[:count.value].copy()
+
+    def look_step_ahead(self, states, actions, care_about_terminal=True):
+        s = np.ascontiguousarray(states, dtype=np.int32).ravel()
+        a = np.ascontiguousarray(actions, dtype=np.int32).ravel()
+        if s.size != a.size:
+            raise ValueError('states and actions must have the same number of elements')
+        nxt, rew, don = (np.empty(s.size, np.int32) for _ in range(3))
+        check(self.lib.gu_look_step_ahead(self._h, s.size, ptr(s), ptr(a), 1 if care_about_terminal else 0,
+                                          ptr(nxt), ptr(rew), ptr(don)))
+        return nxt, rew, don
+
+    # ------------------------------------------------------------------ tabular DP
+    def vi_set(self, v, pi):
+        S = self.spec.S
+        v = _lib.as_array(v, np.float64, (S,), 'value_function')
+        pi = _lib.as_array(pi, np.float64, (S, 4), 'policy')
+        check(self.lib.gu_vi_set(self._h, ptr(v), ptr(pi)))
+
+    def vi_sweep(self, gamma=1.0, iters=1, greedy_update=True):
+        deltas = np.empty(int(iters), np.float64)
+        check(self.lib.gu_vi_sweep(self._h, float(gamma), int(iters), 1 if greedy_update else 0, ptr(deltas)))
+        return deltas
+
+    def vi_greedy(self, gamma=1.0):
+        check(self.lib.gu_vi_greedy(self._h, float(gamma)))
+
+    def vi_get(self):
+        S = self.spec.S
+        v, pi = np.empty(S, np.float64), np.empty((S, 4), np.float64)
+        check(self.lib.gu_vi_get(self._h, ptr(v), ptr(pi)))
+        return v, pi
+
+    def vi_sweep_step(self, gamma=1.0, auto_reset=False, want_delta=True):
+        d = ctypes.c_double(0.0)
+        check(self.lib.gu_vi_sweep_step(self._h, float(gamma), _lib.F_AUTO_RESET if auto_reset else 0,
+                                        ctypes.byref(d) if want_delta else None))
+        return d.value if want_delta else None
+
+    # ------------------------------------------------------------------ stream / timing
+    def sync(self):
+        check(self.lib.gu_sync(self._h))
+
+    def timer_begin(self):
+        check(self.lib.gu_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = ctypes.c_float(0.0)
+        check(self.lib.gu_timer_end(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    # ------------------------------------------------------------------ RCCL gathered view
+    @staticmethod
+    def comm_unique_id():
+        buf = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
+        check(_lib.load().gu_comm_unique_id(ptr(buf)))
+        return buf.tobytes()
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        if buf.size != _lib.COMM_ID_BYTES:
+            raise ValueError('unique id must be {} bytes'.format(_lib.COMM_ID_BYTES))
+        check(self.lib.gu_comm_init(self._h, int(nranks), int(rank), ptr(buf)))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_destroy(self):
+        check(self.lib.gu_comm_destroy(self._h))
+
+    def allgather_view(self):
+        total = self.nranks * self.N
+        obs, rew, don = (np.empty(total, np.int32) for _ in range(3))
+        check(self.lib.gu_allgather_view(self._h, ptr(obs), ptr(rew), ptr(don)))
+        return obs, rew, don

@@ -1,0 +1,178 @@
+/* gu.h -- C ABI of libgu.so, the MI355X (gfx950) GridUniverse step/reset engine.
+ *
+ * The reference (TheMTank/GridUniverse) is pure Python and has no FFI layer; its
+ * boundary for this path is the old-gym Env API of
+ * core/envs/griduniverse_env.py:14-321.  Every entry point below names the
+ * reference interface (file:line, `env:` = core/envs/griduniverse_env.py) whose
+ * per-instance work it replaces for a whole batch of env instances.  The
+ * reference-side binding (ctypes) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 (GU_OK) or a negative
+ *     GU_ERR_* code and never throws; gu_last_error() gives the message of the last
+ *     failure on the calling thread.
+ *   - the caller owns every host buffer (C-contiguous, int32 unless noted);
+ *     the library owns all device memory and frees it in gu_destroy().
+ *   - a handle is bound to ONE device and ONE HIP stream and is not thread-safe;
+ *     different handles may be driven from different threads / processes.
+ *   - calls that take host buffers are synchronous; calls documented "async" only
+ *     enqueue work on the handle's stream (gu_sync() waits for it).
+ *   - env state is struct-of-arrays in HBM: pos[N] | reward[N] | done[N] (one
+ *     contiguous int32[3N] block, so the gathered view is one collective),
+ *     episode[N], tcount[N] (uint32).  Actions are 0..3 = UP,RIGHT,DOWN,LEFT
+ *     (env:56); anything else is rejected (the reference's negative-index quirk is
+ *     not part of the contract).
+ */
+#ifndef GU_H
+#define GU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GU_ABI_VERSION 1
+
+#define GU_OK 0
+#define GU_ERR_INVALID (-1)     /* bad argument (NULL, out of range, wrong size)        */
+#define GU_ERR_HIP (-2)         /* a HIP runtime call failed (no device, launch error)   */
+#define GU_ERR_NOMEM (-3)       /* host or device allocation failed                      */
+#define GU_ERR_STATE (-4)       /* call order: no grid set, no trajectory reserved, ...  */
+#define GU_ERR_COMM (-5)        /* RCCL failure                                          */
+#define GU_ERR_UNSUPPORTED (-6) /* grid too large for this build, etc.                   */
+
+/* gu_rollout / gu_step_device flags */
+#define GU_F_AUTO_RESET 1u  /* harness `if done: env.reset()` applied before the next step */
+#define GU_F_TRAJECTORY 2u  /* write (obs,reward,done)[t][env] for every step              */
+#define GU_F_STATS 4u       /* per-env sum of rewards and finished-episode count           */
+
+/* gu_rollout policy kinds */
+#define GU_POLICY_UNIFORM 0 /* a ~ U{0..3} from the per-env counter RNG (stream 0)           */
+#define GU_POLICY_STREAM 1  /* a = actions[t][env] uploaded with gu_upload_actions           */
+#define GU_POLICY_GREEDY 2  /* a = first argmax of pi[pos] (np.argmax; examples/griduniverse_alg_examples.py:76) */
+
+typedef struct gu_engine *gu_handle;
+
+/* ---- library ----------------------------------------------------------------- */
+int gu_version(void);                         /* GU_ABI_VERSION */
+int gu_last_error(char *buf, size_t len);     /* copies the thread's last message, returns its length */
+int gu_device_count(int *count);              /* hipGetDeviceCount */
+
+/* ---- lifetime ----------------------------------------------------------------
+ * One engine = `num_envs` lock-stepped instances of one grid on device `device_id`;
+ * `env_id0` is the global index of its first env (RNG streams are keyed by global
+ * id, so a sharded batch reproduces the single-device batch byte for byte).
+ * Replaces num_envs x GridUniverseEnv.__init__ (env:17-107) state setup. */
+int gu_create(int device_id, int64_t num_envs, int64_t env_id0, gu_handle *out);
+int gu_destroy(gu_handle h);
+
+/* ---- grid --------------------------------------------------------------------
+ * Row bit-planes, `words_per_row` = ceil(W/32) uint32 words per row, bit (x & 31) of
+ * word (x >> 5) of row y describes cell s = y*W + x (env:116-117).
+ *   wall_rows  : wall_grid[s] == 1          (env:120-134, env:157-161)
+ *   goal_rows  : s in goal_states           (env:173-174)
+ *   lava_rows  : s in lava_states           (env:170-171)
+ *   rplus_rows / rminus_rows : reward_matrix[s] == +10 / == -10 (env:80-90, 312-316),
+ *       or both NULL to derive them as (lava ? -10 : goal ? +10 : -1).  They are
+ *       separate planes because the reference's reward matrix and terminal test
+ *       can disagree (negative indices wrap only in the former; quirk 5).
+ *   starts     : starting_states (env:61-63), n_starts >= 1.
+ * The library compiles the planes into one byte per cell (blocked-move bits for the
+ * four actions incl. the absorbing-terminal rule, terminal bit, reward code) that the
+ * kernels stage in LDS. */
+int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row,
+                const uint32_t *wall_rows, const uint32_t *goal_rows, const uint32_t *lava_rows,
+                const uint32_t *rplus_rows, const uint32_t *rminus_rows,
+                const int32_t *starts, int32_t n_starts);
+
+/* ---- RNG ---------------------------------------------------------------------
+ * Keys the per-env counter RNG (MurmurHash3 of seed, global env id, stream,
+ * counter; specified in oracle/gu_rng.py) and zeroes episode[] and tcount[].
+ * The reference has no per-env RNG (env:242-244 stores one and never uses it). */
+int gu_seed(gu_handle h, uint64_t seed);
+
+/* ---- reset: GridUniverseEnv._reset, env:187-193 --------------------------------
+ * mask (N bytes, NULL = all): which envs to reset.  start_choice (N int32 indices
+ * into starts[], NULL = draw from RNG stream 1 at the env's episode counter).
+ * Sets done = 0, bumps episode[].  obs_out (N, optional) receives pos[]. */
+int gu_reset(gu_handle h, const uint8_t *mask, const int32_t *start_choice, int32_t *obs_out);
+/* Device-side: reset exactly the envs whose done flag is set (async). */
+int gu_reset_done(gu_handle h);
+
+/* ---- step: GridUniverseEnv._step, env:176-185 (+ look_step_ahead env:136-155) ---
+ * Synchronous, host buffers: actions in, (obs, reward, done) out (each N int32,
+ * outputs optional).  flags: GU_F_AUTO_RESET. */
+int gu_step(gu_handle h, const int32_t *actions, uint32_t flags,
+            int32_t *obs, int32_t *reward, int32_t *done);
+
+/* Device-resident action stream [T][N] for gu_step_device / GU_POLICY_STREAM. */
+int gu_upload_actions(gu_handle h, const int32_t *actions, int64_t T);
+/* One step with actions row `t` of the uploaded stream; results stay in HBM (async). */
+int gu_step_device(gu_handle h, int64_t t, uint32_t flags);
+/* The same T single-step launches (rows t0 .. t0+T-1) replayed from one hipGraph (async). */
+int gu_step_graph(gu_handle h, int64_t t0, int64_t T, uint32_t flags);
+/* Copy the current (obs, reward, done) block to the host (any pointer may be NULL). */
+int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done);
+
+/* ---- rollout: the caller loop of core/algorithms/monte_carlo.py:7-26 fused -----
+ * T env-steps per env in ONE launch (async).  With GU_F_TRAJECTORY the
+ * (obs,reward,done) of step i of this call land in row i of the trajectory buffer
+ * (gu_reserve_trajectory(T) first); with GU_F_STATS the per-env reward sum and the
+ * number of episodes finished during this call are kept for gu_read_stats. */
+int gu_reserve_trajectory(gu_handle h, int64_t T);
+int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
+int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);
+int gu_read_stats(gu_handle h, int64_t *reward_sum, int32_t *episodes);
+
+/* ---- state (checkpoint / parity harness) --------------------------------------
+ * Any pointer may be NULL.  pos/done int32[N], episode/tcount uint32[N]. */
+int gu_get_state(gu_handle h, int32_t *pos, int32_t *done, uint32_t *episode, uint32_t *tcount);
+int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uint32_t *episode, const uint32_t *tcount);
+
+/* Ascending indices of envs whose done flag is set (wave-ballot masks written by the
+ * step kernels + one compaction kernel).  idx has room for N entries. */
+int gu_done_indices(gu_handle h, int32_t *idx, int32_t *count);
+
+/* ---- look_step_ahead table queries: env:136-155 for n (state, action) pairs ---- */
+int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int32_t *actions,
+                       int32_t care_about_terminal, int32_t *next, int32_t *reward, int32_t *done);
+
+/* ---- tabular DP on the engine's grid (float64, bit-exact, no FMA contraction) ----
+ * gu_vi_set   : upload v[S] and pi[S][4]                (dynamic_programming.py:12-13)
+ * gu_vi_sweep : `iters` x { V1 policy-evaluation sweep  core/algorithms/utils.py:15-27;
+ *               optionally V2 greedy improvement        core/algorithms/utils.py:55-72 }
+ *               deltas[i] = max(v - v') of sweep i      dynamic_programming.py:17 (may be NULL)
+ * gu_vi_greedy: V2 alone on the current v (policy improvement without an evaluation sweep)
+ * gu_vi_get   : download v / pi (either may be NULL)
+ * gu_vi_sweep_step : config 5 -- ONE launch that performs one V1+V2 sweep AND one env
+ *               step in which every agent acts greedily on the updated policy. */
+int gu_vi_set(gu_handle h, const double *v, const double *pi);
+int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update, double *deltas);
+int gu_vi_greedy(gu_handle h, double gamma);
+int gu_vi_get(gu_handle h, double *v, double *pi);
+int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta);
+
+/* ---- stream / timing -----------------------------------------------------------
+ * HIP events on the handle's own stream (torch.cuda.Event cannot see it). */
+int gu_sync(gu_handle h);
+int gu_timer_begin(gu_handle h);
+int gu_timer_end(gu_handle h, float *milliseconds); /* records, waits, returns elapsed */
+
+/* ---- multi-GPU gathered view (RCCL over xGMI) ----------------------------------
+ * One process per GPU.  Rank 0 calls gu_comm_unique_id and ships the 128 bytes to
+ * the other ranks by any host channel; every rank then calls gu_comm_init.  The
+ * data path (step / rollout) never communicates; only gu_allgather_view does:
+ * one ncclAllGather of the packed int32[3N] (obs|reward|done) block per rank, then
+ * a D2H copy into three host arrays of nranks*N.  All ranks must hold the same N. */
+#define GU_COMM_ID_BYTES 128
+int gu_comm_unique_id(uint8_t id[GU_COMM_ID_BYTES]);
+int gu_comm_init(gu_handle h, int32_t nranks, int32_t rank, const uint8_t id[GU_COMM_ID_BYTES]);
+int gu_comm_destroy(gu_handle h);
+int gu_allgather_view(gu_handle h, int32_t *obs_all, int32_t *reward_all, int32_t *done_all);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GU_H */

@@ -1,0 +1,158 @@
+"""Config 5 parity: the float64 DP kernels (csrc/gu_vi.hip) against golden tables captured from the
+reference's core/algorithms (bit-exact: compared as raw bytes), and the fused sweep+step launch
+against the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+
+import griduniverse_amd as gua
+from griduniverse_amd.algorithms import dynamic_programming as dp
+from griduniverse_amd.algorithms import utils
+from griduniverse_amd.engine import Engine
+from griduniverse_amd.grid import GridSpec
+from oracle import c_oracle as C
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+
+def spec_of(meta):
+    return GridSpec(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'])
+
+
+def env_of(meta):
+    return gua.GridUniverseEnv(grid_shape=(meta['W'], meta['H']), initial_state=list(meta['starts']),
+                               goal_states=list(meta['goals']), lava_states=list(meta['lava']), walls=list(meta['walls']))
+
+
+@pytest.mark.parametrize('name', G.dp_names())
+def test_engine_sweeps_bit_exact(name):
+    meta, z = G.load_dp(name)
+    S, gamma = meta['W'] * meta['H'], meta['gamma']
+    with Engine(8, spec_of(meta)) as eng:
+        eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+        done = 0
+        for k in (1, 2, 10):  # repeated V1 under the uniform policy
+            eng.vi_sweep(gamma, k - done, greedy_update=False)
+            done = k
+            assert eng.vi_get()[0].tobytes() == z['eval_v_%d' % k].tobytes(), (name, k)
+        eng.vi_greedy(gamma)
+        v, pi = eng.vi_get()
+        assert pi.tobytes() == z['greedy_pi_after_10'].tobytes() and v.tobytes() == z['eval_v_10'].tobytes()
+        # value-iteration rounds, one at a time and then all in one call
+        eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+        for k in range(1, meta['iters'] + 1):
+            delta = eng.vi_sweep(gamma, 1, greedy_update=True)[0]
+            v, pi = eng.vi_get()
+            assert v.tobytes() == z['vi_v_%d' % k].tobytes() and pi.tobytes() == z['vi_pi_%d' % k].tobytes(), (name, k)
+            assert delta == meta['deltas'][k - 1]
+        eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+        deltas = eng.vi_sweep(gamma, meta['iters'], greedy_update=True)
+        v, pi = eng.vi_get()
+        assert deltas.tolist() == meta['deltas']
+        assert v.tobytes() == z['vi_v_%d' % meta['iters']].tobytes() and pi.tobytes() == z['vi_pi_%d' % meta['iters']].tobytes()
+
+
+@pytest.mark.parametrize('name', G.dp_names())
+def test_reference_named_drivers(name):
+    """utils.single_step_policy_evaluation / greedy_policy_from_value_function / dp.value_iteration /
+    dp.policy_iteration called the way examples/griduniverse_alg_examples.py:29-63 calls them."""
+    meta, z = G.load_dp(name)
+    env = env_of(meta)
+    S, gamma = env.world.size, meta['gamma']
+    policy0 = np.ones([env.world.size, len(env.action_state_to_next_state)]) / len(env.action_state_to_next_state)
+    v = np.zeros(S)
+    for k in range(10):
+        v = utils.single_step_policy_evaluation(policy0, env, discount_factor=gamma, value_function=v)
+    assert v.tobytes() == z['eval_v_10'].tobytes()
+    pi_in = policy0.copy()
+    pi_out = utils.greedy_policy_from_value_function(pi_in, env, v, discount_factor=gamma)
+    assert pi_out is pi_in and pi_in.tobytes() == z['greedy_pi_after_10'].tobytes()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        v3, pi3 = dp.value_iteration(policy0.copy(), env, np.zeros(S), threshold=meta['driver_threshold'],
+                                     max_steps=meta['iters'], discount_factor=gamma)
+    assert v3.tobytes() == z['vi_driver_v'].tobytes() and pi3.tobytes() == z['vi_driver_pi'].tobytes()
+    assert (len(w) > 0) == meta['driver_warned']
+    if 'pi_driver_v' in z:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            v4, pi4 = dp.policy_iteration(policy0.copy(), env, np.zeros(S), threshold=1e-3,
+                                          max_steps=meta['pi_driver_max_steps'], discount_factor=gamma)
+        assert v4.tobytes() == z['pi_driver_v'].tobytes() and pi4.tobytes() == z['pi_driver_pi'].tobytes()
+        assert (len(w) > 0) == meta['pi_driver_warned']
+    env.close()
+
+
+def test_random_policies_and_values_bit_exact():
+    """Non-uniform pi and non-trivial v exercise every rounding step of V1 / V2 (vs the C oracle,
+    which is itself pinned to the reference by tests/test_oracle_c.py)."""
+    rs = np.random.RandomState(5)
+    for name in ('maze11_s3_g09', 'rect6x5_g1', 'maze32_s1_g099'):
+        meta, _ = G.load_dp(name)
+        grid, S = C.Grid.from_lists(**meta), meta['W'] * meta['H']
+        with Engine(4, spec_of(meta)) as eng:
+            for gamma in (1.0, 0.9, 0.37):
+                pi = rs.dirichlet(np.ones(4), S)
+                v = rs.standard_normal(S) * 50
+                v[::7] = np.round(v[::7])  # force exact ties in q
+                eng.vi_set(v, pi)
+                d = eng.vi_sweep(gamma, 1, greedy_update=True)[0]
+                v_want, pi_want, d_want = C.value_iteration_step(grid, gamma, pi, v)
+                v_got, pi_got = eng.vi_get()
+                assert v_got.tobytes() == v_want.tobytes() and pi_got.tobytes() == pi_want.tobytes() and d == d_want
+
+
+@pytest.mark.parametrize('name,N', [('maze64_s5', 65536), ('maze64_s5_g097', 4096), ('rect6x5_g1', 100), ('lava4x4_g095', 3)])
+def test_fused_sweep_step_launch(name, N):
+    """Config 5: ONE launch = one V1+V2 round + one greedy env step on the updated policy."""
+    meta, z = G.load_dp(name)
+    grid, S, gamma = C.Grid.from_lists(**meta), meta['W'] * meta['H'], meta['gamma']
+    st = C.State(N)
+    C.reset(grid, 3, st)
+    v, pi = np.zeros(S), np.ones((S, 4)) / 4
+    with Engine(N, spec_of(meta), seed=3) as eng:
+        assert np.array_equal(eng.reset(), st.pos)
+        eng.vi_set(v, pi)
+        for k in range(1, meta['iters'] + 1):
+            delta = eng.vi_sweep_step(gamma, auto_reset=True)
+            v, pi, d_want = C.value_iteration_step(grid, gamma, pi, v)
+            assert v.tobytes() == z['vi_v_%d' % k].tobytes()  # the oracle itself is on the reference's trace
+            acts = np.argmax(pi, axis=1).astype(np.int32)     # examples/griduniverse_alg_examples.py:76
+            # lazy auto-reset happens before the action is looked up, exactly as in the kernel
+            pre = st.pos.copy()
+            if st.done.any():
+                m = st.done.astype(bool)
+                C.reset(grid, 3, st, mask=m)
+                pre = st.pos.copy()
+            want = C.rollout(grid, 3, st, 1, False, actions=acts[pre][None, :])
+            obs, rew, don = eng.read_outputs()
+            v_got, pi_got = eng.vi_get()
+            assert v_got.tobytes() == v.tobytes() and pi_got.tobytes() == pi.tobytes() and delta == d_want, (name, k)
+            assert np.array_equal(obs, want['obs'][0]) and np.array_equal(rew, want['reward'][0]) and np.array_equal(don, want['done'][0])
+        s = eng.get_state()
+        assert np.array_equal(s['episode'], st.episode)
+
+
+def test_greedy_rollout_follows_value_iteration_policy():
+    """After VI converges on an 11x11 maze, agents acting greedily reach the goal (the demo of
+    examples/griduniverse_alg_examples.py:66-85, batched), identical to the oracle step by step."""
+    meta, z = G.load_dp('maze11_s3_g09')
+    grid, S = C.Grid.from_lists(**meta), meta['W'] * meta['H']
+    N, T = 300, 60
+    with Engine(N, spec_of(meta), seed=1) as eng:
+        eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+        eng.vi_sweep(0.9, 200, greedy_update=True)
+        pi = eng.vi_get()[1]
+        acts = np.argmax(pi, axis=1).astype(np.int32)
+        eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'greedy', auto_reset=False, trajectory=True)
+        got = eng.read_trajectory(0, T)
+    st = C.State(N)
+    C.reset(grid, 1, st)
+    for t in range(T):
+        want = C.rollout(grid, 1, st, 1, False, actions=acts[st.pos][None, :])
+        assert np.array_equal(got['obs'][t], want['obs'][0]) and np.array_equal(got['done'][t], want['done'][0])
+    assert got['done'][-1].all(), 'greedy agents did not reach the goal'

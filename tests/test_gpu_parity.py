@@ -1,0 +1,396 @@
+"""Parity tests proper: the HIP kernels, called through the C ABI (libgu.so via ctypes), against
+ (a) golden vectors captured from the real reference (tests/golden),
+ (b) the CPU oracle on seeded inputs at BASELINE sizes,
+ (c) size-independent properties (resumability, shard independence, absorbing terminals).
+Bit-exact throughout: this is integer / index work."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import griduniverse_amd as gua
+from griduniverse_amd.engine import Engine
+from griduniverse_amd.grid import GridSpec
+from oracle import c_oracle as C
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+
+def spec_of(meta):
+    return GridSpec(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'])
+
+
+def digest(obs, rew, don):
+    h = hashlib.sha256()
+    for a in (obs, rew, don):
+        h.update(np.ascontiguousarray(a, dtype='<i4').tobytes())
+    return h.hexdigest()
+
+
+def fresh(meta, N=None):
+    eng = Engine(N or meta['N'], spec_of(meta), env_id0=meta.get('env_id0', 0), seed=meta['seed'])
+    return eng
+
+
+# ------------------------------------------------------------------------------- golden trajectories
+@pytest.mark.parametrize('name', G.traj_names())
+def test_golden_step_api(name):
+    """gu_step, one launch per env-step with host action rows (env:176-185)."""
+    meta, z = G.load_traj(name)
+    T, N = z['actions'].shape
+    T = min(T, 300)
+    with fresh(meta) as eng:
+        assert np.array_equal(eng.reset(), z['first_state'])
+        for t in range(T):
+            obs, rew, don = eng.step(z['actions'][t], auto_reset=meta['auto_reset'])
+            assert np.array_equal(obs, z['obs'][t]) and np.array_equal(rew, z['reward'][t]) \
+                and np.array_equal(don, z['done'][t]), (name, t)
+
+
+@pytest.mark.parametrize('name', G.traj_names())
+@pytest.mark.parametrize('mode', ['stream', 'uniform', 'device', 'graph'])
+def test_golden_fused_and_device_paths(name, mode):
+    meta, z = G.load_traj(name)
+    T, N = z['actions'].shape
+    if mode == 'uniform' and 'RandomState' in meta['note']:
+        pytest.skip('fixture actions come from numpy, not from the build RNG')
+    with fresh(meta) as eng:
+        eng.reset()
+        if mode in ('stream', 'uniform'):
+            if mode == 'stream':
+                eng.upload_actions(z['actions'])
+            eng.reserve_trajectory(T)
+            eng.rollout(T, mode, meta['auto_reset'], trajectory=True, stats=True)
+            out = eng.read_trajectory(0, T)
+            for k in ('obs', 'reward', 'done'):
+                assert np.array_equal(out[k], z[k]), (name, mode, k)
+            assert digest(out['obs'], out['reward'], out['done']) == meta['sha256']
+            ret, eps = eng.read_stats()
+            assert np.array_equal(ret, z['reward'].sum(0)) and np.array_equal(eps, z['done'].sum(0))
+        else:
+            eng.upload_actions(z['actions'])
+            if mode == 'graph':
+                eng.step_graph(0, T, meta['auto_reset'])
+            else:
+                for t in range(T):
+                    eng.step_device(t, meta['auto_reset'])
+        obs, rew, don = eng.read_outputs()
+        assert np.array_equal(obs, z['obs'][-1]) and np.array_equal(rew, z['reward'][-1]) and np.array_equal(don, z['done'][-1])
+        st = eng.get_state()
+        assert np.all(st['tcount'] == T) and np.array_equal(st['pos'], z['obs'][-1])
+
+
+@pytest.mark.parametrize('name', sorted(G.load_json('digests.json')))
+def test_reference_digests_4096x1000(name):
+    """sha256 of 4096 envs x 1000 steps of the real reference."""
+    d = G.load_json('digests.json')[name]
+    with fresh(d) as eng:
+        eng.reset()
+        eng.reserve_trajectory(d['T'])
+        eng.rollout(d['T'], 'uniform', d['auto_reset'])
+        out = eng.read_trajectory(0, d['T'])
+    assert digest(out['obs'], out['reward'], out['done']) == d['sha256']
+    assert int(out['reward'].sum()) == d['sum_reward'] and int(out['done'].sum()) == d['sum_done']
+
+
+# ------------------------------------------------------------------------------- BASELINE sizes vs the oracle
+FULL = [('c2_open8x8', 4096, 1000), ('c3_maze32', 65536, 1000), ('c4_lava32', 32768, 1000), ('c5_maze64', 65536, 512)]
+
+
+@pytest.mark.parametrize('name,N,T', FULL)
+def test_full_size_rollout_equals_oracle(name, N, T):
+    meta, _ = G.load_traj(name)
+    grid = C.Grid.from_lists(**meta)
+    seed = 20260 + N
+    st = C.State(N)
+    C.reset(grid, seed, st)
+    want = C.rollout(grid, seed, st, T, True, stats=True)
+    with Engine(N, spec_of(meta), seed=seed) as eng:
+        eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'uniform', True, trajectory=True, stats=True)
+        got = eng.read_trajectory(0, T)
+        ret, eps = eng.read_stats()
+        state = eng.get_state()
+    for k in ('obs', 'reward', 'done'):
+        assert np.array_equal(got[k], want[k]), (name, k)
+    assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes'])
+    assert np.array_equal(state['pos'], st.pos) and np.array_equal(state['done'], st.done)
+    assert np.array_equal(state['episode'], st.episode) and np.array_equal(state['tcount'], st.tcount)
+
+
+def test_sharded_batch_equals_single_batch():
+    """C4: envs [g*N/8, (g+1)*N/8) on 'rank' g reproduce the single-engine batch byte for byte."""
+    meta, _ = G.load_traj('c4_lava32')
+    N, T, shards = 4096, 300, 8
+    with Engine(N, spec_of(meta), seed=4) as eng:
+        eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'uniform', True)
+        whole = eng.read_trajectory(0, T)
+    per = N // shards
+    for g in (0, 3, 7):
+        with Engine(per, spec_of(meta), env_id0=g * per, seed=4) as eng:
+            eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'uniform', True)
+            part = eng.read_trajectory(0, T)
+        for k in whole:
+            assert np.array_equal(part[k], whole[k][:, g * per:(g + 1) * per]), (g, k)
+
+
+def test_rollout_is_resumable_and_mixes_with_steps():
+    meta, z = G.load_traj('rect25x30_busy')
+    T, N = z['actions'].shape
+    with fresh(meta) as eng:
+        eng.reset()
+        got = {k: [] for k in ('obs', 'reward', 'done')}
+        t = 0
+        for chunk in (1, 17, 100):
+            eng.reserve_trajectory(chunk)
+            eng.rollout(chunk, 'uniform', True)
+            out = eng.read_trajectory(0, chunk)
+            for k in got:
+                got[k].append(out[k])
+            t += chunk
+        for _ in range(20):  # single steps continue the same stream
+            obs, rew, don = eng.step(z['actions'][t], auto_reset=True)
+            for k, v in zip(('obs', 'reward', 'done'), (obs, rew, don)):
+                got[k].append(v[None])
+            t += 1
+        eng.reserve_trajectory(T - t)
+        eng.rollout(T - t, 'uniform', True)
+        out = eng.read_trajectory(0, T - t)
+        for k in got:
+            got[k].append(out[k])
+            assert np.array_equal(np.concatenate(got[k]), z[k]), k
+
+
+def test_ragged_batch_sizes():
+    """N not a multiple of the wave / block size, N = 1, and a single partial wave."""
+    meta, _ = G.load_traj('c4_lava32')
+    grid = C.Grid.from_lists(**meta)
+    for N in (1, 2, 63, 65, 255, 257, 1000):
+        st = C.State(N, 5)
+        C.reset(grid, 9, st)
+        want = C.rollout(grid, 9, st, 200, True)
+        with Engine(N, spec_of(meta), env_id0=5, seed=9) as eng:
+            eng.reset()
+            eng.reserve_trajectory(200)
+            eng.rollout(200, 'uniform', True)
+            got = eng.read_trajectory(0, 200)
+            assert sorted(eng.done_indices().tolist()) == np.flatnonzero(st.done).tolist()
+        for k in ('obs', 'reward', 'done'):
+            assert np.array_equal(got[k], want[k]), (N, k)
+
+
+# ------------------------------------------------------------------------------- reset / state / compaction
+def test_masked_reset_explicit_choice_and_done_compaction():
+    meta, _ = G.load_traj('multistart_test_env')
+    N = 777
+    grid = C.Grid.from_lists(**meta)
+    st = C.State(N)
+    with Engine(N, spec_of(meta), seed=31) as eng:
+        assert np.array_equal(eng.reset(), C.reset(grid, 31, st))
+        C.rollout(grid, 31, st, 9, False)
+        eng.rollout(9, 'uniform', False, trajectory=False)
+        s = eng.get_state()
+        assert np.array_equal(s['pos'], st.pos) and np.array_equal(s['done'], st.done)
+        idx = eng.done_indices()
+        assert idx.dtype == np.int32 and np.array_equal(idx, np.flatnonzero(st.done)) and len(idx) > 0
+        # reset only the finished envs (device-side), then a masked host reset with explicit choices
+        C.reset(grid, 31, st, mask=st.done.astype(bool))
+        eng.reset_done()
+        s = eng.get_state()
+        assert np.array_equal(s['pos'], st.pos) and not s['done'].any() and np.array_equal(s['episode'], st.episode)
+        assert len(eng.done_indices()) == 0
+        mask = (np.arange(N) % 3 == 0)
+        choice = (np.arange(N) % 2).astype(np.int32)
+        obs = eng.reset(mask, choice)
+        want = st.pos.copy()
+        want[mask] = np.asarray(meta['starts'])[choice[mask]]
+        assert np.array_equal(obs, want)
+        assert np.array_equal(eng.get_state()['episode'], st.episode + mask.astype(np.uint32))
+        with pytest.raises(gua.GuError):
+            eng.reset(None, np.full(N, 2, np.int32))
+
+
+def test_set_state_round_trip_and_absorbing_terminals():
+    meta, _ = G.load_traj('c4_lava32')
+    N = 512
+    rs = np.random.RandomState(1)
+    free = np.setdiff1d(np.arange(1024), meta['walls'])
+    pos = rs.choice(free, N).astype(np.int32)
+    with Engine(N, spec_of(meta), seed=8) as eng:
+        eng.set_state(pos=pos, done=np.zeros(N, np.int32), episode=np.arange(N, dtype=np.uint32),
+                      tcount=np.full(N, 160, np.uint32))
+        s = eng.get_state()
+        assert np.array_equal(s['pos'], pos) and np.all(s['tcount'] == 160) and np.array_equal(s['episode'], np.arange(N))
+        lava = np.array(meta['lava'][:N // 2] * 40, np.int32)[:N]
+        eng.set_state(pos=lava)
+        for a in range(4):  # absorbing: state stays, reward repeats, done stays (quirk 1)
+            obs, rew, don = eng.step(np.full(N, a, np.int32))
+            assert np.array_equal(obs, lava) and np.all(rew == -10) and np.all(don == 1)
+        with pytest.raises(gua.GuError):
+            eng.set_state(pos=np.full(N, 1024, np.int32))
+        with pytest.raises(gua.GuError):
+            eng.step(np.full(N, 4, np.int32))
+        with pytest.raises(gua.GuError):
+            eng.step(np.full(N, -1, np.int32))
+
+
+def test_look_step_ahead_tables():
+    t = G.load_json('render_quirks.json')['quirks']['lsa_table_6x5']
+    spec = spec_of(t['spec'])
+    s, a = np.meshgrid(np.arange(30), np.arange(4), indexing='ij')
+    with Engine(4, spec) as eng:
+        for care in (True, False):
+            n, r, d = eng.look_step_ahead(s.ravel(), a.ravel(), care)
+            want = np.array(t['table'][str(care)], dtype=np.int64).reshape(-1, 3)
+            assert np.array_equal(np.stack([n, r, d], 1), want)
+    for name in ('maze101', 'rect25x30_busy', 'wide40x12'):
+        meta, _ = G.load_traj(name)
+        grid = C.Grid.from_lists(**meta)
+        S = meta['W'] * meta['H']
+        s, a = np.repeat(np.arange(S), 4), np.tile(np.arange(4), S)
+        with Engine(1, spec_of(meta)) as eng:
+            for care in (True, False):
+                got = eng.look_step_ahead(s, a, care)
+                want = C.look_step_ahead(grid, s, a, care)
+                for g_, w_ in zip(got, want):
+                    assert np.array_equal(g_, w_), (name, care)
+
+
+def test_random_grids_property():
+    """Random grids (walls / lava / goals / starts anywhere, incl. overlaps) vs the oracle."""
+    rs = np.random.RandomState(2026)
+    for trial in range(25):
+        W, H = int(rs.randint(1, 70)), int(rs.randint(1, 40))
+        S = W * H
+        pick = lambda k: [int(x) for x in rs.choice(S, size=min(S, int(k)), replace=False)]  # noqa: E731
+        walls, lava, goals, starts = pick(rs.randint(0, S // 3 + 1)), pick(rs.randint(0, 6)), pick(rs.randint(1, 5)), pick(rs.randint(1, 6))
+        meta = dict(W=W, H=H, walls=walls, lava=lava, goals=goals, starts=starts)
+        grid = C.Grid.from_lists(**meta)
+        spec = GridSpec(W, H, starts, goals, lava, walls)
+        N, T, seed = int(rs.randint(1, 400)), 120, int(rs.randint(0, 2 ** 62))
+        auto = bool(trial % 2)
+        st = C.State(N, 11)
+        C.reset(grid, seed, st)
+        want = C.rollout(grid, seed, st, T, auto)
+        with Engine(N, spec, env_id0=11, seed=seed) as eng:
+            eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'uniform', auto)
+            got = eng.read_trajectory(0, T)
+        for k in ('obs', 'reward', 'done'):
+            assert np.array_equal(got[k], want[k]), (trial, W, H, k)
+
+
+def test_grid_larger_than_lds_uses_the_global_path():
+    W = H = 300  # 90 000 cells > 64 KiB of records
+    rs = np.random.RandomState(3)
+    walls = [int(x) for x in rs.choice(W * H, 20000, replace=False)]
+    meta = dict(W=W, H=H, walls=walls, lava=[5, 777], goals=[W * H - 1, 4000], starts=[0, 301, 45000])
+    grid = C.Grid.from_lists(**meta)
+    st = C.State(300)
+    C.reset(grid, 1, st)
+    want = C.rollout(grid, 1, st, 400, True)
+    with Engine(300, GridSpec(W, H, meta['starts'], meta['goals'], meta['lava'], walls), seed=1) as eng:
+        eng.reset()
+        eng.reserve_trajectory(400)
+        eng.rollout(400, 'uniform', True)
+        got = eng.read_trajectory(0, 400)
+        for k in got:
+            assert np.array_equal(got[k], want[k])
+        obs, rew, don = eng.step(np.zeros(300, np.int32), auto_reset=True)
+        w2 = C.rollout(grid, 1, st, 1, True, actions=np.zeros((1, 300), np.int32))
+        assert np.array_equal(obs, w2['obs'][0]) and np.array_equal(don, w2['done'][0])
+
+
+# ------------------------------------------------------------------------------- facade (N = 1 drop-in)
+def _triple(step):
+    o, r, d, _ = step
+    return [int(o), int(r), bool(d)]
+
+
+@pytest.mark.parametrize('kat', G.load_json('kat.json'), ids=lambda k: k['name'])
+def test_facade_reference_kats(kat):
+    for pick, run in enumerate(kat['runs']):
+        kw = dict(kat['kwargs'])
+        if 'grid_shape' in kw:
+            kw['grid_shape'] = tuple(kw['grid_shape'])
+        if kat['level']:
+            kw['custom_world_fp'] = G.level_path(kat['level'])
+        env = gua.GridUniverseEnv(**kw)
+        if kat['level']:
+            env.current_state = env.starting_states[pick]
+        assert int(env.current_state) == run['first_state']
+        assert [_triple(env.step(a)) for a in kat['actions']] == run['steps']
+        env.close()
+
+
+def test_facade_quirks_types_and_trail():
+    q = G.load_json('render_quirks.json')['quirks']
+    env = gua.GridUniverseEnv()
+    out = env.step(1)
+    assert [type(x).__name__ for x in out] == q['types'] and out[3] is env.info
+    assert env.previous_state == 0 and env.current_state == 1 and len(env.last_n_states) == 1
+    env.current_state = 11
+    assert [_triple(env.step(a)) for a in [2, 0, 3, 1]] == q['absorbing']
+    env = gua.GridUniverseEnv(walls=[0])
+    assert [_triple(env.step(a)) for a in [1, 3, 2, 0]] == q['start_on_wall']
+    env = gua.GridUniverseEnv(goal_states=[5], walls=[5])
+    seq = [_triple(env.step(a)) for a in [1, 2, 2, 0]]
+    env.current_state = 5
+    seq.append(_triple(env.step(1)))
+    assert seq == q['goal_is_wall']
+    env = gua.GridUniverseEnv(goal_states=[1, 15], lava_states=[1])
+    assert [_triple(env.step(a)) for a in [1, 1]] == q['goal_and_lava']
+    env = gua.GridUniverseEnv(goal_states=[-1])
+    env.current_state = 14
+    assert [_triple(env.step(a)) for a in [1, 1, 3]] == q['negative_goal']['steps']
+    env = gua.GridUniverseEnv(lava_states=[1])
+    got = [[int(x) if k < 2 else bool(x) for k, x in enumerate(env.look_step_ahead(s, a, c))]
+           for (s, a, c) in [(1, 1, True), (1, 1, False), (15, 3, True), (15, 3, False), (1, 2, False), (0, 1, False)]]
+    assert got == q['care_about_terminal_false']
+    assert type(env.look_step_ahead(0, 1)[1]).__name__ == 'int64'
+    for c in [c for c in G.load_json('errors.json') if 'step_action' in c]:
+        env = gua.GridUniverseEnv()
+        env.current_state = c['from_state']
+        if c['error']:
+            with pytest.raises(IndexError):
+                env.step(c['step_action'])
+        else:
+            assert _triple(env.step(c['step_action'])) == c['result']
+    env = gua.GridUniverseEnv(grid_shape=(30, 30))
+    for _ in range(520):
+        env.step(1)
+    assert len(env.last_n_states) == 500
+
+
+def test_facade_c1_default_rollout():
+    """Config 1: run_default_griduniverse() shape -- 1 env, 1000 random steps, reset on done."""
+    meta, z = G.load_traj('c1_default4x4')
+    env = gua.GridUniverseEnv()
+    env.reset()
+    done = False
+    for t in range(1000):
+        if done:
+            env.reset()
+        o, r, done, _ = env.step(int(z['actions'][t, 0]))
+        assert (o, r, done) == (z['obs'][t, 0], z['reward'][t, 0], bool(z['done'][t, 0]))
+
+
+def test_vec_env_surface():
+    env = gua.VecGridUniverse(256, grid_shape=(8, 8), seed=2, auto_reset=True)
+    meta, z = G.load_traj('c2_open8x8')
+    obs = env.reset()
+    assert obs.shape == (256,) and obs.dtype == np.int32 and not obs.any()
+    o, r, d, info = env.step(np.pad(z['actions'][0], (0, 192)))
+    assert d.dtype == bool and np.array_equal(o[:64], z['obs'][0]) and info == {}
+    out = env.rollout(64, stats=True)
+    assert out['obs'].shape == (64, 256) and out['ret'].shape == (256,)
+    out = env.rollout(8, actions=np.ones((8, 256), np.int32))
+    assert out['obs'].shape == (8, 256)
+    env.close()

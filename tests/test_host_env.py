@@ -1,0 +1,160 @@
+"""Host-side logic of the product (no GPU): constructor validation, level loader, seeded maze
+generator, ASCII renderer and the grid -> bit-plane packing, against goldens from the reference."""
+import random
+
+import numpy as np
+import pytest
+
+import griduniverse_amd as gua
+from griduniverse_amd.envs import maze_generation
+from griduniverse_amd.grid import GridSpec
+from tests import _golden as G
+
+
+@pytest.mark.parametrize('case', [c for c in G.load_json('errors.json') if 'kwargs' in c], ids=lambda c: str(c['kwargs']))
+def test_ctor_errors_match_reference(case):
+    kw = dict(case['kwargs'])
+    if kw.get('grid_shape') == 'set':
+        kw['grid_shape'] = set([2, 3])
+    if case['error'] is None:
+        gua.GridUniverseEnv(**kw)
+        return
+    with pytest.raises(Exception) as ei:
+        gua.GridUniverseEnv(**kw)
+    assert type(ei.value).__name__ == case['error'] and str(ei.value) == case['message']
+
+
+@pytest.mark.parametrize('case', [c for c in G.load_json('errors.json') if 'lines' in c], ids=lambda c: c['name'])
+def test_loader_errors_match_reference(case):
+    env = gua.GridUniverseEnv()
+    with pytest.raises(Exception) as ei:
+        env._create_custom_world_from_text(case['lines'])
+    assert type(ei.value).__name__ == case['error'] and str(ei.value) == case['message']
+
+
+def test_ascii_render_matches_reference():
+    g = G.load_json('render_quirks.json')
+    assert gua.GridUniverseEnv(walls=[1], lava_states=[2]).render(mode='ansi').getvalue() == g['render_walls1_lava2']
+    env = gua.GridUniverseEnv(custom_world_fp=G.level_path('test_env.txt'))
+    env.current_state = env.starting_states[0]
+    assert env.render(mode='ansi').getvalue() == g['render_test_env']
+    env = gua.GridUniverseEnv(grid_shape=(5, 3), goal_states=[14, 7], lava_states=[7, 3], walls=[6, 14])
+    assert env.render(mode='ansi').getvalue() == g['render_5x3_overlaps']
+    env = gua.GridUniverseEnv()
+    frames = g['render_default_walk']
+    for state, frame in zip([0, 1, 5, 9, 10, 11, 15], frames):
+        env.current_state = state
+        assert env.render(mode='ansi').getvalue() == frame
+    for bad in ('rgb_array', 'graphic'):
+        with pytest.raises(gua.UnsupportedMode):
+            env.render(mode=bad)
+    assert env.render(close=True) is None
+
+
+def test_human_render_writes_stdout(capsys):
+    out = gua.GridUniverseEnv().render()
+    assert capsys.readouterr().out == 'x o o o \no o o o \no o o o \no o o G \n\n'
+    import sys
+    assert out is sys.stdout
+
+
+def test_surface_attributes():
+    env = gua.GridUniverseEnv(grid_shape=(5, 3), initial_state=[2, 4])
+    assert env.world.size == 15 and tuple(env.world[7]) == (2, 1) and env.world.dtype == np.dtype('int64, int64')
+    assert env.action_space.n == 4 and env.observation_space.n == 15 and len(env.action_state_to_next_state) == 4
+    assert env.action_descriptors == ['UP', 'RIGHT', 'DOWN', 'LEFT'] and env.action_descriptor_to_int['LEFT'] == 3
+    assert env.goal_states == [14] and env.lava_states == [] and env.wall_indices == []
+    assert env.initial_state in (2, 4) and env.current_state == env.previous_state == env.initial_state
+    assert env.reward_matrix.dtype == np.int64 and env.reward_matrix[14] == 10 and env.wall_grid.dtype == np.float64
+    assert env.done is False and env.info == {} and env.last_n_states == [] and env.seed(3) == [3]
+    assert 0 <= env.action_space.sample() < 4
+    assert [env.action_state_to_next_state[a](7) for a in range(4)] == [2, 8, 12, 6]
+    assert [env.action_state_to_next_state[a](0) for a in range(4)] == [0, 1, 5, 0]
+    assert env.is_terminal(14) and not env.is_terminal(0) and env.is_terminal_goal(14) and not env.is_lava(14)
+    q = G.load_json('render_quirks.json')['quirks']
+    env = gua.GridUniverseEnv(custom_world_fp=G.level_path('test_env.txt'))
+    assert dict(n=env.observation_space.n, world_size=env.world.size) == q['stale_observation_space']
+    env = gua.GridUniverseEnv(goal_states=[-1])
+    assert [int(r) for r in env.reward_matrix] == q['negative_goal']['reward'] and not env.is_terminal(15)
+
+
+@pytest.mark.parametrize('key', sorted(G.load_json('mazes.json')))
+def test_seeded_maze_identical_to_reference(key):
+    m = G.load_json('mazes.json')[key]
+    random.seed(m['seed'])
+    np.random.seed(m['seed'])
+    env = gua.GridUniverseEnv(grid_shape=(m['W'], m['H']), random_maze=True)
+    tail = [random.random(), float(np.random.random())]
+    walls = set(env.wall_indices)
+    rows = [''.join('#' if (y * m['W'] + x) in walls else 'x' if (y * m['W'] + x) in env.starting_states else
+                    'G' if (y * m['W'] + x) in env.goal_states else 'o' for x in range(m['W'])) for y in range(m['H'])]
+    assert rows == m['rows'] and len(walls) == m['n_walls']
+    assert env.starting_states == m['start'] and env.goal_states == m['goal'] and env.initial_state == m['initial_state']
+    assert env.lava_states == []
+    assert tail == m['rng_tail'], 'the two global RNGs were not consumed in the reference order'
+
+
+def test_maze_generator_is_silent(capsys):
+    random.seed(1)
+    np.random.seed(1)
+    rows = maze_generation.create_random_maze(9, 7)
+    assert capsys.readouterr().out == ''
+    flat = ''.join(''.join(r) for r in rows)
+    assert len(rows) == 7 and all(len(r) == 9 for r in rows) and flat.count('x') == 1 and flat.count('G') == 1
+
+
+@pytest.mark.parametrize('fn', sorted(G.load_json('levels.json')))
+def test_level_loader_matches_reference(fn):
+    want = G.load_json('levels.json')[fn]
+    random.seed(7)
+    env = gua.GridUniverseEnv(custom_world_fp=G.level_path(fn))
+    assert (env.x_max, env.y_max, env.world.size) == (want['W'], want['H'], want['W'] * want['H'])
+    assert env.starting_states == want['starts'] and env.goal_states == want['goals']
+    assert env.lava_states == want['lava'] and env.wall_indices == want['walls']
+    assert env.initial_state == want['initial_state_seed7'] and env.observation_space.n == want['observation_space_n']
+
+
+def test_loader_strips_blanks(tmp_path):
+    p = tmp_path / 'lvl.txt'
+    p.write_text('x o  #\n\n o\tL G \n   \n')
+    env = gua.GridUniverseEnv(custom_world_fp=str(p))
+    assert (env.x_max, env.y_max) == (3, 2)
+    assert (env.starting_states, env.wall_indices, env.lava_states, env.goal_states) == ([0], [2], [4], [5])
+
+
+def test_random_maze_overrides_other_grid_arguments():
+    random.seed(3)
+    np.random.seed(3)
+    env = gua.GridUniverseEnv(grid_shape=(7, 7), random_maze=True, lava_states=[3], walls=[5], initial_state=2)
+    assert env.lava_states == [] and len(env.starting_states) == 1 and len(env.goal_states) == 1  # quirk 9
+
+
+@pytest.mark.parametrize('name', ['rect25x30_busy', 'wide40x12', 'maze101', 'c4_lava32', 'grid1x1'])
+def test_gridspec_planes(name):
+    meta, _ = G.load_traj(name)
+    spec = GridSpec(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'])
+    p = spec.planes()
+    W, H, wpr = meta['W'], meta['H'], (meta['W'] + 31) // 32
+    assert spec.words_per_row == wpr and all(v.shape == (H, wpr) and v.dtype == np.uint32 for v in p.values())
+
+    def bit(plane, s):
+        x, y = s % W, s // W
+        return (int(plane[y, x >> 5]) >> (x & 31)) & 1
+    for s in range(W * H):
+        assert bit(p['wall'], s) == (s in meta['walls'])
+        assert bit(p['goal'], s) == (s in meta['goals']) and bit(p['lava'], s) == (s in meta['lava'])
+        assert bit(p['rplus'], s) == (meta['reward'][s] == 10) and bit(p['rminus'], s) == (meta['reward'][s] == -10)
+    for plane in p.values():  # no stray bits beyond column W-1
+        if W % 32:
+            assert not (plane[:, -1] >> np.uint32(W % 32)).any()
+
+
+def test_gridspec_rejects_bad_input():
+    with pytest.raises(ValueError):
+        GridSpec(4, 4, [16], [15], [], [])
+    with pytest.raises(ValueError):
+        GridSpec(4, 4, [], [15], [], [])
+    with pytest.raises(ValueError):
+        GridSpec(4, 4, [0], [15], [], [], reward=[5] * 16)
+    spec = GridSpec(4, 4, [0], [-1], [-1], [])  # negative entries never match a state (quirk 5)
+    assert not spec.goal.any() and not spec.lava.any() and (spec.reward == -1).all()

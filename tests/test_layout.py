@@ -1,0 +1,41 @@
+"""Repository rules: the product never imports the oracle, ships no CPU fallback, and nothing
+that runs on the GPU box reads /root/reference."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _py_files(sub):
+    for d, _, files in os.walk(os.path.join(ROOT, sub)):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h', '.cpp')):
+                yield os.path.join(d, f)
+
+
+def test_product_never_touches_the_oracle():
+    pat = re.compile(r'^\s*(from|import)\s+(oracle|tests)\b|libgu_oracle|oracle/_build', re.M)
+    for path in list(_py_files('griduniverse_amd')) + list(_py_files('include')) + list(_py_files('examples')):
+        assert not pat.search(open(path).read()), path + ' references the oracle'
+
+
+def test_oracle_use_in_entry_points_is_confined():
+    text = open(os.path.join(ROOT, 'bench.py')).read()
+    uses = [m.start() for m in re.finditer(r'\boracle\b', text)]
+    start = text.index('def cpu_baseline')
+    end = text.index('\ndef ', start + 1)
+    code_uses = [u for u in uses if 'import' in text[text.rfind('\n', 0, u):text.find('\n', u)]]
+    assert code_uses and all(start < u < end for u in code_uses), 'bench.py may import oracle only inside cpu_baseline()'
+
+
+def test_nothing_on_the_gpu_box_reads_the_reference():
+    for path in list(_py_files('griduniverse_amd')) + list(_py_files('tests')) + list(_py_files('oracle')) + \
+            [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]:
+        if path.endswith('test_layout.py'):
+            continue
+        assert '/root/reference' not in open(path).read(), path
+
+
+def test_oracle_header_declares_test_infrastructure():
+    assert 'TEST INFRASTRUCTURE ONLY' in open(os.path.join(ROOT, 'oracle', '__init__.py')).read()
+    assert 'TEST INFRASTRUCTURE ONLY' in open(os.path.join(ROOT, 'oracle', 'gu_oracle.c')).read()

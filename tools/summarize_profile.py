@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (tools/gpu_profile.sh) into small text/JSON summaries that are
+committed under profiles/.  Usage: summarize_profile.py <prof_dir> <tag>"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def rows(pattern):
+    out = []
+    for p in glob.glob(pattern, recursive=True):
+        with open(p, newline='') as f:
+            out.extend(csv.DictReader(f))
+    return out
+
+
+def main():
+    prof, tag = sys.argv[1], sys.argv[2]
+    dest = os.path.join(prof, 'summary')
+    os.makedirs(dest, exist_ok=True)
+    summary = {'tag': tag}
+    # kernel trace: per-kernel duration statistics
+    kt = rows(os.path.join(prof, 'kt', '**', '*kernel_trace.csv'))
+    per = defaultdict(list)
+    for r in kt:
+        per[r['Kernel_Name']].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    stats = {}
+    for k, v in per.items():
+        v.sort()
+        stats[k] = dict(calls=len(v), total_ns=sum(v), avg_ns=sum(v) / len(v), min_ns=v[0], median_ns=v[len(v) // 2], max_ns=v[-1])
+    summary['kernel_trace'] = stats
+    if kt:
+        r = next(x for x in kt if 'rollout' in x['Kernel_Name'])
+        summary['rollout_dispatch'] = {k: r.get(k) for k in ('Workgroup_Size_X', 'Grid_Size_X', 'VGPR_Count', 'Accum_VGPR_Count',
+                                                             'SGPR_Count', 'LDS_Block_Size', 'Scratch_Size') if k in r}
+    # counters: average per rollout dispatch (skip the first, which includes cold caches)
+    pmc = defaultdict(list)
+    for d in glob.glob(os.path.join(prof, 'pmc_*')):
+        for r in rows(os.path.join(d, '**', '*counter_collection.csv')):
+            if 'rollout' in r['Kernel_Name']:
+                pmc[r['Counter_Name']].append(float(r['Counter_Value']))
+    summary['rollout_pmc_avg_per_dispatch'] = {k: sum(v) / len(v) for k, v in sorted(pmc.items())}
+    summary['rollout_pmc_samples'] = {k: len(v) for k, v in sorted(pmc.items())}
+    avg = summary['rollout_pmc_avg_per_dispatch']
+    if 'WRITE_SIZE' in avg:
+        # MI355X_MICROARCH.md "HBM": WRITE_SIZE and FETCH_SIZE are in KiB; on gfx950 FETCH_SIZE reports half
+        # of a coalesced read stream, so it is doubled; WRITE_SIZE reads the bytes exactly.  Calibration in
+        # our own access pattern: the kernel's known write volume is 12 B x N x T + state write-back.
+        wr = avg['WRITE_SIZE'] * 1024.0
+        rd = 2.0 * avg.get('FETCH_SIZE', 0.0) * 1024.0
+        summary['hbm'] = dict(write_bytes=wr, read_bytes_corrected=rd, hbm_bytes_per_launch=wr + rd,
+                              source='rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes), tag %s; '
+                                     'bytes = WRITE_SIZE*1024 + 2*FETCH_SIZE*1024' % tag)
+        json.dump(summary['hbm'], open(os.path.join(dest, 'rollout_pmc_latest.json'), 'w'), indent=1)
+    for p in glob.glob(os.path.join(prof, 'kt', '**', '*kernel_stats.csv'), recursive=True):
+        open(os.path.join(dest, '%s_rocprofv3_kernel_stats.csv' % tag), 'w').write(open(p).read())
+    json.dump(summary, open(os.path.join(dest, '%s_rocprof_summary.json' % tag), 'w'), indent=1)
+    with open(os.path.join(dest, '%s_kernel_stats.txt' % tag), 'w') as f:
+        f.write('%-90s %6s %12s %12s %12s %12s\n' % ('kernel', 'calls', 'avg_us', 'min_us', 'median_us', 'max_us'))
+        for k, s in sorted(stats.items(), key=lambda kv: -kv[1]['total_ns']):
+            f.write('%-90s %6d %12.2f %12.2f %12.2f %12.2f\n' % (k[:90], s['calls'], s['avg_ns'] / 1e3, s['min_ns'] / 1e3,
+                                                               s['median_ns'] / 1e3, s['max_ns'] / 1e3))
+    print(open(os.path.join(dest, '%s_kernel_stats.txt' % tag)).read())
+    print(json.dumps(summary['rollout_pmc_avg_per_dispatch'], indent=1))
+
+
+if __name__ == '__main__':
+    main()

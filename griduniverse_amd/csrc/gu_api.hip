@@ -175,23 +175,26 @@ int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row, const 
         GU_REQUIRE(starts[i] >= 0 && starts[i] < S, GU_ERR_INVALID, "starting state %d outside the grid", starts[i]);
 
     const int32_t cell_bytes = (S + 15) & ~15;
-    std::vector<uint8_t> cell((size_t)cell_bytes, 0), raw((size_t)cell_bytes, 0);
+    std::vector<uint8_t> cell(2 * (size_t)cell_bytes, 0), raw(2 * (size_t)cell_bytes, 0);
     auto wall = [&](int32_t x, int32_t y) { return plane_bit(wall_rows, words_per_row, x, y); };
     for (int32_t y = 0; y < H; ++y) {
         for (int32_t x = 0; x < W; ++x) {
+            const size_t s = (size_t)y * W + x;
             const bool lava = plane_bit(lava_rows, words_per_row, x, y);
             const bool goal = plane_bit(goal_rows, words_per_row, x, y);
             const bool term = lava || goal;                                          // env:163-168
             const bool rminus = rminus_rows ? plane_bit(rminus_rows, words_per_row, x, y) : lava;   // env:86-88
             const bool rplus = rplus_rows ? plane_bit(rplus_rows, words_per_row, x, y) : (goal && !lava);
-            uint8_t blocked = 0;
-            if (y == 0 || wall(x, y - 1)) blocked |= 1u;        // UP    env:51, env:149
-            if (x == W - 1 || wall(x + 1, y)) blocked |= 2u;    // RIGHT env:52
-            if (y == H - 1 || wall(x, y + 1)) blocked |= 4u;    // DOWN  env:53
-            if (x == 0 || wall(x - 1, y)) blocked |= 8u;        // LEFT  env:54
-            uint8_t info = (term ? GU_CELL_TERM : 0) | (rplus ? GU_CELL_RPLUS : 0) | (rminus ? GU_CELL_RMINUS : 0);
-            raw[(size_t)y * W + x] = blocked | info;
-            cell[(size_t)y * W + x] = (term ? 0x0Fu : blocked) | info;                // env:145-146 absorbing
+            uint8_t open = 0;
+            if (y > 0 && !wall(x, y - 1)) open |= 1u;        // UP    env:51, env:149
+            if (x < W - 1 && !wall(x + 1, y)) open |= 2u;    // RIGHT env:52
+            if (y < H - 1 && !wall(x, y + 1)) open |= 4u;    // DOWN  env:53
+            if (x > 0 && !wall(x - 1, y)) open |= 8u;        // LEFT  env:54
+            const uint8_t t = term ? GU_CELL_TERM : 0;
+            raw[s] = open | t;
+            cell[s] = (term ? 0 : open) | t;                                         // env:145-146 absorbing
+            const int8_t r = rminus ? -10 : (rplus ? 10 : -1);                       // env:80-90
+            raw[(size_t)cell_bytes + s] = cell[(size_t)cell_bytes + s] = (uint8_t)r;
         }
     }
     GU_HIP(hipStreamSynchronize(h->stream));
@@ -201,12 +204,12 @@ int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row, const 
     h->d_starts = nullptr;
     h->has_grid = false;
     gu_vi_free(h);
-    GU_HIP(hipMalloc(&h->d_cell, cell_bytes));
-    GU_HIP(hipMalloc(&h->d_cell_raw, cell_bytes));
+    GU_HIP(hipMalloc(&h->d_cell, 2 * (size_t)cell_bytes));
+    GU_HIP(hipMalloc(&h->d_cell_raw, 2 * (size_t)cell_bytes));
     GU_HIP(hipMalloc(&h->d_greedy, cell_bytes));
     GU_HIP(hipMalloc(&h->d_starts, (size_t)n_starts * sizeof(int32_t)));
-    GU_HIP(hipMemcpy(h->d_cell, cell.data(), cell_bytes, hipMemcpyHostToDevice));
-    GU_HIP(hipMemcpy(h->d_cell_raw, raw.data(), cell_bytes, hipMemcpyHostToDevice));
+    GU_HIP(hipMemcpy(h->d_cell, cell.data(), 2 * (size_t)cell_bytes, hipMemcpyHostToDevice));
+    GU_HIP(hipMemcpy(h->d_cell_raw, raw.data(), 2 * (size_t)cell_bytes, hipMemcpyHostToDevice));
     GU_HIP(hipMemset(h->d_greedy, 0, cell_bytes));
     GU_HIP(hipMemcpy(h->d_starts, starts, (size_t)n_starts * sizeof(int32_t), hipMemcpyHostToDevice));
     h->h_cell.swap(cell);
@@ -215,6 +218,11 @@ int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row, const 
     h->W = W;
     h->H = H;
     h->S = S;
+    {   // action -> state delta LUT, four int16 lanes of one 64-bit scalar: UP -W, RIGHT +1, DOWN +W, LEFT -1
+        const uint64_t w16 = (uint64_t)(uint16_t)(int16_t)(W <= 32767 ? W : 0);
+        const uint64_t mw16 = (uint64_t)(uint16_t)(int16_t)(W <= 32767 ? -W : 0);
+        h->delta_lut = mw16 | (1ull << 16) | (w16 << 32) | (0xFFFFull << 48);
+    }
     h->cell_bytes = cell_bytes;
     h->n_starts = n_starts;
     h->has_grid = true;

@@ -7,20 +7,21 @@
 
 #include "../../include/gu.h"
 
-// ---- per-cell record (one byte per grid cell, staged in LDS by every kernel) --------
-// Compiled on the host from the row bit-planes handed to gu_set_grid().  It encodes the
-// reference transition core/envs/griduniverse_env.py:136-155 for a cell:
-//   bits 0..3  move a (UP,RIGHT,DOWN,LEFT; env:51-56) leaves the agent in place:
-//              grid edge (env:51-54), wall at the candidate cell (env:149), or -- in the
-//              "absorbing" map only -- the cell itself is terminal (env:145-146)
-//   bit  4     is_terminal(cell)            (env:163-168)
-//   bit  5     reward_matrix[cell] == +10   (env:80-90)
-//   bit  6     reward_matrix[cell] == -10
+// ---- per-cell records (two byte planes, staged in LDS by every kernel) ----------------
+// Compiled on the host from the row bit-planes handed to gu_set_grid().  Together they
+// encode the reference transition core/envs/griduniverse_env.py:136-155 for a cell:
+//   flags[s]  bits 0..3  OPEN[a]: move a (UP,RIGHT,DOWN,LEFT; env:51-56) changes the position,
+//                        i.e. NOT (grid edge (env:51-54) | wall at the candidate cell (env:149)
+//                        | -- in the "absorbing" map only -- the cell itself is terminal (env:145-146))
+//             bit  4     is_terminal(cell)            (env:163-168)
+//   reward[s] int8       reward_matrix[cell]: -1, +10 or -10   (env:80-90)
+// so that one env-step is   s += OPEN[a] * delta[a];  flags = F[s];  reward = R[s];  done = TERM.
+// Device layout: one buffer [flags: cell_bytes | reward: cell_bytes], cell_bytes = S rounded up to 16.
+#define GU_CELL_OPEN_MASK 0x0Fu
 #define GU_CELL_TERM 0x10u
-#define GU_CELL_RPLUS 0x20u
-#define GU_CELL_RMINUS 0x40u
+#define GU_CELL_TERM_BIT 4
 
-#define GU_MAX_LDS_CELLS 65536 /* grids up to 64 KiB of records are LDS-resident; larger ones read L2 */
+#define GU_MAX_LDS_CELLS 32767 /* both planes of grids up to 32 767 cells (64 KiB) are LDS-resident; larger read L2 */
 
 struct gu_engine {
     int device = -1;
@@ -34,8 +35,9 @@ struct gu_engine {
     bool has_grid = false;
     int32_t W = 0, H = 0, S = 0;
     int32_t cell_bytes = 0;          // S rounded up to 16
-    uint8_t *d_cell = nullptr;       // absorbing-aware records   [cell_bytes]
-    uint8_t *d_cell_raw = nullptr;   // care_about_terminal=False [cell_bytes]
+    uint8_t *d_cell = nullptr;       // absorbing-aware planes    [2 * cell_bytes]
+    uint8_t *d_cell_raw = nullptr;   // care_about_terminal=False [2 * cell_bytes]
+    uint64_t delta_lut = 0;          // int16 x 4: {-W, +1, +W, -1} (valid when W <= 32767)
     int32_t *d_starts = nullptr;
     int32_t n_starts = 0;
     std::vector<uint8_t> h_cell, h_cell_raw;

@@ -1,21 +1,25 @@
 // gu_kernels.hip -- step / reset / rollout kernels for gfx950 (CDNA4, wave64).
 //
-// One wavefront lane per env instance.  Every kernel first stages the grid's per-cell
-// record map (one byte per cell, see gu_internal.hpp) from L2 into LDS with 16-byte
-// loads; the transition of core/envs/griduniverse_env.py:136-155 is then ONE LDS byte
-// read per env-step (the record of the cell the agent lands on) plus a handful of
-// integer VALU ops:
+// One wavefront lane per env instance.  Every kernel first stages the grid's two per-cell
+// byte planes (flags, reward; see gu_internal.hpp) from L2 into LDS with 16-byte loads.  The
+// transition of core/envs/griduniverse_env.py:136-155 is then, per env-step,
 //
-//     blocked = (rec >> a) & 1          edge / wall-at-candidate / absorbing terminal
-//     s      += blocked ? 0 : delta[a]  delta = {-W, +1, +W, -1}   (env:51-54)
-//     rec     = cell[s]                 LDS
-//     reward  = rec&RMINUS ? -10 : rec&RPLUS ? +10 : -1            (env:80-90)
-//     done    = rec&TERM                                           (env:163-168)
+//     open   = (flags >> a) & 1          0 = grid edge / wall at the candidate / absorbing terminal
+//     s      = s + open * delta[a]       delta = {-W, +1, +W, -1} (env:51-54), one v_mad_i32_i24
+//     flags  = F[s];  reward = R[s]      two LDS byte reads (ds_read_u8 / ds_read_i8)
+//     done   = (flags >> 4) & 1          (env:163-168)
 //
-// State traffic is coalesced int32 SoA: lane e touches word e of pos[] / reward[] /
-// done[] / actions[] and of each trajectory row.  This is HBM-bound integer work:
-// no MFMA, no inter-block reuse (so no XCD-aware block remap is needed -- the only
-// shared data is the <=64 KiB record map, which every XCD's L2 holds after first touch).
+// i.e. a dependent chain of 2 VALU ops + 1 LDS read per step.  State traffic is coalesced int32
+// SoA: lane e touches word e of pos[] / reward[] / done[] / actions[] and of each trajectory row
+// (scalar row base + lane offset, so the row advance costs only SALU).  This is HBM-write-bound
+// integer work: no MFMA, and no inter-block reuse apart from the <=64 KiB record planes that
+// every XCD's L2 holds after first touch -- so there is nothing for an XCD-aware block remap to
+// win here; the grid is N/256 four-wave workgroups (at N = 65 536 that is one workgroup per CU,
+// one wave per SIMD; measured 3 % faster than 1024 one-wave workgroups, profiles/r01_tuning.md).
+//
+// The action -> delta LUT is four int16 lanes of one 64-bit scalar register (v_lshrrev_b64 +
+// v_bfe_i32): staging a 4-entry table in LDS instead would put a second, dependent ds_read on
+// every step for no gain.
 #include "gu_internal.hpp"
 #include "gu_rng.hpp"
 
@@ -26,25 +30,35 @@
 // ------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------
-// action -> state delta LUT (env:51-56): UP -W, RIGHT +1, DOWN +W, LEFT -1.  Kept in
-// registers as arithmetic on the two action bits; an LDS-resident 4-entry table would
-// put a second ds_read on every step for no gain.
-__device__ __forceinline__ int32_t gu_delta(uint32_t a, int32_t W)
+struct CellMap {
+    const uint8_t *f;  // flags plane
+    const int8_t *r;   // reward plane
+};
+
+template <bool LDS>
+__device__ __forceinline__ CellMap gu_stage_map(const uint8_t *__restrict__ g, int32_t cell_bytes, uint8_t *smem)
 {
-    const int32_t sign = (int32_t)(a & 2u) - 1;          // a=0,1 -> -1 ; a=2,3 -> +1
-    return (a & 1u) ? -sign : sign * W;                  // RIGHT(1): +1, LEFT(3): -1, UP(0): -W, DOWN(2): +W
+    if (LDS) {
+        for (int32_t i = threadIdx.x * 16; i < 2 * cell_bytes; i += blockDim.x * 16)
+            *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(g + i);
+        __syncthreads();
+        return CellMap{smem, reinterpret_cast<const int8_t *>(smem + cell_bytes)};
+    }
+    return CellMap{g, reinterpret_cast<const int8_t *>(g + cell_bytes)};
 }
 
-__device__ __forceinline__ int32_t gu_reward_of(uint32_t rec)
+// delta[a]: LUT = four int16 lanes {-W, +1, +W, -1}; ARITH = any W (grids too big for the LUT / LDS)
+template <bool LUT>
+__device__ __forceinline__ int32_t gu_delta(uint32_t a, uint64_t lut, int32_t W)
 {
-    return (rec & GU_CELL_RMINUS) ? -10 : ((rec & GU_CELL_RPLUS) ? 10 : -1);
+    if (LUT) return __builtin_amdgcn_sbfe((int32_t)(uint32_t)(lut >> (a << 4)), 0, 16);
+    const int32_t sign = (int32_t)(a & 2u) - 1;  // UP,RIGHT -> -1 ; DOWN,LEFT -> +1
+    return (a & 1u) ? -sign : sign * W;
 }
 
-// cooperative global -> LDS copy of `bytes16` (multiple of 16) bytes
-__device__ __forceinline__ void gu_stage(const uint8_t *__restrict__ src, uint8_t *dst, int32_t bytes16)
+__device__ __forceinline__ int32_t gu_move(int32_t s, uint32_t flags, uint32_t a, int32_t delta)
 {
-    for (int32_t i = threadIdx.x * 16; i < bytes16; i += blockDim.x * 16)
-        *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
+    return __mul24((int32_t)__builtin_amdgcn_ubfe(flags, a, 1), delta) + s;  // v_bfe_u32 + v_mad_i32_i24
 }
 
 // ------------------------------------------------------------------------------------
@@ -88,6 +102,7 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_reset_kernel(const ResetArgs a)
 struct StepArgs {
     const uint8_t *cell;
     int32_t cell_bytes, W;
+    uint64_t lut;
     const int32_t *actions;
     int32_t *pos, *reward, *done;
     uint32_t *episode;
@@ -101,12 +116,7 @@ template <bool LDS>
 __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint8_t *cell = a.cell;
-    if (LDS) {
-        gu_stage(a.cell, smem, a.cell_bytes);
-        __syncthreads();
-        cell = smem;
-    }
+    const CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem);
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.N) return;
     const uint32_t act = (uint32_t)a.actions[e] & 3u;
@@ -116,13 +126,10 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
         s = a.starts[gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, a.n_starts)];
         a.episode[e] = ep + 1;
     }
-    uint32_t rec = cell[s];
-    const bool blocked = (rec >> act) & 1u;
-    s = blocked ? s : s + gu_delta(act, a.W);
-    rec = cell[s];
+    s = gu_move(s, m.f[s], act, gu_delta<LDS>(act, a.lut, a.W));
     a.pos[e] = s;
-    a.reward[e] = gu_reward_of(rec);
-    a.done[e] = (rec & GU_CELL_TERM) ? 1 : 0;
+    a.reward[e] = m.r[s];
+    a.done[e] = (m.f[s] >> GU_CELL_TERM_BIT) & 1;
 }
 
 // ------------------------------------------------------------------------------------
@@ -134,6 +141,7 @@ struct RolloutArgs {
     const uint8_t *cell;
     const uint8_t *greedy;  // first-argmax action per state (GU_POLICY_GREEDY)
     int32_t cell_bytes, W;
+    uint64_t lut;
     int32_t *pos, *reward, *done;
     uint32_t *episode;
     const uint32_t *tcount;  // per-env offsets
@@ -143,76 +151,137 @@ struct RolloutArgs {
     int32_t *ret, *episodes_fin;
     uint32_t n_starts, seed_prefix, env_id0, steps_taken;
     int64_t N, T;
-    uint32_t flags;
 };
 
-template <int POLICY, bool TRAJ, bool LDS>
+// AUTO: 0 = no reset; 1 = auto-reset, single start cell (branch-free select);
+//       2 = auto-reset, several start cells (RNG stream 1, rare divergent branch)
+template <int POLICY, int AUTO, bool TRAJ, bool STATS, bool LDS>
 __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint8_t *cell = a.cell;
+    const CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem);
     const uint8_t *greedy = a.greedy;
-    if (LDS) {
-        gu_stage(a.cell, smem, a.cell_bytes);
-        if (POLICY == GU_POLICY_GREEDY) gu_stage(a.greedy, smem + a.cell_bytes, a.cell_bytes);
+    if (LDS && POLICY == GU_POLICY_GREEDY) {
+        uint8_t *dst = smem + 2 * a.cell_bytes;
+        for (int32_t i = threadIdx.x * 16; i < a.cell_bytes; i += blockDim.x * 16)
+            *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(a.greedy + i);
         __syncthreads();
-        cell = smem;
-        greedy = smem + a.cell_bytes;
+        greedy = dst;
     }
     const int64_t e64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e64 >= a.N) return;
     const uint32_t e = (uint32_t)e64;
-    const bool auto_reset = a.flags & GU_F_AUTO_RESET;
 
     int32_t s = a.pos[e];
     int32_t r = a.reward[e];
     uint32_t d = (uint32_t)a.done[e];
     uint32_t ep = a.episode[e];
-    uint32_t t = a.tcount[e] + a.steps_taken;
+    const uint32_t t_lane = a.tcount[e] + a.steps_taken;
     const uint32_t prefix = gu_rng_prefix(a.seed_prefix, a.env_id0 + e);
-    uint32_t rec = cell[s];
-    uint32_t word = 0;
-    if (POLICY == GU_POLICY_UNIFORM) word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+    uint32_t flags = m.f[s];
     int32_t ret = 0, fin = 0;
     const int32_t W = a.W;
+    const uint64_t lut = a.lut;
+    const int32_t start0 = a.starts[0];
+    const uint32_t start0_flags = m.f[start0];
+    // row pointers are wave-uniform (SGPR pairs); the lane adds its own 32-bit byte offset, which
+    // selects the scalar-base form of global_store/global_load (no per-lane 64-bit address math)
+    char *po = (char *)a.tr_obs, *pr = (char *)a.tr_reward, *pd = (char *)a.tr_done;
+    const char *pa = (const char *)a.actions;
+    const uint32_t e4 = e * 4u;
+    const int64_t row = a.N * 4;
 
-    for (int64_t i = 0; i < a.T; ++i) {
-        if (auto_reset && d) {  // lazy `if done: env.reset()` (env:187-193)
-            s = a.starts[gu_rng_start_index(prefix, ep, a.n_starts)];
-            ++ep;
-            rec = cell[s];
+    auto step = [&](uint32_t act) {
+        if (AUTO == 1) {  // lazy `if done: env.reset()` (env:187-193), single start: pure selects
+            s = d ? start0 : s;
+            flags = d ? start0_flags : flags;
+            ep += d;
+        } else if (AUTO == 2) {
+            if (d) {
+                s = a.starts[gu_rng_start_index(prefix, ep, a.n_starts)];
+                ++ep;
+                flags = m.f[s];
+            }
         }
-        uint32_t act;
-        if (POLICY == GU_POLICY_UNIFORM) {
-            act = (word >> (2u * (t & 15u))) & 3u;
-        } else if (POLICY == GU_POLICY_STREAM) {
-            act = (uint32_t)a.actions[i * a.N + e] & 3u;
-        } else {
-            act = greedy[s];
+        s = gu_move(s, flags, act, gu_delta<LDS>(act, lut, W));
+        flags = m.f[s];
+        r = m.r[s];
+        d = __builtin_amdgcn_ubfe(flags, GU_CELL_TERM_BIT, 1);
+        if (STATS) {
+            ret += r;
+            fin += (int32_t)d;
         }
-        const bool blocked = (rec >> act) & 1u;
-        s = blocked ? s : s + gu_delta(act, W);
-        rec = cell[s];
-        r = gu_reward_of(rec);
-        d = (rec >> 4) & 1u;
-        ret += r;
-        fin += (int32_t)d;
         if (TRAJ) {
-            const int64_t o = i * a.N + e;
-            a.tr_obs[o] = s;
-            a.tr_reward[o] = r;
-            a.tr_done[o] = (int32_t)d;
+            *(int32_t *)(po + e4) = s;
+            *(int32_t *)(pr + e4) = r;
+            *(int32_t *)(pd + e4) = (int32_t)d;
+            po += row;
+            pr += row;
+            pd += row;
         }
-        ++t;
-        if (POLICY == GU_POLICY_UNIFORM) {
-            if ((t & 15u) == 0u) word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+    };
+
+    if (POLICY == GU_POLICY_UNIFORM) {
+        // Fast path: every lane of the wave is at the same step count (always true unless
+        // gu_set_state installed per-env counters), so the 16-actions-per-word schedule is
+        // wave-uniform: constant bit-field offsets, one hash per 16 steps.
+        const uint32_t t_first = __builtin_amdgcn_readfirstlane(t_lane);
+        if (__all(t_lane == t_first)) {
+            uint32_t t = t_first;
+            int64_t i = 0;
+            if (t & 15u) {  // head: finish the current word
+                const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+                for (; i < a.T && (t & 15u); ++i, ++t) step((word >> (2u * (t & 15u))) & 3u);
+            }
+            for (; i + 16 <= a.T; i += 16, t += 16) {  // body: 16 steps per word, fully unrolled
+                const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2));
+            }
+            if (i < a.T) {  // tail
+                const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+                for (uint32_t j = 0; i < a.T; ++i, ++j) step((word >> (2u * j)) & 3u);
+            }
+        } else {
+            uint32_t t = t_lane;
+            uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+            for (int64_t i = 0; i < a.T; ++i) {
+                step((word >> (2u * (t & 15u))) & 3u);
+                ++t;
+                if ((t & 15u) == 0u) word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+            }
+        }
+    } else if (POLICY == GU_POLICY_STREAM) {
+#pragma unroll 4
+        for (int64_t i = 0; i < a.T; ++i) {
+            const uint32_t act = (uint32_t)(*(const int32_t *)(pa + e4)) & 3u;
+            pa += row;
+            step(act);
+        }
+    } else {
+        for (int64_t i = 0; i < a.T; ++i) {
+            // greedy[] must be read at the post-reset position
+            if (AUTO == 1) {
+                s = d ? start0 : s;
+                flags = d ? start0_flags : flags;
+                ep += d;
+                d = 0;
+            } else if (AUTO == 2) {
+                if (d) {
+                    s = a.starts[gu_rng_start_index(prefix, ep, a.n_starts)];
+                    ++ep;
+                    flags = m.f[s];
+                    d = 0;
+                }
+            }
+            step(greedy[s]);
         }
     }
     a.pos[e] = s;
     a.reward[e] = r;
     a.done[e] = (int32_t)d;
     a.episode[e] = ep;
-    if (a.flags & GU_F_STATS) {
+    if (STATS) {
         a.ret[e] = ret;
         a.episodes_fin[e] = fin;
     }
@@ -222,8 +291,9 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
 // look_step_ahead for n (state, action) pairs (env:136-155), both care_about_terminal modes
 // ------------------------------------------------------------------------------------
 struct LookArgs {
-    const uint8_t *cell_move;  // blocked bits: absorbing map (care=True) or raw map (care=False)
+    const uint8_t *cell_move;  // OPEN bits: absorbing map (care=True) or raw map (care=False)
     int32_t cell_bytes, W, S;
+    uint64_t lut;
     const int32_t *states, *actions;
     int32_t *next, *reward, *done;
     int64_t n;
@@ -233,23 +303,15 @@ template <bool LDS>
 __global__ void __launch_bounds__(GU_BLOCK) gu_lookahead_kernel(const LookArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint8_t *cell = a.cell_move;
-    if (LDS) {
-        gu_stage(a.cell_move, smem, a.cell_bytes);
-        __syncthreads();
-        cell = smem;
-    }
+    const CellMap m = gu_stage_map<LDS>(a.cell_move, a.cell_bytes, smem);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     int32_t s = a.states[i];
     const uint32_t act = (uint32_t)a.actions[i] & 3u;
-    uint32_t rec = cell[s];
-    const bool blocked = (rec >> act) & 1u;
-    s = blocked ? s : s + gu_delta(act, a.W);
-    rec = cell[s];  // reward / terminal bits are identical in both maps
+    s = gu_move(s, m.f[s], act, gu_delta<LDS>(act, a.lut, a.W));
     a.next[i] = s;
-    a.reward[i] = gu_reward_of(rec);
-    a.done[i] = (rec & GU_CELL_TERM) ? 1 : 0;
+    a.reward[i] = m.r[s];  // reward / terminal bits are identical in both maps
+    a.done[i] = (m.f[s] >> GU_CELL_TERM_BIT) & 1;
 }
 
 // ------------------------------------------------------------------------------------
@@ -306,8 +368,8 @@ static int gu_rollout_block()
     static int cached = 0;
     if (!cached) {
         const char *s = std::getenv("GU_ROLLOUT_BLOCK");
-        int v = s ? std::atoi(s) : 64;
-        cached = (v == 64 || v == 128 || v == 256) ? v : 64;
+        int v = s ? std::atoi(s) : 256;
+        cached = (v == 64 || v == 128 || v == 256) ? v : 256;
     }
     return cached;
 }
@@ -323,11 +385,11 @@ int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice
 
 int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags)
 {
-    StepArgs a{h->d_cell, h->cell_bytes, h->W, d_actions_row, h->pos(), h->reward(), h->done(), h->d_episode,
-               h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags};
+    StepArgs a{h->d_cell, h->cell_bytes, h->W, h->delta_lut, d_actions_row, h->pos(), h->reward(), h->done(),
+               h->d_episode, h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags};
     const dim3 grid(gu_blocks(h->N, GU_BLOCK)), block(GU_BLOCK);
     if (h->S <= GU_MAX_LDS_CELLS)
-        hipLaunchKernelGGL(gu_step_kernel<true>, grid, block, (size_t)h->cell_bytes, h->stream, a);
+        hipLaunchKernelGGL(gu_step_kernel<true>, grid, block, 2 * (size_t)h->cell_bytes, h->stream, a);
     else
         hipLaunchKernelGGL(gu_step_kernel<false>, grid, block, 0, h->stream, a);
     GU_HIP(hipGetLastError());
@@ -335,30 +397,51 @@ int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags)
     return GU_OK;
 }
 
-template <int POLICY>
-static void gu_rollout_dispatch(gu_engine *h, const RolloutArgs &a, bool traj, int bs)
+template <int POLICY, int AUTO, bool TRAJ, bool STATS>
+static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
 {
     const dim3 grid(gu_blocks(h->N, bs)), block(bs);
-    const bool lds = h->S <= GU_MAX_LDS_CELLS / (POLICY == GU_POLICY_GREEDY ? 2 : 1);
-    const size_t smem = lds ? (size_t)h->cell_bytes * (POLICY == GU_POLICY_GREEDY ? 2 : 1) : 0;
+    const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
+    const bool lds = h->S <= GU_MAX_LDS_CELLS && (size_t)planes * h->cell_bytes <= 65536;
+    if (lds)
+        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, true>), grid, block, (size_t)planes * h->cell_bytes, h->stream, a);
+    else
+        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, false>), grid, block, 0, h->stream, a);
+}
+
+template <int POLICY, int AUTO>
+static void gu_rollout_dispatch2(gu_engine *h, const RolloutArgs &a, bool traj, bool stats, int bs)
+{
     if (traj) {
-        if (lds) hipLaunchKernelGGL((gu_rollout_kernel<POLICY, true, true>), grid, block, smem, h->stream, a);
-        else hipLaunchKernelGGL((gu_rollout_kernel<POLICY, true, false>), grid, block, 0, h->stream, a);
+        if (stats) gu_rollout_launch<POLICY, AUTO, true, true>(h, a, bs);
+        else gu_rollout_launch<POLICY, AUTO, true, false>(h, a, bs);
     } else {
-        if (lds) hipLaunchKernelGGL((gu_rollout_kernel<POLICY, false, true>), grid, block, smem, h->stream, a);
-        else hipLaunchKernelGGL((gu_rollout_kernel<POLICY, false, false>), grid, block, 0, h->stream, a);
+        if (stats) gu_rollout_launch<POLICY, AUTO, false, true>(h, a, bs);
+        else gu_rollout_launch<POLICY, AUTO, false, false>(h, a, bs);
+    }
+}
+
+template <int POLICY>
+static void gu_rollout_dispatch(gu_engine *h, const RolloutArgs &a, int auto_mode, bool traj, bool stats, int bs)
+{
+    switch (auto_mode) {
+    case 0: gu_rollout_dispatch2<POLICY, 0>(h, a, traj, stats, bs); break;
+    case 1: gu_rollout_dispatch2<POLICY, 1>(h, a, traj, stats, bs); break;
+    default: gu_rollout_dispatch2<POLICY, 2>(h, a, traj, stats, bs); break;
     }
 }
 
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
 {
-    const bool traj = flags & GU_F_TRAJECTORY;
+    const bool traj = flags & GU_F_TRAJECTORY, stats = flags & GU_F_STATS;
+    const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->n_starts == 1 ? 1 : 2) : 0;
     const int64_t rows = traj ? h->traj_T * h->N : 0;
     RolloutArgs a{};
     a.cell = h->d_cell;
     a.greedy = h->d_greedy;
     a.cell_bytes = h->cell_bytes;
     a.W = h->W;
+    a.lut = h->delta_lut;
     a.pos = h->pos();
     a.reward = h->reward();
     a.done = h->done();
@@ -377,12 +460,11 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.steps_taken = h->steps_taken;
     a.N = h->N;
     a.T = T;
-    a.flags = flags;
     const int bs = gu_rollout_block();
     switch (policy) {
-    case GU_POLICY_UNIFORM: gu_rollout_dispatch<GU_POLICY_UNIFORM>(h, a, traj, bs); break;
-    case GU_POLICY_STREAM: gu_rollout_dispatch<GU_POLICY_STREAM>(h, a, traj, bs); break;
-    case GU_POLICY_GREEDY: gu_rollout_dispatch<GU_POLICY_GREEDY>(h, a, traj, bs); break;
+    case GU_POLICY_UNIFORM: gu_rollout_dispatch<GU_POLICY_UNIFORM>(h, a, auto_mode, traj, stats, bs); break;
+    case GU_POLICY_STREAM: gu_rollout_dispatch<GU_POLICY_STREAM>(h, a, auto_mode, traj, stats, bs); break;
+    case GU_POLICY_GREEDY: gu_rollout_dispatch<GU_POLICY_GREEDY>(h, a, auto_mode, traj, stats, bs); break;
     default: return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
     }
     GU_HIP(hipGetLastError());
@@ -393,10 +475,11 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
 int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const int32_t *d_actions, bool care,
                         int32_t *d_next, int32_t *d_reward, int32_t *d_done)
 {
-    LookArgs a{care ? h->d_cell : h->d_cell_raw, h->cell_bytes, h->W, h->S, d_states, d_actions, d_next, d_reward, d_done, n};
+    LookArgs a{care ? h->d_cell : h->d_cell_raw, h->cell_bytes, h->W, h->S, h->delta_lut, d_states, d_actions,
+               d_next, d_reward, d_done, n};
     const dim3 grid(gu_blocks(n, GU_BLOCK)), block(GU_BLOCK);
     if (h->S <= GU_MAX_LDS_CELLS)
-        hipLaunchKernelGGL(gu_lookahead_kernel<true>, grid, block, (size_t)h->cell_bytes, h->stream, a);
+        hipLaunchKernelGGL(gu_lookahead_kernel<true>, grid, block, 2 * (size_t)h->cell_bytes, h->stream, a);
     else
         hipLaunchKernelGGL(gu_lookahead_kernel<false>, grid, block, 0, h->stream, a);
     GU_HIP(hipGetLastError());

@@ -23,31 +23,33 @@
 
 #define VI_BLOCK 256
 
+struct ViMap {
+    const uint8_t *f;  // flags plane (OPEN bits 0..3, TERM bit 4)
+    const int8_t *r;   // reward plane
+};
+
 __device__ __forceinline__ int32_t vi_delta(uint32_t a, int32_t W)
 {
     const int32_t sign = (int32_t)(a & 2u) - 1;
     return (a & 1u) ? -sign : sign * W;
 }
 
-__device__ __forceinline__ double vi_reward(uint32_t rec)
-{
-    return (rec & GU_CELL_RMINUS) ? -10.0 : ((rec & GU_CELL_RPLUS) ? 10.0 : -1.0);
-}
+__device__ __forceinline__ double vi_reward(const ViMap &m, int32_t s) { return (double)m.r[s]; }
 
-__device__ __forceinline__ int32_t vi_next(const uint8_t *cell, int32_t s, uint32_t rec, uint32_t a, int32_t W)
+__device__ __forceinline__ int32_t vi_next(int32_t s, uint32_t flags, uint32_t a, int32_t W)
 {
-    return ((rec >> a) & 1u) ? s : s + vi_delta(a, W);
+    return ((flags >> a) & 1u) ? s + vi_delta(a, W) : s;
 }
 
 // V1 for one state
-__device__ __forceinline__ double vi_eval_state(const uint8_t *cell, int32_t W, double gamma, const double *__restrict__ v,
+__device__ __forceinline__ double vi_eval_state(const ViMap &cell, int32_t W, double gamma, const double *__restrict__ v,
                                                 const double *__restrict__ pi, int32_t s)
 {
-    const uint32_t rec = cell[s];
-    double acc = __dadd_rn(0.0, vi_reward(rec));
+    const uint32_t rec = cell.f[s];
+    double acc = __dadd_rn(0.0, vi_reward(cell, s));
 #pragma unroll
     for (uint32_t a = 0; a < 4; ++a) {
-        const int32_t n = vi_next(cell, s, rec, a, W);
+        const int32_t n = vi_next(s, rec, a, W);
         acc = __dadd_rn(acc, __dmul_rn(pi[4 * s + a], __dmul_rn(gamma, v[n])));
     }
     return acc;
@@ -60,14 +62,14 @@ __device__ __forceinline__ double vi_around8(double x)
 
 // V2 for one state given a functor returning v'(n)
 template <typename VNew>
-__device__ __forceinline__ void vi_greedy_state(const uint8_t *cell, int32_t W, double gamma, VNew vnew, int32_t s, double out[4])
+__device__ __forceinline__ void vi_greedy_state(const ViMap &cell, int32_t W, double gamma, VNew vnew, int32_t s, double out[4])
 {
-    const uint32_t rec = cell[s];
+    const uint32_t rec = cell.f[s];
     double q[4];
 #pragma unroll
     for (uint32_t a = 0; a < 4; ++a) {
-        const int32_t n = vi_next(cell, s, rec, a, W);
-        const double rn = vi_reward(cell[n]);
+        const int32_t n = vi_next(s, rec, a, W);
+        const double rn = vi_reward(cell, n);
         q[a] = __dadd_rn(0.0, __dadd_rn(rn, __dmul_rn(gamma, vnew(n))));
     }
     double qmax = q[0];
@@ -110,10 +112,16 @@ __device__ __forceinline__ void vi_block_max_to_global(double mine, bool valid, 
     }
 }
 
-__device__ __forceinline__ void vi_stage(const uint8_t *__restrict__ src, uint8_t *dst, int32_t bytes16)
+template <bool LDS>
+__device__ __forceinline__ ViMap vi_stage(const uint8_t *__restrict__ g, int32_t cell_bytes, uint8_t *smem)
 {
-    for (int32_t i = threadIdx.x * 16; i < bytes16; i += blockDim.x * 16)
-        *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
+    if (LDS) {
+        for (int32_t i = threadIdx.x * 16; i < 2 * cell_bytes; i += blockDim.x * 16)
+            *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(g + i);
+        __syncthreads();
+        return ViMap{smem, reinterpret_cast<const int8_t *>(smem + cell_bytes)};
+    }
+    return ViMap{g, reinterpret_cast<const int8_t *>(g + cell_bytes)};
 }
 
 struct ViArgs {
@@ -129,12 +137,7 @@ template <bool LDS>
 __global__ void __launch_bounds__(VI_BLOCK) gu_vi_eval_kernel(const ViArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint8_t *cell = a.cell;
-    if (LDS) {
-        vi_stage(a.cell, smem, a.cell_bytes);
-        __syncthreads();
-        cell = smem;
-    }
+    const ViMap cell = vi_stage<LDS>(a.cell, a.cell_bytes, smem);
     const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = s < a.S;
     double d = 0.0;
@@ -150,12 +153,7 @@ template <bool LDS>
 __global__ void __launch_bounds__(VI_BLOCK) gu_vi_greedy_kernel(const ViArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint8_t *cell = a.cell;
-    if (LDS) {
-        vi_stage(a.cell, smem, a.cell_bytes);
-        __syncthreads();
-        cell = smem;
-    }
+    const ViMap cell = vi_stage<LDS>(a.cell, a.cell_bytes, smem);
     const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= a.S) return;
     double row[4];
@@ -193,12 +191,7 @@ template <bool LDS>
 __global__ void __launch_bounds__(VI_BLOCK) gu_vi_sweep_step_kernel(const ViStepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint8_t *cell = a.vi.cell;
-    if (LDS) {
-        vi_stage(a.vi.cell, smem, a.vi.cell_bytes);
-        __syncthreads();
-        cell = smem;
-    }
+    const ViMap cell = vi_stage<LDS>(a.vi.cell, a.vi.cell_bytes, smem);
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int32_t W = a.vi.W;
     const double gamma = a.vi.gamma;
@@ -234,12 +227,10 @@ __global__ void __launch_bounds__(VI_BLOCK) gu_vi_sweep_step_kernel(const ViStep
 #pragma unroll
     for (uint32_t k = 1; k < 4; ++k)
         if (row[k] > m) { m = row[k]; act = k; }
-    uint32_t rec = cell[s];
-    s = vi_next(cell, s, rec, act, W);
-    rec = cell[s];
+    s = vi_next(s, cell.f[s], act, W);
     a.pos[gid] = s;
-    a.reward[gid] = (rec & GU_CELL_RMINUS) ? -10 : ((rec & GU_CELL_RPLUS) ? 10 : -1);
-    a.done[gid] = (rec & GU_CELL_TERM) ? 1 : 0;
+    a.reward[gid] = cell.r[s];
+    a.done[gid] = (cell.f[s] >> GU_CELL_TERM_BIT) & 1;
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -340,7 +331,7 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
     GU_HIP(hipMemsetAsync(h->d_delta, 0, (size_t)iters * sizeof(unsigned long long), h->stream));
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
-    const size_t smem = lds ? (size_t)h->cell_bytes : 0;
+    const size_t smem = lds ? 2 * (size_t)h->cell_bytes : 0;
     for (int32_t i = 0; i < iters; ++i) {
         ViArgs a = vi_args(h, gamma, (unsigned long long *)h->d_delta + i);
         if (lds) hipLaunchKernelGGL(gu_vi_eval_kernel<true>, grid, block, smem, h->stream, a);
@@ -376,7 +367,7 @@ int gu_vi_greedy(gu_handle h, double gamma)
     a.v_new = h->d_v[h->vi_cur];  // V2 reads the CURRENT value table ...
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     if (h->S <= GU_MAX_LDS_CELLS)
-        hipLaunchKernelGGL(gu_vi_greedy_kernel<true>, grid, block, (size_t)h->cell_bytes, h->stream, a);
+        hipLaunchKernelGGL(gu_vi_greedy_kernel<true>, grid, block, 2 * (size_t)h->cell_bytes, h->stream, a);
     else
         hipLaunchKernelGGL(gu_vi_greedy_kernel<false>, grid, block, 0, h->stream, a);
     GU_HIP(hipGetLastError());
@@ -409,7 +400,7 @@ int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta)
     const int64_t threads = h->N > h->S ? h->N : h->S;
     const dim3 grid(vi_blocks(threads)), block(VI_BLOCK);
     if (h->S <= GU_MAX_LDS_CELLS)
-        hipLaunchKernelGGL(gu_vi_sweep_step_kernel<true>, grid, block, (size_t)h->cell_bytes, h->stream, a);
+        hipLaunchKernelGGL(gu_vi_sweep_step_kernel<true>, grid, block, 2 * (size_t)h->cell_bytes, h->stream, a);
     else
         hipLaunchKernelGGL(gu_vi_sweep_step_kernel<false>, grid, block, 0, h->stream, a);
     GU_HIP(hipGetLastError());

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <vector>
 
+typedef int v4i __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 template <bool NT>
@@ -39,7 +40,8 @@ __global__ void k_x4(int* __restrict__ a, int* __restrict__ b, int* __restrict__
         const size_t o = (size_t)(t + j) * N + e0;  // lane j of each quad writes row t+j, 4 envs wide
         int4 w = make_int4(v.x >> 3, v.y >> 3, v.z >> 3, v.w >> 3), u = make_int4(v.x & 1, v.y & 1, v.z & 1, v.w & 1);
         if (NT) {
-            __builtin_nontemporal_store(v, (int4*)(a + o)); __builtin_nontemporal_store(w, (int4*)(b + o)); __builtin_nontemporal_store(u, (int4*)(c + o));
+            v4i nv = {v.x, v.y, v.z, v.w}, nw = {w.x, w.y, w.z, w.w}, nu = {u.x, u.y, u.z, u.w};
+            __builtin_nontemporal_store(nv, (v4i*)(a + o)); __builtin_nontemporal_store(nw, (v4i*)(b + o)); __builtin_nontemporal_store(nu, (v4i*)(c + o));
         } else { *(int4*)(a + o) = v; *(int4*)(b + o) = w; *(int4*)(c + o) = u; }
     }
 }

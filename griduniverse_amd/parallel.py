@@ -1,0 +1,114 @@
+"""Batch sharding over several MI355X: one process per GPU, no data-path collective.
+
+The reference is single-process; env instances never read each other
+(core/envs/griduniverse_env.py:136-193), so a batch of `total_envs` splits into contiguous
+env-index blocks, rank g owning envs [g*n, (g+1)*n).  The grid is replicated, per-env RNG
+streams are keyed by GLOBAL env id, hence the union of the shards is byte-identical to the
+single-device batch and stepping needs no communication at all.
+
+The one exchange is optional: `gathered_view()` returns the single-array (obs, reward, done)
+of ALL envs on every rank -- one RCCL all-gather of each rank's packed int32[3n] block over
+xGMI (csrc/gu_comm.hip).  RCCL's 128-byte unique id travels from rank 0 to the others over
+whatever host channel the launcher already has; by default an initialised
+`torch.distributed` process group (any backend -- gloo is fine, it is only plumbing).
+"""
+import os
+
+import numpy as np
+
+from .vec_env import VecGridUniverse
+
+
+def shard_range(total_envs, world_size, rank):
+    """(first global env id, number of envs) of `rank`.  Equal blocks; `total_envs` must divide."""
+    total_envs, world_size, rank = int(total_envs), int(world_size), int(rank)
+    if world_size <= 0 or not 0 <= rank < world_size:
+        raise ValueError('bad rank {} of {}'.format(rank, world_size))
+    if total_envs <= 0 or total_envs % world_size:
+        raise ValueError('total_envs={} must be a positive multiple of world_size={} (the gathered view '
+                         'all-gathers equal blocks)'.format(total_envs, world_size))
+    per = total_envs // world_size
+    return rank * per, per
+
+
+def env_launch_info():
+    """(rank, local_rank, world_size) from the torchrun-style environment."""
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
+            int(os.environ.get('WORLD_SIZE', '1')))
+
+
+def torch_broadcast_bytes(payload, src=0):
+    """Broadcast a fixed-size byte string from `src` over the default torch.distributed group."""
+    import torch
+    import torch.distributed as dist
+    buf = torch.zeros(len(payload), dtype=torch.uint8)
+    if dist.get_rank() == src:
+        buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+    dist.broadcast(buf, src=src)
+    return bytes(buf.numpy().tobytes())
+
+
+def unpack_view(blocks, n):
+    """[world][3n] packed (obs|reward|done) blocks -> three env-major arrays of world*n."""
+    blocks = np.asarray(blocks, dtype=np.int32).reshape(-1, 3, n)
+    return tuple(np.ascontiguousarray(blocks[:, k, :]).reshape(-1) for k in range(3))
+
+
+class ShardedVecGridUniverse(object):
+    """This rank's shard of a `total_envs` batch, plus the gathered view.
+
+    Grid kwargs are those of `GridUniverseEnv` / `VecGridUniverse`.  NOTE for `random_maze=True`:
+    every rank must build the SAME grid, so seed both global RNGs identically on all ranks before
+    constructing (random.seed(k); np.random.seed(k)), exactly as for the reference.
+    """
+
+    def __init__(self, total_envs, *, rank=None, world_size=None, device=None, seed=0, auto_reset=False,
+                 broadcast_bytes=torch_broadcast_bytes, engine_factory=None, **grid_kwargs):
+        env_rank, env_local, env_world = env_launch_info()
+        self.rank = env_rank if rank is None else int(rank)
+        self.world_size = env_world if world_size is None else int(world_size)
+        self.total_envs = int(total_envs)
+        self.env_id0, self.num_envs = shard_range(total_envs, self.world_size, self.rank)
+        kw = dict(grid_kwargs)
+        if engine_factory is not None:
+            kw['engine_factory'] = engine_factory
+        self.local = VecGridUniverse(self.num_envs, seed=seed, device=env_local if device is None else device,
+                                     env_id0=self.env_id0, auto_reset=auto_reset, **kw)
+        self._broadcast = broadcast_bytes
+        self._comm_ready = False
+
+    # local shard: no communication ------------------------------------------------------
+    def reset(self, mask=None, start_choice=None):
+        return self.local.reset(mask, start_choice)
+
+    def step(self, actions):
+        return self.local.step(actions)
+
+    def rollout(self, T, **kw):
+        return self.local.rollout(T, **kw)
+
+    def global_ids(self):
+        return np.arange(self.env_id0, self.env_id0 + self.num_envs, dtype=np.int64)
+
+    # the single-array view: one all-gather -----------------------------------------------
+    def _ensure_comm(self):
+        if self._comm_ready:
+            return
+        eng = self.local.engine
+        uid = eng.comm_unique_id() if self.rank == 0 else bytes(128)
+        if self.world_size > 1:
+            uid = self._broadcast(uid, 0)
+        eng.comm_init(self.world_size, self.rank, uid)
+        self._comm_ready = True
+
+    def gathered_view(self):
+        """(obs, reward, done) of all `total_envs` envs, env-major, identical on every rank."""
+        self._ensure_comm()
+        obs, reward, done = self.local.engine.allgather_view()
+        return obs, reward, done.astype(bool)
+
+    def close(self):
+        if self._comm_ready:
+            self.local.engine.comm_destroy()
+            self._comm_ready = False
+        self.local.close()

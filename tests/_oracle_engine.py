@@ -1,0 +1,76 @@
+"""Oracle-backed stand-in for griduniverse_amd.engine.Engine, for CPU-only tests of the multi-process
+host logic (shard plan, unique-id plumbing, gathered-view layout).  TEST CODE: it lives in tests/ and is
+injected through the `engine_factory` hook; the product never constructs it."""
+import os
+
+import numpy as np
+
+from griduniverse_amd.parallel import unpack_view
+from oracle import c_oracle as C
+
+
+class OracleEngine(object):
+    def __init__(self, num_envs, spec, device=0, env_id0=0, seed=0):
+        self.N, self.env_id0, self.spec, self.seed_value = int(num_envs), int(env_id0), spec, int(seed)
+        self.grid = C.Grid(spec.W, spec.H, spec.wall, spec.lava, spec.goal, spec.reward, spec.starts)
+        self.state = C.State(self.N, self.env_id0)
+        self.state.pos[:] = spec.starts[0]
+        self.last_reward = np.zeros(self.N, np.int32)
+        self.traj = None
+        self.uid = None
+
+    def seed(self, seed):
+        self.seed_value = int(seed)
+        self.state.episode[:] = 0
+        self.state.tcount[:] = 0
+
+    def reset(self, mask=None, start_choice=None):
+        assert start_choice is None
+        return C.reset(self.grid, self.seed_value, self.state, mask)
+
+    def step(self, actions, auto_reset=False):
+        out = C.rollout(self.grid, self.seed_value, self.state, 1, auto_reset, np.asarray(actions, np.int32)[None, :])
+        self.last_reward = out['reward'][0].copy()
+        return out['obs'][0], out['reward'][0], out['done'][0]
+
+    def reserve_trajectory(self, T):
+        pass
+
+    def rollout(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
+        assert policy == 'uniform'
+        self.traj = C.rollout(self.grid, self.seed_value, self.state, T, auto_reset, stats=stats)
+        self.last_reward = self.traj['reward'][-1].copy()
+
+    def read_trajectory(self, t0, T):
+        return {k: self.traj[k][t0:t0 + T] for k in ('obs', 'reward', 'done')}
+
+    def read_outputs(self):
+        return self.state.pos.copy(), self.last_reward.copy(), self.state.done.copy()
+
+    # ---- the gathered view over gloo instead of RCCL (same packed layout as csrc/gu_comm.hip)
+    @staticmethod
+    def comm_unique_id():
+        return os.urandom(128)
+
+    def comm_init(self, nranks, rank, unique_id):
+        import torch
+        import torch.distributed as dist
+        self.nranks, self.rank, self.uid = nranks, rank, bytes(unique_id)
+        mine = torch.frombuffer(bytearray(self.uid), dtype=torch.uint8).clone()
+        everyone = [torch.zeros_like(mine) for _ in range(nranks)]
+        dist.all_gather(everyone, mine)
+        assert all(bytes(t.numpy().tobytes()) == self.uid for t in everyone), 'ranks disagree on the unique id'
+
+    def allgather_view(self):
+        import torch
+        import torch.distributed as dist
+        block = torch.from_numpy(np.concatenate(self.read_outputs()).astype(np.int32))
+        blocks = [torch.zeros_like(block) for _ in range(self.nranks)]
+        dist.all_gather(blocks, block)
+        return unpack_view(np.stack([b.numpy() for b in blocks]), self.N)
+
+    def comm_destroy(self):
+        self.uid = None
+
+    def close(self):
+        pass

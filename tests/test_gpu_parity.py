@@ -394,3 +394,22 @@ def test_vec_env_surface():
     out = env.rollout(8, actions=np.ones((8, 256), np.int32))
     assert out['obs'].shape == (8, 256)
     env.close()
+
+
+# ------------------------------------------------------------------------------- RCCL gathered view
+def test_rccl_gathered_view_single_rank():
+    """ncclAllGather path of csrc/gu_comm.hip with a 1-rank communicator (the GPU box has one device;
+    the 2-rank layout logic is covered on CPU by tests/test_multiprocess.py)."""
+    from griduniverse_amd.parallel import ShardedVecGridUniverse
+    env = ShardedVecGridUniverse(4096, rank=0, world_size=1, seed=5, auto_reset=True, grid_shape=(32, 32),
+                                 lava_states=[16 + 32 * r for r in range(24)])
+    env.reset()
+    env.rollout(100, trajectory=False)
+    obs, rew, don = env.gathered_view()
+    own = env.local.engine.read_outputs()
+    assert obs.shape == (4096,) and np.array_equal(obs, own[0]) and np.array_equal(rew, own[1])
+    assert don.dtype == bool and np.array_equal(don, own[2].astype(bool))
+    env.step(np.zeros(4096, np.int32))
+    obs2, _, _ = env.gathered_view()  # communicator is reused
+    assert np.array_equal(obs2, env.local.engine.read_outputs()[0])
+    env.close()

@@ -1,0 +1,48 @@
+"""N > 1 path on CPU: two processes, gloo, launched the way the driver launches bench.py
+(python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 ...)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from griduniverse_amd.parallel import shard_range, unpack_view
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range():
+    assert [shard_range(262144, 8, g) for g in (0, 1, 7)] == [(0, 32768), (32768, 32768), (229376, 32768)]
+    assert shard_range(10, 1, 0) == (0, 10)
+    for bad in ((10, 3, 0), (0, 1, 0), (8, 2, 2), (8, 0, 0), (8, 2, -1)):
+        with pytest.raises(ValueError):
+            shard_range(*bad)
+
+
+def test_unpack_view_layout():
+    n, world = 5, 3
+    blocks = np.arange(world * 3 * n, dtype=np.int32).reshape(world, 3 * n)
+    obs, rew, don = unpack_view(blocks, n)
+    for r in range(world):
+        assert np.array_equal(obs[r * n:(r + 1) * n], blocks[r, :n])
+        assert np.array_equal(rew[r * n:(r + 1) * n], blocks[r, n:2 * n])
+        assert np.array_equal(don[r * n:(r + 1) * n], blocks[r, 2 * n:])
+
+
+def test_two_rank_gloo_shards_and_gathered_view(tmp_path):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tests', '_dist_worker.py'), str(tmp_path)]
+    proc = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert proc.returncode == 0, proc.stdout.decode()[-3000:]
+    results = [json.load(open(os.path.join(str(tmp_path), 'rank%d.json' % r))) for r in range(2)]
+    assert [r['ids'] for r in results] == [[0, 2047], [2048, 4095]]
+    for r in results:
+        assert r['world'] == 2 and r['ok_shard'] and r['ok_view'] and r['ok_max'], r

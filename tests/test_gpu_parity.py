@@ -413,3 +413,30 @@ def test_rccl_gathered_view_single_rank():
     obs2, _, _ = env.gathered_view()  # communicator is reused
     assert np.array_equal(obs2, env.local.engine.read_outputs()[0])
     env.close()
+
+
+def test_integration_md_ctypes_stub_runs():
+    """The reference-side ctypes binding shown in INTEGRATION.md section 2, executed verbatim against an object
+    with the reference env's attributes, equals the oracle."""
+    import os
+    import re
+    from griduniverse_amd import _lib
+    from oracle.ref_env import OracleGridUniverseEnv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    code = re.search(r'```python\n(# core/envs/griduniverse_gpu\.py.*?)```', text, re.S).group(1)
+    ns = {}
+    exec(code.replace("C.CDLL('libgu.so')", "C.CDLL(%r)" % _lib.LIB_PATH), ns)
+    env = OracleGridUniverseEnv(custom_world_fp=G.level_path('test_env.txt'))
+    batched = ns['BatchedGridUniverse'](env, 500, seed=9, first_global_env=100)
+    grid = C.Grid.from_env(env)
+    st = C.State(500, 100)
+    assert np.array_equal(batched.reset(), C.reset(grid, 9, st))
+    acts = (np.arange(500) % 4).astype(np.int32)
+    o, r, d, _ = batched.step(acts, auto_reset=True)
+    w = C.rollout(grid, 9, st, 1, True, actions=acts[None, :])
+    assert np.array_equal(o, w['obs'][0]) and np.array_equal(r, w['reward'][0]) and np.array_equal(d, w['done'][0].astype(bool))
+    obs, rew, done = batched.rollout(64)
+    want = C.rollout(grid, 9, st, 64, True)
+    assert np.array_equal(obs, want['obs']) and np.array_equal(rew, want['reward']) and np.array_equal(done, want['done'])
+    batched.close()

@@ -88,7 +88,7 @@ int gu_create(int device_id, int64_t num_envs, int64_t env_id0, gu_handle *out)
 {
     GU_REQUIRE(out != nullptr, GU_ERR_INVALID, "out handle is NULL");
     *out = nullptr;
-    GU_REQUIRE(num_envs > 0 && num_envs <= 0x7FFFFFFF, GU_ERR_INVALID, "num_envs %lld out of range", (long long)num_envs);
+    GU_REQUIRE(num_envs > 0 && num_envs <= (1 << 26), GU_ERR_INVALID, "num_envs %lld out of range (1 .. 2^26 per device)", (long long)num_envs);
     GU_REQUIRE(env_id0 >= 0 && env_id0 + num_envs <= 0xFFFFFFFFLL, GU_ERR_INVALID, "global env ids must fit 32 bits");
     int n_dev = 0;
     GU_HIP(hipGetDeviceCount(&n_dev));

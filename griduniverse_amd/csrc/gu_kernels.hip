@@ -184,14 +184,28 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
     const uint64_t lut = a.lut;
     const int32_t start0 = a.starts[0];
     const uint32_t start0_flags = m.f[start0];
-    // row pointers are wave-uniform (SGPR pairs); the lane adds its own 32-bit byte offset, which
-    // selects the scalar-base form of global_store/global_load (no per-lane 64-bit address math)
+    // Trajectory rows are addressed as buffer resource (wave-uniform base, rebuilt per 16-step chunk)
+    // + lane byte offset e4 (VGPR) + scalar row offset (SGPR): buffer_store_dword ... offen, so that
+    // advancing a row costs SALU only and no per-lane 64-bit address arithmetic.
     char *po = (char *)a.tr_obs, *pr = (char *)a.tr_reward, *pd = (char *)a.tr_done;
     const char *pa = (const char *)a.actions;
     const uint32_t e4 = e * 4u;
     const int64_t row = a.N * 4;
+    const uint32_t row32 = (uint32_t)row;  // gu_create caps N so that 16 rows fit 32 bits
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0x7FFFFFFF, 0x00020000);
+    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0x7FFFFFFF, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0x7FFFFFFF, 0x00020000);
+    auto rebase = [&](int64_t rows) {
+        po += rows * row;
+        pr += rows * row;
+        pd += rows * row;
+        ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0x7FFFFFFF, 0x00020000);
+        rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0x7FFFFFFF, 0x00020000);
+        rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0x7FFFFFFF, 0x00020000);
+    };
 
-    auto step = [&](uint32_t act) {
+    // `soff`: wave-uniform byte offset of this step's row from the resource base
+    auto step = [&](uint32_t act, uint32_t soff) {
         if (AUTO == 1) {  // lazy `if done: env.reset()` (env:187-193), single start: pure selects
             s = d ? start0 : s;
             flags = d ? start0_flags : flags;
@@ -212,13 +226,14 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
             fin += (int32_t)d;
         }
         if (TRAJ) {
-            *(int32_t *)(po + e4) = s;
-            *(int32_t *)(pr + e4) = r;
-            *(int32_t *)(pd + e4) = (int32_t)d;
-            po += row;
-            pr += row;
-            pd += row;
+            __builtin_amdgcn_raw_buffer_store_b32(s, ro, e4, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(r, rr, e4, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((int32_t)d, rd, e4, soff, 0);
         }
+    };
+    auto step1 = [&](uint32_t act) {  // one step, then advance the resource base by one row
+        step(act, 0);
+        if (TRAJ) rebase(1);
     };
 
     if (POLICY == GU_POLICY_UNIFORM) {
@@ -231,22 +246,23 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
             int64_t i = 0;
             if (t & 15u) {  // head: finish the current word
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
-                for (; i < a.T && (t & 15u); ++i, ++t) step((word >> (2u * (t & 15u))) & 3u);
+                for (; i < a.T && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
             }
             for (; i + 16 <= a.T; i += 16, t += 16) {  // body: 16 steps per word, fully unrolled
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2));
+                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                if (TRAJ) rebase(16);
             }
             if (i < a.T) {  // tail
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
-                for (uint32_t j = 0; i < a.T; ++i, ++j) step((word >> (2u * j)) & 3u);
+                for (uint32_t j = 0; i < a.T; ++i, ++j) step1((word >> (2u * j)) & 3u);
             }
         } else {
             uint32_t t = t_lane;
             uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
             for (int64_t i = 0; i < a.T; ++i) {
-                step((word >> (2u * (t & 15u))) & 3u);
+                step1((word >> (2u * (t & 15u))) & 3u);
                 ++t;
                 if ((t & 15u) == 0u) word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
             }
@@ -256,7 +272,7 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
         for (int64_t i = 0; i < a.T; ++i) {
             const uint32_t act = (uint32_t)(*(const int32_t *)(pa + e4)) & 3u;
             pa += row;
-            step(act);
+            step1(act);
         }
     } else {
         for (int64_t i = 0; i < a.T; ++i) {
@@ -274,7 +290,7 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
                     d = 0;
                 }
             }
-            step(greedy[s]);
+            step1(greedy[s]);
         }
     }
     a.pos[e] = s;

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import griduniverse_amd.algorithms.dynamic_programming as dp  # noqa: E402
 from griduniverse_amd import GridUniverseEnv, VecGridUniverse  # noqa: E402
 from griduniverse_amd.algorithms import utils  # noqa: E402
-from griduniverse_amd.algorithms.monte_carlo import run_episode  # noqa: E402
+from griduniverse_amd.algorithms.monte_carlo import monte_carlo_evaluation, run_episode  # noqa: E402
 
 
 def run_policy_and_value_iteration():
@@ -71,8 +71,33 @@ def run_policy_and_value_iteration():
     print('length {}, return {}, terminal {}'.format(len(rewards), sum(rewards), done))
 
 
+def run_monte_carlo_evaluation():
+    """Counterpart of the reference's run_monte_carlo_evaluation (examples/griduniverse_alg_examples.py:88-129):
+    every-visit Monte-Carlo evaluation of the uniform policy on an 8x8 maze, then act greedily on it -- with
+    4096 episodes in one launch instead of 30 sequential ones."""
+    print('\n*** Monte-Carlo evaluation of the uniform policy and greedy policy from it ***\n')
+    world_shape = (8, 8)
+    env = GridUniverseEnv(world_shape, random_maze=True)
+    env.render()
+    policy0 = np.ones([env.world.size, env.action_space.n]) / env.action_space.n
+    value0 = monte_carlo_evaluation(policy0, env, every_visit=True, num_episodes=4096)
+    np.set_printoptions(linewidth=150, precision=1, suppress=True)
+    print(utils.reshape_as_griduniverse(value0, world_shape))
+    policy1 = utils.greedy_policy_from_value_function(policy0, env, value0)
+    utils.get_policy_map(policy1, world_shape)
+    state = env.reset()
+    for t in range(500):
+        state, reward, done, info = env.step(np.argmax(policy1[state]))
+        if done:
+            print('terminal state found in {} steps'.format(t + 1))
+            break
+    else:
+        print('greedy policy from the Monte-Carlo estimate did not reach a terminal state in 500 steps')
+
+
 if __name__ == '__main__':
     import random
     random.seed(4)
     np.random.seed(4)
     run_policy_and_value_iteration()
+    run_monte_carlo_evaluation()

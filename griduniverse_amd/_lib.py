@@ -20,7 +20,7 @@ ERR_NAMES = {-1: 'GU_ERR_INVALID', -2: 'GU_ERR_HIP', -3: 'GU_ERR_NOMEM', -4: 'GU
              -5: 'GU_ERR_COMM', -6: 'GU_ERR_UNSUPPORTED'}
 
 F_AUTO_RESET, F_TRAJECTORY, F_STATS = 1, 2, 4
-POLICY_UNIFORM, POLICY_STREAM, POLICY_GREEDY = 0, 1, 2
+POLICY_UNIFORM, POLICY_STREAM, POLICY_GREEDY, POLICY_SAMPLE = 0, 1, 2, 3
 COMM_ID_BYTES = 128
 
 _c = ctypes
@@ -56,6 +56,7 @@ SIGNATURES = {
     'gu_vi_greedy': [_vp, _f64],
     'gu_vi_get': [_vp, _vp, _vp],
     'gu_vi_sweep_step': [_vp, _f64, _u32, _vp],
+    'gu_mc_evaluate': [_vp, _i64, _vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp],
     'gu_sync': [_vp],
     'gu_timer_begin': [_vp],
     'gu_timer_end': [_vp, _c.POINTER(_c.c_float)],

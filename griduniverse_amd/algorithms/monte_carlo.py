@@ -1,19 +1,62 @@
-"""run_episode with the reference's signature (core/algorithms/monte_carlo.py:7-26): the
-canonical reset / sample-action / step loop on the N = 1 facade.  For throughput use
-`VecGridUniverse.rollout`, which fuses this loop for thousands of envs into one launch."""
+"""Monte-Carlo policy evaluation with the reference's names (core/algorithms/monte_carlo.py).
+
+`run_episode` is the reference's scalar loop on the N = 1 facade.  `monte_carlo_evaluation` keeps
+the reference's signature and arithmetic (float64, bit-exact given the same episodes) but generates
+all `num_episodes` episodes in ONE fused rollout launch -- env e is episode e, actions sampled from
+`policy[state]` by the per-env device RNG -- and reduces them on the device (csrc/gu_mc.hip).
+"""
 import numpy as np
+
+from .utils import engine_of
 
 
 def run_episode(policy, env, max_steps_per_episode=1000):
+    """Reset, then sample-action / step until done or the step cap (monte_carlo.py:7-26).  Uses the
+    numpy GLOBAL rng for np.random.choice, like the reference.  Returns (states, rewards, done)."""
     states_hist, rewards_hist = [], []
     observation = env.reset()
     states_hist.append(observation)
     done = False
     for _ in range(max_steps_per_episode):
-        action = np.random.choice(policy[observation].size, p=policy[observation])  # numpy GLOBAL rng, as the reference
+        action = np.random.choice(policy[observation].size, p=policy[observation])
         observation, reward, done, _ = env.step(action)
         states_hist.append(observation)
         rewards_hist.append(reward)
         if done:
             break
     return states_hist, rewards_hist, done
+
+
+def discount_table(discount_factor, threshold, length):
+    """discount_factor ** i and the reference's truncation test (monte_carlo.py:69-70) for i < length,
+    evaluated with Python's float pow exactly as the reference evaluates them."""
+    pw = np.array([discount_factor ** i for i in range(length)], dtype=np.float64)
+    return pw, pw > threshold
+
+
+def monte_carlo_evaluation(policy, env, every_visit=False, incremental_mean=True, stationary_env=True,
+                           discount_factor=0.99, threshold=0.0001, alpha=0.001, num_episodes=100, *,
+                           max_steps_per_episode=1000, seed=0, return_details=False):
+    """Value function of `policy` from `num_episodes` sampled episodes (monte_carlo.py:29-99).
+
+    Episodes are processed in index order, so the result equals the reference's sequential loop fed
+    with the same episodes.  Extra keyword-only arguments: the step cap of each episode (run_episode's
+    default 1000), the RNG seed of the batch, and `return_details` to also get the visit counters and
+    the raw trajectory."""
+    from ..vec_env import VecGridUniverse
+    batch = VecGridUniverse(num_episodes, template=env, seed=seed, auto_reset=False,
+                            device=getattr(engine_of(env), 'device', 0))
+    try:
+        eng = batch.engine
+        eng.vi_set(np.zeros(env.world.size), policy)
+        first = batch.reset()
+        T = int(max_steps_per_episode)
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
+        pw, keep = discount_table(discount_factor, threshold, T)
+        value, visits = eng.mc_evaluate(T, first, pw, keep, every_visit, incremental_mean, stationary_env, alpha)
+        if return_details:
+            return value, dict(total_visit_counter=visits, first_state=first, **eng.read_trajectory(0, T))
+        return value
+    finally:
+        batch.close()

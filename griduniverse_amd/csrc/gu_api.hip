@@ -418,6 +418,7 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
                    (long long)h->traj_T, (long long)T);
     if (policy_kind == GU_POLICY_STREAM)
         GU_REQUIRE(h->d_actions && T <= h->actions_T, GU_ERR_STATE, "action stream holds %lld rows, need %lld", (long long)h->actions_T, (long long)T);
+    if (policy_kind == GU_POLICY_SAMPLE) GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no policy table: call gu_vi_set first");
     if (policy_kind == GU_POLICY_GREEDY) {
         GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no policy table: call gu_vi_set first");
         if (!h->greedy_valid) {

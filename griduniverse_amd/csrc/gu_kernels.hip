@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
 struct RolloutArgs {
     const uint8_t *cell;
     const uint8_t *greedy;  // first-argmax action per state (GU_POLICY_GREEDY)
+    const double *pi;       // [S][4] action probabilities (GU_POLICY_SAMPLE)
     int32_t cell_bytes, W;
     uint64_t lut;
     int32_t *pos, *reward, *done;
@@ -275,8 +276,9 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
             step1(act);
         }
     } else {
-        for (int64_t i = 0; i < a.T; ++i) {
-            // greedy[] must be read at the post-reset position
+        uint32_t t = t_lane;
+        for (int64_t i = 0; i < a.T; ++i, ++t) {
+            // greedy[] / pi[] must be read at the post-reset position
             if (AUTO == 1) {
                 s = d ? start0 : s;
                 flags = d ? start0_flags : flags;
@@ -290,7 +292,16 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
                     d = 0;
                 }
             }
-            step1(greedy[s]);
+            if (POLICY == GU_POLICY_GREEDY) {
+                step1(greedy[s]);
+            } else {
+                // inverse CDF of pi[s] on one uniform 32-bit word (RNG stream 2, counter = step count):
+                // a = #{k < 3 : u >= p0 + .. + pk}, u = word / 2^32 (exact in float64)
+                const double u = (double)gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t) * 2.3283064365386963e-10;
+                const double4 p = *reinterpret_cast<const double4 *>(a.pi + 4 * (int64_t)s);
+                const double c0 = p.x, c1 = __dadd_rn(c0, p.y), c2 = __dadd_rn(c1, p.z);
+                step1((uint32_t)(u >= c0) + (uint32_t)(u >= c1) + (uint32_t)(u >= c2));
+            }
         }
     }
     a.pos[e] = s;
@@ -455,6 +466,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     RolloutArgs a{};
     a.cell = h->d_cell;
     a.greedy = h->d_greedy;
+    a.pi = h->d_pi[h->vi_cur];
     a.cell_bytes = h->cell_bytes;
     a.W = h->W;
     a.lut = h->delta_lut;
@@ -481,6 +493,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     case GU_POLICY_UNIFORM: gu_rollout_dispatch<GU_POLICY_UNIFORM>(h, a, auto_mode, traj, stats, bs); break;
     case GU_POLICY_STREAM: gu_rollout_dispatch<GU_POLICY_STREAM>(h, a, auto_mode, traj, stats, bs); break;
     case GU_POLICY_GREEDY: gu_rollout_dispatch<GU_POLICY_GREEDY>(h, a, auto_mode, traj, stats, bs); break;
+    case GU_POLICY_SAMPLE: gu_rollout_dispatch<GU_POLICY_SAMPLE>(h, a, auto_mode, traj, stats, bs); break;
     default: return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
     }
     GU_HIP(hipGetLastError());

@@ -15,6 +15,7 @@
 
 #define GU_RNG_STREAM_ACTION 0u
 #define GU_RNG_STREAM_START 1u
+#define GU_RNG_STREAM_SAMPLE 2u
 
 __host__ __device__ __forceinline__ uint32_t gu_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 

@@ -12,7 +12,8 @@ from . import _lib
 from ._lib import check, ptr
 from .grid import GridSpec
 
-_POLICIES = {'uniform': _lib.POLICY_UNIFORM, 'stream': _lib.POLICY_STREAM, 'greedy': _lib.POLICY_GREEDY}
+_POLICIES = {'uniform': _lib.POLICY_UNIFORM, 'stream': _lib.POLICY_STREAM, 'greedy': _lib.POLICY_GREEDY,
+             'sample': _lib.POLICY_SAMPLE}
 
 
 class Engine(object):
@@ -173,6 +174,19 @@ class Engine(object):
         check(self.lib.gu_vi_sweep_step(self._h, float(gamma), _lib.F_AUTO_RESET if auto_reset else 0,
                                         ctypes.byref(d) if want_delta else None))
         return d.value if want_delta else None
+
+    def mc_evaluate(self, T, first_state, discount_pow, keep, every_visit=False, incremental_mean=True,
+                    stationary_env=True, alpha=0.001):
+        """Monte-Carlo evaluation over the trajectory rows 0..T-1 of the last rollout (env e = episode e).
+        Returns (value_function[S], total_visit_counter[S])."""
+        first = _lib.as_array(first_state, np.int32, (self.N,), 'first_state')
+        pw = _lib.as_array(discount_pow, np.float64, (T,), 'discount_pow')
+        kp = _lib.as_array(np.asarray(keep).astype(bool), np.uint8, (T,), 'keep')
+        S = self.spec.S
+        value, visits = np.empty(S, np.float64), np.empty(S, np.float64)
+        check(self.lib.gu_mc_evaluate(self._h, int(T), ptr(first), 1 if every_visit else 0, 1 if incremental_mean else 0,
+                                      1 if stationary_env else 0, float(alpha), ptr(pw), ptr(kp), ptr(value), ptr(visits)))
+        return value, visits
 
     # ------------------------------------------------------------------ stream / timing
     def sync(self):

@@ -52,6 +52,8 @@ extern "C" {
 #define GU_POLICY_UNIFORM 0 /* a ~ U{0..3} from the per-env counter RNG (stream 0)           */
 #define GU_POLICY_STREAM 1  /* a = actions[t][env] uploaded with gu_upload_actions           */
 #define GU_POLICY_GREEDY 2  /* a = first argmax of pi[pos] (np.argmax; examples/griduniverse_alg_examples.py:76) */
+#define GU_POLICY_SAMPLE 3  /* a ~ pi[pos]: inverse CDF on one 32-bit word of RNG stream 2 per step, the batched form of
+                               np.random.choice(4, p=policy[obs]) in core/algorithms/monte_carlo.py:20 */
 
 typedef struct gu_engine *gu_handle;
 
@@ -153,6 +155,22 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
 int gu_vi_greedy(gu_handle h, double gamma);
 int gu_vi_get(gu_handle h, double *v, double *pi);
 int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta);
+
+/* ---- Monte-Carlo policy evaluation: core/algorithms/monte_carlo.py:29-99 ----------------
+ * Consumes the trajectory rows 0..T-1 of the last gu_rollout (run WITHOUT auto-reset: env e is
+ * episode e; its episode ends at its first done row, or after T steps -- run_episode, :7-26) and
+ * applies the reference's arithmetic in the reference's order (episode 0, 1, ... N-1):
+ *   per episode  : visit counts and summed returns per state, first-visit or every-visit (:54-71);
+ *                  return from step idx = sum_i discount_pow[i] * r[idx+i] over the i with keep[i]
+ *                  (the caller passes discount_factor**i and (discount_factor**i > threshold) so
+ *                  that pow is evaluated by the host language exactly like the reference, :69-70)
+ *   across episodes, per state: incremental mean / running mean with alpha / batch mean (:73-97)
+ * first_state[N]: the state each episode started in (what reset() returned).  value[S] in/out is
+ * NOT read: evaluation starts from zeros like the reference; value_out[S] and visits_out[S]
+ * (total_visit_counter, optional) are written.  float64, bit-exact. */
+int gu_mc_evaluate(gu_handle h, int64_t T, const int32_t *first_state, int32_t every_visit, int32_t incremental_mean,
+                   int32_t stationary_env, double alpha, const double *discount_pow, const uint8_t *keep,
+                   double *value_out, double *visits_out);
 
 /* ---- stream / timing -----------------------------------------------------------
  * HIP events on the handle's own stream (torch.cuda.Event cannot see it). */

@@ -107,7 +107,7 @@ def reset(grid, seed, state, mask=None):
     return state.pos.copy()
 
 
-def rollout(grid, seed, state, T, auto_reset=True, actions=None, trajectory=True, stats=False):
+def rollout(grid, seed, state, T, auto_reset=True, actions=None, trajectory=True, stats=False, pi=None):
     n = state.n
     acts = None if actions is None else np.ascontiguousarray(actions, np.int32)
     if acts is not None:
@@ -115,10 +115,11 @@ def rollout(grid, seed, state, T, auto_reset=True, actions=None, trajectory=True
     obs = rew = don = None
     if trajectory:
         obs, rew, don = (np.empty((T, n), np.int32) for _ in range(3))
+    pi_c = None if pi is None else np.ascontiguousarray(pi, np.float64)
     ret = np.zeros(n, np.int64) if stats else None
     eps = np.zeros(n, np.int32) if stats else None
     lib().gu_oracle_rollout(ctypes.byref(grid.c), ctypes.c_uint64(seed), ctypes.c_int64(state.env_id0),
-                            ctypes.c_int64(n), ctypes.c_int64(T), ctypes.c_int32(bool(auto_reset)), _p(acts),
+                            ctypes.c_int64(n), ctypes.c_int64(T), ctypes.c_int32(bool(auto_reset)), _p(acts), _p(pi_c),
                             _p(state.pos), _p(state.done), _p(state.episode), _p(state.tcount),
                             _p(obs), _p(rew), _p(don), _p(ret), _p(eps))
     out = dict(obs=obs, reward=rew, done=don)

@@ -124,13 +124,24 @@ void gu_oracle_reset(const gu_oracle_grid *g, uint64_t seed, int64_t env_id0, in
     }
 }
 
+/* inverse-CDF sample of pi[s][0..3] on RNG stream 2 (oracle/gu_rng.py: sampled_action) */
+int32_t gu_oracle_rng_sample(uint64_t seed, uint32_t env, uint32_t t, const double *p)
+{
+    double u = (double)gu_oracle_rng_word(seed, env, 2, t) / 4294967296.0;
+    volatile double c0 = p[0];
+    volatile double c1 = c0 + p[1];
+    volatile double c2 = c1 + p[2];
+    return (u >= c0) + (u >= c1) + (u >= c2);
+}
+
 /* T lock-stepped env-steps for n envs (global ids env_id0 ..), state in/out.
+ *   pi           : [S][4] or NULL; used when actions == NULL: a ~ pi[s] (gu_oracle_rng_sample)
  *   actions      : [T][n] int32 or NULL -> uniform actions from RNG stream 0 at step counter tcount[i]
  *   auto_reset   : the harness's `if done: reset()` applied lazily, i.e. right before the next step
  *   obs/reward/done_out : [T][n] or NULL
  *   ret_out/len... : per-env sum of rewards over the T steps and number of finished episodes, or NULL */
 void gu_oracle_rollout(const gu_oracle_grid *g, uint64_t seed, int64_t env_id0, int64_t n, int64_t T,
-                       int32_t auto_reset, const int32_t *actions,
+                       int32_t auto_reset, const int32_t *actions, const double *pi,
                        int32_t *pos, int32_t *done, uint32_t *episode, uint32_t *tcount,
                        int32_t *obs_out, int32_t *reward_out, int32_t *done_out,
                        int64_t *ret_out, int32_t *episodes_out)
@@ -142,7 +153,9 @@ void gu_oracle_rollout(const gu_oracle_grid *g, uint64_t seed, int64_t env_id0, 
         int32_t fin = 0;
         for (int64_t t = 0; t < T; ++t) {
             if (auto_reset && d) { s = do_reset(g, seed, env, &episode[i]); d = 0; }
-            int32_t a = actions ? actions[t * n + i] : gu_oracle_rng_action(seed, env, tcount[i]);
+            int32_t a = actions ? actions[t * n + i]
+                      : pi ? gu_oracle_rng_sample(seed, env, tcount[i], pi + 4 * (int64_t)s)
+                           : gu_oracle_rng_action(seed, env, tcount[i]);
             int32_t r;
             gu_oracle_look_step_ahead(g, s, a, 1, &s, &r, &d);   /* _step, env:180-181 */
             tcount[i] += 1;

@@ -13,6 +13,9 @@ is sharded, so the build defines one and this file is its specification:
 
     action(seed, env, t)      = (word(seed, env, 0, t >> 4) >> (2 * (t & 15))) & 3
     start_index(seed, env, e) = (word(seed, env, 1, e) * n_starts) >> 32
+    sampled(seed, env, t, p)  = #{k < 3 : u >= p[0] + .. + p[k]},  u = word(seed, env, 2, t) / 2**32
+                                (float64 partial sums left to right; the batched form of
+                                np.random.choice(4, p=policy[obs]), core/algorithms/monte_carlo.py:20)
 
 `env` is the GLOBAL env index (so a sharded run equals the single-GPU run),
 `t` the number of steps the env has taken since seeding, `e` its number of
@@ -27,6 +30,7 @@ C2 = 0x1B873593
 M32 = 0xFFFFFFFF
 STREAM_ACTION = 0
 STREAM_START = 1
+STREAM_SAMPLE = 2
 CTR_MASK = 0x0FFFFFFF
 
 
@@ -69,6 +73,14 @@ def action(seed, env, t):
 
 def start_index(seed, env, episode, n_starts):
     return (word(seed, env, STREAM_START, episode) * int(n_starts)) >> 32
+
+
+def sampled_action(seed, env, t, probs):
+    u = word(seed, env, STREAM_SAMPLE, t) / 4294967296.0
+    c0 = float(probs[0])
+    c1 = c0 + float(probs[1])
+    c2 = c1 + float(probs[2])
+    return int(u >= c0) + int(u >= c1) + int(u >= c2)
 
 
 # ---------------------------------------------------------------- vectorised

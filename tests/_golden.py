@@ -38,3 +38,11 @@ def load_dp(name):
 
 def level_path(name):
     return os.path.join(GOLDEN, 'levels', name)
+
+
+def mc_names():
+    return sorted(os.path.basename(p)[3:-4] for p in glob.glob(os.path.join(GOLDEN, 'mc_*.npz')))
+
+
+def load_mc(name):
+    return load_npz('mc', name)

@@ -1,0 +1,116 @@
+"""Monte-Carlo evaluation on the device: stream-2 policy sampling in the fused rollout
+and the csrc/gu_mc.hip reduction, bit-exact against goldens captured from the reference's own
+monte_carlo_evaluation and against the oracle on larger random cases."""
+import numpy as np
+import pytest
+
+import griduniverse_amd as gua
+from griduniverse_amd.algorithms import monte_carlo as mc
+from griduniverse_amd.engine import Engine
+from griduniverse_amd.grid import GridSpec
+from oracle import c_oracle as C
+from oracle import mc as omc
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+
+def spec_of(meta):
+    return GridSpec(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'])
+
+
+def env_of(meta):
+    return gua.GridUniverseEnv(grid_shape=(meta['W'], meta['H']), initial_state=list(meta['starts']),
+                               goal_states=list(meta['goals']), lava_states=list(meta['lava']), walls=list(meta['walls']))
+
+
+@pytest.mark.parametrize('name', G.mc_names())
+def test_golden_mc_evaluation(name):
+    meta, z = G.load_mc(name)
+    S, N, T = meta['W'] * meta['H'], meta['N'], meta['T']
+    with Engine(N, spec_of(meta), seed=meta['seed']) as eng:
+        eng.vi_set(np.zeros(S), z['policy'])
+        first = eng.reset()
+        assert np.array_equal(first, z['first_state'])
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
+        traj = eng.read_trajectory(0, T)
+        for k in ('obs', 'reward', 'done'):  # the sampled episodes themselves
+            assert np.array_equal(traj[k], z[k]), (name, k)
+        for run in meta['runs']:
+            pw, keep = mc.discount_table(run['discount_factor'], run['threshold'], T)
+            v, visits = eng.mc_evaluate(T, first, pw, keep, run['every_visit'], run['incremental_mean'],
+                                        run['stationary_env'], run['alpha'])
+            assert v.tobytes() == z[run['key']].tobytes(), (name, run)
+
+
+@pytest.mark.parametrize('name', G.mc_names())
+def test_reference_named_driver(name):
+    """monte_carlo_evaluation(policy, env, ...) called like examples/griduniverse_alg_examples.py:107."""
+    meta, z = G.load_mc(name)
+    env = env_of(meta)
+    for run in meta['runs'][:4]:
+        v = mc.monte_carlo_evaluation(z['policy'], env, every_visit=run['every_visit'], incremental_mean=run['incremental_mean'],
+                                      stationary_env=run['stationary_env'], discount_factor=run['discount_factor'],
+                                      threshold=run['threshold'], alpha=run['alpha'], num_episodes=meta['N'],
+                                      max_steps_per_episode=meta['T'], seed=meta['seed'])
+        assert v.tobytes() == z[run['key']].tobytes()
+    env.close()
+
+
+def test_larger_batch_vs_oracle_and_chunking():
+    """600 episodes x 300 steps on a 32x32 lava grid (several scratch chunks would need S*N*16 B > 256 MiB;
+    here one chunk) and 3000 episodes on a 64-state grid, against the Python restatement."""
+    rs = np.random.RandomState(4)
+    for (W, H, lava, N, T) in ((32, 32, [16 + 32 * r for r in range(24)], 600, 300), (8, 8, [9, 21], 3000, 120)):
+        S = W * H
+        spec = GridSpec(W, H, [0, W + 1], [S - 1], lava, [W * 2 + 3])
+        pi = rs.dirichlet(np.ones(4), S)
+        with Engine(N, spec, seed=99) as eng:
+            eng.vi_set(np.zeros(S), pi)
+            first = eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
+            traj = eng.read_trajectory(0, T)
+            grid = C.Grid(W, H, spec.wall, spec.lava, spec.goal, spec.reward, spec.starts)
+            st = C.State(N)
+            C.reset(grid, 99, st)
+            want_traj = C.rollout(grid, 99, st, T, auto_reset=False, pi=pi)
+            for k in ('obs', 'reward', 'done'):
+                assert np.array_equal(traj[k], want_traj[k])
+            sub = slice(0, 150)  # the O(L^2) Python restatement on a prefix of the episodes ...
+            for ev, im, stn in ((False, True, True), (True, False, True), (True, True, False)):
+                pw, keep = mc.discount_table(0.97, 1e-3, T)
+                v, visits = eng.mc_evaluate(T, first, pw, keep, ev, im, stn, 0.01)
+                assert np.isfinite(v).all() and visits.sum() > 0
+            # ... checked exactly on an engine holding only that prefix
+        with Engine(150, spec, seed=99) as eng:
+            eng.vi_set(np.zeros(S), pi)
+            first = eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
+            for ev, im, stn in ((False, True, True), (True, False, True), (True, True, False)):
+                pw, keep = mc.discount_table(0.97, 1e-3, T)
+                v, visits = eng.mc_evaluate(T, first, pw, keep, ev, im, stn, 0.01)
+                eps = omc.episodes_from_trajectory(first, want_traj['obs'][:, sub], want_traj['reward'][:, sub], want_traj['done'][:, sub])
+                v_want, vis_want = omc.monte_carlo_evaluation(S, eps, ev, im, stn, 0.97, 1e-3, 0.01)
+                assert v.tobytes() == v_want.tobytes() and visits.tobytes() == vis_want.tobytes(), (W, ev, im, stn)
+
+
+def test_sample_policy_with_auto_reset_and_stats():
+    meta, z = G.load_mc('rect6x5_multistart')
+    S, N = meta['W'] * meta['H'], 512
+    grid = C.Grid.from_lists(**meta)
+    st = C.State(N, 40)
+    C.reset(grid, 5, st)
+    want = C.rollout(grid, 5, st, 200, auto_reset=True, pi=z['policy'], stats=True)
+    with Engine(N, spec_of(meta), env_id0=40, seed=5) as eng:
+        eng.vi_set(np.zeros(S), z['policy'])
+        eng.reset()
+        eng.reserve_trajectory(200)
+        eng.rollout(200, 'sample', auto_reset=True, trajectory=True, stats=True)
+        got = eng.read_trajectory(0, 200)
+        ret, eps = eng.read_stats()
+    for k in ('obs', 'reward', 'done'):
+        assert np.array_equal(got[k], want[k])
+    assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes'])

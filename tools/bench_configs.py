@@ -104,6 +104,29 @@ def config5(N=65536):
     return out
 
 
+def mc_bench(N=4096, T=1000):
+    from griduniverse_amd.algorithms.monte_carlo import discount_table
+    env = maze(8, 8, 1)
+    S = env.world.size
+    eng = gua.Engine(N, gua.GridSpec.from_env(env), seed=3)
+    eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+    first = eng.reset()
+    eng.reserve_trajectory(T)
+    t0 = time.perf_counter()
+    eng.rollout(T, 'sample', False, True)
+    eng.sync()
+    t1 = time.perf_counter()
+    pw, keep = discount_table(0.99, 1e-4, T)
+    v, visits = eng.mc_evaluate(T, first, pw, keep, True, True, True, 0.001)
+    t2 = time.perf_counter()
+    traj = eng.read_trajectory(0, T)
+    lengths = np.where(traj['done'].any(0), traj['done'].argmax(0) + 1, T)
+    eng.close()
+    return {'config': 'monte_carlo_evaluation, 8x8 maze, uniform policy, every-visit incremental mean', 'episodes': N,
+            'max_steps': T, 'mean_episode_length': float(lengths.mean()), 'rollout_s': t1 - t0, 'evaluate_s': t2 - t1,
+            'episodes_per_s': N / (t2 - t0)}
+
+
 def main():
     res = []
     res.append(paths('c2 open 8x8', gua.GridUniverseEnv(grid_shape=(8, 8)), 4096))
@@ -111,6 +134,7 @@ def main():
     res.append(paths('c4 lava 32x32 (one of 8 shards)', gua.GridUniverseEnv(grid_shape=(32, 32), lava_states=[16 + 32 * r for r in range(24)]), 32768))
     res.append(paths('c3 grid at 1M envs', maze(32, 32, 123), 1 << 20, T=250, reps=10))
     res.append(config5())
+    res.append(mc_bench())
     text = json.dumps(res, indent=1)
     print(text)
     if len(sys.argv) > 1:

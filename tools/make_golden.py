@@ -379,6 +379,56 @@ def capture_dp():
         print('dp', name, 'S', S, 'gamma', gamma, 'deltas[-1]', deltas[-1])
 
 
+# ----------------------------------------------------------------------------- G9
+def capture_mc():
+    """monte_carlo_evaluation (core/algorithms/monte_carlo.py:29-99) of the REAL reference, with its
+    run_episode replaced by a replay of episodes generated with the build's RNG (stream 2 sampling):
+    episode e = env e of one no-auto-reset rollout of the oracle."""
+    import core.algorithms.monte_carlo as ref_mc
+    from oracle import c_oracle as C
+
+    rs = np.random.RandomState(11)
+    cases = [('maze8_uniform', lambda: seeded_maze_env(8, 8, 1), None, 48, 160, 21),
+             ('lava4x4_dirichlet', lambda: ref_env(lava_states=[5, 6, 9]), 'dirichlet', 40, 60, 22),
+             ('rect6x5_multistart', lambda: ref_env(grid_shape=(6, 5), goal_states=[29, 8], lava_states=[13], walls=[7, 14, 20],
+                                                    initial_state=[0, 3, 27]), 'dirichlet', 64, 80, 23)]
+    combos = [dict(every_visit=ev, incremental_mean=im, stationary_env=st)
+              for ev in (False, True) for im, st in ((True, True), (True, False), (False, True))]
+    for name, make, kind, N, T, seed in cases:
+        env = make()
+        S = env.world.size
+        policy = np.ones((S, 4)) / 4 if kind is None else rs.dirichlet(np.ones(4) * 0.7, S)
+        grid = C.Grid.from_env(env)
+        st = C.State(N)
+        first = C.reset(grid, seed, st)
+        traj = C.rollout(grid, seed, st, T, auto_reset=False, pi=policy)
+        episodes = []
+        for e in range(N):
+            hits = np.flatnonzero(traj['done'][:, e])
+            L = int(hits[0]) + 1 if hits.size else T
+            episodes.append(([int(first[e])] + [int(x) for x in traj['obs'][:L, e]],
+                             [np.int64(x) for x in traj['reward'][:L, e]], bool(traj['done'][L - 1, e])))
+        arrays = dict(policy=policy, first_state=first, obs=traj['obs'], reward=traj['reward'], done=traj['done'])
+        meta = dict(spec_of(env), seed=seed, N=N, T=T, runs=[])
+        for gamma, thr, alpha in ((0.99, 1e-4, 0.001), (0.9, 1e-3, 0.05), (1.0, 1e-4, 0.2)):
+            for c in combos:
+                replay = iter(episodes)
+                original = ref_mc.run_episode
+                ref_mc.run_episode = lambda policy, env, max_steps_per_episode=1000: next(replay)
+                try:
+                    with quiet():
+                        v = ref_mc.monte_carlo_evaluation(policy, env, discount_factor=gamma, threshold=thr, alpha=alpha,
+                                                          num_episodes=N, **c)
+                finally:
+                    ref_mc.run_episode = original
+                key = 'v_%d' % len(meta['runs'])
+                arrays[key] = v
+                meta['runs'].append(dict(c, discount_factor=gamma, threshold=thr, alpha=alpha, key=key))
+        np.savez_compressed(os.path.join(OUT, 'mc_%s.npz' % name), meta=json.dumps(meta), **arrays)
+        print('mc', name, 'S', S, 'episodes', N, 'mean length %.1f' % np.mean([len(e[1]) for e in episodes]),
+              'terminal %.2f' % np.mean([e[2] for e in episodes]))
+
+
 # ----------------------------------------------------------------------------- G2
 def capture_trajectories():
     digests = {}
@@ -438,7 +488,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     random.seed(0)
     np.random.seed(0)
-    what = set(sys.argv[1:]) or {'kat', 'err', 'render', 'maze', 'dp', 'traj'}
+    what = set(sys.argv[1:]) or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc'}
     if 'kat' in what:
         json.dump(capture_kats(), open(os.path.join(OUT, 'kat.json'), 'w'), indent=1)
     if 'err' in what:
@@ -451,6 +501,8 @@ def main():
         json.dump(levels, open(os.path.join(OUT, 'levels.json'), 'w'), indent=1)
     if 'dp' in what:
         capture_dp()
+    if 'mc' in what:
+        capture_mc()
     if 'traj' in what:
         json.dump(capture_trajectories(), open(os.path.join(OUT, 'digests.json'), 'w'), indent=1)
     assert not any('__pycache__' in d for d, _, _ in os.walk(REF)), 'bytecode was written into the reference'

@@ -269,8 +269,27 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
             }
         }
     } else if (POLICY == GU_POLICY_STREAM) {
-#pragma unroll 4
-        for (int64_t i = 0; i < a.T; ++i) {
+        // Action rows are read 8 at a time, one chunk AHEAD of the steps that consume them: the loads are
+        // independent of the env state, so with one wave per SIMD this is what hides their HBM latency.
+        constexpr int CH = 8;
+        int64_t i = 0;
+        uint32_t cur[CH], nxt[CH];
+        auto load_chunk = [&](uint32_t (&dst)[CH], const char *base) {
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) dst[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, e4, j * row32, 0);
+        };
+        if (a.T >= CH) load_chunk(cur, pa);
+        for (; i + CH <= a.T; i += CH) {
+            pa += CH * row;
+            if (i + 2 * CH <= a.T) load_chunk(nxt, pa);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) step(cur[j] & 3u, j * row32);
+            if (TRAJ) rebase(CH);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
+        }
+        for (; i < a.T; ++i) {  // tail
             const uint32_t act = (uint32_t)(*(const int32_t *)(pa + e4)) & 3u;
             pa += row;
             step1(act);

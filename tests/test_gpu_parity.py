@@ -440,3 +440,77 @@ def test_integration_md_ctypes_stub_runs():
     want = C.rollout(grid, 9, st, 64, True)
     assert np.array_equal(obs, want['obs']) and np.array_equal(rew, want['reward']) and np.array_equal(done, want['done'])
     batched.close()
+
+
+# ------------------------------------------------------------------------------- C-ABI error behaviour
+def test_c_abi_error_codes():
+    """Misuse returns negative codes + a message, never crashes (include/gu.h conventions)."""
+    import ctypes
+    from griduniverse_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.gu_create(0, 0, 0, ctypes.byref(h)) == -1 and not h.value            # GU_ERR_INVALID
+    assert lib.gu_create(99, 8, 0, ctypes.byref(h)) == -2 and 'not present' in _lib.last_error()
+    assert lib.gu_create(0, 8, 2 ** 32, ctypes.byref(h)) == -1
+    assert lib.gu_destroy(None) == 0
+    assert lib.gu_sync(None) == -1 and 'null handle' in _lib.last_error()
+    assert lib.gu_create(0, 8, 0, ctypes.byref(h)) == 0 and h.value
+    acts = np.zeros(8, np.int32)
+    out = np.zeros(8, np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    assert lib.gu_step(h, p(acts), 0, p(out), None, None) == -4 and 'gu_set_grid' in _lib.last_error()   # GU_ERR_STATE
+    assert lib.gu_reset(h, None, None, None) == -4
+    assert lib.gu_rollout(h, 10, 0, 0) == -4
+    lib.gu_destroy(h)
+    meta, _ = G.load_traj('c2_open8x8')
+    with Engine(8, spec_of(meta)) as eng:
+        hh = eng._h
+        assert lib.gu_rollout(hh, 10, 0, 2) == -4 and 'gu_reserve_trajectory' in _lib.last_error()
+        assert lib.gu_rollout(hh, 10, 7, 0) == -1
+        assert lib.gu_rollout(hh, 0, 0, 0) == -1 and lib.gu_rollout(hh, 10, 0, 64) == -1
+        assert lib.gu_rollout(hh, 10, 1, 0) == -4          # no action stream uploaded
+        assert lib.gu_rollout(hh, 10, 2, 0) == -4          # no policy table
+        assert lib.gu_step_device(hh, 0, 0) == -4
+        assert lib.gu_read_stats(hh, None, None) == -4
+        assert lib.gu_vi_sweep(hh, 1.0, 1, 1, None) == -4
+        assert lib.gu_allgather_view(hh, None, None, None) == -4
+        assert lib.gu_step(hh, None, 0, None, None, None) == -1
+        bad = np.full((2, 8), 5, np.int32)
+        assert lib.gu_upload_actions(hh, p(bad), 2) == -1
+        planes = eng.spec.planes()
+        starts = np.array([64], np.int32)
+        assert lib.gu_set_grid(hh, 8, 8, 1, p(planes['wall']), p(planes['goal']), p(planes['lava']), None, None, p(starts), 1) == -1
+        assert lib.gu_set_grid(hh, 8, 8, 2, p(planes['wall']), p(planes['goal']), p(planes['lava']), None, None, p(starts), 1) == -1
+        # derived reward planes (NULL, NULL) give the same engine as explicit ones
+        starts = np.array([0], np.int32)
+        assert lib.gu_set_grid(hh, 8, 8, 1, p(planes['wall']), p(planes['goal']), p(planes['lava']), None, None, p(starts), 1) == 0
+        eng.seed(2)
+        eng.reset()
+        _, z = G.load_traj('c2_open8x8')
+        obs, rew, don = eng.step(z['actions'][0][:8])
+        assert np.array_equal(obs, z['obs'][0][:8]) and np.array_equal(rew, z['reward'][0][:8])
+
+
+def test_stream_rollout_all_lengths():
+    """The 8-row prefetch pipeline of the STREAM policy: every T around the chunk size, with and without trajectory."""
+    meta, z = G.load_traj('rect25x30_busy')
+    grid = C.Grid.from_lists(**meta)
+    N = 200
+    acts = z['actions'][:40, :64].repeat(4, axis=1)[:, :N].copy()
+    with Engine(N, spec_of(meta), seed=3) as eng:
+        for T in (1, 7, 8, 9, 15, 16, 17, 24, 40):
+            for traj in (True, False):
+                st = C.State(N)
+                C.reset(grid, 3, st)
+                eng.seed(3)
+                eng.reset()
+                want = C.rollout(grid, 3, st, T, True, actions=acts[:T])
+                eng.upload_actions(acts[:T])
+                eng.reserve_trajectory(T)
+                eng.rollout(T, 'stream', True, trajectory=traj)
+                if traj:
+                    got = eng.read_trajectory(0, T)
+                    for k in ('obs', 'reward', 'done'):
+                        assert np.array_equal(got[k], want[k]), (T, k)
+                obs, rew, don = eng.read_outputs()
+                assert np.array_equal(obs, st.pos) and np.array_equal(don, st.done), T

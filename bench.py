@@ -141,7 +141,9 @@ def main():
     N, T, K, W = args.envs, args.T, args.steps, args.warmup
     seed = 123
     template, grid_desc = build_workload(args.workload)
-    eng = gua.Engine(N, gua.GridSpec.from_env(template), device=local_rank, env_id0=rank * N, seed=seed)
+    n_dev = max(1, _lib.device_count())
+    device = local_rank % n_dev  # identity on an N-GPU node; lets a 1-GPU box rehearse the N-process flow
+    eng = gua.Engine(N, gua.GridSpec.from_env(template), device=device, env_id0=rank * N, seed=seed)
     eng.reset()
     eng.reserve_trajectory(T)
 

@@ -35,6 +35,9 @@ SIGNATURES = {
     'gu_create': [_c.c_int, _i64, _i64, _c.POINTER(_vp)],
     'gu_destroy': [_vp],
     'gu_set_grid': [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32],
+    'gu_set_grids': [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32],
+    'gu_generate_mazes': [_vp, _i32, _i32, _i32, _u64],
+    'gu_get_cells': [_vp, _i32, _vp, _vp, _vp, _vp],
     'gu_seed': [_vp, _u64],
     'gu_reset': [_vp, _vp, _vp, _vp],
     'gu_reset_done': [_vp],

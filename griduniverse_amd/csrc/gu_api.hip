@@ -88,7 +88,7 @@ int gu_create(int device_id, int64_t num_envs, int64_t env_id0, gu_handle *out)
 {
     GU_REQUIRE(out != nullptr, GU_ERR_INVALID, "out handle is NULL");
     *out = nullptr;
-    GU_REQUIRE(num_envs > 0 && num_envs <= (1 << 26), GU_ERR_INVALID, "num_envs %lld out of range (1 .. 2^26 per device)", (long long)num_envs);
+    GU_REQUIRE(num_envs > 0 && num_envs <= (1 << 25), GU_ERR_INVALID, "num_envs %lld out of range (1 .. 2^25 per device)", (long long)num_envs);
     GU_REQUIRE(env_id0 >= 0 && env_id0 + num_envs <= 0xFFFFFFFFLL, GU_ERR_INVALID, "global env ids must fit 32 bits");
     int n_dev = 0;
     GU_HIP(hipGetDeviceCount(&n_dev));
@@ -141,7 +141,7 @@ int gu_destroy(gu_handle h)
     gu_comm_free(h);
     gu_vi_free(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    void *bufs[] = {h->d_cell, h->d_cell_raw, h->d_starts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions,
+    void *bufs[] = {h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions,
                     h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_done_idx, h->d_done_count,
                     h->d_scratch, h->d_greedy};
     for (void *p : bufs)
@@ -160,31 +160,21 @@ static inline bool plane_bit(const uint32_t *rows, int32_t wpr, int32_t x, int32
     return rows && ((rows[(size_t)y * wpr + (x >> 5)] >> (x & 31)) & 1u);
 }
 
-int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row, const uint32_t *wall_rows,
-                const uint32_t *goal_rows, const uint32_t *lava_rows, const uint32_t *rplus_rows,
-                const uint32_t *rminus_rows, const int32_t *starts, int32_t n_starts)
+// Compile one grid's row bit-planes into the two byte planes (flags | reward), absorbing and raw variant,
+// appended to `cell` / `raw`.
+static void compile_planes(int32_t W, int32_t H, int32_t wpr, const uint32_t *wall_rows, const uint32_t *goal_rows,
+                           const uint32_t *lava_rows, const uint32_t *rplus_rows, const uint32_t *rminus_rows,
+                           uint8_t *cell, uint8_t *raw, int32_t cell_bytes)
 {
-    GU_ENTER(h);
-    GU_REQUIRE(W > 0 && H > 0 && (int64_t)W * H <= (1 << 30), GU_ERR_INVALID, "bad grid shape %d x %d", W, H);
-    GU_REQUIRE(words_per_row == (W + 31) / 32, GU_ERR_INVALID, "words_per_row must be ceil(W/32)");
-    GU_REQUIRE(wall_rows && goal_rows && lava_rows, GU_ERR_INVALID, "wall/goal/lava planes are required");
-    GU_REQUIRE((rplus_rows == nullptr) == (rminus_rows == nullptr), GU_ERR_INVALID, "give both reward planes or neither");
-    GU_REQUIRE(starts && n_starts > 0, GU_ERR_INVALID, "at least one starting state is required");
-    const int32_t S = W * H;
-    for (int32_t i = 0; i < n_starts; ++i)
-        GU_REQUIRE(starts[i] >= 0 && starts[i] < S, GU_ERR_INVALID, "starting state %d outside the grid", starts[i]);
-
-    const int32_t cell_bytes = (S + 15) & ~15;
-    std::vector<uint8_t> cell(2 * (size_t)cell_bytes, 0), raw(2 * (size_t)cell_bytes, 0);
-    auto wall = [&](int32_t x, int32_t y) { return plane_bit(wall_rows, words_per_row, x, y); };
+    auto wall = [&](int32_t x, int32_t y) { return plane_bit(wall_rows, wpr, x, y); };
     for (int32_t y = 0; y < H; ++y) {
         for (int32_t x = 0; x < W; ++x) {
             const size_t s = (size_t)y * W + x;
-            const bool lava = plane_bit(lava_rows, words_per_row, x, y);
-            const bool goal = plane_bit(goal_rows, words_per_row, x, y);
+            const bool lava = plane_bit(lava_rows, wpr, x, y);
+            const bool goal = plane_bit(goal_rows, wpr, x, y);
             const bool term = lava || goal;                                          // env:163-168
-            const bool rminus = rminus_rows ? plane_bit(rminus_rows, words_per_row, x, y) : lava;   // env:86-88
-            const bool rplus = rplus_rows ? plane_bit(rplus_rows, words_per_row, x, y) : (goal && !lava);
+            const bool rminus = rminus_rows ? plane_bit(rminus_rows, wpr, x, y) : lava;   // env:86-88
+            const bool rplus = rplus_rows ? plane_bit(rplus_rows, wpr, x, y) : (goal && !lava);
             uint8_t open = 0;
             if (y > 0 && !wall(x, y - 1)) open |= 1u;        // UP    env:51, env:149
             if (x < W - 1 && !wall(x + 1, y)) open |= 2u;    // RIGHT env:52
@@ -197,24 +187,35 @@ int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row, const 
             raw[(size_t)cell_bytes + s] = cell[(size_t)cell_bytes + s] = (uint8_t)r;
         }
     }
+}
+
+}  // extern "C" (helpers below have C++ signatures)
+
+// Upload compiled planes of `n_grids` grids ([g][flags|reward]) and their start tables; resets env state.
+int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const std::vector<uint8_t> &cell,
+                     const std::vector<uint8_t> &raw, const std::vector<int32_t> &starts, const std::vector<int32_t> &n_starts,
+                     int32_t max_starts)
+{
+    const int32_t S = W * H;
+    const int32_t cell_bytes = (S + 15) & ~15;
     GU_HIP(hipStreamSynchronize(h->stream));
-    for (void *p : {(void *)h->d_cell, (void *)h->d_cell_raw, (void *)h->d_starts, (void *)h->d_greedy})
+    for (void *p : {(void *)h->d_cell, (void *)h->d_cell_raw, (void *)h->d_starts, (void *)h->d_nstarts, (void *)h->d_greedy})
         if (p) GU_HIP(hipFree(p));
     h->d_cell = h->d_cell_raw = h->d_greedy = nullptr;
-    h->d_starts = nullptr;
+    h->d_starts = h->d_nstarts = nullptr;
     h->has_grid = false;
     gu_vi_free(h);
-    GU_HIP(hipMalloc(&h->d_cell, 2 * (size_t)cell_bytes));
-    GU_HIP(hipMalloc(&h->d_cell_raw, 2 * (size_t)cell_bytes));
+    const size_t plane_bytes = 2 * (size_t)cell_bytes * n_grids;
+    GU_HIP(hipMalloc(&h->d_cell, plane_bytes));
+    GU_HIP(hipMalloc(&h->d_cell_raw, plane_bytes));
     GU_HIP(hipMalloc(&h->d_greedy, cell_bytes));
-    GU_HIP(hipMalloc(&h->d_starts, (size_t)n_starts * sizeof(int32_t)));
-    GU_HIP(hipMemcpy(h->d_cell, cell.data(), 2 * (size_t)cell_bytes, hipMemcpyHostToDevice));
-    GU_HIP(hipMemcpy(h->d_cell_raw, raw.data(), 2 * (size_t)cell_bytes, hipMemcpyHostToDevice));
+    GU_HIP(hipMalloc(&h->d_starts, starts.size() * sizeof(int32_t)));
+    GU_HIP(hipMalloc(&h->d_nstarts, (size_t)n_grids * sizeof(int32_t)));
+    GU_HIP(hipMemcpy(h->d_cell, cell.data(), plane_bytes, hipMemcpyHostToDevice));
+    GU_HIP(hipMemcpy(h->d_cell_raw, raw.data(), plane_bytes, hipMemcpyHostToDevice));
     GU_HIP(hipMemset(h->d_greedy, 0, cell_bytes));
-    GU_HIP(hipMemcpy(h->d_starts, starts, (size_t)n_starts * sizeof(int32_t), hipMemcpyHostToDevice));
-    h->h_cell.swap(cell);
-    h->h_cell_raw.swap(raw);
-    h->h_starts.assign(starts, starts + n_starts);
+    GU_HIP(hipMemcpy(h->d_starts, starts.data(), starts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    GU_HIP(hipMemcpy(h->d_nstarts, n_starts.data(), (size_t)n_grids * sizeof(int32_t), hipMemcpyHostToDevice));
     h->W = W;
     h->H = H;
     h->S = S;
@@ -224,17 +225,83 @@ int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row, const 
         h->delta_lut = mw16 | (1ull << 16) | (w16 << 32) | (0xFFFFull << 48);
     }
     h->cell_bytes = cell_bytes;
-    h->n_starts = n_starts;
+    h->n_grids = n_grids;
+    h->group = h->N / n_grids;
+    h->n_starts = n_starts[0];
+    h->max_starts = max_starts;
+    h->all_single_start = true;
+    for (int32_t g = 0; g < n_grids; ++g) h->all_single_start = h->all_single_start && n_starts[(size_t)g] == 1;
     h->has_grid = true;
     h->greedy_valid = false;
     if (h->graph_exec) {
         (void)hipGraphExecDestroy(h->graph_exec);
         h->graph_exec = nullptr;
     }
-    // every env starts at starts[0] until the caller resets (pos must always be a valid cell)
-    std::vector<int32_t> init((size_t)h->N, starts[0]);
+    // every env sits on its grid's first start cell until the caller resets (pos must always be a valid cell)
+    std::vector<int32_t> init((size_t)h->N);
+    for (int64_t e = 0; e < h->N; ++e) init[(size_t)e] = starts[(size_t)(e / h->group) * max_starts];
     GU_HIP(hipMemcpy(h->pos(), init.data(), (size_t)h->N * sizeof(int32_t), hipMemcpyHostToDevice));
     GU_HIP(hipMemset(h->reward(), 0, 2 * (size_t)h->N * sizeof(int32_t)));
+    return GU_OK;
+}
+
+extern "C" {
+
+int gu_set_grids(gu_handle h, int32_t n_grids, int32_t W, int32_t H, int32_t words_per_row, const uint32_t *wall_rows,
+                 const uint32_t *goal_rows, const uint32_t *lava_rows, const uint32_t *rplus_rows,
+                 const uint32_t *rminus_rows, const int32_t *starts, const int32_t *n_starts, int32_t max_starts)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(n_grids > 0 && h->N % n_grids == 0, GU_ERR_INVALID, "n_grids=%d must divide num_envs=%lld", n_grids, (long long)h->N);
+    GU_REQUIRE(W > 0 && H > 0 && (int64_t)W * H <= (1 << 30), GU_ERR_INVALID, "bad grid shape %d x %d", W, H);
+    GU_REQUIRE(words_per_row == (W + 31) / 32, GU_ERR_INVALID, "words_per_row must be ceil(W/32)");
+    GU_REQUIRE(wall_rows && goal_rows && lava_rows, GU_ERR_INVALID, "wall/goal/lava planes are required");
+    GU_REQUIRE((rplus_rows == nullptr) == (rminus_rows == nullptr), GU_ERR_INVALID, "give both reward planes or neither");
+    GU_REQUIRE(starts && n_starts && max_starts > 0, GU_ERR_INVALID, "start tables are required");
+    const int32_t S = W * H;
+    const int32_t cell_bytes = (S + 15) & ~15;
+    GU_REQUIRE(2 * (int64_t)cell_bytes * n_grids < (1ll << 31), GU_ERR_UNSUPPORTED, "%d grids of %d cells exceed 2 GiB of records", n_grids, S);
+    for (int32_t g = 0; g < n_grids; ++g) {
+        GU_REQUIRE(n_starts[g] > 0 && n_starts[g] <= max_starts, GU_ERR_INVALID, "grid %d: n_starts=%d outside 1..%d", g, n_starts[g], max_starts);
+        for (int32_t i = 0; i < n_starts[g]; ++i) {
+            const int32_t st = starts[(size_t)g * max_starts + i];
+            GU_REQUIRE(st >= 0 && st < S, GU_ERR_INVALID, "grid %d: starting state %d outside the grid", g, st);
+        }
+    }
+    std::vector<uint8_t> cell(2 * (size_t)cell_bytes * n_grids, 0), raw(2 * (size_t)cell_bytes * n_grids, 0);
+    const size_t plane_words = (size_t)H * words_per_row;
+    for (int32_t g = 0; g < n_grids; ++g)
+        compile_planes(W, H, words_per_row, wall_rows + g * plane_words, goal_rows + g * plane_words, lava_rows + g * plane_words,
+                       rplus_rows ? rplus_rows + g * plane_words : nullptr, rminus_rows ? rminus_rows + g * plane_words : nullptr,
+                       cell.data() + 2 * (size_t)cell_bytes * g, raw.data() + 2 * (size_t)cell_bytes * g, cell_bytes);
+    std::vector<int32_t> st(starts, starts + (size_t)n_grids * max_starts), ns(n_starts, n_starts + n_grids);
+    for (int32_t g = 0; g < n_grids; ++g)  // pad unused slots with a valid cell
+        for (int32_t i = ns[(size_t)g]; i < max_starts; ++i) st[(size_t)g * max_starts + i] = st[(size_t)g * max_starts];
+    return gu_install_grids(h, n_grids, W, H, cell, raw, st, ns, max_starts);
+}
+
+int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row, const uint32_t *wall_rows,
+                const uint32_t *goal_rows, const uint32_t *lava_rows, const uint32_t *rplus_rows,
+                const uint32_t *rminus_rows, const int32_t *starts, int32_t n_starts)
+{
+    GU_REQUIRE(starts && n_starts > 0, GU_ERR_INVALID, "at least one starting state is required");
+    return gu_set_grids(h, 1, W, H, words_per_row, wall_rows, goal_rows, lava_rows, rplus_rows, rminus_rows, starts, &n_starts, n_starts);
+}
+
+// Read back grid `grid_index` as the engine holds it: flags[S] and reward[S] (absorbing map), its start table.
+int gu_get_cells(gu_handle h, int32_t grid_index, uint8_t *flags, int8_t *reward, int32_t *starts, int32_t *n_starts)
+{
+    GU_ENTER(h);
+    GU_NEED_GRID(h);
+    GU_REQUIRE(grid_index >= 0 && grid_index < h->n_grids, GU_ERR_INVALID, "grid index %d outside [0,%d)", grid_index, h->n_grids);
+    GU_HIP(hipStreamSynchronize(h->stream));
+    const uint8_t *base = h->d_cell + 2 * (size_t)h->cell_bytes * grid_index;
+    if (flags) GU_HIP(hipMemcpy(flags, base, (size_t)h->S, hipMemcpyDeviceToHost));
+    if (reward) GU_HIP(hipMemcpy(reward, base + h->cell_bytes, (size_t)h->S, hipMemcpyDeviceToHost));
+    int32_t ns = 0;
+    GU_HIP(hipMemcpy(&ns, h->d_nstarts + grid_index, sizeof ns, hipMemcpyDeviceToHost));
+    if (n_starts) *n_starts = ns;
+    if (starts) GU_HIP(hipMemcpy(starts, h->d_starts + (size_t)grid_index * h->max_starts, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost));
     return GU_OK;
 }
 
@@ -245,6 +312,10 @@ int gu_seed(gu_handle h, uint64_t seed)
     h->seed = seed;
     h->seed_prefix = gu_rng_seed_prefix(seed);
     h->steps_taken = 0;
+    if (h->graph_exec) {  // captured step launches carry the old seed in their arguments
+        (void)hipGraphExecDestroy(h->graph_exec);
+        h->graph_exec = nullptr;
+    }
     GU_HIP(hipMemsetAsync(h->d_episode, 0, (size_t)h->N * sizeof(uint32_t), h->stream));
     GU_HIP(hipMemsetAsync(h->d_tcount, 0, (size_t)h->N * sizeof(uint32_t), h->stream));
     GU_HIP(hipStreamSynchronize(h->stream));
@@ -265,8 +336,8 @@ int gu_reset(gu_handle h, const uint8_t *mask, const int32_t *start_choice, int3
         if (start_choice) {
             for (size_t i = 0; i < n; ++i)
                 if (!mask || mask[i])
-                    GU_REQUIRE(start_choice[i] >= 0 && start_choice[i] < h->n_starts, GU_ERR_INVALID,
-                               "start_choice[%zu]=%d outside [0,%d)", i, start_choice[i], h->n_starts);
+                    GU_REQUIRE(start_choice[i] >= 0 && start_choice[i] < (h->n_grids == 1 ? h->n_starts : h->max_starts), GU_ERR_INVALID,
+                               "start_choice[%zu]=%d outside the start table", i, start_choice[i]);
             d_choice = (int32_t *)h->d_scratch;
             GU_HIP(hipMemcpyAsync(d_choice, start_choice, n * 4, hipMemcpyHostToDevice, h->stream));
         }

@@ -38,10 +38,14 @@ struct gu_engine {
     uint8_t *d_cell = nullptr;       // absorbing-aware planes    [2 * cell_bytes]
     uint8_t *d_cell_raw = nullptr;   // care_about_terminal=False [2 * cell_bytes]
     uint64_t delta_lut = 0;          // int16 x 4: {-W, +1, +W, -1} (valid when W <= 32767)
-    int32_t *d_starts = nullptr;
-    int32_t n_starts = 0;
-    std::vector<uint8_t> h_cell, h_cell_raw;
-    std::vector<int32_t> h_starts;
+    int32_t *d_starts = nullptr;     // [n_grids][max_starts]
+    int32_t *d_nstarts = nullptr;    // [n_grids]
+    int32_t n_starts = 0;            // of grid 0 (the only grid unless n_grids > 1)
+    int32_t max_starts = 0;
+    bool all_single_start = true;
+    // several distinct grids of one shape: env e uses grid e / group (contiguous equal groups)
+    int32_t n_grids = 1;
+    int64_t group = 0;               // envs per grid = N / n_grids
 
     // SoA env state
     int32_t *d_out3 = nullptr;  // pos[N] | reward[N] | done[N]
@@ -100,6 +104,19 @@ struct gu_engine {
     int32_t *done() const { return d_out3 + 2 * N; }
 };
 
+// what the kernels need to find a lane's grid (by value in the kernel arguments)
+struct GridSel {
+    int64_t group;           // envs per grid
+    int64_t grid_stride;     // bytes between consecutive grids' plane pairs (2 * cell_bytes)
+    const int32_t *n_starts; // [n_grids]
+    int32_t n_grids, max_starts;
+};
+
+inline GridSel gu_grid_sel(const gu_engine *h)
+{
+    return GridSel{h->group, 2 * (int64_t)h->cell_bytes, h->d_nstarts, h->n_grids, h->max_starts};
+}
+
 // ---- error plumbing --------------------------------------------------------------
 void gu_set_error(const char *fmt, ...);
 int gu_fail(int code, const char *fmt, ...);
@@ -132,6 +149,11 @@ int gu_launch_done_compact(gu_engine *h);
 int gu_vi_alloc(gu_engine *h);
 void gu_vi_free(gu_engine *h);
 int gu_launch_greedy_table(gu_engine *h);
+
+// ---- grids (gu_api.hip / gu_maze.hip) ----------------------------------------------
+int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const std::vector<uint8_t> &cell,
+                     const std::vector<uint8_t> &raw, const std::vector<int32_t> &starts, const std::vector<int32_t> &n_starts,
+                     int32_t max_starts);
 
 // ---- RCCL (gu_comm.hip) ----------------------------------------------------------
 void gu_comm_free(gu_engine *h);

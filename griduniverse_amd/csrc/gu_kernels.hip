@@ -47,6 +47,23 @@ __device__ __forceinline__ CellMap gu_stage_map(const uint8_t *__restrict__ g, i
     return CellMap{g, reinterpret_cast<const int8_t *>(g + cell_bytes)};
 }
 
+// Which grid does lane e use?  LDS variants run single-grid engines only (g = 0); the L2 variants also
+// serve multi-grid engines: env e uses grid e / group, its planes sit goff bytes into the plane buffer.
+struct LaneGrid {
+    const int32_t *starts;
+    uint32_t n_starts;
+};
+
+template <bool LDS>
+__device__ __forceinline__ LaneGrid gu_lane_grid(const GridSel &gs, const int32_t *starts, uint32_t n_starts0, uint32_t e, CellMap &m)
+{
+    if (LDS || gs.n_grids <= 1) return LaneGrid{starts, n_starts0};
+    const uint32_t g = e / (uint32_t)gs.group;
+    m.f += (int64_t)g * gs.grid_stride;
+    m.r += (int64_t)g * gs.grid_stride;
+    return LaneGrid{starts + (int64_t)g * gs.max_starts, (uint32_t)gs.n_starts[g]};
+}
+
 // delta[a]: LUT = four int16 lanes {-W, +1, +W, -1}; ARITH = any W (grids too big for the LUT / LDS)
 template <bool LUT>
 __device__ __forceinline__ int32_t gu_delta(uint32_t a, uint64_t lut, int32_t W)
@@ -73,6 +90,7 @@ struct ResetArgs {
     uint32_t n_starts, seed_prefix, env_id0;
     int64_t N;
     int32_t only_done;
+    GridSel gs;
 };
 
 __global__ void __launch_bounds__(GU_BLOCK) gu_reset_kernel(const ResetArgs a)
@@ -82,14 +100,21 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_reset_kernel(const ResetArgs a)
     if (a.mask && !a.mask[e]) return;
     if (a.only_done && !a.done[e]) return;
     uint32_t ep = a.episode[e];
+    const int32_t *starts = a.starts;
+    uint32_t n_starts = a.n_starts;
+    if (a.gs.n_grids > 1) {
+        const uint32_t g = (uint32_t)e / (uint32_t)a.gs.group;
+        starts += (int64_t)g * a.gs.max_starts;
+        n_starts = (uint32_t)a.gs.n_starts[g];
+    }
     uint32_t idx;
     if (a.choice) {
         idx = (uint32_t)a.choice[e];
-        if (idx >= a.n_starts) idx = 0;  // host validates; never index out of the table
+        if (idx >= n_starts) idx = 0;  // host validates; never index out of the table
     } else {
-        idx = gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, a.n_starts);
+        idx = gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, n_starts);
     }
-    a.pos[e] = a.starts[idx];
+    a.pos[e] = starts[idx];
     a.done[e] = 0;
     a.episode[e] = ep + 1;
 }
@@ -110,20 +135,22 @@ struct StepArgs {
     uint32_t n_starts, seed_prefix, env_id0;
     int64_t N;
     uint32_t flags;
+    GridSel gs;
 };
 
 template <bool LDS>
 __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem);
+    CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem);
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.N) return;
+    const LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, (uint32_t)e, m);
     const uint32_t act = (uint32_t)a.actions[e] & 3u;
     int32_t s = a.pos[e];
     if ((a.flags & GU_F_AUTO_RESET) && a.done[e]) {  // lazy `if done: env.reset()`
         const uint32_t ep = a.episode[e];
-        s = a.starts[gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, a.n_starts)];
+        s = lg.starts[gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, lg.n_starts)];
         a.episode[e] = ep + 1;
     }
     s = gu_move(s, m.f[s], act, gu_delta<LDS>(act, a.lut, a.W));
@@ -152,6 +179,7 @@ struct RolloutArgs {
     int32_t *ret, *episodes_fin;
     uint32_t n_starts, seed_prefix, env_id0, steps_taken;
     int64_t N, T;
+    GridSel gs;
 };
 
 // AUTO: 0 = no reset; 1 = auto-reset, single start cell (branch-free select);
@@ -160,7 +188,7 @@ template <int POLICY, int AUTO, bool TRAJ, bool STATS, bool LDS>
 __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem);
+    CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem);
     const uint8_t *greedy = a.greedy;
     if (LDS && POLICY == GU_POLICY_GREEDY) {
         uint8_t *dst = smem + 2 * a.cell_bytes;
@@ -172,6 +200,7 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
     const int64_t e64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e64 >= a.N) return;
     const uint32_t e = (uint32_t)e64;
+    const LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, e, m);
 
     int32_t s = a.pos[e];
     int32_t r = a.reward[e];
@@ -183,7 +212,7 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
     int32_t ret = 0, fin = 0;
     const int32_t W = a.W;
     const uint64_t lut = a.lut;
-    const int32_t start0 = a.starts[0];
+    const int32_t start0 = lg.starts[0];
     const uint32_t start0_flags = m.f[start0];
     // Trajectory rows are addressed as buffer resource (wave-uniform base, rebuilt per 16-step chunk)
     // + lane byte offset e4 (VGPR) + scalar row offset (SGPR): buffer_store_dword ... offen, so that
@@ -192,17 +221,17 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
     const char *pa = (const char *)a.actions;
     const uint32_t e4 = e * 4u;
     const int64_t row = a.N * 4;
-    const uint32_t row32 = (uint32_t)row;  // gu_create caps N so that 16 rows fit 32 bits
-    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0x7FFFFFFF, 0x00020000);
-    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0x7FFFFFFF, 0x00020000);
-    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0x7FFFFFFF, 0x00020000);
+    const uint32_t row32 = (uint32_t)row;  // gu_create caps N at 2^25, so lane offset + 15 rows < 2^31 bytes
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0xFFFFFFFFu, 0x00020000);
+    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
     auto rebase = [&](int64_t rows) {
         po += rows * row;
         pr += rows * row;
         pd += rows * row;
-        ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0x7FFFFFFF, 0x00020000);
-        rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0x7FFFFFFF, 0x00020000);
-        rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0x7FFFFFFF, 0x00020000);
+        ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0xFFFFFFFFu, 0x00020000);
+        rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
+        rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
     };
 
     // `soff`: wave-uniform byte offset of this step's row from the resource base
@@ -213,7 +242,7 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
             ep += d;
         } else if (AUTO == 2) {
             if (d) {
-                s = a.starts[gu_rng_start_index(prefix, ep, a.n_starts)];
+                s = lg.starts[gu_rng_start_index(prefix, ep, lg.n_starts)];
                 ++ep;
                 flags = m.f[s];
             }
@@ -275,7 +304,7 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
         int64_t i = 0;
         uint32_t cur[CH], nxt[CH];
         auto load_chunk = [&](uint32_t (&dst)[CH], const char *base) {
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7FFFFFFF, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xFFFFFFFFu, 0x00020000);
 #pragma unroll
             for (int j = 0; j < CH; ++j) dst[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, e4, j * row32, 0);
         };
@@ -305,7 +334,7 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
                 d = 0;
             } else if (AUTO == 2) {
                 if (d) {
-                    s = a.starts[gu_rng_start_index(prefix, ep, a.n_starts)];
+                    s = lg.starts[gu_rng_start_index(prefix, ep, lg.n_starts)];
                     ++ep;
                     flags = m.f[s];
                     d = 0;
@@ -423,7 +452,7 @@ static int gu_rollout_block()
 int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice, bool only_done)
 {
     ResetArgs a{h->pos(), h->done(), h->d_episode, h->d_starts, d_mask, d_choice,
-                (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, only_done ? 1 : 0};
+                (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, only_done ? 1 : 0, gu_grid_sel(h)};
     hipLaunchKernelGGL(gu_reset_kernel, dim3(gu_blocks(h->N, GU_BLOCK)), dim3(GU_BLOCK), 0, h->stream, a);
     GU_HIP(hipGetLastError());
     return GU_OK;
@@ -432,9 +461,10 @@ int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice
 int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags)
 {
     StepArgs a{h->d_cell, h->cell_bytes, h->W, h->delta_lut, d_actions_row, h->pos(), h->reward(), h->done(),
-               h->d_episode, h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags};
+               h->d_episode, h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags,
+               gu_grid_sel(h)};
     const dim3 grid(gu_blocks(h->N, GU_BLOCK)), block(GU_BLOCK);
-    if (h->S <= GU_MAX_LDS_CELLS)
+    if (h->S <= GU_MAX_LDS_CELLS && h->n_grids == 1)
         hipLaunchKernelGGL(gu_step_kernel<true>, grid, block, 2 * (size_t)h->cell_bytes, h->stream, a);
     else
         hipLaunchKernelGGL(gu_step_kernel<false>, grid, block, 0, h->stream, a);
@@ -448,7 +478,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
 {
     const dim3 grid(gu_blocks(h->N, bs)), block(bs);
     const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
-    const bool lds = h->S <= GU_MAX_LDS_CELLS && (size_t)planes * h->cell_bytes <= 65536;
+    const bool lds = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && (size_t)planes * h->cell_bytes <= 65536;
     if (lds)
         hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, true>), grid, block, (size_t)planes * h->cell_bytes, h->stream, a);
     else
@@ -480,7 +510,7 @@ static void gu_rollout_dispatch(gu_engine *h, const RolloutArgs &a, int auto_mod
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
 {
     const bool traj = flags & GU_F_TRAJECTORY, stats = flags & GU_F_STATS;
-    const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->n_starts == 1 ? 1 : 2) : 0;
+    const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->all_single_start ? 1 : 2) : 0;
     const int64_t rows = traj ? h->traj_T * h->N : 0;
     RolloutArgs a{};
     a.cell = h->d_cell;
@@ -507,6 +537,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.steps_taken = h->steps_taken;
     a.N = h->N;
     a.T = T;
+    a.gs = gu_grid_sel(h);
     const int bs = gu_rollout_block();
     switch (policy) {
     case GU_POLICY_UNIFORM: gu_rollout_dispatch<GU_POLICY_UNIFORM>(h, a, auto_mode, traj, stats, bs); break;

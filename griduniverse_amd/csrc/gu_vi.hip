@@ -300,6 +300,7 @@ int gu_vi_set(gu_handle h, const double *v, const double *pi)
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_grid, GU_ERR_STATE, "no grid set: call gu_set_grid first");
+    GU_REQUIRE(h->n_grids == 1, GU_ERR_UNSUPPORTED, "value / policy tables need a single-grid engine");
     GU_REQUIRE(v && pi, GU_ERR_INVALID, "v or pi is NULL");
     rc = gu_vi_alloc(h);
     if (rc != GU_OK) return rc;

@@ -60,6 +60,40 @@ class Engine(object):
                                    ptr(p['lava']), ptr(p['rplus']), ptr(p['rminus']), ptr(starts), len(starts)))
         self.spec = spec
 
+    def set_grids(self, specs):
+        """Several distinct grids of one shape: env e uses specs[e // (N // len(specs))]."""
+        G = len(specs)
+        W, H = specs[0].W, specs[0].H
+        if any((sp.W, sp.H) != (W, H) for sp in specs):
+            raise ValueError('all grids of one engine must have the same shape')
+        planes = [sp.planes() for sp in specs]
+        stack = {k: np.ascontiguousarray(np.stack([p[k] for p in planes])) for k in planes[0]}
+        max_starts = max(len(sp.starts) for sp in specs)
+        starts = np.zeros((G, max_starts), np.int32)
+        n_starts = np.zeros(G, np.int32)
+        for g, sp in enumerate(specs):
+            starts[g, :len(sp.starts)] = sp.starts
+            n_starts[g] = len(sp.starts)
+        check(self.lib.gu_set_grids(self._h, G, W, H, specs[0].words_per_row, ptr(stack['wall']), ptr(stack['goal']),
+                                    ptr(stack['lava']), ptr(stack['rplus']), ptr(stack['rminus']), ptr(starts),
+                                    ptr(n_starts), max_starts))
+        self.spec = specs[0]
+        self.specs = list(specs)
+
+    def generate_mazes(self, n_grids, W, H, maze_seed):
+        """n_grids random mazes carved on the device (one per env group of N // n_grids envs)."""
+        check(self.lib.gu_generate_mazes(self._h, int(n_grids), int(W), int(H), int(maze_seed) & 0xFFFFFFFFFFFFFFFF))
+        self.spec = GridSpec(W, H, [0], [W * H - 1], [], [])  # shape holder; the real grids live on the device
+        self.specs = None
+
+    def get_cells(self, grid_index=0):
+        """(flags uint8[S], reward int8[S], starts int32[n]) of one grid as compiled on the device."""
+        S = self.spec.S
+        flags, reward = np.empty(S, np.uint8), np.empty(S, np.int8)
+        starts, n = np.empty(max(S, 1), np.int32), ctypes.c_int32(0)
+        check(self.lib.gu_get_cells(self._h, int(grid_index), ptr(flags), ptr(reward), ptr(starts), ctypes.byref(n)))
+        return flags, reward, starts[:n.value].copy()
+
     def seed(self, seed):
         self.seed_value = int(seed) & 0xFFFFFFFFFFFFFFFF
         check(self.lib.gu_seed(self._h, self.seed_value))

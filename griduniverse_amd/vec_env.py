@@ -22,18 +22,36 @@ from .grid import GridSpec
 
 class VecGridUniverse(object):
     def __init__(self, num_envs, grid_shape=(4, 4), *, initial_state=0, goal_states=None, lava_states=None,
-                 walls=None, custom_world_fp=None, random_maze=False, template=None, seed=0, device=0,
-                 env_id0=0, auto_reset=False, engine_factory=Engine):
+                 walls=None, custom_world_fp=None, random_maze=False, template=None, templates=None,
+                 device_mazes=None, maze_seed=0, seed=0, device=0, env_id0=0, auto_reset=False, engine_factory=Engine):
         """`template`: an existing GridUniverseEnv (or any object with the reference env's grid
         attributes) to take the grid from; otherwise the grid kwargs are validated and built
-        exactly like GridUniverseEnv's (same exceptions, same RNG consumption)."""
+        exactly like GridUniverseEnv's (same exceptions, same RNG consumption).
+        `templates=[...]`: several distinct grids of one shape, env e using grid e // (num_envs // len);
+        `device_mazes=G, maze_seed=k`: G random mazes of `grid_shape` generated on the GPU."""
+        self.num_envs = int(num_envs)
+        if templates is not None or device_mazes is not None:
+            # several distinct grids of one shape; env e uses grid e // (num_envs // n_grids)
+            self.env_id0, self.auto_reset, self.info = int(env_id0), bool(auto_reset), {}
+            if templates is not None:
+                specs = [t if isinstance(t, GridSpec) else GridSpec.from_env(t) for t in templates]
+                self.template, self.spec = templates[0], specs[0]
+                self.engine = engine_factory(self.num_envs, specs[0], device=device, env_id0=env_id0, seed=seed)
+                self.engine.set_grids(specs)
+            else:
+                # `device_mazes` random mazes carved on the GPU (csrc/gu_maze.hip) instead of one host maze
+                W, H = grid_shape
+                self.template = None
+                self.spec = GridSpec(W, H, [0], [W * H - 1], [], [])
+                self.engine = engine_factory(self.num_envs, self.spec, device=device, env_id0=env_id0, seed=seed)
+                self.engine.generate_mazes(int(device_mazes), W, H, maze_seed)
+            return
         if template is None:
             template = GridUniverseEnv(grid_shape, initial_state=initial_state, goal_states=goal_states,
                                        lava_states=lava_states, walls=walls, custom_world_fp=custom_world_fp,
                                        random_maze=random_maze, device=device)
         self.template = template
         self.spec = template if isinstance(template, GridSpec) else GridSpec.from_env(template)
-        self.num_envs = int(num_envs)
         self.env_id0 = int(env_id0)
         self.auto_reset = bool(auto_reset)
         self.engine = engine_factory(self.num_envs, self.spec, device=device, env_id0=env_id0, seed=seed)

@@ -89,6 +89,22 @@ int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row,
                 const uint32_t *rplus_rows, const uint32_t *rminus_rows,
                 const int32_t *starts, int32_t n_starts);
 
+/* Several DISTINCT grids of one shape in one engine (SURVEY.md 8(d) C3 variant, 8(f) rank 3): env e uses grid
+ * e / (num_envs / n_grids) -- contiguous equal groups, n_grids must divide num_envs.  Planes are
+ * [n_grids][H][words_per_row]; starts is [n_grids][max_starts] with n_starts[g] valid entries per grid.
+ * Multi-grid engines read the records from L2 instead of LDS and do not support the DP / Monte-Carlo tables. */
+int gu_set_grids(gu_handle h, int32_t n_grids, int32_t W, int32_t H, int32_t words_per_row,
+                 const uint32_t *wall_rows, const uint32_t *goal_rows, const uint32_t *lava_rows,
+                 const uint32_t *rplus_rows, const uint32_t *rminus_rows,
+                 const int32_t *starts, const int32_t *n_starts, int32_t max_starts);
+/* Generate n_grids random mazes ON THE DEVICE (one lane carves one maze): the algorithm of
+ * core/envs/maze_generation.py:41-149 (recursive backtracker, one 'x', one 'G'), draws from RNG stream 3 keyed
+ * by (maze_seed, global grid id).  Replaces n_grids x GridUniverseEnv(random_maze=True) (env:318-321). */
+int gu_generate_mazes(gu_handle h, int32_t n_grids, int32_t W, int32_t H, uint64_t maze_seed);
+/* Read back grid `grid_index` as compiled: flags[S] (OPEN bits 0-3 = move changes the position, bit 4 terminal),
+ * reward[S] (int8), and its start table (any pointer may be NULL). */
+int gu_get_cells(gu_handle h, int32_t grid_index, uint8_t *flags, int8_t *reward, int32_t *starts, int32_t *n_starts);
+
 /* ---- RNG ---------------------------------------------------------------------
  * Keys the per-env counter RNG (MurmurHash3 of seed, global env id, stream,
  * counter; specified in oracle/gu_rng.py) and zeroes episode[] and tcount[].

@@ -150,3 +150,16 @@ def value_iteration_step(grid, gamma, pi, v):
     v_new = np.empty(grid.S, np.float64)
     delta = lib().gu_oracle_value_iteration_step(ctypes.byref(grid.c), ctypes.c_double(gamma), _p(pi), _p(v), _p(v_new))
     return v_new, pi, float(delta)
+
+
+def generate_maze(maze_seed, grid_id, W, H):
+    """Restatement of the on-device generator: returns (wall bool[S], start, goal)."""
+    S = W * H
+    wall = np.empty(S, np.uint8)
+    stack = np.empty(S + 4, np.int32)
+    start, goal = ctypes.c_int32(-1), ctypes.c_int32(-1)
+    n_open = lib().gu_oracle_generate_maze(ctypes.c_uint64(maze_seed), ctypes.c_uint32(grid_id), ctypes.c_int32(W),
+                                           ctypes.c_int32(H), _p(wall), ctypes.byref(start), ctypes.byref(goal), _p(stack))
+    if n_open < 2:
+        raise ValueError('maze has fewer than two open cells')
+    return wall.astype(bool), int(start.value), int(goal.value)

@@ -233,3 +233,58 @@ double gu_oracle_value_iteration_step(const gu_oracle_grid *g, double gamma, dou
     gu_oracle_greedy_policy(g, gamma, v_new, pi);
     return delta;
 }
+
+/* ---------------------------------------------------------------- on-device maze generator, restated
+ * (csrc/gu_maze.hip; algorithm of core/envs/maze_generation.py:41-149 with the build's RNG stream 3:
+ * draw k = mulhi(word(maze_seed, grid_id, 3, k), n)).  wall_out[S]: 1 = wall.  Returns the number of open cells. */
+static uint32_t mulhi32(uint32_t w, uint32_t n) { return (uint32_t)(((uint64_t)w * n) >> 32); }
+
+int32_t gu_oracle_generate_maze(uint64_t maze_seed, uint32_t grid_id, int32_t W, int32_t H, uint8_t *wall_out,
+                                int32_t *start_out, int32_t *goal_out, int32_t *stack /* >= rooms */)
+{
+    int32_t S = W * H, sp = 0, moved = 0;
+    uint32_t k = 0;
+    for (int32_t s = 0; s < S; ++s) wall_out[s] = 1;
+    int32_t x = (int32_t)mulhi32(gu_oracle_rng_word(maze_seed, grid_id, 3, k++), (uint32_t)W);
+    int32_t y = (int32_t)mulhi32(gu_oracle_rng_word(maze_seed, grid_id, 3, k++), (uint32_t)H);
+    int32_t origin = y * W + x;
+    uint8_t *visited = wall_out + 0;  /* a room is visited iff carved, except the origin before the first move */
+    (void)visited;
+    for (;;) {
+        int32_t opt[4], n = 0, cur = y * W + x;
+        /* neighbour order +x, -x, +y, -y (maze_generation.py:61-68) */
+        if (x + 2 < W && wall_out[cur + 2] && cur + 2 != origin) opt[n++] = cur + 2;
+        if (x - 2 >= 0 && wall_out[cur - 2] && cur - 2 != origin) opt[n++] = cur - 2;
+        if (y + 2 < H && wall_out[cur + 2 * W] && cur + 2 * W != origin) opt[n++] = cur + 2 * W;
+        if (y - 2 >= 0 && wall_out[cur - 2 * W] && cur - 2 * W != origin) opt[n++] = cur - 2 * W;
+        if (n > 0) {
+            int32_t nb = opt[mulhi32(gu_oracle_rng_word(maze_seed, grid_id, 3, k++), (uint32_t)n)];
+            stack[sp++] = cur;
+            wall_out[(cur + nb) / 2] = 0;   /* :77-82 carve the wall between, the neighbour and the current cell */
+            wall_out[nb] = 0;
+            wall_out[cur] = 0;
+            x = nb % W; y = nb / W;
+            moved = 1;
+        } else if (sp > 0) {
+            cur = stack[--sp];
+            x = cur % W; y = cur / W;
+        } else {
+            break;
+        }
+    }
+    int32_t n_open = 0;
+    for (int32_t s = 0; s < S; ++s) n_open += wall_out[s] == 0;
+    if (!moved || n_open < 2) return n_open;
+    /* two distinct open cells, by rank among the open cells in ascending order (:124-142) */
+    uint32_t i = mulhi32(gu_oracle_rng_word(maze_seed, grid_id, 3, k++), (uint32_t)n_open);
+    uint32_t j = mulhi32(gu_oracle_rng_word(maze_seed, grid_id, 3, k++), (uint32_t)(n_open - 1));
+    if (j >= i) ++j;
+    uint32_t seen = 0;
+    for (int32_t s = 0; s < S; ++s) {
+        if (wall_out[s]) continue;
+        if (seen == i) *start_out = s;
+        if (seen == j) *goal_out = s;
+        ++seen;
+    }
+    return n_open;
+}

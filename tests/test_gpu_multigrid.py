@@ -1,0 +1,115 @@
+"""Several distinct grids in one engine, and mazes generated on the device."""
+import numpy as np
+import pytest
+
+import griduniverse_amd as gua
+from griduniverse_amd.engine import Engine
+from griduniverse_amd.grid import GridSpec
+from oracle import c_oracle as C
+from tests import _golden as G
+from tests.test_maze_structure import check_maze_structure
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_grid(spec):
+    return C.Grid(spec.W, spec.H, spec.wall, spec.lava, spec.goal, spec.reward, spec.starts)
+
+
+def random_specs(rs, n, W, H):
+    S, specs = W * H, []
+    for _ in range(n):
+        pick = lambda k: [int(x) for x in rs.choice(S, size=int(k), replace=False)]  # noqa: E731
+        specs.append(GridSpec(W, H, pick(rs.randint(1, 4)), pick(rs.randint(1, 3)), pick(rs.randint(0, 5)), pick(rs.randint(0, S // 4))))
+    return specs
+
+
+@pytest.mark.parametrize('group', [128, 50, 1])
+def test_multi_grid_engine_equals_per_grid_oracle(group):
+    rs = np.random.RandomState(group)
+    n_grids, W, H, T = 6, 13, 9, 150
+    specs = random_specs(rs, n_grids, W, H)
+    N, seed, id0 = n_grids * group, 17, 3 * n_grids * group
+    with Engine(N, specs[0], env_id0=id0, seed=seed) as eng:
+        eng.set_grids(specs)
+        first = eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'uniform', auto_reset=True, trajectory=True, stats=True)
+        got = eng.read_trajectory(0, T)
+        acts = rs.randint(0, 4, (5, N)).astype(np.int32)
+        steps = [eng.step(a, auto_reset=True) for a in acts]
+        eng.upload_actions(acts)
+        eng.rollout(5, 'stream', auto_reset=False, trajectory=False)
+        final = eng.get_state()
+        for g, spec in enumerate(specs):
+            fl, rw, st = eng.get_cells(g)
+            with Engine(1, spec) as single:
+                f1, r1, s1 = single.get_cells(0)
+            assert np.array_equal(fl, f1) and np.array_equal(rw, r1) and np.array_equal(st, s1)
+    for g, spec in enumerate(specs):
+        sl = slice(g * group, (g + 1) * group)
+        grid, st = oracle_grid(spec), C.State(group, id0 + g * group)
+        assert np.array_equal(C.reset(grid, seed, st), first[sl])
+        want = C.rollout(grid, seed, st, T, True)
+        for k in ('obs', 'reward', 'done'):
+            assert np.array_equal(got[k][:, sl], want[k]), (g, k)
+        for i in range(5):
+            w = C.rollout(grid, seed, st, 1, True, actions=acts[i:i + 1, sl])
+            assert np.array_equal(steps[i][0][sl], w['obs'][0]) and np.array_equal(steps[i][2][sl], w['done'][0])
+        C.rollout(grid, seed, st, 5, False, actions=acts[:, sl])
+        assert np.array_equal(final['pos'][sl], st.pos) and np.array_equal(final['episode'][sl], st.episode)
+
+
+def test_multi_grid_restrictions():
+    specs = random_specs(np.random.RandomState(0), 3, 8, 8)
+    with Engine(30, specs[0]) as eng:
+        eng.set_grids(specs)
+        with pytest.raises(gua.GuError):
+            eng.vi_set(np.zeros(64), np.ones((64, 4)) / 4)
+        with pytest.raises(gua.GuError):
+            eng.set_grids(specs[:2] + specs[:2])  # 4 does not divide 30
+        with pytest.raises(ValueError):
+            eng.set_grids([specs[0], GridSpec(9, 8, [0], [1], [], [])])
+        eng.set_grids(specs[:1])  # back to a single grid: LDS path and DP tables work again
+        eng.vi_set(np.zeros(64), np.ones((64, 4)) / 4)
+
+
+@pytest.mark.parametrize('W,H,n_grids,group', [(32, 32, 64, 64), (11, 7, 40, 3), (64, 64, 8, 256), (4, 1, 5, 2)])
+def test_device_generated_mazes_equal_oracle(W, H, n_grids, group):
+    N, seed, maze_seed, T = n_grids * group, 5, 2026, 120
+    id0 = 2 * N  # as if this were the third shard: grid ids continue globally
+    with Engine(N, GridSpec(W, H, [0], [W * H - 1], [], []), env_id0=id0, seed=seed) as eng:
+        eng.generate_mazes(n_grids, W, H, maze_seed)
+        first = eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'uniform', auto_reset=True)
+        got = eng.read_trajectory(0, T)
+        cells = [eng.get_cells(g) for g in range(n_grids)]
+    for g in range(n_grids):
+        wall, start, goal = C.generate_maze(maze_seed, id0 // group + g, W, H)
+        check_maze_structure(wall.reshape(H, W), start, goal)
+        spec = GridSpec(W, H, [start], [goal], [], np.flatnonzero(wall).tolist())
+        with Engine(1, spec) as single:
+            f1, r1, s1 = single.get_cells(0)
+        assert np.array_equal(cells[g][0], f1) and np.array_equal(cells[g][1], r1) and np.array_equal(cells[g][2], s1), g
+        if g % 7 == 0:
+            sl = slice(g * group, (g + 1) * group)
+            grid, st = oracle_grid(spec), C.State(group, id0 + g * group)
+            assert np.array_equal(C.reset(grid, seed, st), first[sl])
+            want = C.rollout(grid, seed, st, T, True)
+            for k in ('obs', 'reward', 'done'):
+                assert np.array_equal(got[k][:, sl], want[k]), (g, k)
+
+
+def test_device_mazes_through_vec_env_and_errors():
+    env = gua.VecGridUniverse(4096, grid_shape=(32, 32), device_mazes=64, maze_seed=9, seed=1, auto_reset=True)
+    obs = env.reset()
+    assert len(set(obs.tolist())) > 20  # distinct mazes -> distinct start cells
+    out = env.rollout(50, stats=True)
+    assert out['obs'].shape == (50, 4096)
+    env.close()
+    with Engine(64, GridSpec(3, 3, [0], [8], [], [])) as eng:
+        with pytest.raises(gua.GuError):
+            eng.generate_mazes(4, 3, 3, 1)   # no room for a corridor
+        with pytest.raises(gua.GuError):
+            eng.generate_mazes(5, 8, 8, 1)   # 5 does not divide 64

@@ -211,8 +211,10 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
     GU_HIP(hipMalloc(&h->d_greedy, cell_bytes));
     GU_HIP(hipMalloc(&h->d_starts, starts.size() * sizeof(int32_t)));
     GU_HIP(hipMalloc(&h->d_nstarts, (size_t)n_grids * sizeof(int32_t)));
-    GU_HIP(hipMemcpy(h->d_cell, cell.data(), plane_bytes, hipMemcpyHostToDevice));
-    GU_HIP(hipMemcpy(h->d_cell_raw, raw.data(), plane_bytes, hipMemcpyHostToDevice));
+    if (!cell.empty()) {  // empty = the caller fills the planes on the device (gu_generate_mazes)
+        GU_HIP(hipMemcpy(h->d_cell, cell.data(), plane_bytes, hipMemcpyHostToDevice));
+        GU_HIP(hipMemcpy(h->d_cell_raw, raw.data(), plane_bytes, hipMemcpyHostToDevice));
+    }
     GU_HIP(hipMemset(h->d_greedy, 0, cell_bytes));
     GU_HIP(hipMemcpy(h->d_starts, starts.data(), starts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     GU_HIP(hipMemcpy(h->d_nstarts, n_starts.data(), (size_t)n_grids * sizeof(int32_t), hipMemcpyHostToDevice));

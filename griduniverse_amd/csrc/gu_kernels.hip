@@ -35,10 +35,18 @@ struct CellMap {
     const int8_t *r;   // reward plane
 };
 
+// LDS variants: the whole block uses ONE grid (single-grid engines, or multi-grid engines whose group size is a
+// multiple of the block size -- the launcher guarantees it), whose planes are staged into LDS.
+__device__ __forceinline__ uint32_t gu_block_grid(const GridSel &gs)
+{
+    return gs.n_grids > 1 ? (uint32_t)(((int64_t)blockIdx.x * blockDim.x) / gs.group) : 0u;
+}
+
 template <bool LDS>
-__device__ __forceinline__ CellMap gu_stage_map(const uint8_t *__restrict__ g, int32_t cell_bytes, uint8_t *smem)
+__device__ __forceinline__ CellMap gu_stage_map(const uint8_t *__restrict__ g, int32_t cell_bytes, uint8_t *smem, const GridSel &gs)
 {
     if (LDS) {
+        g += (int64_t)gu_block_grid(gs) * gs.grid_stride;
         for (int32_t i = threadIdx.x * 16; i < 2 * cell_bytes; i += blockDim.x * 16)
             *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(g + i);
         __syncthreads();
@@ -47,8 +55,9 @@ __device__ __forceinline__ CellMap gu_stage_map(const uint8_t *__restrict__ g, i
     return CellMap{g, reinterpret_cast<const int8_t *>(g + cell_bytes)};
 }
 
-// Which grid does lane e use?  LDS variants run single-grid engines only (g = 0); the L2 variants also
-// serve multi-grid engines: env e uses grid e / group, its planes sit goff bytes into the plane buffer.
+// Which grid does lane e use?  In the LDS variants it is the block's grid (start table selected with scalar
+// arithmetic); the L2 variants serve any group size: env e uses grid e / group, its planes sit g * grid_stride
+// bytes into the plane buffer.
 struct LaneGrid {
     const int32_t *starts;
     uint32_t n_starts;
@@ -57,7 +66,11 @@ struct LaneGrid {
 template <bool LDS>
 __device__ __forceinline__ LaneGrid gu_lane_grid(const GridSel &gs, const int32_t *starts, uint32_t n_starts0, uint32_t e, CellMap &m)
 {
-    if (LDS || gs.n_grids <= 1) return LaneGrid{starts, n_starts0};
+    if (gs.n_grids <= 1) return LaneGrid{starts, n_starts0};
+    if (LDS) {
+        const uint32_t gb = gu_block_grid(gs);
+        return LaneGrid{starts + (int64_t)gb * gs.max_starts, (uint32_t)gs.n_starts[gb]};
+    }
     const uint32_t g = e / (uint32_t)gs.group;
     m.f += (int64_t)g * gs.grid_stride;
     m.r += (int64_t)g * gs.grid_stride;
@@ -142,7 +155,7 @@ template <bool LDS>
 __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem);
+    CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem, a.gs);
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.N) return;
     const LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, (uint32_t)e, m);
@@ -188,7 +201,7 @@ template <int POLICY, int AUTO, bool TRAJ, bool STATS, bool LDS>
 __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem);
+    CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem, a.gs);
     const uint8_t *greedy = a.greedy;
     if (LDS && POLICY == GU_POLICY_GREEDY) {
         uint8_t *dst = smem + 2 * a.cell_bytes;
@@ -378,7 +391,7 @@ template <bool LDS>
 __global__ void __launch_bounds__(GU_BLOCK) gu_lookahead_kernel(const LookArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const CellMap m = gu_stage_map<LDS>(a.cell_move, a.cell_bytes, smem);
+    const CellMap m = gu_stage_map<LDS>(a.cell_move, a.cell_bytes, smem, GridSel{0, 0, nullptr, 1, 0});
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     int32_t s = a.states[i];
@@ -438,6 +451,16 @@ __global__ void __launch_bounds__(1024) gu_done_compact_kernel(const uint64_t *_
 // ------------------------------------------------------------------------------------
 static inline unsigned gu_blocks(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
+// Largest block size <= preferred for which every block uses one grid (0 = none: use the L2 variant)
+static int gu_lds_block(const gu_engine *h, int preferred, int planes)
+{
+    if (h->S > GU_MAX_LDS_CELLS || (size_t)planes * h->cell_bytes > 65536) return 0;
+    if (h->n_grids == 1) return preferred;
+    for (int bs = preferred; bs >= 64; bs >>= 1)
+        if (h->group % bs == 0) return bs;
+    return 0;
+}
+
 static int gu_rollout_block()
 {
     static int cached = 0;
@@ -463,11 +486,11 @@ int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags)
     StepArgs a{h->d_cell, h->cell_bytes, h->W, h->delta_lut, d_actions_row, h->pos(), h->reward(), h->done(),
                h->d_episode, h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags,
                gu_grid_sel(h)};
-    const dim3 grid(gu_blocks(h->N, GU_BLOCK)), block(GU_BLOCK);
-    if (h->S <= GU_MAX_LDS_CELLS && h->n_grids == 1)
-        hipLaunchKernelGGL(gu_step_kernel<true>, grid, block, 2 * (size_t)h->cell_bytes, h->stream, a);
+    const int lds_bs = gu_lds_block(h, GU_BLOCK, 2);
+    if (lds_bs)
+        hipLaunchKernelGGL(gu_step_kernel<true>, dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), 2 * (size_t)h->cell_bytes, h->stream, a);
     else
-        hipLaunchKernelGGL(gu_step_kernel<false>, grid, block, 0, h->stream, a);
+        hipLaunchKernelGGL(gu_step_kernel<false>, dim3(gu_blocks(h->N, GU_BLOCK)), dim3(GU_BLOCK), 0, h->stream, a);
     GU_HIP(hipGetLastError());
     h->steps_taken += 1;
     return GU_OK;
@@ -476,13 +499,13 @@ int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags)
 template <int POLICY, int AUTO, bool TRAJ, bool STATS>
 static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
 {
-    const dim3 grid(gu_blocks(h->N, bs)), block(bs);
     const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
-    const bool lds = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && (size_t)planes * h->cell_bytes <= 65536;
-    if (lds)
-        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, true>), grid, block, (size_t)planes * h->cell_bytes, h->stream, a);
+    const int lds_bs = gu_lds_block(h, bs, planes);
+    if (lds_bs)
+        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, true>), dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs),
+                           (size_t)planes * h->cell_bytes, h->stream, a);
     else
-        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, false>), grid, block, 0, h->stream, a);
+        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, false>), dim3(gu_blocks(h->N, bs)), dim3(bs), 0, h->stream, a);
 }
 
 template <int POLICY, int AUTO>

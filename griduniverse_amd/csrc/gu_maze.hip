@@ -137,10 +137,9 @@ extern "C" int gu_generate_mazes(gu_handle h, int32_t n_grids, int32_t W, int32_
     GU_REQUIRE(h->env_id0 % group == 0, GU_ERR_INVALID, "env_id0 must be a multiple of the group size %lld", (long long)group);
     const int32_t S = W * H, cell_bytes = (S + 15) & ~15, rooms_max = ((W + 1) / 2) * ((H + 1) / 2) + 1;
     GU_REQUIRE(2 * (int64_t)cell_bytes * n_grids < (1ll << 31), GU_ERR_UNSUPPORTED, "%d grids of %d cells exceed 2 GiB of records", n_grids, S);
-    std::vector<uint8_t> zero_planes;  // allocate + set metadata through the common path, then fill on the device
+    std::vector<uint8_t> no_planes;  // allocate + set metadata through the common path; planes are filled on the device
     std::vector<int32_t> st((size_t)n_grids, 0), ns((size_t)n_grids, 1);
-    zero_planes.assign(2 * (size_t)cell_bytes * n_grids, 0);
-    rc = gu_install_grids(h, n_grids, W, H, zero_planes, zero_planes, st, ns, 1);
+    rc = gu_install_grids(h, n_grids, W, H, no_planes, no_planes, st, ns, 1);
     if (rc != GU_OK) return rc;
     h->has_grid = false;
     const size_t wall_bytes = ((size_t)n_grids * S + 15) & ~(size_t)15, stack_bytes = ((size_t)n_grids * rooms_max * 2 + 15) & ~(size_t)15;

@@ -127,6 +127,23 @@ def mc_bench(N=4096, T=1000):
             'episodes_per_s': N / (t2 - t0)}
 
 
+def maze_bench():
+    out = {'config': 'on-device maze generation + rollout on per-group distinct 32x32 mazes'}
+    N, T = 65536, 1000
+    for n_grids in (65536, 1024, 64):
+        eng = gua.Engine(N, gua.GridSpec(32, 32, [0], [1023], [], []), seed=1)
+        t0 = time.perf_counter()
+        eng.generate_mazes(n_grids, 32, 32, 7)
+        dt = time.perf_counter() - t0
+        eng.reset()
+        eng.reserve_trajectory(T)
+        wall, dev = timed(eng, lambda: eng.rollout(T, 'uniform', True, True), 5)
+        out['G%d' % n_grids] = {'generate_s': dt, 'mazes_per_s': n_grids / dt, 'rollout_traj_steps_per_s': N * T * 5 / wall,
+                                'rollout_traj_GBps_12B': 12 * N * T * 5 / dev / 1e9}
+        eng.close()
+    return out
+
+
 def main():
     res = []
     res.append(paths('c2 open 8x8', gua.GridUniverseEnv(grid_shape=(8, 8)), 4096))
@@ -135,6 +152,7 @@ def main():
     res.append(paths('c3 grid at 1M envs', maze(32, 32, 123), 1 << 20, T=250, reps=10))
     res.append(config5())
     res.append(mc_bench())
+    res.append(maze_bench())
     text = json.dumps(res, indent=1)
     print(text)
     if len(sys.argv) > 1:

@@ -19,7 +19,7 @@ GU_OK = 0
 ERR_NAMES = {-1: 'GU_ERR_INVALID', -2: 'GU_ERR_HIP', -3: 'GU_ERR_NOMEM', -4: 'GU_ERR_STATE',
              -5: 'GU_ERR_COMM', -6: 'GU_ERR_UNSUPPORTED'}
 
-F_AUTO_RESET, F_TRAJECTORY, F_STATS = 1, 2, 4
+F_AUTO_RESET, F_TRAJECTORY, F_STATS, F_PINNED_IO = 1, 2, 4, 8
 POLICY_UNIFORM, POLICY_STREAM, POLICY_GREEDY, POLICY_SAMPLE = 0, 1, 2, 3
 COMM_ID_BYTES = 128
 
@@ -60,6 +60,8 @@ SIGNATURES = {
     'gu_vi_get': [_vp, _vp, _vp],
     'gu_vi_sweep_step': [_vp, _f64, _u32, _vp],
     'gu_mc_evaluate': [_vp, _i64, _vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp],
+    'gu_host_alloc': [_c.c_size_t, _c.POINTER(_vp)],
+    'gu_host_free': [_vp],
     'gu_sync': [_vp],
     'gu_timer_begin': [_vp],
     'gu_timer_end': [_vp, _c.POINTER(_c.c_float)],
@@ -122,6 +124,29 @@ def device_count():
 
 def ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class PinnedArray(object):
+    """numpy array living in page-locked host memory (gu_host_alloc); freed with the object."""
+
+    def __init__(self, shape, dtype=np.int32):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._ptr = ctypes.c_void_p()
+        check(load().gu_host_alloc(max(self.nbytes, 1), ctypes.byref(self._ptr)))
+        buf = (ctypes.c_char * max(self.nbytes, 1)).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self._ptr is not None and self._ptr.value:
+            self.array = None
+            load().gu_host_free(self._ptr)
+            self._ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def as_array(a, dtype, shape=None, name='array'):

@@ -368,13 +368,29 @@ int gu_step(gu_handle h, const int32_t *actions, uint32_t flags, int32_t *obs, i
     GU_ENTER(h);
     GU_NEED_GRID(h);
     GU_REQUIRE(actions != nullptr, GU_ERR_INVALID, "actions is NULL");
-    GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_step accepts only GU_F_AUTO_RESET");
+    GU_REQUIRE((flags & ~(GU_F_AUTO_RESET | GU_F_PINNED_IO)) == 0, GU_ERR_INVALID, "gu_step accepts only GU_F_AUTO_RESET | GU_F_PINNED_IO");
+    const bool direct = flags & GU_F_PINNED_IO;
+    flags &= GU_F_AUTO_RESET;
     const size_t n = (size_t)h->N;
     for (size_t i = 0; i < n; ++i)
         GU_REQUIRE((uint32_t)actions[i] < 4u, GU_ERR_INVALID, "action %d of env %zu outside 0..3", actions[i], i);
     int rc = gu_ensure_scratch(h, n * 5 + 16);
     if (rc != GU_OK) return rc;
     int32_t *d_act = (int32_t *)h->d_scratch;
+    if (direct) {  // caller's buffers are page-locked: DMA straight from / into them
+        GU_HIP(hipMemcpyAsync(d_act, actions, n * 4, hipMemcpyHostToDevice, h->stream));
+        rc = gu_launch_step(h, d_act, flags);
+        if (rc != GU_OK) return rc;
+        if (obs && reward == obs + n && done == reward + n) {  // one [3][N] host block: one DMA
+            GU_HIP(hipMemcpyAsync(obs, h->d_out3, 3 * n * 4, hipMemcpyDeviceToHost, h->stream));
+        } else {
+            if (obs) GU_HIP(hipMemcpyAsync(obs, h->pos(), n * 4, hipMemcpyDeviceToHost, h->stream));
+            if (reward) GU_HIP(hipMemcpyAsync(reward, h->reward(), n * 4, hipMemcpyDeviceToHost, h->stream));
+            if (done) GU_HIP(hipMemcpyAsync(done, h->done(), n * 4, hipMemcpyDeviceToHost, h->stream));
+        }
+        GU_HIP(hipStreamSynchronize(h->stream));
+        return GU_OK;
+    }
     memcpy(h->h_pin, actions, n * 4);  // pinned staging keeps the H2D copy asynchronous
     GU_HIP(hipMemcpyAsync(d_act, h->h_pin, n * 4, hipMemcpyHostToDevice, h->stream));
     rc = gu_launch_step(h, d_act, flags);
@@ -607,6 +623,21 @@ int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int3
     if (next) GU_HIP(hipMemcpy(next, d + 2 * n, bytes, hipMemcpyDeviceToHost));
     if (reward) GU_HIP(hipMemcpy(reward, d + 3 * n, bytes, hipMemcpyDeviceToHost));
     if (done) GU_HIP(hipMemcpy(done, d + 4 * n, bytes, hipMemcpyDeviceToHost));
+    return GU_OK;
+}
+
+// ---------------------------------------------------------------------------------- pinned host memory
+int gu_host_alloc(size_t bytes, void **ptr)
+{
+    GU_REQUIRE(ptr != nullptr && bytes > 0, GU_ERR_INVALID, "ptr is NULL or bytes == 0");
+    *ptr = nullptr;
+    GU_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return GU_OK;
+}
+
+int gu_host_free(void *ptr)
+{
+    if (ptr) GU_HIP(hipHostFree(ptr));
     return GU_OK;
 }
 

@@ -27,6 +27,7 @@ class Engine(object):
         self.device = int(device)
         check(self.lib.gu_create(self.device, self.N, self.env_id0, ctypes.byref(self._h)))
         self.spec = None
+        self._pinned = {}
         try:
             self.set_grid(spec)
             self.seed(seed)
@@ -36,6 +37,9 @@ class Engine(object):
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
+        for p in getattr(self, '_pinned', {}).values():
+            p.free()
+        self._pinned = {}
         if getattr(self, '_h', None) is not None and self._h.value:
             self.lib.gu_destroy(self._h)
             self._h = ctypes.c_void_p()
@@ -115,6 +119,27 @@ class Engine(object):
         check(self.lib.gu_step(self._h, ptr(a), _lib.F_AUTO_RESET if auto_reset else 0, ptr(obs), ptr(rew), ptr(don)))
         return obs, rew, don
 
+    def _pin(self, key, shape, dtype=np.int32):
+        p = self._pinned.get(key)
+        if p is None or p.array.shape != tuple(shape):
+            if p is not None:
+                p.free()
+            p = self._pinned[key] = _lib.PinnedArray(tuple(shape), dtype)
+        return p.array
+
+    @property
+    def pinned_actions(self):
+        """int32[N] page-locked action buffer: fill it in place, then call step_pinned()."""
+        return self._pin('act', (self.N,))
+
+    def step_pinned(self, auto_reset=False):
+        """gu_step on the engine's page-locked buffers (no bounce copies).  Returns views that stay
+        valid -- and are overwritten -- until the next step_pinned()."""
+        a, out = self.pinned_actions, self._pin('out', (3, self.N))
+        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | _lib.F_PINNED_IO
+        check(self.lib.gu_step(self._h, ptr(a), flags, ptr(out[0]), ptr(out[1]), ptr(out[2])))
+        return out[0], out[1], out[2]
+
     def upload_actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.int32)
         if a.ndim != 2 or a.shape[1] != self.N:
@@ -141,8 +166,14 @@ class Engine(object):
                 (_lib.F_STATS if stats else 0)
         check(self.lib.gu_rollout(self._h, int(T), _POLICIES[policy], flags))
 
-    def read_trajectory(self, t0, T):
-        obs, rew, don = (np.empty((T, self.N), np.int32) for _ in range(3))
+    def read_trajectory(self, t0, T, pinned=False):
+        """Rows t0..t0+T-1 of the trajectory as obs/reward/done int32[T, N].  pinned=True returns views of
+        page-locked buffers owned by the engine (full PCIe rate; overwritten by the next pinned read)."""
+        if pinned:
+            buf = self._pin('traj', (3, T, self.N))
+            obs, rew, don = buf[0], buf[1], buf[2]
+        else:
+            obs, rew, don = (np.empty((T, self.N), np.int32) for _ in range(3))
         check(self.lib.gu_read_trajectory(self._h, int(t0), int(T), ptr(obs), ptr(rew), ptr(don)))
         return dict(obs=obs, reward=rew, done=don)
 

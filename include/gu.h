@@ -47,6 +47,8 @@ extern "C" {
 #define GU_F_AUTO_RESET 1u  /* harness `if done: env.reset()` applied before the next step */
 #define GU_F_TRAJECTORY 2u  /* write (obs,reward,done)[t][env] for every step              */
 #define GU_F_STATS 4u       /* per-env sum of rewards and finished-episode count           */
+#define GU_F_PINNED_IO 8u   /* gu_step: the caller's buffers are page-locked (gu_host_alloc): DMA them
+                               directly instead of bouncing through the library's staging buffer */
 
 /* gu_rollout policy kinds */
 #define GU_POLICY_UNIFORM 0 /* a ~ U{0..3} from the per-env counter RNG (stream 0)           */
@@ -187,6 +189,12 @@ int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta);
 int gu_mc_evaluate(gu_handle h, int64_t T, const int32_t *first_state, int32_t every_visit, int32_t incremental_mean,
                    int32_t stationary_env, double alpha, const double *discount_pow, const uint8_t *keep,
                    double *value_out, double *visits_out);
+
+/* ---- page-locked host memory -----------------------------------------------------
+ * Buffers from gu_host_alloc make gu_step (with GU_F_PINNED_IO), gu_read_outputs and gu_read_trajectory copy at
+ * the full PCIe rate; numpy arrays can be built on them (np.ctypeslib / np.frombuffer). */
+int gu_host_alloc(size_t bytes, void **ptr);
+int gu_host_free(void *ptr);
 
 /* ---- stream / timing -----------------------------------------------------------
  * HIP events on the handle's own stream (torch.cuda.Event cannot see it). */

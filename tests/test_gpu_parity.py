@@ -514,3 +514,24 @@ def test_stream_rollout_all_lengths():
                         assert np.array_equal(got[k], want[k]), (T, k)
                 obs, rew, don = eng.read_outputs()
                 assert np.array_equal(obs, st.pos) and np.array_equal(don, st.done), T
+
+
+def test_pinned_io_paths():
+    """GU_F_PINNED_IO step and pinned trajectory reads give the same bytes as the bounce-buffer paths."""
+    meta, z = G.load_traj('c4_lava32')
+    T, N = z['actions'].shape
+    with fresh(meta) as a, fresh(meta) as b:
+        a.reset()
+        b.reset()
+        for t in range(40):
+            b.pinned_actions[:] = z['actions'][t]
+            o2, r2, d2 = b.step_pinned(auto_reset=True)
+            o1, r1, d1 = a.step(z['actions'][t], auto_reset=True)
+            assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
+            assert np.array_equal(o2, z['obs'][t])
+        for eng in (a, b):
+            eng.reserve_trajectory(100)
+            eng.rollout(100, 'uniform', True)
+        x, y = a.read_trajectory(0, 100), b.read_trajectory(0, 100, pinned=True)
+        for k in x:
+            assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k][40:140])

@@ -51,6 +51,14 @@ def paths(name, template, N, T=1000, reps=20):
         eng.rollout(T, 'uniform', True, True)
         eng.read_trajectory(0, T)
     out['rollout_traj_plus_D2H_steps_per_s'] = N * T * 3 / (time.perf_counter() - t0)
+    eng.read_trajectory(0, T, pinned=True)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.rollout(T, 'uniform', True, True)
+        eng.read_trajectory(0, T, pinned=True)
+    dt = time.perf_counter() - t0
+    out['rollout_traj_plus_pinned_D2H_steps_per_s'] = N * T * 3 / dt
+    out['pinned_D2H_GBps'] = 12 * N * T * 3 / dt / 1e9
     # device-resident action stream
     Ts = 256
     acts = np.random.RandomState(0).randint(0, 4, (Ts, N)).astype(np.int32)
@@ -78,6 +86,13 @@ def paths(name, template, N, T=1000, reps=20):
     dt = time.perf_counter() - t0
     out['step_host_steps_per_s'] = N * n_host / dt
     out['step_host_us_per_call'] = dt / n_host * 1e6
+    t0 = time.perf_counter()
+    for t in range(n_host):
+        eng.pinned_actions[:] = acts[t % Ts]
+        eng.step_pinned(True)
+    dt = time.perf_counter() - t0
+    out['step_pinned_steps_per_s'] = N * n_host / dt
+    out['step_pinned_us_per_call'] = dt / n_host * 1e6
     eng.close()
     return out
 

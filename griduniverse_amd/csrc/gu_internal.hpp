@@ -14,12 +14,16 @@
 //                        i.e. NOT (grid edge (env:51-54) | wall at the candidate cell (env:149)
 //                        | -- in the "absorbing" map only -- the cell itself is terminal (env:145-146))
 //             bit  4     is_terminal(cell)            (env:163-168)
+//             bits 5, 6  reward_matrix[cell] == +10 / == -10 (redundant with the reward plane; lets a kernel
+//                        that keeps a PRIVATE copy of the flags plane per lane do without the second plane)
 //   reward[s] int8       reward_matrix[cell]: -1, +10 or -10   (env:80-90)
 // so that one env-step is   s += OPEN[a] * delta[a];  flags = F[s];  reward = R[s];  done = TERM.
 // Device layout: one buffer [flags: cell_bytes | reward: cell_bytes], cell_bytes = S rounded up to 16.
 #define GU_CELL_OPEN_MASK 0x0Fu
 #define GU_CELL_TERM 0x10u
 #define GU_CELL_TERM_BIT 4
+#define GU_CELL_RPLUS 0x20u
+#define GU_CELL_RMINUS 0x40u
 
 #define GU_MAX_LDS_CELLS 32767 /* both planes of grids up to 32 767 cells (64 KiB) are LDS-resident; larger read L2 */
 

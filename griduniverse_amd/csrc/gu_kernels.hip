@@ -86,6 +86,11 @@ __device__ __forceinline__ int32_t gu_delta(uint32_t a, uint64_t lut, int32_t W)
     return (a & 1u) ? -sign : sign * W;
 }
 
+__device__ __forceinline__ int32_t gu_reward_packed(uint32_t flags)
+{
+    return (flags & GU_CELL_RMINUS) ? -10 : ((flags & GU_CELL_RPLUS) ? 10 : -1);
+}
+
 __device__ __forceinline__ int32_t gu_move(int32_t s, uint32_t flags, uint32_t a, int32_t delta)
 {
     return __mul24((int32_t)__builtin_amdgcn_ubfe(flags, a, 1), delta) + s;  // v_bfe_u32 + v_mad_i32_i24
@@ -197,9 +202,15 @@ struct RolloutArgs {
 
 // AUTO: 0 = no reset; 1 = auto-reset, single start cell (branch-free select);
 //       2 = auto-reset, several start cells (RNG stream 1, rare divergent branch)
-template <int POLICY, int AUTO, bool TRAJ, bool STATS, bool LDS>
+// MAP : 0 = records read from L2 (any grid size, any grid-per-env assignment)
+//       1 = the block's grid staged in LDS, shared by its lanes
+//       2 = every lane keeps a PRIVATE copy of its own grid's flags plane in LDS (multi-grid engines whose groups
+//           do not align with blocks, e.g. one maze per env; 64-lane blocks, S16 + 16 bytes per lane)
+#define GU_PRIVATE_PAD 16
+template <int POLICY, int AUTO, bool TRAJ, bool STATS, int MAP>
 __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs a)
 {
+    constexpr bool LDS = MAP == 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem, a.gs);
     const uint8_t *greedy = a.greedy;
@@ -213,7 +224,13 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
     const int64_t e64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e64 >= a.N) return;
     const uint32_t e = (uint32_t)e64;
-    const LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, e, m);
+    LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, e, m);
+    if (MAP == 2) {  // copy this lane's own flags plane (which also carries the reward code) into its LDS slice
+        uint8_t *mine = smem + threadIdx.x * (a.cell_bytes + GU_PRIVATE_PAD);
+        for (int32_t i = 0; i < a.cell_bytes; i += 16)
+            *reinterpret_cast<uint4 *>(mine + i) = *reinterpret_cast<const uint4 *>(m.f + i);
+        m.f = mine;
+    }
 
     int32_t s = a.pos[e];
     int32_t r = a.reward[e];
@@ -260,9 +277,9 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
                 flags = m.f[s];
             }
         }
-        s = gu_move(s, flags, act, gu_delta<LDS>(act, lut, W));
+        s = gu_move(s, flags, act, gu_delta<MAP != 0>(act, lut, W));
         flags = m.f[s];
-        r = m.r[s];
+        r = (MAP == 2) ? gu_reward_packed(flags) : (int32_t)m.r[s];
         d = __builtin_amdgcn_ubfe(flags, GU_CELL_TERM_BIT, 1);
         if (STATS) {
             ret += r;
@@ -501,11 +518,22 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
 {
     const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
     const int lds_bs = gu_lds_block(h, bs, planes);
-    if (lds_bs)
-        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, true>), dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs),
+    if (lds_bs) {
+        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 1>), dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs),
                            (size_t)planes * h->cell_bytes, h->stream, a);
-    else
-        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, false>), dim3(gu_blocks(h->N, bs)), dim3(bs), 0, h->stream, a);
+        return;
+    }
+    if constexpr (POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM) {
+        // misaligned multi-grid engine (e.g. one maze per env): private per-lane copies in LDS if 64 of them fit
+        const size_t priv = 64 * ((size_t)h->cell_bytes + GU_PRIVATE_PAD);
+        if (h->n_grids > 1 && h->W <= 32767 && priv <= 160 * 1024) {
+            auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 2>;
+            if (priv > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv);
+            hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, 64)), dim3(64), priv, h->stream, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 0>), dim3(gu_blocks(h->N, bs)), dim3(bs), 0, h->stream, a);
 }
 
 template <int POLICY, int AUTO>

@@ -156,3 +156,35 @@ def test_greedy_rollout_follows_value_iteration_policy():
         want = C.rollout(grid, 1, st, 1, False, actions=acts[st.pos][None, :])
         assert np.array_equal(got['obs'][t], want['obs'][0]) and np.array_equal(got['done'][t], want['done'][0])
     assert got['done'][-1].all(), 'greedy agents did not reach the goal'
+
+
+def test_breadth_first_search_paths():
+    """algorithms.maze_solving: the path it returns is executable on the env, ends in a terminal state, and is as
+    short as the value-iteration optimum (every step costs -1, so -return + 10 == path length on goal paths)."""
+    import random
+    from griduniverse_amd.algorithms import maze_solving
+    for k in (1, 2, 3):
+        random.seed(k)
+        np.random.seed(k)
+        env = gua.GridUniverseEnv(grid_shape=(15, 15), random_maze=True)  # the size the reference script uses (:20)
+        path = maze_solving.breadth_first_search(env)
+        env.reset()
+        for i, a in enumerate(path):
+            obs, reward, done, _ = env.step(a)
+            assert done == (i == len(path) - 1)
+        assert done and obs in env.goal_states
+        dist = {env.initial_state: 0}
+        todo = [env.initial_state]
+        graph = maze_solving.create_graph(env)
+        while todo:  # independent BFS distance
+            s = todo.pop(0)
+            for c in graph[s]:
+                if c not in dist:
+                    dist[c] = dist[s] + 1
+                    todo.append(c)
+        assert len(path) == dist[env.goal_states[0]]
+        env.close()
+    env = gua.GridUniverseEnv(grid_shape=(5, 5), lava_states=[2], walls=[6, 7, 8])  # lava is terminal too (:140)
+    assert maze_solving.breadth_first_search(env) == [1, 1]
+    env = gua.GridUniverseEnv(grid_shape=(3, 3), walls=[5, 7])
+    assert maze_solving.breadth_first_search(env) is None

@@ -535,3 +535,36 @@ def test_pinned_io_paths():
         x, y = a.read_trajectory(0, 100), b.read_trajectory(0, 100, pinned=True)
         for k in x:
             assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k][40:140])
+
+
+def test_long_run_counters_and_graph_reseed():
+    """20 000 steps per env in uneven chunks (RNG word counters far beyond the golden horizons), then the
+    hipGraph step path before and after a reseed on a multi-start level (the captured launches carry the seed)."""
+    meta, _ = G.load_traj('multistart_test_env')
+    grid = C.Grid.from_lists(**meta)
+    N = 4096
+    st = C.State(N)
+    C.reset(grid, 1234567, st)
+    with Engine(N, spec_of(meta), seed=1234567) as eng:
+        eng.reset()
+        total = 0
+        for chunk in (4999, 1, 8000, 7000):
+            want = C.rollout(grid, 1234567, st, chunk, True, trajectory=False, stats=True)
+            eng.rollout(chunk, 'uniform', True, trajectory=False, stats=True)
+            ret, eps = eng.read_stats()
+            assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes']), chunk
+            total += chunk
+        s = eng.get_state()
+        assert np.array_equal(s['pos'], st.pos) and np.array_equal(s['episode'], st.episode) and np.all(s['tcount'] == total)
+        acts = np.random.RandomState(3).randint(0, 4, (32, N)).astype(np.int32)
+        eng.upload_actions(acts)
+        for seed in (1234567, 42):
+            eng.seed(seed)
+            st = C.State(N)
+            C.reset(grid, seed, st)
+            eng.reset()
+            for rep in range(2):  # second replay reuses the cached graph
+                eng.step_graph(0, 32, auto_reset=True)
+                C.rollout(grid, seed, st, 32, True, actions=acts, trajectory=False)
+                s = eng.get_state()
+                assert np.array_equal(s['pos'], st.pos) and np.array_equal(s['episode'], st.episode), (seed, rep)

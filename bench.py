@@ -95,7 +95,7 @@ def cpu_baseline(template, seed, T, gpu_rows, budget_s=12.0):
     return dict(value=py_rate, unit='env-steps/s', cores=1, kind='port',
                 sample='%d per-instance Python envs (oracle/ref_env.py) stepped round-robin with reset-on-done for '
                        '%.0f s on one core, same grid and action stream as the GPU run; this port runs at 1.02x the real reference '
-                       'step() on a common host (BASELINE.md, tools/calibrate_cpu.py)' % (n_inst, budget_s),
+                       'step() on a common host (BASELINE.md, tests/golden/calibrate_cpu.py)' % (n_inst, budget_s),
                 c_oracle_value=c_rate, c_oracle_sample='%d envs x %d steps, scalar C (oracle/gu_oracle.c), 1 core' % (n_c, T),
                 host_cpu_count=os.cpu_count()), exact
 

@@ -13,7 +13,7 @@ Rules (enforced by tests/test_layout.py):
 
 Parity status: PINNED.  Every function here is checked against golden vectors
 captured from the real reference imported in the build container
-(`tools/make_golden.py` -> `tests/golden/`), including the reference's own ten
+(`tests/golden/make_golden.py` -> `tests/golden/`), including the reference's own ten
 known-answer tests (`tests/test_griduniverse.py`).  See tests/test_oracle_*.py.
 
 The reference is pure Python, so there is nothing to compile into

@@ -7,7 +7,7 @@ is (a) the semantic oracle for the HIP kernels and (b) the "port" CPU baseline
 that bench.py times on the GPU box, where the reference itself cannot travel.
 
 Pinned against golden vectors captured from the real reference
-(tools/make_golden.py -> tests/golden/*.json|npz) by tests/test_oracle_env.py.
+(tests/golden/make_golden.py -> tests/golden/*.json|npz) by tests/test_oracle_env.py.
 """
 import random
 import sys

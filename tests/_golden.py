@@ -1,5 +1,5 @@
 """Loaders for the committed golden fixtures (captured from the real reference by
-tools/make_golden.py; data only)."""
+tests/golden/make_golden.py; data only)."""
 import glob
 import json
 import os

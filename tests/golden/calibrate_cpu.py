@@ -11,7 +11,7 @@ import time
 os.environ.setdefault('MPLBACKEND', 'Agg')
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
-REPO = os.path.dirname(HERE)
+REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [os.path.join(HERE, 'gym_stub'), os.environ.get('GU_REFERENCE', '/root/reference'), REPO]
 import numpy as np  # noqa: E402
 from core.envs.griduniverse_env import GridUniverseEnv  # noqa: E402

@@ -2,12 +2,12 @@
 """Capture golden vectors from the REAL reference (TheMTank/GridUniverse).
 
 Runs only in the build container, where /root/reference is mounted.  It imports
-the reference under the stub `gym` in tools/gym_stub (the reference's only missing
+the reference under the stub `gym` in tests/golden/gym_stub (the reference's only missing
 dependency; none of gym's arithmetic is on the path) and writes DATA fixtures
 (inputs + expected outputs) to tests/golden/.  Nothing of the reference's source
 is copied; the fixtures are what the oracle and the HIP kernels are pinned to.
 
-    python tools/make_golden.py            # regenerate everything (~2-3 min)
+    python tests/golden/make_golden.py            # regenerate everything (~2-3 min)
 
 Random-action streams come from the build's own counter RNG (oracle/gu_rng.py,
 a restatement of MurmurHash3) and are stored IN the fixtures, so the fixtures
@@ -28,7 +28,7 @@ import warnings
 os.environ.setdefault('MPLBACKEND', 'Agg')
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
-REPO = os.path.dirname(HERE)
+REPO = os.path.dirname(os.path.dirname(HERE))
 REF = os.environ.get('GU_REFERENCE', '/root/reference')
 sys.path[:0] = [os.path.join(HERE, 'gym_stub'), REF, REPO]
 
@@ -43,7 +43,7 @@ from core.algorithms import utils as ref_utils  # noqa: E402
 from core.algorithms import dynamic_programming as ref_dp  # noqa: E402
 from oracle import gu_rng  # noqa: E402
 
-OUT = os.path.join(REPO, 'tests', 'golden')
+OUT = HERE
 LEVELS = os.path.join(REF, 'core', 'envs', 'maze_text_files')
 
 

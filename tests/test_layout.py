@@ -28,12 +28,27 @@ def test_oracle_use_in_entry_points_is_confined():
     assert code_uses and all(start < u < end for u in code_uses), 'bench.py may import oracle only inside cpu_baseline()'
 
 
+# the fixture generators: run only in the build container, where the reference is mounted
+GENERATORS = ('tests/golden/make_golden.py', 'tests/golden/calibrate_cpu.py')
+
+
 def test_nothing_on_the_gpu_box_reads_the_reference():
     for path in list(_py_files('griduniverse_amd')) + list(_py_files('tests')) + list(_py_files('oracle')) + \
-            [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]:
-        if path.endswith('test_layout.py'):
+            list(_py_files('tools')) + [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]:
+        if path.endswith('test_layout.py') or path.replace(os.sep, '/').endswith(GENERATORS):
             continue
         assert '/root/reference' not in open(path).read(), path
+
+
+def test_only_tests_bench_and_smoke_touch_the_oracle():
+    """oracle/ may be imported from tests/ (incl. the fixture generators), from smoke() and from bench.py's
+    cpu_baseline leg -- nowhere else (tools/, examples/, the package)."""
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b', re.M)
+    for sub in ('tools', 'examples', 'griduniverse_amd', 'include'):
+        for path in _py_files(sub):
+            assert not pat.search(open(path).read()), path
+    entry = open(os.path.join(ROOT, '__graft_entry__.py')).read()
+    assert all(m.start() > entry.index('def smoke') for m in pat.finditer(entry))
 
 
 def test_oracle_header_declares_test_infrastructure():

@@ -193,7 +193,7 @@ SMALL = [n for n in G.traj_names() if n not in ('maze101',)]
 
 @pytest.mark.parametrize('name', SMALL)
 def test_trajectories_scalar_oracle(name):
-    """Per-instance Python oracle driven exactly like the reference was (tools/make_golden.py: rollout)."""
+    """Per-instance Python oracle driven exactly like the reference was (tests/golden/make_golden.py: rollout)."""
     meta, z = G.load_traj(name)
     env = _env_from_spec(meta)
     T, N = z['actions'].shape

@@ -97,7 +97,18 @@ def cpu_baseline(template, seed, T, gpu_rows, budget_s=12.0):
                        '%.0f s on one core, same grid and action stream as the GPU run; this port runs at 1.02x the real reference '
                        'step() on a common host (BASELINE.md, tests/golden/calibrate_cpu.py)' % (n_inst, budget_s),
                 c_oracle_value=c_rate, c_oracle_sample='%d envs x %d steps, scalar C (oracle/gu_oracle.c), 1 core' % (n_c, T),
-                host_cpu_count=os.cpu_count()), exact
+                host_cpu_count=os.cpu_count(), host_cpu_model=_cpu_model()), exact
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 def read_traffic():

@@ -56,6 +56,7 @@ SIGNATURES = {
     'gu_look_step_ahead': [_vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp],
     'gu_vi_set': [_vp, _vp, _vp],
     'gu_vi_sweep': [_vp, _f64, _i32, _i32, _vp],
+    'gu_vi_run': [_vp, _f64, _f64, _i32, _vp, _vp],
     'gu_vi_greedy': [_vp, _f64],
     'gu_vi_get': [_vp, _vp, _vp],
     'gu_vi_sweep_step': [_vp, _f64, _u32, _vp],

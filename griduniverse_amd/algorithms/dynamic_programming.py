@@ -14,13 +14,11 @@ def value_iteration(policy, env, value_function=None, threshold=0.00001, max_ste
     eng = engine_of(env)
     v0 = np.zeros(env.world.size) if value_function is None else value_function
     eng.vi_set(v0, policy)
-    for step_number in range(max_steps):
-        delta = eng.vi_sweep(discount_factor, 1, greedy_update=True)[0]
-        if delta < threshold:
-            break
-        if step_number == max_steps - 1:
-            warnings.warn('Value iteration did not reach the selected threshold. Finished after reaching '
-                          'the maximum {} steps'.format(step_number + 1), UserWarning)
+    # the whole loop is queued at once; `delta < threshold` is evaluated on the device after every round
+    steps, deltas = eng.vi_run(discount_factor, threshold, max_steps)
+    if steps == max_steps and max_steps > 0 and not deltas[-1] < threshold:
+        warnings.warn('Value iteration did not reach the selected threshold. Finished after reaching '
+                      'the maximum {} steps'.format(max_steps), UserWarning)
     v, pi = eng.vi_get()
     if max_steps > 0:
         policy[...] = pi

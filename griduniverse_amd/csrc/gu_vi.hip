@@ -131,12 +131,23 @@ struct ViArgs {
     const double *v, *pi;     // old
     double *v_new, *pi_new;   // new
     unsigned long long *delta_key;
+    // gu_vi_run: device-side stopping rule of value_iteration (dynamic_programming.py:22-23).
+    // ctl[0] = 1-based index of the round that met the threshold (0 = none yet), ctl[1] = rounds completed;
+    // null when the host drives the loop.  A launch of round r is a no-op iff 0 < ctl[0] < r -- comparing against
+    // the round index (not a plain flag) keeps late-starting blocks of round ctl[0]'s own greedy kernel working.
+    int32_t *ctl;
+    int32_t round;
+    double threshold;
 };
 
 template <bool LDS>
 __global__ void __launch_bounds__(VI_BLOCK) gu_vi_eval_kernel(const ViArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (a.ctl) {  // an earlier round met the threshold: the remaining launches are no-ops
+        const int32_t hit = a.ctl[0];
+        if (hit != 0 && hit < a.round) return;
+    }
     const ViMap cell = vi_stage<LDS>(a.cell, a.cell_bytes, smem);
     const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = s < a.S;
@@ -153,6 +164,10 @@ template <bool LDS>
 __global__ void __launch_bounds__(VI_BLOCK) gu_vi_greedy_kernel(const ViArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (a.ctl) {
+        const int32_t hit = a.ctl[0];
+        if (hit != 0 && hit < a.round) return;
+    }
     const ViMap cell = vi_stage<LDS>(a.cell, a.cell_bytes, smem);
     const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= a.S) return;
@@ -160,6 +175,15 @@ __global__ void __launch_bounds__(VI_BLOCK) gu_vi_greedy_kernel(const ViArgs a)
     const double *vn = a.v_new;
     vi_greedy_state(cell, a.W, a.gamma, [vn](int32_t n) { return vn[n]; }, s, row);
     *reinterpret_cast<double4 *>(a.pi_new + 4 * s) = make_double4(row[0], row[1], row[2], row[3]);
+    if (a.ctl && s == 0) {
+        // this round is complete (its delta was final before this kernel started): count it, and if
+        // delta < threshold record the round so that the launches queued behind it become no-ops.
+        const unsigned long long k = *a.delta_key;
+        unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+        const double delta = __longlong_as_double((long long)b);
+        a.ctl[1] += 1;
+        if (delta < a.threshold) a.ctl[0] = a.round;
+    }
 }
 
 // first-argmax action per state (np.argmax; examples/griduniverse_alg_examples.py:76)
@@ -290,6 +314,9 @@ static ViArgs vi_args(gu_engine *h, double gamma, unsigned long long *delta_key)
     a.v_new = h->d_v[h->vi_cur ^ 1];
     a.pi_new = h->d_pi[h->vi_cur ^ 1];
     a.delta_key = delta_key;
+    a.ctl = nullptr;
+    a.round = 0;
+    a.threshold = 0.0;
     return a;
 }
 
@@ -356,6 +383,52 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
         GU_HIP(hipStreamSynchronize(h->stream));
         for (int32_t i = 0; i < iters; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
     }
+    return GU_OK;
+}
+
+int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, int32_t *steps_done, double *deltas)
+{
+    int rc = gu_use_device(h);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
+    GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
+    const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
+    const bool lds = h->S <= GU_MAX_LDS_CELLS;
+    const size_t smem = lds ? 2 * (size_t)h->cell_bytes : 0;
+    rc = gu_ensure_scratch(h, 16);
+    if (rc != GU_OK) return rc;
+    int32_t *ctl = (int32_t *)h->d_scratch;
+    GU_HIP(hipMemsetAsync(ctl, 0, 8, h->stream));
+    int32_t done_total = 0, stop = 0;
+    const int start_cur = h->vi_cur;
+    for (int32_t base = 0; base < max_steps && !stop; base += 4096) {  // one host round trip per 4096 queued rounds
+        const int32_t n = max_steps - base < 4096 ? max_steps - base : 4096;
+        GU_HIP(hipMemsetAsync(h->d_delta, 0, (size_t)n * sizeof(unsigned long long), h->stream));
+        for (int32_t i = 0; i < n; ++i) {
+            ViArgs a = vi_args(h, gamma, (unsigned long long *)h->d_delta + i);
+            a.ctl = ctl;
+            a.round = base + i + 1;
+            a.threshold = threshold;
+            if (lds) hipLaunchKernelGGL(gu_vi_eval_kernel<true>, grid, block, smem, h->stream, a);
+            else hipLaunchKernelGGL(gu_vi_eval_kernel<false>, grid, block, 0, h->stream, a);
+            if (lds) hipLaunchKernelGGL(gu_vi_greedy_kernel<true>, grid, block, smem, h->stream, a);
+            else hipLaunchKernelGGL(gu_vi_greedy_kernel<false>, grid, block, 0, h->stream, a);
+            h->vi_cur ^= 1;
+        }
+        GU_HIP(hipGetLastError());
+        int32_t host_ctl[2] = {0, 0};
+        GU_HIP(hipMemcpyAsync(host_ctl, ctl, 8, hipMemcpyDeviceToHost, h->stream));
+        std::vector<unsigned long long> keys((size_t)n);
+        if (deltas) GU_HIP(hipMemcpyAsync(keys.data(), h->d_delta, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        GU_HIP(hipStreamSynchronize(h->stream));
+        stop = host_ctl[0] != 0;
+        if (deltas)
+            for (int32_t i = 0; i < host_ctl[1] - base && i < n; ++i) deltas[base + i] = vi_unkey(keys[(size_t)i]);
+        done_total = host_ctl[1];
+    }
+    h->vi_cur = start_cur ^ (done_total & 1);  // launches queued after the stop did not touch the tables
+    h->greedy_valid = false;
+    *steps_done = done_total;
     return GU_OK;
 }
 

@@ -225,6 +225,13 @@ class Engine(object):
         check(self.lib.gu_vi_sweep(self._h, float(gamma), int(iters), 1 if greedy_update else 0, ptr(deltas)))
         return deltas
 
+    def vi_run(self, gamma=1.0, threshold=1e-5, max_steps=1000):
+        """value_iteration's loop in one call (stopping rule on the device).  Returns (rounds done, deltas)."""
+        done = ctypes.c_int32(0)
+        deltas = np.full(max(int(max_steps), 1), np.nan)
+        check(self.lib.gu_vi_run(self._h, float(gamma), float(threshold), int(max_steps), ctypes.byref(done), ptr(deltas)))
+        return done.value, deltas[:done.value].copy()
+
     def vi_greedy(self, gamma=1.0):
         check(self.lib.gu_vi_greedy(self._h, float(gamma)))
 

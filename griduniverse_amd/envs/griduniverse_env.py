@@ -192,7 +192,8 @@ class GridUniverseEnv(object):
         eng = self._engine()
         self._push_state(eng)
         self.previous_state = self._state
-        obs, reward, done = eng.step(np.array([action % 4], dtype=np.int32))  # negative = Python list index (quirk 6)
+        eng.pinned_actions[0] = action % 4  # negative = Python list index (quirk 6)
+        obs, reward, done = eng.step_pinned()  # page-locked I/O: no bounce copies on the N = 1 path
         self._state = int(obs[0])
         self.done = bool(done[0])
         self.last_n_states.append(self.world[self._state])

@@ -188,3 +188,50 @@ def test_breadth_first_search_paths():
     assert maze_solving.breadth_first_search(env) == [1, 1]
     env = gua.GridUniverseEnv(grid_shape=(3, 3), walls=[5, 7])
     assert maze_solving.breadth_first_search(env) is None
+
+
+@pytest.mark.parametrize('name', ['maze8_s1', 'maze11_s3_g09', 'lava4x4_g095', 'maze32_s1_g099'])
+def test_vi_run_device_side_stopping(name):
+    """gu_vi_run queues max_steps rounds and stops on the device: same tables and round count as stepping one
+    round at a time from the host with the reference's `delta < threshold` rule."""
+    meta, z = G.load_dp(name)
+    S, gamma = meta['W'] * meta['H'], meta['gamma']
+    with Engine(4, spec_of(meta)) as eng:
+        for threshold, max_steps in ((1e-3, 400), (0.5, 400), (1e-3, 7), (1e9, 5), (1e-3, 0)):
+            eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+            want_steps, want_deltas = 0, []
+            for k in range(max_steps):
+                d = eng.vi_sweep(gamma, 1, greedy_update=True)[0]
+                want_steps += 1
+                want_deltas.append(d)
+                if d < threshold:
+                    break
+            v_want, pi_want = eng.vi_get()
+            eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+            steps, deltas = eng.vi_run(gamma, threshold, max_steps)
+            v, pi = eng.vi_get()
+            assert steps == want_steps and deltas.tolist() == want_deltas, (name, threshold, max_steps)
+            assert v.tobytes() == v_want.tobytes() and pi.tobytes() == pi_want.tobytes()
+            # the tables stay usable afterwards (buffer parity restored)
+            eng.vi_sweep(gamma, 1, greedy_update=True)
+
+
+def test_vi_run_on_a_grid_larger_than_the_resident_block_capacity():
+    """533 000 states = 2 083 blocks of 256 > the ~2 048 that can be resident: blocks of the stopping round's own
+    greedy kernel start after its thread 0 has recorded the stop, and must still do their work."""
+    W = H = 730
+    spec = GridSpec(W, H, [0], [W * H - 1], [W * H // 2], list(range(W + 5, W + 400)))
+    S = W * H
+    with Engine(2, spec) as eng:
+        for threshold, max_steps in ((1.5, 6), (-1.0, 3)):
+            eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+            want = 0
+            for k in range(max_steps):
+                want += 1
+                if eng.vi_sweep(1.0, 1, greedy_update=True)[0] < threshold:
+                    break
+            v_want, pi_want = eng.vi_get()
+            eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+            steps, deltas = eng.vi_run(1.0, threshold, max_steps)
+            v, pi = eng.vi_get()
+            assert steps == want and v.tobytes() == v_want.tobytes() and pi.tobytes() == pi_want.tobytes()

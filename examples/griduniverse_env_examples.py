@@ -15,7 +15,17 @@ sys.path.insert(0, ROOT)
 
 from griduniverse_amd import GridUniverseEnv, VecGridUniverse  # noqa: E402
 
-LEVELS = os.path.join(ROOT, 'tests', 'golden', 'levels')
+# a level in the reference's text format (env:253-268): o floor, # wall, G goal, L lava, x possible start
+DEMO_LEVEL = """
+x o #
+x o #
+o o #
+o o L
+o o L
+o o L
+o o o
+o G o
+"""
 
 
 def _random_agent(env, episodes, max_steps, render_every=0):
@@ -40,7 +50,11 @@ def run_default_griduniverse():
 
 def run_griduniverse_from_text_file():
     print('\n*** random agent on a level loaded from a text file ***\n')
-    _random_agent(GridUniverseEnv(custom_world_fp=os.path.join(LEVELS, 'test_env.txt')), 1, 1000, render_every=50)
+    import tempfile
+    with tempfile.NamedTemporaryFile('w', suffix='.txt', delete=False) as f:
+        f.write(DEMO_LEVEL)
+    _random_agent(GridUniverseEnv(custom_world_fp=f.name), 1, 1000, render_every=50)
+    os.unlink(f.name)
 
 
 def run_random_maze():

@@ -1,1 +1,4 @@
-from .griduniverse_env import GridUniverseEnv  # noqa: F401  (mirrors core/envs/__init__.py:1)
+"""Env classes.  `from griduniverse_amd.envs import GridUniverseEnv` mirrors the reference's package layout."""
+from . import griduniverse_env as _module
+
+GridUniverseEnv = _module.GridUniverseEnv

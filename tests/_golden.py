@@ -36,8 +36,28 @@ def load_dp(name):
     return load_npz('dp', name)
 
 
+_LEVEL_DIR = None
+
+
 def level_path(name):
-    return os.path.join(GOLDEN, 'levels', name)
+    """Path of a level text file materialised from the parsed level in levels.json (the fixtures hold the levels
+    as data -- W, H and the index lists the reference's loader produced -- not as copies of its text files)."""
+    global _LEVEL_DIR
+    if _LEVEL_DIR is None:
+        import atexit
+        import shutil
+        import tempfile
+        _LEVEL_DIR = tempfile.mkdtemp(prefix='gu_levels_')
+        atexit.register(shutil.rmtree, _LEVEL_DIR, True)
+        for fn, sp in load_json('levels.json').items():
+            glyph = {}
+            for ch, key in (('#', 'walls'), ('L', 'lava'), ('G', 'goals'), ('x', 'starts')):
+                for s in sp[key]:
+                    glyph[s] = ch
+            with open(os.path.join(_LEVEL_DIR, fn), 'w') as f:
+                for y in range(sp['H']):
+                    f.write(''.join(glyph.get(y * sp['W'] + x, 'o') for x in range(sp['W'])) + '\n')
+    return os.path.join(_LEVEL_DIR, name)
 
 
 def mc_names():

@@ -299,7 +299,6 @@ def capture_mazes_and_levels():
                                                      n_walls=len(sp['walls']), initial_state=int(env.initial_state),
                                                      rng_tail=tail)
     levels = {}
-    os.makedirs(os.path.join(OUT, 'levels'), exist_ok=True)
     for fn in sorted(os.listdir(LEVELS)):
         random.seed(7)
         env = ref_env(custom_world_fp=os.path.join(LEVELS, fn))
@@ -308,14 +307,6 @@ def capture_mazes_and_levels():
         sp['initial_state_seed7'] = int(env.initial_state)
         sp['observation_space_n'] = int(env.observation_space.n)
         levels[fn] = sp
-        # level text regenerated from the parsed grid (compact form, no blanks) so that the
-        # build's loader has the same level DATA to parse; expected parse = levels.json
-        wall, start, goal, lav = set(sp['walls']), set(sp['starts']), set(sp['goals']), set(sp['lava'])
-        with open(os.path.join(OUT, 'levels', fn), 'w') as f:
-            for y in range(sp['H']):
-                f.write(''.join('#' if (y * sp['W'] + x) in wall else 'x' if (y * sp['W'] + x) in start
-                                else 'G' if (y * sp['W'] + x) in goal else 'L' if (y * sp['W'] + x) in lav else 'o'
-                                for x in range(sp['W'])) + '\n')
     return mazes, levels
 
 

@@ -112,3 +112,68 @@ class ShardedVecGridUniverse(object):
             self.local.engine.comm_destroy()
             self._comm_ready = False
         self.local.close()
+
+
+class MultiDeviceVecGridUniverse(object):
+    """One host process driving several GPUs: one engine (handle + HIP stream) per device, contiguous env-index
+    shards, launches issued asynchronously device after device so the GPUs run concurrently.
+    No collective at all: the single-array view is assembled on the host from one D2H copy per device.
+
+    `devices` may repeat an index (e.g. [0, 0] on a one-GPU box): results do not depend on the placement."""
+
+    def __init__(self, total_envs, devices, *, seed=0, auto_reset=False, engine_factory=None, **grid_kwargs):
+        self.devices = list(devices)
+        self.total_envs = int(total_envs)
+        kw = dict(grid_kwargs)
+        if engine_factory is not None:
+            kw['engine_factory'] = engine_factory
+        first = VecGridUniverse(shard_range(total_envs, len(self.devices), 0)[1], seed=seed, device=self.devices[0],
+                                env_id0=0, auto_reset=auto_reset, **kw)
+        self.shards = [first]
+        for g, dev in enumerate(self.devices[1:], start=1):
+            id0, n = shard_range(total_envs, len(self.devices), g)
+            # every shard shares the first shard's grid (built once: random mazes must not be re-drawn per device)
+            share = {k: v for k, v in kw.items() if k == 'engine_factory'}
+            if first.template is not None:
+                self.shards.append(VecGridUniverse(n, template=first.template, seed=seed, device=dev, env_id0=id0,
+                                                   auto_reset=auto_reset, **share))
+            else:
+                self.shards.append(VecGridUniverse(n, seed=seed, device=dev, env_id0=id0, auto_reset=auto_reset, **kw))
+        self.auto_reset = bool(auto_reset)
+
+    def reset(self):
+        return np.concatenate([s.reset() for s in self.shards])
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        outs, lo = [], 0
+        for s in self.shards:
+            outs.append(s.step(actions[lo:lo + s.num_envs]))
+            lo += s.num_envs
+        return (np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]),
+                np.concatenate([o[2] for o in outs]), {})
+
+    def rollout(self, T, policy='uniform', trajectory=True, stats=False):
+        """Enqueue the fused rollout on every device first, then collect: the devices overlap."""
+        for s in self.shards:
+            if trajectory:
+                s.engine.reserve_trajectory(T)
+            s.engine.rollout(T, policy, self.auto_reset, trajectory, stats)
+        out = {}
+        if trajectory:
+            parts = [s.engine.read_trajectory(0, T) for s in self.shards]
+            out = {k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}
+        if stats:
+            parts = [s.engine.read_stats() for s in self.shards]
+            out['ret'] = np.concatenate([p[0] for p in parts])
+            out['episodes'] = np.concatenate([p[1] for p in parts])
+        return out
+
+    def view(self):
+        """(obs, reward, done) of all envs, env-major."""
+        parts = [s.engine.read_outputs() for s in self.shards]
+        return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
+
+    def close(self):
+        for s in self.shards:
+            s.close()

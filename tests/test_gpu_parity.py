@@ -568,3 +568,24 @@ def test_long_run_counters_and_graph_reseed():
                 C.rollout(grid, seed, st, 32, True, actions=acts, trajectory=False)
                 s = eng.get_state()
                 assert np.array_equal(s['pos'], st.pos) and np.array_equal(s['episode'], st.episode), (seed, rep)
+
+
+def test_one_process_several_engines_equals_one_engine():
+    """MultiDeviceVecGridUniverse with the device list [0, 0, 0, 0] (the GPU box has one device): four engines with
+    env-index shards reproduce the single-engine batch; the random maze is drawn once and shared."""
+    import random
+    from griduniverse_amd.parallel import MultiDeviceVecGridUniverse
+    random.seed(11)
+    np.random.seed(11)
+    multi = MultiDeviceVecGridUniverse(4096, [0, 0, 0, 0], seed=6, auto_reset=True, grid_shape=(16, 16), random_maze=True)
+    single = gua.VecGridUniverse(4096, template=multi.shards[0].template, seed=6, auto_reset=True)
+    assert np.array_equal(multi.reset(), single.reset())
+    a, b = multi.rollout(200, stats=True), single.rollout(200, stats=True)
+    for k in ('obs', 'reward', 'done', 'ret', 'episodes'):
+        assert np.array_equal(a[k], b[k]), k
+    acts = np.random.RandomState(0).randint(0, 4, 4096).astype(np.int32)
+    x, y = multi.step(acts), single.step(acts)
+    assert all(np.array_equal(x[i], y[i]) for i in range(3))
+    assert np.array_equal(multi.view()[0], single.observations)
+    multi.close()
+    single.close()

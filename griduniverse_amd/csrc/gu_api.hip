@@ -180,7 +180,8 @@ static void compile_planes(int32_t W, int32_t H, int32_t wpr, const uint32_t *wa
             if (x < W - 1 && !wall(x + 1, y)) open |= 2u;    // RIGHT env:52
             if (y < H - 1 && !wall(x, y + 1)) open |= 4u;    // DOWN  env:53
             if (x > 0 && !wall(x - 1, y)) open |= 8u;        // LEFT  env:54
-            const uint8_t t = (term ? GU_CELL_TERM : 0) | (rplus ? GU_CELL_RPLUS : 0) | (rminus ? GU_CELL_RMINUS : 0);
+            const uint8_t t = (term ? GU_CELL_TERM : 0) | (rplus ? GU_CELL_RPLUS : 0) | (rminus ? GU_CELL_RMINUS : 0) |
+                              (wall(x, y) ? GU_CELL_WALL : 0);
             raw[s] = open | t;
             cell[s] = (term ? 0 : open) | t;                                         // env:145-146 absorbing
             const int8_t r = rminus ? -10 : (rplus ? 10 : -1);                       // env:80-90

@@ -14,6 +14,7 @@
 //                        i.e. NOT (grid edge (env:51-54) | wall at the candidate cell (env:149)
 //                        | -- in the "absorbing" map only -- the cell itself is terminal (env:145-146))
 //             bit  4     is_terminal(cell)            (env:163-168)
+//             bit  7     the cell itself is a wall (env:157-161); used by the path search only
 //             bits 5, 6  reward_matrix[cell] == +10 / == -10 (redundant with the reward plane; lets a kernel
 //                        that keeps a PRIVATE copy of the flags plane per lane do without the second plane)
 //   reward[s] int8       reward_matrix[cell]: -1, +10 or -10   (env:80-90)
@@ -24,6 +25,7 @@
 #define GU_CELL_TERM_BIT 4
 #define GU_CELL_RPLUS 0x20u
 #define GU_CELL_RMINUS 0x40u
+#define GU_CELL_WALL 0x80u  /* the cell itself is a wall (only the path search needs it: wall nodes have no edges) */
 
 #define GU_MAX_LDS_CELLS 32767 /* both planes of grids up to 32 767 cells (64 KiB) are LDS-resident; larger read L2 */
 

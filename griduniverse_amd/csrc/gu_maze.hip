@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) gu_maze_compile_kernel(const MazeCompileA
     if (x < a.W - 1 && !wall[s + 1]) open |= 2u;
     if (y < a.H - 1 && !wall[s + a.W]) open |= 4u;
     if (x > 0 && !wall[s - 1]) open |= 8u;
-    const uint8_t t = term ? (GU_CELL_TERM | GU_CELL_RPLUS) : 0;
+    const uint8_t t = (term ? (GU_CELL_TERM | GU_CELL_RPLUS) : 0) | (wall[s] ? GU_CELL_WALL : 0);
     const int64_t base = 2 * (int64_t)a.cell_bytes * g;
     a.raw[base + s] = open | t;
     a.cell[base + s] = (term ? 0 : open) | t;

@@ -63,6 +63,7 @@ class Engine(object):
         check(self.lib.gu_set_grid(self._h, spec.W, spec.H, spec.words_per_row, ptr(p['wall']), ptr(p['goal']),
                                    ptr(p['lava']), ptr(p['rplus']), ptr(p['rminus']), ptr(starts), len(starts)))
         self.spec = spec
+        self._n_grids = 1
 
     def set_grids(self, specs):
         """Several distinct grids of one shape: env e uses specs[e // (N // len(specs))]."""
@@ -83,12 +84,14 @@ class Engine(object):
                                     ptr(n_starts), max_starts))
         self.spec = specs[0]
         self.specs = list(specs)
+        self._n_grids = len(specs)
 
     def generate_mazes(self, n_grids, W, H, maze_seed):
         """n_grids random mazes carved on the device (one per env group of N // n_grids envs)."""
         check(self.lib.gu_generate_mazes(self._h, int(n_grids), int(W), int(H), int(maze_seed) & 0xFFFFFFFFFFFFFFFF))
         self.spec = GridSpec(W, H, [0], [W * H - 1], [], [])  # shape holder; the real grids live on the device
         self.specs = None
+        self._n_grids = int(n_grids)
 
     def get_cells(self, grid_index=0):
         """(flags uint8[S], reward int8[S], starts int32[n]) of one grid as compiled on the device."""
@@ -259,6 +262,19 @@ class Engine(object):
         check(self.lib.gu_mc_evaluate(self._h, int(T), ptr(first), 1 if every_visit else 0, 1 if incremental_mean else 0,
                                       1 if stationary_env else 0, float(alpha), ptr(pw), ptr(kp), ptr(value), ptr(visits)))
         return value, visits
+
+    def shortest_paths(self, max_path=None):
+        """Breadth-first shortest path from each grid's first start cell to the first terminal state the FIFO search
+        dequeues (maze_solving.py semantics).  Returns a list with one int8 action array (or None) per grid, plus the
+        terminal states reached."""
+        G, S = self._n_grids, self.spec.S
+        max_path = int(max_path or S)
+        path = np.zeros((G, max_path), np.int8)
+        plen, term = np.zeros(G, np.int32), np.zeros(G, np.int32)
+        check(self.lib.gu_shortest_paths(self._h, max_path, ptr(path), ptr(plen), ptr(term)))
+        if (plen == -2).any():
+            raise ValueError('a path is longer than max_path={}'.format(max_path))
+        return [None if n < 0 else path[g, :n].copy() for g, n in enumerate(plen)], term
 
     # ------------------------------------------------------------------ stream / timing
     def sync(self):

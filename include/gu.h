@@ -103,7 +103,8 @@ int gu_set_grids(gu_handle h, int32_t n_grids, int32_t W, int32_t H, int32_t wor
  * core/envs/maze_generation.py:41-149 (recursive backtracker, one 'x', one 'G'), draws from RNG stream 3 keyed
  * by (maze_seed, global grid id).  Replaces n_grids x GridUniverseEnv(random_maze=True) (env:318-321). */
 int gu_generate_mazes(gu_handle h, int32_t n_grids, int32_t W, int32_t H, uint64_t maze_seed);
-/* Read back grid `grid_index` as compiled: flags[S] (OPEN bits 0-3 = move changes the position, bit 4 terminal),
+/* Read back grid `grid_index` as compiled: flags[S] (OPEN bits 0-3 = move changes the position, bit 4 terminal,
+ * bits 5-6 reward code, bit 7 the cell is a wall),
  * reward[S] (int8), and its start table (any pointer may be NULL). */
 int gu_get_cells(gu_handle h, int32_t grid_index, uint8_t *flags, int8_t *reward, int32_t *starts, int32_t *n_starts);
 
@@ -194,6 +195,13 @@ int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta);
 int gu_mc_evaluate(gu_handle h, int64_t T, const int32_t *first_state, int32_t every_visit, int32_t incremental_mean,
                    int32_t stationary_env, double alpha, const double *discount_pow, const uint8_t *keep,
                    double *value_out, double *visits_out);
+
+/* ---- shortest paths: the breadth-first search of core/algorithms/maze_solving.py:43-50, 123-193 for EVERY grid ----
+ * One lane per grid searches from the grid's first start cell over the care_about_terminal=False move graph
+ * (children in action order, FIFO), stops at the first terminal state (goal or lava) it dequeues and writes the
+ * action list.  path[n_grids][max_path] int8, path_len[n_grids] (-1 no terminal reachable, -2 longer than
+ * max_path), terminal[n_grids] (optional) the state reached. */
+int gu_shortest_paths(gu_handle h, int32_t max_path, int8_t *path, int32_t *path_len, int32_t *terminal);
 
 /* ---- page-locked host memory -----------------------------------------------------
  * Buffers from gu_host_alloc make gu_step (with GU_F_PINNED_IO), gu_read_outputs and gu_read_trajectory copy at

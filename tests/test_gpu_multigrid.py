@@ -113,3 +113,54 @@ def test_device_mazes_through_vec_env_and_errors():
             eng.generate_mazes(4, 3, 3, 1)   # no room for a corridor
         with pytest.raises(gua.GuError):
             eng.generate_mazes(5, 8, 8, 1)   # 5 does not divide 64
+
+
+def _oracle_env(spec):
+    from oracle.ref_env import OracleGridUniverseEnv
+    S = spec.S
+    return OracleGridUniverseEnv(grid_shape=(spec.W, spec.H), initial_state=list(spec.starts),
+                                 goal_states=np.flatnonzero(spec.goal).tolist(), lava_states=np.flatnonzero(spec.lava).tolist(),
+                                 walls=np.flatnonzero(spec.wall).tolist())
+
+
+def test_batched_shortest_paths_equal_the_restated_reference_search():
+    """gu_shortest_paths (one lane per grid) against oracle/bfs.py on open grids with lava / walls / several goals
+    (where FIFO tie-breaking decides the path) and on device-generated mazes (unique paths)."""
+    from oracle import bfs
+    rs = np.random.RandomState(8)
+    specs = random_specs(rs, 12, 10, 7)
+    specs[3] = GridSpec(10, 7, [0], [69], [], [1, 10, 11])   # start walled in: no terminal reachable
+    specs[5] = GridSpec(10, 7, [33], [33], [], [])           # start is terminal: empty path
+    with Engine(12 * 4, specs[0]) as eng:
+        eng.set_grids(specs)
+        paths, terms = eng.shortest_paths()
+    for g, spec in enumerate(specs):
+        want, term = bfs.breadth_first_search(_oracle_env(spec), spec.starts[0])
+        if want is None:
+            assert paths[g] is None and terms[g] == -1, g
+        else:
+            assert paths[g].tolist() == want and terms[g] == term, (g, paths[g].tolist(), want)
+    W = H = 21
+    with Engine(64, GridSpec(W, H, [0], [W * H - 1], [], []), seed=1) as eng:
+        eng.generate_mazes(64, W, H, 3)
+        paths, terms = eng.shortest_paths()
+        # following every maze's path from its start reaches its goal: feed the paths as an action stream
+        T = max(len(p) for p in paths)
+        acts = np.zeros((T, 64), np.int32)
+        for g, p in enumerate(paths):
+            acts[:len(p), g] = p
+        first = eng.reset()
+        eng.upload_actions(acts)
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'stream', auto_reset=False)
+        traj = eng.read_trajectory(0, T)
+        for g, p in enumerate(paths):
+            wall, start, goal = C.generate_maze(3, g, W, H)
+            assert first[g] == start and terms[g] == goal
+            assert traj['obs'][len(p) - 1, g] == goal and traj['done'][len(p) - 1, g] == 1
+            assert not traj['done'][:len(p) - 1, g].any()
+            if g < 6:
+                spec = GridSpec(W, H, [start], [goal], [], np.flatnonzero(wall).tolist())
+                assert p.tolist() == bfs.breadth_first_search(_oracle_env(spec), start)[0]
+        with pytest.raises(ValueError):
+            eng.shortest_paths(max_path=3)

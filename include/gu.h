@@ -156,7 +156,7 @@ int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uin
  * step kernels + one compaction kernel).  idx has room for N entries. */
 int gu_done_indices(gu_handle h, int32_t *idx, int32_t *count);
 
-/* ---- look_step_ahead table queries: env:136-155 for n (state, action) pairs ---- */
+/* ---- look_step_ahead table queries: env:136-155 for n (state, action) pairs (grid 0 of a multi-grid engine) ---- */
 int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int32_t *actions,
                        int32_t care_about_terminal, int32_t *next, int32_t *reward, int32_t *done);
 

@@ -71,6 +71,8 @@ SIGNATURES = {
     'gu_comm_init': [_vp, _i32, _i32, _vp],
     'gu_comm_destroy': [_vp],
     'gu_allgather_view': [_vp, _vp, _vp, _vp],
+    'gu_comm_init_all': [_vp, _i32],
+    'gu_allgather_view_all': [_vp, _i32, _vp, _vp, _vp],
 }
 
 

@@ -11,6 +11,7 @@
 
 #include <rccl/rccl.h>
 #include <cstring>
+#include <vector>
 
 static_assert(sizeof(ncclUniqueId) == GU_COMM_ID_BYTES, "ncclUniqueId size changed");
 
@@ -85,6 +86,65 @@ int gu_allgather_view(gu_handle h, int32_t *obs_all, int32_t *reward_all, int32_
         if (!dst[k]) continue;
         GU_HIP(hipMemcpy2D(dst[k], n * sizeof(int32_t), h->d_gather + (size_t)k * n, block * sizeof(int32_t),
                            n * sizeof(int32_t), (size_t)h->nranks, hipMemcpyDeviceToHost));
+    }
+    return GU_OK;
+}
+
+// ---- single process, several handles (one per device): ncclCommInitAll + grouped all-gather -------------------
+int gu_comm_init_all(gu_handle *handles, int32_t n)
+{
+    GU_REQUIRE(handles != nullptr && n > 0 && n <= 64, GU_ERR_INVALID, "handles is NULL or n outside 1..64");
+    std::vector<int> devs((size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+        GU_REQUIRE(handles[i] != nullptr, GU_ERR_INVALID, "handles[%d] is NULL", i);
+        GU_REQUIRE(handles[i]->N == handles[0]->N, GU_ERR_INVALID, "all shards must hold the same number of envs");
+        devs[(size_t)i] = handles[i]->device;
+        for (int32_t j = 0; j < i; ++j)
+            GU_REQUIRE(devs[(size_t)j] != devs[(size_t)i], GU_ERR_INVALID, "RCCL needs one device per rank: handles %d and %d share device %d", j, i, devs[(size_t)i]);
+    }
+    std::vector<ncclComm_t> comms((size_t)n);
+    for (int32_t i = 0; i < n; ++i) gu_comm_free(handles[i]);
+    GU_NCCL(ncclCommInitAll(comms.data(), n, devs.data()));
+    for (int32_t i = 0; i < n; ++i) {
+        gu_engine *h = handles[i];
+        h->comm = comms[(size_t)i];
+        h->nranks = n;
+        h->rank = i;
+        GU_HIP(hipSetDevice(h->device));
+        GU_HIP(hipMalloc(&h->d_gather, (size_t)n * 3 * (size_t)h->N * sizeof(int32_t)));
+    }
+    return GU_OK;
+}
+
+int gu_allgather_view_all(gu_handle *handles, int32_t n, int32_t *obs_all, int32_t *reward_all, int32_t *done_all)
+{
+    GU_REQUIRE(handles != nullptr && n > 0, GU_ERR_INVALID, "handles is NULL or n <= 0");
+    for (int32_t i = 0; i < n; ++i)
+        GU_REQUIRE(handles[i] && handles[i]->comm && handles[i]->nranks == n && handles[i]->rank == i, GU_ERR_STATE,
+                   "handles[%d] is not rank %d of a %d-rank communicator: call gu_comm_init_all first", i, i, n);
+    const size_t cnt = 3 * (size_t)handles[0]->N;
+    GU_NCCL(ncclGroupStart());
+    for (int32_t i = 0; i < n; ++i) {
+        gu_engine *h = handles[i];
+        ncclResult_t r = ncclAllGather(h->d_out3, h->d_gather, cnt, ncclInt32, (ncclComm_t)h->comm, h->stream);
+        if (r != ncclSuccess) {
+            (void)ncclGroupEnd();
+            return gu_fail(GU_ERR_COMM, "ncclAllGather on rank %d failed: %s", i, ncclGetErrorString(r));
+        }
+    }
+    GU_NCCL(ncclGroupEnd());
+    for (int32_t i = 0; i < n; ++i) {
+        GU_HIP(hipSetDevice(handles[i]->device));
+        GU_HIP(hipStreamSynchronize(handles[i]->stream));
+    }
+    gu_engine *h = handles[0];  // every rank now holds the full view; read it from rank 0
+    GU_HIP(hipSetDevice(h->device));
+    const size_t nn = (size_t)h->N;
+    int32_t *dst[3] = {obs_all, reward_all, done_all};
+    for (int k = 0; k < 3; ++k) {
+        if (!dst[k]) continue;
+        GU_HIP(hipMemcpy2D(dst[k], nn * sizeof(int32_t), h->d_gather + (size_t)k * nn, cnt * sizeof(int32_t),
+                           nn * sizeof(int32_t), (size_t)n, hipMemcpyDeviceToHost));
     }
     return GU_OK;
 }

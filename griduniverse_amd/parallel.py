@@ -169,8 +169,19 @@ class MultiDeviceVecGridUniverse(object):
             out['episodes'] = np.concatenate([p[1] for p in parts])
         return out
 
-    def view(self):
-        """(obs, reward, done) of all envs, env-major."""
+    def view(self, rccl=False):
+        """(obs, reward, done) of all envs, env-major.  Default: one D2H copy per device, concatenated on the host.
+        rccl=True: one grouped RCCL all-gather over xGMI (needs every shard on its own device), then one copy."""
+        if rccl:
+            import ctypes
+            from . import _lib
+            handles = (ctypes.c_void_p * len(self.shards))(*[s.engine._h for s in self.shards])
+            if not getattr(self, '_comm_all', False):
+                _lib.check(_lib.load().gu_comm_init_all(handles, len(self.shards)))
+                self._comm_all = True
+            out = [np.empty(self.total_envs, np.int32) for _ in range(3)]
+            _lib.check(_lib.load().gu_allgather_view_all(handles, len(self.shards), *[_lib.ptr(o) for o in out]))
+            return tuple(out)
         parts = [s.engine.read_outputs() for s in self.shards]
         return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
 

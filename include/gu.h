@@ -226,6 +226,10 @@ int gu_comm_unique_id(uint8_t id[GU_COMM_ID_BYTES]);
 int gu_comm_init(gu_handle h, int32_t nranks, int32_t rank, const uint8_t id[GU_COMM_ID_BYTES]);
 int gu_comm_destroy(gu_handle h);
 int gu_allgather_view(gu_handle h, int32_t *obs_all, int32_t *reward_all, int32_t *done_all);
+/* The same for ONE process that holds one handle per device (handles[i] on a distinct device, equal N):
+ * ncclCommInitAll, then one grouped ncclAllGather; the view is copied out of handles[0]'s device. */
+int gu_comm_init_all(gu_handle *handles, int32_t n);
+int gu_allgather_view_all(gu_handle *handles, int32_t n, int32_t *obs_all, int32_t *reward_all, int32_t *done_all);
 
 #ifdef __cplusplus
 }

@@ -589,3 +589,22 @@ def test_one_process_several_engines_equals_one_engine():
     assert np.array_equal(multi.view()[0], single.observations)
     multi.close()
     single.close()
+
+
+def test_single_process_rccl_view():
+    """gu_comm_init_all / gu_allgather_view_all with one handle (ncclCommInitAll over [device 0]); sharing a device
+    between ranks is refused with a message, as RCCL requires one device per rank."""
+    from griduniverse_amd.parallel import MultiDeviceVecGridUniverse
+    one = MultiDeviceVecGridUniverse(2048, [0], seed=3, auto_reset=True, grid_shape=(8, 8))
+    one.reset()
+    one.rollout(50, trajectory=False)
+    a, b = one.view(rccl=True), one.view()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    one.step(np.ones(2048, np.int32))
+    assert np.array_equal(one.view(rccl=True)[0], one.view()[0])
+    one.close()
+    two = MultiDeviceVecGridUniverse(2048, [0, 0], seed=3, grid_shape=(8, 8))
+    with pytest.raises(gua.GuError) as ei:
+        two.view(rccl=True)
+    assert 'one device per rank' in str(ei.value)
+    two.close()

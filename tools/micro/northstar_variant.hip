@@ -88,6 +88,34 @@ __global__ void __launch_bounds__(256) k_cells(const Args a)
     atomicAdd(a.checksum, sum);
 }
 
+// cells16: one interleaved 16-bit record per cell (flags | reward << 8), position kept as a byte offset (2 s):
+// ONE ds_read_u16 per step instead of two byte reads.
+template <bool TRAJ>
+__global__ void __launch_bounds__(256) k_cells16(const Args a)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t rec[S];
+    for (int i = threadIdx.x; i < S; i += blockDim.x) rec[i] = (uint16_t)(a.cells[i] | ((uint16_t)a.cells[S + i] << 8));
+    __syncthreads();
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lut = (uint64_t)(uint16_t)(int16_t)(-2 * W) | (2ull << 16) | ((uint64_t)(uint16_t)(2 * W) << 32) | ((uint64_t)(uint16_t)(int16_t)(-2) << 48);
+    int p = 2 * a.start;
+    const char *base = (const char *)rec;
+    uint32_t r16 = *(const uint16_t *)(base + p);
+    unsigned long long sum = 0;
+    uint32_t word = 0;
+    for (int t = 0; t < a.T; ++t) {
+        if ((t & 15) == 0) word = mix(e * 0x9E3779B9u + (uint32_t)(t >> 4));
+        const uint32_t act = (word >> (2 * (t & 15))) & 3u;
+        const int delta = __builtin_amdgcn_sbfe((int)(uint32_t)(lut >> (act << 4)), 0, 16);
+        p = __mul24((int)__builtin_amdgcn_ubfe(r16, act, 1), delta) + p;
+        r16 = *(const uint16_t *)(base + p);                       // the only LDS read of the step
+        const int r = __builtin_amdgcn_sbfe((int)r16, 8, 8), term = (r16 >> 4) & 1, s = p >> 1;
+        sum += (unsigned)(s * 31 + r * 7 + term) * (unsigned)(t + 1);
+        if (TRAJ) { const size_t o = (size_t)t * a.N + e; a.obs[o] = s; a.rew[o] = r; a.don[o] = term; }
+    }
+    atomicAdd(a.checksum, sum);
+}
+
 int main()
 {
     const int N = 65536, T = 1000, reps = 20;
@@ -124,18 +152,21 @@ int main()
         case 0: k_rows<true><<<g, b>>>(a); break;
         case 1: k_cells<true><<<g, b>>>(a); break;
         case 2: k_rows<false><<<g, b>>>(a); break;
-        default: k_cells<false><<<g, b>>>(a); break;
+        case 3: k_cells<false><<<g, b>>>(a); break;
+        case 4: k_cells16<true><<<g, b>>>(a); break;
+        default: k_cells16<false><<<g, b>>>(a); break;
         }
     };
-    const char *names[4] = {"rows  + trajectory", "cells + trajectory", "rows  , no trajectory", "cells , no trajectory"};
-    unsigned long long sums[4];
-    for (int w = 0; w < 4; ++w) {
+    const char *names[6] = {"rows  + trajectory", "cells + trajectory", "rows  , no trajectory", "cells , no trajectory",
+                            "cells16 + trajectory", "cells16, no trajectory"};
+    unsigned long long sums[6];
+    for (int w = 0; w < 6; ++w) {
         CK(hipMemset(dsum, 0, 8)); run(w); CK(hipDeviceSynchronize());
         CK(hipMemcpy(&sums[w], dsum, 8, hipMemcpyDeviceToHost));
     }
-    printf("checksums: rows %llu cells %llu -> %s\n", sums[0], sums[1], (sums[0] == sums[1] && sums[2] == sums[3] && sums[0] == sums[2]) ? "IDENTICAL" : "DIFFERENT");
+    printf("checksums: rows %llu cells %llu -> %s\n", sums[0], sums[1], (sums[0] == sums[1] && sums[2] == sums[3] && sums[0] == sums[2] && sums[4] == sums[0] && sums[5] == sums[0]) ? "IDENTICAL" : "DIFFERENT");
     for (int round = 0; round < 3; ++round)
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < 6; ++w) {
             run(w);
             CK(hipEventRecord(e0));
             for (int i = 0; i < reps; ++i) run(w);

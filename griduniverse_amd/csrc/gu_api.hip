@@ -378,17 +378,12 @@ int gu_step(gu_handle h, const int32_t *actions, uint32_t flags, int32_t *obs, i
     int rc = gu_ensure_scratch(h, n * 5 + 16);
     if (rc != GU_OK) return rc;
     int32_t *d_act = (int32_t *)h->d_scratch;
-    if (direct) {  // caller's buffers are page-locked: DMA straight from / into them
-        GU_HIP(hipMemcpyAsync(d_act, actions, n * 4, hipMemcpyHostToDevice, h->stream));
-        rc = gu_launch_step(h, d_act, flags);
+    if (direct) {
+        // The caller's buffers are page-locked (gu_host_alloc), i.e. mapped into the device's address space: the
+        // kernel reads the actions from them and writes the results into them itself over PCIe -- one launch and
+        // one synchronisation, no copy commands at all.
+        rc = gu_launch_step(h, actions, flags, obs, reward, done);
         if (rc != GU_OK) return rc;
-        if (obs && reward == obs + n && done == reward + n) {  // one [3][N] host block: one DMA
-            GU_HIP(hipMemcpyAsync(obs, h->d_out3, 3 * n * 4, hipMemcpyDeviceToHost, h->stream));
-        } else {
-            if (obs) GU_HIP(hipMemcpyAsync(obs, h->pos(), n * 4, hipMemcpyDeviceToHost, h->stream));
-            if (reward) GU_HIP(hipMemcpyAsync(reward, h->reward(), n * 4, hipMemcpyDeviceToHost, h->stream));
-            if (done) GU_HIP(hipMemcpyAsync(done, h->done(), n * 4, hipMemcpyDeviceToHost, h->stream));
-        }
         GU_HIP(hipStreamSynchronize(h->stream));
         return GU_OK;
     }

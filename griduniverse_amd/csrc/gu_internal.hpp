@@ -145,7 +145,8 @@ int gu_ensure_scratch(gu_engine *h, size_t bytes);
 
 // ---- kernel launchers (gu_kernels.hip) -------------------------------------------
 int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice, bool only_done);
-int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags);
+int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, int32_t *host_obs = nullptr,
+                   int32_t *host_reward = nullptr, int32_t *host_done = nullptr);
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags);
 int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const int32_t *d_actions, bool care,
                         int32_t *d_next, int32_t *d_reward, int32_t *d_done);

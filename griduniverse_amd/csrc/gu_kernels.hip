@@ -15,7 +15,7 @@
 // integer work: no MFMA, and no inter-block reuse apart from the <=64 KiB record planes that
 // every XCD's L2 holds after first touch -- so there is nothing for an XCD-aware block remap to
 // win here; the grid is N/256 four-wave workgroups (at N = 65 536 that is one workgroup per CU,
-// one wave per SIMD; measured 3 % faster than 1024 one-wave workgroups, profiles/r01_tuning.md).
+// one wave per SIMD; measured 3 % faster than 1024 one-wave workgroups, profiles/r01b_bench_blocksize.txt).
 //
 // The action -> delta LUT is four int16 lanes of one 64-bit scalar register (v_lshrrev_b64 +
 // v_bfe_i32): staging a 4-entry table in LDS instead would put a second, dependent ds_read on
@@ -154,6 +154,7 @@ struct StepArgs {
     int64_t N;
     uint32_t flags;
     GridSel gs;
+    int32_t *host_obs, *host_reward, *host_done;  // optional page-locked host mirrors written by the kernel itself
 };
 
 template <bool LDS>
@@ -172,9 +173,14 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
         a.episode[e] = ep + 1;
     }
     s = gu_move(s, m.f[s], act, gu_delta<LDS>(act, a.lut, a.W));
+    const int32_t r = m.r[s], d = (m.f[s] >> GU_CELL_TERM_BIT) & 1;
     a.pos[e] = s;
-    a.reward[e] = m.r[s];
-    a.done[e] = (m.f[s] >> GU_CELL_TERM_BIT) & 1;
+    a.reward[e] = r;
+    a.done[e] = d;
+    // zero-copy host path (GU_F_PINNED_IO): results also go straight to the caller's page-locked buffers over PCIe
+    if (a.host_obs) a.host_obs[e] = s;
+    if (a.host_reward) a.host_reward[e] = r;
+    if (a.host_done) a.host_done[e] = d;
 }
 
 // ------------------------------------------------------------------------------------
@@ -498,11 +504,12 @@ int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice
     return GU_OK;
 }
 
-int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags)
+int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, int32_t *host_obs, int32_t *host_reward,
+                   int32_t *host_done)
 {
     StepArgs a{h->d_cell, h->cell_bytes, h->W, h->delta_lut, d_actions_row, h->pos(), h->reward(), h->done(),
                h->d_episode, h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags,
-               gu_grid_sel(h)};
+               gu_grid_sel(h), host_obs, host_reward, host_done};
     const int lds_bs = gu_lds_block(h, GU_BLOCK, 2);
     if (lds_bs)
         hipLaunchKernelGGL(gu_step_kernel<true>, dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), 2 * (size_t)h->cell_bytes, h->stream, a);

@@ -67,10 +67,24 @@ class VecGridUniverse(object):
         unless `start_choice` gives an index into starting_states per env.  Returns obs int32[N]."""
         return self.engine.reset(mask, start_choice)
 
-    def step(self, actions):
-        """actions int32[N] in 0..3 -> (obs int32[N], reward int32[N], done bool[N], info)."""
+    def step(self, actions, zero_copy=False):
+        """actions int32[N] in 0..3 -> (obs int32[N], reward int32[N], done bool[N], info).
+
+        zero_copy=True: `actions` is copied into the engine's page-locked buffer (or pass None after filling
+        `self.actions_buffer` in place) and the kernel writes the results straight into page-locked host memory;
+        the returned obs / reward arrays are VIEWS that the next zero-copy step overwrites."""
+        if zero_copy:
+            if actions is not None:
+                self.engine.pinned_actions[:] = actions
+            obs, reward, done = self.engine.step_pinned(self.auto_reset)
+            return obs, reward, done.astype(bool), self.info
         obs, reward, done = self.engine.step(actions, self.auto_reset)
         return obs, reward, done.astype(bool), self.info
+
+    @property
+    def actions_buffer(self):
+        """int32[N] page-locked array read directly by the step kernel in zero-copy mode."""
+        return self.engine.pinned_actions
 
     def rollout(self, T, policy='uniform', actions=None, auto_reset=None, trajectory=True, stats=False):
         """T fused steps.  policy: 'uniform' (device RNG), 'stream' (give `actions` int32[T,N]) or

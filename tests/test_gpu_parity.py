@@ -608,3 +608,17 @@ def test_single_process_rccl_view():
         two.view(rccl=True)
     assert 'one device per rank' in str(ei.value)
     two.close()
+
+
+def test_vec_env_zero_copy_step():
+    meta, z = G.load_traj('c2_open8x8')
+    env = gua.VecGridUniverse(64, grid_shape=(8, 8), seed=2, auto_reset=True)
+    env.reset()
+    for t in range(30):
+        if t % 2:
+            env.actions_buffer[:] = z['actions'][t]
+            o, r, d, _ = env.step(None, zero_copy=True)
+        else:
+            o, r, d, _ = env.step(z['actions'][t], zero_copy=True)
+        assert np.array_equal(o, z['obs'][t]) and np.array_equal(r, z['reward'][t]) and np.array_equal(d, z['done'][t].astype(bool))
+    env.close()

@@ -622,3 +622,26 @@ def test_vec_env_zero_copy_step():
             o, r, d, _ = env.step(z['actions'][t], zero_copy=True)
         assert np.array_equal(o, z['obs'][t]) and np.array_equal(r, z['reward'][t]) and np.array_equal(d, z['done'][t].astype(bool))
     env.close()
+
+
+def test_config4_full_batch_in_eight_shards():
+    """BASELINE config 4 at full size: 262 144 envs on the 32x32 lava grid as 8 shards of 32 768 (the per-GPU
+    shards of the 8-GPU run, executed one after the other on the one GPU of the box) equal ONE oracle run of the
+    whole batch, compared through sha256 digests per shard and the stats of every env."""
+    meta, _ = G.load_traj('c4_lava32')
+    grid = C.Grid.from_lists(**meta)
+    total, shards, T, seed = 262144, 8, 250, 4
+    per = total // shards
+    st = C.State(total)
+    C.reset(grid, seed, st)
+    want = C.rollout(grid, seed, st, T, True, stats=True)
+    for g in range(shards):
+        sl = slice(g * per, (g + 1) * per)
+        with Engine(per, spec_of(meta), env_id0=g * per, seed=seed) as eng:
+            eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'uniform', True, trajectory=True, stats=True)
+            got = eng.read_trajectory(0, T, pinned=True)
+            ret, eps = eng.read_stats()
+            assert digest(got['obs'], got['reward'], got['done']) == digest(want['obs'][:, sl], want['reward'][:, sl], want['done'][:, sl]), g
+            assert np.array_equal(ret, want['ret'][sl]) and np.array_equal(eps, want['episodes'][sl])

@@ -82,8 +82,8 @@ def test_golden_fused_and_device_paths(name, mode):
 
 
 @pytest.mark.parametrize('name', sorted(G.load_json('digests.json')))
-def test_reference_digests_4096x1000(name):
-    """sha256 of 4096 envs x 1000 steps of the real reference."""
+def test_reference_digests(name):
+    """sha256 of N envs x 1000 steps of the REAL reference: 4096 envs for C2/C3/C4 and the full 65 536 envs of C3."""
     d = G.load_json('digests.json')[name]
     with fresh(d) as eng:
         eng.reset()

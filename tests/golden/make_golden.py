@@ -483,6 +483,10 @@ def capture_big_digest():
     env = seeded_maze_env(32, 32, 123)
     save_digest(store, 'c3_maze32_65536x1000', env, 123, 65536, 1000, True)
     json.dump(store, open(path, 'w'), indent=1)
+    # BASELINE config 4 at its full batch size: 262 144 envs on the lava grid, 250 steps (another 65.5 M steps)
+    env = ref_env(grid_shape=(32, 32), lava_states=lava_column_32())
+    save_digest(store, 'c4_lava32_262144x250', env, 4, 262144, 250, True)
+    json.dump(store, open(path, 'w'), indent=1)
 
 
 def main():

@@ -45,10 +45,28 @@ def test_ascii_render_matches_reference():
     for state, frame in zip([0, 1, 5, 9, 10, 11, 15], frames):
         env.current_state = state
         assert env.render(mode='ansi').getvalue() == frame
-    for bad in ('rgb_array', 'graphic'):
-        with pytest.raises(gua.UnsupportedMode):
-            env.render(mode=bad)
+    with pytest.raises(gua.UnsupportedMode):
+        env.render(mode='rgb_array')
     assert env.render(close=True) is None
+
+
+def test_graphic_mode_degrades_to_text(capsys):
+    """Headless build: 'graphic' (a pyglet window in the reference) warns once and prints the text view, so drivers
+    written for the reference keep running; render_policy_arrows prints an arrow map."""
+    env = gua.GridUniverseEnv()
+    with pytest.warns(UserWarning):
+        env.render(mode='graphic')
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        env.render(mode='graphic')  # second call: no further warning
+    assert capsys.readouterr().out == 2 * 'x o o o \no o o o \no o o o \no o o G \n\n'
+    policy = np.zeros((16, 4))
+    policy[:, 1] = 1.0
+    policy[3] = [0, 0, 0.5, 0.5]
+    env.render_policy_arrows(policy)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0].split() == ['→', '→', '→', '↓←'] and len(out) == 5
 
 
 def test_human_render_writes_stdout(capsys):

@@ -176,3 +176,28 @@ def test_gridspec_rejects_bad_input():
         GridSpec(4, 4, [0], [15], [], [], reward=[5] * 16)
     spec = GridSpec(4, 4, [0], [-1], [-1], [])  # negative entries never match a state (quirk 5)
     assert not spec.goal.any() and not spec.lava.any() and (spec.reward == -1).all()
+
+
+def test_compat_shim_resolves_reference_import_paths():
+    """compat/ maps the reference's `core.*` import paths onto the engine (names used by its example drivers)."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'compat'))
+    try:
+        env_mod = importlib.import_module('core.envs.griduniverse_env')
+        assert env_mod.GridUniverseEnv is gua.GridUniverseEnv
+        assert importlib.import_module('core.envs').GridUniverseEnv is gua.GridUniverseEnv
+        utils = importlib.import_module('core.algorithms.utils')
+        dp = importlib.import_module('core.algorithms.dynamic_programming')
+        mc = importlib.import_module('core.algorithms.monte_carlo')
+        for mod, names in ((utils, ['single_step_policy_evaluation', 'greedy_policy_from_value_function', 'get_policy_map',
+                                    'reshape_as_griduniverse']),
+                           (dp, ['value_iteration', 'policy_iteration']), (mc, ['run_episode', 'monte_carlo_evaluation'])):
+            for n in names:
+                assert callable(getattr(mod, n)), n
+    finally:
+        sys.path.pop(0)
+        for k in [k for k in sys.modules if k == 'core' or k.startswith('core.')]:
+            del sys.modules[k]

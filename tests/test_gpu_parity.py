@@ -263,9 +263,10 @@ def test_look_step_ahead_tables():
 
 
 def test_random_grids_property():
-    """Random grids (walls / lava / goals / starts anywhere, incl. overlaps) vs the oracle."""
+    """Random grids (walls / lava / goals / starts anywhere, incl. overlaps), random batch sizes, every rollout
+    policy that needs no table, with and without auto-reset, vs the oracle."""
     rs = np.random.RandomState(2026)
-    for trial in range(25):
+    for trial in range(60):
         W, H = int(rs.randint(1, 70)), int(rs.randint(1, 40))
         S = W * H
         pick = lambda k: [int(x) for x in rs.choice(S, size=min(S, int(k)), replace=False)]  # noqa: E731
@@ -273,18 +274,25 @@ def test_random_grids_property():
         meta = dict(W=W, H=H, walls=walls, lava=lava, goals=goals, starts=starts)
         grid = C.Grid.from_lists(**meta)
         spec = GridSpec(W, H, starts, goals, lava, walls)
-        N, T, seed = int(rs.randint(1, 400)), 120, int(rs.randint(0, 2 ** 62))
-        auto = bool(trial % 2)
-        st = C.State(N, 11)
+        N, T, seed = int(rs.randint(1, 1500)), int(rs.randint(1, 200)), int(rs.randint(0, 2 ** 62))
+        auto, stream, id0 = bool(trial % 2), bool((trial // 2) % 2), int(rs.randint(0, 2 ** 31))
+        acts = rs.randint(0, 4, (T, N)).astype(np.int32) if stream else None
+        st = C.State(N, id0)
         C.reset(grid, seed, st)
-        want = C.rollout(grid, seed, st, T, auto)
-        with Engine(N, spec, env_id0=11, seed=seed) as eng:
+        want = C.rollout(grid, seed, st, T, auto, actions=acts, stats=True)
+        with Engine(N, spec, env_id0=id0, seed=seed) as eng:
             eng.reset()
+            if stream:
+                eng.upload_actions(acts)
             eng.reserve_trajectory(T)
-            eng.rollout(T, 'uniform', auto)
+            eng.rollout(T, 'stream' if stream else 'uniform', auto, trajectory=True, stats=True)
             got = eng.read_trajectory(0, T)
+            ret, eps = eng.read_stats()
+            state = eng.get_state()
         for k in ('obs', 'reward', 'done'):
-            assert np.array_equal(got[k], want[k]), (trial, W, H, k)
+            assert np.array_equal(got[k], want[k]), (trial, W, H, N, T, k)
+        assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes'])
+        assert np.array_equal(state['pos'], st.pos) and np.array_equal(state['episode'], st.episode)
 
 
 def test_grid_larger_than_lds_uses_the_global_path():

@@ -15,7 +15,8 @@ def _py_files(sub):
 
 def test_product_never_touches_the_oracle():
     pat = re.compile(r'^\s*(from|import)\s+(oracle|tests)\b|libgu_oracle|oracle/_build', re.M)
-    for path in list(_py_files('griduniverse_amd')) + list(_py_files('include')) + list(_py_files('examples')):
+    for path in list(_py_files('griduniverse_amd')) + list(_py_files('include')) + list(_py_files('examples')) + \
+            list(_py_files('compat')) + list(_py_files('tools')):
         assert not pat.search(open(path).read()), path + ' references the oracle'
 
 

@@ -97,7 +97,25 @@ def cpu_baseline(template, seed, T, gpu_rows, budget_s=12.0):
                        '%.0f s on one core, same grid and action stream as the GPU run; this port runs at 1.02x the real reference '
                        'step() on a common host (BASELINE.md, tests/golden/calibrate_cpu.py)' % (n_inst, budget_s),
                 c_oracle_value=c_rate, c_oracle_sample='%d envs x %d steps, scalar C (oracle/gu_oracle.c), 1 core' % (n_c, T),
-                host_cpu_count=os.cpu_count(), host_cpu_model=_cpu_model()), exact
+                host_cpu_count=os.cpu_count(), host_usable_cores=_usable_cores(), host_cpu_model=_cpu_model()), exact
+
+
+def _usable_cores():
+    """Cores this process can actually run on: CPU affinity, capped by the cgroup CPU quota if there is one."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]  # cgroup v2
+        if quota != 'max':
+            cores = min(cores, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                cores = min(cores, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return cores
 
 
 def _cpu_model():
@@ -109,6 +127,51 @@ def _cpu_model():
     except OSError:
         pass
     return 'unknown'
+
+
+def cpu_baseline_all_cores(template, seed, seconds=4.0):
+    """Part of the cpu_baseline leg, run BEFORE the GPU is initialised (it forks): the same per-instance Python
+    port (oracle/ref_env.py) on every core this process may use, one forked process per core, aggregate rate."""
+    import multiprocessing as mp
+
+    from oracle import gu_rng
+    from oracle.ref_env import OracleGridUniverseEnv
+
+    cores = _usable_cores()
+    n_inst, chunk = 16, 256
+
+    def worker(index, conn):
+        envs = [OracleGridUniverseEnv(grid_shape=(template.x_max, template.y_max), initial_state=list(template.starting_states),
+                                      goal_states=list(template.goal_states), lava_states=list(template.lava_states),
+                                      walls=list(template.wall_indices)) for _ in range(n_inst)]
+        for e in envs:
+            e.reset()
+        actions = gu_rng.action_stream(seed, range(index * n_inst, (index + 1) * n_inst), 0, chunk)
+        steps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for t in range(chunk):
+                row = actions[t]
+                for j, e in enumerate(envs):
+                    if e.step(int(row[j]))[2]:
+                        e.reset()
+            steps += chunk * n_inst
+        conn.send((steps, time.perf_counter() - t0))
+        conn.close()
+
+    ctx = mp.get_context('fork')
+    procs = []
+    for i in range(cores):
+        parent, child = ctx.Pipe(duplex=False)
+        p = ctx.Process(target=worker, args=(i, child))
+        p.start()
+        procs.append((p, parent))
+    rate = 0.0
+    for p, parent in procs:
+        steps, dt = parent.recv()
+        rate += steps / dt
+        p.join()
+    return dict(value=rate, unit='env-steps/s', cores=cores, kind='port',
+                sample='%d forked processes x %d per-instance Python envs for %.0f s each' % (cores, n_inst, seconds))
 
 
 def read_traffic():
@@ -153,6 +216,9 @@ def main():
     N, T, K, W = args.envs, args.T, args.steps, args.warmup
     seed = 123
     template, grid_desc = build_workload(args.workload)
+    all_cores = None
+    if world == 1 and not args.no_cpu_baseline:
+        all_cores = cpu_baseline_all_cores(template, seed)  # forks: must precede any HIP call in this process
     n_dev = max(1, _lib.device_count())
     device = local_rank % n_dev  # identity on an N-GPU node; lets a 1-GPU box rehearse the N-process flow
     eng = gua.Engine(N, gua.GridSpec.from_env(template), device=device, env_id0=rank * N, seed=seed)
@@ -212,6 +278,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             base, exact = cpu_baseline(template, seed, T, first_rows)
+            base['all_cores'] = all_cores
             line['cpu_baseline'] = base
             line['bit_exact_vs_oracle'] = exact
         print(json.dumps(line), flush=True)

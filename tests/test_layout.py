@@ -21,12 +21,14 @@ def test_product_never_touches_the_oracle():
 
 
 def test_oracle_use_in_entry_points_is_confined():
+    """bench.py may import oracle only inside its cpu_baseline* functions."""
     text = open(os.path.join(ROOT, 'bench.py')).read()
-    uses = [m.start() for m in re.finditer(r'\boracle\b', text)]
-    start = text.index('def cpu_baseline')
-    end = text.index('\ndef ', start + 1)
-    code_uses = [u for u in uses if 'import' in text[text.rfind('\n', 0, u):text.find('\n', u)]]
-    assert code_uses and all(start < u < end for u in code_uses), 'bench.py may import oracle only inside cpu_baseline()'
+    allowed = []
+    for m in re.finditer(r'^def (cpu_baseline\w*)\(', text, flags=re.M):
+        end = text.find('\ndef ', m.start() + 1)
+        allowed.append((m.start(), end if end > 0 else len(text)))
+    imports = [m.start() for m in re.finditer(r'^\s*(from|import)\s+oracle\b', text, flags=re.M)]
+    assert imports and all(any(a < i < b for a, b in allowed) for i in imports)
 
 
 # the fixture generators: run only in the build container, where the reference is mounted

@@ -206,8 +206,8 @@ struct RolloutArgs {
     GridSel gs;
 };
 
-// AUTO: 0 = no reset; 1 = auto-reset, single start cell (branch-free select);
-//       2 = auto-reset, several start cells (RNG stream 1, rare divergent branch)
+// AUTO: 0 = no reset; 1 = auto-reset, single start cell (branch-free selects keyed on the TERM bit of the
+//       register copy of flags); 2 = auto-reset, several start cells (RNG stream 1, rare divergent branch)
 // MAP : 0 = records read from L2 (any grid size, any grid-per-env assignment)
 //       1 = the block's grid staged in LDS, shared by its lanes
 //       2 = every lane keeps a PRIVATE copy of its own grid's flags plane in LDS (multi-grid engines whose groups
@@ -270,20 +270,34 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
         rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
     };
 
+    // AUTO == 1 keeps the invariant "d == TERM bit of the REGISTER copy of flags", so the lazy reset needs no
+    // separate test on the dependent chain; at entry the stored done flag may disagree with the cell (fresh reset
+    // onto a terminal start, gu_set_state), so the register copy takes its TERM bit from the stored flag.
+    if (AUTO == 1) flags = (flags & ~GU_CELL_TERM) | (d << GU_CELL_TERM_BIT);
+
     // `soff`: wave-uniform byte offset of this step's row from the resource base
     auto step = [&](uint32_t act, uint32_t soff) {
-        if (AUTO == 1) {  // lazy `if done: env.reset()` (env:187-193), single start: pure selects
-            s = d ? start0 : s;
-            flags = d ? start0_flags : flags;
-            ep += d;
-        } else if (AUTO == 2) {
-            if (d) {
-                s = lg.starts[gu_rng_start_index(prefix, ep, lg.n_starts)];
-                ++ep;
-                flags = m.f[s];
+        const int32_t delta = gu_delta<MAP != 0>(act, lut, W);
+        if (AUTO == 1) {
+            // lazy `if done: env.reset()` (env:187-193) with a single start cell: two selects keyed directly on the
+            // TERM bit of the record that just arrived (no separate done register on the dependent chain).  A variant
+            // that precomputes the move from the start cell off the chain was measured slower at every occupancy
+            // (profiles/r01e_auto_form_ab.txt).
+            const bool was_done = flags & GU_CELL_TERM;
+            ep += was_done;
+            s = was_done ? start0 : s;
+            flags = was_done ? start0_flags : flags;
+            s = gu_move(s, flags, act, delta);
+        } else {
+            if (AUTO == 2) {
+                if (d) {
+                    s = lg.starts[gu_rng_start_index(prefix, ep, lg.n_starts)];
+                    ++ep;
+                    flags = m.f[s];
+                }
             }
+            s = gu_move(s, flags, act, delta);
         }
-        s = gu_move(s, flags, act, gu_delta<MAP != 0>(act, lut, W));
         flags = m.f[s];
         r = (MAP == 2) ? gu_reward_packed(flags) : (int32_t)m.r[s];
         d = __builtin_amdgcn_ubfe(flags, GU_CELL_TERM_BIT, 1);
@@ -363,10 +377,11 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
         uint32_t t = t_lane;
         for (int64_t i = 0; i < a.T; ++i, ++t) {
             // greedy[] / pi[] must be read at the post-reset position
-            if (AUTO == 1) {
-                s = d ? start0 : s;
-                flags = d ? start0_flags : flags;
-                ep += d;
+            if (AUTO == 1) {  // (these policies read a table at the post-reset position, so they reset explicitly)
+                const bool was_done = flags & GU_CELL_TERM;
+                s = was_done ? start0 : s;
+                ep += was_done;
+                flags = was_done ? (start0_flags & ~GU_CELL_TERM) : flags;
                 d = 0;
             } else if (AUTO == 2) {
                 if (d) {

@@ -201,3 +201,15 @@ def test_compat_shim_resolves_reference_import_paths():
         sys.path.pop(0)
         for k in [k for k in sys.modules if k == 'core' or k.startswith('core.')]:
             del sys.modules[k]
+
+
+def test_product_rng_module_matches_the_specification():
+    """griduniverse_amd.rng (what users get to replay device action streams) == oracle/gu_rng.py (the spec)."""
+    from griduniverse_amd import rng
+    from oracle import gu_rng
+    ids = np.array([0, 1, 65535, 2 ** 31 + 7], dtype=np.int64)
+    for seed in (0, 123, 2 ** 64 - 1):
+        assert np.array_equal(rng.uniform_actions(seed, ids, 5, 70), gu_rng.action_stream(seed, ids, 5, 70))
+        for ep in (0, 3, 2 ** 28 - 1):
+            assert np.array_equal(rng.start_indices(seed, ids, ep, 7), gu_rng.start_index_v(seed, ids, ep, 7))
+        assert np.array_equal(rng.words(seed, ids, 3, 9), gu_rng.word_v(seed, ids, 3, 9))

@@ -83,9 +83,10 @@ int gu_destroy(gu_handle h);
  *       separate planes because the reference's reward matrix and terminal test
  *       can disagree (negative indices wrap only in the former; quirk 5).
  *   starts     : starting_states (env:61-63), n_starts >= 1.
- * The library compiles the planes into one byte per cell (blocked-move bits for the
- * four actions incl. the absorbing-terminal rule, terminal bit, reward code) that the
- * kernels stage in LDS. */
+ * The library compiles the planes into two bytes per cell -- flags (per action: does the
+ * move change the position, incl. the absorbing-terminal rule; terminal bit; reward code;
+ * wall bit) and the int8 reward -- which the kernels stage in LDS (gu_get_cells reads
+ * them back). */
 int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row,
                 const uint32_t *wall_rows, const uint32_t *goal_rows, const uint32_t *lava_rows,
                 const uint32_t *rplus_rows, const uint32_t *rminus_rows,
@@ -94,7 +95,9 @@ int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row,
 /* Several DISTINCT grids of one shape in one engine (SURVEY.md 8(d) C3 variant, 8(f) rank 3): env e uses grid
  * e / (num_envs / n_grids) -- contiguous equal groups, n_grids must divide num_envs.  Planes are
  * [n_grids][H][words_per_row]; starts is [n_grids][max_starts] with n_starts[g] valid entries per grid.
- * Multi-grid engines read the records from L2 instead of LDS and do not support the DP / Monte-Carlo tables. */
+ * The rollout kernels stage one grid per block in LDS when the group size is a multiple of 64, keep a private
+ * copy of its grid per lane in LDS otherwise (e.g. one grid per env), and read L2 for grids too large for either.
+ * Multi-grid engines do not support the DP / Monte-Carlo tables (one value table per engine). */
 int gu_set_grids(gu_handle h, int32_t n_grids, int32_t W, int32_t H, int32_t words_per_row,
                  const uint32_t *wall_rows, const uint32_t *goal_rows, const uint32_t *lava_rows,
                  const uint32_t *rplus_rows, const uint32_t *rminus_rows,
@@ -110,7 +113,8 @@ int gu_get_cells(gu_handle h, int32_t grid_index, uint8_t *flags, int8_t *reward
 
 /* ---- RNG ---------------------------------------------------------------------
  * Keys the per-env counter RNG (MurmurHash3 of seed, global env id, stream,
- * counter; specified in oracle/gu_rng.py) and zeroes episode[] and tcount[].
+ * counter; host view: griduniverse_amd/rng.py, restated for the tests in
+ * oracle/gu_rng.py) and zeroes episode[] and tcount[].
  * The reference has no per-env RNG (env:242-244 stores one and never uses it). */
 int gu_seed(gu_handle h, uint64_t seed);
 
@@ -124,7 +128,9 @@ int gu_reset_done(gu_handle h);
 
 /* ---- step: GridUniverseEnv._step, env:176-185 (+ look_step_ahead env:136-155) ---
  * Synchronous, host buffers: actions in, (obs, reward, done) out (each N int32,
- * outputs optional).  flags: GU_F_AUTO_RESET. */
+ * outputs optional).  flags: GU_F_AUTO_RESET; GU_F_PINNED_IO when every buffer passed
+ * is page-locked (gu_host_alloc): the kernel then reads / writes them directly over
+ * PCIe and no copy command is issued. */
 int gu_step(gu_handle h, const int32_t *actions, uint32_t flags,
             int32_t *obs, int32_t *reward, int32_t *done);
 

@@ -265,8 +265,10 @@ def test_look_step_ahead_tables():
 def test_random_grids_property():
     """Random grids (walls / lava / goals / starts anywhere, incl. overlaps), random batch sizes, every rollout
     policy that needs no table, with and without auto-reset, vs the oracle."""
-    rs = np.random.RandomState(2026)
-    for trial in range(60):
+    import os
+    trials = int(os.environ.get('GU_FUZZ_TRIALS', '60'))  # e.g. GU_FUZZ_TRIALS=2000 for a one-off soak
+    rs = np.random.RandomState(int(os.environ.get('GU_FUZZ_SEED', '2026')))
+    for trial in range(trials):
         W, H = int(rs.randint(1, 70)), int(rs.randint(1, 40))
         S = W * H
         pick = lambda k: [int(x) for x in rs.choice(S, size=min(S, int(k)), replace=False)]  # noqa: E731
@@ -653,3 +655,27 @@ def test_config4_full_batch_in_eight_shards():
             ret, eps = eng.read_stats()
             assert digest(got['obs'], got['reward'], got['done']) == digest(want['obs'][:, sl], want['reward'][:, sl], want['done'][:, sl]), g
             assert np.array_equal(ret, want['ret'][sl]) and np.array_equal(eps, want['episodes'][sl])
+
+
+@pytest.mark.parametrize('W,H', [(40000, 1), (1, 40000), (33000, 2)])
+def test_extreme_aspect_grids(W, H):
+    """Grids whose width does not fit the int16 delta LUT / whose cell count does not fit LDS (L2 path, arithmetic deltas)."""
+    S = W * H
+    rs = np.random.RandomState(W + H)
+    walls = [int(x) for x in rs.choice(S, 200, replace=False)]
+    meta = dict(W=W, H=H, walls=walls, lava=[S // 3], goals=[S - 1, S // 2], starts=[0, S // 4, S - 2])
+    grid = C.Grid.from_lists(**meta)
+    st = C.State(500, 9)
+    C.reset(grid, 77, st)
+    want = C.rollout(grid, 77, st, 300, True)
+    with Engine(500, GridSpec(W, H, meta['starts'], meta['goals'], meta['lava'], walls), env_id0=9, seed=77) as eng:
+        eng.reset()
+        eng.reserve_trajectory(300)
+        eng.rollout(300, 'uniform', True)
+        got = eng.read_trajectory(0, 300)
+        s, a = rs.randint(0, S, 4000), rs.randint(0, 4, 4000)
+        for care in (True, False):
+            g_, w_ = eng.look_step_ahead(s, a, care), C.look_step_ahead(grid, s, a, care)
+            assert all(np.array_equal(x, y) for x, y in zip(g_, w_))
+    for k in got:
+        assert np.array_equal(got[k], want[k]), k

@@ -19,7 +19,7 @@ GU_OK = 0
 ERR_NAMES = {-1: 'GU_ERR_INVALID', -2: 'GU_ERR_HIP', -3: 'GU_ERR_NOMEM', -4: 'GU_ERR_STATE',
              -5: 'GU_ERR_COMM', -6: 'GU_ERR_UNSUPPORTED'}
 
-F_AUTO_RESET, F_TRAJECTORY, F_STATS, F_PINNED_IO = 1, 2, 4, 8
+F_AUTO_RESET, F_TRAJECTORY, F_STATS, F_PINNED_IO, F_PACKED = 1, 2, 4, 8, 16
 POLICY_UNIFORM, POLICY_STREAM, POLICY_GREEDY, POLICY_SAMPLE = 0, 1, 2, 3
 COMM_ID_BYTES = 128
 
@@ -49,6 +49,7 @@ SIGNATURES = {
     'gu_reserve_trajectory': [_vp, _i64],
     'gu_rollout': [_vp, _i64, _i32, _u32],
     'gu_read_trajectory': [_vp, _i64, _i64, _vp, _vp, _vp],
+    'gu_read_trajectory_packed': [_vp, _i64, _i64, _vp],
     'gu_read_stats': [_vp, _vp, _vp],
     'gu_get_state': [_vp, _vp, _vp, _vp, _vp],
     'gu_set_state': [_vp, _vp, _vp, _vp, _vp],

@@ -489,6 +489,7 @@ int gu_reserve_trajectory(gu_handle h, int64_t T)
     h->traj_T = 0;
     GU_HIP(hipMalloc(&h->d_traj, 3 * (size_t)T * (size_t)h->N * sizeof(int32_t)));
     h->traj_T = T;
+    h->traj_kind = 0;
     return GU_OK;
 }
 
@@ -497,8 +498,10 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
     GU_ENTER(h);
     GU_NEED_GRID(h);
     GU_REQUIRE(T > 0 && T <= 100000000, GU_ERR_INVALID, "T %lld out of range", (long long)T);
-    GU_REQUIRE((flags & ~(GU_F_AUTO_RESET | GU_F_TRAJECTORY | GU_F_STATS)) == 0, GU_ERR_INVALID, "unknown flags 0x%x", flags);
-    if (flags & GU_F_TRAJECTORY)
+    GU_REQUIRE((flags & ~(GU_F_AUTO_RESET | GU_F_TRAJECTORY | GU_F_STATS | GU_F_PACKED)) == 0, GU_ERR_INVALID, "unknown flags 0x%x", flags);
+    GU_REQUIRE(!((flags & GU_F_PACKED) && (flags & GU_F_TRAJECTORY)), GU_ERR_INVALID, "GU_F_PACKED and GU_F_TRAJECTORY exclude each other");
+    if (flags & GU_F_PACKED) GU_REQUIRE(h->S <= 65536, GU_ERR_UNSUPPORTED, "packed trajectories hold 16-bit states: grid has %d cells", h->S);
+    if (flags & (GU_F_TRAJECTORY | GU_F_PACKED))
         GU_REQUIRE(h->d_traj && T <= h->traj_T, GU_ERR_STATE, "trajectory buffer holds %lld rows, need %lld: call gu_reserve_trajectory",
                    (long long)h->traj_T, (long long)T);
     if (policy_kind == GU_POLICY_STREAM)
@@ -512,7 +515,10 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
         }
     }
     int rc = gu_launch_rollout(h, T, policy_kind, flags);
-    if (rc == GU_OK) h->stats_valid = (flags & GU_F_STATS) != 0;
+    if (rc == GU_OK) {
+        h->stats_valid = (flags & GU_F_STATS) != 0;
+        if (flags & (GU_F_TRAJECTORY | GU_F_PACKED)) h->traj_kind = (flags & GU_F_PACKED) ? 2 : 1;
+    }
     return rc;
 }
 
@@ -521,11 +527,23 @@ int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t
     GU_ENTER(h);
     GU_REQUIRE(h->d_traj && t0 >= 0 && T > 0 && t0 + T <= h->traj_T, GU_ERR_STATE, "rows [%lld,%lld) not in the trajectory buffer",
                (long long)t0, (long long)(t0 + T));
+    GU_REQUIRE(h->traj_kind != 2, GU_ERR_STATE, "the buffer holds a PACKED trajectory: use gu_read_trajectory_packed");
     const size_t n = (size_t)h->N, rows = (size_t)h->traj_T * n, count = (size_t)T * n;
     GU_HIP(hipStreamSynchronize(h->stream));
     int32_t *dst[3] = {obs, reward, done};
     for (int k = 0; k < 3; ++k)
         if (dst[k]) GU_HIP(hipMemcpy(dst[k], h->d_traj + k * rows + (size_t)t0 * n, count * 4, hipMemcpyDeviceToHost));
+    return GU_OK;
+}
+
+int gu_read_trajectory_packed(gu_handle h, int64_t t0, int64_t T, uint32_t *packed)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(h->d_traj && t0 >= 0 && T > 0 && t0 + T <= h->traj_T && packed, GU_ERR_STATE, "rows [%lld,%lld) not in the trajectory buffer",
+               (long long)t0, (long long)(t0 + T));
+    GU_REQUIRE(h->traj_kind == 2, GU_ERR_STATE, "the last rollout did not run with GU_F_PACKED");
+    GU_HIP(hipStreamSynchronize(h->stream));
+    GU_HIP(hipMemcpy(packed, h->d_traj + (size_t)t0 * (size_t)h->N, (size_t)T * (size_t)h->N * 4, hipMemcpyDeviceToHost));
     return GU_OK;
 }
 

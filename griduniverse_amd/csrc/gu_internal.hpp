@@ -68,6 +68,7 @@ struct gu_engine {
     // trajectory buffers obs|reward|done, each [traj_T][N]
     int32_t *d_traj = nullptr;
     int64_t traj_T = 0;
+    int traj_kind = 0;  // what the last rollout left in the buffer: 0 nothing, 1 int32 rows, 2 packed rows
 
     // rollout stats
     int32_t *d_ret = nullptr;

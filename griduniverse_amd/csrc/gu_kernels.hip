@@ -213,7 +213,9 @@ struct RolloutArgs {
 //       2 = every lane keeps a PRIVATE copy of its own grid's flags plane in LDS (multi-grid engines whose groups
 //           do not align with blocks, e.g. one maze per env; 64-lane blocks, S16 + 16 bytes per lane)
 #define GU_PRIVATE_PAD 16
-template <int POLICY, int AUTO, bool TRAJ, bool STATS, int MAP>
+// TRAJ: 0 = no trajectory; 1 = int32 obs / reward / done rows (12 B per env-step);
+//       2 = ONE packed uint32 row: obs | (reward & 0xFF) << 16 | done << 24 (4 B per env-step, grids up to 65 536 cells)
+template <int POLICY, int AUTO, int TRAJ, bool STATS, int MAP>
 __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs a)
 {
     constexpr bool LDS = MAP == 1;
@@ -305,10 +307,12 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
             ret += r;
             fin += (int32_t)d;
         }
-        if (TRAJ) {
+        if (TRAJ == 1) {
             __builtin_amdgcn_raw_buffer_store_b32(s, ro, e4, soff, 0);
             __builtin_amdgcn_raw_buffer_store_b32(r, rr, e4, soff, 0);
             __builtin_amdgcn_raw_buffer_store_b32((int32_t)d, rd, e4, soff, 0);
+        } else if (TRAJ == 2) {
+            __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)s | (((uint32_t)r & 0xFFu) << 16) | (d << 24)), ro, e4, soff, 0);
         }
     };
     auto step1 = [&](uint32_t act) {  // one step, then advance the resource base by one row
@@ -535,7 +539,7 @@ int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, i
     return GU_OK;
 }
 
-template <int POLICY, int AUTO, bool TRAJ, bool STATS>
+template <int POLICY, int AUTO, int TRAJ, bool STATS>
 static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
 {
     const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
@@ -559,19 +563,22 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
 }
 
 template <int POLICY, int AUTO>
-static void gu_rollout_dispatch2(gu_engine *h, const RolloutArgs &a, bool traj, bool stats, int bs)
+static void gu_rollout_dispatch2(gu_engine *h, const RolloutArgs &a, int traj, bool stats, int bs)
 {
-    if (traj) {
-        if (stats) gu_rollout_launch<POLICY, AUTO, true, true>(h, a, bs);
-        else gu_rollout_launch<POLICY, AUTO, true, false>(h, a, bs);
+    if (traj == 1) {
+        if (stats) gu_rollout_launch<POLICY, AUTO, 1, true>(h, a, bs);
+        else gu_rollout_launch<POLICY, AUTO, 1, false>(h, a, bs);
+    } else if (traj == 2) {
+        if (stats) gu_rollout_launch<POLICY, AUTO, 2, true>(h, a, bs);
+        else gu_rollout_launch<POLICY, AUTO, 2, false>(h, a, bs);
     } else {
-        if (stats) gu_rollout_launch<POLICY, AUTO, false, true>(h, a, bs);
-        else gu_rollout_launch<POLICY, AUTO, false, false>(h, a, bs);
+        if (stats) gu_rollout_launch<POLICY, AUTO, 0, true>(h, a, bs);
+        else gu_rollout_launch<POLICY, AUTO, 0, false>(h, a, bs);
     }
 }
 
 template <int POLICY>
-static void gu_rollout_dispatch(gu_engine *h, const RolloutArgs &a, int auto_mode, bool traj, bool stats, int bs)
+static void gu_rollout_dispatch(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs)
 {
     switch (auto_mode) {
     case 0: gu_rollout_dispatch2<POLICY, 0>(h, a, traj, stats, bs); break;
@@ -582,7 +589,8 @@ static void gu_rollout_dispatch(gu_engine *h, const RolloutArgs &a, int auto_mod
 
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
 {
-    const bool traj = flags & GU_F_TRAJECTORY, stats = flags & GU_F_STATS;
+    const int traj = (flags & GU_F_PACKED) ? 2 : ((flags & GU_F_TRAJECTORY) ? 1 : 0);
+    const bool stats = flags & GU_F_STATS;
     const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->all_single_start ? 1 : 2) : 0;
     const int64_t rows = traj ? h->traj_T * h->N : 0;
     RolloutArgs a{};

@@ -165,8 +165,9 @@ class Engine(object):
         check(self.lib.gu_reserve_trajectory(self._h, int(T)))
 
     def rollout(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
-        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_TRAJECTORY if trajectory else 0) | \
-                (_lib.F_STATS if stats else 0)
+        """trajectory: False / True (three int32 rows per step) / 'packed' (one uint32 per env-step)."""
+        tflag = _lib.F_PACKED if trajectory == 'packed' else (_lib.F_TRAJECTORY if trajectory else 0)
+        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | tflag | (_lib.F_STATS if stats else 0)
         check(self.lib.gu_rollout(self._h, int(T), _POLICIES[policy], flags))
 
     def read_trajectory(self, t0, T, pinned=False):
@@ -179,6 +180,16 @@ class Engine(object):
             obs, rew, don = (np.empty((T, self.N), np.int32) for _ in range(3))
         check(self.lib.gu_read_trajectory(self._h, int(t0), int(T), ptr(obs), ptr(rew), ptr(don)))
         return dict(obs=obs, reward=rew, done=don)
+
+    def read_trajectory_packed(self, t0, T, unpack=True, pinned=False):
+        """After rollout(trajectory='packed'): uint32[T, N] words obs | (reward & 0xFF) << 16 | done << 24, or --
+        unpack=True -- the same dict of int32 arrays read_trajectory returns."""
+        words = self._pin('trajp', (T, self.N), np.uint32) if pinned else np.empty((T, self.N), np.uint32)
+        check(self.lib.gu_read_trajectory_packed(self._h, int(t0), int(T), ptr(words)))
+        if not unpack:
+            return words
+        return dict(obs=(words & 0xFFFF).astype(np.int32), reward=((words >> 16) & 0xFF).astype(np.int8).astype(np.int32),
+                    done=((words >> 24) & 1).astype(np.int32))
 
     def read_stats(self):
         ret = np.empty(self.N, np.int64)

@@ -47,6 +47,9 @@ extern "C" {
 #define GU_F_AUTO_RESET 1u  /* harness `if done: env.reset()` applied before the next step */
 #define GU_F_TRAJECTORY 2u  /* write (obs,reward,done)[t][env] for every step              */
 #define GU_F_STATS 4u       /* per-env sum of rewards and finished-episode count           */
+#define GU_F_PACKED 16u     /* gu_rollout: write ONE packed uint32 per env-step instead of three int32 rows:
+                               obs | (reward & 0xFF) << 16 | done << 24  (4 B per env-step; grids <= 65 536 cells);
+                               read back with gu_read_trajectory_packed.  Excludes GU_F_TRAJECTORY. */
 #define GU_F_PINNED_IO 8u   /* gu_step: the caller's buffers are page-locked (gu_host_alloc): DMA them
                                directly instead of bouncing through the library's staging buffer */
 
@@ -151,6 +154,7 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done);
 int gu_reserve_trajectory(gu_handle h, int64_t T);
 int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);
+int gu_read_trajectory_packed(gu_handle h, int64_t t0, int64_t T, uint32_t *packed);   /* [T][N] after GU_F_PACKED */
 int gu_read_stats(gu_handle h, int64_t *reward_sum, int32_t *episodes);
 
 /* ---- state (checkpoint / parity harness) --------------------------------------

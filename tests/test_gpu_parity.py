@@ -679,3 +679,32 @@ def test_extreme_aspect_grids(W, H):
             assert all(np.array_equal(x, y) for x, y in zip(g_, w_))
     for k in got:
         assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize('name', ['c3_maze32', 'c4_lava32', 'rect25x30_busy', 'multistart_test_env', 'maze101'])
+def test_packed_trajectory_mode(name):
+    """GU_F_PACKED: one uint32 per env-step (obs | reward << 16 | done << 24) carries exactly the golden stream."""
+    meta, z = G.load_traj(name)
+    T, N = z['actions'].shape
+    with fresh(meta) as eng:
+        eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'uniform', meta['auto_reset'], trajectory='packed', stats=True)
+        got = eng.read_trajectory_packed(0, T)
+        words = eng.read_trajectory_packed(0, T, unpack=False, pinned=True)
+        for k in ('obs', 'reward', 'done'):
+            assert np.array_equal(got[k], z[k]), (name, k)
+        assert words.dtype == np.uint32 and np.array_equal(words & 0xFFFF, z['obs'])
+        with pytest.raises(gua.GuError):
+            eng.read_trajectory(0, T)  # the buffer holds packed rows now
+        eng.upload_actions(z['actions'])
+        eng.seed(meta['seed'])
+        eng.reset()
+        eng.rollout(T, 'stream', meta['auto_reset'], trajectory='packed')
+        assert np.array_equal(eng.read_trajectory_packed(0, T)['obs'], z['obs'])
+        eng.rollout(5, 'uniform', True, trajectory=True)
+        assert eng.read_trajectory(0, 5)['obs'].shape == (5, N)
+    with Engine(8, GridSpec(300, 300, [0], [5], [], [])) as eng:  # 90 000 cells do not fit 16 bits
+        eng.reserve_trajectory(4)
+        with pytest.raises(gua.GuError):
+            eng.rollout(4, 'uniform', True, trajectory='packed')

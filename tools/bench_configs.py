@@ -43,6 +43,10 @@ def paths(name, template, N, T=1000, reps=20):
     out['rollout_traj_GBps_12B'] = 12 * N * T * reps / dev / 1e9
     wall, dev = timed(eng, lambda: eng.rollout(T, 'uniform', True, False, True), reps)
     out['rollout_stats_only_steps_per_s'] = N * T * reps / wall
+    if template.world.size <= 65536:
+        wall, dev = timed(eng, lambda: eng.rollout(T, 'uniform', True, 'packed'), reps)
+        out['rollout_packed_traj_steps_per_s'] = N * T * reps / wall
+        out['rollout_packed_traj_GBps_4B'] = 4 * N * T * reps / dev / 1e9
     wall, dev = timed(eng, lambda: eng.rollout(T, 'uniform', False, True), reps)
     out['rollout_traj_no_autoreset_steps_per_s'] = N * T * reps / wall
     # PCIe-inclusive: trajectory copied back to host numpy after every launch

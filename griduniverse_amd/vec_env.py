@@ -89,7 +89,8 @@ class VecGridUniverse(object):
     def rollout(self, T, policy='uniform', actions=None, auto_reset=None, trajectory=True, stats=False):
         """T fused steps.  policy: 'uniform' (device RNG), 'stream' (give `actions` int32[T,N]) or
         'greedy' (argmax of the policy table set through `engine.vi_set`).  Returns a dict with
-        obs/reward/done int32[T,N] when `trajectory`, plus ret/episodes when `stats`."""
+        obs/reward/done int32[T,N] when `trajectory` (True, or 'packed' to move 4 instead of 12 bytes per
+        env-step through HBM and PCIe), plus ret/episodes when `stats`."""
         auto = self.auto_reset if auto_reset is None else bool(auto_reset)
         if actions is not None:
             policy = 'stream'
@@ -97,7 +98,10 @@ class VecGridUniverse(object):
         if trajectory:
             self.engine.reserve_trajectory(T)
         self.engine.rollout(T, policy, auto, trajectory, stats)
-        out = self.engine.read_trajectory(0, T) if trajectory else {}
+        if trajectory == 'packed':  # one uint32 per env-step on the device, unpacked to the same three arrays here
+            out = self.engine.read_trajectory_packed(0, T)
+        else:
+            out = self.engine.read_trajectory(0, T) if trajectory else {}
         if stats:
             out['ret'], out['episodes'] = self.engine.read_stats()
         return out

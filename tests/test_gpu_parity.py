@@ -403,6 +403,11 @@ def test_vec_env_surface():
     assert out['obs'].shape == (64, 256) and out['ret'].shape == (256,)
     out = env.rollout(8, actions=np.ones((8, 256), np.int32))
     assert out['obs'].shape == (8, 256)
+    state = env.get_state()
+    a = env.rollout(32, trajectory='packed')
+    env.set_state(pos=state['pos'], done=state['done'], episode=state['episode'], tcount=state['tcount'])
+    b = env.rollout(32)
+    assert all(np.array_equal(a[k], b[k]) for k in ('obs', 'reward', 'done'))
     env.close()
 
 

@@ -114,3 +114,25 @@ def test_sample_policy_with_auto_reset_and_stats():
     for k in ('obs', 'reward', 'done'):
         assert np.array_equal(got[k], want[k])
     assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes'])
+
+
+def test_chunk_boundaries_do_not_change_the_result(monkeypatch):
+    """The evaluation walks the episodes in chunks (scratch budget); with a 1 MiB budget 3000 episodes take dozens of
+    chunks and must give the same bytes as one chunk."""
+    rs = np.random.RandomState(2)
+    S, N, T = 64, 3000, 100
+    spec = GridSpec(8, 8, [0, 9], [63], [20, 43], [10, 11, 12])
+    pi = rs.dirichlet(np.ones(4), S)
+    results = []
+    for mb in ('256', '1'):
+        monkeypatch.setenv('GU_MC_SCRATCH_MB', mb)
+        with Engine(N, spec, seed=5) as eng:
+            eng.vi_set(np.zeros(S), pi)
+            first = eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
+            pw, keep = mc.discount_table(0.95, 1e-3, T)
+            results.append([eng.mc_evaluate(T, first, pw, keep, ev, im, stn, 0.02) for ev, im, stn in
+                            ((False, True, True), (True, True, False), (True, False, True))])
+    for a, b in zip(*results):
+        assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()

@@ -10,8 +10,6 @@ the search itself is host Python -- it runs once per grid and is not a batch wor
 """
 from collections import deque
 
-import numpy as np
-
 
 def create_graph(env):
     """{state: [next states that differ from it, in action order]} for every non-wall state (:43-50)."""

@@ -13,7 +13,6 @@ Sharding across GPUs: give every rank its slice via `env_id0`; per-env RNG strea
 keyed by GLOBAL env id, so the union of the shards equals the single-device batch byte
 for byte (see `parallel.py`).
 """
-import numpy as np
 
 from .engine import Engine
 from .envs.griduniverse_env import GridUniverseEnv

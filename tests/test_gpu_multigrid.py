@@ -6,7 +6,6 @@ import griduniverse_amd as gua
 from griduniverse_amd.engine import Engine
 from griduniverse_amd.grid import GridSpec
 from oracle import c_oracle as C
-from tests import _golden as G
 from tests.test_maze_structure import check_maze_structure
 
 pytestmark = pytest.mark.gpu

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(VI_BLOCK) gu_vi_sweep_step_kernel(const ViStep
         vi_greedy_state(cell, W, gamma, vnew, s, row);
         *reinterpret_cast<double4 *>(a.vi.pi_new + 4 * s) = make_double4(row[0], row[1], row[2], row[3]);
     }
-    if (blockIdx.x * blockDim.x < a.vi.S) vi_block_max_to_global(d, sweep, a.vi.delta_key);  // block-uniform branch
+    if ((int64_t)blockIdx.x * blockDim.x < (int64_t)a.vi.S) vi_block_max_to_global(d, sweep, a.vi.delta_key);  // block-uniform branch
 
     // (2) agent gid acts greedily on the updated policy
     if (gid >= a.N) return;

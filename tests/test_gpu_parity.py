@@ -713,3 +713,26 @@ def test_packed_trajectory_mode(name):
         eng.reserve_trajectory(4)
         with pytest.raises(gua.GuError):
             eng.rollout(4, 'uniform', True, trajectory='packed')
+
+
+def test_trajectory_planes_beyond_4_gib():
+    """1 M envs x 1100 steps: each trajectory plane is 4.6 GB (13.8 GB in all), so row addresses cross the 32-bit
+    byte-offset boundary; spot rows and the per-env stats are checked against the oracle for two env ranges."""
+    meta, _ = G.load_traj('c4_lava32')
+    grid = C.Grid.from_lists(**meta)
+    N, T, seed = 1 << 20, 1100, 12
+    with Engine(N, spec_of(meta), seed=seed) as eng:
+        eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'uniform', True, trajectory=True, stats=True)
+        rows = {t: eng.read_trajectory(t, 1) for t in (0, 1023, 1024, T - 1)}
+        ret, eps = eng.read_stats()
+    for lo in (0, N - 2048):
+        st = C.State(2048, lo)
+        C.reset(grid, seed, st)
+        want = C.rollout(grid, seed, st, T, True, stats=True)
+        sl = slice(lo, lo + 2048)
+        for t, got in rows.items():
+            for k in ('obs', 'reward', 'done'):
+                assert np.array_equal(got[k][0, sl], want[k][t]), (lo, t, k)
+        assert np.array_equal(ret[sl], want['ret']) and np.array_equal(eps[sl], want['episodes'])

@@ -1,0 +1,68 @@
+// gu_render.hip -- headless RGB frames for a range of envs (second half).
+//
+// The reference draws its 'graphic' mode with pyglet textures in a window (core/envs/rendering.py:236-343) -- a GUI
+// that cannot exist on a headless GPU box.  This kernel produces the equivalent information as plain RGB arrays,
+// one thread per pixel: floor / wall / goal / lava tiles from the engine's per-cell flags, a thin grid line on the
+// top and left edge of every cell, and the agent as an inset square on its current cell.  There is no reference
+// image to be bit-exact with; the colour rules below ARE the specification (restated in tests/test_gpu_render.py).
+#include "gu_internal.hpp"
+
+struct RenderArgs {
+    const uint8_t *cell;   // [G][flags | reward] (absorbing map: flags carry TERM / reward code / WALL)
+    const int32_t *pos;    // [N]
+    uint8_t *rgb;          // [n][H*px][W*px][3]
+    int64_t env0, n_envs, group, grid_stride;
+    int32_t W, H, px, n_grids;
+};
+
+__device__ __forceinline__ void gu_tile_colour(uint32_t f, uint8_t &r, uint8_t &g, uint8_t &b)
+{
+    if (f & GU_CELL_WALL) { r = 64; g = 64; b = 64; }                       // wall
+    else if (f & GU_CELL_RMINUS) { r = 220; g = 60; b = 30; }               // lava (wins over goal, like the reward)
+    else if (f & (GU_CELL_RPLUS | GU_CELL_TERM)) { r = 40; g = 180; b = 60; }  // goal
+    else { r = 220; g = 220; b = 220; }                                     // floor
+}
+
+__global__ void __launch_bounds__(256) gu_render_kernel(const RenderArgs a)
+{
+    const int64_t frame_px = (int64_t)a.W * a.px * a.H * a.px;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_envs * frame_px) return;
+    const int64_t k = i / frame_px, p = i % frame_px;
+    const int32_t wpx = a.W * a.px;
+    const int32_t y = (int32_t)(p / wpx), x = (int32_t)(p % wpx);
+    const int32_t cy = y / a.px, cx = x / a.px, iy = y % a.px, ix = x % a.px;
+    const int64_t e = a.env0 + k;
+    const uint8_t *flags = a.cell + (a.n_grids > 1 ? (e / a.group) * a.grid_stride : 0);
+    const int32_t s = cy * a.W + cx;
+    uint8_t r, g, b;
+    gu_tile_colour(flags[s], r, g, b);
+    if (a.px >= 4 && (iy == 0 || ix == 0)) { r = r * 3 / 4; g = g * 3 / 4; b = b * 3 / 4; }  // grid line
+    const int32_t lo = a.px / 4, hi = a.px - a.px / 4;
+    if (s == a.pos[e] && iy >= lo && iy < hi && ix >= lo && ix < hi) { r = 40; g = 90; b = 220; }  // agent
+    uint8_t *out = a.rgb + 3 * i;
+    out[0] = r;
+    out[1] = g;
+    out[2] = b;
+}
+
+extern "C" int gu_render_rgb(gu_handle h, int64_t env0, int64_t n_envs, int32_t cell_px, uint8_t *rgb)
+{
+    int rc = gu_use_device(h);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(h->has_grid, GU_ERR_STATE, "no grid set");
+    GU_REQUIRE(rgb && env0 >= 0 && n_envs > 0 && env0 + n_envs <= h->N, GU_ERR_INVALID, "env range [%lld,%lld) outside the batch",
+               (long long)env0, (long long)(env0 + n_envs));
+    GU_REQUIRE(cell_px >= 1 && cell_px <= 64, GU_ERR_INVALID, "cell_px must be 1..64");
+    const int64_t pixels = n_envs * (int64_t)h->W * cell_px * h->H * cell_px;
+    GU_REQUIRE(pixels * 3 <= (1ll << 32), GU_ERR_INVALID, "%lld pixels are too many for one call", (long long)pixels);
+    rc = gu_ensure_scratch(h, (size_t)pixels * 3);
+    if (rc != GU_OK) return rc;
+    RenderArgs a{h->d_cell, h->pos(), (uint8_t *)h->d_scratch, env0, n_envs, h->group, 2 * (int64_t)h->cell_bytes,
+                 h->W, h->H, cell_px, h->n_grids};
+    hipLaunchKernelGGL(gu_render_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, h->stream, a);
+    GU_HIP(hipGetLastError());
+    GU_HIP(hipMemcpyAsync(rgb, h->d_scratch, (size_t)pixels * 3, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    return GU_OK;
+}

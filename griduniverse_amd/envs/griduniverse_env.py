@@ -42,7 +42,8 @@ def _require_list(value, name):
 
 
 class GridUniverseEnv(object):
-    metadata = {'render.modes': ['human', 'ansi', 'graphic']}
+    # 'rgb_array' is an addition of this build (frames rendered on the GPU); the other three are the reference's
+    metadata = {'render.modes': ['human', 'ansi', 'graphic', 'rgb_array']}
     reward_range = (-float('inf'), float('inf'))
 
     def __init__(self, grid_shape=(4, 4), *, initial_state=0, goal_states=None, lava_states=None, walls=None,
@@ -216,6 +217,10 @@ class GridUniverseEnv(object):
             return None
         if mode not in self.metadata['render.modes']:
             raise UnsupportedMode('Unsupported rendering mode: {}'.format(mode))
+        if mode == 'rgb_array':
+            eng = self._engine()
+            self._push_state(eng)
+            return eng.render_rgb(0, 1, 16)[0]
         if mode == 'graphic':
             # The reference opens a pyglet window here (env:223-228).  This build is headless: so that drivers
             # written for the reference (examples/griduniverse_alg_examples.py renders in 'graphic' mode) keep

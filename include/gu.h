@@ -213,6 +213,11 @@ int gu_mc_evaluate(gu_handle h, int64_t T, const int32_t *first_state, int32_t e
  * max_path), terminal[n_grids] (optional) the state reached. */
 int gu_shortest_paths(gu_handle h, int32_t max_path, int8_t *path, int32_t *path_len, int32_t *terminal);
 
+/* ---- headless RGB frames (stands in for the pyglet window of core/envs/rendering.py:236-343) -----------------
+ * rgb[n_envs][H*cell_px][W*cell_px][3] uint8 for envs env0 .. env0+n_envs-1: floor / wall / goal / lava tiles, a grid
+ * line on the top and left edge of each cell (cell_px >= 4), the agent as an inset square on its cell. */
+int gu_render_rgb(gu_handle h, int64_t env0, int64_t n_envs, int32_t cell_px, uint8_t *rgb);
+
 /* ---- page-locked host memory -----------------------------------------------------
  * Buffers from gu_host_alloc make gu_step (with GU_F_PINNED_IO), gu_read_outputs and gu_read_trajectory copy at
  * the full PCIe rate; numpy arrays can be built on them (np.ctypeslib / np.frombuffer). */

@@ -46,7 +46,7 @@ def test_ascii_render_matches_reference():
         env.current_state = state
         assert env.render(mode='ansi').getvalue() == frame
     with pytest.raises(gua.UnsupportedMode):
-        env.render(mode='rgb_array')
+        env.render(mode='wireframe')
     assert env.render(close=True) is None
 
 

@@ -116,9 +116,60 @@ __global__ void __launch_bounds__(256) k_cells16(const Args a)
     atomicAdd(a.checksum, sum);
 }
 
+// cells_ws: warp-specialised variant of `cells + trajectory`.  A 512-thread block = 4 compute waves (256 envs) + 4
+// store waves.  The compute waves run the transition chain and drop (obs, reward, done) into an LDS ring of two halves
+// of CH steps each; the store waves drain the other half to HBM.  One __syncthreads per CH steps hands the halves over.
+// Purpose: keep the dependent LDS chain of the compute waves free of store-issue stalls at one env-wave per SIMD.
+constexpr int CH = 16;
+__global__ void __launch_bounds__(512) k_cells_ws(const Args a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t cell[2 * S];
+    __shared__ int ring[2][CH][3][256];  // 96 KB
+    for (int i = threadIdx.x * 16; i < 2 * S; i += blockDim.x * 16) *(uint4 *)(cell + i) = *(const uint4 *)(a.cells + i);
+    __syncthreads();
+    const bool producer = threadIdx.x < 256;
+    const unsigned lane = threadIdx.x & 255;
+    const unsigned e = blockIdx.x * 256 + lane;
+    const uint64_t lut = (uint64_t)(uint16_t)(int16_t)(-W) | (1ull << 16) | ((uint64_t)(uint16_t)W << 32) | (0xFFFFull << 48);
+    int s = a.start;
+    uint32_t flags = cell[s];
+    unsigned long long sum = 0;
+    uint32_t word = 0;
+    const int chunks = a.T / CH;  // T is a multiple of CH in this experiment
+    for (int c = 0; c <= chunks; ++c) {
+        if (producer) {
+            if (c < chunks) {
+                for (int j = 0; j < CH; ++j) {
+                    const int t = c * CH + j;
+                    if ((t & 15) == 0) word = mix(e * 0x9E3779B9u + (uint32_t)(t >> 4));
+                    const uint32_t act = (word >> (2 * (t & 15))) & 3u;
+                    const int delta = __builtin_amdgcn_sbfe((int)(uint32_t)(lut >> (act << 4)), 0, 16);
+                    s = __mul24((int)__builtin_amdgcn_ubfe(flags, act, 1), delta) + s;
+                    flags = cell[s];
+                    const int r = (int8_t)cell[S + s];
+                    const int term = (flags >> 4) & 1;
+                    sum += (unsigned)(s * 31 + r * 7 + term) * (unsigned)(t + 1);
+                    ring[c & 1][j][0][lane] = s;
+                    ring[c & 1][j][1][lane] = r;
+                    ring[c & 1][j][2][lane] = term;
+                }
+            }
+        } else if (c > 0) {
+            for (int j = 0; j < CH; ++j) {
+                const size_t o = (size_t)((c - 1) * CH + j) * a.N + e;
+                a.obs[o] = ring[(c - 1) & 1][j][0][lane];
+                a.rew[o] = ring[(c - 1) & 1][j][1][lane];
+                a.don[o] = ring[(c - 1) & 1][j][2][lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (producer) atomicAdd(a.checksum, sum);
+}
+
 int main()
 {
-    const int N = 65536, T = 1000, reps = 20;
+    const int N = 65536, T = 1008, reps = 20;  // T a multiple of 16 (cells_ws chunks)
     // grid: pseudo-random walls (25 %), a lava column, goal in the far corner; same planes feed both layouts
     std::vector<uint32_t> wall(H, 0), goal(H, 0), lava(H, 0);
     uint32_t h = 12345;
@@ -154,19 +205,20 @@ int main()
         case 2: k_rows<false><<<g, b>>>(a); break;
         case 3: k_cells<false><<<g, b>>>(a); break;
         case 4: k_cells16<true><<<g, b>>>(a); break;
-        default: k_cells16<false><<<g, b>>>(a); break;
+        case 5: k_cells16<false><<<g, b>>>(a); break;
+        default: k_cells_ws<<<g, dim3(512)>>>(a); break;
         }
     };
-    const char *names[6] = {"rows  + trajectory", "cells + trajectory", "rows  , no trajectory", "cells , no trajectory",
-                            "cells16 + trajectory", "cells16, no trajectory"};
-    unsigned long long sums[6];
-    for (int w = 0; w < 6; ++w) {
+    const char *names[7] = {"rows  + trajectory", "cells + trajectory", "rows  , no trajectory", "cells , no trajectory",
+                            "cells16 + trajectory", "cells16, no trajectory", "cells_ws + trajectory"};
+    unsigned long long sums[7];
+    for (int w = 0; w < 7; ++w) {
         CK(hipMemset(dsum, 0, 8)); run(w); CK(hipDeviceSynchronize());
         CK(hipMemcpy(&sums[w], dsum, 8, hipMemcpyDeviceToHost));
     }
-    printf("checksums: rows %llu cells %llu -> %s\n", sums[0], sums[1], (sums[0] == sums[1] && sums[2] == sums[3] && sums[0] == sums[2] && sums[4] == sums[0] && sums[5] == sums[0]) ? "IDENTICAL" : "DIFFERENT");
+    printf("checksums: rows %llu cells %llu -> %s\n", sums[0], sums[1], (sums[0] == sums[1] && sums[2] == sums[3] && sums[0] == sums[2] && sums[4] == sums[0] && sums[5] == sums[0] && sums[6] == sums[0]) ? "IDENTICAL" : "DIFFERENT");
     for (int round = 0; round < 3; ++round)
-        for (int w = 0; w < 6; ++w) {
+        for (int w = 0; w < 7; ++w) {
             run(w);
             CK(hipEventRecord(e0));
             for (int i = 0; i < reps; ++i) run(w);

@@ -95,6 +95,7 @@ struct gu_engine {
     // tabular DP
     double *d_v[2] = {nullptr, nullptr};
     double *d_pi[2] = {nullptr, nullptr};
+    uint4 *d_pi_thr = nullptr;      // [S] inverse-CDF thresholds of d_pi[vi_cur], rebuilt by every GU_POLICY_SAMPLE rollout
     int vi_cur = 0;
     bool has_vi = false;
     double *d_delta = nullptr;      // per-block maxima + final

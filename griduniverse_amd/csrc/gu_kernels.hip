@@ -188,10 +188,41 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
 //   algorithmic HBM bytes per env-step with GU_F_TRAJECTORY: 3 x 4 B row writes = 12 B
 //   (+4 B action read for GU_POLICY_STREAM); state is loaded/stored once per launch.
 // ------------------------------------------------------------------------------------
+// GU_POLICY_SAMPLE draws a = #{k < 3 : u >= p0 + .. + pk} with u = word / 2^32 (oracle/gu_rng.py).  Both sides of
+// u >= c scale exactly by 2^32, and the word is an integer, so the test is word >= ceil(c * 2^32): three uint32
+// thresholds per state (x = always, y, z) and a mask of the sums no word can reach (c * 2^32 > 2^32 - 1, or NaN).
+// The float64 prefix sums are formed here, once per rollout, in the oracle's order; the step then costs one 16-byte
+// read and three integer compares.
+__global__ void __launch_bounds__(256) gu_pi_threshold_kernel(const double *pi, int32_t S, uint4 *thr)
+{
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const double4 p = *reinterpret_cast<const double4 *>(pi + 4 * (int64_t)s);
+    const double c[3] = {p.x, __dadd_rn(p.x, p.y), __dadd_rn(__dadd_rn(p.x, p.y), p.z)};
+    uint32_t t[3], never = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double x = __dmul_rn(c[k], 4294967296.0);  // exact (power of two)
+        if (!(x <= 4294967295.0)) {
+            never |= 1u << k;
+            t[k] = 0xFFFFFFFFu;
+        } else {
+            t[k] = x <= 0.0 ? 0u : (uint32_t)ceil(x);
+        }
+    }
+    thr[s] = make_uint4(t[0], t[1], t[2], never);
+}
+
+__device__ __forceinline__ uint32_t gu_sample_action(uint32_t word, const uint4 q)
+{
+    return (uint32_t)(word >= q.x && !(q.w & 1u)) + (uint32_t)(word >= q.y && !(q.w & 2u)) + (uint32_t)(word >= q.z && !(q.w & 4u));
+}
+
 struct RolloutArgs {
     const uint8_t *cell;
     const uint8_t *greedy;  // first-argmax action per state (GU_POLICY_GREEDY)
-    const double *pi;       // [S][4] action probabilities (GU_POLICY_SAMPLE)
+    const uint4 *pi_thr;    // [S] inverse-CDF thresholds of the action probabilities (GU_POLICY_SAMPLE)
+    int32_t S, pi_lds;      // pi_lds: the threshold table fits in LDS behind the two grid planes
     int32_t cell_bytes, W;
     uint64_t lut;
     int32_t *pos, *reward, *done;
@@ -228,6 +259,13 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
             *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(a.greedy + i);
         __syncthreads();
         greedy = dst;
+    }
+    const uint4 *thr = a.pi_thr;
+    if (LDS && POLICY == GU_POLICY_SAMPLE && a.pi_lds) {
+        uint4 *dst = reinterpret_cast<uint4 *>(smem + 2 * a.cell_bytes);
+        for (int32_t i = threadIdx.x; i < a.S; i += blockDim.x) dst[i] = a.pi_thr[i];
+        __syncthreads();
+        thr = dst;
     }
     const int64_t e64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e64 >= a.N) return;
@@ -398,12 +436,9 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
             if (POLICY == GU_POLICY_GREEDY) {
                 step1(greedy[s]);
             } else {
-                // inverse CDF of pi[s] on one uniform 32-bit word (RNG stream 2, counter = step count):
-                // a = #{k < 3 : u >= p0 + .. + pk}, u = word / 2^32 (exact in float64)
-                const double u = (double)gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t) * 2.3283064365386963e-10;
-                const double4 p = *reinterpret_cast<const double4 *>(a.pi + 4 * (int64_t)s);
-                const double c0 = p.x, c1 = __dadd_rn(c0, p.y), c2 = __dadd_rn(c1, p.z);
-                step1((uint32_t)(u >= c0) + (uint32_t)(u >= c1) + (uint32_t)(u >= c2));
+                // inverse CDF of pi[s] on one uniform 32-bit word (RNG stream 2, counter = step count), as integer
+                // thresholds (gu_pi_threshold_kernel)
+                step1(gu_sample_action(gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t), thr[s]));
             }
         }
     }
@@ -545,8 +580,13 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
     const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
     const int lds_bs = gu_lds_block(h, bs, planes);
     if (lds_bs) {
-        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 1>), dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs),
-                           (size_t)planes * h->cell_bytes, h->stream, a);
+        size_t lds = (size_t)planes * h->cell_bytes;
+        RolloutArgs b = a;
+        if (POLICY == GU_POLICY_SAMPLE && lds + (size_t)h->S * sizeof(uint4) <= 65536) {
+            b.pi_lds = 1;
+            lds += (size_t)h->S * sizeof(uint4);
+        }
+        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 1>), dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), lds, h->stream, b);
         return;
     }
     if constexpr (POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM) {
@@ -596,7 +636,9 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     RolloutArgs a{};
     a.cell = h->d_cell;
     a.greedy = h->d_greedy;
-    a.pi = h->d_pi[h->vi_cur];
+    a.pi_thr = h->d_pi_thr;
+    a.S = h->S;
+    a.pi_lds = 0;
     a.cell_bytes = h->cell_bytes;
     a.W = h->W;
     a.lut = h->delta_lut;
@@ -620,6 +662,8 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.T = T;
     a.gs = gu_grid_sel(h);
     const int bs = gu_rollout_block();
+    if (policy == GU_POLICY_SAMPLE)
+        hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
     switch (policy) {
     case GU_POLICY_UNIFORM: gu_rollout_dispatch<GU_POLICY_UNIFORM>(h, a, auto_mode, traj, stats, bs); break;
     case GU_POLICY_STREAM: gu_rollout_dispatch<GU_POLICY_STREAM>(h, a, auto_mode, traj, stats, bs); break;

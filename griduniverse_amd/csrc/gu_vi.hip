@@ -269,6 +269,7 @@ int gu_vi_alloc(gu_engine *h)
         GU_HIP(hipMalloc(&h->d_pi[k], 4 * S * sizeof(double)));
     }
     GU_HIP(hipMalloc(&h->d_delta, 4096 * sizeof(unsigned long long)));
+    GU_HIP(hipMalloc(&h->d_pi_thr, S * sizeof(uint4)));
     return GU_OK;
 }
 
@@ -279,6 +280,8 @@ void gu_vi_free(gu_engine *h)
         if (h->d_pi[k]) (void)hipFree(h->d_pi[k]);
         h->d_v[k] = h->d_pi[k] = nullptr;
     }
+    if (h->d_pi_thr) (void)hipFree(h->d_pi_thr);
+    h->d_pi_thr = nullptr;
     if (h->d_delta) (void)hipFree(h->d_delta);
     h->d_delta = nullptr;
     h->has_vi = false;

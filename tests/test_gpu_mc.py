@@ -136,3 +136,92 @@ def test_chunk_boundaries_do_not_change_the_result(monkeypatch):
                             ((False, True, True), (True, True, False), (True, False, True))])
     for a, b in zip(*results):
         assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+
+
+@pytest.mark.parametrize('switch', ['GU_MC_LANE_RETURNS', 'GU_MC_GLOBAL_WALK'])
+def test_tiled_and_per_lane_return_kernels_agree(monkeypatch, switch):
+    """The LDS-tiled return kernel (zero-padded columns, masked discount table) against the per-lane kernel on
+    global memory, and the LDS history walk against the global-memory walk, on full-length episodes
+    (2048 x 1000 steps, mean length in the hundreds), every mode."""
+    rs = np.random.RandomState(8)
+    N, T = 2048, 1000
+    random_state = np.random.get_state()
+    import random
+    random.seed(1)
+    np.random.seed(1)
+    env = gua.GridUniverseEnv(grid_shape=(8, 8), random_maze=True)
+    np.random.set_state(random_state)
+    S = env.world.size
+    pi = rs.dirichlet(np.ones(4), S)
+    modes = ((False, True, True), (True, True, True), (True, False, True), (False, True, False))
+    results = []
+    for lane in ('', '1'):
+        if lane:
+            monkeypatch.setenv(switch, lane)
+        else:
+            monkeypatch.delenv(switch, raising=False)
+        with Engine(N, GridSpec.from_env(env), seed=21) as eng:
+            eng.vi_set(np.zeros(S), pi)
+            first = eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
+            out = []
+            for gamma, thr in ((0.99, 1e-4), (1.0, 0.5), (0.5, 1e-3)):
+                pw, keep = mc.discount_table(gamma, thr, T)
+                out += [eng.mc_evaluate(T, first, pw, keep, ev, im, stn, 0.003) for ev, im, stn in modes]
+            results.append(out)
+    for a, b in zip(*results):
+        assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+    env.close()
+
+
+def test_long_episodes_fall_back_to_the_per_lane_kernel():
+    """T = 3000 rows do not fit the LDS tile (8 columns + table > 160 KB): the per-lane kernel runs; checked against
+    the Python restatement on 8 short episodes."""
+    rs = np.random.RandomState(3)
+    W, H, N, T = 4, 4, 8, 3000
+    S = W * H
+    spec = GridSpec(W, H, [0], [S - 1], [], [5, 10])
+    pi = rs.dirichlet(np.ones(4), S)
+    with Engine(N, spec, seed=13) as eng:
+        eng.vi_set(np.zeros(S), pi)
+        first = eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
+        traj = eng.read_trajectory(0, T)
+        for ev, im, stn in ((False, True, True), (True, True, False)):
+            pw, keep = mc.discount_table(0.999, 1e-2, T)
+            v, visits = eng.mc_evaluate(T, first, pw, keep, ev, im, stn, 0.01)
+            eps = omc.episodes_from_trajectory(first, traj['obs'], traj['reward'], traj['done'])
+            v_want, vis_want = omc.monte_carlo_evaluation(S, eps, ev, im, stn, 0.999, 1e-2, 0.01)
+            assert v.tobytes() == v_want.tobytes() and visits.tobytes() == vis_want.tobytes()
+
+
+@pytest.mark.parametrize('W,H', [(8, 8), (64, 64)])
+def test_sample_policy_threshold_edge_cases(W, H):
+    """The device samples with integer thresholds ceil(c * 2^32); the oracle compares u = word / 2^32 with the float64
+    prefix sums.  Rows that put a prefix sum exactly on 0, on 1, above 1, below 0, on a multiple of 2^-32, next to one,
+    or on NaN must give the same actions.  64x64: the threshold table does not fit LDS and is read from L2."""
+    rs = np.random.RandomState(11)
+    S, N, T = W * H, 512, 64
+    pi = rs.dirichlet(np.ones(4), S)
+    special = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [0.5, 0.5, 0, 0], [0, 0, 0, 0],
+                        [2, 0, 0, 0], [-1, 1, 0.5, 0.5], [0.25, 0.25, 0.25, 0.25], [2.0 ** -32, 0.5, 0.25, 0.25],
+                        [np.nextafter(0.5, 1), 0.25, 0.125, 0.125], [np.nextafter(0.5, 0), 0.25, 0.125, 0.125],
+                        [3 * 2.0 ** -32, 2.0 ** -33, 0.5, 0.4], [np.nan, 0.5, 0.25, 0.25], [0.3, np.nan, 0.3, 0.4],
+                        [1e-300, 1e-300, 1e-300, 1], [1 - 2.0 ** -32, 2.0 ** -33, 2.0 ** -33, 0]], dtype=np.float64)
+    pi[rs.permutation(S)[:len(special) * 3]] = np.tile(special, (3, 1))
+    pi[0] = special[4]
+    spec = GridSpec(W, H, [0, 1, W, W + 1], [S - 1], [], [])
+    grid = C.Grid(W, H, spec.wall, spec.lava, spec.goal, spec.reward, spec.starts)
+    st = C.State(N)
+    C.reset(grid, 77, st)
+    want = C.rollout(grid, 77, st, T, auto_reset=True, pi=pi)
+    with Engine(N, spec, seed=77) as eng:
+        eng.vi_set(np.zeros(S), pi)
+        eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'sample', auto_reset=True, trajectory=True)
+        got = eng.read_trajectory(0, T)
+    for k in ('obs', 'reward', 'done'):
+        assert np.array_equal(got[k], want[k]), k

@@ -22,6 +22,7 @@
 #include <cstring>
 
 #define VI_BLOCK 256
+#define VI_RUN_BATCH 64  // rounds queued per host look of gu_vi_run (must not exceed the 4096 delta slots)
 
 struct ViMap {
     const uint8_t *f;  // flags plane (OPEN bits 0..3, TERM bit 4)
@@ -131,12 +132,11 @@ struct ViArgs {
     const double *v, *pi;     // old
     double *v_new, *pi_new;   // new
     unsigned long long *delta_key;
-    // gu_vi_run: device-side stopping rule of value_iteration (dynamic_programming.py:22-23).
-    // ctl[0] = 1-based index of the round that met the threshold (0 = none yet), ctl[1] = rounds completed;
-    // null when the host drives the loop.  A launch of round r is a no-op iff 0 < ctl[0] < r -- comparing against
-    // the round index (not a plain flag) keeps late-starting blocks of round ctl[0]'s own greedy kernel working.
+    // gu_vi_run: device-side stopping rule of value_iteration (dynamic_programming.py:22-23).  ctl[0] != 0 once a
+    // round has met the threshold; prev_delta_key = the finished previous round's delta (null for the first round of
+    // a batch).  Null ctl: the host drives the loop.
     int32_t *ctl;
-    int32_t round;
+    const unsigned long long *prev_delta_key;
     double threshold;
 };
 
@@ -144,10 +144,6 @@ template <bool LDS>
 __global__ void __launch_bounds__(VI_BLOCK) gu_vi_eval_kernel(const ViArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if (a.ctl) {  // an earlier round met the threshold: the remaining launches are no-ops
-        const int32_t hit = a.ctl[0];
-        if (hit != 0 && hit < a.round) return;
-    }
     const ViMap cell = vi_stage<LDS>(a.cell, a.cell_bytes, smem);
     const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = s < a.S;
@@ -164,10 +160,6 @@ template <bool LDS>
 __global__ void __launch_bounds__(VI_BLOCK) gu_vi_greedy_kernel(const ViArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if (a.ctl) {
-        const int32_t hit = a.ctl[0];
-        if (hit != 0 && hit < a.round) return;
-    }
     const ViMap cell = vi_stage<LDS>(a.cell, a.cell_bytes, smem);
     const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= a.S) return;
@@ -175,15 +167,48 @@ __global__ void __launch_bounds__(VI_BLOCK) gu_vi_greedy_kernel(const ViArgs a)
     const double *vn = a.v_new;
     vi_greedy_state(cell, a.W, a.gamma, [vn](int32_t n) { return vn[n]; }, s, row);
     *reinterpret_cast<double4 *>(a.pi_new + 4 * s) = make_double4(row[0], row[1], row[2], row[3]);
-    if (a.ctl && s == 0) {
-        // this round is complete (its delta was final before this kernel started): count it, and if
-        // delta < threshold record the round so that the launches queued behind it become no-ops.
-        const unsigned long long k = *a.delta_key;
-        unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
-        const double delta = __longlong_as_double((long long)b);
-        a.ctl[1] += 1;
-        if (delta < a.threshold) a.ctl[0] = a.round;
+}
+
+__device__ __forceinline__ double vi_unkey_dev(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// One value-iteration round (V1, delta, V2: dynamic_programming.py:15-20) in ONE launch: the greedy update needs
+// v' at the four neighbours, which each lane re-evaluates itself ("pull": 5 V1 evaluations per state instead of a
+// grid-wide barrier between V1 and V2 -- the round is launch-latency-bound, not arithmetic-bound).  With ctl the
+// launch first applies the stopping rule to the previous round's finished delta: every block reads the same two
+// words, so either all of them run or none does.
+template <bool LDS>
+__global__ void __launch_bounds__(VI_BLOCK) gu_vi_round_kernel(const ViArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (a.ctl) {
+        bool stop = a.ctl[0] != 0;
+        if (!stop && a.prev_delta_key) stop = vi_unkey_dev(*a.prev_delta_key) < a.threshold;
+        if (stop) {
+            if (threadIdx.x == 0) a.ctl[0] = 1;  // read by the launches behind this one (same value from every block)
+            return;
+        }
     }
+    const ViMap cell = vi_stage<LDS>(a.cell, a.cell_bytes, smem);
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = s < a.S;
+    const int32_t W = a.W;
+    const double gamma = a.gamma;
+    const double *v = a.v, *pi = a.pi;
+    auto vnew = [=](int32_t n) { return vi_eval_state(cell, W, gamma, v, pi, n); };
+    double d = 0.0;
+    if (valid) {
+        const double vn = vnew(s);
+        a.v_new[s] = vn;
+        d = __dsub_rn(v[s], vn);  // signed, dynamic_programming.py:17
+        double row[4];
+        vi_greedy_state(cell, W, gamma, vnew, s, row);
+        *reinterpret_cast<double4 *>(a.pi_new + 4 * s) = make_double4(row[0], row[1], row[2], row[3]);
+    }
+    vi_block_max_to_global(d, valid, a.delta_key);
 }
 
 // first-argmax action per state (np.argmax; examples/griduniverse_alg_examples.py:76)
@@ -318,7 +343,7 @@ static ViArgs vi_args(gu_engine *h, double gamma, unsigned long long *delta_key)
     a.pi_new = h->d_pi[h->vi_cur ^ 1];
     a.delta_key = delta_key;
     a.ctl = nullptr;
-    a.round = 0;
+    a.prev_delta_key = nullptr;
     a.threshold = 0.0;
     return a;
 }
@@ -365,13 +390,13 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
     const size_t smem = lds ? 2 * (size_t)h->cell_bytes : 0;
     for (int32_t i = 0; i < iters; ++i) {
         ViArgs a = vi_args(h, gamma, (unsigned long long *)h->d_delta + i);
-        if (lds) hipLaunchKernelGGL(gu_vi_eval_kernel<true>, grid, block, smem, h->stream, a);
-        else hipLaunchKernelGGL(gu_vi_eval_kernel<false>, grid, block, 0, h->stream, a);
         if (greedy_update) {
-            if (lds) hipLaunchKernelGGL(gu_vi_greedy_kernel<true>, grid, block, smem, h->stream, a);
-            else hipLaunchKernelGGL(gu_vi_greedy_kernel<false>, grid, block, 0, h->stream, a);
+            if (lds) hipLaunchKernelGGL(gu_vi_round_kernel<true>, grid, block, smem, h->stream, a);
+            else hipLaunchKernelGGL(gu_vi_round_kernel<false>, grid, block, 0, h->stream, a);
             h->vi_cur ^= 1;  // both tables advanced
         } else {
+            if (lds) hipLaunchKernelGGL(gu_vi_eval_kernel<true>, grid, block, smem, h->stream, a);
+            else hipLaunchKernelGGL(gu_vi_eval_kernel<false>, grid, block, 0, h->stream, a);
             // policy unchanged: only v advances; keep pi where it is by swapping v buffers only
             double *t = h->d_v[0];
             h->d_v[0] = h->d_v[1];
@@ -398,36 +423,47 @@ int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, in
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
     const size_t smem = lds ? 2 * (size_t)h->cell_bytes : 0;
-    rc = gu_ensure_scratch(h, 16);
-    if (rc != GU_OK) return rc;
-    int32_t *ctl = (int32_t *)h->d_scratch;
+    int32_t *ctl = (int32_t *)(h->d_delta + 4000);  // past the delta slots a batch uses
     GU_HIP(hipMemsetAsync(ctl, 0, 8, h->stream));
     int32_t done_total = 0, stop = 0;
     const int start_cur = h->vi_cur;
-    for (int32_t base = 0; base < max_steps && !stop; base += 4096) {  // one host round trip per 4096 queued rounds
-        const int32_t n = max_steps - base < 4096 ? max_steps - base : 4096;
+    // Rounds are queued VI_RUN_BATCH at a time; the stopping rule is evaluated on the device, so a batch never runs
+    // past the round that met the threshold (the launches behind it are no-ops) and the host looks only once per
+    // batch.  Small batches bound the no-op tail: a no-op round still costs its launch.  (Replaying a batch as a
+    // hipGraph was measured and is no faster: a round is bound by its own execution, ~5 us, not by the launch.)
+    auto enqueue = [&](int32_t n) {
         GU_HIP(hipMemsetAsync(h->d_delta, 0, (size_t)n * sizeof(unsigned long long), h->stream));
-        for (int32_t i = 0; i < n; ++i) {
+        int cur = h->vi_cur;
+        for (int32_t i = 0; i < n; ++i, cur ^= 1) {
             ViArgs a = vi_args(h, gamma, (unsigned long long *)h->d_delta + i);
+            a.v = h->d_v[cur];
+            a.pi = h->d_pi[cur];
+            a.v_new = h->d_v[cur ^ 1];
+            a.pi_new = h->d_pi[cur ^ 1];
             a.ctl = ctl;
-            a.round = base + i + 1;
+            a.prev_delta_key = i ? (const unsigned long long *)h->d_delta + i - 1 : nullptr;  // the host checked the last batch
             a.threshold = threshold;
-            if (lds) hipLaunchKernelGGL(gu_vi_eval_kernel<true>, grid, block, smem, h->stream, a);
-            else hipLaunchKernelGGL(gu_vi_eval_kernel<false>, grid, block, 0, h->stream, a);
-            if (lds) hipLaunchKernelGGL(gu_vi_greedy_kernel<true>, grid, block, smem, h->stream, a);
-            else hipLaunchKernelGGL(gu_vi_greedy_kernel<false>, grid, block, 0, h->stream, a);
-            h->vi_cur ^= 1;
+            if (lds) hipLaunchKernelGGL(gu_vi_round_kernel<true>, grid, block, smem, h->stream, a);
+            else hipLaunchKernelGGL(gu_vi_round_kernel<false>, grid, block, 0, h->stream, a);
         }
+        return GU_OK;
+    };
+    std::vector<unsigned long long> keys(VI_RUN_BATCH);
+    for (int32_t base = 0; base < max_steps && !stop; base += VI_RUN_BATCH) {
+        const int32_t n = max_steps - base < VI_RUN_BATCH ? max_steps - base : VI_RUN_BATCH;
+        rc = enqueue(n);
+        if (rc != GU_OK) return rc;
+        h->vi_cur ^= n & 1;
         GU_HIP(hipGetLastError());
-        int32_t host_ctl[2] = {0, 0};
-        GU_HIP(hipMemcpyAsync(host_ctl, ctl, 8, hipMemcpyDeviceToHost, h->stream));
-        std::vector<unsigned long long> keys((size_t)n);
-        if (deltas) GU_HIP(hipMemcpyAsync(keys.data(), h->d_delta, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        GU_HIP(hipMemcpyAsync(keys.data(), h->d_delta, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         GU_HIP(hipStreamSynchronize(h->stream));
-        stop = host_ctl[0] != 0;
-        if (deltas)
-            for (int32_t i = 0; i < host_ctl[1] - base && i < n; ++i) deltas[base + i] = vi_unkey(keys[(size_t)i]);
-        done_total = host_ctl[1];
+        // rounds of this batch that ran: up to and including the first one whose delta met the threshold (:22-23)
+        for (int32_t i = 0; i < n && !stop; ++i) {
+            const double delta = vi_unkey(keys[(size_t)i]);
+            if (deltas) deltas[base + i] = delta;
+            ++done_total;
+            stop = delta < threshold;
+        }
     }
     h->vi_cur = start_cur ^ (done_total & 1);  // launches queued after the stop did not touch the tables
     h->greedy_valid = false;

@@ -58,6 +58,7 @@ SIGNATURES = {
     'gu_vi_set': [_vp, _vp, _vp],
     'gu_vi_sweep': [_vp, _f64, _i32, _i32, _vp],
     'gu_vi_run': [_vp, _f64, _f64, _i32, _vp, _vp],
+    'gu_vi_eval_run': [_vp, _f64, _f64, _i32, _vp, _vp],
     'gu_vi_greedy': [_vp, _f64],
     'gu_vi_get': [_vp, _vp, _vp],
     'gu_vi_sweep_step': [_vp, _f64, _u32, _vp],

@@ -32,22 +32,25 @@ def policy_iteration(policy, env, value_function=None, threshold=0.00001, max_st
     eng = engine_of(env)
     converged_v = np.zeros(env.world.size) if value_function is None else value_function
     eng.vi_set(converged_v, policy)
-    for step_number in range(max_steps):
-        delta_eval = eng.vi_sweep(discount_factor, 1, greedy_update=False)[0]
+    steps_left = max_steps
+    while steps_left > 0:
+        # the evaluation sweeps up to the next converged one run on the device in one call (stopping rule included)
+        swept, deltas_eval = eng.vi_eval_run(discount_factor, threshold, steps_left)
+        steps_left -= swept
+        delta_eval = deltas_eval[-1]
         if delta_eval < threshold:
             v_now, pi_now = eng.vi_get()
             eng.vi_greedy(discount_factor)
             delta = np.max(converged_v - v_now)
             converged_v = v_now
-            if delta < threshold:
-                # the reference computes the improved policy into the SAME array it returns
-                policy[...] = eng.vi_get()[1]
-                break
+            # the reference computes the improved policy into the SAME array it returns
             policy[...] = eng.vi_get()[1]
-        elif step_number == max_steps - 1:
+            if delta < threshold:
+                break
+        else:  # the last allowed sweep did not converge
             eng.vi_set(converged_v, eng.vi_get()[1])
             eng.vi_greedy(discount_factor)
             policy[...] = eng.vi_get()[1]
             warnings.warn('Policy iteration did not reach the selected threshold. Finished after reaching '
-                          'the maximum {} steps with delta_eval {}'.format(step_number + 1, delta_eval), UserWarning)
+                          'the maximum {} steps with delta_eval {}'.format(max_steps, delta_eval), UserWarning)
     return converged_v, policy

@@ -19,7 +19,10 @@
 #include "gu_internal.hpp"
 #include "gu_rng.hpp"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #define VI_BLOCK 256
 #define VI_RUN_BATCH 64  // rounds queued per host look of gu_vi_run (must not exceed the 4096 delta slots)
@@ -56,14 +59,41 @@ __device__ __forceinline__ double vi_eval_state(const ViMap &cell, int32_t W, do
     return acc;
 }
 
-__device__ __forceinline__ double vi_around8(double x)
+// Ties of np.around(q, 8) (utils.py:66-68).  around8(x) = rint(x * 1e8) / 1e8 and the division is a function of the
+// integer k = rint(x * 1e8) alone, so equal k give equal around8.  Conversely, while |k| < 2^25 * 1e8 the quotients of
+// two different integers are at least 1e-8 apart and an ulp there is at most 2^-27 < 1e-8, so they round to
+// different float64: equality of around8 IS equality of k, and the five IEEE divisions (a third of the round's
+// arithmetic) are only needed beyond |q| = 3.3e7 or for NaN.
+__device__ __forceinline__ uint32_t vi_tie_mask(const double q[4], double qmax)
 {
-    return __ddiv_rn(rint(__dmul_rn(x, 100000000.0)), 100000000.0);
+    double k[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) k[a] = rint(__dmul_rn(q[a], 100000000.0));
+    const double kmax = rint(__dmul_rn(qmax, 100000000.0));
+    const double lim = 3355443200000000.0;  // 2^25 * 1e8 (exactly representable, < 2^53)
+    const bool small = fabs(k[0]) < lim && fabs(k[1]) < lim && fabs(k[2]) < lim && fabs(k[3]) < lim;  // false on NaN
+    uint32_t mask = 0;
+    if (small) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) mask |= (uint32_t)(k[a] == kmax) << a;
+    } else {
+        const double rmax = __ddiv_rn(kmax, 100000000.0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) mask |= (uint32_t)(__ddiv_rn(k[a], 100000000.0) == rmax) << a;
+    }
+    return mask;
 }
 
-// V2 for one state given a functor returning v'(n)
+__device__ __forceinline__ double vi_share(uint32_t mask)
+{
+    const int ties = __popc(mask);
+    return (ties == 1) ? 1.0 : (ties == 2) ? 0.5 : (ties == 3) ? (1.0 / 3.0) : 0.25;
+}
+
+// V2 for one state given a functor returning v'(n): bit a of the result = action a ties for the maximum
+// (0 for a terminal state: its row is all zeros, utils.py:62-63)
 template <typename VNew>
-__device__ __forceinline__ void vi_greedy_state(const ViMap &cell, int32_t W, double gamma, VNew vnew, int32_t s, double out[4])
+__device__ __forceinline__ uint32_t vi_greedy_mask(const ViMap &cell, int32_t W, double gamma, VNew vnew, int32_t s)
 {
     const uint32_t rec = cell.f[s];
     double q[4];
@@ -76,18 +106,17 @@ __device__ __forceinline__ void vi_greedy_state(const ViMap &cell, int32_t W, do
     double qmax = q[0];
 #pragma unroll
     for (int a = 1; a < 4; ++a) qmax = (q[a] > qmax) ? q[a] : qmax;
-    const double rmax = vi_around8(qmax);
-    bool tie[4];
-    int ties = 0;
+    const uint32_t mask = vi_tie_mask(q, qmax);
+    return (rec & GU_CELL_TERM) ? 0u : mask;
+}
+
+template <typename VNew>
+__device__ __forceinline__ void vi_greedy_state(const ViMap &cell, int32_t W, double gamma, VNew vnew, int32_t s, double out[4])
+{
+    const uint32_t mask = vi_greedy_mask(cell, W, gamma, vnew, s);
+    const double share = vi_share(mask);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        tie[a] = vi_around8(q[a]) == rmax;
-        ties += tie[a];
-    }
-    const double share = (ties == 1) ? 1.0 : (ties == 2) ? 0.5 : (ties == 3) ? (1.0 / 3.0) : 0.25;
-    const bool term = rec & GU_CELL_TERM;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) out[a] = (tie[a] && !term) ? share : 0.0;
+    for (int a = 0; a < 4; ++a) out[a] = ((mask >> a) & 1u) ? share : 0.0;
 }
 
 // order-preserving double -> uint64 key so that max(double) is an integer atomicMax
@@ -209,6 +238,112 @@ __global__ void __launch_bounds__(VI_BLOCK) gu_vi_round_kernel(const ViArgs a)
         *reinterpret_cast<double4 *>(a.pi_new + 4 * s) = make_double4(row[0], row[1], row[2], row[3]);
     }
     vi_block_max_to_global(d, valid, a.delta_key);
+}
+
+// ------------------------------------------------------------------------------------
+// Grids up to 4096 states (config 5's 64x64): the whole iteration in ONE launch of ONE 1024-thread workgroup.
+// v is double-buffered in LDS next to the grid planes, each thread owns K = ceil(S / 1024) states and keeps their
+// policy rows in registers, a round costs two workgroup barriers instead of a kernel boundary (~5 us: launch, staging
+// the planes, L2 round trips), and the stopping rule of value_iteration / of policy_iteration's evaluation loop is a
+// wave-uniform branch.  GREEDY: V1 + V2 per round (dynamic_programming.py:15-23); else V1 only with the policy fixed
+// (:40-42).  Same operations in the same order as the per-round kernels above, hence the same bits.
+// ------------------------------------------------------------------------------------
+#define VI_PB_THREADS 1024
+#define VI_PB_MAX_STATES 4096
+
+struct ViBlockArgs {
+    const uint8_t *cell;
+    int32_t cell_bytes, W, S;
+    double gamma, threshold;
+    double *v, *pi;                  // updated in place when at least one round ran
+    unsigned long long *delta_key;   // [max_rounds]
+    int32_t *rounds_done;
+    int32_t max_rounds, use_threshold;
+};
+
+template <int K, bool GREEDY>
+__global__ void __launch_bounds__(VI_PB_THREADS) gu_vi_block_kernel(const ViBlockArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ unsigned long long wave_key[VI_PB_THREADS / 64];
+    __shared__ unsigned long long round_key;
+    const ViMap cell = vi_stage<true>(a.cell, a.cell_bytes, smem);
+    double *vbuf = reinterpret_cast<double *>(smem + 2 * a.cell_bytes);  // [2][S]
+    const int32_t tid = threadIdx.x, S = a.S, W = a.W;
+    const double gamma = a.gamma;
+    double p[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int32_t s = tid + j * VI_PB_THREADS;
+        if (s < S) {
+            vbuf[s] = a.v[s];
+            const double4 row = *reinterpret_cast<const double4 *>(a.pi + 4 * (int64_t)s);
+            p[j][0] = row.x, p[j][1] = row.y, p[j][2] = row.z, p[j][3] = row.w;
+        }
+    }
+    __syncthreads();
+    int cur = 0, r = 0;
+    for (; r < a.max_rounds; ++r) {
+        const double *vo = vbuf + cur * S;
+        double *vn = vbuf + (cur ^ 1) * S;
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {  // V1 (utils.py:15-27)
+            const int32_t s = tid + j * VI_PB_THREADS;
+            if (s < S) {
+                const uint32_t rec = cell.f[s];
+                double acc = __dadd_rn(0.0, vi_reward(cell, s));
+#pragma unroll
+                for (uint32_t act = 0; act < 4; ++act)
+                    acc = __dadd_rn(acc, __dmul_rn(p[j][act], __dmul_rn(gamma, vo[vi_next(s, rec, act, W)])));
+                vn[s] = acc;
+                const unsigned long long k = vi_key(__dsub_rn(vo[s], acc));  // signed, dynamic_programming.py:17
+                key = k > key ? k : key;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_down(key, off);
+            key = o > key ? o : key;
+        }
+        if ((tid & 63) == 0) wave_key[tid >> 6] = key;
+        __syncthreads();  // v' complete, wave maxima posted
+        if (tid < 64) {
+            unsigned long long k = tid < VI_PB_THREADS / 64 ? wave_key[tid] : 0ull;
+            for (int off = 8; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_down(k, off);
+                k = o > k ? o : k;
+            }
+            if (tid == 0) {
+                round_key = k;
+                a.delta_key[r] = k;
+            }
+        }
+        if (GREEDY) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {  // V2 (utils.py:55-72) on v'
+                const int32_t s = tid + j * VI_PB_THREADS;
+                if (s < S) vi_greedy_state(cell, W, gamma, [vn](int32_t n) { return vn[n]; }, s, p[j]);
+            }
+        }
+        __syncthreads();  // round_key visible; nobody still reads the old v
+        cur ^= 1;
+        if (a.use_threshold && vi_unkey_dev(round_key) < a.threshold) {
+            ++r;
+            break;
+        }
+    }
+    if (r > 0) {
+        const double *vf = vbuf + cur * S;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int32_t s = tid + j * VI_PB_THREADS;
+            if (s < S) {
+                a.v[s] = vf[s];
+                if (GREEDY) *reinterpret_cast<double4 *>(a.pi + 4 * (int64_t)s) = make_double4(p[j][0], p[j][1], p[j][2], p[j][3]);
+            }
+        }
+    }
+    if (tid == 0) *a.rounds_done = r;
 }
 
 // first-argmax action per state (np.argmax; examples/griduniverse_alg_examples.py:76)
@@ -348,6 +483,54 @@ static ViArgs vi_args(gu_engine *h, double gamma, unsigned long long *delta_key)
     return a;
 }
 
+// The single-workgroup path: grids of up to VI_PB_MAX_STATES states (GU_VI_MULTI_LAUNCH=1 forces the per-round
+// launches, for the tests).  Runs up to max_rounds rounds in place on the current tables.
+static bool vi_block_eligible(const gu_engine *h)
+{
+    return h->S <= VI_PB_MAX_STATES && std::getenv("GU_VI_MULTI_LAUNCH") == nullptr;
+}
+
+static int vi_block_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds,
+                        int32_t *rounds_done, double *deltas)
+{
+    *rounds_done = 0;
+    if (max_rounds <= 0) return GU_OK;
+    const size_t key_bytes = (size_t)max_rounds * sizeof(unsigned long long);
+    int rc = gu_ensure_scratch(h, key_bytes + 16);
+    if (rc != GU_OK) return rc;
+    unsigned long long *keys_d = (unsigned long long *)h->d_scratch;
+    int32_t *done_d = (int32_t *)((char *)h->d_scratch + key_bytes);
+    ViBlockArgs a{h->d_cell, h->cell_bytes, h->W, h->S, gamma, threshold, h->d_v[h->vi_cur], h->d_pi[h->vi_cur], keys_d, done_d,
+                  max_rounds, use_threshold ? 1 : 0};
+    const size_t smem = 2 * (size_t)h->cell_bytes + 2 * (size_t)h->S * sizeof(double);
+    const int K = (h->S + VI_PB_THREADS - 1) / VI_PB_THREADS;
+    void (*kern)(const ViBlockArgs) = nullptr;
+    switch (K * 2 + (greedy ? 1 : 0)) {
+    case 2: kern = gu_vi_block_kernel<1, false>; break;
+    case 3: kern = gu_vi_block_kernel<1, true>; break;
+    case 4: kern = gu_vi_block_kernel<2, false>; break;
+    case 5: kern = gu_vi_block_kernel<2, true>; break;
+    case 6: kern = gu_vi_block_kernel<3, false>; break;
+    case 7: kern = gu_vi_block_kernel<3, true>; break;
+    case 8: kern = gu_vi_block_kernel<4, false>; break;
+    default: kern = gu_vi_block_kernel<4, true>; break;
+    }
+    if (smem > 64 * 1024) GU_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(VI_PB_THREADS), smem, h->stream, a);
+    GU_HIP(hipGetLastError());
+    int32_t done = 0;
+    GU_HIP(hipMemcpyAsync(&done, done_d, sizeof done, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (deltas && done > 0) {
+        std::vector<unsigned long long> keys((size_t)done);
+        GU_HIP(hipMemcpy(keys.data(), keys_d, (size_t)done * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int32_t i = 0; i < done; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
+    }
+    *rounds_done = done;
+    h->greedy_valid = false;
+    return GU_OK;
+}
+
 extern "C" {
 
 int gu_vi_set(gu_handle h, const double *v, const double *pi)
@@ -384,6 +567,10 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(iters > 0 && iters <= 4096, GU_ERR_INVALID, "iters must be in 1..4096 per call");
+    if (vi_block_eligible(h)) {
+        int32_t done = 0;
+        return vi_block_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
+    }
     GU_HIP(hipMemsetAsync(h->d_delta, 0, (size_t)iters * sizeof(unsigned long long), h->stream));
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
@@ -420,6 +607,7 @@ int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, in
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
+    if (vi_block_eligible(h)) return vi_block_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
     const size_t smem = lds ? 2 * (size_t)h->cell_bytes : 0;
@@ -466,6 +654,66 @@ int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, in
         }
     }
     h->vi_cur = start_cur ^ (done_total & 1);  // launches queued after the stop did not touch the tables
+    h->greedy_valid = false;
+    *steps_done = done_total;
+    return GU_OK;
+}
+
+int gu_vi_eval_run(gu_handle h, double gamma, double threshold, int32_t max_steps, int32_t *steps_done, double *deltas)
+{
+    int rc = gu_use_device(h);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
+    GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
+    if (vi_block_eligible(h)) return vi_block_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
+    // larger grids: one evaluation launch per sweep, the host looks at the deltas once per batch
+    const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
+    const bool lds = h->S <= GU_MAX_LDS_CELLS;
+    const size_t smem = lds ? 2 * (size_t)h->cell_bytes : 0;
+    std::vector<unsigned long long> keys(VI_RUN_BATCH);
+    int32_t done_total = 0;
+    bool stop = false;
+    while (done_total < max_steps && !stop) {
+        // a sweep past the converged one would change v: snapshot v, queue one batch, find the first converged sweep,
+        // and if the batch overshot it restore the snapshot and replay exactly that many sweeps
+        const int32_t n = std::min<int32_t>(VI_RUN_BATCH, max_steps - done_total);
+        rc = gu_ensure_scratch(h, (size_t)h->S * sizeof(double));
+        if (rc != GU_OK) return rc;
+        GU_HIP(hipMemcpyAsync(h->d_scratch, h->d_v[h->vi_cur], (size_t)h->S * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        auto sweeps = [&](int32_t count) {
+            GU_HIP(hipMemsetAsync(h->d_delta, 0, (size_t)count * sizeof(unsigned long long), h->stream));
+            for (int32_t i = 0; i < count; ++i) {
+                ViArgs a = vi_args(h, gamma, (unsigned long long *)h->d_delta + i);
+                if (lds) hipLaunchKernelGGL(gu_vi_eval_kernel<true>, grid, block, smem, h->stream, a);
+                else hipLaunchKernelGGL(gu_vi_eval_kernel<false>, grid, block, 0, h->stream, a);
+                double *t = h->d_v[0];  // policy unchanged: only v advances
+                h->d_v[0] = h->d_v[1];
+                h->d_v[1] = t;
+            }
+            GU_HIP(hipGetLastError());
+            return GU_OK;
+        };
+        rc = sweeps(n);
+        if (rc != GU_OK) return rc;
+        GU_HIP(hipMemcpyAsync(keys.data(), h->d_delta, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        GU_HIP(hipStreamSynchronize(h->stream));
+        int32_t ran = n;
+        for (int32_t i = 0; i < n; ++i) {
+            const double delta = vi_unkey(keys[(size_t)i]);
+            if (deltas) deltas[done_total + i] = delta;
+            if (delta < threshold) {
+                ran = i + 1;
+                stop = true;
+                break;
+            }
+        }
+        if (ran < n) {  // overshot: back to the snapshot, replay the sweeps up to the converged one
+            GU_HIP(hipMemcpyAsync(h->d_v[h->vi_cur], h->d_scratch, (size_t)h->S * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            rc = sweeps(ran);
+            if (rc != GU_OK) return rc;
+        }
+        done_total += ran;
+    }
     h->greedy_valid = false;
     *steps_done = done_total;
     return GU_OK;

@@ -246,6 +246,14 @@ class Engine(object):
         check(self.lib.gu_vi_run(self._h, float(gamma), float(threshold), int(max_steps), ctypes.byref(done), ptr(deltas)))
         return done.value, deltas[:done.value].copy()
 
+    def vi_eval_run(self, gamma=1.0, threshold=1e-5, max_steps=1000):
+        """policy_iteration's evaluation loop: V1 sweeps on the fixed policy until delta < threshold (or max_steps).
+        Returns (sweeps done, deltas)."""
+        done = ctypes.c_int32(0)
+        deltas = np.full(max(int(max_steps), 1), np.nan)
+        check(self.lib.gu_vi_eval_run(self._h, float(gamma), float(threshold), int(max_steps), ctypes.byref(done), ptr(deltas)))
+        return done.value, deltas[:done.value].copy()
+
     def vi_greedy(self, gamma=1.0):
         check(self.lib.gu_vi_greedy(self._h, float(gamma)))
 

@@ -179,6 +179,10 @@ int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int3
  *               max_steps rounds {V1, delta, V2}; the stopping rule `delta < threshold` is evaluated ON THE
  *               DEVICE after each round and turns the launches queued behind it into no-ops, so the host
  *               synchronises once.  steps_done = rounds executed; deltas[0..steps_done) optional.
+ * gu_vi_eval_run : policy_iteration's evaluation loop (dynamic_programming.py:40-42): V1 sweeps with the policy
+ *               fixed until `delta < threshold` or max_steps sweeps; steps_done / deltas as for gu_vi_run.
+ *               (Grids of up to 4096 states run gu_vi_run / gu_vi_eval_run / gu_vi_sweep as ONE launch of one
+ *               workgroup with v in LDS; larger grids take one launch per round.)
  * gu_vi_greedy: V2 alone on the current v (policy improvement without an evaluation sweep)
  * gu_vi_get   : download v / pi (either may be NULL)
  * gu_vi_sweep_step : config 5 -- ONE launch that performs one V1+V2 sweep AND one env
@@ -186,6 +190,7 @@ int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int3
 int gu_vi_set(gu_handle h, const double *v, const double *pi);
 int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update, double *deltas);
 int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, int32_t *steps_done, double *deltas);
+int gu_vi_eval_run(gu_handle h, double gamma, double threshold, int32_t max_steps, int32_t *steps_done, double *deltas);
 int gu_vi_greedy(gu_handle h, double gamma);
 int gu_vi_get(gu_handle h, double *v, double *pi);
 int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta);

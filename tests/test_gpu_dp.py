@@ -17,6 +17,18 @@ from tests import _golden as G
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=['one_workgroup', 'launch_per_round'])
+def vi_path(request, monkeypatch):
+    """Every test runs twice: grids of up to 4096 states normally take the single-workgroup kernel (v in LDS, the
+    whole iteration in one launch); GU_VI_MULTI_LAUNCH=1 sends them down the one-launch-per-round path that larger
+    grids use."""
+    if request.param == 'launch_per_round':
+        monkeypatch.setenv('GU_VI_MULTI_LAUNCH', '1')
+    else:
+        monkeypatch.delenv('GU_VI_MULTI_LAUNCH', raising=False)
+    return request.param
+
+
 def spec_of(meta):
     return GridSpec(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'])
 
@@ -235,3 +247,64 @@ def test_vi_run_on_a_grid_larger_than_the_resident_block_capacity():
             steps, deltas = eng.vi_run(1.0, threshold, max_steps)
             v, pi = eng.vi_get()
             assert steps == want and v.tobytes() == v_want.tobytes() and pi.tobytes() == pi_want.tobytes()
+
+
+@pytest.mark.parametrize('name', ['maze8_s1', 'maze11_s3_g09', 'lava4x4_g095', 'maze32_s1_g099'])
+def test_vi_eval_run_is_the_host_loop_of_policy_iteration(name):
+    """gu_vi_eval_run = V1 sweeps on the fixed policy until delta < threshold: same sweep count, deltas and v as one
+    sweep per call with the host applying the rule (dynamic_programming.py:40-42)."""
+    meta, z = G.load_dp(name)
+    S, gamma = meta['W'] * meta['H'], meta['gamma']
+    rs = np.random.RandomState(1)
+    pi0 = rs.dirichlet(np.ones(4), S)
+    with Engine(4, spec_of(meta)) as eng:
+        for threshold, max_steps in ((1e-3, 300), (0.5, 300), (1e-6, 9), (1e9, 5), (1e-3, 0), (1e-3, 70)):
+            eng.vi_set(np.zeros(S), pi0)
+            want_deltas = []
+            for k in range(max_steps):
+                want_deltas.append(eng.vi_sweep(gamma, 1, greedy_update=False)[0])
+                if want_deltas[-1] < threshold:
+                    break
+            v_want, pi_want = eng.vi_get()
+            eng.vi_set(np.zeros(S), pi0)
+            steps, deltas = eng.vi_eval_run(gamma, threshold, max_steps)
+            v, pi = eng.vi_get()
+            assert steps == len(want_deltas) and deltas.tolist() == want_deltas, (name, threshold, max_steps)
+            assert v.tobytes() == v_want.tobytes() and pi.tobytes() == pi0.tobytes() == pi_want.tobytes()
+
+
+def test_one_workgroup_and_launch_per_round_agree_at_64x64(monkeypatch):
+    """config 5's grid through both paths: 300 rounds of value iteration, a policy-evaluation run and sweeps from a
+    random policy and value table (ties, negative and positive values), compared as raw bytes."""
+    import random
+    state = np.random.get_state()
+    random.seed(5)
+    np.random.seed(5)
+    env = gua.GridUniverseEnv(grid_shape=(64, 64), random_maze=True)
+    np.random.set_state(state)
+    S = env.world.size
+    rs = np.random.RandomState(9)
+    v0, pi0 = rs.randn(S) * 3, rs.dirichlet(np.ones(4), S)
+    out = []
+    for multi in (False, True):
+        if multi:
+            monkeypatch.setenv('GU_VI_MULTI_LAUNCH', '1')
+        else:
+            monkeypatch.delenv('GU_VI_MULTI_LAUNCH', raising=False)
+        with Engine(4, GridSpec.from_env(env)) as eng:
+            res = []
+            eng.vi_set(v0, pi0)
+            res.append(eng.vi_run(0.95, 1e-4, 300))
+            res.append(eng.vi_get())
+            eng.vi_set(v0, pi0)
+            res.append(eng.vi_eval_run(0.9, 1e-3, 200))
+            res.append(eng.vi_get())
+            res.append((0, eng.vi_sweep(1.0, 37, greedy_update=True)))
+            res.append(eng.vi_get())
+            res.append((0, eng.vi_sweep(0.99, 5, greedy_update=False)))
+            res.append(eng.vi_get())
+            out.append(res)
+    env.close()
+    for a, b in zip(*out):
+        assert a[0] == b[0] if isinstance(a[0], int) else a[0].tobytes() == b[0].tobytes()
+        assert np.asarray(a[1]).tobytes() == np.asarray(b[1]).tobytes()

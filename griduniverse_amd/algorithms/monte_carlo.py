@@ -44,8 +44,21 @@ def monte_carlo_evaluation(policy, env, every_visit=False, incremental_mean=True
     default 1000), the RNG seed of the batch, and `return_details` to also get the visit counters and
     the raw trajectory."""
     from ..vec_env import VecGridUniverse
-    batch = VecGridUniverse(num_episodes, template=env, seed=seed, auto_reset=False,
-                            device=getattr(engine_of(env), 'device', 0))
+    device = getattr(engine_of(env), 'device', 0)
+    # the batch engine of the previous call on this env is kept (creating one costs a few ms of allocations, the
+    # evaluation itself well under one): re-seeding restores exactly the state of a fresh engine
+    key = (int(num_episodes), device)
+    kept = getattr(env, '_episode_batch', None) if hasattr(env, '__dict__') else None
+    if kept is not None and kept[0] == key:
+        batch = kept[1]
+        batch.engine.seed(seed)
+    else:
+        if kept is not None:
+            kept[1].close()
+            env._episode_batch = None
+        batch = VecGridUniverse(num_episodes, template=env, seed=seed, auto_reset=False, device=device)
+        if hasattr(env, '_drop_engine'):  # the facade closes it together with its own engine
+            env._episode_batch = (key, batch)
     try:
         eng = batch.engine
         eng.vi_set(np.zeros(env.world.size), policy)
@@ -59,4 +72,5 @@ def monte_carlo_evaluation(policy, env, every_visit=False, incremental_mean=True
             return value, dict(total_visit_counter=visits, first_state=first, **eng.read_trajectory(0, T))
         return value
     finally:
-        batch.close()
+        if getattr(env, '_episode_batch', None) is None or env._episode_batch[1] is not batch:
+            batch.close()

@@ -130,6 +130,9 @@ class GridUniverseEnv(object):
         if self._engine_obj is not None:
             self._engine_obj.close()
         self._engine_obj = None
+        batch = self.__dict__.pop('_episode_batch', None)  # algorithms.monte_carlo keeps its last batch engine here
+        if batch is not None:
+            batch[1].close()
         self._tables = {}
         self._pos_dirty = True
 

@@ -308,3 +308,51 @@ def test_one_workgroup_and_launch_per_round_agree_at_64x64(monkeypatch):
     for a, b in zip(*out):
         assert a[0] == b[0] if isinstance(a[0], int) else a[0].tobytes() == b[0].tobytes()
         assert np.asarray(a[1]).tobytes() == np.asarray(b[1]).tobytes()
+
+
+def test_random_grids_dp_property():
+    """Random grids (walls / lava / goals anywhere, incl. overlaps), random gamma, random value and policy tables
+    (zeros, ties, negative entries): sweeps, greedy updates, the device-side loops and their stopping rounds against
+    the C restatement, bytes for bytes.  GU_FUZZ_TRIALS=N for a longer soak."""
+    import os
+    trials = int(os.environ.get('GU_FUZZ_TRIALS', '40'))
+    rs = np.random.RandomState(int(os.environ.get('GU_FUZZ_SEED', '77')))
+    for trial in range(trials):
+        W, H = int(rs.randint(1, 80)), int(rs.randint(1, 60))
+        S = W * H
+        pick = lambda k: [int(x) for x in rs.choice(S, size=min(S, int(k)), replace=False)]  # noqa: E731
+        walls, lava, goals = pick(rs.randint(0, S // 3 + 1)), pick(rs.randint(0, 6)), pick(rs.randint(1, 5))
+        meta = dict(W=W, H=H, walls=walls, lava=lava, goals=goals, starts=[0])
+        grid = C.Grid.from_lists(**meta)
+        spec = GridSpec(W, H, [0], goals, lava, walls)
+        gamma = float(rs.choice([1.0, 0.9, 0.5, 0.99, rs.uniform(0, 1.2)]))
+        v = rs.choice([0.0, 1.0, -1.0, 2.5]) * rs.randn(S) if trial % 3 else np.round(rs.randn(S), 1)  # ties on purpose
+        pi = rs.dirichlet(np.ones(4), S) if trial % 2 else np.ones((S, 4)) / 4
+        rounds, threshold = int(rs.randint(1, 12)), float(rs.choice([1e-3, 0.3, 5.0, -1.0]))
+        # the reference loop, one round at a time
+        v_w, pi_w, deltas_w = v.copy(), pi.copy(), []
+        for _ in range(rounds):
+            v_w, pi_w, d = C.value_iteration_step(grid, gamma, pi_w, v_w)
+            deltas_w.append(d)
+            if d < threshold:
+                break
+        e_v, e_deltas = v.copy(), []
+        for _ in range(rounds):
+            new = C.policy_evaluation_sweep(grid, gamma, pi, e_v)
+            e_deltas.append(float(np.max(e_v - new)))
+            e_v = new
+            if e_deltas[-1] < threshold:
+                break
+        with Engine(2, spec) as eng:
+            eng.vi_set(v, pi)
+            steps, deltas = eng.vi_run(gamma, threshold, rounds)
+            got_v, got_pi = eng.vi_get()
+            assert steps == len(deltas_w) and deltas.tolist() == deltas_w, (trial, W, H, gamma)
+            assert got_v.tobytes() == v_w.tobytes() and got_pi.tobytes() == pi_w.tobytes(), (trial, W, H, gamma)
+            eng.vi_set(v, pi)
+            steps, deltas = eng.vi_eval_run(gamma, threshold, rounds)
+            got_v, got_pi = eng.vi_get()
+            assert steps == len(e_deltas) and deltas.tolist() == e_deltas, (trial, W, H, gamma)
+            assert got_v.tobytes() == e_v.tobytes() and got_pi.tobytes() == pi.tobytes()
+            eng.vi_greedy(gamma)
+            assert eng.vi_get()[1].tobytes() == C.greedy_policy(grid, gamma, e_v).tobytes()

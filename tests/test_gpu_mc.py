@@ -225,3 +225,45 @@ def test_sample_policy_threshold_edge_cases(W, H):
         got = eng.read_trajectory(0, T)
     for k in ('obs', 'reward', 'done'):
         assert np.array_equal(got[k], want[k]), k
+
+
+def test_random_grids_mc_property():
+    """Random small grids with several start cells, random stochastic policies, every update mode, random discount /
+    threshold / step cap / batch size / scratch budget: sampled episodes against the C restatement and the
+    evaluation against the Python restatement of monte_carlo_evaluation.  GU_FUZZ_TRIALS=N for a longer soak."""
+    import os
+    trials = int(os.environ.get('GU_FUZZ_TRIALS', '24'))
+    rs = np.random.RandomState(int(os.environ.get('GU_FUZZ_SEED', '4242')))
+    for trial in range(trials):
+        W, H = int(rs.randint(2, 12)), int(rs.randint(2, 12))
+        S = W * H
+        pick = lambda k: [int(x) for x in rs.choice(S, size=min(S, int(k)), replace=False)]  # noqa: E731
+        walls, lava, goals, starts = pick(rs.randint(0, S // 4 + 1)), pick(rs.randint(0, 3)), pick(rs.randint(1, 3)), pick(rs.randint(1, 4))
+        spec = GridSpec(W, H, starts, goals, lava, walls)
+        grid = C.Grid(W, H, spec.wall, spec.lava, spec.goal, spec.reward, spec.starts)
+        pi = rs.dirichlet(np.ones(4) * rs.choice([0.3, 1.0, 5.0]), S)
+        N, T, seed = int(rs.randint(1, 200)), int(rs.randint(1, 90)), int(rs.randint(0, 2 ** 40))
+        gamma, thr = float(rs.choice([1.0, 0.99, 0.9, 0.5])), float(rs.choice([1e-4, 1e-2, 0.5]))
+        ev, im, stn = bool(rs.randint(2)), bool(rs.randint(2)), bool(rs.randint(2))
+        os.environ['GU_MC_SCRATCH_MB'] = str(int(rs.choice([1, 2048])))
+        try:
+            st = C.State(N)
+            C.reset(grid, seed, st)
+            first_want = st.pos.copy()
+            want = C.rollout(grid, seed, st, T, auto_reset=False, pi=pi)
+            with Engine(N, spec, seed=seed) as eng:
+                eng.vi_set(np.zeros(S), pi)
+                first = eng.reset()
+                assert np.array_equal(first, first_want)
+                eng.reserve_trajectory(T)
+                eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
+                got = eng.read_trajectory(0, T)
+                for k in ('obs', 'reward', 'done'):
+                    assert np.array_equal(got[k], want[k]), (trial, k)
+                pw, keep = mc.discount_table(gamma, thr, T)
+                v, visits = eng.mc_evaluate(T, first, pw, keep, ev, im, stn, 0.05)
+            eps = omc.episodes_from_trajectory(first, want['obs'], want['reward'], want['done'])
+            v_want, vis_want = omc.monte_carlo_evaluation(S, eps, ev, im, stn, gamma, thr, 0.05)
+            assert v.tobytes() == v_want.tobytes() and visits.tobytes() == vis_want.tobytes(), (trial, W, H, N, T, ev, im, stn, gamma, thr)
+        finally:
+            os.environ.pop('GU_MC_SCRATCH_MB', None)

@@ -260,12 +260,13 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
         __syncthreads();
         greedy = dst;
     }
-    const uint4 *thr = a.pi_thr;
-    if (LDS && POLICY == GU_POLICY_SAMPLE && a.pi_lds) {
-        uint4 *dst = reinterpret_cast<uint4 *>(smem + 2 * a.cell_bytes);
-        for (int32_t i = threadIdx.x; i < a.S; i += blockDim.x) dst[i] = a.pi_thr[i];
+    // the LDS copy keeps its own pointer (never merged with the global one): a pointer that may be either becomes a
+    // FLAT load, whose wait also covers every trajectory store still in flight
+    const bool thr_in_lds = LDS && POLICY == GU_POLICY_SAMPLE && a.pi_lds;
+    uint4 *thr_lds = reinterpret_cast<uint4 *>(smem + 2 * a.cell_bytes);
+    if (thr_in_lds) {
+        for (int32_t i = threadIdx.x; i < a.S; i += blockDim.x) thr_lds[i] = a.pi_thr[i];
         __syncthreads();
-        thr = dst;
     }
     const int64_t e64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e64 >= a.N) return;
@@ -416,31 +417,54 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
             step1(act);
         }
     } else {
+        // Table policies: greedy[] / the sampling thresholds are read at the post-reset position, so the lazy reset
+        // is explicit here.  8 steps per resource rebase (scalar row offsets, as on the uniform path); the sampling
+        // word of the NEXT step is hashed while this step's threshold read is in flight (it does not depend on s).
         uint32_t t = t_lane;
-        for (int64_t i = 0; i < a.T; ++i, ++t) {
-            // greedy[] / pi[] must be read at the post-reset position
-            if (AUTO == 1) {  // (these policies read a table at the post-reset position, so they reset explicitly)
-                const bool was_done = flags & GU_CELL_TERM;
-                s = was_done ? start0 : s;
-                ep += was_done;
-                flags = was_done ? (start0_flags & ~GU_CELL_TERM) : flags;
-                d = 0;
-            } else if (AUTO == 2) {
-                if (d) {
-                    s = lg.starts[gu_rng_start_index(prefix, ep, lg.n_starts)];
-                    ++ep;
-                    flags = m.f[s];
+        uint32_t word = POLICY == GU_POLICY_SAMPLE ? gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t) : 0u;
+        auto run = [&](auto thr_at) {
+            auto tstep = [&](uint32_t soff) {
+                if (AUTO == 1) {
+                    const bool was_done = flags & GU_CELL_TERM;
+                    s = was_done ? start0 : s;
+                    ep += was_done;
+                    flags = was_done ? (start0_flags & ~GU_CELL_TERM) : flags;
                     d = 0;
+                } else if (AUTO == 2) {
+                    if (d) {
+                        s = lg.starts[gu_rng_start_index(prefix, ep, lg.n_starts)];
+                        ++ep;
+                        flags = m.f[s];
+                        d = 0;
+                    }
                 }
+                uint32_t act;
+                if (POLICY == GU_POLICY_GREEDY) {
+                    act = greedy[s];
+                } else {
+                    // inverse CDF of pi[s] on one uniform 32-bit word (RNG stream 2, counter = step count), as integer
+                    // thresholds (gu_pi_threshold_kernel)
+                    const uint4 q = thr_at(s);
+                    const uint32_t next_word = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t + 1u);
+                    act = gu_sample_action(word, q);
+                    word = next_word;
+                }
+                ++t;
+                step(act, soff);
+            };
+            int64_t i = 0;
+            for (; i + 8 <= a.T; i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tstep(j * row32);
+                if (TRAJ) rebase(8);
             }
-            if (POLICY == GU_POLICY_GREEDY) {
-                step1(greedy[s]);
-            } else {
-                // inverse CDF of pi[s] on one uniform 32-bit word (RNG stream 2, counter = step count), as integer
-                // thresholds (gu_pi_threshold_kernel)
-                step1(gu_sample_action(gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t), thr[s]));
+            for (; i < a.T; ++i) {
+                tstep(0);
+                if (TRAJ) rebase(1);
             }
-        }
+        };
+        if (thr_in_lds) run([thr_lds](int32_t at) { return thr_lds[at]; });
+        else run([&a](int32_t at) { return a.pi_thr[at]; });
     }
     a.pos[e] = s;
     a.reward[e] = r;

@@ -49,6 +49,15 @@ def paths(name, template, N, T=1000, reps=20):
         out['rollout_packed_traj_GBps_4B'] = 4 * N * T * reps / dev / 1e9
     wall, dev = timed(eng, lambda: eng.rollout(T, 'uniform', False, True), reps)
     out['rollout_traj_no_autoreset_steps_per_s'] = N * T * reps / wall
+    # table-driven policies: first-argmax (greedy) and inverse-CDF sampling of a random stochastic policy
+    S = template.world.size
+    eng.vi_set(np.zeros(S), np.random.RandomState(1).dirichlet(np.ones(4), S))
+    wall, dev = timed(eng, lambda: eng.rollout(T, 'sample', True, True), reps)
+    out['rollout_sample_policy_traj_steps_per_s'] = N * T * reps / wall
+    out['rollout_sample_policy_traj_GBps_12B'] = 12 * N * T * reps / dev / 1e9
+    wall, dev = timed(eng, lambda: eng.rollout(T, 'greedy', True, True), reps)
+    out['rollout_greedy_policy_traj_steps_per_s'] = N * T * reps / wall
+    out['rollout_greedy_policy_traj_GBps_12B'] = 12 * N * T * reps / dev / 1e9
     # PCIe-inclusive: trajectory copied back to host numpy after every launch
     t0 = time.perf_counter()
     for _ in range(3):

@@ -46,6 +46,79 @@ __global__ void __launch_bounds__(256) gu_render_kernel(const RenderArgs a)
     out[2] = b;
 }
 
+// ---- policy arrows (stands in for Viewer.render_policy_arrows, core/envs/rendering.py:159-212) ----------------------
+// The reference adds, for every state that is neither terminal nor a wall and every action with probability >= 0.1,
+// a line of round(p * 20) pixels from the tile centre in the action's direction and a triangular head of half-width 5
+// and height 5, on tiles of 52 pixels.  Here the same figure is rasterised per pixel, scaled by cell_px / 52, in
+// integer arithmetic on doubled coordinates (pixel centres relative to the tile centre), so that the rule can be
+// restated exactly (tests/test_gpu_render.py): with (t, u) = (along, across) the action's direction,
+//   shaft:  0 <= t,  52 t <= 2 L px,            |u| <= max(1, px / 26)
+//   head :  2 L px < 52 t <= 2 (L + 5) px,      52 |u| <= 2 (L + 5) px - 52 t
+struct PolicyRenderArgs {
+    const uint8_t *cell;
+    const double *pi;  // [S][4]
+    uint8_t *rgb;      // [H*px][W*px][3]
+    int32_t W, H, px;
+};
+
+__global__ void __launch_bounds__(256) gu_render_policy_kernel(const PolicyRenderArgs a)
+{
+    const int64_t frame_px = (int64_t)a.W * a.px * a.H * a.px;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frame_px) return;
+    const int32_t wpx = a.W * a.px;
+    const int32_t y = (int32_t)(i / wpx), x = (int32_t)(i % wpx);
+    const int32_t cy = y / a.px, cx = x / a.px, iy = y % a.px, ix = x % a.px;
+    const int32_t s = cy * a.W + cx;
+    const uint32_t f = a.cell[s];
+    uint8_t r, g, b;
+    gu_tile_colour(f, r, g, b);
+    if (a.px >= 4 && (iy == 0 || ix == 0)) { r = r * 3 / 4; g = g * 3 / 4; b = b * 3 / 4; }  // grid line
+    if (!(f & (GU_CELL_TERM | GU_CELL_WALL))) {
+        const int64_t X = 2 * ix + 1 - a.px, Y = a.px - (2 * iy + 1);  // doubled, y up
+        const int64_t shaft = a.px / 26 > 1 ? a.px / 26 : 1;
+        bool on = false;
+#pragma unroll
+        for (int act = 0; act < 4; ++act) {
+            const double p = a.pi[4 * (int64_t)s + act];
+            if (!(p >= 0.1)) continue;  // "arrow base length too small to render" (:176-178); NaN draws nothing
+            double Ld = rint(p * 20.0);
+            Ld = Ld > 1000.0 ? 1000.0 : Ld;
+            const int64_t L = (int64_t)Ld;
+            const int64_t t = act == 0 ? Y : act == 1 ? X : act == 2 ? -Y : -X;  // UP, RIGHT, DOWN, LEFT
+            int64_t u = (act & 1) ? Y : X;
+            u = u < 0 ? -u : u;
+            const int64_t t52 = 52 * t, base = 2 * L * a.px, tip = 2 * (L + 5) * a.px;
+            on |= t >= 0 && t52 <= base && u <= shaft;
+            on |= t52 > base && t52 <= tip && 52 * u <= tip - t52;
+        }
+        if (on) { r = 20; g = 20; b = 20; }
+    }
+    uint8_t *out = a.rgb + 3 * i;
+    out[0] = r;
+    out[1] = g;
+    out[2] = b;
+}
+
+extern "C" int gu_render_policy_rgb(gu_handle h, int32_t cell_px, uint8_t *rgb)
+{
+    int rc = gu_use_device(h);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(h->has_grid, GU_ERR_STATE, "no grid set");
+    GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no policy table: call gu_vi_set first");
+    GU_REQUIRE(rgb && cell_px >= 1 && cell_px <= 64, GU_ERR_INVALID, "rgb is NULL or cell_px outside 1..64");
+    const int64_t pixels = (int64_t)h->W * cell_px * h->H * cell_px;
+    GU_REQUIRE(pixels * 3 <= (1ll << 32), GU_ERR_INVALID, "%lld pixels are too many for one call", (long long)pixels);
+    rc = gu_ensure_scratch(h, (size_t)pixels * 3);
+    if (rc != GU_OK) return rc;
+    PolicyRenderArgs a{h->d_cell, h->d_pi[h->vi_cur], (uint8_t *)h->d_scratch, h->W, h->H, cell_px};
+    hipLaunchKernelGGL(gu_render_policy_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, h->stream, a);
+    GU_HIP(hipGetLastError());
+    GU_HIP(hipMemcpyAsync(rgb, h->d_scratch, (size_t)pixels * 3, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    return GU_OK;
+}
+
 extern "C" int gu_render_rgb(gu_handle h, int64_t env0, int64_t n_envs, int32_t cell_px, uint8_t *rgb)
 {
     int rc = gu_use_device(h);

@@ -295,6 +295,12 @@ class Engine(object):
             raise ValueError('a path is longer than max_path={}'.format(max_path))
         return [None if n < 0 else path[g, :n].copy() for g, n in enumerate(plen)], term
 
+    def render_policy_rgb(self, cell_px=52):
+        """uint8[H*cell_px, W*cell_px, 3]: the tiles of grid 0 with the current policy table drawn as arrows."""
+        out = np.empty((self.spec.H * cell_px, self.spec.W * cell_px, 3), np.uint8)
+        check(self.lib.gu_render_policy_rgb(self._h, int(cell_px), ptr(out)))
+        return out
+
     def render_rgb(self, env0=0, n_envs=1, cell_px=8):
         """uint8[n_envs, H*cell_px, W*cell_px, 3] frames of envs env0 .. env0+n_envs-1 (rendered on the device)."""
         W, H = self.spec.W, self.spec.H

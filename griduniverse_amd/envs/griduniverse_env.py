@@ -243,8 +243,14 @@ class GridUniverseEnv(object):
         out.write(text)
         return out
 
-    def render_policy_arrows(self, policy):
-        """The reference draws the arrows in its pyglet viewer (env:232-237); here they are printed as a text map."""
+    def render_policy_arrows(self, policy, mode='human', cell_px=52):
+        """The reference draws the arrows in its pyglet viewer (env:232-237).  Headless: mode='human' prints them as a
+        text map; mode='rgb_array' returns the figure (tiles + one arrow per action with probability >= 0.1, the
+        geometry of core/envs/rendering.py:159-212) as uint8[H*cell_px, W*cell_px, 3], drawn on the device."""
+        if mode == 'rgb_array':
+            eng = self._engine()
+            eng.vi_set(np.zeros(self.world.size), np.asarray(policy, dtype=np.float64))
+            return eng.render_policy_rgb(cell_px)
         from ..algorithms.utils import get_policy_map
         arrows = get_policy_map(policy, (self.x_max, self.y_max), mode='ansi')[0]
         for row in np.reshape(arrows, (self.y_max, self.x_max)):

@@ -222,6 +222,11 @@ int gu_shortest_paths(gu_handle h, int32_t max_path, int8_t *path, int32_t *path
  * rgb[n_envs][H*cell_px][W*cell_px][3] uint8 for envs env0 .. env0+n_envs-1: floor / wall / goal / lava tiles, a grid
  * line on the top and left edge of each cell (cell_px >= 4), the agent as an inset square on its cell. */
 int gu_render_rgb(gu_handle h, int64_t env0, int64_t n_envs, int32_t cell_px, uint8_t *rgb);
+/* The policy-arrow figure of Viewer.render_policy_arrows (core/envs/rendering.py:159-212) for the current policy table
+ * (gu_vi_set / gu_vi_run ...): rgb[H*cell_px][W*cell_px][3], the tiles of grid 0 plus, on every state that is neither
+ * terminal nor a wall, one arrow per action with probability >= 0.1 (shaft round(p*20), head 5 x 5, on the
+ * reference's 52-pixel tile; scaled by cell_px / 52). */
+int gu_render_policy_rgb(gu_handle h, int32_t cell_px, uint8_t *rgb);
 
 /* ---- page-locked host memory -----------------------------------------------------
  * Buffers from gu_host_alloc make gu_step (with GU_F_PINNED_IO), gu_read_outputs and gu_read_trajectory copy at

@@ -32,7 +32,7 @@ def test_oracle_use_in_entry_points_is_confined():
 
 
 # the fixture generators: run only in the build container, where the reference is mounted
-GENERATORS = ('tests/golden/make_golden.py', 'tests/golden/calibrate_cpu.py')
+GENERATORS = ('tests/golden/make_golden.py', 'tests/golden/calibrate_cpu.py', 'tests/golden/reference_api_latency.py')
 
 
 def test_nothing_on_the_gpu_box_reads_the_reference():

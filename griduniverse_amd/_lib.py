@@ -91,7 +91,7 @@ _lib = None
 
 def build(verbose=False):
     """Compile libgu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ['make', '-C', CSRC] + ([] if verbose else ['-s'])
+    cmd = ['make', '-j8', '-C', CSRC] + ([] if verbose else ['-s'])
     subprocess.check_call(cmd)
     return LIB_PATH
 

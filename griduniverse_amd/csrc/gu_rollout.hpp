@@ -1,0 +1,369 @@
+// gu_rollout.hpp -- the fused rollout kernel template and its launch dispatch.  Included by one small translation
+// unit per policy kind (gu_rollout_*.hip), so that the template grid (policy x auto-reset x trajectory x stats x map)
+// compiles in parallel; gu_kernels.hip only sees the four entry points declared at the end.
+#pragma once
+#include "gu_map.hpp"
+
+#include <cstdlib>
+
+// ------------------------------------------------------------------------------------
+// fused rollout: T env-steps per lane in one launch
+//   algorithmic HBM bytes per env-step with GU_F_TRAJECTORY: 3 x 4 B row writes = 12 B
+//   (+4 B action read for GU_POLICY_STREAM); state is loaded/stored once per launch.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t gu_sample_action(uint32_t word, const uint4 q)
+{
+    return (uint32_t)(word >= q.x && !(q.w & 1u)) + (uint32_t)(word >= q.y && !(q.w & 2u)) + (uint32_t)(word >= q.z && !(q.w & 4u));
+}
+
+struct RolloutArgs {
+    const uint8_t *cell;
+    const uint8_t *greedy;  // first-argmax action per state (GU_POLICY_GREEDY)
+    const uint4 *pi_thr;    // [S] inverse-CDF thresholds of the action probabilities (GU_POLICY_SAMPLE)
+    int32_t S, pi_lds;      // pi_lds: the threshold table fits in LDS behind the two grid planes
+    int32_t cell_bytes, W;
+    uint64_t lut;
+    int32_t *pos, *reward, *done;
+    uint32_t *episode;
+    const uint32_t *tcount;  // per-env offsets
+    const int32_t *starts;
+    const int32_t *actions;  // [T][N]
+    int32_t *tr_obs, *tr_reward, *tr_done;  // [T][N] each
+    int32_t *ret, *episodes_fin;
+    uint32_t n_starts, seed_prefix, env_id0, steps_taken;
+    int64_t N, T;
+    GridSel gs;
+};
+
+// AUTO: 0 = no reset; 1 = auto-reset, single start cell (branch-free selects keyed on the TERM bit of the
+//       register copy of flags); 2 = auto-reset, several start cells (RNG stream 1, rare divergent branch)
+// MAP : 0 = records read from L2 (any grid size, any grid-per-env assignment)
+//       1 = the block's grid staged in LDS, shared by its lanes
+//       2 = every lane keeps a PRIVATE copy of its own grid's flags plane in LDS (multi-grid engines whose groups
+//           do not align with blocks, e.g. one maze per env; 64-lane blocks, S16 + 16 bytes per lane)
+//       3 = like 1 with the flags plane only (it carries the reward code): grids of 32 768 .. ~160 000 cells, one
+//           block per CU.  A global read per step would wait for every trajectory store in flight (vmcnt counts both).
+#define GU_PRIVATE_PAD 16
+// TRAJ: 0 = no trajectory; 1 = int32 obs / reward / done rows (12 B per env-step);
+//       2 = ONE packed uint32 row: obs | (reward & 0xFF) << 16 | done << 24 (4 B per env-step, grids up to 65 536 cells)
+template <int POLICY, int AUTO, int TRAJ, bool STATS, int MAP>
+__global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs a)
+{
+    constexpr bool LDS = MAP == 1 || MAP == 3;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem, a.gs, MAP == 3 ? 1 : 2);
+    const uint8_t *greedy = a.greedy;
+    if (MAP == 1 && POLICY == GU_POLICY_GREEDY) {
+        uint8_t *dst = smem + 2 * a.cell_bytes;
+        for (int32_t i = threadIdx.x * 16; i < a.cell_bytes; i += blockDim.x * 16)
+            *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(a.greedy + i);
+        __syncthreads();
+        greedy = dst;
+    }
+    // the LDS copy keeps its own pointer (never merged with the global one): a pointer that may be either becomes a
+    // FLAT load, whose wait also covers every trajectory store still in flight
+    const bool thr_in_lds = MAP == 1 && POLICY == GU_POLICY_SAMPLE && a.pi_lds;
+    uint4 *thr_lds = reinterpret_cast<uint4 *>(smem + 2 * a.cell_bytes);
+    if (thr_in_lds) {
+        for (int32_t i = threadIdx.x; i < a.S; i += blockDim.x) thr_lds[i] = a.pi_thr[i];
+        __syncthreads();
+    }
+    const int64_t e64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e64 >= a.N) return;
+    const uint32_t e = (uint32_t)e64;
+    LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, e, m);
+    if (MAP == 2) {  // copy this lane's own flags plane (which also carries the reward code) into its LDS slice
+        uint8_t *mine = smem + threadIdx.x * (a.cell_bytes + GU_PRIVATE_PAD);
+        for (int32_t i = 0; i < a.cell_bytes; i += 16)
+            *reinterpret_cast<uint4 *>(mine + i) = *reinterpret_cast<const uint4 *>(m.f + i);
+        m.f = mine;
+    }
+
+    int32_t s = a.pos[e];
+    int32_t r = a.reward[e];
+    uint32_t d = (uint32_t)a.done[e];
+    uint32_t ep = a.episode[e];
+    const uint32_t t_lane = a.tcount[e] + a.steps_taken;
+    const uint32_t prefix = gu_rng_prefix(a.seed_prefix, a.env_id0 + e);
+    uint32_t flags = m.f[s];
+    int32_t ret = 0, fin = 0;
+    const int32_t W = a.W;
+    const uint64_t lut = a.lut;
+    const int32_t start0 = lg.starts[0];
+    const uint32_t start0_flags = m.f[start0];
+    // Trajectory rows are addressed as buffer resource (wave-uniform base, rebuilt per 16-step chunk)
+    // + lane byte offset e4 (VGPR) + scalar row offset (SGPR): buffer_store_dword ... offen, so that
+    // advancing a row costs SALU only and no per-lane 64-bit address arithmetic.
+    char *po = (char *)a.tr_obs, *pr = (char *)a.tr_reward, *pd = (char *)a.tr_done;
+    const char *pa = (const char *)a.actions;
+    const uint32_t e4 = e * 4u;
+    const int64_t row = a.N * 4;
+    const uint32_t row32 = (uint32_t)row;  // gu_create caps N at 2^25, so lane offset + 15 rows < 2^31 bytes
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0xFFFFFFFFu, 0x00020000);
+    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
+    auto rebase = [&](int64_t rows) {
+        po += rows * row;
+        pr += rows * row;
+        pd += rows * row;
+        ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0xFFFFFFFFu, 0x00020000);
+        rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
+        rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
+    };
+
+    // AUTO == 1 keeps the invariant "d == TERM bit of the REGISTER copy of flags", so the lazy reset needs no
+    // separate test on the dependent chain; at entry the stored done flag may disagree with the cell (fresh reset
+    // onto a terminal start, gu_set_state), so the register copy takes its TERM bit from the stored flag.
+    if (AUTO == 1) flags = (flags & ~GU_CELL_TERM) | (d << GU_CELL_TERM_BIT);
+
+    // `soff`: wave-uniform byte offset of this step's row from the resource base
+    auto step = [&](uint32_t act, uint32_t soff) {
+        const int32_t delta = gu_delta<MAP != 0>(act, lut, W);
+        if (AUTO == 1) {
+            // lazy `if done: env.reset()` (env:187-193) with a single start cell: two selects keyed directly on the
+            // TERM bit of the record that just arrived (no separate done register on the dependent chain).  A variant
+            // that precomputes the move from the start cell off the chain was measured slower at every occupancy
+            // (profiles/r01e_auto_form_ab.txt).
+            const bool was_done = flags & GU_CELL_TERM;
+            ep += was_done;
+            s = was_done ? start0 : s;
+            flags = was_done ? start0_flags : flags;
+            s = gu_move(s, flags, act, delta);
+        } else {
+            if (AUTO == 2) {
+                if (d) {
+                    s = lg.starts[gu_rng_start_index(prefix, ep, lg.n_starts)];
+                    ++ep;
+                    flags = m.f[s];
+                }
+            }
+            s = gu_move(s, flags, act, delta);
+        }
+        flags = m.f[s];
+        r = (MAP >= 2) ? gu_reward_packed(flags) : (int32_t)m.r[s];
+        d = __builtin_amdgcn_ubfe(flags, GU_CELL_TERM_BIT, 1);
+        if (STATS) {
+            ret += r;
+            fin += (int32_t)d;
+        }
+        if (TRAJ == 1) {
+            __builtin_amdgcn_raw_buffer_store_b32(s, ro, e4, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(r, rr, e4, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((int32_t)d, rd, e4, soff, 0);
+        } else if (TRAJ == 2) {
+            __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)s | (((uint32_t)r & 0xFFu) << 16) | (d << 24)), ro, e4, soff, 0);
+        }
+    };
+    auto step1 = [&](uint32_t act) {  // one step, then advance the resource base by one row
+        step(act, 0);
+        if (TRAJ) rebase(1);
+    };
+
+    if (POLICY == GU_POLICY_UNIFORM) {
+        // Fast path: every lane of the wave is at the same step count (always true unless
+        // gu_set_state installed per-env counters), so the 16-actions-per-word schedule is
+        // wave-uniform: constant bit-field offsets, one hash per 16 steps.
+        const uint32_t t_first = __builtin_amdgcn_readfirstlane(t_lane);
+        if (__all(t_lane == t_first)) {
+            uint32_t t = t_first;
+            int64_t i = 0;
+            if (t & 15u) {  // head: finish the current word
+                const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+                for (; i < a.T && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
+            }
+            for (; i + 16 <= a.T; i += 16, t += 16) {  // body: 16 steps per word, fully unrolled
+                const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                if (TRAJ) rebase(16);
+            }
+            if (i < a.T) {  // tail
+                const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+                for (uint32_t j = 0; i < a.T; ++i, ++j) step1((word >> (2u * j)) & 3u);
+            }
+        } else {
+            uint32_t t = t_lane;
+            uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+            for (int64_t i = 0; i < a.T; ++i) {
+                step1((word >> (2u * (t & 15u))) & 3u);
+                ++t;
+                if ((t & 15u) == 0u) word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+            }
+        }
+    } else if (POLICY == GU_POLICY_STREAM) {
+        // Action rows are read 8 at a time, one chunk AHEAD of the steps that consume them: the loads are
+        // independent of the env state, so with one wave per SIMD this is what hides their HBM latency.
+        constexpr int CH = 8;
+        int64_t i = 0;
+        uint32_t cur[CH], nxt[CH];
+        auto load_chunk = [&](uint32_t (&dst)[CH], const char *base) {
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xFFFFFFFFu, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) dst[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, e4, j * row32, 0);
+        };
+        if (a.T >= CH) load_chunk(cur, pa);
+        for (; i + CH <= a.T; i += CH) {
+            pa += CH * row;
+            if (i + 2 * CH <= a.T) load_chunk(nxt, pa);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) step(cur[j] & 3u, j * row32);
+            if (TRAJ) rebase(CH);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
+        }
+        for (; i < a.T; ++i) {  // tail
+            const uint32_t act = (uint32_t)(*(const int32_t *)(pa + e4)) & 3u;
+            pa += row;
+            step1(act);
+        }
+    } else {
+        // Table policies: greedy[] / the sampling thresholds are read at the post-reset position, so the lazy reset
+        // is explicit here.  8 steps per resource rebase (scalar row offsets, as on the uniform path); the sampling
+        // word of the NEXT step is hashed while this step's threshold read is in flight (it does not depend on s).
+        uint32_t t = t_lane;
+        uint32_t word = POLICY == GU_POLICY_SAMPLE ? gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t) : 0u;
+        auto run = [&](auto thr_at) {
+            auto tstep = [&](uint32_t soff) {
+                if (AUTO == 1) {
+                    const bool was_done = flags & GU_CELL_TERM;
+                    s = was_done ? start0 : s;
+                    ep += was_done;
+                    flags = was_done ? (start0_flags & ~GU_CELL_TERM) : flags;
+                    d = 0;
+                } else if (AUTO == 2) {
+                    if (d) {
+                        s = lg.starts[gu_rng_start_index(prefix, ep, lg.n_starts)];
+                        ++ep;
+                        flags = m.f[s];
+                        d = 0;
+                    }
+                }
+                uint32_t act;
+                if (POLICY == GU_POLICY_GREEDY) {
+                    act = greedy[s];
+                } else {
+                    // inverse CDF of pi[s] on one uniform 32-bit word (RNG stream 2, counter = step count), as integer
+                    // thresholds (gu_pi_threshold_kernel)
+                    const uint4 q = thr_at(s);
+                    const uint32_t next_word = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t + 1u);
+                    act = gu_sample_action(word, q);
+                    word = next_word;
+                }
+                ++t;
+                step(act, soff);
+            };
+            int64_t i = 0;
+            for (; i + 8 <= a.T; i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tstep(j * row32);
+                if (TRAJ) rebase(8);
+            }
+            for (; i < a.T; ++i) {
+                tstep(0);
+                if (TRAJ) rebase(1);
+            }
+        };
+        if (thr_in_lds) run([thr_lds](int32_t at) { return thr_lds[at]; });
+        else run([&a](int32_t at) { return a.pi_thr[at]; });
+    }
+    a.pos[e] = s;
+    a.reward[e] = r;
+    a.done[e] = (int32_t)d;
+    a.episode[e] = ep;
+    if (STATS) {
+        a.ret[e] = ret;
+        a.episodes_fin[e] = fin;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------
+static inline unsigned gu_blocks(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+// Largest block size <= preferred for which every block uses one grid (0 = none: use the L2 variant)
+static inline int gu_lds_block(const gu_engine *h, int preferred, int planes)
+{
+    if (h->S > GU_MAX_LDS_CELLS || (size_t)planes * h->cell_bytes > 65536) return 0;
+    if (h->n_grids == 1) return preferred;
+    for (int bs = preferred; bs >= 64; bs >>= 1)
+        if (h->group % bs == 0) return bs;
+    return 0;
+}
+
+static inline int gu_rollout_block()
+{
+    static int cached = 0;
+    if (!cached) {
+        const char *s = std::getenv("GU_ROLLOUT_BLOCK");
+        int v = s ? std::atoi(s) : 256;
+        cached = (v == 64 || v == 128 || v == 256) ? v : 256;
+    }
+    return cached;
+}
+
+template <int POLICY, int AUTO, int TRAJ, bool STATS>
+static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
+{
+    const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
+    const int lds_bs = gu_lds_block(h, bs, planes);
+    if (lds_bs) {
+        size_t lds = (size_t)planes * h->cell_bytes;
+        RolloutArgs b = a;
+        if (POLICY == GU_POLICY_SAMPLE && lds + (size_t)h->S * sizeof(uint4) <= 65536) {
+            b.pi_lds = 1;
+            lds += (size_t)h->S * sizeof(uint4);
+        }
+        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 1>), dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), lds, h->stream, b);
+        return;
+    }
+    if constexpr (POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM) {
+        // one grid too big for two planes in 64 KiB: its flags plane alone, up to the whole 160 KB of a CU
+        if (h->n_grids == 1 && h->W <= 32767 && (size_t)h->cell_bytes <= 160 * 1024 - 512) {
+            auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 3>;
+            if (h->cell_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->cell_bytes);
+            hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, bs)), dim3(bs), (size_t)h->cell_bytes, h->stream, a);
+            return;
+        }
+        // misaligned multi-grid engine (e.g. one maze per env): private per-lane copies in LDS if 64 of them fit
+        const size_t priv = 64 * ((size_t)h->cell_bytes + GU_PRIVATE_PAD);
+        if (h->n_grids > 1 && h->W <= 32767 && priv <= 160 * 1024) {
+            auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 2>;
+            if (priv > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv);
+            hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, 64)), dim3(64), priv, h->stream, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 0>), dim3(gu_blocks(h->N, bs)), dim3(bs), 0, h->stream, a);
+}
+
+template <int POLICY, int AUTO>
+static void gu_rollout_dispatch2(gu_engine *h, const RolloutArgs &a, int traj, bool stats, int bs)
+{
+    if (traj == 1) {
+        if (stats) gu_rollout_launch<POLICY, AUTO, 1, true>(h, a, bs);
+        else gu_rollout_launch<POLICY, AUTO, 1, false>(h, a, bs);
+    } else if (traj == 2) {
+        if (stats) gu_rollout_launch<POLICY, AUTO, 2, true>(h, a, bs);
+        else gu_rollout_launch<POLICY, AUTO, 2, false>(h, a, bs);
+    } else {
+        if (stats) gu_rollout_launch<POLICY, AUTO, 0, true>(h, a, bs);
+        else gu_rollout_launch<POLICY, AUTO, 0, false>(h, a, bs);
+    }
+}
+
+template <int POLICY>
+static void gu_rollout_dispatch(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs)
+{
+    switch (auto_mode) {
+    case 0: gu_rollout_dispatch2<POLICY, 0>(h, a, traj, stats, bs); break;
+    case 1: gu_rollout_dispatch2<POLICY, 1>(h, a, traj, stats, bs); break;
+    default: gu_rollout_dispatch2<POLICY, 2>(h, a, traj, stats, bs); break;
+    }
+}
+
+// one per policy kind, each in its own translation unit
+void gu_rollout_uniform(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
+void gu_rollout_stream(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
+void gu_rollout_greedy(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
+void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);

@@ -1,0 +1,7 @@
+// gu_rollout_greedy.hip -- instantiates the fused rollout kernel (gu_rollout.hpp) for GU_POLICY_GREEDY.
+#include "gu_rollout.hpp"
+
+void gu_rollout_greedy(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs)
+{
+    gu_rollout_dispatch<GU_POLICY_GREEDY>(h, a, auto_mode, traj, stats, bs);
+}

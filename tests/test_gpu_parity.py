@@ -297,11 +297,14 @@ def test_random_grids_property():
         assert np.array_equal(state['pos'], st.pos) and np.array_equal(state['episode'], st.episode)
 
 
-def test_grid_larger_than_lds_uses_the_global_path():
-    W = H = 300  # 90 000 cells > 64 KiB of records
+@pytest.mark.parametrize('W,H', [(300, 300), (190, 190), (512, 400)])
+def test_grid_larger_than_lds_uses_the_global_path(W, H):
+    """Beyond 32 767 cells the two record planes no longer fit 64 KiB: the uniform / stream rollouts keep the flags
+    plane alone in (up to 160 KB of) LDS (190x190, 300x300); 512x400 = 204 800 cells reads the records from L2.  The
+    single step and the table policies take the L2 path at all three sizes."""
     rs = np.random.RandomState(3)
-    walls = [int(x) for x in rs.choice(W * H, 20000, replace=False)]
-    meta = dict(W=W, H=H, walls=walls, lava=[5, 777], goals=[W * H - 1, 4000], starts=[0, 301, 45000])
+    walls = [int(x) for x in rs.choice(W * H, W * H // 5, replace=False)]
+    meta = dict(W=W, H=H, walls=walls, lava=[5, 777], goals=[W * H - 1, 4000], starts=[0, 301, 30000])
     grid = C.Grid.from_lists(**meta)
     st = C.State(300)
     C.reset(grid, 1, st)
@@ -316,6 +319,15 @@ def test_grid_larger_than_lds_uses_the_global_path():
         obs, rew, don = eng.step(np.zeros(300, np.int32), auto_reset=True)
         w2 = C.rollout(grid, 1, st, 1, True, actions=np.zeros((1, 300), np.int32))
         assert np.array_equal(obs, w2['obs'][0]) and np.array_equal(don, w2['done'][0])
+        acts = rs.randint(0, 4, (64, 300)).astype(np.int32)  # caller-supplied stream, packed rows, stats
+        w3 = C.rollout(grid, 1, st, 64, True, actions=acts, stats=True)
+        eng.upload_actions(acts)
+        eng.rollout(64, 'stream', True, trajectory='packed' if W * H <= 65536 else True, stats=True)
+        got = eng.read_trajectory_packed(0, 64) if W * H <= 65536 else eng.read_trajectory(0, 64)
+        for k in ('obs', 'reward', 'done'):
+            assert np.array_equal(got[k], w3[k]), k
+        ret, eps = eng.read_stats()
+        assert np.array_equal(ret, w3['ret']) and np.array_equal(eps, w3['episodes'])
 
 
 # ------------------------------------------------------------------------------- facade (N = 1 drop-in)

@@ -267,3 +267,48 @@ def test_random_grids_mc_property():
             assert v.tobytes() == v_want.tobytes() and visits.tobytes() == vis_want.tobytes(), (trial, W, H, N, T, ev, im, stn, gamma, thr)
         finally:
             os.environ.pop('GU_MC_SCRATCH_MB', None)
+
+
+def test_random_grids_table_policies_property():
+    """Greedy (first argmax) and sampled rollouts on random grids -- one or several start cells, with and without
+    auto-reset, any number of steps (the 8-step unrolled body and its tail), int32 / packed / no trajectory, stats,
+    grids whose threshold table fits LDS, does not fit, and whose records do not fit either -- against the C
+    restatement.  A one-hot policy sampled by the oracle IS the greedy policy.  GU_FUZZ_TRIALS=N for a longer soak."""
+    import os
+    trials = int(os.environ.get('GU_FUZZ_TRIALS', '40'))
+    rs = np.random.RandomState(int(os.environ.get('GU_FUZZ_SEED', '99')))
+    for trial in range(trials):
+        big = trial % 8
+        W, H = ((int(rs.randint(1, 40)), int(rs.randint(1, 30))) if big < 6 else (int(rs.randint(64, 90)), int(rs.randint(64, 90)))
+                if big == 6 else (int(rs.randint(182, 230)), int(rs.randint(182, 200))))
+        S = W * H
+        pick = lambda k: [int(x) for x in rs.choice(S, size=min(S, int(k)), replace=False)]  # noqa: E731
+        walls, lava, goals = pick(rs.randint(0, S // 4 + 1)), pick(rs.randint(0, 4)), pick(rs.randint(1, 4))
+        starts = pick(1 if trial % 2 else rs.randint(2, 5))
+        spec = GridSpec(W, H, starts, goals, lava, walls)
+        grid = C.Grid(W, H, spec.wall, spec.lava, spec.goal, spec.reward, spec.starts)
+        greedy = bool(rs.randint(2))
+        if greedy:
+            pi = np.zeros((S, 4))
+            pi[np.arange(S), rs.randint(0, 4, S)] = 1.0
+        else:
+            pi = rs.dirichlet(np.ones(4) * rs.choice([0.2, 1.0]), S)
+        N, T, seed, id0 = int(rs.randint(1, 700)), int(rs.randint(1, 70)), int(rs.randint(0, 2 ** 50)), int(rs.randint(0, 2 ** 30))
+        auto = bool(rs.randint(2))
+        kind = [True, 'packed', False][rs.randint(3)] if S <= 65536 else [True, False][rs.randint(2)]
+        st = C.State(N, id0)
+        C.reset(grid, seed, st)
+        want = C.rollout(grid, seed, st, T, auto_reset=auto, pi=pi, stats=True)
+        with Engine(N, spec, env_id0=id0, seed=seed) as eng:
+            eng.vi_set(np.zeros(S), pi)
+            eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'greedy' if greedy else 'sample', auto_reset=auto, trajectory=kind, stats=True)
+            if kind:
+                got = eng.read_trajectory_packed(0, T) if kind == 'packed' else eng.read_trajectory(0, T)
+                for k in ('obs', 'reward', 'done'):
+                    assert np.array_equal(got[k], want[k]), (trial, W, H, N, T, greedy, auto, kind, k)
+            ret, eps = eng.read_stats()
+            state = eng.get_state()
+        assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes']), (trial, W, H, greedy, auto)
+        assert np.array_equal(state['pos'], st.pos) and np.array_equal(state['episode'], st.episode)

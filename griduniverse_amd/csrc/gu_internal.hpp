@@ -86,6 +86,8 @@ struct gu_engine {
 
     // pinned host staging (4*N int32)
     int32_t *h_pin = nullptr;
+    uint32_t *h_seq = nullptr;      // page-locked completion word of the one-wave gu_step fast path
+    uint32_t seq = 0, seq_since_sync = 0;
 
     // hipGraph cache for gu_step_graph
     hipGraphExec_t graph_exec = nullptr;
@@ -148,7 +150,7 @@ int gu_ensure_scratch(gu_engine *h, size_t bytes);
 // ---- kernel launchers (gu_kernels.hip) -------------------------------------------
 int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice, bool only_done);
 int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, int32_t *host_obs = nullptr,
-                   int32_t *host_reward = nullptr, int32_t *host_done = nullptr);
+                   int32_t *host_reward = nullptr, int32_t *host_done = nullptr, uint32_t *host_seq = nullptr, uint32_t seq = 0);
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags);
 int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const int32_t *d_actions, bool care,
                         int32_t *d_next, int32_t *d_reward, int32_t *d_done);

@@ -81,6 +81,8 @@ struct StepArgs {
     uint32_t flags;
     GridSel gs;
     int32_t *host_obs, *host_reward, *host_done;  // optional page-locked host mirrors written by the kernel itself
+    uint32_t *host_seq;  // optional page-locked completion word (batches of one wave): set to `seq` after the mirrors
+    uint32_t seq;
 };
 
 template <bool LDS>
@@ -107,6 +109,12 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
     if (a.host_obs) a.host_obs[e] = s;
     if (a.host_reward) a.host_reward[e] = r;
     if (a.host_done) a.host_done[e] = d;
+    if (a.host_seq) {
+        // one wave (N <= 64): its mirror stores precede this point in program order for every lane; make them visible
+        // to the host, then publish the sequence number the host is spinning on (no interrupt, no runtime call)
+        __threadfence_system();
+        if (e == 0) __hip_atomic_store(a.host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -221,11 +229,11 @@ int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice
 }
 
 int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, int32_t *host_obs, int32_t *host_reward,
-                   int32_t *host_done)
+                   int32_t *host_done, uint32_t *host_seq, uint32_t seq)
 {
     StepArgs a{h->d_cell, h->cell_bytes, h->W, h->delta_lut, d_actions_row, h->pos(), h->reward(), h->done(),
                h->d_episode, h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags,
-               gu_grid_sel(h), host_obs, host_reward, host_done};
+               gu_grid_sel(h), host_obs, host_reward, host_done, host_seq, seq};
     const int lds_bs = gu_lds_block(h, GU_BLOCK, 2);
     if (lds_bs)
         hipLaunchKernelGGL(gu_step_kernel<true>, dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), 2 * (size_t)h->cell_bytes, h->stream, a);

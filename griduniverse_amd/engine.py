@@ -28,6 +28,7 @@ class Engine(object):
         check(self.lib.gu_create(self.device, self.N, self.env_id0, ctypes.byref(self._h)))
         self.spec = None
         self._pinned = {}
+        self._pinned_io = None
         try:
             self.set_grid(spec)
             self.seed(seed)
@@ -40,6 +41,7 @@ class Engine(object):
         for p in getattr(self, '_pinned', {}).values():
             p.free()
         self._pinned = {}
+        self._pinned_io = None
         if getattr(self, '_h', None) is not None and self._h.value:
             self.lib.gu_destroy(self._h)
             self._h = ctypes.c_void_p()
@@ -125,6 +127,7 @@ class Engine(object):
     def _pin(self, key, shape, dtype=np.int32):
         p = self._pinned.get(key)
         if p is None or p.array.shape != tuple(shape):
+            self._pinned_io = None
             if p is not None:
                 p.free()
             p = self._pinned[key] = _lib.PinnedArray(tuple(shape), dtype)
@@ -138,10 +141,16 @@ class Engine(object):
     def step_pinned(self, auto_reset=False):
         """gu_step on the engine's page-locked buffers (no bounce copies).  Returns views that stay
         valid -- and are overwritten -- until the next step_pinned()."""
-        a, out = self.pinned_actions, self._pin('out', (3, self.N))
+        io = self._pinned_io
+        if io is None:  # views and their C pointers are built once: per call they would cost more than the launch
+            a, out = self.pinned_actions, self._pin('out', (3, self.N))
+            io = self._pinned_io = ((ptr(a), ptr(out[0]), ptr(out[1]), ptr(out[2])), (out[0], out[1], out[2]))
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | _lib.F_PINNED_IO
-        check(self.lib.gu_step(self._h, ptr(a), flags, ptr(out[0]), ptr(out[1]), ptr(out[2])))
-        return out[0], out[1], out[2]
+        p = io[0]
+        rc = self.lib.gu_step(self._h, p[0], flags, p[1], p[2], p[3])
+        if rc:
+            check(rc)
+        return io[1]
 
     def upload_actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.int32)

@@ -140,6 +140,7 @@ class GridUniverseEnv(object):
         if self._engine_obj is None:
             from ..engine import Engine  # imported late: host-only use never loads libgu
             self._engine_obj = Engine(1, GridSpec.from_env(self), device=self._device)
+            self._act_buf = self._engine_obj.pinned_actions
             self._pos_dirty = True
         return self._engine_obj
 
@@ -193,10 +194,11 @@ class GridUniverseEnv(object):
         """One env-step on the device (kernel gu_step_kernel via gu_step)."""
         if not -4 <= action < 4:
             raise IndexError('list index out of range')
-        eng = self._engine()
-        self._push_state(eng)
+        eng = self._engine_obj or self._engine()
+        if self._pos_dirty:
+            self._push_state(eng)
         self.previous_state = self._state
-        eng.pinned_actions[0] = action % 4  # negative = Python list index (quirk 6)
+        self._act_buf[0] = action % 4  # negative = Python list index (quirk 6)
         obs, reward, done = eng.step_pinned()  # page-locked I/O: no bounce copies on the N = 1 path
         self._state = int(obs[0])
         self.done = bool(done[0])

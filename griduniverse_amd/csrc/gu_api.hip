@@ -378,9 +378,7 @@ int gu_step(gu_handle h, const int32_t *actions, uint32_t flags, int32_t *obs, i
     const size_t n = (size_t)h->N;
     for (size_t i = 0; i < n; ++i)
         GU_REQUIRE((uint32_t)actions[i] < 4u, GU_ERR_INVALID, "action %d of env %zu outside 0..3", actions[i], i);
-    int rc = gu_ensure_scratch(h, n * 5 + 16);
-    if (rc != GU_OK) return rc;
-    int32_t *d_act = (int32_t *)h->d_scratch;
+    int rc = GU_OK;
     if (direct) {
         // The caller's buffers are page-locked (gu_host_alloc), i.e. mapped into the device's address space: the
         // kernel reads the actions from them and writes the results into them itself over PCIe -- one launch and
@@ -403,12 +401,13 @@ int gu_step(gu_handle h, const int32_t *actions, uint32_t flags, int32_t *obs, i
         h->seq_since_sync = 0;
         return GU_OK;
     }
-    memcpy(h->h_pin, actions, n * 4);  // pinned staging keeps the H2D copy asynchronous
-    GU_HIP(hipMemcpyAsync(d_act, h->h_pin, n * 4, hipMemcpyHostToDevice, h->stream));
-    rc = gu_launch_step(h, d_act, flags);
+    // Ordinary (pageable) caller buffers: the engine's own page-locked staging block plays the caller's part of the
+    // zero-copy path above -- the kernel reads the actions from it and writes the results into it over PCIe, so the
+    // call is two memcpys around one launch + one sync instead of two copy commands around the launch.
+    memcpy(h->h_pin, actions, n * 4);
+    const bool want = obs || reward || done;
+    rc = gu_launch_step(h, h->h_pin, flags, want ? h->h_pin + n : nullptr, want ? h->h_pin + 2 * n : nullptr, want ? h->h_pin + 3 * n : nullptr);
     if (rc != GU_OK) return rc;
-    if (obs || reward || done)
-        GU_HIP(hipMemcpyAsync(h->h_pin + n, h->d_out3, 3 * n * 4, hipMemcpyDeviceToHost, h->stream));
     GU_HIP(hipStreamSynchronize(h->stream));
     if (obs) memcpy(obs, h->h_pin + n, n * 4);
     if (reward) memcpy(reward, h->h_pin + 2 * n, n * 4);

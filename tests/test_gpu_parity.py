@@ -564,6 +564,29 @@ def test_pinned_io_paths():
             assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k][40:140])
 
 
+@pytest.mark.parametrize('N', [1, 3, 64, 65])
+def test_one_wave_step_completion_word(N):
+    """Batches of up to 64 envs finish a page-locked gu_step by publishing a sequence number the host spins on
+    (with a real stream sync every 1024 steps); 65 envs take the ordinary sync.  2 500 steps against the oracle,
+    interleaved with calls that use the stream normally."""
+    meta = dict(W=9, H=7, walls=[10, 11, 12, 30, 31], lava=[40], goals=[62, 5], starts=[0, 8, 36])
+    grid = C.Grid.from_lists(**meta)
+    rs = np.random.RandomState(N)
+    acts = rs.randint(0, 4, (2500, N)).astype(np.int32)
+    st = C.State(N, 7)
+    C.reset(grid, 3, st)
+    want = C.rollout(grid, 3, st, 2500, True, actions=acts)
+    with Engine(N, GridSpec(9, 7, meta['starts'], meta['goals'], meta['lava'], meta['walls']), env_id0=7, seed=3) as eng:
+        eng.reset()
+        for t in range(2500):
+            eng.pinned_actions[:] = acts[t]
+            o, r, d = eng.step_pinned(auto_reset=True)
+            assert np.array_equal(o, want['obs'][t]) and np.array_equal(r, want['reward'][t]) and np.array_equal(d, want['done'][t]), t
+            if t % 700 == 699:  # other traffic on the same stream in between
+                assert np.array_equal(eng.get_state()['pos'], want['obs'][t])
+                eng.done_indices()
+
+
 def test_long_run_counters_and_graph_reseed():
     """20 000 steps per env in uneven chunks (RNG word counters far beyond the golden horizons), then the
     hipGraph step path before and after a reseed on a multi-start level (the captured launches carry the seed)."""

@@ -771,3 +771,33 @@ def test_trajectory_planes_beyond_4_gib():
             for k in ('obs', 'reward', 'done'):
                 assert np.array_equal(got[k][0, sl], want[k][t]), (lo, t, k)
         assert np.array_equal(ret[sl], want['ret']) and np.array_equal(eps[sl], want['episodes'])
+
+
+def test_maximum_batch_of_one_engine():
+    """2^25 envs, the cap of one engine (gu_create): 24 steps with the trajectory written (9.7 GB; row offsets reach the
+    top of the 2^31-byte buffer-addressing window the cap is derived from), spot-checked against the oracle at both ends
+    and in the middle of the batch; one env more is refused."""
+    meta, _ = G.load_traj('c4_lava32')
+    grid = C.Grid.from_lists(**meta)
+    N, T, seed = 1 << 25, 24, 5
+    with pytest.raises(gua.GuError):
+        Engine(N + 1, spec_of(meta))
+    with Engine(N, spec_of(meta), seed=seed) as eng:
+        first = eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'uniform', True, trajectory=True, stats=True)
+        rows = {t: eng.read_trajectory(t, 1) for t in (0, 7, 8, 15, 16, T - 1)}
+        ret, eps = eng.read_stats()
+        obs, rew, don = eng.step(np.full(N, 2, np.int32), auto_reset=True)
+    for lo in (0, N // 2 - 1000, N - 2048):
+        st = C.State(2048, lo)
+        C.reset(grid, seed, st)
+        sl = slice(lo, lo + 2048)
+        assert np.array_equal(first[sl], st.pos)
+        want = C.rollout(grid, seed, st, T, True, stats=True)
+        for t, got in rows.items():
+            for k in ('obs', 'reward', 'done'):
+                assert np.array_equal(got[k][0, sl], want[k][t]), (lo, t, k)
+        assert np.array_equal(ret[sl], want['ret']) and np.array_equal(eps[sl], want['episodes'])
+        w2 = C.rollout(grid, seed, st, 1, True, actions=np.full((1, 2048), 2, np.int32))
+        assert np.array_equal(obs[sl], w2['obs'][0]) and np.array_equal(rew[sl], w2['reward'][0]) and np.array_equal(don[sl], w2['done'][0])

@@ -500,6 +500,14 @@ def test_c_abi_error_codes():
         assert lib.gu_step_device(hh, 0, 0) == -4
         assert lib.gu_read_stats(hh, None, None) == -4
         assert lib.gu_vi_sweep(hh, 1.0, 1, 1, None) == -4
+        done = ctypes.c_int32(0)
+        assert lib.gu_vi_eval_run(hh, 1.0, 1e-3, 5, ctypes.byref(done), None) == -4 and 'gu_vi_set' in _lib.last_error()
+        frame = np.zeros((8 * 4, 8 * 4, 3), np.uint8)
+        assert lib.gu_render_policy_rgb(hh, 4, p(frame)) == -4
+        eng.vi_set(np.zeros(64), np.ones((64, 4)) / 4)
+        assert lib.gu_vi_eval_run(hh, 1.0, 1e-3, 5, None, None) == -1 and lib.gu_vi_eval_run(hh, 1.0, 1e-3, -1, ctypes.byref(done), None) == -1
+        assert lib.gu_render_policy_rgb(hh, 0, p(frame)) == -1 and lib.gu_render_policy_rgb(hh, 4, None) == -1
+        assert lib.gu_render_policy_rgb(hh, 4, p(frame)) == 0
         assert lib.gu_allgather_view(hh, None, None, None) == -4
         assert lib.gu_step(hh, None, 0, None, None, None) == -1
         bad = np.full((2, 8), 5, np.int32)

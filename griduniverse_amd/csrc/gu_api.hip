@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -118,6 +119,8 @@ int gu_create(int device_id, int64_t num_envs, int64_t env_id0, gu_handle *out)
         GU_HIP(hipHostMalloc(&h->h_pin, 4 * n * sizeof(int32_t), hipHostMallocDefault));
         GU_HIP(hipHostMalloc(&h->h_seq, 64, hipHostMallocDefault));
         *h->h_seq = 0;
+        GU_HIP(hipMalloc(&h->d_blocks_done, sizeof(uint32_t)));
+        GU_HIP(hipMemsetAsync(h->d_blocks_done, 0, sizeof(uint32_t), h->stream));
         GU_HIP(hipMemsetAsync(h->d_out3, 0, 3 * n * sizeof(int32_t), h->stream));
         GU_HIP(hipMemsetAsync(h->d_episode, 0, n * sizeof(uint32_t), h->stream));
         GU_HIP(hipMemsetAsync(h->d_tcount, 0, n * sizeof(uint32_t), h->stream));
@@ -150,6 +153,7 @@ int gu_destroy(gu_handle h)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_seq) (void)hipHostFree(h->h_seq);
+    if (h->d_blocks_done) (void)hipFree(h->d_blocks_done);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -367,6 +371,31 @@ int gu_reset_done(gu_handle h)
 }
 
 // ---------------------------------------------------------------------------------- step
+// One step whose actions / results live in page-locked host memory, and the wait for it.  The kernel publishes a
+// sequence number in page-locked memory after the last block's result stores and the host spins on it -- a PCIe round
+// trip instead of the runtime's completion path: 14.0 -> 10.4 us per call at up to 64 envs, 15.5 -> 12.7 at 4096.  Only
+// for batches of up to 8192 envs: the per-block system-scope fence serialises the PCIe result stream of larger ones
+// (65 536 envs: 57 us against 43 us with the ordinary synchronisation, measured in one process).  Bounded: after ~1 ms
+// of spinning, and every 1024 steps anyway, the real stream synchronisation runs (GU_STEP_SYNC=1 forces it).
+static int gu_step_and_wait(gu_engine *h, const int32_t *actions, uint32_t flags, int32_t *obs, int32_t *reward, int32_t *done)
+{
+    int rc;
+    if (h->N <= 8192 && h->seq_since_sync < 1024 && !std::getenv("GU_STEP_SYNC")) {
+        const uint32_t seq = ++h->seq;
+        rc = gu_launch_step(h, actions, flags, obs, reward, done, h->h_seq, seq);
+        if (rc != GU_OK) return rc;
+        ++h->seq_since_sync;
+        for (int spin = 0; spin < 2000000; ++spin)
+            if (__atomic_load_n(h->h_seq, __ATOMIC_ACQUIRE) == seq) return GU_OK;
+    } else {
+        rc = gu_launch_step(h, actions, flags, obs, reward, done);
+        if (rc != GU_OK) return rc;
+    }
+    GU_HIP(hipStreamSynchronize(h->stream));
+    h->seq_since_sync = 0;
+    return GU_OK;
+}
+
 int gu_step(gu_handle h, const int32_t *actions, uint32_t flags, int32_t *obs, int32_t *reward, int32_t *done)
 {
     GU_ENTER(h);
@@ -383,32 +412,15 @@ int gu_step(gu_handle h, const int32_t *actions, uint32_t flags, int32_t *obs, i
         // The caller's buffers are page-locked (gu_host_alloc), i.e. mapped into the device's address space: the
         // kernel reads the actions from them and writes the results into them itself over PCIe -- one launch and
         // one synchronisation, no copy commands at all.
-        if (h->N <= 64 && h->seq_since_sync < 1024) {
-            // a batch of one wave (the N = 1 facade): the kernel publishes a sequence number in page-locked memory
-            // after its result stores and the host spins on it -- a PCIe round trip instead of the runtime's
-            // completion path.  Bounded: after ~1 ms of spinning, or every 1024 steps, fall back to the real sync.
-            const uint32_t seq = ++h->seq;
-            rc = gu_launch_step(h, actions, flags, obs, reward, done, h->h_seq, seq);
-            if (rc != GU_OK) return rc;
-            ++h->seq_since_sync;
-            for (int spin = 0; spin < 2000000; ++spin)
-                if (__atomic_load_n(h->h_seq, __ATOMIC_ACQUIRE) == seq) return GU_OK;
-        } else {
-            rc = gu_launch_step(h, actions, flags, obs, reward, done);
-            if (rc != GU_OK) return rc;
-        }
-        GU_HIP(hipStreamSynchronize(h->stream));
-        h->seq_since_sync = 0;
-        return GU_OK;
+        return gu_step_and_wait(h, actions, flags, obs, reward, done);
     }
     // Ordinary (pageable) caller buffers: the engine's own page-locked staging block plays the caller's part of the
     // zero-copy path above -- the kernel reads the actions from it and writes the results into it over PCIe, so the
     // call is two memcpys around one launch + one sync instead of two copy commands around the launch.
     memcpy(h->h_pin, actions, n * 4);
     const bool want = obs || reward || done;
-    rc = gu_launch_step(h, h->h_pin, flags, want ? h->h_pin + n : nullptr, want ? h->h_pin + 2 * n : nullptr, want ? h->h_pin + 3 * n : nullptr);
+    rc = gu_step_and_wait(h, h->h_pin, flags, want ? h->h_pin + n : nullptr, want ? h->h_pin + 2 * n : nullptr, want ? h->h_pin + 3 * n : nullptr);
     if (rc != GU_OK) return rc;
-    GU_HIP(hipStreamSynchronize(h->stream));
     if (obs) memcpy(obs, h->h_pin + n, n * 4);
     if (reward) memcpy(reward, h->h_pin + 2 * n, n * 4);
     if (done) memcpy(done, h->h_pin + 3 * n, n * 4);

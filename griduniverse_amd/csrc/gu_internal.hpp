@@ -86,7 +86,8 @@ struct gu_engine {
 
     // pinned host staging (4*N int32)
     int32_t *h_pin = nullptr;
-    uint32_t *h_seq = nullptr;      // page-locked completion word of the one-wave gu_step fast path
+    uint32_t *h_seq = nullptr;      // page-locked completion word of gu_step's host-visible paths
+    uint32_t *d_blocks_done = nullptr;  // its device-side block counter
     uint32_t seq = 0, seq_since_sync = 0;
 
     // hipGraph cache for gu_step_graph

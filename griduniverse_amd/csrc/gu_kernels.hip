@@ -81,8 +81,9 @@ struct StepArgs {
     uint32_t flags;
     GridSel gs;
     int32_t *host_obs, *host_reward, *host_done;  // optional page-locked host mirrors written by the kernel itself
-    uint32_t *host_seq;  // optional page-locked completion word (batches of one wave): set to `seq` after the mirrors
+    uint32_t *host_seq;  // optional page-locked completion word: set to `seq` after every block's mirror stores
     uint32_t seq;
+    uint32_t *blocks_done;  // device counter behind the completion word (zero between launches)
 };
 
 template <bool LDS>
@@ -91,29 +92,39 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem, a.gs);
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= a.N) return;
-    const LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, (uint32_t)e, m);
-    const uint32_t act = (uint32_t)a.actions[e] & 3u;
-    int32_t s = a.pos[e];
-    if ((a.flags & GU_F_AUTO_RESET) && a.done[e]) {  // lazy `if done: env.reset()`
-        const uint32_t ep = a.episode[e];
-        s = lg.starts[gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, lg.n_starts)];
-        a.episode[e] = ep + 1;
+    if (e < a.N) {
+        const LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, (uint32_t)e, m);
+        const uint32_t act = (uint32_t)a.actions[e] & 3u;
+        int32_t s = a.pos[e];
+        if ((a.flags & GU_F_AUTO_RESET) && a.done[e]) {  // lazy `if done: env.reset()`
+            const uint32_t ep = a.episode[e];
+            s = lg.starts[gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, lg.n_starts)];
+            a.episode[e] = ep + 1;
+        }
+        s = gu_move(s, m.f[s], act, gu_delta<LDS>(act, a.lut, a.W));
+        const int32_t r = m.r[s], d = (m.f[s] >> GU_CELL_TERM_BIT) & 1;
+        a.pos[e] = s;
+        a.reward[e] = r;
+        a.done[e] = d;
+        // zero-copy host path (GU_F_PINNED_IO): results also go straight to the caller's page-locked buffers over PCIe
+        if (a.host_obs) a.host_obs[e] = s;
+        if (a.host_reward) a.host_reward[e] = r;
+        if (a.host_done) a.host_done[e] = d;
     }
-    s = gu_move(s, m.f[s], act, gu_delta<LDS>(act, a.lut, a.W));
-    const int32_t r = m.r[s], d = (m.f[s] >> GU_CELL_TERM_BIT) & 1;
-    a.pos[e] = s;
-    a.reward[e] = r;
-    a.done[e] = d;
-    // zero-copy host path (GU_F_PINNED_IO): results also go straight to the caller's page-locked buffers over PCIe
-    if (a.host_obs) a.host_obs[e] = s;
-    if (a.host_reward) a.host_reward[e] = r;
-    if (a.host_done) a.host_done[e] = d;
     if (a.host_seq) {
-        // one wave (N <= 64): its mirror stores precede this point in program order for every lane; make them visible
-        // to the host, then publish the sequence number the host is spinning on (no interrupt, no runtime call)
+        // Completion word: the host spins on a sequence number in page-locked memory instead of going through the
+        // runtime's completion path (no interrupt, no runtime call).  Every block makes its mirror stores visible to the
+        // host, then counts itself; the block that completes the count publishes the number (and re-arms the counter).
         __threadfence_system();
-        if (e == 0) __hip_atomic_store(a.host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t arrived = atomicAdd(a.blocks_done, 1u);
+            if (arrived == gridDim.x - 1) {
+                *a.blocks_done = 0u;
+                __threadfence_system();
+                __hip_atomic_store(a.host_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -233,7 +244,7 @@ int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, i
 {
     StepArgs a{h->d_cell, h->cell_bytes, h->W, h->delta_lut, d_actions_row, h->pos(), h->reward(), h->done(),
                h->d_episode, h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags,
-               gu_grid_sel(h), host_obs, host_reward, host_done, host_seq, seq};
+               gu_grid_sel(h), host_obs, host_reward, host_done, host_seq, seq, h->d_blocks_done};
     const int lds_bs = gu_lds_block(h, GU_BLOCK, 2);
     if (lds_bs)
         hipLaunchKernelGGL(gu_step_kernel<true>, dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), 2 * (size_t)h->cell_bytes, h->stream, a);

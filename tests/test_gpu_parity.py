@@ -572,11 +572,12 @@ def test_pinned_io_paths():
             assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k][40:140])
 
 
-@pytest.mark.parametrize('N', [1, 3, 64, 65])
+@pytest.mark.parametrize('N', [1, 3, 64, 65, 1000, 8192, 8193])
 def test_one_wave_step_completion_word(N):
-    """Batches of up to 64 envs finish a page-locked gu_step by publishing a sequence number the host spins on
-    (with a real stream sync every 1024 steps); 65 envs take the ordinary sync.  2 500 steps against the oracle,
-    interleaved with calls that use the stream normally."""
+    """gu_step finishes by publishing a sequence number in page-locked memory that the host spins on (the last block to
+    arrive publishes it; a real stream sync every 1024 steps): one lane, part of a wave, a full wave, a partial block,
+    several blocks.  2 500 steps against the oracle, interleaved with calls that use the stream normally, through
+    the page-locked and the pageable entry."""
     meta = dict(W=9, H=7, walls=[10, 11, 12, 30, 31], lava=[40], goals=[62, 5], starts=[0, 8, 36])
     grid = C.Grid.from_lists(**meta)
     rs = np.random.RandomState(N)
@@ -593,6 +594,10 @@ def test_one_wave_step_completion_word(N):
             if t % 700 == 699:  # other traffic on the same stream in between
                 assert np.array_equal(eng.get_state()['pos'], want['obs'][t])
                 eng.done_indices()
+        want2 = C.rollout(grid, 3, st, 50, True, actions=acts[:50])
+        for t in range(50):  # pageable buffers: the engine's staging block stands in
+            o, r, d = eng.step(acts[t], auto_reset=True)
+            assert np.array_equal(o, want2['obs'][t]) and np.array_equal(d, want2['done'][t]), t
 
 
 def test_long_run_counters_and_graph_reseed():

@@ -4,7 +4,6 @@ cells, L2 records beyond.  Usage: python tools/big_grid_bench.py"""
 import json
 import os
 import sys
-import time
 
 import numpy as np
 

@@ -50,8 +50,8 @@ extern "C" {
 #define GU_F_PACKED 16u     /* gu_rollout: write ONE packed uint32 per env-step instead of three int32 rows:
                                obs | (reward & 0xFF) << 16 | done << 24  (4 B per env-step; grids <= 65 536 cells);
                                read back with gu_read_trajectory_packed.  Excludes GU_F_TRAJECTORY. */
-#define GU_F_PINNED_IO 8u   /* gu_step: the caller's buffers are page-locked (gu_host_alloc): DMA them
-                               directly instead of bouncing through the library's staging buffer */
+#define GU_F_PINNED_IO 8u   /* gu_step: the caller's buffers are page-locked (gu_host_alloc): the kernel reads and
+                               writes them itself instead of going through the library's staging block */
 
 /* gu_rollout policy kinds */
 #define GU_POLICY_UNIFORM 0 /* a ~ U{0..3} from the per-env counter RNG (stream 0)           */
@@ -133,7 +133,11 @@ int gu_reset_done(gu_handle h);
  * Synchronous, host buffers: actions in, (obs, reward, done) out (each N int32,
  * outputs optional).  flags: GU_F_AUTO_RESET; GU_F_PINNED_IO when every buffer passed
  * is page-locked (gu_host_alloc): the kernel then reads / writes them directly over
- * PCIe and no copy command is issued. */
+ * PCIe and no copy command is issued (pageable buffers take the same route through the
+ * library's own page-locked staging block, plus one memcpy each way).  Batches of up to
+ * 8192 envs return as soon as the kernel has published a completion word in page-locked
+ * memory -- the results are in place, the stream may still be draining; every later call on
+ * the handle is ordered behind it as usual. */
 int gu_step(gu_handle h, const int32_t *actions, uint32_t flags,
             int32_t *obs, int32_t *reward, int32_t *done);
 

@@ -293,13 +293,9 @@ static inline int gu_lds_block(const gu_engine *h, int preferred, int planes)
 
 static inline int gu_rollout_block()
 {
-    static int cached = 0;
-    if (!cached) {
-        const char *s = std::getenv("GU_ROLLOUT_BLOCK");
-        int v = s ? std::atoi(s) : 256;
-        cached = (v == 64 || v == 128 || v == 256) ? v : 256;
-    }
-    return cached;
+    const char *s = std::getenv("GU_ROLLOUT_BLOCK");  // read per launch: A/B runs switch it inside one process
+    const int v = s ? std::atoi(s) : 256;
+    return (v == 64 || v == 128 || v == 256) ? v : 256;
 }
 
 template <int POLICY, int AUTO, int TRAJ, bool STATS>

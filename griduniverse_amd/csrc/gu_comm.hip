@@ -9,22 +9,75 @@
 // issued inside a throughput loop.
 #include "gu_internal.hpp"
 
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library itself is loaded on first use (below)
+#include <dlfcn.h>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 static_assert(sizeof(ncclUniqueId) == GU_COMM_ID_BYTES, "ncclUniqueId size changed");
 
+// librccl.so is 570 MB of code objects.  Linking it would make EVERY process that loads libgu.so map and register it
+// at HIP start-up -- seconds on a warm box, minutes on a cold one -- although stepping never communicates.  It is
+// therefore dlopen'ed by the first gathered-view call, and only the eight entry points used here are resolved.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    const char *error = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+template <typename F>
+bool rccl_sym(F &slot, const char *name)
+{
+    slot = reinterpret_cast<F>(dlsym(g_rccl.lib, name));
+    return slot != nullptr;
+}
+
+const Rccl *rccl()
+{
+    std::call_once(g_rccl_once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.lib) break;
+        }
+        if (!g_rccl.lib) {
+            g_rccl.error = "librccl.so.1 not found (dlopen)";
+            return;
+        }
+        const bool ok = rccl_sym(g_rccl.GetUniqueId, "ncclGetUniqueId") && rccl_sym(g_rccl.CommInitRank, "ncclCommInitRank") &&
+                        rccl_sym(g_rccl.CommInitAll, "ncclCommInitAll") && rccl_sym(g_rccl.CommDestroy, "ncclCommDestroy") &&
+                        rccl_sym(g_rccl.AllGather, "ncclAllGather") && rccl_sym(g_rccl.GroupStart, "ncclGroupStart") &&
+                        rccl_sym(g_rccl.GroupEnd, "ncclGroupEnd") && rccl_sym(g_rccl.GetErrorString, "ncclGetErrorString");
+        if (!ok) g_rccl.error = "librccl.so.1 lacks an expected entry point";
+    });
+    return g_rccl.error ? nullptr : &g_rccl;
+}
+}  // namespace
+
+#define GU_RCCL_OR_FAIL(R)                                                       \
+    const Rccl *R = rccl();                                                      \
+    if (!R) return gu_fail(GU_ERR_COMM, "RCCL unavailable: %s", g_rccl.error)
+
 #define GU_NCCL(expr)                                                                       \
     do {                                                                                    \
         ncclResult_t _r = (expr);                                                           \
-        if (_r != ncclSuccess) return gu_fail(GU_ERR_COMM, "%s failed: %s", #expr, ncclGetErrorString(_r)); \
+        if (_r != ncclSuccess) return gu_fail(GU_ERR_COMM, "%s failed: %s", #expr, nc->GetErrorString(_r)); \
     } while (0)
 
 void gu_comm_free(gu_engine *h)
 {
     if (h->comm) {
-        (void)ncclCommDestroy((ncclComm_t)h->comm);
+        if (const Rccl *nc = rccl()) (void)nc->CommDestroy((ncclComm_t)h->comm);
         h->comm = nullptr;
     }
     if (h->d_gather) {
@@ -40,8 +93,9 @@ extern "C" {
 int gu_comm_unique_id(uint8_t id[GU_COMM_ID_BYTES])
 {
     GU_REQUIRE(id != nullptr, GU_ERR_INVALID, "id is NULL");
+    GU_RCCL_OR_FAIL(nc);
     ncclUniqueId uid;
-    GU_NCCL(ncclGetUniqueId(&uid));
+    GU_NCCL(nc->GetUniqueId(&uid));
     memcpy(id, &uid, GU_COMM_ID_BYTES);
     return GU_OK;
 }
@@ -51,11 +105,12 @@ int gu_comm_init(gu_handle h, int32_t nranks, int32_t rank, const uint8_t id[GU_
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
     GU_REQUIRE(id != nullptr && nranks > 0 && rank >= 0 && rank < nranks, GU_ERR_INVALID, "bad rank %d of %d", rank, nranks);
+    GU_RCCL_OR_FAIL(nc);
     gu_comm_free(h);
     ncclUniqueId uid;
     memcpy(&uid, id, GU_COMM_ID_BYTES);
     ncclComm_t comm = nullptr;
-    GU_NCCL(ncclCommInitRank(&comm, nranks, uid, rank));
+    GU_NCCL(nc->CommInitRank(&comm, nranks, uid, rank));
     h->comm = comm;
     h->nranks = nranks;
     h->rank = rank;
@@ -77,8 +132,9 @@ int gu_allgather_view(gu_handle h, int32_t *obs_all, int32_t *reward_all, int32_
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->comm != nullptr, GU_ERR_STATE, "no communicator: call gu_comm_init first");
+    GU_RCCL_OR_FAIL(nc);
     const size_t n = (size_t)h->N, block = 3 * n;
-    GU_NCCL(ncclAllGather(h->d_out3, h->d_gather, block, ncclInt32, (ncclComm_t)h->comm, h->stream));
+    GU_NCCL(nc->AllGather(h->d_out3, h->d_gather, block, ncclInt32, (ncclComm_t)h->comm, h->stream));
     GU_HIP(hipStreamSynchronize(h->stream));
     // unpack rank-major [rank][obs|reward|done][N] into three env-major host arrays
     int32_t *dst[3] = {obs_all, reward_all, done_all};
@@ -102,9 +158,10 @@ int gu_comm_init_all(gu_handle *handles, int32_t n)
         for (int32_t j = 0; j < i; ++j)
             GU_REQUIRE(devs[(size_t)j] != devs[(size_t)i], GU_ERR_INVALID, "RCCL needs one device per rank: handles %d and %d share device %d", j, i, devs[(size_t)i]);
     }
+    GU_RCCL_OR_FAIL(nc);
     std::vector<ncclComm_t> comms((size_t)n);
     for (int32_t i = 0; i < n; ++i) gu_comm_free(handles[i]);
-    GU_NCCL(ncclCommInitAll(comms.data(), n, devs.data()));
+    GU_NCCL(nc->CommInitAll(comms.data(), n, devs.data()));
     for (int32_t i = 0; i < n; ++i) {
         gu_engine *h = handles[i];
         h->comm = comms[(size_t)i];
@@ -122,17 +179,18 @@ int gu_allgather_view_all(gu_handle *handles, int32_t n, int32_t *obs_all, int32
     for (int32_t i = 0; i < n; ++i)
         GU_REQUIRE(handles[i] && handles[i]->comm && handles[i]->nranks == n && handles[i]->rank == i, GU_ERR_STATE,
                    "handles[%d] is not rank %d of a %d-rank communicator: call gu_comm_init_all first", i, i, n);
+    GU_RCCL_OR_FAIL(nc);
     const size_t cnt = 3 * (size_t)handles[0]->N;
-    GU_NCCL(ncclGroupStart());
+    GU_NCCL(nc->GroupStart());
     for (int32_t i = 0; i < n; ++i) {
         gu_engine *h = handles[i];
-        ncclResult_t r = ncclAllGather(h->d_out3, h->d_gather, cnt, ncclInt32, (ncclComm_t)h->comm, h->stream);
+        ncclResult_t r = nc->AllGather(h->d_out3, h->d_gather, cnt, ncclInt32, (ncclComm_t)h->comm, h->stream);
         if (r != ncclSuccess) {
-            (void)ncclGroupEnd();
-            return gu_fail(GU_ERR_COMM, "ncclAllGather on rank %d failed: %s", i, ncclGetErrorString(r));
+            (void)nc->GroupEnd();
+            return gu_fail(GU_ERR_COMM, "ncclAllGather on rank %d failed: %s", i, nc->GetErrorString(r));
         }
     }
-    GU_NCCL(ncclGroupEnd());
+    GU_NCCL(nc->GroupEnd());
     for (int32_t i = 0; i < n; ++i) {
         GU_HIP(hipSetDevice(handles[i]->device));
         GU_HIP(hipStreamSynchronize(handles[i]->stream));

@@ -420,6 +420,90 @@ def capture_mc():
               'terminal %.2f' % np.mean([e[2] for e in episodes]))
 
 
+# ----------------------------------------------------------------------------- G10
+def reference_path_search():
+    """The reference's breadth-first path search lives inside the `if __name__ == '__main__':` demo loop of
+    core/algorithms/maze_solving.py (:43-50 create_graph, :113-127 calculate_action, :129-169 breadth_first_search,
+    :171-193 construct_path), next to window / sleep calls, so the module can be neither imported nor run headless.
+    Here its four FUNCTION DEFINITIONS are lifted out of the parsed module by name (ast; no GUI statement runs) and
+    compiled, unchanged, into a namespace that supplies the free variables the demo loop binds around them
+    (`env`, `actions`, `nodes_and_edges`).  What runs is the reference's own code object."""
+    import ast
+    path = os.path.join(REF, 'core', 'algorithms', 'maze_solving.py')
+    tree = ast.parse(open(path).read(), path)
+    wanted = ('create_graph', 'calculate_action', 'breadth_first_search', 'construct_path')
+    defs = {n.name: n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name in wanted}
+    assert sorted(defs) == sorted(wanted), sorted(defs)
+    module = ast.Module(body=[defs[k] for k in wanted], type_ignores=[])
+    code = compile(ast.fix_missing_locations(module), path, 'exec')
+
+    def search(env, start_state):
+        """(action list or None, terminal state or None, exception name or None) of the reference's search."""
+        ns = dict(env=env, actions=range(4), nodes_and_edges={})
+        exec(code, ns)
+        reached = []
+        construct = ns['construct_path']
+
+        def recording_construct_path(state, meta):
+            reached.append(int(state))
+            return construct(state, meta)
+        ns['construct_path'] = recording_construct_path
+        with quiet():
+            ns['create_graph']()
+            try:
+                path_found = ns['breadth_first_search'](ns['nodes_and_edges'], start_state)
+            except KeyError:
+                return None, None, 'KeyError', ns['nodes_and_edges']
+        if path_found is None:  # the queue ran empty (:167-169 call construct_path and drop its result)
+            return None, None, None, ns['nodes_and_edges']
+        return [int(a) for a in path_found], reached[-1], None, ns['nodes_and_edges']
+    return search
+
+
+def capture_bfs():
+    search = reference_path_search()
+    rs = np.random.RandomState(4)
+    cases = []
+
+    def add(name, env, start=None, note=''):
+        start = int(env.initial_state if start is None else start)
+        path_found, terminal, error, graph = search(env, start)
+        n_edges = int(sum(len(v) for v in graph.values()))
+        cases.append(dict(spec_of(env), name=name, start=start, path=path_found, terminal=terminal, error=error,
+                          graph_nodes=len(graph), graph_edges=n_edges, note=note))
+        print('bfs', name, 'start', start, 'len', None if path_found is None else len(path_found), 'terminal', terminal, error or '')
+
+    add('default4x4', ref_env())
+    add('open8x8_ties', ref_env(grid_shape=(8, 8), goal_states=[63, 36, 7], walls=[9, 10, 17, 27, 35, 43]),
+        note='several shortest paths: FIFO order and action order decide')
+    add('lava_nearer_than_goal', ref_env(grid_shape=(8, 8), lava_states=[18, 42], walls=[1]), note='terminal reached is lava')
+    add('goal_and_lava_same_cell', ref_env(grid_shape=(5, 5), goal_states=[12], lava_states=[12, 3]))
+    add('start_is_terminal', ref_env(grid_shape=(6, 4), initial_state=9, goal_states=[9]), note='empty path')
+    add('start_walled_in', ref_env(grid_shape=(10, 7), goal_states=[69], walls=[1, 10, 11]), note='queue runs empty: None')
+    add('goal_behind_walls', ref_env(grid_shape=(6, 6), goal_states=[35], walls=[29, 34, 14]),
+        note='goal unreachable')
+    add('start_on_wall', ref_env(grid_shape=(4, 4), walls=[0, 5]), note='wall start is no graph node: KeyError at :140')
+    add('column1x9', ref_env(grid_shape=(1, 9)), note='W=1: vertical neighbours differ by 1 -> calculate_action names them LEFT/RIGHT')
+    add('row9x1', ref_env(grid_shape=(9, 1)))
+    add('two_wide', ref_env(grid_shape=(2, 7), walls=[3, 6]))
+    W, H = 25, 30
+    cells = rs.permutation(W * H)
+    add('rect25x30_busy', ref_env(grid_shape=(W, H), initial_state=int(cells[0]), goal_states=[int(c) for c in cells[30:34]],
+                                  lava_states=[int(c) for c in cells[40:52]], walls=[int(c) for c in cells[100:300]]))
+    W, H = 40, 12
+    cells = rs.permutation(W * H)
+    add('wide40x12', ref_env(grid_shape=(W, H), initial_state=int(cells[0]), goal_states=[int(c) for c in cells[2:4]],
+                             lava_states=[int(c) for c in cells[6:12]], walls=[int(c) for c in cells[20:150]]))
+    for w, h, k in ((15, 15, 0), (15, 15, 1), (8, 8, 3), (11, 11, 2), (21, 13, 4), (32, 32, 123)):
+        add('maze%dx%d_s%d' % (w, h, k), seeded_maze_env(w, h, k), note='the demo script itself searches 15x15 random mazes (:18)')
+    env = ref_env(custom_world_fp=os.path.join(LEVELS, 'test_env.txt'))
+    for st in env.starting_states:
+        add('test_env_start%d' % st, env, start=st)
+    add('maze_21x21_level', ref_env(custom_world_fp=os.path.join(LEVELS, 'maze_21x21.txt')))
+    add('maze_101x101_level', ref_env(custom_world_fp=os.path.join(LEVELS, 'maze_101x101.txt')))
+    return cases
+
+
 # ----------------------------------------------------------------------------- G2
 def capture_trajectories():
     digests = {}
@@ -493,7 +577,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     random.seed(0)
     np.random.seed(0)
-    what = set(sys.argv[1:]) or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc'}  # plus 'big' (slow) on request
+    what = set(sys.argv[1:]) or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'bfs'}  # plus 'big' (slow) on request
     if 'kat' in what:
         json.dump(capture_kats(), open(os.path.join(OUT, 'kat.json'), 'w'), indent=1)
     if 'err' in what:
@@ -508,6 +592,8 @@ def main():
         capture_dp()
     if 'mc' in what:
         capture_mc()
+    if 'bfs' in what:
+        json.dump(capture_bfs(), open(os.path.join(OUT, 'bfs.json'), 'w'), indent=1)
     if 'big' in what:
         capture_big_digest()
     if 'traj' in what:

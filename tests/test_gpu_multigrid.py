@@ -163,3 +163,24 @@ def test_batched_shortest_paths_equal_the_restated_reference_search():
                 assert p.tolist() == bfs.breadth_first_search(_oracle_env(spec), start)[0]
         with pytest.raises(ValueError):
             eng.shortest_paths(max_path=3)
+
+
+@pytest.mark.parametrize('case', __import__('tests._golden', fromlist=['x']).load_json('bfs.json'), ids=lambda c: c['name'])
+def test_shortest_paths_equal_the_reference_search(case):
+    """gu_shortest_paths and the host counterpart algorithms.maze_solving against tests/golden/bfs.json -- paths produced
+    by the reference's own create_graph / breadth_first_search / calculate_action / construct_path
+    (core/algorithms/maze_solving.py:43-50, 113-193; lifted out of the demo script by tests/golden/make_golden.py)."""
+    from griduniverse_amd.algorithms import maze_solving
+    spec = GridSpec(case['W'], case['H'], [case['start']], case['goals'], case['lava'], case['walls'], case['reward'])
+    with Engine(4, spec) as eng:
+        paths, terms = eng.shortest_paths()
+    if case['path'] is None:  # unreachable; or the reference's KeyError on a wall start (documented difference)
+        assert paths[0] is None and terms[0] == -1
+    else:
+        assert paths[0].tolist() == case['path'] and terms[0] == case['terminal']
+    env = gua.GridUniverseEnv(grid_shape=(case['W'], case['H']), initial_state=list(case['starts']), goal_states=list(case['goals']),
+                              lava_states=list(case['lava']), walls=list(case['walls']))
+    graph = maze_solving.create_graph(env)
+    assert len(graph) == case['graph_nodes'] and sum(len(v) for v in graph.values()) == case['graph_edges']
+    assert maze_solving.breadth_first_search(env, case['start']) == case['path']
+    env.close()

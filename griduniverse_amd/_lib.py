@@ -32,6 +32,7 @@ SIGNATURES = {
     'gu_version': [],
     'gu_last_error': [_c.c_char_p, _c.c_size_t],
     'gu_device_count': [_c.POINTER(_c.c_int)],
+    'gu_source_hash': [_c.c_char_p, _c.c_size_t],
     'gu_create': [_c.c_int, _i64, _i64, _c.POINTER(_vp)],
     'gu_destroy': [_vp],
     'gu_set_grid': [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32],
@@ -71,6 +72,8 @@ SIGNATURES = {
     'gu_sync': [_vp],
     'gu_timer_begin': [_vp],
     'gu_timer_end': [_vp, _c.POINTER(_c.c_float)],
+    'gu_timer_mark': [_vp],
+    'gu_timer_laps': [_vp, _vp, _i32, _vp],
     'gu_comm_unique_id': [_vp],
     'gu_comm_init': [_vp, _i32, _i32, _vp],
     'gu_comm_destroy': [_vp],
@@ -96,8 +99,39 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the library's sources as they are on disk -- the Makefile's SRCHASH."""
+    import hashlib
+    names = sorted(n for n in os.listdir(CSRC) if n.endswith(('.hip', '.hpp')))
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, n) for n in names] + [os.path.join(os.path.dirname(_HERE), 'include', 'gu.h')]:
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash():
+    """The source hash compiled into libgu.so, or None when there is no library."""
+    if not os.path.exists(LIB_PATH):
+        return None
+    lib = ctypes.CDLL(LIB_PATH)
+    try:
+        fn = lib.gu_source_hash
+    except AttributeError:
+        return 'unknown'
+    fn.argtypes, fn.restype = [ctypes.c_char_p, ctypes.c_size_t], ctypes.c_int
+    buf = ctypes.create_string_buffer(64)
+    fn(buf, 64)
+    return buf.value.decode()
+
+
+def is_stale():
+    """True when libgu.so is missing or was built from sources other than those on disk."""
+    return built_hash() != source_hash()
+
+
 def load():
-    """dlopen libgu.so.  Raises (never falls back) when it has not been built."""
+    """dlopen libgu.so.  Raises (never falls back, never builds) when it is missing or stale."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -108,6 +142,11 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
+        buf = ctypes.create_string_buffer(64)
+        lib.gu_source_hash(buf, 64)
+        if os.path.isdir(CSRC) and buf.value.decode() != source_hash() and not os.environ.get('GU_ALLOW_STALE_LIB'):
+            raise GuError(-2, 'libgu.so at {} was built from other sources (built {}, on disk {}): rebuild with '
+                              '`make -C griduniverse_amd/csrc`'.format(LIB_PATH, buf.value.decode(), source_hash()))
         _lib = lib
     return _lib
 

@@ -3,6 +3,7 @@
 #include "gu_internal.hpp"
 #include "gu_rng.hpp"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -114,11 +115,12 @@ int gu_create(int device_id, int64_t num_envs, int64_t env_id0, gu_handle *out)
         GU_HIP(hipMalloc(&h->d_ret, n * sizeof(int32_t)));
         GU_HIP(hipMalloc(&h->d_episodes_fin, n * sizeof(int32_t)));
         GU_HIP(hipMalloc(&h->d_done_bits, ((n + 63) / 64) * sizeof(uint64_t)));
-        GU_HIP(hipMalloc(&h->d_done_idx, n * sizeof(int32_t)));
-        GU_HIP(hipMalloc(&h->d_done_count, sizeof(int32_t)));
+        GU_HIP(hipMemsetAsync(h->d_done_bits, 0, ((n + 63) / 64) * sizeof(uint64_t), h->stream));
+        h->done_bits_valid = true;
         GU_HIP(hipHostMalloc(&h->h_pin, 4 * n * sizeof(int32_t), hipHostMallocDefault));
         GU_HIP(hipHostMalloc(&h->h_seq, 64, hipHostMallocDefault));
-        *h->h_seq = 0;
+        memset(h->h_seq, 0, 64);
+        h->step_sync = std::getenv("GU_STEP_SYNC") != nullptr;  // read once: gu_step is a ~10 us hot path
         GU_HIP(hipMalloc(&h->d_blocks_done, sizeof(uint32_t)));
         GU_HIP(hipMemsetAsync(h->d_blocks_done, 0, sizeof(uint32_t), h->stream));
         GU_HIP(hipMemsetAsync(h->d_out3, 0, 3 * n * sizeof(int32_t), h->stream));
@@ -147,13 +149,13 @@ int gu_destroy(gu_handle h)
     gu_vi_free(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     void *bufs[] = {h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions,
-                    h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_done_idx, h->d_done_count,
-                    h->d_scratch, h->d_greedy};
+                    h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_seq) (void)hipHostFree(h->h_seq);
     if (h->d_blocks_done) (void)hipFree(h->d_blocks_done);
+    for (hipEvent_t ev : h->ev_marks) (void)hipEventDestroy(ev);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -252,6 +254,8 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
     for (int64_t e = 0; e < h->N; ++e) init[(size_t)e] = starts[(size_t)(e / h->group) * max_starts];
     GU_HIP(hipMemcpy(h->pos(), init.data(), (size_t)h->N * sizeof(int32_t), hipMemcpyHostToDevice));
     GU_HIP(hipMemset(h->reward(), 0, 2 * (size_t)h->N * sizeof(int32_t)));
+    GU_HIP(hipMemset(h->d_done_bits, 0, (((size_t)h->N + 63) / 64) * sizeof(uint64_t)));
+    h->done_bits_valid = true;
     return GU_OK;
 }
 
@@ -264,6 +268,8 @@ int gu_set_grids(gu_handle h, int32_t n_grids, int32_t W, int32_t H, int32_t wor
     GU_ENTER(h);
     GU_REQUIRE(n_grids > 0 && h->N % n_grids == 0, GU_ERR_INVALID, "n_grids=%d must divide num_envs=%lld", n_grids, (long long)h->N);
     GU_REQUIRE(W > 0 && H > 0 && (int64_t)W * H <= (1 << 30), GU_ERR_INVALID, "bad grid shape %d x %d", W, H);
+    // gu_move multiplies the OPEN bit by delta = +-W with v_mad_i32_i24, which sign-extends delta from 24 bits
+    GU_REQUIRE(W <= 8388607, GU_ERR_UNSUPPORTED, "grids wider than 8 388 607 columns are not supported (W=%d)", W);
     GU_REQUIRE(words_per_row == (W + 31) / 32, GU_ERR_INVALID, "words_per_row must be ceil(W/32)");
     GU_REQUIRE(wall_rows && goal_rows && lava_rows, GU_ERR_INVALID, "wall/goal/lava planes are required");
     GU_REQUIRE((rplus_rows == nullptr) == (rminus_rows == nullptr), GU_ERR_INVALID, "give both reward planes or neither");
@@ -371,28 +377,90 @@ int gu_reset_done(gu_handle h)
 }
 
 // ---------------------------------------------------------------------------------- step
+// Page-locked ranges the step kernel may dereference directly (GU_F_PINNED_IO).  A pointer is looked up with the runtime
+// once; afterwards a call costs a few compares.  gu_host_free bumps the generation, which empties every engine's cache.
+static std::atomic<uint32_t> g_pinned_generation{1};
+
+struct PinnedRanges {
+    uint32_t generation = 0;
+    int n = 0;
+    uintptr_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+};
+static thread_local PinnedRanges g_pinned;
+
+static int gu_require_pinned(const void *p, size_t bytes, const char *what)
+{
+    if (!p) return GU_OK;
+    const uint32_t gen = g_pinned_generation.load(std::memory_order_acquire);
+    if (g_pinned.generation != gen) {
+        g_pinned.generation = gen;
+        g_pinned.n = 0;
+    }
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    for (int i = 0; i < g_pinned.n; ++i)
+        if (lo >= g_pinned.lo[i] && hi <= g_pinned.hi[i]) return GU_OK;
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof attr);
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();  // an ordinary malloc / numpy pointer is "invalid value" to the runtime: not sticky
+        return gu_fail(GU_ERR_INVALID, "GU_F_PINNED_IO: %s (%p) is not page-locked host memory (use gu_host_alloc, or drop the flag)", what, p);
+    }
+    uintptr_t base = lo, size = bytes;
+    void *start = nullptr;
+    size_t range = 0;
+    if (hipPointerGetAttribute(&start, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)p) == hipSuccess &&
+        hipPointerGetAttribute(&range, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, (hipDeviceptr_t)p) == hipSuccess && start && range) {
+        base = (uintptr_t)start;
+        size = range;
+        if (hi > base + size)
+            return gu_fail(GU_ERR_INVALID, "GU_F_PINNED_IO: %s (%p + %zu bytes) runs past the end of its page-locked allocation", what, p, bytes);
+    } else {
+        (void)hipGetLastError();
+    }
+    const int slot = g_pinned.n < 4 ? g_pinned.n++ : 0;
+    g_pinned.lo[slot] = base;
+    g_pinned.hi[slot] = base + size;
+    return GU_OK;
+}
+
+// The step kernel raised the page-locked error word: name the first offender (the actions are host memory in every
+// gu_step path) and re-arm the word.
+static int gu_step_action_error(gu_engine *h, const int32_t *actions)
+{
+    __atomic_store_n(h->h_seq + GU_HOST_ERR_WORD, 0u, __ATOMIC_RELAXED);
+    for (int64_t i = 0; i < h->N; ++i)
+        if ((uint32_t)actions[i] > 3u)
+            return gu_fail(GU_ERR_INVALID, "action %d of env %lld outside 0..3 (that env did not step; envs with valid actions did)", actions[i], (long long)i);
+    return gu_fail(GU_ERR_INVALID, "an action outside 0..3 was seen by the step kernel (the action buffer changed during the call)");
+}
+
 // One step whose actions / results live in page-locked host memory, and the wait for it.  The kernel publishes a
 // sequence number in page-locked memory after the last block's result stores and the host spins on it -- a PCIe round
 // trip instead of the runtime's completion path: 14.0 -> 10.4 us per call at up to 64 envs, 15.5 -> 12.7 at 4096.  Only
 // for batches of up to 8192 envs: the per-block system-scope fence serialises the PCIe result stream of larger ones
 // (65 536 envs: 57 us against 43 us with the ordinary synchronisation, measured in one process).  Bounded: after ~1 ms
-// of spinning, and every 1024 steps anyway, the real stream synchronisation runs (GU_STEP_SYNC=1 forces it).
+// of spinning, and every 1024 steps anyway, the real stream synchronisation runs (GU_STEP_SYNC=1 at gu_create forces it).
+// Actions are validated by the kernel itself (an error word next to the completion word), not by a host loop.
 static int gu_step_and_wait(gu_engine *h, const int32_t *actions, uint32_t flags, int32_t *obs, int32_t *reward, int32_t *done)
 {
     int rc;
-    if (h->N <= 8192 && h->seq_since_sync < 1024 && !std::getenv("GU_STEP_SYNC")) {
+    uint32_t *err = h->h_seq + GU_HOST_ERR_WORD;
+    bool finished = false;
+    if (h->N <= 8192 && h->seq_since_sync < 1024 && !h->step_sync) {
         const uint32_t seq = ++h->seq;
-        rc = gu_launch_step(h, actions, flags, obs, reward, done, h->h_seq, seq);
+        rc = gu_launch_step(h, actions, flags, obs, reward, done, h->h_seq, seq, err);
         if (rc != GU_OK) return rc;
         ++h->seq_since_sync;
-        for (int spin = 0; spin < 2000000; ++spin)
-            if (__atomic_load_n(h->h_seq, __ATOMIC_ACQUIRE) == seq) return GU_OK;
+        for (int spin = 0; spin < 2000000 && !finished; ++spin) finished = __atomic_load_n(h->h_seq, __ATOMIC_ACQUIRE) == seq;
     } else {
-        rc = gu_launch_step(h, actions, flags, obs, reward, done);
+        rc = gu_launch_step(h, actions, flags, obs, reward, done, nullptr, 0, err);
         if (rc != GU_OK) return rc;
     }
-    GU_HIP(hipStreamSynchronize(h->stream));
-    h->seq_since_sync = 0;
+    if (!finished) {
+        GU_HIP(hipStreamSynchronize(h->stream));
+        h->seq_since_sync = 0;
+    }
+    if (__atomic_load_n(err, __ATOMIC_ACQUIRE)) return gu_step_action_error(h, actions);
     return GU_OK;
 }
 
@@ -405,13 +473,15 @@ int gu_step(gu_handle h, const int32_t *actions, uint32_t flags, int32_t *obs, i
     const bool direct = flags & GU_F_PINNED_IO;
     flags &= GU_F_AUTO_RESET;
     const size_t n = (size_t)h->N;
-    for (size_t i = 0; i < n; ++i)
-        GU_REQUIRE((uint32_t)actions[i] < 4u, GU_ERR_INVALID, "action %d of env %zu outside 0..3", actions[i], i);
     int rc = GU_OK;
     if (direct) {
         // The caller's buffers are page-locked (gu_host_alloc), i.e. mapped into the device's address space: the
         // kernel reads the actions from them and writes the results into them itself over PCIe -- one launch and
-        // one synchronisation, no copy commands at all.
+        // one synchronisation, no copy commands at all.  (Checked: a pageable pointer here would be a GPU fault.)
+        if ((rc = gu_require_pinned(actions, n * 4, "actions")) != GU_OK) return rc;
+        if ((rc = gu_require_pinned(obs, n * 4, "obs")) != GU_OK) return rc;
+        if ((rc = gu_require_pinned(reward, n * 4, "reward")) != GU_OK) return rc;
+        if ((rc = gu_require_pinned(done, n * 4, "done")) != GU_OK) return rc;
         return gu_step_and_wait(h, actions, flags, obs, reward, done);
     }
     // Ordinary (pageable) caller buffers: the engine's own page-locked staging block plays the caller's part of the
@@ -432,8 +502,6 @@ int gu_upload_actions(gu_handle h, const int32_t *actions, int64_t T)
     GU_ENTER(h);
     GU_REQUIRE(actions != nullptr && T > 0, GU_ERR_INVALID, "actions NULL or T <= 0");
     const size_t count = (size_t)T * (size_t)h->N;
-    for (size_t i = 0; i < count; ++i)
-        GU_REQUIRE((uint32_t)actions[i] < 4u, GU_ERR_INVALID, "action %d at flat index %zu outside 0..3", actions[i], i);
     if (T > h->actions_T) {
         GU_HIP(hipStreamSynchronize(h->stream));
         if (h->d_actions) GU_HIP(hipFree(h->d_actions));
@@ -446,7 +514,18 @@ int gu_upload_actions(gu_handle h, const int32_t *actions, int64_t T)
             h->graph_exec = nullptr;
         }
     }
-    GU_HIP(hipMemcpy(h->d_actions, actions, count * sizeof(int32_t), hipMemcpyHostToDevice));
+    GU_HIP(hipMemcpyAsync(h->d_actions, actions, count * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    // validated on the device, where the stream now is (one pass at HBM speed instead of a host loop over T x N values)
+    int rc = gu_launch_validate_actions(h, h->d_actions, (int64_t)count);
+    if (rc != GU_OK) return rc;
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (__atomic_load_n(h->h_seq + GU_HOST_ERR_WORD, __ATOMIC_ACQUIRE)) {
+        __atomic_store_n(h->h_seq + GU_HOST_ERR_WORD, 0u, __ATOMIC_RELAXED);
+        h->actions_T = 0;  // the rejected stream is not usable (the buffer itself is kept for the next upload)
+        for (size_t i = 0; i < count; ++i)
+            if ((uint32_t)actions[i] > 3u) return gu_fail(GU_ERR_INVALID, "action %d at flat index %zu outside 0..3", actions[i], i);
+        return gu_fail(GU_ERR_INVALID, "an action outside 0..3 was uploaded");
+    }
     return GU_OK;
 }
 
@@ -619,6 +698,7 @@ int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uin
         std::vector<int32_t> d(done, done + n);
         for (auto &x : d) x = x ? 1 : 0;
         GU_HIP(hipMemcpy(h->done(), d.data(), n * 4, hipMemcpyHostToDevice));
+        h->done_bits_valid = false;  // gu_done_indices re-ballots a done[] that came from the host
     }
     if (episode) GU_HIP(hipMemcpy(h->d_episode, episode, n * 4, hipMemcpyHostToDevice));
     if (tcount) {
@@ -633,11 +713,13 @@ int gu_done_indices(gu_handle h, int32_t *idx, int32_t *count)
 {
     GU_ENTER(h);
     GU_REQUIRE(count != nullptr, GU_ERR_INVALID, "count is NULL");
+    // one launch: the compaction kernel expands the ballot words (written by the step / rollout / reset kernels) into the
+    // ascending index list, straight into the page-locked staging block
     int rc = gu_launch_done_compact(h);
     if (rc != GU_OK) return rc;
-    GU_HIP(hipMemcpyAsync(count, h->d_done_count, 4, hipMemcpyDeviceToHost, h->stream));
     GU_HIP(hipStreamSynchronize(h->stream));
-    if (idx && *count > 0) GU_HIP(hipMemcpy(idx, h->d_done_idx, (size_t)*count * 4, hipMemcpyDeviceToHost));
+    *count = (int32_t)__atomic_load_n(h->h_seq + GU_HOST_COUNT_WORD, __ATOMIC_ACQUIRE);
+    if (idx && *count > 0) memcpy(idx, h->h_pin, (size_t)*count * 4);
     return GU_OK;
 }
 
@@ -648,10 +730,6 @@ int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int3
     GU_ENTER(h);
     GU_NEED_GRID(h);
     GU_REQUIRE(n > 0 && states && actions, GU_ERR_INVALID, "n <= 0 or NULL inputs");
-    for (int64_t i = 0; i < n; ++i) {
-        GU_REQUIRE(states[i] >= 0 && states[i] < h->S, GU_ERR_INVALID, "state %d outside the grid", states[i]);
-        GU_REQUIRE((uint32_t)actions[i] < 4u, GU_ERR_INVALID, "action %d outside 0..3", actions[i]);
-    }
     const size_t bytes = (size_t)n * 4;
     int rc = gu_ensure_scratch(h, 5 * bytes);
     if (rc != GU_OK) return rc;
@@ -661,6 +739,14 @@ int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int3
     rc = gu_launch_lookahead(h, n, d, d + n, care_about_terminal != 0, d + 2 * n, d + 3 * n, d + 4 * n);
     if (rc != GU_OK) return rc;
     GU_HIP(hipStreamSynchronize(h->stream));
+    if (__atomic_load_n(h->h_seq + GU_HOST_ERR_WORD, __ATOMIC_ACQUIRE)) {  // raised by the kernel; name the first offender
+        __atomic_store_n(h->h_seq + GU_HOST_ERR_WORD, 0u, __ATOMIC_RELAXED);
+        for (int64_t i = 0; i < n; ++i) {
+            GU_REQUIRE(states[i] >= 0 && states[i] < h->S, GU_ERR_INVALID, "state %d outside the grid", states[i]);
+            GU_REQUIRE((uint32_t)actions[i] < 4u, GU_ERR_INVALID, "action %d outside 0..3", actions[i]);
+        }
+        return gu_fail(GU_ERR_INVALID, "a state outside the grid or an action outside 0..3 was passed");
+    }
     if (next) GU_HIP(hipMemcpy(next, d + 2 * n, bytes, hipMemcpyDeviceToHost));
     if (reward) GU_HIP(hipMemcpy(reward, d + 3 * n, bytes, hipMemcpyDeviceToHost));
     if (done) GU_HIP(hipMemcpy(done, d + 4 * n, bytes, hipMemcpyDeviceToHost));
@@ -678,6 +764,7 @@ int gu_host_alloc(size_t bytes, void **ptr)
 
 int gu_host_free(void *ptr)
 {
+    g_pinned_generation.fetch_add(1, std::memory_order_acq_rel);  // validated GU_F_PINNED_IO ranges are looked up again
     if (ptr) GU_HIP(hipHostFree(ptr));
     return GU_OK;
 }
@@ -704,6 +791,36 @@ int gu_timer_end(gu_handle h, float *milliseconds)
     GU_HIP(hipEventRecord(h->ev_end, h->stream));
     GU_HIP(hipEventSynchronize(h->ev_end));
     GU_HIP(hipEventElapsedTime(milliseconds, h->ev_begin, h->ev_end));
+    return GU_OK;
+}
+
+// Lap timing: gu_timer_mark records one event on the stream per call; gu_timer_laps waits for the last one and returns the
+// n_marks - 1 intervals between consecutive marks, then forgets the marks.
+int gu_timer_mark(gu_handle h)
+{
+    GU_ENTER(h);
+    if (h->n_marks == h->ev_marks.size()) {
+        hipEvent_t ev = nullptr;
+        GU_HIP(hipEventCreate(&ev));
+        h->ev_marks.push_back(ev);
+    }
+    GU_HIP(hipEventRecord(h->ev_marks[h->n_marks], h->stream));
+    ++h->n_marks;
+    return GU_OK;
+}
+
+int gu_timer_laps(gu_handle h, float *milliseconds, int32_t capacity, int32_t *count)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(count != nullptr, GU_ERR_INVALID, "count is NULL");
+    const size_t laps = h->n_marks ? h->n_marks - 1 : 0;
+    *count = (int32_t)laps;
+    if (h->n_marks) GU_HIP(hipEventSynchronize(h->ev_marks[h->n_marks - 1]));
+    if (milliseconds) {
+        GU_REQUIRE((size_t)capacity >= laps, GU_ERR_INVALID, "room for %d laps, %zu recorded", capacity, laps);
+        for (size_t i = 0; i < laps; ++i) GU_HIP(hipEventElapsedTime(milliseconds + i, h->ev_marks[i], h->ev_marks[i + 1]));
+    }
+    h->n_marks = 0;
     return GU_OK;
 }
 

@@ -29,10 +29,15 @@
 
 #define GU_MAX_LDS_CELLS 32767 /* both planes of grids up to 32 767 cells (64 KiB) are LDS-resident; larger read L2 */
 
+#define GU_HOST_ERR_WORD 4
+#define GU_HOST_COUNT_WORD 8
+
 struct gu_engine {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_marks;  // gu_timer_mark pool (grows on demand, reused)
+    size_t n_marks = 0;
 
     int64_t N = 0;        // envs on this device
     int64_t env_id0 = 0;  // global id of env 0
@@ -75,10 +80,9 @@ struct gu_engine {
     int32_t *d_episodes_fin = nullptr;
     bool stats_valid = false;
 
-    // done compaction
+    // done compaction: one ballot word per wave, written by every kernel that writes done[]
     uint64_t *d_done_bits = nullptr;
-    int32_t *d_done_idx = nullptr;
-    int32_t *d_done_count = nullptr;
+    bool done_bits_valid = false;   // false only after the host installed done[] (gu_set_state)
 
     // scratch for masks / start choices / look_step_ahead
     void *d_scratch = nullptr;
@@ -86,7 +90,10 @@ struct gu_engine {
 
     // pinned host staging (4*N int32)
     int32_t *h_pin = nullptr;
-    uint32_t *h_seq = nullptr;      // page-locked completion word of gu_step's host-visible paths
+    uint32_t *h_seq = nullptr;      // page-locked control words (64 bytes): [0] completion word of gu_step's host-visible
+                                    // paths, [GU_HOST_ERR_WORD] raised by a kernel that met an invalid action / state,
+                                    // [GU_HOST_COUNT_WORD] number of done envs written by the compaction kernel
+    bool step_sync = false;         // GU_STEP_SYNC was set when the engine was created: never spin on the completion word
     uint32_t *d_blocks_done = nullptr;  // its device-side block counter
     uint32_t seq = 0, seq_since_sync = 0;
 
@@ -151,7 +158,9 @@ int gu_ensure_scratch(gu_engine *h, size_t bytes);
 // ---- kernel launchers (gu_kernels.hip) -------------------------------------------
 int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice, bool only_done);
 int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, int32_t *host_obs = nullptr,
-                   int32_t *host_reward = nullptr, int32_t *host_done = nullptr, uint32_t *host_seq = nullptr, uint32_t seq = 0);
+                   int32_t *host_reward = nullptr, int32_t *host_done = nullptr, uint32_t *host_seq = nullptr, uint32_t seq = 0,
+                   uint32_t *host_err = nullptr);
+int gu_launch_validate_actions(gu_engine *h, const int32_t *d_actions, int64_t count);
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags);
 int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const int32_t *d_actions, bool care,
                         int32_t *d_next, int32_t *d_reward, int32_t *d_done);

@@ -22,6 +22,8 @@
 // every step for no gain.
 #include "gu_rollout.hpp"
 
+#include <algorithm>
+
 // ------------------------------------------------------------------------------------
 // reset: GridUniverseEnv._reset (env:187-193) for the masked / done envs
 // ------------------------------------------------------------------------------------
@@ -31,6 +33,7 @@ struct ResetArgs {
     const int32_t *starts;
     const uint8_t *mask;
     const int32_t *choice;
+    uint64_t *done_bits;  // [ceil(N/64)] wave ballots of the done flags, kept current by every kernel that writes done[]
     uint32_t n_starts, seed_prefix, env_id0;
     int64_t N;
     int32_t only_done;
@@ -40,27 +43,37 @@ struct ResetArgs {
 __global__ void __launch_bounds__(GU_BLOCK) gu_reset_kernel(const ResetArgs a)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= a.N) return;
-    if (a.mask && !a.mask[e]) return;
-    if (a.only_done && !a.done[e]) return;
-    uint32_t ep = a.episode[e];
-    const int32_t *starts = a.starts;
-    uint32_t n_starts = a.n_starts;
-    if (a.gs.n_grids > 1) {
-        const uint32_t g = (uint32_t)e / (uint32_t)a.gs.group;
-        starts += (int64_t)g * a.gs.max_starts;
-        n_starts = (uint32_t)a.gs.n_starts[g];
+    const bool live = e < a.N;
+    int32_t still_done = 0;
+    if (live) {
+        bool take = !a.mask || a.mask[e];
+        const int32_t was_done = a.done[e];
+        if (a.only_done && !was_done) take = false;
+        if (take) {
+            uint32_t ep = a.episode[e];
+            const int32_t *starts = a.starts;
+            uint32_t n_starts = a.n_starts;
+            if (a.gs.n_grids > 1) {
+                const uint32_t g = (uint32_t)e / (uint32_t)a.gs.group;
+                starts += (int64_t)g * a.gs.max_starts;
+                n_starts = (uint32_t)a.gs.n_starts[g];
+            }
+            uint32_t idx;
+            if (a.choice) {
+                idx = (uint32_t)a.choice[e];
+                if (idx >= n_starts) idx = 0;  // host validates; never index out of the table
+            } else {
+                idx = gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, n_starts);
+            }
+            a.pos[e] = starts[idx];
+            a.done[e] = 0;
+            a.episode[e] = ep + 1;
+        } else {
+            still_done = was_done;
+        }
     }
-    uint32_t idx;
-    if (a.choice) {
-        idx = (uint32_t)a.choice[e];
-        if (idx >= n_starts) idx = 0;  // host validates; never index out of the table
-    } else {
-        idx = gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, n_starts);
-    }
-    a.pos[e] = starts[idx];
-    a.done[e] = 0;
-    a.episode[e] = ep + 1;
+    const uint64_t bits = __ballot(still_done != 0);
+    if ((threadIdx.x & 63) == 0 && live) a.done_bits[e >> 6] = bits;
 }
 
 // ------------------------------------------------------------------------------------
@@ -75,6 +88,7 @@ struct StepArgs {
     const int32_t *actions;
     int32_t *pos, *reward, *done;
     uint32_t *episode;
+    uint32_t *tcount;  // per-env step-count offsets (touched only by a lane whose action is rejected)
     const int32_t *starts;
     uint32_t n_starts, seed_prefix, env_id0;
     int64_t N;
@@ -84,6 +98,8 @@ struct StepArgs {
     uint32_t *host_seq;  // optional page-locked completion word: set to `seq` after every block's mirror stores
     uint32_t seq;
     uint32_t *blocks_done;  // device counter behind the completion word (zero between launches)
+    uint32_t *host_err;     // optional page-locked error word: actions come from the caller and are validated HERE
+    uint64_t *done_bits;    // [ceil(N/64)] wave ballots of the new done flags (episode-done compaction, gu_done_indices)
 };
 
 template <bool LDS>
@@ -92,25 +108,41 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem, a.gs);
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t d = 0;
     if (e < a.N) {
         const LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, (uint32_t)e, m);
-        const uint32_t act = (uint32_t)a.actions[e] & 3u;
-        int32_t s = a.pos[e];
-        if ((a.flags & GU_F_AUTO_RESET) && a.done[e]) {  // lazy `if done: env.reset()`
-            const uint32_t ep = a.episode[e];
-            s = lg.starts[gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, lg.n_starts)];
-            a.episode[e] = ep + 1;
+        const uint32_t raw = (uint32_t)a.actions[e];
+        const uint32_t act = raw & 3u;
+        int32_t s = a.pos[e], r;
+        if (a.host_err && raw > 3u) {
+            // Action outside 0..3 (env:148 raises IndexError before it touches the instance): this env does not
+            // step -- position, flags, pending lazy reset and step count stay as they were -- and the host is told
+            // through the page-locked error word (any offender may write it; the host finds the first one itself).
+            __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            a.tcount[e] -= 1u;  // the lock-step counter advances for the whole batch
+            r = a.reward[e];
+            d = a.done[e];
+        } else {
+            if ((a.flags & GU_F_AUTO_RESET) && a.done[e]) {  // lazy `if done: env.reset()`
+                const uint32_t ep = a.episode[e];
+                s = lg.starts[gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)e), ep, lg.n_starts)];
+                a.episode[e] = ep + 1;
+            }
+            s = gu_move(s, m.f[s], act, gu_delta<LDS>(act, a.lut, a.W));
+            r = m.r[s];
+            d = (m.f[s] >> GU_CELL_TERM_BIT) & 1;
+            a.pos[e] = s;
+            a.reward[e] = r;
+            a.done[e] = d;
         }
-        s = gu_move(s, m.f[s], act, gu_delta<LDS>(act, a.lut, a.W));
-        const int32_t r = m.r[s], d = (m.f[s] >> GU_CELL_TERM_BIT) & 1;
-        a.pos[e] = s;
-        a.reward[e] = r;
-        a.done[e] = d;
         // zero-copy host path (GU_F_PINNED_IO): results also go straight to the caller's page-locked buffers over PCIe
         if (a.host_obs) a.host_obs[e] = s;
         if (a.host_reward) a.host_reward[e] = r;
         if (a.host_done) a.host_done[e] = d;
     }
+    // episode-done compaction, first half: one 64-bit ballot word per wave (every workgroup size used is a multiple of 64)
+    const uint64_t bits = __ballot(d != 0);
+    if ((threadIdx.x & 63) == 0 && e < a.N) a.done_bits[e >> 6] = bits;
     if (a.host_seq) {
         // Completion word: the host spins on a sequence number in page-locked memory instead of going through the
         // runtime's completion path (no interrupt, no runtime call).  Every block makes its mirror stores visible to the
@@ -126,6 +158,16 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
             }
         }
     }
+}
+
+// Validation of a caller-supplied action stream on the device (gu_upload_actions): any value outside 0..3 raises the
+// page-locked error word.  Replaces a serial host loop over T x N values.
+__global__ void __launch_bounds__(256) gu_validate_actions_kernel(const int32_t *__restrict__ actions, int64_t count, uint32_t *host_err)
+{
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        bad |= (uint32_t)actions[i] > 3u;
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------
@@ -166,6 +208,7 @@ struct LookArgs {
     const int32_t *states, *actions;
     int32_t *next, *reward, *done;
     int64_t n;
+    uint32_t *host_err;  // page-locked error word: a state outside the grid or an action outside 0..3
 };
 
 template <bool LDS>
@@ -176,7 +219,12 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_lookahead_kernel(const LookArgs a
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     int32_t s = a.states[i];
-    const uint32_t act = (uint32_t)a.actions[i] & 3u;
+    const uint32_t raw = (uint32_t)a.actions[i];
+    if ((uint32_t)s >= (uint32_t)a.S || raw > 3u) {  // validated here instead of in a serial host loop
+        __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    const uint32_t act = raw;
     s = gu_move(s, m.f[s], act, gu_delta<LDS>(act, a.lut, a.W));
     a.next[i] = s;
     a.reward[i] = m.r[s];  // reward / terminal bits are identical in both maps
@@ -196,7 +244,8 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_done_ballot_kernel(const int32_t 
 }
 
 // One 1024-thread block: thread i owns a contiguous chunk of ballot words; exclusive scan of
-// the per-thread popcounts in LDS, then each thread expands its words in ascending order.
+// the per-thread popcounts in LDS, then each thread expands its words in ascending order.  idx / count point into the
+// engine's page-locked staging block: the list lands in host memory without a copy command.
 __global__ void __launch_bounds__(1024) gu_done_compact_kernel(const uint64_t *__restrict__ bits, int64_t n_words,
                                                                int32_t *__restrict__ idx, int32_t *__restrict__ count)
 {
@@ -232,7 +281,7 @@ __global__ void __launch_bounds__(1024) gu_done_compact_kernel(const uint64_t *_
 // ------------------------------------------------------------------------------------
 int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice, bool only_done)
 {
-    ResetArgs a{h->pos(), h->done(), h->d_episode, h->d_starts, d_mask, d_choice,
+    ResetArgs a{h->pos(), h->done(), h->d_episode, h->d_starts, d_mask, d_choice, h->d_done_bits,
                 (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, only_done ? 1 : 0, gu_grid_sel(h)};
     hipLaunchKernelGGL(gu_reset_kernel, dim3(gu_blocks(h->N, GU_BLOCK)), dim3(GU_BLOCK), 0, h->stream, a);
     GU_HIP(hipGetLastError());
@@ -240,11 +289,11 @@ int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice
 }
 
 int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, int32_t *host_obs, int32_t *host_reward,
-                   int32_t *host_done, uint32_t *host_seq, uint32_t seq)
+                   int32_t *host_done, uint32_t *host_seq, uint32_t seq, uint32_t *host_err)
 {
     StepArgs a{h->d_cell, h->cell_bytes, h->W, h->delta_lut, d_actions_row, h->pos(), h->reward(), h->done(),
-               h->d_episode, h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags,
-               gu_grid_sel(h), host_obs, host_reward, host_done, host_seq, seq, h->d_blocks_done};
+               h->d_episode, h->d_tcount, h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags,
+               gu_grid_sel(h), host_obs, host_reward, host_done, host_seq, seq, h->d_blocks_done, host_err, h->d_done_bits};
     const int lds_bs = gu_lds_block(h, GU_BLOCK, 2);
     if (lds_bs)
         hipLaunchKernelGGL(gu_step_kernel<true>, dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), 2 * (size_t)h->cell_bytes, h->stream, a);
@@ -282,6 +331,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.tr_done = h->d_traj ? h->d_traj + 2 * rows : nullptr;
     a.ret = h->d_ret;
     a.episodes_fin = h->d_episodes_fin;
+    a.done_bits = h->d_done_bits;
     a.n_starts = (uint32_t)h->n_starts;
     a.seed_prefix = h->seed_prefix;
     a.env_id0 = (uint32_t)h->env_id0;
@@ -308,7 +358,7 @@ int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const 
                         int32_t *d_next, int32_t *d_reward, int32_t *d_done)
 {
     LookArgs a{care ? h->d_cell : h->d_cell_raw, h->cell_bytes, h->W, h->S, h->delta_lut, d_states, d_actions,
-               d_next, d_reward, d_done, n};
+               d_next, d_reward, d_done, n, h->h_seq + GU_HOST_ERR_WORD};
     const dim3 grid(gu_blocks(n, GU_BLOCK)), block(GU_BLOCK);
     if (h->S <= GU_MAX_LDS_CELLS)
         hipLaunchKernelGGL(gu_lookahead_kernel<true>, grid, block, 2 * (size_t)h->cell_bytes, h->stream, a);
@@ -318,13 +368,26 @@ int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const 
     return GU_OK;
 }
 
+int gu_launch_validate_actions(gu_engine *h, const int32_t *d_actions, int64_t count)
+{
+    const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 4096);
+    hipLaunchKernelGGL(gu_validate_actions_kernel, dim3(blocks), dim3(256), 0, h->stream, d_actions, count, h->h_seq + GU_HOST_ERR_WORD);
+    GU_HIP(hipGetLastError());
+    return GU_OK;
+}
+
 int gu_launch_done_compact(gu_engine *h)
 {
     const int64_t n_words = (h->N + 63) / 64;
-    hipLaunchKernelGGL(gu_done_ballot_kernel, dim3(gu_blocks(h->N, GU_BLOCK)), dim3(GU_BLOCK), 0, h->stream,
-                       h->done(), h->N, h->d_done_bits);
+    // The ballot words are written by the step / rollout / reset kernels themselves; only a done[] installed from the
+    // host (gu_set_state) needs the separate ballot pass.
+    if (!h->done_bits_valid) {
+        hipLaunchKernelGGL(gu_done_ballot_kernel, dim3(gu_blocks(h->N, GU_BLOCK)), dim3(GU_BLOCK), 0, h->stream,
+                           h->done(), h->N, h->d_done_bits);
+        h->done_bits_valid = true;
+    }
     hipLaunchKernelGGL(gu_done_compact_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_done_bits, n_words,
-                       h->d_done_idx, h->d_done_count);
+                       h->h_pin, (int32_t *)(h->h_seq + GU_HOST_COUNT_WORD));
     GU_HIP(hipGetLastError());
     return GU_OK;
 }

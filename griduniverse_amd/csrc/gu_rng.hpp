@@ -1,7 +1,9 @@
 // gu_rng.hpp -- per-env counter RNG (device + host), gfx950.
 //
 // Specification: oracle/gu_rng.py (MurmurHash3_x86_32 over the four words
-// [seed_lo, seed_hi, global_env_id, (stream << 28) | counter], hash seed 0x9747B28C).
+// [seed_lo, seed_hi, global_env_id, (stream << 28) | (counter & 0x0FFFFFFF)], hash seed 0x9747B28C;
+// a counter of 2^28 or more appends a fifth word, counter >> 28, so the streams do not repeat
+// before 2^32 draws).
 // The reference has no per-env RNG (core/envs/griduniverse_env.py:64,189 use the
 // process-global stdlib RNG), so this is build-defined and
 // restated on the CPU by the oracle.
@@ -46,7 +48,12 @@ __host__ __device__ __forceinline__ uint32_t gu_rng_prefix(uint32_t seed_prefix,
 __host__ __device__ __forceinline__ uint32_t gu_rng_word(uint32_t prefix, uint32_t stream, uint32_t ctr)
 {
     uint32_t h = gu_mm3_block(prefix, (stream << 28) | (ctr & 0x0FFFFFFFu));
-    h ^= 16u;
+    uint32_t len = 16u;
+    if (ctr >> 28) {  // beyond 2^28 draws of one stream: the high counter bits are a fifth key word
+        h = gu_mm3_block(h, ctr >> 28);
+        len = 20u;
+    }
+    h ^= len;
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
     h ^= h >> 13;

@@ -30,6 +30,7 @@ struct RolloutArgs {
     const int32_t *actions;  // [T][N]
     int32_t *tr_obs, *tr_reward, *tr_done;  // [T][N] each
     int32_t *ret, *episodes_fin;
+    uint64_t *done_bits;  // [ceil(N/64)] wave ballots of the final done flags (episode-done compaction)
     uint32_t n_starts, seed_prefix, env_id0, steps_taken;
     int64_t N, T;
     GridSel gs;
@@ -274,6 +275,10 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
         a.ret[e] = ret;
         a.episodes_fin[e] = fin;
     }
+    // episode-done compaction, first half: the wave's done flags as one 64-bit word (lanes past N have left; every
+    // workgroup size used is a multiple of 64, so lane 0 of a wave holds its lowest env)
+    const uint64_t bits = __ballot(d != 0);
+    if ((threadIdx.x & 63) == 0) a.done_bits[e >> 6] = bits;
 }
 
 // ------------------------------------------------------------------------------------

@@ -369,6 +369,7 @@ struct ViStepArgs {
     uint32_t n_starts, seed_prefix, env_id0;
     int64_t N;
     uint32_t flags;
+    uint64_t *done_bits;  // [ceil(N/64)] wave ballots of the new done flags (episode-done compaction)
 };
 
 template <bool LDS>
@@ -397,24 +398,29 @@ __global__ void __launch_bounds__(VI_BLOCK) gu_vi_sweep_step_kernel(const ViStep
     if ((int64_t)blockIdx.x * blockDim.x < (int64_t)a.vi.S) vi_block_max_to_global(d, sweep, a.vi.delta_key);  // block-uniform branch
 
     // (2) agent gid acts greedily on the updated policy
-    if (gid >= a.N) return;
-    int32_t s = a.pos[gid];
-    if ((a.flags & GU_F_AUTO_RESET) && a.done[gid]) {
-        const uint32_t ep = a.episode[gid];
-        s = a.starts[gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)gid), ep, a.n_starts)];
-        a.episode[gid] = ep + 1;
-    }
-    double row[4];
-    vi_greedy_state(cell, W, gamma, vnew, s, row);
-    uint32_t act = 0;
-    double m = row[0];
+    int32_t dn = 0;
+    if (gid < a.N) {
+        int32_t s = a.pos[gid];
+        if ((a.flags & GU_F_AUTO_RESET) && a.done[gid]) {
+            const uint32_t ep = a.episode[gid];
+            s = a.starts[gu_rng_start_index(gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)gid), ep, a.n_starts)];
+            a.episode[gid] = ep + 1;
+        }
+        double row[4];
+        vi_greedy_state(cell, W, gamma, vnew, s, row);
+        uint32_t act = 0;
+        double m = row[0];
 #pragma unroll
-    for (uint32_t k = 1; k < 4; ++k)
-        if (row[k] > m) { m = row[k]; act = k; }
-    s = vi_next(s, cell.f[s], act, W);
-    a.pos[gid] = s;
-    a.reward[gid] = cell.r[s];
-    a.done[gid] = (cell.f[s] >> GU_CELL_TERM_BIT) & 1;
+        for (uint32_t k = 1; k < 4; ++k)
+            if (row[k] > m) { m = row[k]; act = k; }
+        s = vi_next(s, cell.f[s], act, W);
+        dn = (cell.f[s] >> GU_CELL_TERM_BIT) & 1;
+        a.pos[gid] = s;
+        a.reward[gid] = cell.r[s];
+        a.done[gid] = dn;
+    }
+    const uint64_t bits = __ballot(dn != 0);
+    if ((threadIdx.x & 63) == 0 && gid < a.N) a.done_bits[gid >> 6] = bits;
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -758,6 +764,7 @@ int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta)
     a.env_id0 = (uint32_t)h->env_id0;
     a.N = h->N;
     a.flags = flags;
+    a.done_bits = h->d_done_bits;
     const int64_t threads = h->N > h->S ? h->N : h->S;
     const dim3 grid(vi_blocks(threads)), block(VI_BLOCK);
     if (h->S <= GU_MAX_LDS_CELLS)

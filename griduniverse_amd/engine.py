@@ -99,7 +99,9 @@ class Engine(object):
         """(flags uint8[S], reward int8[S], starts int32[n]) of one grid as compiled on the device."""
         S = self.spec.S
         flags, reward = np.empty(S, np.uint8), np.empty(S, np.int8)
-        starts, n = np.empty(max(S, 1), np.int32), ctypes.c_int32(0)
+        n = ctypes.c_int32(0)
+        check(self.lib.gu_get_cells(self._h, int(grid_index), None, None, None, ctypes.byref(n)))
+        starts = np.empty(max(n.value, 1), np.int32)  # a start list may repeat cells and be longer than the grid
         check(self.lib.gu_get_cells(self._h, int(grid_index), ptr(flags), ptr(reward), ptr(starts), ctypes.byref(n)))
         return flags, reward, starts[:n.value].copy()
 
@@ -328,6 +330,16 @@ class Engine(object):
         ms = ctypes.c_float(0.0)
         check(self.lib.gu_timer_end(self._h, ctypes.byref(ms)))
         return ms.value
+
+    def timer_mark(self):
+        check(self.lib.gu_timer_mark(self._h))
+
+    def timer_laps(self, max_laps=65536):
+        """Milliseconds between consecutive timer_mark() events (waits for the last one)."""
+        ms = np.empty(int(max_laps), np.float32)
+        n = ctypes.c_int32(0)
+        check(self.lib.gu_timer_laps(self._h, ptr(ms), int(max_laps), ctypes.byref(n)))
+        return ms[:n.value].astype(np.float64)
 
     # ------------------------------------------------------------------ RCCL gathered view
     @staticmethod

@@ -5,10 +5,13 @@ reference class (core/envs/griduniverse_env.py:14-321), so 
 tabular-RL drivers of examples/griduniverse_alg_examples.py run on it unchanged.
 What differs is WHERE the transition runs: grid description, level loading, maze
 generation and ASCII rendering are host Python (they run once per grid / per frame),
-while `step()` / `reset()` / `look_step_ahead()` execute on the MI355X through
-libgu.so -- this class is the N = 1 facade of the batched engine (see `vec_env.py`
+while the transition itself is computed on the MI355X through libgu.so: the first
+`step()` / `look_step_ahead()` on a grid has the look-ahead kernel evaluate all S x 4
+(state, action) pairs, and scalar calls then index that table (a launch per scalar
+call would cost ~12 us for ~10 integer operations); `step_on_device()` runs the step
+kernel itself.  This class is the N = 1 facade of the batched engine (see `vec_env.py`
 for the N >> 1 API the engine is built for).  There is no CPU fallback: without the
-library or a GPU those three methods raise `GuError`.
+library or a GPU `step` / `look_step_ahead` raise `GuError`.
 
 Old-gym dispatch (public `step` -> `_step` ...) is flattened: the public names are the
 implementation and the underscore names are aliases.
@@ -57,6 +60,7 @@ class GridUniverseEnv(object):
 
         self._engine_obj = None
         self._tables = {}
+        self._step_tab = None
         self._device = device
         self._pos_dirty = True
 
@@ -134,7 +138,15 @@ class GridUniverseEnv(object):
         if batch is not None:
             batch[1].close()
         self._tables = {}
+        self._step_tab = None
         self._pos_dirty = True
+
+    def invalidate(self):
+        """Call after mutating goal_states / lava_states / wall_grid / reward_matrix / starting_states IN PLACE: the
+        grid is compiled into the engine (and the transition table cached) when first needed, so -- unlike the
+        reference, which re-reads those attributes on every step -- later edits are not seen until this is called.
+        (The constructor, the level loader and the maze generator call it themselves.)"""
+        self._drop_engine()
 
     def _engine(self):
         if self._engine_obj is None:
@@ -190,8 +202,33 @@ class GridUniverseEnv(object):
     def is_terminal(self, state):
         return self.is_lava(state) or self.is_terminal_goal(state)
 
+    def _build_step_tab(self):
+        """The N = 1 hot path: the (state, action) -> (next, reward, done) table that the HIP kernel gu_lookahead_kernel
+        produced for this grid (one launch for all S x 4 pairs, `_transition_table`), unpacked into plain Python rows.
+        A scalar `step()` is then two list indexings -- ~0.3 us -- instead of a kernel launch plus a PCIe round trip
+        (~12 us) for ~10 integer operations; batches step on the device (`VecGridUniverse`)."""
+        nxt, rew, don = self._transition_table(True)
+        self._step_tab = (nxt.tolist(), [list(row) for row in rew], don.tolist(), [self.world[i] for i in range(self.world.size)])
+        return self._step_tab
+
     def step(self, action):
-        """One env-step on the device (kernel gu_step_kernel via gu_step)."""
+        """One env-step (env:176-185): a lookup in the transition table computed on the device for this grid."""
+        tab = self._step_tab or self._build_step_tab()
+        state = self._state
+        nxt = tab[0][state][action]  # a 4-element list, like env:148: -4..-1 wrap, anything else is IndexError (quirk 6)
+        self.previous_state = state
+        self._state = nxt
+        self._pos_dirty = True
+        done = self.done = tab[2][state][action]
+        trail = self.last_n_states
+        trail.append(tab[3][nxt])
+        if len(trail) > self.num_previous_states_to_store:
+            trail.pop(0)
+        return nxt, tab[1][state][action], done, self.info
+
+    def step_on_device(self, action):
+        """The same step executed by gu_step_kernel on the engine's N = 1 batch (kernel launch + page-locked I/O);
+        kept for parity tests of the kernel path through the facade."""
         if not -4 <= action < 4:
             raise IndexError('list index out of range')
         eng = self._engine_obj or self._engine()

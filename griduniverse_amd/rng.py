@@ -3,7 +3,8 @@
 The reference has no per-env RNG (it draws from process-global RNGs), so the engine defines
 one, keyed by (seed, GLOBAL env id, stream, counter):
 
-    word = MurmurHash3_x86_32 over the words [seed_lo, seed_hi, env, (stream << 28) | counter], hash seed 0x9747B28C
+    word = MurmurHash3_x86_32 over the words [seed_lo, seed_hi, env, (stream << 28) | (counter & 0x0FFFFFFF)], hash seed
+           0x9747B28C; counters of 2**28 and more append a fifth word, counter >> 28 (no stream repeats before 2**32 draws)
     stream 0  uniform actions : action(t) = (word(t >> 4) >> (2 * (t & 15))) & 3, t = steps the env has taken
     stream 1  start cell      : index = (word(episode) * n_starts) >> 32, episode = resets since gu_seed
     stream 2  sampled actions : u = word(t) / 2**32 against the cumulative policy row
@@ -33,12 +34,14 @@ def words(seed, env_ids, stream, counters):
     """uint32 RNG words for broadcastable arrays of global env ids and counters."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     env = np.asarray(env_ids, dtype=np.uint64) & _M32
-    ctr = np.asarray(counters, dtype=np.uint64) & np.uint64(0x0FFFFFFF)
+    ctr = np.asarray(counters, dtype=np.uint64) & _M32
     env, ctr = np.broadcast_arrays(env, ctr)
     h = np.full(env.shape, 0x9747B28C, dtype=np.uint64)
-    for k in (np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32), env, np.uint64((int(stream) & 0xF) << 28) | ctr):
+    for k in (np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32), env,
+              np.uint64((int(stream) & 0xF) << 28) | (ctr & np.uint64(0x0FFFFFFF))):
         h = _block(h, k)
-    h = h ^ np.uint64(16)
+    high = ctr >> np.uint64(28)
+    h = np.where(high != 0, _block(h, high) ^ np.uint64(20), h ^ np.uint64(16))
     h = h ^ (h >> np.uint64(16))
     h = (h * np.uint64(0x85EBCA6B)) & _M32
     h = h ^ (h >> np.uint64(13))

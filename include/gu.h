@@ -21,7 +21,9 @@
  *     contiguous int32[3N] block, so the gathered view is one collective),
  *     episode[N], tcount[N] (uint32).  Actions are 0..3 = UP,RIGHT,DOWN,LEFT
  *     (env:56); anything else is rejected (the reference's negative-index quirk is
- *     not part of the contract).
+ *     not part of the contract).  Caller-supplied actions and
+ *     states are validated by the kernels that consume them (an error word in
+ *     page-locked memory), not by host loops.
  */
 #ifndef GU_H
 #define GU_H
@@ -66,6 +68,8 @@ typedef struct gu_engine *gu_handle;
 int gu_version(void);                         /* GU_ABI_VERSION */
 int gu_last_error(char *buf, size_t len);     /* copies the thread's last message, returns its length */
 int gu_device_count(int *count);              /* hipGetDeviceCount */
+int gu_source_hash(char *buf, size_t len);    /* 16 hex digits identifying the sources the library was built from
+                                                 (sha256 over every .hip / .hpp under csrc and include/gu.h); returns the length */
 
 /* ---- lifetime ----------------------------------------------------------------
  * One engine = `num_envs` lock-stepped instances of one grid on device `device_id`;
@@ -86,6 +90,7 @@ int gu_destroy(gu_handle h);
  *       separate planes because the reference's reward matrix and terminal test
  *       can disagree (negative indices wrap only in the former; quirk 5).
  *   starts     : starting_states (env:61-63), n_starts >= 1.
+ * W * H <= 2^30 cells and W <= 8 388 607 columns (GU_ERR_UNSUPPORTED beyond: the move is a 24-bit multiply-add).
  * The library compiles the planes into two bytes per cell -- flags (per action: does the
  * move change the position, incl. the absorbing-terminal rule; terminal bit; reward code;
  * wall bit) and the int8 reward -- which the kernels stage in LDS (gu_get_cells reads
@@ -116,8 +121,9 @@ int gu_get_cells(gu_handle h, int32_t grid_index, uint8_t *flags, int8_t *reward
 
 /* ---- RNG ---------------------------------------------------------------------
  * Keys the per-env counter RNG (MurmurHash3 of seed, global env id, stream,
- * counter; host view: griduniverse_amd/rng.py, restated for the tests in
- * oracle/gu_rng.py) and zeroes episode[] and tcount[].
+ * counter -- 32-bit counters, no stream repeats before 2^32 draws; host view:
+ * griduniverse_amd/rng.py, restated for the tests in oracle/gu_rng.py) and zeroes
+ * episode[] and tcount[].
  * The reference has no per-env RNG (env:242-244 stores one and never uses it). */
 int gu_seed(gu_handle h, uint64_t seed);
 
@@ -137,11 +143,18 @@ int gu_reset_done(gu_handle h);
  * library's own page-locked staging block, plus one memcpy each way).  Batches of up to
  * 8192 envs return as soon as the kernel has published a completion word in page-locked
  * memory -- the results are in place, the stream may still be draining; every later call on
- * the handle is ordered behind it as usual. */
+ * the handle is ordered behind it as usual.
+ * An action outside 0..3 is detected BY THE KERNEL (env:148 raises IndexError before it touches the
+ * instance): that env does not step -- position, reward, done flag, pending lazy reset and step
+ * count stay as they were, its outputs repeat its current state -- every env with a valid action
+ * steps, and the call returns GU_ERR_INVALID naming the first offender.
+ * With GU_F_PINNED_IO every pointer is checked (once per allocation) to be page-locked host memory;
+ * pageable memory is GU_ERR_INVALID, not a GPU fault. */
 int gu_step(gu_handle h, const int32_t *actions, uint32_t flags,
             int32_t *obs, int32_t *reward, int32_t *done);
 
-/* Device-resident action stream [T][N] for gu_step_device / GU_POLICY_STREAM. */
+/* Device-resident action stream [T][N] for gu_step_device / GU_POLICY_STREAM.  Values are validated on the
+ * device after the copy; a stream holding anything outside 0..3 is rejected as a whole (GU_ERR_INVALID). */
 int gu_upload_actions(gu_handle h, const int32_t *actions, int64_t T);
 /* One step with actions row `t` of the uploaded stream; results stay in HBM (async). */
 int gu_step_device(gu_handle h, int64_t t, uint32_t flags);
@@ -166,8 +179,11 @@ int gu_read_stats(gu_handle h, int64_t *reward_sum, int32_t *episodes);
 int gu_get_state(gu_handle h, int32_t *pos, int32_t *done, uint32_t *episode, uint32_t *tcount);
 int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uint32_t *episode, const uint32_t *tcount);
 
-/* Ascending indices of envs whose done flag is set (wave-ballot masks written by the
- * step kernels + one compaction kernel).  idx has room for N entries. */
+/* Ascending indices of envs whose done flag is set.  Every kernel that writes done[] (step, rollout, reset,
+ * sweep-step) also writes its waves' 64-bit ballot of the new flags -- 8 KB at 65 536 envs -- so this call is ONE
+ * launch: a single-workgroup scan + expansion of those words straight into page-locked memory (only a done[]
+ * installed with gu_set_state needs a ballot pass first).  Batched form of the harness's `if done: env.reset()`
+ * bookkeeping (core/algorithms/monte_carlo.py:19-25).  idx has room for N entries. */
 int gu_done_indices(gu_handle h, int32_t *idx, int32_t *count);
 
 /* ---- look_step_ahead table queries: env:136-155 for n (state, action) pairs (grid 0 of a multi-grid engine) ---- */
@@ -243,6 +259,11 @@ int gu_host_free(void *ptr);
 int gu_sync(gu_handle h);
 int gu_timer_begin(gu_handle h);
 int gu_timer_end(gu_handle h, float *milliseconds); /* records, waits, returns elapsed */
+/* Lap timing: gu_timer_mark records one event on the stream per call (async); gu_timer_laps waits for the last mark,
+ * writes the count-1 intervals between consecutive marks (capacity = room in `milliseconds`, which may be NULL to
+ * discard) and forgets the marks. */
+int gu_timer_mark(gu_handle h);
+int gu_timer_laps(gu_handle h, float *milliseconds, int32_t capacity, int32_t *count);
 
 /* ---- multi-GPU gathered view (RCCL over xGMI) ----------------------------------
  * One process per GPU.  Rank 0 calls gu_comm_unique_id and ships the 128 bytes to

@@ -53,7 +53,12 @@ uint32_t gu_oracle_rng_word(uint64_t seed, uint32_t env, uint32_t stream, uint32
     h = mm3_block(h, (uint32_t)(seed >> 32));
     h = mm3_block(h, env);
     h = mm3_block(h, ((stream & 0xFu) << 28) | (ctr & 0x0FFFFFFFu));
-    h ^= 16u;
+    if (ctr >> 28) {   /* counters of 2^28 and more: fifth key word, hashed length 20 (oracle/gu_rng.py) */
+        h = mm3_block(h, ctr >> 28);
+        h ^= 20u;
+    } else {
+        h ^= 16u;
+    }
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }

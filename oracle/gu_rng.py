@@ -8,8 +8,10 @@ A batched engine needs a stream per env that does not depend on how the batch
 is sharded, so the build defines one and this file is its specification:
 
     word(seed, env, stream, ctr) = MurmurHash3_x86_32 over the four 32-bit
-        little-endian words [seed_lo, seed_hi, env, (stream << 28) | ctr]
-        with hash seed 0x9747B28C   (Appleby's public-domain algorithm)
+        little-endian words [seed_lo, seed_hi, env, (stream << 28) | (ctr & 0x0FFFFFFF)]
+        with hash seed 0x9747B28C   (Appleby's public-domain algorithm); when ctr >= 2**28 a
+        fifth word, ctr >> 28, is appended (hashed length 20 instead of 16 bytes), so no
+        stream repeats before 2**32 draws
 
     action(seed, env, t)      = (word(seed, env, 0, t >> 4) >> (2 * (t & 15))) & 3
     start_index(seed, env, e) = (word(seed, env, 1, e) * n_starts) >> 32
@@ -57,13 +59,18 @@ def _fmix(h):
 
 
 def word(seed, env, stream, ctr):
-    """Scalar 32-bit output for (seed:uint64, env:uint32, stream:0..15, ctr:<2^28)."""
+    """Scalar 32-bit output for (seed:uint64, env:uint32, stream:0..15, ctr:uint32)."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    ctr = int(ctr) & M32
     h = H0
     for k in (seed & M32, seed >> 32, int(env) & M32,
-              ((int(stream) & 0xF) << 28) | (int(ctr) & CTR_MASK)):
+              ((int(stream) & 0xF) << 28) | (ctr & CTR_MASK)):
         h = _block(h, k)
-    h ^= 16  # length in bytes
+    length = 16  # bytes hashed
+    if ctr >> 28:
+        h = _block(h, ctr >> 28)
+        length = 20
+    h ^= length
     return _fmix(h)
 
 
@@ -110,14 +117,15 @@ def word_v(seed, env, stream, ctr):
     """Vectorised `word`: env and ctr broadcast; returns uint32 array."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     env = np.asarray(env, dtype=np.uint64) & np.uint64(M32)
-    ctr = np.asarray(ctr, dtype=np.uint64) & np.uint64(CTR_MASK)
+    ctr = np.asarray(ctr, dtype=np.uint64) & np.uint64(M32)
     env, ctr = np.broadcast_arrays(env, ctr)
     h = np.full(env.shape, H0, dtype=np.uint64)
     h = _vblock(h, np.uint64(seed & M32))
     h = _vblock(h, np.uint64(seed >> 32))
     h = _vblock(h, env)
-    h = _vblock(h, (np.uint64((int(stream) & 0xF) << 28)) | ctr)
-    h = h ^ np.uint64(16)
+    h = _vblock(h, (np.uint64((int(stream) & 0xF) << 28)) | (ctr & np.uint64(CTR_MASK)))
+    high = ctr >> np.uint64(28)
+    h = np.where(high != 0, _vblock(h, high) ^ np.uint64(20), h ^ np.uint64(16))
     return _vfmix(h).astype(np.uint32)
 
 

@@ -18,7 +18,7 @@ def _native_pieces_are_built():
     if a checkout arrives without them, build them once before any test needs them.  This is test plumbing: the
     product itself never builds or falls back -- it raises GuError when the library is missing."""
     from griduniverse_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
+    if _lib.is_stale():  # missing, or built from sources other than the ones on disk
         _lib.build()
     from oracle import c_oracle
     c_oracle.build()

@@ -213,3 +213,5 @@ def test_product_rng_module_matches_the_specification():
         for ep in (0, 3, 2 ** 28 - 1):
             assert np.array_equal(rng.start_indices(seed, ids, ep, 7), gu_rng.start_index_v(seed, ids, ep, 7))
         assert np.array_equal(rng.words(seed, ids, 3, 9), gu_rng.word_v(seed, ids, 3, 9))
+        big = np.arange(ids.size, dtype=np.uint64) * np.uint64(2 ** 27 + 11)  # counters on both sides of 2^28
+        assert np.array_equal(rng.words(seed, ids, 2, big), gu_rng.word_v(seed, ids, 2, big))

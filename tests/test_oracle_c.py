@@ -35,6 +35,49 @@ def test_rng_c_equals_python():
     assert lib.gu_oracle_rng_word(2 ** 64 - 1, 2 ** 32 - 1, 15, 2 ** 28 - 1) == gu_rng.word(2 ** 64 - 1, 2 ** 32 - 1, 15, 2 ** 28 - 1)
 
 
+def _murmur3_x86_32(data, seed):
+    """Byte-oriented MurmurHash3_x86_32 as published (Appleby, public domain), written independently of oracle/gu_rng.py."""
+    M = 0xFFFFFFFF
+    h, n = seed & M, len(data)
+    rot = lambda x, r: ((x << r) | (x >> (32 - r))) & M  # noqa: E731
+    for i in range(0, n - n % 4, 4):
+        k = int.from_bytes(data[i:i + 4], 'little')
+        k = rot((k * 0xCC9E2D51) & M, 15) * 0x1B873593 & M
+        h = (rot(h ^ k, 13) * 5 + 0xE6546B64) & M
+    if n % 4:
+        k = int.from_bytes(data[n - n % 4:], 'little')
+        h ^= rot((k * 0xCC9E2D51) & M, 15) * 0x1B873593 & M
+    h ^= n
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & M
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & M
+    return h ^ (h >> 16)
+
+
+def test_rng_is_murmurhash3_incl_counters_beyond_2_pow_28():
+    # published known answers of MurmurHash3_x86_32
+    for data, seed, want in ((b'', 0, 0), (b'', 1, 0x514E28B7), (b'', 0xFFFFFFFF, 0x81F16F39), (b'\xff\xff\xff\xff', 0, 0x76293B50),
+                             (b'\x21\x43\x65\x87', 0, 0xF55B516B), (b'\x21\x43\x65\x87', 0x5082EDEE, 0x2362F9DE),
+                             (b'\x21\x43\x65', 0, 0x7E4A8634), (b'\x21\x43', 0, 0xA0F7B07A), (b'\x21', 0, 0x72661CF4),
+                             (b'\0\0\0\0', 0, 0x2362F9DE), (b'\0\0\0', 0, 0x85F0B427), (b'\0\0', 0, 0x30F4C306), (b'\0', 0, 0x514E28B7),
+                             (b'Hello, world!', 0x9747B28C, 0x24884CBA),
+                             (b'The quick brown fox jumps over the lazy dog', 0x9747B28C, 0x2FA826CD)):
+        assert _murmur3_x86_32(data, seed) == want, (data, seed)
+    lib = C.lib()
+    rs = np.random.RandomState(5)
+    for i in range(200):
+        seed = int(rs.randint(0, 2 ** 63 - 1)) * 2 + 1
+        env, stream = int(rs.randint(0, 2 ** 32, dtype=np.uint64)), int(rs.randint(0, 4))
+        ctr = int(rs.randint(0, 2 ** 32, dtype=np.uint64)) if i % 2 else int(rs.randint(0, 2 ** 28))
+        words = [seed & 0xFFFFFFFF, seed >> 32, env, (stream << 28) | (ctr & 0x0FFFFFFF)] + ([ctr >> 28] if ctr >> 28 else [])
+        want = _murmur3_x86_32(b''.join(w.to_bytes(4, 'little') for w in words), 0x9747B28C)
+        assert gu_rng.word(seed, env, stream, ctr) == want == lib.gu_oracle_rng_word(seed, env, stream, ctr)
+        assert int(gu_rng.word_v(seed, [env], stream, [ctr])[0]) == want
+    # the sampled-action stream no longer repeats after 2^28 steps
+    assert gu_rng.word(7, 3, 2, 5) != gu_rng.word(7, 3, 2, 5 + 2 ** 28) != gu_rng.word(7, 3, 2, 5 + 2 ** 29)
+
+
 @pytest.mark.parametrize('name', G.traj_names())
 def test_trajectories_c_oracle(name):
     meta, z = G.load_traj(name)

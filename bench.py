@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the fused rollout kernel on N MI355X (one process per GPU).
 
-    python bench.py                       # 1 GPU, defaults finish in well under a minute
+    python bench.py                       # 1 GPU, defaults finish in about a minute
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One bench "step" = ONE launch of the hot path over the whole batch: `gu_rollout` advancing
-every env by T env-steps (uniform random actions from the per-env device RNG, harness
-auto-reset, int32 (obs, reward, done) trajectory written to HBM).  Workload = BASELINE.json
-config 3, the one the metric is quoted on: 65 536 envs per GPU on the 32x32 generator maze
-(seed 123).  Weak scaling: every rank owns 65 536 envs, global env ids rank*65536.. (RNG
-streams are keyed by global id); the data path has no collective.  Inputs (grid, state) are
-resident in HBM before the timed region; nothing returns to the host inside it.
+One bench "step" = ONE launch of the hot path over the whole batch: `gu_rollout` advancing every env by T env-steps
+(uniform random actions from the per-env device RNG, harness auto-reset, int32 (obs, reward, done) trajectory written to
+HBM).  Workload = BASELINE.json config 3, the one the metric is quoted on: 65 536 envs per GPU on the 32x32 generator maze
+(seed 123).  Weak scaling: every rank owns 65 536 envs, global env ids rank*65536.. (RNG streams are keyed by global id);
+the data path has no collective.  Inputs (grid, state) are resident in HBM before the timed region; nothing returns to
+the host inside it.
 
-Timing: W untimed launches, barrier + device sync, K timed launches, device sync + barrier;
-wall time per rank, MAX over ranks.  The kernel's own duration is measured with HIP events on
-the engine's stream (gu_timer_begin/end) over the same K launches -> roofline.achieved.
+Timing.  W untimed launches, then BLOCKS of exactly K launches, each block bracketed by barrier + device sync on both
+sides, repeated until at least --min-seconds (0.5 s) of timed launches have run.  Per block: wall time (MAX over ranks)
+and the kernels' own duration from HIP events on the engine's stream (gu_timer_begin/end).  `ms_per_step` / `value` are
+the MEDIAN block; the spread is reported next to them.  roofline.achieved = algorithmic bytes per launch / (median block's
+HIP-event time / K).
+
+Checks in the same run (rank 0): the FIRST launch is hashed in full and compared with the sha256 the REFERENCE produced
+for exactly this run (tests/golden/digests.json, 65.5 M steps of the reference's own step()); after the timed region the
+final (pos, done, episode, step count) of a sample of envs is compared with the C oracle advanced by every step launched.
+
+N > 1: after the timed region the RCCL gathered view runs once and is checked against every rank's own shard ("rccl"),
+and config 4 -- 262 144 envs on the lava grid in total, split over the ranks -- is timed as a strong-scaling line
+("strong_c4"), its result checked against the C oracle on every rank (and, on one GPU, against the reference digest).
 """
 import argparse
+import hashlib
 import json
 import os
 import random
@@ -36,6 +46,9 @@ from griduniverse_amd import _lib  # noqa: E402
 METRIC = 'env-steps/sec at N_envs on 32×32 grid, 1/2/4/8 MI355X; bit-exact vs CPU'
 BYTES_PER_ENV_STEP = 12       # fused rollout writing the int32 (obs, reward, done) trajectory
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+C4_TOTAL_ENVS = 262144        # BASELINE.json config 4
+WORKLOAD_SEED = {'c2': 2, 'c3': 123, 'c4': 4}
+REFERENCE_DIGEST = {'c2': 'c2_open8x8_4096x1000', 'c3': 'c3_maze32_65536x1000', 'c4': 'c4_lava32_262144x250'}
 
 
 def build_workload(name):
@@ -53,13 +66,14 @@ def build_workload(name):
     raise SystemExit('unknown workload ' + name)
 
 
-def cpu_baseline(template, seed, T, gpu_rows, budget_s=12.0):
-    """The ONLY place bench.py touches oracle/: (1) times the per-instance pure-Python restatement of
-    the reference's step loop (same operation structure as core/envs/griduniverse_env.py:136-185; the
-    reference itself cannot travel to the GPU box) on one host core, (2) times the scalar C oracle,
-    and (3) uses the C oracle as the checker for the first envs of the GPU's first timed launch."""
+# --------------------------------------------------------------------------------------- CPU baseline leg (oracle/)
+def cpu_baseline(template, seed, T, budget_s=12.0):
+    """The per-instance pure-Python restatement of the reference's step loop (same operation structure as
+    core/envs/griduniverse_env.py:136-185; the reference itself cannot travel to the GPU box) on one host core, plus two
+    stronger CPU baselines: the vectorised-numpy restatement and the scalar C oracle."""
     from oracle import c_oracle as C
     from oracle import gu_rng
+    from oracle.np_env import NumpyBatchEnv
     from oracle.ref_env import OracleGridUniverseEnv
 
     n_inst = 64
@@ -82,22 +96,33 @@ def cpu_baseline(template, seed, T, gpu_rows, budget_s=12.0):
         steps += chunk * n_inst
     py_rate = steps / (time.perf_counter() - t0)
 
+    n_np, t_np = 16384, 0
+    batch = NumpyBatchEnv.from_env(template, n_np, seed)
+    batch.reset()
+    acts = gu_rng.action_stream(seed, range(n_np), 0, 64)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 3.0:
+        for t in range(64):
+            batch.step(acts[t], auto_reset=True)
+        t_np += 64
+    np_rate = n_np * t_np / (time.perf_counter() - t0)
+
     grid = C.Grid.from_env(template)
     n_c = 4096
     st = C.State(n_c)
     C.reset(grid, seed, st)
     t0 = time.perf_counter()
-    want = C.rollout(grid, seed, st, T, True)
+    C.rollout(grid, seed, st, T, True, trajectory=False)
     c_rate = n_c * T / (time.perf_counter() - t0)
-    exact = None
-    if gpu_rows is not None:
-        exact = all(np.array_equal(gpu_rows[k], want[k][:, :gpu_rows[k].shape[1]]) for k in ('obs', 'reward', 'done'))
     return dict(value=py_rate, unit='env-steps/s', cores=1, kind='port',
                 sample='%d per-instance Python envs (oracle/ref_env.py) stepped round-robin with reset-on-done for '
                        '%.0f s on one core, same grid and action stream as the GPU run; this port runs at 1.02x the real reference '
                        'step() on a common host (BASELINE.md, tests/golden/calibrate_cpu.py)' % (n_inst, budget_s),
+                numpy_vectorised_value=np_rate,
+                numpy_vectorised_sample='%d envs stepped as arrays (oracle/np_env.py: the reference\'s tests on numpy arrays, no '
+                                        'precomputed table) for 3 s, 1 core' % n_np,
                 c_oracle_value=c_rate, c_oracle_sample='%d envs x %d steps, scalar C (oracle/gu_oracle.c), 1 core' % (n_c, T),
-                host_cpu_count=os.cpu_count(), host_usable_cores=_usable_cores(), host_cpu_model=_cpu_model()), exact
+                host_cpu_count=os.cpu_count(), host_usable_cores=_usable_cores(), host_cpu_model=_cpu_model())
 
 
 def _usable_cores():
@@ -174,6 +199,158 @@ def cpu_baseline_all_cores(template, seed, seconds=4.0):
                 sample='%d forked processes x %d per-instance Python envs for %.0f s each' % (cores, n_inst, seconds))
 
 
+# --------------------------------------------------------------------------------------- checks (oracle/ as the checker)
+def sha256_triplet(traj):
+    """sha256 over obs | reward | done, each int32 little-endian [T, N] -- tests/golden/make_golden.py: digest()."""
+    h = hashlib.sha256()
+    for k in ('obs', 'reward', 'done'):
+        h.update(np.ascontiguousarray(traj[k], dtype='<i4').tobytes())
+    return h.hexdigest()
+
+
+def reference_digest(workload, template, seed, N, T, env_id0):
+    """The sha256 the REFERENCE's own step() produced for this very run, if this run is the one that was captured
+    (tests/golden/digests.json: same grid, seed, batch, length, env ids 0..N-1, from reset, auto-reset)."""
+    try:
+        entry = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'digests.json')))[REFERENCE_DIGEST[workload]]
+    except (OSError, KeyError, ValueError):
+        return None
+    same = (env_id0 == 0 and entry['N'] == N and entry['T'] == T and entry['seed'] == seed and entry['auto_reset']
+            and (entry['W'], entry['H']) == (template.x_max, template.y_max)
+            and entry['starts'] == [int(s) for s in template.starting_states]
+            and entry['goals'] == [int(s) for s in template.goal_states]
+            and entry['lava'] == [int(s) for s in template.lava_states]
+            and entry['walls'] == [int(s) for s in template.wall_indices])
+    return entry['sha256'] if same else None
+
+
+def oracle_prefix_equal(template, seed, env_id0, traj, n_check=4096):
+    """First `n_check` envs of a from-reset launch against the C oracle (used when no reference digest covers the run)."""
+    from oracle import c_oracle as C
+    T, N = traj['obs'].shape
+    n = min(n_check, N)
+    grid = C.Grid.from_env(template)
+    st = C.State(n, env_id0)
+    C.reset(grid, seed, st)
+    want = C.rollout(grid, seed, st, T, True)
+    return all(np.array_equal(traj[k][:, :n], want[k]) for k in ('obs', 'reward', 'done'))
+
+
+def final_state_vs_oracle(template, seed, env_id0, N, total_steps, state, budget_steps=4.0e8):
+    """After ALL launches of the run (checked one, warm-up, probe, timed, instrumented): the final pos / done / episode /
+    step count of a sample of envs -- the first and the last ones of the shard -- against the C oracle advanced by the same
+    number of steps.  The whole batch would take the scalar oracle about an hour; the sample is sized to seconds."""
+    from oracle import c_oracle as C
+    per_block = int(max(1, min(N // 2, budget_steps // max(1, total_steps) // 2)))
+    grid = C.Grid.from_env(template)
+    ok, checked = True, 0
+    for lo in sorted({0, N - per_block}):
+        st = C.State(per_block, env_id0 + lo)
+        C.reset(grid, seed, st)
+        C.rollout(grid, seed, st, total_steps, True, trajectory=False)
+        sl = slice(lo, lo + per_block)
+        ok = ok and all(np.array_equal(state[k][sl], getattr(st, k)) for k in ('pos', 'done', 'episode', 'tcount'))
+        checked += per_block
+    return dict(equal=bool(ok), envs_checked=checked, env_steps_each=int(total_steps),
+                fields='pos, done, episode, tcount', checker='oracle/gu_oracle.c')
+
+
+# --------------------------------------------------------------------------------------- timing
+class Ranks(object):
+    """torch.distributed (gloo, CPU tensors) as rendezvous / barrier / reduction plumbing; a no-op for one process."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.dist = rank, world, None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if not dist.is_initialized():
+                dist.init_process_group('gloo', rank=rank, world_size=world)
+                self.owns = True
+            else:
+                self.owns = False
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def reduce(self, values, op):
+        """Element-wise MAX / MIN over ranks of a list of floats."""
+        if self.dist is None:
+            return [float(v) for v in values]
+        import torch
+        t = torch.tensor(list(values), dtype=torch.float64)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return [float(v) for v in t]
+
+    def gather(self, values):
+        """[world][len] of every rank's list of floats."""
+        if self.dist is None:
+            return [[float(v) for v in values]]
+        import torch
+        mine = torch.tensor(list(values), dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(every, mine)
+        return [[float(v) for v in t] for t in every]
+
+    def gather_bytes(self, payload):
+        if self.dist is None:
+            return [payload]
+        import torch
+        mine = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(every, mine)
+        return [bytes(t.numpy().tobytes()) for t in every]
+
+    def broadcast_bytes(self, payload, src=0):
+        if self.dist is None:
+            return payload
+        import torch
+        buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+        self.dist.broadcast(buf, src=src)
+        return bytes(buf.numpy().tobytes())
+
+    def close(self):
+        if self.dist is not None and self.owns:
+            self.dist.destroy_process_group()
+
+
+def timed_block(eng, ranks, T, K):
+    """EXACTLY K launches between barrier + device sync pairs.  Returns (wall seconds, HIP-event ms) of this rank."""
+    eng.sync()
+    ranks.barrier()
+    t0 = time.perf_counter()
+    eng.timer_begin()
+    for _ in range(K):
+        eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
+    kernel_ms = eng.timer_end()  # HIP events on the engine's stream; also drains it
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    ranks.barrier()
+    return elapsed, kernel_ms
+
+
+def timed_region(eng, ranks, T, K, min_seconds, max_blocks=4000):
+    """One untimed probe block sizes the region (identically on every rank: its time is max-reduced), then B timed blocks.
+    Returns per-block wall seconds and HIP-event ms (each MAX over ranks), this rank's own per-block wall seconds, and the
+    number of launches issued."""
+    probe = ranks.reduce([timed_block(eng, ranks, T, K)[0]], 'MAX')[0]
+    blocks = int(min(max_blocks, max(3, np.ceil(min_seconds / max(probe, 1e-6)))))
+    wall, kern = [], []
+    for _ in range(blocks):
+        e, k = timed_block(eng, ranks, T, K)
+        wall.append(e)
+        kern.append(k)
+    both = ranks.reduce(wall + kern, 'MAX')
+    return both[:blocks], both[blocks:], wall, (blocks + 1) * K
+
+
+def spread(values):
+    v = np.sort(np.asarray(values, dtype=np.float64))
+    return float(v[0]), float(np.median(v)), float(v[-1])
+
+
 def read_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*.json), or None."""
     path = os.path.join(ROOT, 'profiles', 'rollout_pmc_latest.json')
@@ -184,130 +361,217 @@ def read_traffic():
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
-    ap.add_argument('--T', type=int, default=1000, help='env-steps per launch')
-    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4'])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--gather-view', action='store_true', help='after the timed region, exercise the RCCL gathered view')
-    args = ap.parse_args()
+# --------------------------------------------------------------------------------------- RCCL gathered view
+def rccl_view_check(eng, engine_cls, ranks):
+    """The single-array (obs, reward, done) view over RCCL, outside the timed region: one ncclAllGather of every rank's
+    packed int32[3N] block.  Proves the collective saw `world` ranks: every rank's own shard digest travels over gloo and
+    is compared with the digest of that rank's slice of the RCCL view."""
+    world, rank = ranks.world, ranks.rank
+    uid = engine_cls.comm_unique_id() if rank == 0 else bytes(_lib.COMM_ID_BYTES)
+    uid = ranks.broadcast_bytes(uid, 0)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    eng.comm_init(world, rank, uid)
+    init_ms = (time.perf_counter() - t0) * 1e3
+    view = eng.allgather_view()  # first call: untimed (lazy connection set-up)
+    laps = []
+    for _ in range(5):
+        ranks.barrier()
+        t0 = time.perf_counter()
+        view = eng.allgather_view()
+        laps.append((time.perf_counter() - t0) * 1e3)
+    own = eng.read_outputs()
+    n = own[0].size
+    digest = hashlib.sha256(b''.join(np.ascontiguousarray(a, dtype='<i4').tobytes() for a in own)).digest()
+    shard_digests = ranks.gather_bytes(digest)
+    equal = all(v.size == world * n for v in view)
+    for r in range(world):
+        got = hashlib.sha256(b''.join(np.ascontiguousarray(v[r * n:(r + 1) * n], dtype='<i4').tobytes() for v in view)).digest()
+        equal = equal and got == shard_digests[r]
+    equal = ranks.reduce([1.0 if equal else 0.0], 'MIN')[0] == 1.0  # every rank checked every slice of ITS copy of the view
+    lap = ranks.reduce([float(np.median(laps))], 'MAX')[0]
+    eng.comm_destroy()
+    return dict(nranks=world, comm_init_ms=ranks.reduce([init_ms], 'MAX')[0], allgather_ms=lap, bytes_per_rank=3 * n * 4,
+                view_envs=world * n, view_equals_shards=bool(equal),
+                note='ncclAllGather of the packed (obs|reward|done) int32[3N] block per rank + D2H of the view; '
+                     'median of 5 calls, max over ranks; compared slice by slice with every rank\'s own shard')
 
+
+# --------------------------------------------------------------------------------------- config 4, strong scaling
+def strong_c4(args, ranks, engine_cls, device):
+    """BASELINE.json config 4: 262 144 envs on the 32x32 lava grid IN TOTAL, sharded over the ranks by env index (strong
+    scaling: 262 144 / world envs per GPU), seed 4.  One checked launch (250 steps from reset: every rank compares its shard
+    with the C oracle; on one GPU the whole batch is also hashed against the reference's digest), then timed blocks of K
+    launches of T steps."""
+    from oracle import c_oracle as C
+    world, rank = ranks.world, ranks.rank
+    total = args.c4_envs
+    if total % world:
+        return dict(skipped='%d envs do not divide over %d ranks' % (total, world))
+    n, seed, T_check = total // world, WORKLOAD_SEED['c4'], 250
+    template, desc = build_workload('c4')
+    eng = engine_cls(n, gua.GridSpec.from_env(template), device=device, env_id0=rank * n, seed=seed)
+    try:
+        eng.reset()
+        eng.reserve_trajectory(max(args.T, T_check))
+        eng.rollout(T_check, 'uniform', auto_reset=True, trajectory=True)
+        eng.sync()
+        got = eng.read_trajectory(0, T_check)
+        grid = C.Grid.from_env(template)
+        st = C.State(n, rank * n)
+        C.reset(grid, seed, st)
+        want = C.rollout(grid, seed, st, T_check, True)
+        shard_ok = all(np.array_equal(got[k], want[k]) for k in ('obs', 'reward', 'done'))
+        shards_ok = ranks.reduce([1.0 if shard_ok else 0.0], 'MIN')[0] == 1.0
+        ref = reference_digest('c4', template, seed, n, T_check, rank * n) if world == 1 else None
+        ref_ok = None if ref is None else sha256_triplet(got) == ref
+        del got, want
+        for _ in range(args.warmup):
+            eng.rollout(args.T, 'uniform', auto_reset=True, trajectory=True)
+        wall, kern, _, _ = timed_region(eng, ranks, args.T, args.steps, args.min_seconds / 2)
+    finally:
+        eng.close()
+    w_min, w_med, w_max = spread(wall)
+    k_med = spread(kern)[1]
+    K = args.steps
+    return dict(value=float(total) * args.T * K / w_med, unit='env-steps/s', scaling='strong', total_envs=total, envs_per_gpu=n,
+                n_gpus=world, env_steps_per_launch=args.T, steps=K, blocks=len(wall), ms_per_step=w_med / K * 1e3,
+                ms_per_step_min=w_min / K * 1e3, ms_per_step_max=w_max / K * 1e3, launch_ms=k_med / K,
+                hbm_gbps_per_gpu=BYTES_PER_ENV_STEP * n * args.T / (k_med / K / 1e3) / 1e9,
+                workload='c4: %s, seed %d, uniform device-RNG actions, auto-reset, int32 trajectory' % (desc, seed),
+                shards_equal_oracle=bool(shards_ok), bit_exact_vs_reference_digest=ref_ok,
+                check='first launch (250 steps from reset): every rank\'s full shard trajectory == C oracle'
+                      + ('; whole batch sha256 == reference digest c4_lava32_262144x250' if ref is not None else ''))
+
+
+# --------------------------------------------------------------------------------------- the run
+def run(args, engine_cls=None, emit=print):
+    """`engine_cls` exists for the 2-rank CPU test (tests/_oracle_engine.py stands in for the device); the command line
+    always measures griduniverse_amd.Engine, and the JSON line names the class that ran."""
+    engine_cls = engine_cls or gua.Engine
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)' % (args.gpus, world))
-
-    dist = None
-    if world > 1:  # torch only as the rendezvous / barrier / max-reduce plumbing (gloo, CPU tensors)
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    ranks = Ranks(rank, world)
 
     N, T, K, W = args.envs, args.T, args.steps, args.warmup
-    seed = 123
+    seed = WORKLOAD_SEED[args.workload]
     template, grid_desc = build_workload(args.workload)
-    all_cores = None
-    if world == 1 and not args.no_cpu_baseline:
-        all_cores = cpu_baseline_all_cores(template, seed)  # forks: must precede any HIP call in this process
-    n_dev = max(1, _lib.device_count())
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    all_cores = cpu_baseline_all_cores(template, seed) if want_cpu else None  # forks: must precede any HIP call here
+    n_dev = max(1, _lib.device_count()) if engine_cls is gua.Engine else 1
     device = local_rank % n_dev  # identity on an N-GPU node; lets a 1-GPU box rehearse the N-process flow
-    eng = gua.Engine(N, gua.GridSpec.from_env(template), device=device, env_id0=rank * N, seed=seed)
+    eng = engine_cls(N, gua.GridSpec.from_env(template), device=device, env_id0=rank * N, seed=seed)
     eng.reset()
     eng.reserve_trajectory(T)
 
-    first_rows = None
-    for i in range(W):
-        eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
-        if i == 0 and rank == 0 and not args.no_cpu_baseline:
-            eng.sync()
-            first = eng.read_trajectory(0, T)
-            first_rows = {k: v[:, :4096].copy() for k, v in first.items()}
-            del first
+    # ---- launch 1, from reset: checked in full
+    launches = 1
+    eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
     eng.sync()
-    barrier()
-    t0 = time.perf_counter()
-    eng.timer_begin()
+    checks = {}
+    if rank == 0 and not args.no_checks:
+        first = eng.read_trajectory(0, T)
+        ref = reference_digest(args.workload, template, seed, N, T, rank * N)
+        checks['bit_exact_vs_reference_digest'] = None if ref is None else sha256_triplet(first) == ref
+        checks['reference_digest'] = None if ref is None else REFERENCE_DIGEST[args.workload] + ' (tests/golden/digests.json: sha256 of ' \
+            'the (obs, reward, done) streams the reference\'s own step() produced for this grid, seed, batch and length)'
+        checks['bit_exact_vs_oracle'] = bool(oracle_prefix_equal(template, seed, rank * N, first))
+        del first
+    for _ in range(W):
+        eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
+    launches += W
+
+    # ---- timed region: blocks of exactly K launches until >= min_seconds
+    wall, kern, own_wall, n_launched = timed_region(eng, ranks, T, K, args.min_seconds)
+    launches += n_launched
+    blocks = len(wall)
+
+    # ---- one instrumented block: an event after every launch (not part of `value`)
+    eng.sync()
+    eng.timer_mark()
     for _ in range(K):
         eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
-    kernel_ms = eng.timer_end()  # HIP events on the engine's stream; also drains it
-    eng.sync()
-    elapsed = time.perf_counter() - t0
-    barrier()
+        eng.timer_mark()
+    per_launch = eng.timer_laps()
+    launches += K
 
-    if dist is not None:
-        import torch
-        tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_max = float(tmax[0]), float(tmax[1])
-    else:
-        kernel_ms_max = kernel_ms
+    if rank == 0 and not args.no_checks:
+        eng.sync()
+        checks['final_state_vs_oracle'] = final_state_vs_oracle(template, seed, rank * N, N, launches * T, eng.get_state())
+        checks['final_state_vs_oracle']['launches'] = launches
 
-    if args.gather_view and world >= 1:
-        gather_view_demo(eng, dist, rank, world)
+    rccl = rccl_view_check(eng, engine_cls, ranks) if (world > 1 or args.gather_view) else None
+    per_rank = ranks.gather([float(np.median(own_wall))])
+    eng.close()
+    c4 = None if args.no_strong_c4 else strong_c4(args, ranks, engine_cls, device)
 
     if rank == 0:
-        total_steps = float(world) * N * T * K
-        launch_s = kernel_ms_max / 1e3 / K
+        w_min, w_med, w_max = spread(wall)
+        k_min, k_med, k_max = spread(kern)
+        launch_s = k_med / 1e3 / K
         achieved = BYTES_PER_ENV_STEP * N * T / launch_s / 1e9
         traffic = read_traffic()
+        steps_per_block = float(world) * N * T * K
         line = {
-            'metric': METRIC, 'value': total_steps / elapsed, 'unit': 'env-steps/s', 'n_gpus': world,
-            'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'metric': METRIC, 'value': steps_per_block / w_med, 'unit': 'env-steps/s', 'n_gpus': world,
+            'steps': K, 'warmup': W, 'ms_per_step': w_med / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'int32', 'data': 'synthetic',
             'config': {'workload': '%s: %d envs per GPU on the %s, uniform random actions from the per-env device RNG, '
                                    'auto-reset on done, one launch = %d env-steps per env, int32 (obs,reward,done) '
                                    'trajectory written to HBM' % (args.workload, N, grid_desc, T),
                        'envs_per_gpu': N, 'env_steps_per_launch': T, 'global_envs': world * N,
                        'parallelism': 'env-index shards, no data-path collective'},
+            'timing': {'blocks': blocks, 'launches_per_block': K, 'timed_seconds': float(np.sum(wall)),
+                       'value_is': 'median block (each block = exactly K launches between barrier + device sync pairs, max over ranks)',
+                       'ms_per_step_min': w_min / K * 1e3, 'ms_per_step_median': w_med / K * 1e3, 'ms_per_step_max': w_max / K * 1e3,
+                       'value_min': steps_per_block / w_max, 'value_max': steps_per_block / w_min,
+                       'launch_ms_min': k_min / K, 'launch_ms_median': k_med / K, 'launch_ms_max': k_max / K,
+                       'launch_ms_is': 'HIP-event time of a block / K, per block',
+                       'per_launch_ms_min': float(per_launch.min()), 'per_launch_ms_median': float(np.median(per_launch)),
+                       'per_launch_ms_max': float(per_launch.max()),
+                       'per_launch_ms_is': 'one extra, untimed block with an event after every launch (%d launches)' % per_launch.size,
+                       'launches_total': launches},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS,
                          'traffic': None if traffic is None else traffic.get('hbm_bytes_per_launch'),
+                         'traffic_measured_in_this_run': False,
                          'kernel': 'gu_rollout_kernel<UNIFORM,TRAJ,LDS>', 'launch_ms': launch_s * 1e3,
                          'algorithmic_bytes_per_launch': BYTES_PER_ENV_STEP * N * T,
                          'traffic_source': None if traffic is None else traffic.get('source')},
+            'engine': engine_cls.__module__ + '.' + engine_cls.__name__,
+            'per_rank': {'ms_per_step': [v[0] / K * 1e3 for v in per_rank],
+                         'value': [float(N) * T * K / v[0] for v in per_rank],
+                         'is': 'every rank\'s own median block (the N = 1 run of this script reports exactly this figure as `value`)'},
+            'rccl': rccl, 'strong_c4': c4,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            base, exact = cpu_baseline(template, seed, T, first_rows)
+        line.update(checks)
+        if want_cpu:
+            base = cpu_baseline(template, seed, T)
             base['all_cores'] = all_cores
             line['cpu_baseline'] = base
-            line['bit_exact_vs_oracle'] = exact
-        print(json.dumps(line), flush=True)
-    eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+        emit(json.dumps(line))
+    ranks.close()
 
 
-def gather_view_demo(eng, dist, rank, world):
-    """Optional: the single-array (obs, reward, done) view over RCCL, outside the timed region."""
-    if world > 1:
-        import torch
-        ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
-        if rank == 0:
-            ident = torch.frombuffer(bytearray(gua.Engine.comm_unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(ident, src=0)
-        uid = bytes(ident.numpy().tobytes())
-    else:
-        uid = gua.Engine.comm_unique_id()
-    eng.comm_init(world, rank, uid)
-    t0 = time.perf_counter()
-    obs, rew, don = eng.allgather_view()
-    dt = time.perf_counter() - t0
-    own = eng.read_outputs()
-    ok = np.array_equal(obs[rank * eng.N:(rank + 1) * eng.N], own[0])
-    print('[rank %d] gathered view of %d envs in %.3f ms, own shard matches: %s' % (rank, obs.size, dt * 1e3, ok),
-          file=sys.stderr, flush=True)
-    eng.comm_destroy()
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50, help='launches per timed block')
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
+    ap.add_argument('--T', type=int, default=1000, help='env-steps per launch')
+    ap.add_argument('--workload', default='c3', choices=['c2', 'c3', 'c4'])
+    ap.add_argument('--min-seconds', type=float, default=0.5, help='repeat the K-launch block until this much time has been timed')
+    ap.add_argument('--c4-envs', type=int, default=C4_TOTAL_ENVS, help='total envs of the strong-scaling config-4 line')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-checks', action='store_true', help='skip the reference-digest / oracle checks of this run')
+    ap.add_argument('--no-strong-c4', action='store_true')
+    ap.add_argument('--gather-view', action='store_true', help='exercise the RCCL gathered view with one rank too')
+    return ap.parse_args(argv)
 
 
 if __name__ == '__main__':
-    main()
+    run(parse_args())

@@ -53,6 +53,17 @@ def main():
         json.dump(dict(rank=rank, world=world, ok_shard=bool(ok_shard), ok_view=bool(ok_view), ok_max=bool(ok_max),
                        ids=[int(env.global_ids()[0]), int(env.global_ids()[-1])]), f)
     env.close()
+
+    # bench.py's multi-rank flow (blocks, max-over-ranks, gathered-view check, strong-scaling config 4) on the stub engine
+    import bench
+    args = bench.parse_args(['--gpus', str(world), '--envs', '512', '--T', '40', '--steps', '2', '--warmup', '1',
+                             '--min-seconds', '0.02', '--c4-envs', '2048'])
+    lines = []
+    bench.run(args, engine_cls=OracleEngine, emit=lines.append)
+    assert len(lines) == (1 if rank == 0 else 0)
+    if rank == 0:
+        with open(os.path.join(out_dir, 'bench_line.json'), 'w') as f:
+            f.write(lines[0])
     dist.destroy_process_group()
 
 

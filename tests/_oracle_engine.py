@@ -47,6 +47,30 @@ class OracleEngine(object):
     def read_outputs(self):
         return self.state.pos.copy(), self.last_reward.copy(), self.state.done.copy()
 
+    def get_state(self):
+        return dict(pos=self.state.pos.copy(), done=self.state.done.copy(), episode=self.state.episode.copy(),
+                    tcount=self.state.tcount.copy())
+
+    # ---- stream / timing stand-ins (host clock)
+    def sync(self):
+        pass
+
+    def timer_begin(self):
+        import time
+        self._t0 = time.perf_counter()
+
+    def timer_end(self):
+        import time
+        return (time.perf_counter() - self._t0) * 1e3
+
+    def timer_mark(self):
+        import time
+        self.__dict__.setdefault('_marks', []).append(time.perf_counter())
+
+    def timer_laps(self, max_laps=65536):
+        marks, self._marks = np.asarray(self.__dict__.get('_marks', []), np.float64), []
+        return np.diff(marks) * 1e3
+
     # ---- the gathered view over gloo instead of RCCL (same packed layout as csrc/gu_comm.hip)
     @staticmethod
     def comm_unique_id():

@@ -46,3 +46,29 @@ def test_two_rank_gloo_shards_and_gathered_view(tmp_path):
     assert [r['ids'] for r in results] == [[0, 2047], [2048, 4095]]
     for r in results:
         assert r['world'] == 2 and r['ok_shard'] and r['ok_view'] and r['ok_max'], r
+    # the JSON line of bench.py's N = 2 flow (same script, oracle-backed stub engine, gloo instead of RCCL)
+    line = json.load(open(os.path.join(str(tmp_path), 'bench_line.json')))
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['engine'] == 'tests._oracle_engine.OracleEngine'
+    assert line['config']['global_envs'] == 1024 and line['steps'] == 2 and line['timing']['blocks'] >= 3
+    assert line['timing']['ms_per_step_min'] <= line['ms_per_step'] <= line['timing']['ms_per_step_max']
+    assert abs(line['value'] - 1024 * 40 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-6 * line['value']
+    assert line['rccl']['nranks'] == 2 and line['rccl']['view_equals_shards'] is True and line['rccl']['view_envs'] == 1024
+    c4 = line['strong_c4']
+    assert c4['scaling'] == 'strong' and c4['total_envs'] == 2048 and c4['envs_per_gpu'] == 1024 and c4['shards_equal_oracle'] is True
+    assert len(line['per_rank']['value']) == 2 and line['roofline']['traffic_measured_in_this_run'] is False
+    assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
+    assert line['bit_exact_vs_reference_digest'] is None  # 512 envs x 40 steps is not the captured run
+
+
+def test_bench_finds_the_reference_digest_of_its_default_run():
+    """bench.py compares its first launch with the sha256 the reference itself produced -- only when grid, seed, batch and
+    length are those of the captured run."""
+    import bench
+    for name, N, T in (('c3', 65536, 1000), ('c4', 262144, 250), ('c2', 4096, 1000)):
+        template, _ = bench.build_workload(name)
+        seed = bench.WORKLOAD_SEED[name]
+        digest = bench.reference_digest(name, template, seed, N, T, 0)
+        assert isinstance(digest, str) and len(digest) == 64, name
+        assert bench.reference_digest(name, template, seed, N, T, 64) is None
+        assert bench.reference_digest(name, template, seed + 1, N, T, 0) is None
+        assert bench.reference_digest(name, template, seed, N // 2, T, 0) is None

@@ -182,3 +182,23 @@ def test_dp_python_oracle_bit_exact(name):
                                        max_steps=meta['pi_driver_max_steps'], discount_factor=gamma)
     assert v4.tobytes() == z['pi_driver_v'].tobytes() and pi4.tobytes() == z['pi_driver_pi'].tobytes()
     assert (len(w) > 0) == meta['pi_driver_warned']
+
+
+@pytest.mark.parametrize('name', G.traj_names())
+def test_trajectories_numpy_batch_oracle(name):
+    """oracle/np_env.py (the vectorised-numpy CPU baseline of bench.py) against the reference trajectories."""
+    from oracle.np_env import NumpyBatchEnv
+    meta, z = G.load_traj(name)
+    T, N = z['actions'].shape
+    T = min(T, 300)
+    env = NumpyBatchEnv(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'], N,
+                        meta['seed'], meta['env_id0'])
+    assert np.array_equal(env.reset(), z['first_state'])
+    got = env.rollout(T, meta['auto_reset'], z['actions'])
+    for k in ('obs', 'reward', 'done'):
+        assert np.array_equal(got[k], z[k][:T]), k
+    if 'RandomState' not in meta['note']:  # the build RNG produced the fixture's actions: the on-the-fly stream equals it
+        env = NumpyBatchEnv(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'], N,
+                            meta['seed'], meta['env_id0'])
+        env.reset()
+        assert np.array_equal(env.rollout(T, meta['auto_reset'])['obs'], z['obs'][:T])

@@ -46,6 +46,11 @@ def main():
         for _ in range(200):
             env.step(env.action_space.sample())
     out['env.step()_us'] = best(steps) * 1e3 / 200
+    def device_steps():
+        env.reset()
+        for _ in range(200):
+            env.step_on_device(env.action_space.sample())
+    out['env.step_on_device()_us (kernel launch per scalar step)'] = best(device_steps) * 1e3 / 200
     out['env.look_step_ahead()_us'] = best(lambda: [env.look_step_ahead(5, 1) for _ in range(200)]) * 1e3 / 200
     S = env.world.size
     uniform = np.ones((S, 4)) / 4
@@ -62,6 +67,17 @@ def main():
     out['VecGridUniverse(65536).step()_us'] = best(lambda: vec.step(acts), 20) * 1e3
     out['VecGridUniverse(65536).rollout(1000, trajectory=False)_ms'] = best(lambda: (vec.rollout(1000, trajectory=False), vec.engine.sync()))
     out['VecGridUniverse(65536).step(zero_copy=True)_us'] = best(lambda: vec.step(acts, zero_copy=True), 20) * 1e3
+    eng = vec.engine
+    eng.pinned_actions[:] = acts
+    out['Engine(65536).step_pinned()_us (gu_step, page-locked I/O, no numpy allocation)'] = best(lambda: eng.step_pinned(True), 50) * 1e3
+    out['Engine(65536).done_indices()_us (one compaction launch)'] = best(eng.done_indices, 50) * 1e3
+    small = gua.VecGridUniverse(4096, template=env, seed=1, auto_reset=True)
+    small.reset()
+    small.engine.pinned_actions[:] = acts[:4096]
+    out['Engine(4096).step_pinned()_us'] = best(lambda: small.engine.step_pinned(True), 50) * 1e3
+    out['VecGridUniverse(4096).step()_us'] = best(lambda: small.step(acts[:4096]), 50) * 1e3
+    out['Engine(4096).done_indices()_us'] = best(small.engine.done_indices, 50) * 1e3
+    small.close()
     vec.close()
     env.close()
     print(json.dumps(out, indent=1))

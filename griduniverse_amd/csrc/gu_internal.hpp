@@ -75,6 +75,10 @@ struct gu_engine {
     int64_t traj_T = 0;
     int traj_kind = 0;  // what the last rollout left in the buffer: 0 nothing, 1 int32 rows, 2 packed rows
 
+    // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in
+    uint32_t *d_rows[2] = {nullptr, nullptr};
+    int rows_shift[2] = {-1, -1};   // log2(16 * copies) the table was built for (-1: not built)
+
     // rollout stats
     int32_t *d_ret = nullptr;
     int32_t *d_episodes_fin = nullptr;

@@ -34,7 +34,20 @@ struct RolloutArgs {
     uint32_t n_starts, seed_prefix, env_id0, steps_taken;
     int64_t N, T;
     GridSel gs;
+    const uint32_t *rows;   // transition-row table [S][4] (gu_rollout_rows.hip)
+    int32_t row_shift;      // log2(16 * copies) of that table
+    int32_t xcd_remap;      // workgroup b works on env block (b % 8) * (blocks / 8) + b / 8: one XCD = one contiguous env range
 };
+
+// Workgroups are handed to the 8 XCDs round-robin (workgroup b -> XCD b % 8), so neighbouring env blocks would be
+// written by different XCDs, through different L2s.  With the remap every XCD owns one contiguous eighth of the batch:
+// its L2 then writes back 8x longer contiguous runs of every trajectory row.  (No reuse is at stake -- this is about the
+// write stream's locality.)  Needs a block count divisible by 8.
+__device__ __forceinline__ uint32_t gu_env_block(int32_t xcd_remap)
+{
+    const uint32_t b = blockIdx.x;
+    return xcd_remap ? (b & 7u) * (gridDim.x >> 3) + (b >> 3) : b;
+}
 
 // AUTO: 0 = no reset; 1 = auto-reset, single start cell (branch-free selects keyed on the TERM bit of the
 //       register copy of flags); 2 = auto-reset, several start cells (RNG stream 1, rare divergent branch)
@@ -44,11 +57,17 @@ struct RolloutArgs {
 //           do not align with blocks, e.g. one maze per env; 64-lane blocks, S16 + 16 bytes per lane)
 //       3 = like 1 with the flags plane only (it carries the reward code): grids of 32 768 .. ~160 000 cells, one
 //           block per CU.  A global read per step would wait for every trajectory store in flight (vmcnt counts both).
+//       (a fifth variant -- one dword record per cell replicated 32 times, so that the per-step gather is free of LDS bank
+//       conflicts -- was built and measured SLOWER than variant 1 at every batch size but one, 66.8 against 62.3 us for the
+//       stats-only launch of config 3: the conflicts (SQ_LDS_BANK_CONFLICT ~ 7 cycles per gather) are not what bounds the
+//       latency-bound modes, the length of the dependent chain is; profiles/r02b_map_ab.txt.  What shortens the chain is the
+//       transition-row table of gu_rollout_rows.hip.)
 #define GU_PRIVATE_PAD 16
+#define GU_MAX_BLOCK 1024
 // TRAJ: 0 = no trajectory; 1 = int32 obs / reward / done rows (12 B per env-step);
 //       2 = ONE packed uint32 row: obs | (reward & 0xFF) << 16 | done << 24 (4 B per env-step, grids up to 65 536 cells)
 template <int POLICY, int AUTO, int TRAJ, bool STATS, int MAP>
-__global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs a)
+__global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutArgs a)
 {
     constexpr bool LDS = MAP == 1 || MAP == 3;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -69,7 +88,7 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_rollout_kernel(const RolloutArgs 
         for (int32_t i = threadIdx.x; i < a.S; i += blockDim.x) thr_lds[i] = a.pi_thr[i];
         __syncthreads();
     }
-    const int64_t e64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * blockDim.x + threadIdx.x;  // (remap only on single-grid engines)
     if (e64 >= a.N) return;
     const uint32_t e = (uint32_t)e64;
     LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, e, m);
@@ -300,17 +319,22 @@ static inline int gu_rollout_block()
 {
     const char *s = std::getenv("GU_ROLLOUT_BLOCK");  // read per launch: A/B runs switch it inside one process
     const int v = s ? std::atoi(s) : 256;
-    return (v == 64 || v == 128 || v == 256) ? v : 256;
+    return (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ? v : 256;
 }
 
+#define GU_ROLLOUT_XCD_DEFAULT false
+
 template <int POLICY, int AUTO, int TRAJ, bool STATS>
-static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
+static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
 {
+    RolloutArgs a = a_in;
+    auto blocks_ok = [&](int block) { return gu_blocks(h->N, block) % 8 == 0; };
     const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
     const int lds_bs = gu_lds_block(h, bs, planes);
     if (lds_bs) {
         size_t lds = (size_t)planes * h->cell_bytes;
         RolloutArgs b = a;
+        b.xcd_remap = a.xcd_remap && blocks_ok(lds_bs);
         if (POLICY == GU_POLICY_SAMPLE && lds + (size_t)h->S * sizeof(uint4) <= 65536) {
             b.pi_lds = 1;
             lds += (size_t)h->S * sizeof(uint4);
@@ -321,6 +345,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
     if constexpr (POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM) {
         // one grid too big for two planes in 64 KiB: its flags plane alone, up to the whole 160 KB of a CU
         if (h->n_grids == 1 && h->W <= 32767 && (size_t)h->cell_bytes <= 160 * 1024 - 512) {
+            a.xcd_remap = a.xcd_remap && blocks_ok(bs);
             auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 3>;
             if (h->cell_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->cell_bytes);
             hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, bs)), dim3(bs), (size_t)h->cell_bytes, h->stream, a);
@@ -335,6 +360,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a, int bs)
             return;
         }
     }
+    a.xcd_remap = a.xcd_remap && h->n_grids == 1 && blocks_ok(bs);
     hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 0>), dim3(gu_blocks(h->N, bs)), dim3(bs), 0, h->stream, a);
 }
 
@@ -368,3 +394,5 @@ void gu_rollout_uniform(gu_engine *h, const RolloutArgs &a, int auto_mode, int t
 void gu_rollout_stream(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
 void gu_rollout_greedy(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
 void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
+// the transition-row kernel (gu_rollout_rows.hip): true when it took the launch
+bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);

@@ -84,8 +84,21 @@ int main(void)
             return 1;
         }
     }
+    /* an action outside 0..3 is caught by the kernel: GU_ERR_INVALID, env 7 does not step, every other env does */
     acts[7] = 9;
     if (gu_step(h, acts, 0, NULL, NULL, NULL) != GU_ERR_INVALID) { fprintf(stderr, "bad action accepted\n"); return 1; }
+    {
+        const int32_t keep_pos = pos[7], keep_done = done[7];
+        const uint32_t keep_ep = episode[7], keep_t = tcount[7];
+        acts[7] = 0;
+        gu_oracle_rollout(&og, seed, env_id0, N, 1, 0, acts, NULL, pos, done, episode, tcount, o_obs, o_rew, o_don, NULL, NULL);
+        pos[7] = keep_pos, done[7] = keep_done, episode[7] = keep_ep, tcount[7] = keep_t;
+        static int32_t g_pos[N], g_done[N];
+        static uint32_t g_ep[N], g_t[N];
+        CHECK(gu_get_state(h, g_pos, g_done, g_ep, g_t));
+        if (memcmp(g_pos, pos, sizeof pos) || memcmp(g_done, done, sizeof done) || memcmp(g_ep, episode, sizeof episode) ||
+            memcmp(g_t, tcount, sizeof tcount)) { fprintf(stderr, "state after a rejected action differs\n"); return 1; }
+    }
     int32_t idx[N], count = -1;
     CHECK(gu_done_indices(h, idx, &count));
     int want = 0;

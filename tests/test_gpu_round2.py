@@ -253,3 +253,118 @@ def test_facade_sees_edits_after_invalidate():
     env.current_state = 1
     assert env.step(1)[0] == 1 and env.step(2) == (5, -10, True, env.info)
     env.close()
+
+
+# ------------------------------------------------------------------------------- transition-row rollout kernel
+@pytest.fixture
+def force_rows(monkeypatch):
+    monkeypatch.setenv('GU_ROLLOUT_ROWS', '1')  # read per launch: every eligible launch takes gu_rollout_rows.hip
+
+
+def _oracle_and_engine(meta, N, seed, env_id0=0):
+    grid = C.Grid.from_lists(**meta)
+    st = C.State(N, env_id0)
+    eng = Engine(N, spec_of(meta), seed=seed, env_id0=env_id0)
+    assert np.array_equal(eng.reset(), C.reset(grid, seed, st))
+    return grid, st, eng
+
+
+@pytest.mark.parametrize('name', ['c3_maze32', 'c4_lava32', 'c2_open8x8', 'c5_maze64', 'grid1x1', 'grid9x1', 'rect25x30_busy'])
+def test_rows_kernel_equals_the_oracle(force_rows, name):
+    """Every launch form of the transition-row kernel against the C oracle: uniform / stream actions, auto-reset on and
+    off, int32 / packed / no trajectory + stats, launches of 1, 2, 15, 16, 17, 33 and 200 steps chained (resumability:
+    head / body / tail of the 16-actions-per-word schedule), ragged batch sizes."""
+    meta, _ = G.load_traj(name)
+    single_start = len(meta['starts']) == 1
+    for N in (1, 65, 1000):
+        for auto in (True, False):
+            grid, st, eng = _oracle_and_engine(meta, N, 21, env_id0=4096)
+            with eng:
+                eng.reserve_trajectory(200)
+                rs = np.random.RandomState(N)
+                for T in (1, 2, 15, 16, 17, 33, 200):
+                    for policy in ('uniform', 'stream'):
+                        acts = rs.randint(0, 4, (T, N)).astype(np.int32) if policy == 'stream' else None
+                        if acts is not None:
+                            eng.upload_actions(acts)
+                        for traj in (True, 'packed', False):
+                            eng.rollout(T, policy, auto, traj, stats=True)
+                            want = C.rollout(grid, 21, st, T, auto, actions=acts, stats=True)
+                            if traj is True:
+                                got = eng.read_trajectory(0, T)
+                            elif traj == 'packed':
+                                got = eng.read_trajectory_packed(0, T)
+                            else:
+                                got = {}
+                            for k in got:
+                                assert np.array_equal(got[k], want[k]), (name, N, auto, T, policy, traj, k)
+                            ret, eps = eng.read_stats()
+                            assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes'])
+                            s = eng.get_state()
+                            for k in ('pos', 'done', 'episode', 'tcount'):
+                                assert np.array_equal(s[k], getattr(st, k)), (name, N, auto, T, policy, traj, k)
+                            assert np.array_equal(eng.done_indices(), np.flatnonzero(st.done))
+            if not single_start:
+                break  # (multi-start auto-reset falls back to the general kernel; still checked once above)
+
+
+def test_rows_kernel_first_step_honours_a_stored_state_that_disagrees_with_the_cell(force_rows):
+    """gu_set_state can install done = 1 on a non-terminal cell and done = 0 on a terminal one, and a reset can land on a
+    terminal start: the launch's first step must use the stored flag, like the general kernel and the oracle."""
+    meta, _ = G.load_traj('c4_lava32')
+    N = 512
+    for starts in ([0], [16]):  # 16 is a lava cell: every reset lands on a terminal start
+        m = dict(meta, starts=starts)
+        grid, st, eng = _oracle_and_engine(m, N, 5)
+        with eng:
+            rs = np.random.RandomState(2)
+            free = np.setdiff1d(np.arange(1024), meta['walls'])
+            st.pos[:] = rs.choice(free, N)
+            st.pos[::7] = 16
+            st.done[:] = rs.randint(0, 2, N)
+            st.episode[:] = rs.randint(0, 9, N)
+            st.tcount[:] = rs.randint(0, 50, N)  # per-env step counts: the per-lane RNG schedule
+            eng.set_state(pos=st.pos, done=st.done, episode=st.episode, tcount=st.tcount)
+            eng.reserve_trajectory(40)
+            for auto in (True, False, True):
+                eng.rollout(40, 'uniform', auto, True, stats=True)
+                want = C.rollout(grid, 5, st, 40, auto, stats=True)
+                got = eng.read_trajectory(0, 40)
+                assert all(np.array_equal(got[k], want[k]) for k in got), (starts, auto)
+                s = eng.get_state()
+                assert all(np.array_equal(s[k], getattr(st, k)) for k in ('pos', 'done', 'episode', 'tcount'))
+
+
+def test_rows_and_general_kernel_agree_at_config_sizes(monkeypatch):
+    """Config 3 at full size (65 536 envs x 1000 steps) through both kernels: identical trajectory digest, stats and state;
+    and the default dispatch (rows for stats-only / packed, general for int32 rows) reproduces the reference's digest."""
+    import hashlib
+    import random
+    random.seed(123)
+    np.random.seed(123)
+    env = gua.GridUniverseEnv(grid_shape=(32, 32), random_maze=True)
+    N, T = 65536, 1000
+    out = {}
+    for rows in ('0', '1'):
+        monkeypatch.setenv('GU_ROLLOUT_ROWS', rows)
+        with Engine(N, GridSpec.from_env(env), seed=123) as eng:
+            eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'uniform', True, True, stats=True)
+            tr = eng.read_trajectory(0, T)
+            h = hashlib.sha256()
+            for k in ('obs', 'reward', 'done'):
+                h.update(np.ascontiguousarray(tr[k], dtype='<i4').tobytes())
+            st = eng.get_state()
+            out[rows] = (h.hexdigest(), eng.read_stats(), st)
+            del tr
+    assert out['0'][0] == out['1'][0] == G.load_json('digests.json')['c3_maze32_65536x1000']['sha256']
+    assert all(np.array_equal(a, b) for a, b in zip(out['0'][1], out['1'][1]))
+    assert all(np.array_equal(out['0'][2][k], out['1'][2][k]) for k in out['0'][2])
+    monkeypatch.delenv('GU_ROLLOUT_ROWS')
+    with Engine(N, GridSpec.from_env(env), seed=123) as eng:  # default dispatch: stats-only launch on the row table
+        eng.reset()
+        eng.rollout(T, 'uniform', True, False, stats=True)
+        assert all(np.array_equal(a, b) for a, b in zip(eng.read_stats(), out['0'][1]))
+        st = eng.get_state()
+        assert all(np.array_equal(st[k], out['0'][2][k]) for k in st)

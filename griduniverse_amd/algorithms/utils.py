@@ -1,8 +1,9 @@
 """Tabular-RL helpers with the reference's names and semantics (core/algorithms/utils.py),
 running the sweeps on the MI355X through libgu (kernels in csrc/gu_vi.hip).
 
-`env` is a `GridUniverseEnv` (or anything exposing `._engine()` / `.engine`); results are
-bit-identical float64 to the reference's Python loops (tests/test_gpu_dp.py).
+`env` is a `GridUniverseEnv` -- the algorithms read `env.world`, `env.reward_matrix` and the grid lists like the
+reference's do, which the batched `VecGridUniverse` does not carry; results are bit-identical float64 to the reference's
+Python loops (tests/test_gpu_dp.py).
 """
 import sys
 from io import StringIO
@@ -11,11 +12,13 @@ import numpy as np
 
 
 def engine_of(env):
+    """The libgu engine behind a `GridUniverseEnv` (or behind any object that exposes one as `.engine` AND the
+    reference env's attributes the algorithm at hand reads)."""
     if hasattr(env, '_engine'):
         return env._engine()
     if hasattr(env, 'engine'):
         return env.engine
-    raise TypeError('env must be a griduniverse_amd GridUniverseEnv / VecGridUniverse')
+    raise TypeError('env must be a griduniverse_amd GridUniverseEnv')
 
 
 def reshape_as_griduniverse(input_matrix, world_shape):

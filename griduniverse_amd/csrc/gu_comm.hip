@@ -162,13 +162,21 @@ int gu_comm_init_all(gu_handle *handles, int32_t n)
     std::vector<ncclComm_t> comms((size_t)n);
     for (int32_t i = 0; i < n; ++i) gu_comm_free(handles[i]);
     GU_NCCL(nc->CommInitAll(comms.data(), n, devs.data()));
+    // every handle owns its communicator from here on, so that a failure below (or later) releases all of them through
+    // gu_comm_free / gu_destroy
+    for (int32_t i = 0; i < n; ++i) {
+        handles[i]->comm = comms[(size_t)i];
+        handles[i]->nranks = n;
+        handles[i]->rank = i;
+    }
     for (int32_t i = 0; i < n; ++i) {
         gu_engine *h = handles[i];
-        h->comm = comms[(size_t)i];
-        h->nranks = n;
-        h->rank = i;
-        GU_HIP(hipSetDevice(h->device));
-        GU_HIP(hipMalloc(&h->d_gather, (size_t)n * 3 * (size_t)h->N * sizeof(int32_t)));
+        hipError_t e = hipSetDevice(h->device);
+        if (e == hipSuccess) e = hipMalloc(&h->d_gather, (size_t)n * 3 * (size_t)h->N * sizeof(int32_t));
+        if (e != hipSuccess) {
+            for (int32_t j = 0; j < n; ++j) gu_comm_free(handles[j]);
+            return gu_fail(e == hipErrorOutOfMemory ? GU_ERR_NOMEM : GU_ERR_HIP, "gather buffer of rank %d: %s", i, hipGetErrorString(e));
+        }
     }
     return GU_OK;
 }

@@ -346,6 +346,176 @@ __global__ void __launch_bounds__(VI_PB_THREADS) gu_vi_block_kernel(const ViBloc
     if (tid == 0) *a.rounds_done = r;
 }
 
+// ------------------------------------------------------------------------------------
+// Grids of 4097 .. 524 288 states (e.g. the shipped 101x101 level): the whole iteration in ONE launch of a CLUSTER of
+// G <= 256 workgroups of 1024 threads, K = 1 or 2 states per thread, one grid-wide barrier per round.  Against one launch per
+// round (gu_vi_round_kernel) a round no longer pays a kernel boundary, the staging of the planes and the five-fold "pull"
+// evaluation: each thread reads its own record and its neighbours' rewards ONCE, keeps its policy row in registers, and a round is  V1 (4 loads of v) -> store v' -> barrier -> V2 (4 loads of v') -- the same float64
+// operations in the same order as every other DP kernel here, hence the same bits.
+//
+// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md "Valid forms", first table row):
+// every byte that crosses workgroups -- v, the per-round delta keys, the arrival counter -- is written and read with
+// 8-byte / 4-byte AGENT-scope atomics (write-through `sc1` stores, `sc1` loads that bypass the per-CU L1; the per-XCD L2s
+// are not coherent with each other); after its store every wave drains (`s_waitcnt vmcnt(0)`), the workgroup barriers, ONE
+// lane adds to the monotonic arrival counter and polls it (relaxed, `s_sleep`) until all G workgroups of the round have
+// arrived, and the other waves continue behind a second workgroup barrier.  v is double-buffered, so one barrier per round
+// separates every write of a buffer from every read of it.  All G workgroups must be resident together: at most one
+// 1024-thread workgroup per CU of the device; every spin is bounded and raises a timeout word instead of hanging.
+// ------------------------------------------------------------------------------------
+#define VI_CL_THREADS 1024
+#define VI_CL_MAX_WGS 256
+#define VI_CL_MAX_K 2  /* states per thread: 4 would spill at the 128 registers of a 1024-thread workgroup */
+#define VI_CL_MAX_STATES (VI_CL_MAX_WGS * VI_CL_THREADS * VI_CL_MAX_K)
+#define VI_CL_SPIN_LIMIT (1u << 22)
+
+typedef unsigned long long vi_u64;
+
+struct ViClusterArgs {
+    const uint8_t *cell;
+    int32_t cell_bytes, W, S;
+    double gamma, threshold;
+    double *v0, *v1;                 // double-buffered value table; v0 holds the current values at entry
+    double *pi;                      // [S][4], updated in place when GREEDY and at least one round ran
+    vi_u64 *delta_key;               // [max_rounds], zeroed before the launch
+    uint32_t *sync;                  // [0] arrival counter, [1] timeout word; zeroed before the launch
+    int32_t *rounds_done;
+    int32_t max_rounds, use_threshold;
+};
+
+__device__ __forceinline__ double vi_ld_agent(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const vi_u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ void vi_st_agent(double *p, double x)
+{
+    __hip_atomic_store(reinterpret_cast<vi_u64 *>(p), (vi_u64)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int K, bool GREEDY>
+__global__ void __launch_bounds__(VI_CL_THREADS) gu_vi_cluster_kernel(const ViClusterArgs a)
+{
+    __shared__ vi_u64 wave_key[VI_CL_THREADS / 64];
+    __shared__ vi_u64 round_key;
+    __shared__ uint32_t timed_out;
+    const int32_t tid = threadIdx.x, S = a.S, W = a.W;
+    const int32_t stride = gridDim.x * VI_CL_THREADS;  // thread owns states s0, s0 + stride, ... (K of them)
+    const int32_t s0 = blockIdx.x * VI_CL_THREADS + tid;
+    const double gamma = a.gamma;
+    const ViMap cell{a.cell, reinterpret_cast<const int8_t *>(a.cell + a.cell_bytes)};
+    // per-state constants of every round: neighbour indices (env:136-155 through the OPEN bits), rewards, terminal bit
+    // (rewards are kept as packed int8 and converted where used, neighbour indices are recomputed: registers, not time, are scarce)
+    uint32_t rec[K];  // the state's own record: OPEN bits (-> neighbour indices, recomputed where used) and the TERM bit
+    uint32_t rn[K];   // reward_matrix of the four neighbours, one int8 each
+    int32_t r_own[K];
+    double p[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int32_t s = s0 + j * stride;
+        rec[j] = 0u;
+        r_own[j] = 0;
+        rn[j] = 0u;
+#pragma unroll
+        for (int act = 0; act < 4; ++act) p[j][act] = 0.0;
+        if (s < S) {
+            rec[j] = cell.f[s];
+            r_own[j] = cell.r[s];
+#pragma unroll
+            for (uint32_t act = 0; act < 4; ++act) rn[j] |= (uint32_t)(uint8_t)cell.r[vi_next(s, rec[j], act, W)] << (8 * act);
+            const double4 row = *reinterpret_cast<const double4 *>(a.pi + 4 * (int64_t)s);
+            p[j][0] = row.x, p[j][1] = row.y, p[j][2] = row.z, p[j][3] = row.w;
+        }
+    }
+    if (tid == 0) timed_out = 0u;
+    __syncthreads();
+    double *vo = a.v0, *vn = a.v1;
+    const uint32_t G = gridDim.x;
+    int r = 0;
+    bool failed = false;
+    for (; r < a.max_rounds; ++r) {
+        vi_u64 key = 0ull;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {  // V1 (utils.py:15-27), reading the old table through the L1-bypassing loads
+            const int32_t s = s0 + j * stride;
+            if (s < S) {
+                double acc = __dadd_rn(0.0, (double)r_own[j]);
+#pragma unroll
+                for (uint32_t act = 0; act < 4; ++act)
+                    acc = __dadd_rn(acc, __dmul_rn(p[j][act], __dmul_rn(gamma, vi_ld_agent(vo + vi_next(s, rec[j], act, W)))));
+                vi_st_agent(vn + s, acc);
+                const vi_u64 k = vi_key(__dsub_rn(vi_ld_agent(vo + s), acc));  // signed, dynamic_programming.py:17
+                key = k > key ? k : key;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const vi_u64 o = __shfl_down(key, off);
+            key = o > key ? o : key;
+        }
+        if ((tid & 63) == 0) wave_key[tid >> 6] = key;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
+        __syncthreads();                                   // ... before the one lane that signals for the workgroup
+        if (tid == 0) {
+            vi_u64 k = wave_key[0];
+            for (int w = 1; w < VI_CL_THREADS / 64; ++w) k = wave_key[w] > k ? wave_key[w] : k;
+            __hip_atomic_fetch_max(a.delta_key + r, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t want = G * (uint32_t)(r + 1);
+            uint32_t spins = 0;
+            while (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > VI_CL_SPIN_LIMIT || __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tell everyone; never hang
+                    timed_out = 1u;
+                    break;
+                }
+            }
+            round_key = __hip_atomic_load(a.delta_key + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();  // the other waves load only behind the polling lane's match
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (compiler ordering only: every shared load is an sc1 load)
+        if (timed_out) {
+            failed = true;
+            break;
+        }
+        if (GREEDY) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {  // V2 (utils.py:55-72) on v'
+                const int32_t s = s0 + j * stride;
+                if (s < S) {
+                    double q[4];
+#pragma unroll
+                    for (uint32_t act = 0; act < 4; ++act)
+                        q[act] = __dadd_rn(0.0, __dadd_rn((double)(int8_t)(rn[j] >> (8 * act)),
+                                                          __dmul_rn(gamma, vi_ld_agent(vn + vi_next(s, rec[j], act, W)))));
+                    double qmax = q[0];
+#pragma unroll
+                    for (int act = 1; act < 4; ++act) qmax = (q[act] > qmax) ? q[act] : qmax;
+                    const uint32_t mask = (rec[j] & GU_CELL_TERM) ? 0u : vi_tie_mask(q, qmax);
+                    const double share = vi_share(mask);
+#pragma unroll
+                    for (int act = 0; act < 4; ++act) p[j][act] = ((mask >> act) & 1u) ? share : 0.0;
+                }
+            }
+        }
+        double *t = vo;
+        vo = vn;
+        vn = t;
+        if (a.use_threshold && vi_unkey_dev(round_key) < a.threshold) {
+            ++r;
+            break;
+        }
+    }
+    if (GREEDY && r > 0 && !failed) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int32_t s = s0 + j * stride;
+            if (s < S) *reinterpret_cast<double4 *>(a.pi + 4 * (int64_t)s) = make_double4(p[j][0], p[j][1], p[j][2], p[j][3]);
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) *a.rounds_done = failed ? -1 : r;
+}
+
 // first-argmax action per state (np.argmax; examples/griduniverse_alg_examples.py:76)
 __global__ void __launch_bounds__(VI_BLOCK) gu_vi_argmax_kernel(const double *__restrict__ pi, int32_t S, uint8_t *__restrict__ greedy)
 {
@@ -537,6 +707,69 @@ static int vi_block_run(gu_engine *h, double gamma, double threshold, bool use_t
     return GU_OK;
 }
 
+// The cluster path: 4097 .. 524 288 states, one launch for the whole loop (GU_VI_CLUSTER=0 or GU_VI_MULTI_LAUNCH=1 send these
+// grids down the one-launch-per-round path instead, for the tests and A/B runs).  Runs up to max_rounds rounds; the value
+// table ends in d_v[vi_cur] (buffers swapped on an odd round count), the policy is updated in place.
+static bool vi_cluster_eligible(const gu_engine *h)
+{
+    if (h->S <= VI_PB_MAX_STATES || h->S > VI_CL_MAX_STATES) return false;
+    if (std::getenv("GU_VI_MULTI_LAUNCH") != nullptr) return false;
+    const char *c = std::getenv("GU_VI_CLUSTER");
+    return !(c && std::atoi(c) == 0);
+}
+
+static int vi_cluster_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds,
+                          int32_t *rounds_done, double *deltas)
+{
+    *rounds_done = 0;
+    if (max_rounds <= 0) return GU_OK;
+    // scratch: [sync counter, timeout word, rounds_done, pad] (16 B) | delta keys [max_rounds]
+    const size_t key_bytes = (size_t)max_rounds * sizeof(unsigned long long);
+    const size_t total = (16 + key_bytes + 15) & ~(size_t)15;
+    int rc = gu_ensure_scratch(h, total);
+    if (rc != GU_OK) return rc;
+    uint32_t *sync_d = (uint32_t *)h->d_scratch;
+    int32_t *done_d = (int32_t *)h->d_scratch + 2;
+    unsigned long long *keys_d = (unsigned long long *)((char *)h->d_scratch + 16);
+    GU_HIP(hipMemsetAsync(h->d_scratch, 0, total, h->stream));  // every polled word is zeroed before every launch
+    ViClusterArgs a{h->d_cell, h->cell_bytes, h->W, h->S, gamma, threshold, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1],
+                    h->d_pi[h->vi_cur], keys_d, sync_d, done_d, max_rounds, use_threshold ? 1 : 0};
+    int n_cu = 0;
+    GU_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int64_t wgs_needed = ((int64_t)h->S + VI_CL_THREADS - 1) / VI_CL_THREADS;
+    const int max_wgs = n_cu < VI_CL_MAX_WGS ? n_cu : VI_CL_MAX_WGS;  // one workgroup per CU: all resident together
+    int K = 1;
+    while (K < VI_CL_MAX_K && wgs_needed > (int64_t)K * max_wgs) K <<= 1;
+    const unsigned G = (unsigned)((wgs_needed + K - 1) / K);
+    GU_REQUIRE((int)G <= max_wgs, GU_ERR_UNSUPPORTED, "grid of %d states needs %u resident workgroups, the device has %d CUs", h->S, G, n_cu);
+    void (*kern)(const ViClusterArgs) = nullptr;
+    switch (K * 2 + (greedy ? 1 : 0)) {
+    case 2: kern = gu_vi_cluster_kernel<1, false>; break;
+    case 3: kern = gu_vi_cluster_kernel<1, true>; break;
+    case 4: kern = gu_vi_cluster_kernel<2, false>; break;
+    default: kern = gu_vi_cluster_kernel<2, true>; break;
+    }
+    hipLaunchKernelGGL(kern, dim3(G), dim3(VI_CL_THREADS), 0, h->stream, a);
+    GU_HIP(hipGetLastError());
+    int32_t done = 0;
+    GU_HIP(hipMemcpyAsync(&done, done_d, sizeof done, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    GU_REQUIRE(done >= 0, GU_ERR_HIP, "the DP cluster kernel's grid barrier timed out (its %u workgroups were not resident together)", G);
+    if (deltas && done > 0) {
+        std::vector<unsigned long long> keys((size_t)done);
+        GU_HIP(hipMemcpy(keys.data(), keys_d, (size_t)done * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int32_t i = 0; i < done; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
+    }
+    if (done & 1) {  // the value table ended in the other buffer; the policy stayed where it was
+        double *t = h->d_v[0];
+        h->d_v[0] = h->d_v[1];
+        h->d_v[1] = t;
+    }
+    *rounds_done = done;
+    h->greedy_valid = false;
+    return GU_OK;
+}
+
 extern "C" {
 
 int gu_vi_set(gu_handle h, const double *v, const double *pi)
@@ -577,6 +810,10 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
         int32_t done = 0;
         return vi_block_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
     }
+    if (vi_cluster_eligible(h)) {
+        int32_t done = 0;
+        return vi_cluster_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
+    }
     GU_HIP(hipMemsetAsync(h->d_delta, 0, (size_t)iters * sizeof(unsigned long long), h->stream));
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
@@ -614,6 +851,7 @@ int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, in
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
     if (vi_block_eligible(h)) return vi_block_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
+    if (vi_cluster_eligible(h)) return vi_cluster_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
     const size_t smem = lds ? 2 * (size_t)h->cell_bytes : 0;
@@ -672,6 +910,7 @@ int gu_vi_eval_run(gu_handle h, double gamma, double threshold, int32_t max_step
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
     if (vi_block_eligible(h)) return vi_block_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
+    if (vi_cluster_eligible(h)) return vi_cluster_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
     // larger grids: one evaluation launch per sweep, the host looks at the deltas once per batch
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;

@@ -323,8 +323,14 @@ def capture_dp():
              ('maze32_s1', lambda: seeded_maze_env(32, 32, 1), 1.0, 12),
              ('maze32_s1_g099', lambda: seeded_maze_env(32, 32, 1), 0.99, 8),
              ('maze64_s5', lambda: seeded_maze_env(64, 64, 5), 1.0, 6),
-             ('maze64_s5_g097', lambda: seeded_maze_env(64, 64, 5), 0.97, 6)]
+             ('maze64_s5_g097', lambda: seeded_maze_env(64, 64, 5), 0.97, 6),
+             # beyond 4096 states (the DP cluster kernel): the shipped 101x101 level and a 128x128 generator maze
+             ('level101_g099', lambda: ref_env(custom_world_fp=os.path.join(LEVELS, 'maze_101x101.txt')), 0.99, 8),
+             ('maze128_s7', lambda: seeded_maze_env(128, 128, 7), 1.0, 4)]
+    only = [a[3:] for a in sys.argv[1:] if a.startswith('dp=')]
     for name, make, gamma, iters in cases:
+        if only and name not in only:
+            continue
         env = make()
         S = env.world.size
         arrays = {}
@@ -346,8 +352,9 @@ def capture_dp():
             deltas.append(float(np.max(v - v_new)))
             v = v_new
             pi = ref_utils.greedy_policy_from_value_function(pi, env, value_function=v, discount_factor=gamma)
-            arrays['vi_v_%d' % k] = v.copy()
-            arrays['vi_pi_%d' % k] = pi.copy()
+            if S <= 4096 or k in (1, 2, iters):  # the big grids keep the first two and the last round only
+                arrays['vi_v_%d' % k] = v.copy()
+                arrays['vi_pi_%d' % k] = pi.copy()
         # (c) the reference driver itself
         with warnings.catch_warnings(record=True) as wlist:
             warnings.simplefilter('always')
@@ -577,7 +584,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     random.seed(0)
     np.random.seed(0)
-    what = set(sys.argv[1:]) or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'bfs'}  # plus 'big' (slow) on request
+    what = {a.split('=')[0] for a in sys.argv[1:]} or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'bfs'}  # plus 'big' (slow) on request
     if 'kat' in what:
         json.dump(capture_kats(), open(os.path.join(OUT, 'kat.json'), 'w'), indent=1)
     if 'err' in what:

@@ -152,12 +152,13 @@ def test_dp_c_oracle_bit_exact(name):
     v, pi = np.zeros(S), pi0.copy()
     for k in range(1, meta['iters'] + 1):
         v, pi, delta = C.value_iteration_step(grid, gamma, pi, v)
-        assert v.tobytes() == z['vi_v_%d' % k].tobytes(), (name, k)
-        assert pi.tobytes() == z['vi_pi_%d' % k].tobytes(), (name, k)
+        if 'vi_v_%d' % k in z:  # (grids beyond 4096 states keep rounds 1, 2 and the last one)
+            assert v.tobytes() == z['vi_v_%d' % k].tobytes(), (name, k)
+            assert pi.tobytes() == z['vi_pi_%d' % k].tobytes(), (name, k)
         assert delta == meta['deltas'][k - 1]
 
 
-@pytest.mark.parametrize('name', [n for n in G.dp_names() if 'maze64' not in n and 'maze32' not in n])
+@pytest.mark.parametrize('name', [n for n in G.dp_names() if not any(big in n for big in ('maze64', 'maze32', 'level101', 'maze128'))])
 def test_dp_python_oracle_bit_exact(name):
     meta, z = G.load_dp(name)
     env = _oracle_env(meta)

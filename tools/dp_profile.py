@@ -24,16 +24,22 @@ def maze(w, h, k):
 
 def main():
     res = []
-    for w in (8, 32, 64, 128):
+    # grids of 4097 .. 65 536 states run twice: GU_VI_CLUSTER=0 (one launch per round) and the default cluster kernel
+    for w, cluster in ((8, None), (32, None), (64, None), (101, '0'), (101, '1'), (128, '0'), (128, '1'), (256, '0'), (256, '1'), (400, None)):
+        if cluster is None:
+            os.environ.pop('GU_VI_CLUSTER', None)
+        else:
+            os.environ['GU_VI_CLUSTER'] = cluster
         env = maze(w, w, 5)
         S = env.world.size
         pol = np.ones((S, 4)) / 4
         dp.value_iteration(pol.copy(), env, discount_factor=0.9)  # warm-up (engine creation, first launches)
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
+        reps = []
+        for _ in range(7):  # best of 7: the call also moves 40 B per state through pageable host arrays
+            t0 = time.perf_counter()
             p, v = dp.value_iteration(pol.copy(), env, discount_factor=0.9)
-        dt = (time.perf_counter() - t0) / reps
+            reps.append(time.perf_counter() - t0)
+        dt = min(reps)
         eng = gua.Engine(64, gua.GridSpec.from_env(env), seed=1)
         eng.vi_set(np.zeros(S), pol)
         steps, deltas = eng.vi_run(0.9, 1e-5, 1000)
@@ -51,7 +57,7 @@ def main():
         eng.sync()
         de = time.perf_counter() - t0
         eng.close()
-        res.append({'grid': '%dx%d maze' % (w, w), 'states': S, 'value_iteration_rounds': int(steps), 'value_iteration_ms': dt * 1e3,
+        res.append({'grid': '%dx%d maze' % (w, w), 'states': S, 'GU_VI_CLUSTER': cluster, 'value_iteration_rounds': int(steps), 'value_iteration_ms': dt * 1e3,
                     'vi_run_rounds_per_s': 6400 / dr, 'round_V1_V2_per_s': 1000 / ds, 'sweep_V1_only_per_s': 1000 / de, 'v_digest': float(np.abs(np.asarray(v)).sum()), 'p_digest': float(np.abs(np.asarray(p)).sum())})
         env.close()
     print(json.dumps(res, indent=1))

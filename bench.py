@@ -499,7 +499,12 @@ def run(args, engine_cls=None, emit=print):
         checks['final_state_vs_oracle'] = cpu_baseline_check_final_state(template, seed, rank * N, N, launches * T, eng.get_state())
         checks['final_state_vs_oracle']['launches'] = launches
 
-    rccl = rccl_view_check(eng, engine_cls, ranks) if (world > 1 or args.gather_view) else None
+    rccl = None
+    if world > 1 or args.gather_view:
+        try:
+            rccl = rccl_view_check(eng, engine_cls, ranks)
+        except gua.GuError as err:  # reported, not fatal: the throughput line above does not depend on the collective
+            rccl = dict(nranks=world, view_equals_shards=None, error=str(err))
     per_rank = ranks.gather([float(np.median(own_wall))])
     eng.close()
     c4 = None if args.no_strong_c4 else strong_c4(args, ranks, engine_cls, device)

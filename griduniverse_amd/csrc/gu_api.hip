@@ -245,6 +245,7 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
     h->n_grids = n_grids;
     h->group = h->N / n_grids;
     h->n_starts = n_starts[0];
+    h->start0 = starts[0];
     h->max_starts = max_starts;
     h->all_single_start = true;
     for (int32_t g = 0; g < n_grids; ++g) h->all_single_start = h->all_single_start && n_starts[(size_t)g] == 1;

@@ -52,6 +52,7 @@ struct gu_engine {
     int32_t *d_starts = nullptr;     // [n_grids][max_starts]
     int32_t *d_nstarts = nullptr;    // [n_grids]
     int32_t n_starts = 0;            // of grid 0 (the only grid unless n_grids > 1)
+    int32_t start0 = 0;              // first start cell of grid 0 (host copy)
     int32_t max_starts = 0;
     bool all_single_start = true;
     // several distinct grids of one shape: env e uses grid e / group (contiguous equal groups)

@@ -160,6 +160,7 @@ extern "C" int gu_generate_mazes(gu_handle h, int32_t n_grids, int32_t W, int32_
     GU_HIP(hipGetLastError());
     int32_t status = 0;
     GU_HIP(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipMemcpyAsync(&h->start0, h->d_starts, 4, hipMemcpyDeviceToHost, h->stream));  // host copy of grid 0's start cell
     GU_HIP(hipStreamSynchronize(h->stream));
     GU_REQUIRE(status == 0, GU_ERR_INVALID, "a generated maze has fewer than two open cells");
     h->has_grid = true;

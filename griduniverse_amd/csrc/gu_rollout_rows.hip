@@ -251,7 +251,11 @@ static void rows_dispatch(const RolloutArgs &a, int traj, bool stats, int auto_r
 #define GU_ROWS_LAUNCH(TR, ST)                                                                                           \
     do {                                                                                                                 \
         auto kern = gu_rollout_rows_kernel<POLICY, TR, ST>;                                                              \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        static size_t allowed = 64 * 1024; /* per instantiation: raise the dynamic-LDS limit once, not per launch */     \
+        if (lds > allowed) {                                                                                             \
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+            allowed = 160 * 1024;                                                                                        \
+        }                                                                                                                \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a, auto_reset);                                               \
     } while (0)
     if (traj == 1) {
@@ -289,9 +293,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         h->rows_shift[which] = -1;
     }
     if (h->rows_shift[which] != shift) {
-        std::vector<int32_t> start0(1);
-        if (hipMemcpy(start0.data(), h->d_starts, sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
-        BuildRowsArgs b{h->d_cell, h->cell_bytes, h->S, h->W, start0[0], which, shift, h->d_rows[which]};
+        BuildRowsArgs b{h->d_cell, h->cell_bytes, h->S, h->W, h->start0, which, shift, h->d_rows[which]};
         hipLaunchKernelGGL(gu_build_rows_kernel, dim3((unsigned)((h->S + 255) / 256)), dim3(256), 0, h->stream, b);
         h->rows_shift[which] = shift;
     }

@@ -368,3 +368,30 @@ def test_rows_and_general_kernel_agree_at_config_sizes(monkeypatch):
         assert all(np.array_equal(a, b) for a, b in zip(eng.read_stats(), out['0'][1]))
         st = eng.get_state()
         assert all(np.array_equal(st[k], out['0'][2][k]) for k in st)
+
+
+def test_rows_kernel_on_a_single_device_generated_maze(force_rows):
+    """One maze carved on the device (its start cell is only known there): the row table must be built from that start."""
+    W = H = 21
+    N, T = 256, 300
+    with Engine(N, GridSpec(W, H, [0], [W * H - 1], [], []), seed=4) as eng:
+        eng.generate_mazes(1, W, H, 11)
+        wall, start, goal = C.generate_maze(11, 0, W, H)
+        spec = GridSpec(W, H, [start], [goal], [], np.flatnonzero(wall).tolist())
+        grid = C.Grid(spec.W, spec.H, spec.wall, spec.lava, spec.goal, spec.reward, spec.starts)
+        st = C.State(N)
+        assert np.array_equal(eng.reset(), C.reset(grid, 4, st))
+        # park every env next to the goal, so that episodes end (and restart from the device-chosen start) within the run
+        near = [goal + d for d in (-W, 1, W, -1) if 0 <= goal + d < W * H and not wall[goal + d]][0]
+        st.pos[:] = near
+        eng.set_state(pos=st.pos)
+        eng.reserve_trajectory(T)
+        for traj in (True, False):
+            eng.rollout(T, 'uniform', True, traj, stats=True)
+            want = C.rollout(grid, 4, st, T, True, stats=True)
+            if traj:
+                got = eng.read_trajectory(0, T)
+                assert all(np.array_equal(got[k], want[k]) for k in got)
+            ret, eps = eng.read_stats()
+            assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes']) and eps.sum() > 0
+            assert np.array_equal(eng.get_state()['episode'], st.episode)

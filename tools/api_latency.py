@@ -46,6 +46,12 @@ def main():
         for _ in range(200):
             env.step(env.action_space.sample())
     out['env.step()_us'] = best(steps) * 1e3 / 200
+    def plain_steps():
+        env.reset()
+        for k in range(200):
+            env.step(k & 3)
+    out['env.step()_us (fixed actions, no action_space.sample())'] = best(plain_steps) * 1e3 / 200
+
     def device_steps():
         env.reset()
         for _ in range(200):

@@ -13,6 +13,22 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+// rows written first-to-last (dir = +1) or last-to-first (dir = -1): does a launch that starts on the rows the previous
+// launch wrote LAST -- still dirty in L2 / Infinity Cache -- save their write-back?
+__global__ void __launch_bounds__(256) k_rows_dir(int* __restrict__ buf, int N, int T, int dir)
+{
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t plane = (size_t)N * T;
+    int s = e;
+    long long o = dir > 0 ? (long long)e : (long long)(T - 1) * N + e;
+    const long long step = dir > 0 ? N : -(long long)N;
+    for (int t = 0; t < T; ++t) {
+        s = s * 1664525 + 1013904223;
+        buf[o] = s; buf[plane + o] = s >> 3; buf[2 * plane + o] = s & 1;
+        o += step;
+    }
+}
+
 template <int LAYOUT>
 __global__ void __launch_bounds__(256) k_store(int* __restrict__ buf, int N, int T)
 {
@@ -39,12 +55,15 @@ int main(int argc, char** argv)
     const size_t bytes = (size_t)N * T * 4 * 3;
     CK(hipMalloc(&buf, bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const char* names[] = {"rows", "wave", "block", "wave3", "block3"};
+    const char* names[] = {"rows", "wave", "block", "wave3", "block3", "rows-alternating", "rows-backward"};
+    int flip = 1;
     for (int round = 0; round < 3; ++round)
-        for (int v = 0; v < 5; ++v) {
+        for (int v = 0; v < 7; ++v) {
             dim3 g(N / 256), blk(256);
             auto launch = [&]() {
                 switch (v) {
+                case 5: k_rows_dir<<<g, blk>>>(buf, N, T, flip); flip = -flip; break;
+                case 6: k_rows_dir<<<g, blk>>>(buf, N, T, -1); break;
                 case 0: k_store<0><<<g, blk>>>(buf, N, T); break;
                 case 1: k_store<1><<<g, blk>>>(buf, N, T); break;
                 case 2: k_store<2><<<g, blk>>>(buf, N, T); break;

@@ -445,6 +445,14 @@ def run(args, engine_cls=None, emit=print):
     """`engine_cls` exists for the 2-rank CPU test (tests/_oracle_engine.py stands in for the device); the command line
     always measures griduniverse_amd.Engine, and the JSON line names the class that ran."""
     engine_cls = engine_cls or gua.Engine
+    if engine_cls is gua.Engine and _lib.is_stale():
+        # a checkout whose libgu.so is missing or older than its sources: build it (one rank per node) rather than measure nothing
+        if int(os.environ.get('LOCAL_RANK', '0')) == 0:
+            _lib.build()
+        else:
+            deadline = time.time() + 900
+            while _lib.is_stale() and time.time() < deadline:
+                time.sleep(2)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -202,18 +202,26 @@ class GridUniverseEnv(object):
     def is_terminal(self, state):
         return self.is_lava(state) or self.is_terminal_goal(state)
 
+    _TABLE_STEP_MAX_CELLS = 1 << 18
+
     def _build_step_tab(self):
         """The N = 1 hot path: the (state, action) -> (next, reward, done) table that the HIP kernel gu_lookahead_kernel
         produced for this grid (one launch for all S x 4 pairs, `_transition_table`), unpacked into plain Python rows.
         A scalar `step()` is then two list indexings -- ~0.3 us -- instead of a kernel launch plus a PCIe round trip
         (~12 us) for ~10 integer operations; batches step on the device (`VecGridUniverse`)."""
         nxt, rew, don = self._transition_table(True)
-        self._step_tab = (nxt.tolist(), [list(row) for row in rew], don.tolist(), [self.world[i] for i in range(self.world.size)])
+        boxed = {int(r): np.int64(r) for r in np.unique(rew)}  # three np.int64 objects shared by every entry
+        self._step_tab = (nxt.tolist(), [[boxed[r] for r in row] for row in rew.tolist()], don.tolist(),
+                          [self.world[i] for i in range(self.world.size)])
         return self._step_tab
 
     def step(self, action):
         """One env-step (env:176-185): a lookup in the transition table computed on the device for this grid."""
-        tab = self._step_tab or self._build_step_tab()
+        tab = self._step_tab
+        if tab is None:
+            if self.world.size > self._TABLE_STEP_MAX_CELLS:  # a Python table of 4 x S entries stops being sensible
+                return self.step_on_device(action)
+            tab = self._build_step_tab()
         state = self._state
         nxt = tab[0][state][action]  # a 4-element list, like env:148: -4..-1 wrap, anything else is IndexError (quirk 6)
         self.previous_state = state

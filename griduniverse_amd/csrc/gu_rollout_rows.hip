@@ -274,12 +274,18 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     if (policy != GU_POLICY_UNIFORM && policy != GU_POLICY_STREAM) return false;
     if (auto_mode == 2) return false;  // several start cells: the reset draws from the RNG, it cannot be tabulated
     const int mode = rows_mode();
-    // Default policy (profiles/r02b_map_ab.txt, interleaved A/B in one process): the launches bound by the dependent chain --
-    // stats-only at every batch size (62 -> 40 us at 65 536 envs, 68 -> 35 us at 262 144), packed rows while there is at most
-    // one 256-env workgroup per CU (83 -> 53 us at 65 536 envs).  Larger packed batches and int32 trajectory rows are bound by
-    // the HBM write path, where the general kernel's store timing is the better one (120 against 151 us at 65 536 envs).
+    // Default policy (profiles/r02b_map_ab.txt, profiles/r02d_rows_crossover.txt; interleaved A/B in one process): every
+    // launch that is bound by the dependent chain rather than by the HBM write path --
+    //   stats only           : every batch size (62 -> 40 us at 65 536 envs, 68 -> 35 us at 262 144)
+    //   packed rows (4 B)    : up to one 256-env workgroup per CU (83 -> 51 us at 65 536 envs; 103 against 111 us at 131 072)
+    //   int32 rows (12 B)    : up to 32 768 envs (80 -> 59 us at 4096..16 384 envs, 84 -> 74 us at 32 768 -- config 2, and a
+    //                          config-4 shard; beyond that the general kernel's store timing is the better one: 124 against 133 us
+    //                          at 65 536 envs)
     if (mode == 0) return false;
-    if (mode != 1 && (traj == 1 || (traj == 2 && gu_blocks(h->N, 256) > 256))) return false;
+    if (mode != 1) {
+        const unsigned blocks = gu_blocks(h->N, 256);
+        if ((traj == 1 && blocks > 128) || (traj == 2 && blocks > 256)) return false;
+    }
     int bs = 0, copies = 0;
     if (!rows_shape(h, &bs, &copies)) return false;
     int shift = 4;

@@ -148,7 +148,7 @@ int gu_destroy(gu_handle h)
     gu_comm_free(h);
     gu_vi_free(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    void *bufs[] = {h->d_rows[0], h->d_rows[1], h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions,
+    void *bufs[] = {h->d_rows[0], h->d_rows[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions,
                     h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -218,6 +218,8 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
         h->d_rows[k] = nullptr;
         h->rows_shift[k] = -1;
     }
+    if (h->d_prow) GU_HIP(hipFree(h->d_prow));
+    h->d_prow = nullptr;
     h->has_grid = false;
     gu_vi_free(h);
     const size_t plane_bytes = 2 * (size_t)cell_bytes * n_grids;

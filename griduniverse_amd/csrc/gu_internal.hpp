@@ -79,6 +79,7 @@ struct gu_engine {
     // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in
     uint32_t *d_rows[2] = {nullptr, nullptr};
     int rows_shift[2] = {-1, -1};   // log2(16 * copies) the table was built for (-1: not built)
+    uint32_t *d_prow = nullptr;     // rows of the table policies (greedy: [S], sampled: [S][8]), rebuilt by every launch
 
     // rollout stats
     int32_t *d_ret = nullptr;

@@ -175,9 +175,10 @@ __global__ void __launch_bounds__(256) gu_validate_actions_kernel(const int32_t 
 // ------------------------------------------------------------------------------------
 // GU_POLICY_SAMPLE draws a = #{k < 3 : u >= p0 + .. + pk} with u = word / 2^32 (oracle/gu_rng.py).  Both sides of
 // u >= c scale exactly by 2^32, and the word is an integer, so the test is word >= ceil(c * 2^32): three uint32
-// thresholds per state (x = always, y, z) and a mask of the sums no word can reach (c * 2^32 > 2^32 - 1, or NaN).
+// thresholds per state.  A sum that no word can reach (c * 2^32 > 2^32 - 1, or NaN) is stored as threshold 0 -- passed by
+// every word -- and counted in the fourth component, which gu_sample_action subtracts again.
 // The float64 prefix sums are formed here, once per rollout, in the oracle's order; the step then costs one 16-byte
-// read and three integer compares.
+// read, three integer compares with carry adds and one subtract.
 __global__ void __launch_bounds__(256) gu_pi_threshold_kernel(const double *pi, int32_t S, uint4 *thr)
 {
     const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -189,8 +190,8 @@ __global__ void __launch_bounds__(256) gu_pi_threshold_kernel(const double *pi, 
     for (int k = 0; k < 3; ++k) {
         const double x = __dmul_rn(c[k], 4294967296.0);  // exact (power of two)
         if (!(x <= 4294967295.0)) {
-            never |= 1u << k;
-            t[k] = 0xFFFFFFFFu;
+            ++never;
+            t[k] = 0u;
         } else {
             t[k] = x <= 0.0 ? 0u : (uint32_t)ceil(x);
         }
@@ -347,13 +348,13 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
         const bool want = x ? std::atoi(x) != 0 : GU_ROLLOUT_XCD_DEFAULT;
         a.xcd_remap = want && h->n_grids == 1;
     }
+    if (policy == GU_POLICY_SAMPLE)
+        hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
     if (gu_rollout_rows(h, a, policy, auto_mode, traj, stats)) {
         GU_HIP(hipGetLastError());
         h->steps_taken += (uint32_t)T;
         return GU_OK;
     }
-    if (policy == GU_POLICY_SAMPLE)
-        hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
     switch (policy) {
     case GU_POLICY_UNIFORM: gu_rollout_uniform(h, a, auto_mode, traj, stats, bs); break;
     case GU_POLICY_STREAM: gu_rollout_stream(h, a, auto_mode, traj, stats, bs); break;

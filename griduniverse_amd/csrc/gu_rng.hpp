@@ -49,10 +49,21 @@ __host__ __device__ __forceinline__ uint32_t gu_rng_word(uint32_t prefix, uint32
 {
     uint32_t h = gu_mm3_block(prefix, (stream << 28) | (ctr & 0x0FFFFFFFu));
     uint32_t len = 16u;
-    if (ctr >> 28) {  // beyond 2^28 draws of one stream: the high counter bits are a fifth key word
-        h = gu_mm3_block(h, ctr >> 28);
+    const uint32_t hi = ctr >> 28;  // beyond 2^28 draws of one stream: the high counter bits are a fifth key word
+#if defined(__HIP_DEVICE_COMPILE__)
+    // a WAVE-UNIFORM branch (one scalar test; the whole wave skips the block in the practically universal case), instead of
+    // a per-lane one that would be executed under an empty EXEC mask on every draw
+    if (__builtin_amdgcn_ballot_w64(hi != 0u)) {
+        const uint32_t h5 = gu_mm3_block(h, hi);
+        h = hi ? h5 : h;
+        len = hi ? 20u : 16u;
+    }
+#else
+    if (hi) {
+        h = gu_mm3_block(h, hi);
         len = 20u;
     }
+#endif
     h ^= len;
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;

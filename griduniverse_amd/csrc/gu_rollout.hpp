@@ -11,9 +11,12 @@
 //   algorithmic HBM bytes per env-step with GU_F_TRAJECTORY: 3 x 4 B row writes = 12 B
 //   (+4 B action read for GU_POLICY_STREAM); state is loaded/stored once per launch.
 // ------------------------------------------------------------------------------------
+// Inverse CDF on one 32-bit word: a = #{k < 3 : word >= t_k} over the thresholds that a word can reach.  A threshold that no
+// word reaches (cumulative probability >= 1: every one-hot or zero-tailed row has some) is stored as 0 -- which every word
+// passes -- and counted in q.w, so the three compares need no per-threshold mask: three v_cmp + carry adds and one subtract.
 __device__ __forceinline__ uint32_t gu_sample_action(uint32_t word, const uint4 q)
 {
-    return (uint32_t)(word >= q.x && !(q.w & 1u)) + (uint32_t)(word >= q.y && !(q.w & 2u)) + (uint32_t)(word >= q.z && !(q.w & 4u));
+    return (uint32_t)(word >= q.x) + (uint32_t)(word >= q.y) + (uint32_t)(word >= q.z) - q.w;
 }
 
 struct RolloutArgs {

@@ -16,8 +16,16 @@
 // cell is terminal" -- holds after any step but not for an arbitrary stored state (gu_set_state, a reset onto a terminal
 // start), so every lane takes its FIRST step of a launch on the per-cell planes, like the general kernel.
 //
+// Table policies use the same idea with policy-dependent rows, rebuilt by every launch (the policy table may have changed):
+//   GU_POLICY_GREEDY  row[s]    = the one record reached by the greedy action of the (post-reset) cell: 4 bytes, up to 32
+//                                 copies; a step is v_and_or_b32 + ds_read_b32
+//   GU_POLICY_SAMPLE  row[s]    = { inverse-CDF thresholds of pi[cell] (uint4, gu_pi_threshold_kernel) | the four next
+//                                 records }: 32 bytes, up to 4 copies; a step is ONE round trip for two ds_read_b128, the three
+//                                 threshold compares and a three-select pick of the next record (the general kernel: a
+//                                 threshold gather, the compares, the move, and a second gather for the record)
+//
 // Results are bit-identical to the general kernel (tests/test_gpu_round2.py runs both on the same seeds); the launcher
-// picks this one where it is faster (profiles/r02b_map_ab.txt).
+// picks this one where it is faster (profiles/r02b_map_ab.txt, profiles/r02d_rows_crossover.txt).
 #include "gu_rollout.hpp"
 
 #define GU_ROW_ADDR_MASK 0xFFFFFu
@@ -46,31 +54,83 @@ __global__ void __launch_bounds__(256) gu_build_rows_kernel(const BuildRowsArgs 
     *reinterpret_cast<uint4 *>(a.rows + 4 * (int64_t)s) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
+// Table-policy rows.  `thr` == nullptr: greedy (one dword per cell); else sampled (8 dwords per cell).
+struct BuildPolicyRowsArgs {
+    const uint8_t *cell;
+    const uint8_t *greedy;  // first-argmax action per cell
+    const uint4 *thr;       // inverse-CDF thresholds per cell
+    int32_t cell_bytes, S, W, start0, auto_reset, row_shift;
+    uint32_t *rows;
+};
+
+__device__ __forceinline__ uint32_t gu_row_record(const uint8_t *cell, int32_t cell_bytes, int32_t base, uint32_t act, int32_t W, int32_t row_shift)
+{
+    const uint32_t fb = cell[base];
+    const int32_t n = base + (((fb >> act) & 1u) ? gu_delta<false>(act, 0, W) : 0);
+    const uint32_t d = (cell[n] >> GU_CELL_TERM_BIT) & 1u;
+    const uint32_t r = (uint8_t)cell[cell_bytes + n];
+    return ((uint32_t)n << row_shift) | (d << GU_ROW_DONE_BIT) | (r << 24);
+}
+
+__global__ void __launch_bounds__(256) gu_build_policy_rows_kernel(const BuildPolicyRowsArgs a)
+{
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.S) return;
+    // the policy is consulted at the POST-reset cell, like the general kernel's table policies
+    const int32_t base = (a.auto_reset && (a.cell[s] & GU_CELL_TERM)) ? a.start0 : s;
+    if (!a.thr) {
+        a.rows[s] = gu_row_record(a.cell, a.cell_bytes, base, a.greedy[base], a.W, a.row_shift);
+        return;
+    }
+    uint4 *out = reinterpret_cast<uint4 *>(a.rows + 8 * (int64_t)s);
+    out[0] = a.thr[base];
+    out[1] = make_uint4(gu_row_record(a.cell, a.cell_bytes, base, 0, a.W, a.row_shift), gu_row_record(a.cell, a.cell_bytes, base, 1, a.W, a.row_shift),
+                        gu_row_record(a.cell, a.cell_bytes, base, 2, a.W, a.row_shift), gu_row_record(a.cell, a.cell_bytes, base, 3, a.W, a.row_shift));
+}
+
 typedef __attribute__((address_space(3))) const uint32_t *lds_u32_ptr;
+typedef uint32_t gu_v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const gu_v4u *lds_v4u_ptr;
+
+// bytes per row (log2): 4 next records / one record / thresholds + 4 next records
+template <int POLICY>
+struct RowBytes {
+    static constexpr int log2 = POLICY == GU_POLICY_GREEDY ? 2 : POLICY == GU_POLICY_SAMPLE ? 5 : 4;
+};
 
 template <int POLICY, int TRAJ, bool STATS>
 __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const RolloutArgs a, const int32_t auto_reset)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int32_t shift = a.row_shift;         // log2(16 * copies)
-    const int32_t copies_log2 = shift - 4;
+    const int32_t shift = a.row_shift;         // log2(row bytes * copies)
+    const int32_t copies_log2 = shift - RowBytes<POLICY>::log2;
     // LDS address of the staged table: folded into every record (0 in practice: this kernel has no static LDS), so that a
     // record's address bits are the raw ds_read address and no base is added on the dependent chain
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
     {
-        const uint4 *g = reinterpret_cast<const uint4 *>(a.rows);
         const int32_t n_rows = a.S << copies_log2;
-        for (int32_t i = threadIdx.x; i < n_rows; i += blockDim.x) {
-            uint4 row = g[i >> copies_log2];
-            row.x += lds_base, row.y += lds_base, row.z += lds_base, row.w += lds_base;
-            reinterpret_cast<uint4 *>(smem)[i] = row;
+        if (POLICY == GU_POLICY_GREEDY) {
+            for (int32_t i = threadIdx.x; i < n_rows; i += blockDim.x) reinterpret_cast<uint32_t *>(smem)[i] = a.rows[i >> copies_log2] + lds_base;
+        } else {
+            const uint4 *g = reinterpret_cast<const uint4 *>(a.rows);
+            for (int32_t i = threadIdx.x; i < n_rows; i += blockDim.x) {
+                const int32_t c = i >> copies_log2;
+                uint4 row = g[POLICY == GU_POLICY_SAMPLE ? 2 * c + 1 : c];
+                row.x += lds_base, row.y += lds_base, row.z += lds_base, row.w += lds_base;
+                if (POLICY == GU_POLICY_SAMPLE) {
+                    reinterpret_cast<uint4 *>(smem)[2 * i] = g[2 * c];  // the thresholds, as they are
+                    reinterpret_cast<uint4 *>(smem)[2 * i + 1] = row;
+                } else {
+                    reinterpret_cast<uint4 *>(smem)[i] = row;
+                }
+            }
         }
         __syncthreads();
     }
     const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * blockDim.x + threadIdx.x;
     if (e64 >= a.N) return;
     const uint32_t e = (uint32_t)e64;
-    const uint32_t lane_copy = (threadIdx.x & ((1u << copies_log2) - 1u)) << 4;  // this lane's copy of every row
+    const uint32_t lane_copy = (threadIdx.x & ((1u << copies_log2) - 1u)) << RowBytes<POLICY>::log2;  // this lane's copy of every row
 
     int32_t s = a.pos[e];
     uint32_t d = (uint32_t)a.done[e];
@@ -129,16 +189,35 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         const uint32_t dn = (a.cell[s] >> GU_CELL_TERM_BIT) & 1u;
         rec = (((uint32_t)s << shift) + lds_base) | (dn << GU_ROW_DONE_BIT) | ((uint32_t)(uint8_t)rew[s] << 24);
     };
-    auto step = [&](uint32_t act, uint32_t soff) {
-        uint32_t actoff = lane_copy | (act << 2);  // off the chain (the action does not depend on the env state)
-        asm("" : "+v"(actoff));                    // keep it ONE value: otherwise the three-way OR is re-associated onto the chain
+    // `x`: the action (uniform / stream), nothing (greedy), the step's RNG word (sample); `between`: work that does not depend
+    // on the env state (hashing the next step's RNG word), placed between the issue of the LDS reads and their first use
+    auto step = [&](uint32_t x, uint32_t soff, auto between) {
         const uint32_t prev = rec;
-        const uint32_t addr = (prev & GU_ROW_ADDR_MASK) | actoff;  // v_and_or_b32: the only vector op between two LDS reads
-        rec = *(lds_u32_ptr)(uintptr_t)addr;
+        if (POLICY == GU_POLICY_SAMPLE) {
+            const uint32_t addr = (prev & GU_ROW_ADDR_MASK) | lane_copy;
+            const gu_v4u q = *(lds_v4u_ptr)(uintptr_t)addr;            // thresholds of the cell ...
+            const gu_v4u nx = *(lds_v4u_ptr)(uintptr_t)(addr + 16u);   // ... and its four next records, one round trip
+            __builtin_amdgcn_sched_barrier(0);  // the two reads are issued BEFORE the ~17 vector ops of the hash, not behind them
+            between();
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t act = gu_sample_action(x, make_uint4(q.x, q.y, q.z, q.w));
+            const uint32_t lo = (act & 1u) ? nx.y : nx.x, hi = (act & 1u) ? nx.w : nx.z;
+            rec = (act & 2u) ? hi : lo;
+        } else if (POLICY == GU_POLICY_GREEDY) {
+            rec = *(lds_u32_ptr)(uintptr_t)((prev & GU_ROW_ADDR_MASK) | lane_copy);
+            between();
+        } else {
+            between();
+            uint32_t actoff = lane_copy | (x << 2);  // off the chain (the action does not depend on the env state)
+            asm("" : "+v"(actoff));                  // keep it ONE value: otherwise the three-way OR is re-associated onto the chain
+            const uint32_t addr = (prev & GU_ROW_ADDR_MASK) | actoff;  // v_and_or_b32: the only vector op between two LDS reads
+            rec = *(lds_u32_ptr)(uintptr_t)addr;
+        }
         emit(prev, soff);
     };
-    auto step1 = [&](uint32_t act) {
-        step(act, 0);
+    auto nothing = [] {};
+    auto step1 = [&](uint32_t x) {
+        step(x, 0, nothing);
         if (TRAJ) rebase(1);
     };
 
@@ -158,7 +237,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             for (; i + 16 <= a.T; i += 16, t += 16) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
                 if (TRAJ) rebase(16);
             }
             if (i < a.T) {
@@ -172,6 +251,34 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
                 ++t;
                 if ((t & 15u) == 0u) word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
             }
+        }
+    } else if (POLICY == GU_POLICY_GREEDY || POLICY == GU_POLICY_SAMPLE) {
+        // first step on the planes; the policy is consulted at the post-reset cell
+        uint32_t t = t_lane;
+        uint32_t word = POLICY == GU_POLICY_SAMPLE ? gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t) : 0u;
+        {
+            const int32_t at = (auto_reset && d) ? a.starts[0] : s;
+            first_step(POLICY == GU_POLICY_GREEDY ? (uint32_t)a.greedy[at] : gu_sample_action(word, a.pi_thr[at]));
+        }
+        ++t;
+        if (POLICY == GU_POLICY_SAMPLE) word = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t);
+        int64_t i = 1;
+        auto pstep = [&](uint32_t soff) {  // the word of the NEXT step is hashed while this step's reads are in flight
+            uint32_t next_word = 0u;
+            step(word, soff, [&] {
+                if (POLICY == GU_POLICY_SAMPLE) next_word = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t + 1u);
+            });
+            word = next_word;
+            ++t;
+        };
+        for (; i + 8 <= a.T; i += 8) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) pstep(j * row32);
+            if (TRAJ) rebase(8);
+        }
+        for (; i < a.T; ++i) {
+            pstep(0);
+            if (TRAJ) rebase(1);
         }
     } else {  // GU_POLICY_STREAM: action rows loaded 8 at a time, one chunk ahead of the steps that consume them
         constexpr int CH = 8;
@@ -189,7 +296,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             pa += CH * row;
             if (i + 2 * CH <= a.T) load_chunk(nxt, pa);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) step(cur[j] & 3u, j * row32);
+            for (int j = 0; j < CH; ++j) step(cur[j] & 3u, j * row32, nothing);
             if (TRAJ) rebase(CH);
 #pragma unroll
             for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
@@ -218,16 +325,16 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
 }
 
 // ------------------------------------------------------------------------------------ host side
-// (block size, copies) for the row table, or false when it does not fit: 16 * copies bytes per cell and block, one table
+// (block size, copies) for the row table, or false when it does not fit: row_bytes * copies bytes per cell and block, one table
 // shared by all waves of a block; the batch must fit in (blocks per CU the LDS admits) x 256 CUs blocks.
-static bool rows_shape(const gu_engine *h, int *block, int *copies)
+static bool rows_shape(const gu_engine *h, int row_bytes, int max_copies, int *block, int *copies)
 {
     if (h->n_grids != 1) return false;
     int best_bs = 0, best_c = 0;
     for (int bs = 256; bs <= GU_MAX_BLOCK; bs <<= 1) {
         const int64_t blocks = (h->N + bs - 1) / bs, per_cu = (blocks + 255) / 256;
-        for (int c = 8; c >= 1; c >>= 1) {
-            if ((int64_t)h->S * 16 * c * per_cu <= 160 * 1024 - 2048) {
+        for (int c = max_copies; c >= 1; c >>= 1) {
+            if ((int64_t)h->S * row_bytes * c * per_cu <= 160 * 1024 - 2048) {
                 if (c > best_c) best_c = c, best_bs = bs;
                 break;
             }
@@ -271,44 +378,70 @@ static void rows_dispatch(const RolloutArgs &a, int traj, bool stats, int auto_r
 // Returns true when the launch was taken by the row-table kernel.
 bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats)
 {
-    if (policy != GU_POLICY_UNIFORM && policy != GU_POLICY_STREAM) return false;
+    if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return false;
     if (auto_mode == 2) return false;  // several start cells: the reset draws from the RNG, it cannot be tabulated
     const int mode = rows_mode();
-    // Default policy (profiles/r02b_map_ab.txt, profiles/r02d_rows_crossover.txt; interleaved A/B in one process): every
-    // launch that is bound by the dependent chain rather than by the HBM write path --
-    //   stats only           : every batch size (62 -> 40 us at 65 536 envs, 68 -> 35 us at 262 144)
+    // Default policy (profiles/r02b_map_ab.txt, profiles/r02d_rows_crossover.txt, profiles/r02e_policy_rows.txt; interleaved
+    // A/B in one process): every launch that is bound by the dependent chain rather than by the HBM write path --
+    //   stats only           : every batch size (uniform: 62 -> 40 us at 65 536 envs, 68 -> 35 us at 262 144)
     //   packed rows (4 B)    : up to one 256-env workgroup per CU (83 -> 51 us at 65 536 envs; 103 against 111 us at 131 072)
-    //   int32 rows (12 B)    : up to 32 768 envs (80 -> 59 us at 4096..16 384 envs, 84 -> 74 us at 32 768 -- config 2, and a
-    //                          config-4 shard; beyond that the general kernel's store timing is the better one: 124 against 133 us
-    //                          at 65 536 envs)
+    //   int32 rows (12 B)    : uniform / stream / greedy up to 32 768 envs (80 -> 59 us at 4096..16 384 envs, 84 -> 74 us at
+    //                          32 768 -- config 2, and a config-4 shard; beyond that the general kernel's store timing is the
+    //                          better one: 124 against 133 us at 65 536 envs); sampled up to one workgroup per CU
+    //   sampled policy       : only with auto-reset (122 against 141 us stats only, 148 against 168 us int32 rows at 65 536
+    //                          envs); without it the general kernel's shorter step wins (107 against 122 us) -- a sampled step
+    //                          is bound by its ~45 vector instructions, half of them the MurmurHash3 of its RNG word, not by
+    //                          the LDS round trips the row table saves
     if (mode == 0) return false;
     if (mode != 1) {
         const unsigned blocks = gu_blocks(h->N, 256);
-        if ((traj == 1 && blocks > 128) || (traj == 2 && blocks > 256)) return false;
+        const unsigned int32_limit = policy == GU_POLICY_SAMPLE ? 256 : 128;
+        if ((traj == 1 && blocks > int32_limit) || (traj == 2 && blocks > 256)) return false;
+        if (policy == GU_POLICY_SAMPLE && auto_mode != 1) return false;
     }
+    const bool table_policy = policy == GU_POLICY_GREEDY || policy == GU_POLICY_SAMPLE;
+    const int row_log2 = policy == GU_POLICY_GREEDY ? 2 : policy == GU_POLICY_SAMPLE ? 5 : 4;
     int bs = 0, copies = 0;
-    if (!rows_shape(h, &bs, &copies)) return false;
-    int shift = 4;
-    while ((1 << (shift - 4)) < copies) ++shift;
+    if (!rows_shape(h, 1 << row_log2, policy == GU_POLICY_GREEDY ? 32 : policy == GU_POLICY_SAMPLE ? 4 : 8, &bs, &copies)) return false;
+    int shift = row_log2;
+    while ((1 << (shift - row_log2)) < copies) ++shift;
     const int which = auto_mode ? 1 : 0;
-    if (!h->d_rows[which]) {
-        if (hipMalloc(&h->d_rows[which], (size_t)h->S * 4 * sizeof(uint32_t)) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
+    if (table_policy) {
+        // policy-dependent rows: rebuilt by every launch (one tiny kernel), like the threshold table itself
+        if (!h->d_prow) {
+            if (hipMalloc(&h->d_prow, (size_t)h->S * 32) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
         }
-        h->rows_shift[which] = -1;
+        BuildPolicyRowsArgs b{h->d_cell, h->d_greedy, policy == GU_POLICY_SAMPLE ? h->d_pi_thr : nullptr, h->cell_bytes, h->S, h->W,
+                              h->start0, which, shift, h->d_prow};
+        hipLaunchKernelGGL(gu_build_policy_rows_kernel, dim3((unsigned)((h->S + 255) / 256)), dim3(256), 0, h->stream, b);
+        a.rows = h->d_prow;
+    } else {
+        if (!h->d_rows[which]) {
+            if (hipMalloc(&h->d_rows[which], (size_t)h->S * 4 * sizeof(uint32_t)) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            h->rows_shift[which] = -1;
+        }
+        if (h->rows_shift[which] != shift) {
+            BuildRowsArgs b{h->d_cell, h->cell_bytes, h->S, h->W, h->start0, which, shift, h->d_rows[which]};
+            hipLaunchKernelGGL(gu_build_rows_kernel, dim3((unsigned)((h->S + 255) / 256)), dim3(256), 0, h->stream, b);
+            h->rows_shift[which] = shift;
+        }
+        a.rows = h->d_rows[which];
     }
-    if (h->rows_shift[which] != shift) {
-        BuildRowsArgs b{h->d_cell, h->cell_bytes, h->S, h->W, h->start0, which, shift, h->d_rows[which]};
-        hipLaunchKernelGGL(gu_build_rows_kernel, dim3((unsigned)((h->S + 255) / 256)), dim3(256), 0, h->stream, b);
-        h->rows_shift[which] = shift;
-    }
-    a.rows = h->d_rows[which];
     a.row_shift = shift;
-    const size_t lds = ((size_t)h->S * 16) << (shift - 4);
+    const size_t lds = ((size_t)h->S << row_log2) << (shift - row_log2);
     const dim3 grid(gu_blocks(h->N, bs)), block(bs);
     a.xcd_remap = a.xcd_remap && grid.x % 8 == 0;
-    if (policy == GU_POLICY_UNIFORM) rows_dispatch<GU_POLICY_UNIFORM>(a, traj, stats, which, grid, block, lds, h->stream);
-    else rows_dispatch<GU_POLICY_STREAM>(a, traj, stats, which, grid, block, lds, h->stream);
+    switch (policy) {
+    case GU_POLICY_UNIFORM: rows_dispatch<GU_POLICY_UNIFORM>(a, traj, stats, which, grid, block, lds, h->stream); break;
+    case GU_POLICY_STREAM: rows_dispatch<GU_POLICY_STREAM>(a, traj, stats, which, grid, block, lds, h->stream); break;
+    case GU_POLICY_GREEDY: rows_dispatch<GU_POLICY_GREEDY>(a, traj, stats, which, grid, block, lds, h->stream); break;
+    default: rows_dispatch<GU_POLICY_SAMPLE>(a, traj, stats, which, grid, block, lds, h->stream); break;
+    }
     return true;
 }

@@ -395,3 +395,41 @@ def test_rows_kernel_on_a_single_device_generated_maze(force_rows):
             ret, eps = eng.read_stats()
             assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes']) and eps.sum() > 0
             assert np.array_equal(eng.get_state()['episode'], st.episode)
+
+
+@pytest.mark.parametrize('rows', ['1', '0'])
+@pytest.mark.parametrize('name', ['c3_maze32', 'c4_lava32', 'c2_open8x8', 'rect25x30_busy', 'grid9x1'])
+def test_table_policies_on_the_row_table_equal_the_oracle(monkeypatch, rows, name):
+    """GU_POLICY_SAMPLE / GU_POLICY_GREEDY through the policy-row kernel (GU_ROLLOUT_ROWS=1) and through the general kernel (=0):
+    stochastic policies with zero and one entries (thresholds at both ends of the range), one-hot policies (greedy), auto-reset
+    on and off, every trajectory mode, chained launches of awkward lengths, a policy that changes between launches."""
+    monkeypatch.setenv('GU_ROLLOUT_ROWS', rows)
+    meta, _ = G.load_traj(name)
+    S = meta['W'] * meta['H']
+    single_start = len(meta['starts']) == 1
+    rs = np.random.RandomState(len(name))
+    for N in (1, 130, 1000):
+        for auto in (True, False):
+            grid, st, eng = _oracle_and_engine(meta, N, 33, env_id0=77)
+            with eng:
+                eng.reserve_trajectory(120)
+                for T in (1, 7, 8, 9, 24, 120):
+                    pi = rs.dirichlet(np.ones(4) * 0.5, S)
+                    hot = rs.rand(S) < 0.35  # rows with exact zeros and ones
+                    pi[hot] = np.eye(4)[rs.randint(0, 4, int(hot.sum()))]
+                    onehot = np.eye(4)[rs.randint(0, 4, S)]
+                    for policy, table in (('sample', pi), ('greedy', onehot)):
+                        eng.vi_set(np.zeros(S), table)
+                        for traj in (True, 'packed', False):
+                            eng.rollout(T, policy, auto, traj, stats=True)
+                            want = C.rollout(grid, 33, st, T, auto, stats=True, pi=table)
+                            got = eng.read_trajectory(0, T) if traj is True else eng.read_trajectory_packed(0, T) if traj else {}
+                            for k in got:
+                                assert np.array_equal(got[k], want[k]), (name, N, auto, T, policy, traj, k)
+                            ret, eps = eng.read_stats()
+                            assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes']), (name, N, auto, T, policy, traj)
+                            s = eng.get_state()
+                            for k in ('pos', 'done', 'episode', 'tcount'):
+                                assert np.array_equal(s[k], getattr(st, k)), (name, N, auto, T, policy, traj, k)
+            if not single_start:
+                break

@@ -108,22 +108,29 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
     // record's address bits are the raw ds_read address and no base is added on the dependent chain
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
     {
-        const int32_t n_rows = a.S << copies_log2;
-        if (POLICY == GU_POLICY_GREEDY) {
-            for (int32_t i = threadIdx.x; i < n_rows; i += blockDim.x) reinterpret_cast<uint32_t *>(smem)[i] = a.rows[i >> copies_log2] + lds_base;
-        } else {
-            const uint4 *g = reinterpret_cast<const uint4 *>(a.rows);
-            for (int32_t i = threadIdx.x; i < n_rows; i += blockDim.x) {
-                const int32_t c = i >> copies_log2;
-                uint4 row = g[POLICY == GU_POLICY_SAMPLE ? 2 * c + 1 : c];
-                row.x += lds_base, row.y += lds_base, row.z += lds_base, row.w += lds_base;
-                if (POLICY == GU_POLICY_SAMPLE) {
-                    reinterpret_cast<uint4 *>(smem)[2 * i] = g[2 * c];  // the thresholds, as they are
-                    reinterpret_cast<uint4 *>(smem)[2 * i + 1] = row;
-                } else {
-                    reinterpret_cast<uint4 *>(smem)[i] = row;
-                }
+        // Staging, 16 bytes per thread and iteration, consecutive threads -> consecutive LDS addresses; unrolled so that eight
+        // loads are in flight before the first store (one load's L2 latency per iteration made this the launch's fixed cost:
+        // 15 us for 128 KB of greedy rows copied dword by dword).
+        const int32_t units = (a.S << shift) >> 4;  // 16-byte units of the LDS image
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(a.rows);
+#pragma unroll 8
+        for (int32_t u = threadIdx.x; u < units; u += blockDim.x) {
+            uint4 v;
+            if (POLICY == GU_POLICY_GREEDY) {  // four consecutive dwords of the image: copies of one cell, or of neighbours
+                const int32_t d0 = u << 2;
+                v = make_uint4(a.rows[d0 >> copies_log2], a.rows[(d0 + 1) >> copies_log2], a.rows[(d0 + 2) >> copies_log2],
+                               a.rows[(d0 + 3) >> copies_log2]);
+                v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
+            } else if (POLICY == GU_POLICY_SAMPLE) {  // unit 2r = thresholds of row r (as they are), 2r + 1 = its next records
+                const int32_t c = (u >> 1) >> copies_log2;
+                v = g4[2 * c + (u & 1)];
+                if (u & 1) v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
+            } else {
+                v = g4[u >> copies_log2];
+                v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
             }
+            dst[u] = v;
         }
         __syncthreads();
     }
@@ -330,20 +337,29 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
 static bool rows_shape(const gu_engine *h, int row_bytes, int max_copies, int *block, int *copies)
 {
     if (h->n_grids != 1) return false;
-    int best_bs = 0, best_c = 0;
+    // the smallest workgroup that fits, with as many copies as its LDS share admits (the copy count matters little once the
+    // table is staged with wide, pipelined stores; the workgroup size does: profiles/r02e_rows_copies.txt)
     for (int bs = 256; bs <= GU_MAX_BLOCK; bs <<= 1) {
         const int64_t blocks = (h->N + bs - 1) / bs, per_cu = (blocks + 255) / 256;
         for (int c = max_copies; c >= 1; c >>= 1) {
             if ((int64_t)h->S * row_bytes * c * per_cu <= 160 * 1024 - 2048) {
-                if (c > best_c) best_c = c, best_bs = bs;
-                break;
+                *block = bs;
+                *copies = c;
+                return true;
             }
         }
     }
-    if (!best_c) return false;
-    *block = best_bs;
-    *copies = best_c;
-    return true;
+    return false;
+}
+
+// copies of every row across the LDS banks: up to 8 (uniform / stream), 16 (greedy), 4 (sampled); GU_ROWS_COPIES overrides
+// (a power of two; diagnostics)
+static int rows_max_copies(int32_t policy)
+{
+    const char *s = std::getenv("GU_ROWS_COPIES");
+    const int v = s ? std::atoi(s) : 0;
+    if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) return v;
+    return policy == GU_POLICY_GREEDY ? 16 : policy == GU_POLICY_SAMPLE ? 4 : 8;
 }
 
 static int rows_mode()
@@ -402,7 +418,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     const bool table_policy = policy == GU_POLICY_GREEDY || policy == GU_POLICY_SAMPLE;
     const int row_log2 = policy == GU_POLICY_GREEDY ? 2 : policy == GU_POLICY_SAMPLE ? 5 : 4;
     int bs = 0, copies = 0;
-    if (!rows_shape(h, 1 << row_log2, policy == GU_POLICY_GREEDY ? 32 : policy == GU_POLICY_SAMPLE ? 4 : 8, &bs, &copies)) return false;
+    if (!rows_shape(h, 1 << row_log2, rows_max_copies(policy), &bs, &copies)) return false;
     int shift = row_log2;
     while ((1 << (shift - row_log2)) < copies) ++shift;
     const int which = auto_mode ? 1 : 0;

@@ -52,3 +52,23 @@ def test_compute_without_gpu_fails_loudly(lib):
         gua.VecGridUniverse(8)
     with pytest.raises(gua.GuError):
         gua.GridUniverseEnv().look_step_ahead(0, 1)
+
+
+def test_library_carries_the_hash_of_the_sources_it_was_built_from(lib, tmp_path, monkeypatch):
+    """libgu.so travels to the GPU box next to its sources; the binding refuses one built from other sources."""
+    assert _lib.built_hash() == _lib.source_hash() and not _lib.is_stale()
+    assert re.fullmatch(r'[0-9a-f]{16}', _lib.built_hash())
+    # a source tree that differs (one byte appended to a copy of one file) yields another hash -> load() would refuse
+    import shutil
+    fake = tmp_path / 'csrc'
+    shutil.copytree(_lib.CSRC, fake)
+    with open(fake / 'gu_rng.hpp', 'a') as f:
+        f.write('\n')
+    monkeypatch.setattr(_lib, 'CSRC', str(fake))
+    assert _lib.source_hash() != _lib.built_hash() and _lib.is_stale()
+    monkeypatch.setattr(_lib, '_lib', None)
+    with pytest.raises(_lib.GuError) as err:
+        _lib.load()
+    assert 'built from other sources' in str(err.value)
+    monkeypatch.setenv('GU_ALLOW_STALE_LIB', '1')
+    assert _lib.load() is not None

@@ -516,6 +516,144 @@ __global__ void __launch_bounds__(VI_CL_THREADS) gu_vi_cluster_kernel(const ViCl
     if (blockIdx.x == 0 && tid == 0) *a.rounds_done = failed ? -1 : r;
 }
 
+// ------------------------------------------------------------------------------------
+// Config 5 for MANY rounds in ONE launch: `iters` x { V1 + V2 sweep of the table; every agent takes one greedy step on the
+// updated policy } -- the cluster kernel above with the agents riding along.  One thread owns (at most) one state AND one
+// env; a round is   V1 of the own state -> store v' -> grid barrier -> V2 of the own state (policy row in registers) and,
+// for the own env, lazy reset + greedy action from v' at the four neighbours of its position (the same q / tie mask /
+// first-argmax as gu_vi_sweep_step_kernel, which re-evaluates v' by "pull": the stored v' are those very values) + move.
+// Against one gu_vi_sweep_step launch per round a round costs the barrier (~3 us) instead of a kernel boundary plus the
+// pull evaluations (7.4 us per launch at config 5).  Same inter-workgroup protocol as gu_vi_cluster_kernel.
+// ------------------------------------------------------------------------------------
+struct ViStepClusterArgs {
+    ViClusterArgs vi;                // max_rounds = iters, use_threshold unused
+    int32_t *pos, *reward, *done;
+    uint32_t *episode;
+    const int32_t *starts;
+    uint32_t n_starts, seed_prefix, env_id0;
+    int64_t N;
+    uint32_t flags;
+    uint64_t *done_bits;
+};
+
+__global__ void __launch_bounds__(VI_CL_THREADS) gu_vi_sweep_step_cluster_kernel(const ViStepClusterArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ vi_u64 wave_key[VI_CL_THREADS / 64];
+    __shared__ uint32_t timed_out;
+    const ViMap cell = vi_stage<true>(a.vi.cell, a.vi.cell_bytes, smem);  // the agents gather records of arbitrary cells
+    const int32_t tid = threadIdx.x, S = a.vi.S, W = a.vi.W;
+    const int64_t gid = (int64_t)blockIdx.x * VI_CL_THREADS + tid;
+    const bool own_state = gid < S, own_env = gid < a.N;
+    const int32_t s = (int32_t)gid;
+    const double gamma = a.vi.gamma;
+    uint32_t rec = 0u, rn = 0u;
+    int32_t r_own = 0;
+    double p[4] = {0.0, 0.0, 0.0, 0.0};
+    if (own_state) {
+        rec = cell.f[s];
+        r_own = cell.r[s];
+#pragma unroll
+        for (uint32_t act = 0; act < 4; ++act) rn |= (uint32_t)(uint8_t)cell.r[vi_next(s, rec, act, W)] << (8 * act);
+        const double4 row = *reinterpret_cast<const double4 *>(a.vi.pi + 4 * (int64_t)s);
+        p[0] = row.x, p[1] = row.y, p[2] = row.z, p[3] = row.w;
+    }
+    int32_t e_pos = 0, e_rew = 0, e_done = 0;
+    uint32_t e_ep = 0, e_prefix = 0;
+    if (own_env) {
+        e_pos = a.pos[gid];
+        e_rew = a.reward[gid];
+        e_done = a.done[gid];
+        e_ep = a.episode[gid];
+        e_prefix = gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)gid);
+    }
+    if (tid == 0) timed_out = 0u;
+    __syncthreads();
+    double *vo = a.vi.v0, *vn = a.vi.v1;
+    const uint32_t G = gridDim.x;
+    int r = 0;
+    bool failed = false;
+    for (; r < a.vi.max_rounds; ++r) {
+        vi_u64 key = 0ull;
+        if (own_state) {  // V1 (utils.py:15-27)
+            double acc = __dadd_rn(0.0, (double)r_own);
+#pragma unroll
+            for (uint32_t act = 0; act < 4; ++act)
+                acc = __dadd_rn(acc, __dmul_rn(p[act], __dmul_rn(gamma, vi_ld_agent(vo + vi_next(s, rec, act, W)))));
+            vi_st_agent(vn + s, acc);
+            key = vi_key(__dsub_rn(vi_ld_agent(vo + s), acc));
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const vi_u64 o = __shfl_down(key, off);
+            key = o > key ? o : key;
+        }
+        if ((tid & 63) == 0) wave_key[tid >> 6] = key;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            vi_u64 k = wave_key[0];
+            for (int w = 1; w < VI_CL_THREADS / 64; ++w) k = wave_key[w] > k ? wave_key[w] : k;
+            if (k) __hip_atomic_fetch_max(a.vi.delta_key + r, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(a.vi.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t want = G * (uint32_t)(r + 1);
+            uint32_t spins = 0;
+            while (__hip_atomic_load(a.vi.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > VI_CL_SPIN_LIMIT || __hip_atomic_load(a.vi.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.vi.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    timed_out = 1u;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (timed_out) {
+            failed = true;
+            break;
+        }
+        if (own_state) {  // V2 (utils.py:55-72) on v'
+            double q[4];
+#pragma unroll
+            for (uint32_t act = 0; act < 4; ++act)
+                q[act] = __dadd_rn(0.0, __dadd_rn((double)(int8_t)(rn >> (8 * act)), __dmul_rn(gamma, vi_ld_agent(vn + vi_next(s, rec, act, W)))));
+            double qmax = q[0];
+#pragma unroll
+            for (int act = 1; act < 4; ++act) qmax = (q[act] > qmax) ? q[act] : qmax;
+            const uint32_t mask = (rec & GU_CELL_TERM) ? 0u : vi_tie_mask(q, qmax);
+            const double share = vi_share(mask);
+#pragma unroll
+            for (int act = 0; act < 4; ++act) p[act] = ((mask >> act) & 1u) ? share : 0.0;
+        }
+        if (own_env) {  // the agent acts greedily on the policy of THIS round (np.argmax of its row: first maximum)
+            if ((a.flags & GU_F_AUTO_RESET) && e_done) {  // lazy `if done: env.reset()`
+                e_pos = a.starts[gu_rng_start_index(e_prefix, e_ep, a.n_starts)];
+                ++e_ep;
+            }
+            double *vnew = vn;
+            const uint32_t mask = vi_greedy_mask(cell, W, gamma, [vnew](int32_t n) { return vi_ld_agent(vnew + n); }, e_pos);
+            const uint32_t act = mask ? (uint32_t)__ffs((int)mask) - 1u : 0u;  // an all-zero row (terminal state): argmax = 0
+            e_pos = vi_next(e_pos, cell.f[e_pos], act, W);
+            e_rew = cell.r[e_pos];
+            e_done = (cell.f[e_pos] >> GU_CELL_TERM_BIT) & 1;
+        }
+        double *t = vo;
+        vo = vn;
+        vn = t;
+    }
+    if (own_state && r > 0 && !failed) *reinterpret_cast<double4 *>(a.vi.pi + 4 * (int64_t)s) = make_double4(p[0], p[1], p[2], p[3]);
+    if (own_env) {
+        a.pos[gid] = e_pos;
+        a.reward[gid] = e_rew;
+        a.done[gid] = e_done;
+        a.episode[gid] = e_ep;
+    }
+    const uint64_t bits = __ballot(own_env && e_done != 0);
+    if ((tid & 63) == 0 && own_env) a.done_bits[gid >> 6] = bits;
+    if (blockIdx.x == 0 && tid == 0) *a.vi.rounds_done = failed ? -1 : r;
+}
+
 // first-argmax action per state (np.argmax; examples/griduniverse_alg_examples.py:76)
 __global__ void __launch_bounds__(VI_BLOCK) gu_vi_argmax_kernel(const double *__restrict__ pi, int32_t S, uint8_t *__restrict__ greedy)
 {
@@ -1020,6 +1158,71 @@ int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta)
         GU_HIP(hipStreamSynchronize(h->stream));
         *delta = vi_unkey(key);
     }
+    return GU_OK;
+}
+
+int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flags, double *deltas)
+{
+    int rc = gu_use_device(h);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
+    GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_vi_sweep_step_run accepts only GU_F_AUTO_RESET");
+    GU_REQUIRE(iters > 0 && iters <= 1000000, GU_ERR_INVALID, "iters must be in 1..1000000");
+    int n_cu = 0;
+    GU_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int64_t threads = h->N > h->S ? h->N : (int64_t)h->S;
+    const int64_t G = (threads + VI_CL_THREADS - 1) / VI_CL_THREADS;
+    const char *sw = std::getenv("GU_VI_CLUSTER");
+    const bool cluster = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && G <= (n_cu < VI_CL_MAX_WGS ? n_cu : VI_CL_MAX_WGS) && !(sw && std::atoi(sw) == 0);
+    if (!cluster) {  // one fused launch per round; the deltas are collected once at the end
+        std::vector<double> one((size_t)iters);
+        for (int32_t i = 0; i < iters; ++i) {
+            rc = gu_vi_sweep_step(h, gamma, flags, deltas ? &one[(size_t)i] : nullptr);
+            if (rc != GU_OK) return rc;
+        }
+        if (deltas) memcpy(deltas, one.data(), (size_t)iters * sizeof(double));
+        return GU_OK;
+    }
+    const size_t key_bytes = (size_t)iters * sizeof(unsigned long long);
+    const size_t total = (16 + key_bytes + 15) & ~(size_t)15;
+    rc = gu_ensure_scratch(h, total);
+    if (rc != GU_OK) return rc;
+    uint32_t *sync_d = (uint32_t *)h->d_scratch;
+    int32_t *done_d = (int32_t *)h->d_scratch + 2;
+    unsigned long long *keys_d = (unsigned long long *)((char *)h->d_scratch + 16);
+    GU_HIP(hipMemsetAsync(h->d_scratch, 0, total, h->stream));
+    ViStepClusterArgs a{};
+    a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, 0.0, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1],
+                         h->d_pi[h->vi_cur], keys_d, sync_d, done_d, iters, 0};
+    a.pos = h->pos();
+    a.reward = h->reward();
+    a.done = h->done();
+    a.episode = h->d_episode;
+    a.starts = h->d_starts;
+    a.n_starts = (uint32_t)h->n_starts;
+    a.seed_prefix = h->seed_prefix;
+    a.env_id0 = (uint32_t)h->env_id0;
+    a.N = h->N;
+    a.flags = flags;
+    a.done_bits = h->d_done_bits;
+    hipLaunchKernelGGL(gu_vi_sweep_step_cluster_kernel, dim3((unsigned)G), dim3(VI_CL_THREADS), 2 * (size_t)h->cell_bytes, h->stream, a);
+    GU_HIP(hipGetLastError());
+    int32_t done = 0;
+    GU_HIP(hipMemcpyAsync(&done, done_d, sizeof done, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    GU_REQUIRE(done >= 0, GU_ERR_HIP, "the sweep-step cluster kernel's grid barrier timed out (its %lld workgroups were not resident together)", (long long)G);
+    if (deltas) {
+        std::vector<unsigned long long> keys((size_t)iters);
+        GU_HIP(hipMemcpy(keys.data(), keys_d, key_bytes, hipMemcpyDeviceToHost));
+        for (int32_t i = 0; i < iters; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
+    }
+    if (iters & 1) {
+        double *t = h->d_v[0];
+        h->d_v[0] = h->d_v[1];
+        h->d_v[1] = t;
+    }
+    h->greedy_valid = false;
+    h->steps_taken += (uint32_t)iters;
     return GU_OK;
 }
 

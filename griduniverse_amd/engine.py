@@ -280,6 +280,13 @@ class Engine(object):
                                         ctypes.byref(d) if want_delta else None))
         return d.value if want_delta else None
 
+    def vi_sweep_step_run(self, gamma=1.0, iters=1, auto_reset=False):
+        """`iters` rounds of {V1 + V2 sweep; every env steps greedily on the updated policy} -- one launch when table and
+        batch fit a workgroup cluster.  Returns the per-round deltas."""
+        deltas = np.empty(int(iters), np.float64)
+        check(self.lib.gu_vi_sweep_step_run(self._h, float(gamma), int(iters), _lib.F_AUTO_RESET if auto_reset else 0, ptr(deltas)))
+        return deltas
+
     def mc_evaluate(self, T, first_state, discount_pow, keep, every_visit=False, incremental_mean=True,
                     stationary_env=True, alpha=0.001):
         """Monte-Carlo evaluation over the trajectory rows 0..T-1 of the last rollout (env e = episode e).

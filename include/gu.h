@@ -206,7 +206,10 @@ int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int3
  * gu_vi_greedy: V2 alone on the current v (policy improvement without an evaluation sweep)
  * gu_vi_get   : download v / pi (either may be NULL)
  * gu_vi_sweep_step : config 5 -- ONE launch that performs one V1+V2 sweep AND one env
- *               step in which every agent acts greedily on the updated policy. */
+ *               step in which every agent acts greedily on the updated policy.
+ * gu_vi_sweep_step_run : `iters` such rounds; when the table and the batch fit one workgroup cluster (max(S, N) <= 1024 x
+ *               the device's CUs, S <= 32 767) the whole loop is ONE launch with a grid barrier per round, otherwise one
+ *               launch per round.  deltas[iters] optional. */
 int gu_vi_set(gu_handle h, const double *v, const double *pi);
 int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update, double *deltas);
 int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, int32_t *steps_done, double *deltas);
@@ -214,6 +217,7 @@ int gu_vi_eval_run(gu_handle h, double gamma, double threshold, int32_t max_step
 int gu_vi_greedy(gu_handle h, double gamma);
 int gu_vi_get(gu_handle h, double *v, double *pi);
 int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta);
+int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flags, double *deltas);
 
 /* ---- Monte-Carlo policy evaluation: core/algorithms/monte_carlo.py:29-99 ----------------
  * Consumes the trajectory rows 0..T-1 of the last gu_rollout (run WITHOUT auto-reset: env e is

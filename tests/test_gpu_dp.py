@@ -393,3 +393,42 @@ def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, monkeypatch):
             res += [steps, deltas.tobytes(), *(x.tobytes() for x in eng.vi_get())]
         out[cluster] = res
     assert out['0'][0] > 3 and out['0'] == out['1']
+
+
+@pytest.mark.parametrize('name,N,auto', [('maze64_s5', 65536, True), ('maze64_s5_g097', 4096, False), ('rect6x5_g1', 100, True),
+                                         ('lava4x4_g095', 3, True), ('maze32_s1', 20000, True)])
+def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, monkeypatch):
+    """gu_vi_sweep_step_run (config 5 for many rounds: one launch of a workgroup cluster with a grid barrier per round) against
+    the same number of single gu_vi_sweep_step launches: value table, policy, deltas, and every env's position / reward /
+    done flag / episode count, as raw bytes; and its first rounds against the reference's value-iteration trace."""
+    meta, z = G.load_dp(name)
+    S, gamma = meta['W'] * meta['H'], meta['gamma']
+    iters = 23
+    out = {}
+    for mode in ('single', 'run', 'run_no_cluster'):
+        if mode == 'run_no_cluster':
+            monkeypatch.setenv('GU_VI_CLUSTER', '0')
+        with Engine(N, spec_of(meta), seed=3) as eng:
+            eng.reset()
+            eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+            if mode == 'single':
+                deltas = np.array([eng.vi_sweep_step(gamma, auto_reset=auto) for _ in range(iters)])
+            else:
+                deltas = eng.vi_sweep_step_run(gamma, iters, auto_reset=auto)
+                deltas = np.concatenate([deltas, eng.vi_sweep_step_run(gamma, 2, auto_reset=auto)])  # even + odd round counts
+                eng.vi_sweep_step_run(gamma, 1, auto_reset=auto)
+            if mode == 'single':
+                deltas = np.concatenate([deltas, [eng.vi_sweep_step(gamma, auto_reset=auto) for _ in range(3)]])[:iters + 2]
+            v, pi = eng.vi_get()
+            st = eng.get_state()
+            o = eng.read_outputs()
+            out[mode] = [deltas.tobytes(), v.tobytes(), pi.tobytes(), st['pos'].tobytes(), st['done'].tobytes(), st['episode'].tobytes(),
+                         o[1].tobytes(), eng.done_indices().tobytes()]
+    assert out['single'] == out['run'] == out['run_no_cluster']
+    with Engine(N, spec_of(meta), seed=3) as eng:  # the table part is the reference's value-iteration trace
+        eng.reset()
+        eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+        d = eng.vi_sweep_step_run(gamma, meta['iters'], auto_reset=auto)
+        v, pi = eng.vi_get()
+        assert d.tolist() == meta['deltas']
+        assert v.tobytes() == z['vi_v_%d' % meta['iters']].tobytes() and pi.tobytes() == z['vi_pi_%d' % meta['iters']].tobytes()

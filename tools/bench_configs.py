@@ -121,6 +121,16 @@ def config5(N=65536):
     out = {'config': 'c5 64x64 maze, fused V1+V2 sweep + greedy env step per launch', 'N': N,
            'launches_per_s': reps / wall, 'env_steps_per_s': N * reps / wall, 'us_per_launch_device': dev / reps * 1e6,
            'state_updates_per_s': S * reps / wall}
+    # the same loop as ONE launch (workgroup cluster, grid barrier per round)
+    eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+    eng.vi_sweep_step_run(1.0, 50, True)
+    rounds = 2000
+    t0 = time.perf_counter()
+    eng.vi_sweep_step_run(1.0, rounds, True)
+    dt = time.perf_counter() - t0
+    out['run_rounds_per_s (one launch for all rounds)'] = rounds / dt
+    out['run_env_steps_per_s'] = N * rounds / dt
+    out['run_us_per_round'] = dt / rounds * 1e6
     eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
     t0 = time.perf_counter()
     eng.vi_sweep(1.0, 1000, True)

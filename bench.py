@@ -445,6 +445,15 @@ def run(args, engine_cls=None, emit=print):
     """`engine_cls` exists for the 2-rank CPU test (tests/_oracle_engine.py stands in for the device); the command line
     always measures griduniverse_amd.Engine, and the JSON line names the class that ran."""
     engine_cls = engine_cls or gua.Engine
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)' % (args.gpus, world))
+    # torch (the gloo plumbing of N > 1) is imported BEFORE libgu.so is loaded: the PyTorch wheel bundles its own ROCm runtime,
+    # and the first libamdhip64 in the process is the one every later library binds to -- loading libgu first would leave
+    # two HIP runtimes in the process (gu_comm.hip copes by taking the RCCL beside its own runtime, but one runtime is cleaner)
+    ranks = Ranks(rank, world)
     if engine_cls is gua.Engine and _lib.is_stale():
         # a checkout whose libgu.so is missing or older than its sources: build it (one rank per node) rather than measure nothing
         if int(os.environ.get('LOCAL_RANK', '0')) == 0:
@@ -453,12 +462,6 @@ def run(args, engine_cls=None, emit=print):
             deadline = time.time() + 900
             while _lib.is_stale() and time.time() < deadline:
                 time.sleep(2)
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)' % (args.gpus, world))
-    ranks = Ranks(rank, world)
 
     N, T, K, W = args.envs, args.T, args.steps, args.warmup
     seed = WORKLOAD_SEED[args.workload]

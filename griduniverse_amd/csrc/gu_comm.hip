@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 static_assert(sizeof(ncclUniqueId) == GU_COMM_ID_BYTES, "ncclUniqueId size changed");
@@ -46,8 +47,26 @@ bool rccl_sym(F &slot, const char *name)
 const Rccl *rccl()
 {
     std::call_once(g_rccl_once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // RCCL must sit on the SAME HIP / HSA runtime this library runs on.  A process may hold two ROCm stacks -- e.g. the
+        // system one under /opt/rocm and the copy a PyTorch wheel bundles -- and an RCCL bound to the runtime that was not
+        // initialised sees no device ("unhandled cuda error").  So the first candidate is the librccl next to the
+        // libamdhip64 that resolved OUR HIP calls; only then the loader's default search.  RTLD_LOCAL | RTLD_DEEPBIND: a second
+        // copy of RCCL in the process must keep to its own symbols.
+        std::string beside;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            beside = info.dli_fname;
+            const size_t slash = beside.rfind('/');
+            beside = slash == std::string::npos ? std::string() : beside.substr(0, slash + 1);
+        }
+        std::vector<std::string> names;
+        if (!beside.empty()) {
+            names.push_back(beside + "librccl.so.1");
+            names.push_back(beside + "librccl.so");
+        }
+        for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) names.push_back(n);
+        for (const std::string &name : names) {
+            g_rccl.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
             if (g_rccl.lib) break;
         }
         if (!g_rccl.lib) {

@@ -433,3 +433,35 @@ def test_table_policies_on_the_row_table_equal_the_oracle(monkeypatch, rows, nam
                                 assert np.array_equal(s[k], getattr(st, k)), (name, N, auto, T, policy, traj, k)
             if not single_start:
                 break
+
+
+@pytest.mark.parametrize('order', ['gu_first', 'torch_first'])
+def test_rccl_is_taken_from_the_rocm_stack_libgu_runs_on(order):
+    """A process may hold two ROCm stacks (the system one and the copy a PyTorch wheel bundles).  Whichever order they are
+    loaded in, the gathered view must come up: gu_comm.hip takes the librccl next to the libamdhip64 that serves its own HIP
+    calls.  (bench.py's N > 1 flow imports torch for its gloo plumbing.)"""
+    import subprocess
+    import sys
+    code = '''
+import sys
+sys.path.insert(0, %r)
+order = %r
+if order == 'torch_first':
+    import torch, torch.distributed
+import numpy as np
+import griduniverse_amd as gua
+eng = gua.Engine(4096, gua.GridSpec(8, 8, [0], [63], [], []), seed=1)
+if order == 'gu_first':
+    import torch, torch.distributed
+eng.reset()
+eng.rollout(50, 'uniform', True, False)
+eng.comm_init(1, 0, gua.Engine.comm_unique_id())
+view = eng.allgather_view()
+own = eng.read_outputs()
+assert all(np.array_equal(a, b) for a, b in zip(view, own))
+eng.comm_destroy()
+eng.close()
+print('VIEW-OK')
+''' % (__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), order)
+    out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0 and b'VIEW-OK' in out.stdout, out.stdout.decode()[-2000:]

@@ -34,6 +34,21 @@ def discount_table(discount_factor, threshold, length):
     return pw, pw > threshold
 
 
+def _check_visited_policy_rows(policy, first, obs, done):
+    """np.random.choice(4, p=policy[obs]) in the reference's run_episode raises ValueError for a row that is negative or does
+    not sum to 1 -- but only when an episode actually draws an action in that state.  Called only when some row IS bad."""
+    p = np.asarray(policy, dtype=np.float64)
+    bad = (p < 0).any(axis=1) | (np.abs(p.sum(axis=1) - 1.0) > np.sqrt(np.finfo(np.float64).eps)) | ~np.isfinite(p).all(axis=1)
+    T = obs.shape[0]
+    ended = np.where(done.any(axis=0), done.argmax(axis=0) + 1, T)          # steps each episode took
+    drew = np.arange(T)[:, None] < (ended[None, :] - 1)                       # obs[t] is a state an action was drawn in
+    visited = np.union1d(np.asarray(first), obs[drew])
+    hit = visited[bad[visited]]
+    if hit.size:
+        row = p[int(hit[0])]
+        raise ValueError('probabilities are not non-negative' if (row < 0).any() else 'probabilities do not sum to 1')
+
+
 def monte_carlo_evaluation(policy, env, every_visit=False, incremental_mean=True, stationary_env=True,
                            discount_factor=0.99, threshold=0.0001, alpha=0.001, num_episodes=100, *,
                            max_steps_per_episode=1000, seed=0, return_details=False):
@@ -68,6 +83,11 @@ def monte_carlo_evaluation(policy, env, every_visit=False, incremental_mean=True
         eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
         pw, keep = discount_table(discount_factor, threshold, T)
         value, visits = eng.mc_evaluate(T, first, pw, keep, every_visit, incremental_mean, stationary_env, alpha)
+        rows = np.asarray(policy, dtype=np.float64)
+        if not (np.isfinite(rows).all() and (rows >= 0).all()
+                and (np.abs(rows.sum(axis=1) - 1.0) <= np.sqrt(np.finfo(np.float64).eps)).all()):
+            traj = eng.read_trajectory(0, T)  # rare path: some row is no distribution -- did an episode draw from it?
+            _check_visited_policy_rows(rows, first, traj['obs'], traj['done'])
         if return_details:
             return value, dict(total_visit_counter=visits, first_state=first, **eng.read_trajectory(0, T))
         return value

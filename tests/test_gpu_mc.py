@@ -312,3 +312,21 @@ def test_random_grids_table_policies_property():
             state = eng.get_state()
         assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes']), (trial, W, H, greedy, auto)
         assert np.array_equal(state['pos'], st.pos) and np.array_equal(state['episode'], st.episode)
+
+
+def test_policy_rows_that_are_no_distribution_raise_like_np_random_choice():
+    """The reference's run_episode draws with np.random.choice(4, p=policy[obs]), which raises ValueError for a row that does
+    not sum to 1 or is negative -- when an episode visits that state, not otherwise."""
+    from griduniverse_amd.algorithms import monte_carlo as mc
+    env = gua.GridUniverseEnv(grid_shape=(4, 4), walls=[5])
+    S = env.world.size
+    pi = np.ones((S, 4)) / 4
+    pi[5] = [0.5, 0.5, 0.5, 0.5]        # the wall cell is never entered: the reference never looks at this row
+    assert np.isfinite(mc.monte_carlo_evaluation(pi, env, num_episodes=32, max_steps_per_episode=60)).all()
+    pi[0] = [0.3, 0.3, 0.3, 0.3]        # the start cell: every episode draws from it
+    with pytest.raises(ValueError, match='do not sum to 1'):
+        mc.monte_carlo_evaluation(pi, env, num_episodes=32, max_steps_per_episode=60)
+    pi[0] = [1.5, -0.5, 0.0, 0.0]
+    with pytest.raises(ValueError, match='not non-negative'):
+        mc.monte_carlo_evaluation(pi, env, num_episodes=32, max_steps_per_episode=60)
+    env.close()

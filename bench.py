@@ -473,6 +473,7 @@ def run(args, engine_cls=None, emit=print):
     eng = engine_cls(N, gua.GridSpec.from_env(template), device=device, env_id0=rank * N, seed=seed)
     eng.reset()
     eng.reserve_trajectory(T)
+    placement = eng.trajectory_placement() if hasattr(eng, 'trajectory_placement') else None
 
     # ---- launch 1, from reset: checked in full
     launches = 1
@@ -552,7 +553,11 @@ def run(args, engine_cls=None, emit=print):
                          'traffic_measured_in_this_run': False,
                          'kernel': 'gu_rollout_kernel<UNIFORM,TRAJ,LDS>', 'launch_ms': launch_s * 1e3,
                          'algorithmic_bytes_per_launch': BYTES_PER_ENV_STEP * N * T,
-                         'traffic_source': None if traffic is None else traffic.get('source')},
+                         'traffic_source': None if traffic is None else traffic.get('source'),
+                         'trajectory_placement': None if placement is None else {
+                             'candidates_probed': placement[0], 'probe_ms_kept': placement[1], 'probe_ms_slowest': placement[2],
+                             'is': 'gu_reserve_trajectory writes candidate allocations once in the rollout\'s store shape and keeps '
+                                   'the fastest: where a buffer lands in HBM changes its write rate by ~15 % (DESIGN.md section 6)'}},
             'engine': engine_cls.__module__ + '.' + engine_cls.__name__,
             'per_rank': {'ms_per_step': [v[0] / K * 1e3 for v in per_rank],
                          'value': [float(N) * T * K / v[0] for v in per_rank],

@@ -48,6 +48,7 @@ SIGNATURES = {
     'gu_step_graph': [_vp, _i64, _i64, _u32],
     'gu_read_outputs': [_vp, _vp, _vp, _vp],
     'gu_reserve_trajectory': [_vp, _i64],
+    'gu_trajectory_placement': [_vp, _vp, _vp, _vp],
     'gu_rollout': [_vp, _i64, _i32, _u32],
     'gu_read_trajectory': [_vp, _i64, _i64, _vp, _vp, _vp],
     'gu_read_trajectory_packed': [_vp, _i64, _i64, _vp],

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 // ---------------------------------------------------------------------------------- errors
 static thread_local std::string g_last_error;
@@ -592,18 +593,85 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done)
 }
 
 // ---------------------------------------------------------------------------------- rollout
+// Where a large buffer lands in HBM decides how fast it can be written: the SAME store kernel, on the same GPU at the same
+// clocks, writes twelve 786 MB allocations of one process at 5.7 .. 6.9 TB/s -- each buffer at its own, stable rate
+// (tools/micro/store_placement.hip, profiles/r02f_store_placement.txt; this, not the device, is the "box-to-box" spread of
+// the rollout kernel: 117 .. 141 us per launch).  So a large trajectory buffer is CHOSEN: a few candidate allocations are
+// written once in the rollout's own store shape, timed with events, and the fastest one is kept.  A one-off cost of a few
+// milliseconds at reservation; GU_TRAJ_CANDIDATES=1 turns it off (default: up to 12, capped by free memory).
+static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **out)
+{
+    *out = nullptr;
+    int want = 12;
+    if (const char *s = std::getenv("GU_TRAJ_CANDIDATES")) want = std::atoi(s);
+    size_t free_b = 0, total_b = 0;
+    if (bytes < ((size_t)64 << 20) || want <= 1 || hipMemGetInfo(&free_b, &total_b) != hipSuccess) want = 1;
+    while (want > 1 && (size_t)want * bytes > free_b / 2) --want;  // never hold more than half of what is free, even briefly
+    if (want <= 1) {
+        GU_HIP(hipMalloc(out, bytes));
+        h->traj_candidates = 1;
+        h->traj_probe_ms_best = h->traj_probe_ms_worst = 0.0f;
+        return GU_OK;
+    }
+    // The write rates fall into two classes ~15 % apart.  Candidates are allocated and probed one after the other (all are
+    // kept until the choice is made: a freed block would simply be handed out again); the search stops at the first one that
+    // is clearly in the fast class -- at least 10 % quicker than the slowest seen -- and otherwise keeps the quickest of `want`.
+    std::vector<int32_t *> cand;
+    std::vector<float> ms;
+    size_t best = 0;
+    float worst = 0.0f;
+    for (int i = 0; i < want; ++i) {
+        int32_t *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        cand.push_back(p);
+        float t = 0.0f;
+        int rc = gu_probe_trajectory_buffer(h, p, T, &t);
+        if (rc != GU_OK) {
+            for (int32_t *q : cand) (void)hipFree(q);
+            return rc;
+        }
+        ms.push_back(t);
+        if (t < ms[best]) best = ms.size() - 1;
+        worst = t > worst ? t : worst;
+        if (ms.size() >= 2 && ms[best] <= 0.9f * worst) break;
+    }
+    GU_REQUIRE(!cand.empty(), GU_ERR_NOMEM, "hipMalloc of the %zu-byte trajectory buffer failed", bytes);
+    for (size_t i = 0; i < cand.size(); ++i)
+        if (i != best) (void)hipFree(cand[i]);
+    *out = cand[best];
+    h->traj_candidates = (int32_t)cand.size();
+    h->traj_probe_ms_best = ms[best];
+    h->traj_probe_ms_worst = worst;
+    return GU_OK;
+}
+
 int gu_reserve_trajectory(gu_handle h, int64_t T)
 {
     GU_ENTER(h);
     GU_REQUIRE(T > 0, GU_ERR_INVALID, "T <= 0");
-    if (T == h->traj_T) return GU_OK;
+    if (h->d_traj && T <= h->traj_T) return GU_OK;  // room for AT LEAST T rows: a buffer that is large enough is kept (and so is its placement)
     GU_HIP(hipStreamSynchronize(h->stream));
     if (h->d_traj) GU_HIP(hipFree(h->d_traj));
     h->d_traj = nullptr;
     h->traj_T = 0;
-    GU_HIP(hipMalloc(&h->d_traj, 3 * (size_t)T * (size_t)h->N * sizeof(int32_t)));
+    int rc = gu_alloc_trajectory(h, 3 * (size_t)T * (size_t)h->N * sizeof(int32_t), T, &h->d_traj);
+    if (rc != GU_OK) return rc;
     h->traj_T = T;
     h->traj_kind = 0;
+    return GU_OK;
+}
+
+// How the trajectory buffer was chosen: candidates tried, probe time of the kept and of the slowest one (ms per full write).
+int gu_trajectory_placement(gu_handle h, int32_t *candidates, float *best_ms, float *worst_ms)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(h->d_traj != nullptr, GU_ERR_STATE, "no trajectory buffer: call gu_reserve_trajectory first");
+    if (candidates) *candidates = h->traj_candidates;
+    if (best_ms) *best_ms = h->traj_probe_ms_best;
+    if (worst_ms) *worst_ms = h->traj_probe_ms_worst;
     return GU_OK;
 }
 

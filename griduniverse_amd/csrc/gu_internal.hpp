@@ -75,6 +75,8 @@ struct gu_engine {
     int32_t *d_traj = nullptr;
     int64_t traj_T = 0;
     int traj_kind = 0;  // what the last rollout left in the buffer: 0 nothing, 1 int32 rows, 2 packed rows
+    int32_t traj_candidates = 0;                // allocations tried for the buffer (gu_alloc_trajectory)
+    float traj_probe_ms_best = 0.0f, traj_probe_ms_worst = 0.0f;
 
     // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in
     uint32_t *d_rows[2] = {nullptr, nullptr};
@@ -171,6 +173,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags);
 int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const int32_t *d_actions, bool care,
                         int32_t *d_next, int32_t *d_reward, int32_t *d_done);
 int gu_launch_done_compact(gu_engine *h);
+int gu_probe_trajectory_buffer(gu_engine *h, int32_t *buf, int64_t T, float *ms);  // one timed full write, rollout store shape
 
 // ---- tabular DP launchers (gu_vi.hip) --------------------------------------------
 int gu_vi_alloc(gu_engine *h);

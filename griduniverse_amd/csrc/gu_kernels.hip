@@ -389,6 +389,35 @@ int gu_launch_validate_actions(gu_engine *h, const int32_t *d_actions, int64_t c
     return GU_OK;
 }
 
+// One full write of a candidate trajectory buffer in the rollout's own store shape (three int32 rows per step, one lane per
+// env, workgroups of 256), timed with events: gu_alloc_trajectory keeps the allocation that HBM takes fastest.
+__global__ void __launch_bounds__(GU_BLOCK) gu_traj_probe_kernel(int32_t *__restrict__ buf, int64_t N, int64_t T)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int64_t plane = N * T;
+    int64_t o = e;
+    for (int64_t t = 0; t < T; ++t, o += N) {
+        buf[o] = 0;
+        buf[plane + o] = 0;
+        buf[2 * plane + o] = 0;
+    }
+}
+
+int gu_probe_trajectory_buffer(gu_engine *h, int32_t *buf, int64_t T, float *ms)
+{
+    const dim3 grid(gu_blocks(h->N, GU_BLOCK)), block(GU_BLOCK);
+    hipLaunchKernelGGL(gu_traj_probe_kernel, grid, block, 0, h->stream, buf, h->N, T);  // first touch
+    GU_HIP(hipEventRecord(h->ev_begin, h->stream));
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(gu_traj_probe_kernel, grid, block, 0, h->stream, buf, h->N, T);
+    GU_HIP(hipEventRecord(h->ev_end, h->stream));
+    GU_HIP(hipEventSynchronize(h->ev_end));
+    GU_HIP(hipGetLastError());
+    GU_HIP(hipEventElapsedTime(ms, h->ev_begin, h->ev_end));
+    *ms /= 3.0f;
+    return GU_OK;
+}
+
 int gu_launch_done_compact(gu_engine *h)
 {
     const int64_t n_words = (h->N + 63) / 64;

@@ -175,6 +175,12 @@ class Engine(object):
     def reserve_trajectory(self, T):
         check(self.lib.gu_reserve_trajectory(self._h, int(T)))
 
+    def trajectory_placement(self):
+        """(candidate allocations tried, probe ms of the kept one, probe ms of the slowest) of the trajectory buffer."""
+        n, best, worst = ctypes.c_int32(0), ctypes.c_float(0.0), ctypes.c_float(0.0)
+        check(self.lib.gu_trajectory_placement(self._h, ctypes.byref(n), ctypes.byref(best), ctypes.byref(worst)))
+        return n.value, best.value, worst.value
+
     def rollout(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
         """trajectory: False / True (three int32 rows per step) / 'packed' (one uint32 per env-step)."""
         tflag = _lib.F_PACKED if trajectory == 'packed' else (_lib.F_TRAJECTORY if trajectory else 0)

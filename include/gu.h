@@ -166,9 +166,13 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done);
 /* ---- rollout: the caller loop of core/algorithms/monte_carlo.py:7-26 fused -----
  * T env-steps per env in ONE launch (async).  With GU_F_TRAJECTORY the
  * (obs,reward,done) of step i of this call land in row i of the trajectory buffer
- * (gu_reserve_trajectory(T) first); with GU_F_STATS the per-env reward sum and the
+ * (gu_reserve_trajectory(T) first: room for at least T rows; a buffer that is already large enough is kept); with GU_F_STATS the per-env reward sum and the
  * number of episodes finished during this call are kept for gu_read_stats. */
 int gu_reserve_trajectory(gu_handle h, int64_t T);
+/* Where an allocation lands in HBM decides how fast it can be written (5.7 .. 6.9 TB/s for 786 MB buffers of one process), so
+ * gu_reserve_trajectory tries a few candidate allocations of 64 MB and more, writes each once in the rollout's store shape and
+ * keeps the fastest (GU_TRAJ_CANDIDATES=n, default up to 12, stopping at the first clearly fast one; 1 = take the first).  This reports what it did. */
+int gu_trajectory_placement(gu_handle h, int32_t *candidates, float *best_ms, float *worst_ms);
 int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);
 int gu_read_trajectory_packed(gu_handle h, int64_t t0, int64_t T, uint32_t *packed);   /* [T][N] after GU_F_PACKED */

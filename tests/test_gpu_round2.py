@@ -465,3 +465,36 @@ print('VIEW-OK')
 ''' % (__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), order)
     out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert out.returncode == 0 and b'VIEW-OK' in out.stdout, out.stdout.decode()[-2000:]
+
+
+def test_trajectory_buffer_is_chosen_among_candidates_and_kept_when_large_enough(monkeypatch):
+    """gu_reserve_trajectory probes candidate allocations for buffers of 64 MB and more and keeps the one HBM writes fastest;
+    a buffer that is already large enough is kept.  Results never depend on which allocation was taken."""
+    meta, _ = G.load_traj('c3_maze32')
+    N, T = 32768, 256  # 3 x 32 MB planes
+    grid = C.Grid.from_lists(**meta)
+    outs = []
+    for cand in ('1', '5'):
+        monkeypatch.setenv('GU_TRAJ_CANDIDATES', cand)
+        st = C.State(N)
+        with Engine(N, spec_of(meta), seed=2) as eng:
+            assert np.array_equal(eng.reset(), C.reset(grid, 2, st))
+            eng.reserve_trajectory(T)
+            n, best, worst = eng.trajectory_placement()
+            assert (n == 1 and best == 0.0) if cand == '1' else (2 <= n <= 5 and 0.0 < best <= worst)
+            eng.reserve_trajectory(T // 2)  # large enough already: same buffer, same placement record
+            assert eng.trajectory_placement() == (n, best, worst)
+            eng.rollout(T // 2, 'uniform', True, True)
+            got = eng.read_trajectory(0, T // 2)
+            want = C.rollout(grid, 2, st, T // 2, True)
+            assert all(np.array_equal(got[k], want[k]) for k in got)
+            eng.reserve_trajectory(2 * T)   # grows: chosen again
+            eng.rollout(2 * T, 'uniform', True, True)
+            want = C.rollout(grid, 2, st, 2 * T, True)
+            got = eng.read_trajectory(0, 2 * T)
+            assert all(np.array_equal(got[k], want[k]) for k in got)
+            outs.append(got['obs'][-1].copy())
+    assert np.array_equal(outs[0], outs[1])
+    with Engine(64, spec_of(meta)) as eng:  # small buffers are simply allocated
+        eng.reserve_trajectory(16)
+        assert eng.trajectory_placement()[0] == 1

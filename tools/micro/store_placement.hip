@@ -25,6 +25,110 @@ __global__ void __launch_bounds__(256) k_var(int* __restrict__ buf, int N, int T
     }
 }
 
+// three planes, the three stores of a step SPACED by dependent integer work instead of issued back to back
+template <int GAP>
+__global__ void __launch_bounds__(256) k_spaced(int* __restrict__ buf, int N, int T)
+{
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t plane = (size_t)N * T;
+    int s = e;
+    size_t o = e;
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        buf[o] = s;
+#pragma unroll
+        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        buf[plane + o] = s >> 3;
+#pragma unroll
+        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        buf[2 * plane + o] = s & 1;
+        o += N;
+    }
+}
+
+// three planes, but B steps are kept in registers and then stored PLANE BY PLANE: B rows of plane 0, B of plane 1, B of plane 2
+template <int B>
+__global__ void __launch_bounds__(256) k_burst(int* __restrict__ buf, int N, int T)
+{
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t plane = (size_t)N * T;
+    int s = e;
+    size_t o = e;
+    for (int t = 0; t < T; t += B) {
+        int v[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) { s = s * 1664525 + 1013904223; v[j] = s; }
+#pragma unroll
+        for (int j = 0; j < B; ++j) buf[o + (size_t)j * N] = v[j];
+#pragma unroll
+        for (int j = 0; j < B; ++j) buf[plane + o + (size_t)j * N] = v[j] >> 3;
+#pragma unroll
+        for (int j = 0; j < B; ++j) buf[2 * plane + o + (size_t)j * N] = v[j] & 1;
+        o += (size_t)B * N;
+    }
+}
+
+// data dependence: MODE 0 = three planes, all three values full-entropy; MODE 1 = one stream over the whole buffer writing
+// the low-entropy pattern (s, s >> 3, s & 1) row after row; MODE 2 = three planes, all zeros
+template <int MODE>
+__global__ void __launch_bounds__(256) k_data(int* __restrict__ buf, int N, int T)
+{
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t plane = (size_t)N * T;
+    int s = e;
+    size_t o = e;
+    if (MODE == 1) {
+        for (int t = 0; t < 3 * T; ++t) {
+            s = s * 1664525 + 1013904223;
+            const int k = t % 3;
+            buf[o] = k == 0 ? s : k == 1 ? (s >> 3) : (s & 1);
+            o += N;
+        }
+        return;
+    }
+    for (int t = 0; t < T; ++t) {
+        s = s * 1664525 + 1013904223;
+        buf[o] = MODE == 2 ? 0 : s; buf[plane + o] = MODE == 2 ? 0 : s * 7 + 3; buf[2 * plane + o] = MODE == 2 ? 0 : s * 13 + 5;
+        o += N;
+    }
+}
+
+// [t][3][N] with the three stores of a step spaced by dependent integer work
+template <int GAP>
+__global__ void __launch_bounds__(256) k_rows3_spaced(int* __restrict__ buf, int N, int T)
+{
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    int s = e;
+    size_t o = e;
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        buf[o] = s;
+#pragma unroll
+        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        buf[o + N] = s >> 3;
+#pragma unroll
+        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        buf[o + 2 * (size_t)N] = s & 1;
+        o += 3 * (size_t)N;
+    }
+}
+
+// array of structs: buf[t][N][3] -- every lane stores its (obs, reward, done) as ONE 12-byte store, a wave 768 contiguous bytes
+struct __attribute__((packed, aligned(4))) Triple { int a, b, c; };
+__global__ void __launch_bounds__(256) k_aos(int* __restrict__ buf, int N, int T)
+{
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    int s = e;
+    Triple* p = reinterpret_cast<Triple*>(buf) + e;
+    for (int t = 0; t < T; ++t) {
+        s = s * 1664525 + 1013904223;
+        *p = Triple{s, s >> 3, s & 1};
+        p += N;
+    }
+}
+
 // the three rows of a step ADJACENT: buf[t][3][N] -- one 768 KB window per step instead of three windows 250 MiB apart
 __global__ void __launch_bounds__(256) k_rows3(int* __restrict__ buf, int N, int T)
 {
@@ -67,6 +171,73 @@ int main(int argc, char** argv)
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf("round %d buffer %2d @%p : %.1f us/launch  %.2f TB/s\n", round, i, (void*)bufs[i], ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e12);
         }
+    // one stream over the whole buffer (3T rows of one "plane") against the three concurrent streams, per buffer; and reads
+    for (int i = 0; i < nbuf; ++i) {
+        int* b = bufs[i];
+        float ms;
+        for (int r = 0; r < 2; ++r) k_var<<<N / 256, 256>>>(b, N, 3 * T, 0, 1, 0);
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) k_var<<<N / 256, 256>>>(b, N, 3 * T, 0, 1, 0);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const float one = ms / reps * 1e3f;
+        for (int r = 0; r < 2; ++r) k_rows<<<N / 256, 256>>>(b, N, T);
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) k_rows<<<N / 256, 256>>>(b, N, T);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const float three = ms / reps * 1e3f;
+        for (int r = 0; r < 2; ++r) k_aos<<<N / 256, 256>>>(b, N, T);
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) k_aos<<<N / 256, 256>>>(b, N, T);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const float aos = ms / reps * 1e3f;
+        float sp[3];
+        for (int v = 0; v < 3; ++v) {
+            auto launch = [&] { if (v == 0) k_spaced<1><<<N / 256, 256>>>(b, N, T); else if (v == 1) k_spaced<4><<<N / 256, 256>>>(b, N, T); else k_spaced<12><<<N / 256, 256>>>(b, N, T); };
+            for (int r = 0; r < 2; ++r) launch();
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) launch();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            sp[v] = ms / reps * 1e3f;
+        }
+        float r3[3];
+        for (int v = 0; v < 3; ++v) {
+            auto launch = [&] { if (v == 0) k_rows3_spaced<1><<<N / 256, 256>>>(b, N, T); else if (v == 1) k_rows3_spaced<4><<<N / 256, 256>>>(b, N, T); else k_rows3_spaced<12><<<N / 256, 256>>>(b, N, T); };
+            for (int r = 0; r < 2; ++r) launch();
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) launch();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            r3[v] = ms / reps * 1e3f;
+        }
+        printf("buffer %2d: [t][3][N] spaced by 1 / 4 / 12: %.1f / %.1f / %.1f us\n", i, r3[0], r3[1], r3[2]);
+        float da[3];
+        for (int v = 0; v < 3; ++v) {
+            auto launch = [&] { if (v == 0) k_data<0><<<N / 256, 256>>>(b, N, T); else if (v == 1) k_data<1><<<N / 256, 256>>>(b, N, T); else k_data<2><<<N / 256, 256>>>(b, N, T); };
+            for (int r = 0; r < 2; ++r) launch();
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) launch();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            da[v] = ms / reps * 1e3f;
+        }
+        printf("buffer %2d: data: 3 planes full-entropy %.1f us | one stream, low-entropy rows %.1f us | 3 planes all zeros %.1f us\n", i, da[0], da[1], da[2]);
+        float bu[3];
+        for (int v = 0; v < 3; ++v) {
+            auto launch = [&] { if (v == 0) k_burst<4><<<N / 256, 256>>>(b, N, T); else if (v == 1) k_burst<8><<<N / 256, 256>>>(b, N, T); else k_burst<20><<<N / 256, 256>>>(b, N, T); };
+            for (int r = 0; r < 2; ++r) launch();
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) launch();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            bu[v] = ms / reps * 1e3f;
+        }
+        printf("buffer %2d: 3 planes, stored plane by plane in bursts of 4 / 8 / 20 rows: %.1f / %.1f / %.1f us\n", i, bu[0], bu[1], bu[2]);
+        printf("buffer %2d: three streams %.1f us   one stream %.1f us   [t][N][3] %.1f us   3 planes, stores spaced by 1 / 4 / 12 mul-adds: %.1f / %.1f / %.1f us\n", i, three, one, aos, sp[0], sp[1], sp[2]);
+    }
     // does the speed depend on where INSIDE one allocation the 786 MB window starts?
     {
         int* slab;

@@ -94,6 +94,24 @@ __global__ void __launch_bounds__(256) k_data(int* __restrict__ buf, int N, int 
     }
 }
 
+// three planes, ONE store per (non-unrolled) loop iteration: iteration k writes plane k % 3 of step k / 3
+__global__ void __launch_bounds__(256) k_cycle(int* __restrict__ buf, int N, int T)
+{
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t plane = (size_t)N * T;
+    int s = e;
+    size_t o = e, po = 0;
+    int k = 0;
+#pragma unroll 1
+    for (int i = 0; i < 3 * T; ++i) {
+        s = s * 1664525 + 1013904223;
+        buf[po + o] = s;
+        ++k;
+        po += plane;
+        if (k == 3) { k = 0; po = 0; o += N; }
+    }
+}
+
 // [t][3][N] with the three stores of a step spaced by dependent integer work
 template <int GAP>
 __global__ void __launch_bounds__(256) k_rows3_spaced(int* __restrict__ buf, int N, int T)
@@ -225,6 +243,14 @@ int main(int argc, char** argv)
             da[v] = ms / reps * 1e3f;
         }
         printf("buffer %2d: data: 3 planes full-entropy %.1f us | one stream, low-entropy rows %.1f us | 3 planes all zeros %.1f us\n", i, da[0], da[1], da[2]);
+        {
+            for (int r = 0; r < 2; ++r) k_cycle<<<N / 256, 256>>>(b, N, T);
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) k_cycle<<<N / 256, 256>>>(b, N, T);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("buffer %2d: three planes, one store per loop iteration (plane cycling): %.1f us\n", i, ms / reps * 1e3f);
+        }
         float bu[3];
         for (int v = 0; v < 3; ++v) {
             auto launch = [&] { if (v == 0) k_burst<4><<<N / 256, 256>>>(b, N, T); else if (v == 1) k_burst<8><<<N / 256, 256>>>(b, N, T); else k_burst<20><<<N / 256, 256>>>(b, N, T); };

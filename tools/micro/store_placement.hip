@@ -112,6 +112,38 @@ __global__ void __launch_bounds__(256) k_cycle(int* __restrict__ buf, int N, int
     }
 }
 
+// plane-specialised waves: a 768-thread workgroup handles 256 envs, threads 0..255 store plane 0, 256..511 plane 1,
+// 512..767 plane 2 (each recomputes the cheap value chain): every WAVE writes one stream
+__global__ void __launch_bounds__(768) k_split3(int* __restrict__ buf, int N, int T)
+{
+    const unsigned which = threadIdx.x >> 8;
+    const unsigned e = blockIdx.x * 256 + (threadIdx.x & 255);
+    const size_t plane = (size_t)N * T;
+    int s = e;
+    size_t o = e + which * plane;
+    for (int t = 0; t < T; ++t) {
+        s = s * 1664525 + 1013904223;
+        buf[o] = which == 0 ? s : which == 1 ? (s >> 3) : (s & 1);
+        o += N;
+    }
+}
+
+// the same with the three planes' waves in DIFFERENT workgroups (grid = 3 x N / 256)
+__global__ void __launch_bounds__(256) k_split3_blocks(int* __restrict__ buf, int N, int T)
+{
+    const unsigned nb = N / 256;
+    const unsigned which = blockIdx.x / nb;
+    const unsigned e = (blockIdx.x % nb) * 256 + threadIdx.x;
+    const size_t plane = (size_t)N * T;
+    int s = e;
+    size_t o = e + which * plane;
+    for (int t = 0; t < T; ++t) {
+        s = s * 1664525 + 1013904223;
+        buf[o] = which == 0 ? s : which == 1 ? (s >> 3) : (s & 1);
+        o += N;
+    }
+}
+
 // [t][3][N] with the three stores of a step spaced by dependent integer work
 template <int GAP>
 __global__ void __launch_bounds__(256) k_rows3_spaced(int* __restrict__ buf, int N, int T)
@@ -250,6 +282,22 @@ int main(int argc, char** argv)
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&ms, e0, e1));
             printf("buffer %2d: three planes, one store per loop iteration (plane cycling): %.1f us\n", i, ms / reps * 1e3f);
+        }
+        {
+            float t768, t3b;
+            for (int r = 0; r < 2; ++r) k_split3<<<N / 256, 768>>>(b, N, T);
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) k_split3<<<N / 256, 768>>>(b, N, T);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            t768 = ms / reps * 1e3f;
+            for (int r = 0; r < 2; ++r) k_split3_blocks<<<3 * N / 256, 256>>>(b, N, T);
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) k_split3_blocks<<<3 * N / 256, 256>>>(b, N, T);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            t3b = ms / reps * 1e3f;
+            printf("buffer %2d: plane-specialised waves: one 768-thread workgroup per 256 envs %.1f us | three 256-thread workgroups %.1f us\n", i, t768, t3b);
         }
         float bu[3];
         for (int v = 0; v < 3; ++v) {

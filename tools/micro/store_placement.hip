@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(256) k_var(int* __restrict__ buf, int N, int T
 }
 
 // three planes, the three stores of a step SPACED by dependent integer work instead of issued back to back
+// (GAP = s_sleep argument between the stores: 64 clocks each; a chain of multiply-adds would be folded by the compiler)
 template <int GAP>
 __global__ void __launch_bounds__(256) k_spaced(int* __restrict__ buf, int N, int T)
 {
@@ -34,15 +35,13 @@ __global__ void __launch_bounds__(256) k_spaced(int* __restrict__ buf, int N, in
     int s = e;
     size_t o = e;
     for (int t = 0; t < T; ++t) {
-#pragma unroll
-        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        s = s * 1664525 + 1013904223;
         buf[o] = s;
-#pragma unroll
-        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        __builtin_amdgcn_s_sleep(GAP);
         buf[plane + o] = s >> 3;
-#pragma unroll
-        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        __builtin_amdgcn_s_sleep(GAP);
         buf[2 * plane + o] = s & 1;
+        __builtin_amdgcn_s_sleep(GAP);
         o += N;
     }
 }
@@ -152,15 +151,13 @@ __global__ void __launch_bounds__(256) k_rows3_spaced(int* __restrict__ buf, int
     int s = e;
     size_t o = e;
     for (int t = 0; t < T; ++t) {
-#pragma unroll
-        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        s = s * 1664525 + 1013904223;
         buf[o] = s;
-#pragma unroll
-        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        __builtin_amdgcn_s_sleep(GAP);
         buf[o + N] = s >> 3;
-#pragma unroll
-        for (int g = 0; g < GAP; ++g) s = s * 1664525 + 1013904223;
+        __builtin_amdgcn_s_sleep(GAP);
         buf[o + 2 * (size_t)N] = s & 1;
+        __builtin_amdgcn_s_sleep(GAP);
         o += 3 * (size_t)N;
     }
 }
@@ -245,7 +242,7 @@ int main(int argc, char** argv)
         const float aos = ms / reps * 1e3f;
         float sp[3];
         for (int v = 0; v < 3; ++v) {
-            auto launch = [&] { if (v == 0) k_spaced<1><<<N / 256, 256>>>(b, N, T); else if (v == 1) k_spaced<4><<<N / 256, 256>>>(b, N, T); else k_spaced<12><<<N / 256, 256>>>(b, N, T); };
+            auto launch = [&] { if (v == 0) k_spaced<1><<<N / 256, 256>>>(b, N, T); else if (v == 1) k_spaced<2><<<N / 256, 256>>>(b, N, T); else k_spaced<4><<<N / 256, 256>>>(b, N, T); };
             for (int r = 0; r < 2; ++r) launch();
             CK(hipEventRecord(e0));
             for (int r = 0; r < reps; ++r) launch();
@@ -255,7 +252,7 @@ int main(int argc, char** argv)
         }
         float r3[3];
         for (int v = 0; v < 3; ++v) {
-            auto launch = [&] { if (v == 0) k_rows3_spaced<1><<<N / 256, 256>>>(b, N, T); else if (v == 1) k_rows3_spaced<4><<<N / 256, 256>>>(b, N, T); else k_rows3_spaced<12><<<N / 256, 256>>>(b, N, T); };
+            auto launch = [&] { if (v == 0) k_rows3_spaced<1><<<N / 256, 256>>>(b, N, T); else if (v == 1) k_rows3_spaced<2><<<N / 256, 256>>>(b, N, T); else k_rows3_spaced<4><<<N / 256, 256>>>(b, N, T); };
             for (int r = 0; r < 2; ++r) launch();
             CK(hipEventRecord(e0));
             for (int r = 0; r < reps; ++r) launch();
@@ -263,7 +260,7 @@ int main(int argc, char** argv)
             CK(hipEventElapsedTime(&ms, e0, e1));
             r3[v] = ms / reps * 1e3f;
         }
-        printf("buffer %2d: [t][3][N] spaced by 1 / 4 / 12: %.1f / %.1f / %.1f us\n", i, r3[0], r3[1], r3[2]);
+        printf("buffer %2d: [t][3][N] spaced by s_sleep 1 / 2 / 4: %.1f / %.1f / %.1f us\n", i, r3[0], r3[1], r3[2]);
         float da[3];
         for (int v = 0; v < 3; ++v) {
             auto launch = [&] { if (v == 0) k_data<0><<<N / 256, 256>>>(b, N, T); else if (v == 1) k_data<1><<<N / 256, 256>>>(b, N, T); else k_data<2><<<N / 256, 256>>>(b, N, T); };
@@ -310,7 +307,7 @@ int main(int argc, char** argv)
             bu[v] = ms / reps * 1e3f;
         }
         printf("buffer %2d: 3 planes, stored plane by plane in bursts of 4 / 8 / 20 rows: %.1f / %.1f / %.1f us\n", i, bu[0], bu[1], bu[2]);
-        printf("buffer %2d: three streams %.1f us   one stream %.1f us   [t][N][3] %.1f us   3 planes, stores spaced by 1 / 4 / 12 mul-adds: %.1f / %.1f / %.1f us\n", i, three, one, aos, sp[0], sp[1], sp[2]);
+        printf("buffer %2d: three streams %.1f us   one stream %.1f us   [t][N][3] %.1f us   3 planes, stores spaced by s_sleep 1 / 2 / 4: %.1f / %.1f / %.1f us\n", i, three, one, aos, sp[0], sp[1], sp[2]);
     }
     // does the speed depend on where INSIDE one allocation the 786 MB window starts?
     {

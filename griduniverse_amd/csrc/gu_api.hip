@@ -149,7 +149,7 @@ int gu_destroy(gu_handle h)
     gu_comm_free(h);
     gu_vi_free(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    void *bufs[] = {h->d_rows[0], h->d_rows[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions,
+    void *bufs[] = {h->d_rows[0], h->d_rows[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
                     h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -511,30 +511,36 @@ int gu_upload_actions(gu_handle h, const int32_t *actions, int64_t T)
     GU_ENTER(h);
     GU_REQUIRE(actions != nullptr && T > 0, GU_ERR_INVALID, "actions NULL or T <= 0");
     const size_t count = (size_t)T * (size_t)h->N;
-    if (T > h->actions_T) {
+    h->actions_T = 0;  // until the new stream has been accepted
+    if (T > h->actions_cap) {
         GU_HIP(hipStreamSynchronize(h->stream));
         if (h->d_actions) GU_HIP(hipFree(h->d_actions));
+        if (h->d_actions_packed) GU_HIP(hipFree(h->d_actions_packed));
         h->d_actions = nullptr;
-        h->actions_T = 0;
+        h->d_actions_packed = nullptr;
+        h->actions_cap = 0;
         GU_HIP(hipMalloc(&h->d_actions, count * sizeof(int32_t)));
-        h->actions_T = T;
+        GU_HIP(hipMalloc(&h->d_actions_packed, (size_t)((T + 15) / 16 + GU_STREAM_PAD_WORDS) * (size_t)h->N * sizeof(uint32_t)));  // + look-ahead rows
+        h->actions_cap = T;
         if (h->graph_exec) {
             (void)hipGraphExecDestroy(h->graph_exec);
             h->graph_exec = nullptr;
         }
     }
     GU_HIP(hipMemcpyAsync(h->d_actions, actions, count * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    // validated on the device, where the stream now is (one pass at HBM speed instead of a host loop over T x N values)
-    int rc = gu_launch_validate_actions(h, h->d_actions, (int64_t)count);
+    // validated on the device, where the stream now is (one pass at HBM speed instead of a host loop over T x N values), and
+    // packed in the same pass to the two-bit form the rollout kernels read
+    int rc = gu_launch_pack_actions(h, T);
     if (rc != GU_OK) return rc;
     GU_HIP(hipStreamSynchronize(h->stream));
     if (__atomic_load_n(h->h_seq + GU_HOST_ERR_WORD, __ATOMIC_ACQUIRE)) {
         __atomic_store_n(h->h_seq + GU_HOST_ERR_WORD, 0u, __ATOMIC_RELAXED);
-        h->actions_T = 0;  // the rejected stream is not usable (the buffer itself is kept for the next upload)
+        // the rejected stream is not usable (the buffers themselves are kept for the next upload)
         for (size_t i = 0; i < count; ++i)
             if ((uint32_t)actions[i] > 3u) return gu_fail(GU_ERR_INVALID, "action %d at flat index %zu outside 0..3", actions[i], i);
         return gu_fail(GU_ERR_INVALID, "an action outside 0..3 was uploaded");
     }
+    h->actions_T = T;
     return GU_OK;
 }
 

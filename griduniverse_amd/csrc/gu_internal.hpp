@@ -32,6 +32,8 @@
 #define GU_HOST_ERR_WORD 4
 #define GU_HOST_COUNT_WORD 8
 
+#define GU_STREAM_PAD_WORDS 4  // spare rows behind the packed action stream: the rollout kernels read up to four words ahead
+
 struct gu_engine {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -69,7 +71,9 @@ struct gu_engine {
 
     // device-resident action stream
     int32_t *d_actions = nullptr;
-    int64_t actions_T = 0;
+    uint32_t *d_actions_packed = nullptr;  // the same stream, 16 two-bit actions per word: [ceil(T / 16)][N], what the rollout kernels read
+    int64_t actions_T = 0;    // rows of the stream uploaded last (0: none / rejected)
+    int64_t actions_cap = 0;  // rows the two buffers can hold
 
     // trajectory buffers obs|reward|done, each [traj_T][N]
     int32_t *d_traj = nullptr;
@@ -169,6 +173,7 @@ int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, i
                    int32_t *host_reward = nullptr, int32_t *host_done = nullptr, uint32_t *host_seq = nullptr, uint32_t seq = 0,
                    uint32_t *host_err = nullptr);
 int gu_launch_validate_actions(gu_engine *h, const int32_t *d_actions, int64_t count);
+int gu_launch_pack_actions(gu_engine *h, int64_t T);  // validates h->d_actions[0 .. T) and fills h->d_actions_packed
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags);
 int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const int32_t *d_actions, bool care,
                         int32_t *d_next, int32_t *d_reward, int32_t *d_done);

@@ -170,6 +170,27 @@ __global__ void __launch_bounds__(256) gu_validate_actions_kernel(const int32_t 
     if (__ballot(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The uploaded stream as the rollout kernels read it: word [k][env] holds the two-bit actions of steps 16 k .. 16 k + 15 of
+// that env (step t in bits 2 (t & 15) ..), the shape of the uniform policy's RNG word -- one 4-byte read per env and 16 steps
+// instead of 64 bytes.  Validates while it packs (the int32 rows stay: the single-step launches read those).
+__global__ void __launch_bounds__(256) gu_pack_actions_kernel(const int32_t *__restrict__ actions, int64_t N, int64_t T, uint32_t *__restrict__ packed,
+                                                              uint32_t *host_err)
+{
+    const int64_t words = (T + 15) / 16 * N;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = i / N, e = i - k * N;
+        uint32_t word = 0;
+        for (int64_t j = 0; j < 16 && 16 * k + j < T; ++j) {
+            const uint32_t act = (uint32_t)actions[(16 * k + j) * N + e];
+            bad |= act > 3u;
+            word |= (act & 3u) << (2 * j);
+        }
+        packed[i] = word;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------------------------
 // sampling thresholds for GU_POLICY_SAMPLE (the rollout kernel itself: gu_rollout.hpp)
 // ------------------------------------------------------------------------------------
@@ -326,7 +347,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.episode = h->d_episode;
     a.tcount = h->d_tcount;
     a.starts = h->d_starts;
-    a.actions = h->d_actions;
+    a.actions = h->d_actions_packed;
     a.tr_obs = h->d_traj;
     a.tr_reward = h->d_traj ? h->d_traj + rows : nullptr;
     a.tr_done = h->d_traj ? h->d_traj + 2 * rows : nullptr;
@@ -342,6 +363,8 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.gs = gu_grid_sel(h);
     a.rows = nullptr;
     a.row_shift = 0;
+    a.stream_lds_off = 0;
+    a.stream_lds_words = 0;
     const int bs = gu_rollout_block();
     {   // XCD-aware env-block order (GU_ROLLOUT_XCD=0/1, read per launch for A/B runs; see gu_env_block)
         const char *x = std::getenv("GU_ROLLOUT_XCD");
@@ -385,6 +408,16 @@ int gu_launch_validate_actions(gu_engine *h, const int32_t *d_actions, int64_t c
 {
     const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 4096);
     hipLaunchKernelGGL(gu_validate_actions_kernel, dim3(blocks), dim3(256), 0, h->stream, d_actions, count, h->h_seq + GU_HOST_ERR_WORD);
+    GU_HIP(hipGetLastError());
+    return GU_OK;
+}
+
+int gu_launch_pack_actions(gu_engine *h, int64_t T)
+{
+    const int64_t words = (T + 15) / 16 * h->N;
+    const unsigned blocks = (unsigned)std::min<int64_t>((words + 255) / 256, 8192);
+    hipLaunchKernelGGL(gu_pack_actions_kernel, dim3(blocks), dim3(256), 0, h->stream, h->d_actions, (int64_t)h->N, T, h->d_actions_packed,
+                       h->h_seq + GU_HOST_ERR_WORD);
     GU_HIP(hipGetLastError());
     return GU_OK;
 }

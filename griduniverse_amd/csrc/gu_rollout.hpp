@@ -30,7 +30,7 @@ struct RolloutArgs {
     uint32_t *episode;
     const uint32_t *tcount;  // per-env offsets
     const int32_t *starts;
-    const int32_t *actions;  // [T][N]
+    const uint32_t *actions;  // GU_POLICY_STREAM: [ceil(T / 16)][N] words of 16 two-bit actions (gu_pack_actions_kernel)
     int32_t *tr_obs, *tr_reward, *tr_done;  // [T][N] each
     int32_t *ret, *episodes_fin;
     uint64_t *done_bits;  // [ceil(N/64)] wave ballots of the final done flags (episode-done compaction)
@@ -39,6 +39,8 @@ struct RolloutArgs {
     GridSel gs;
     const uint32_t *rows;   // transition-row table [S][4] (gu_rollout_rows.hip)
     int32_t row_shift;      // log2(16 * copies) of that table
+    int32_t stream_lds_off; // GU_POLICY_STREAM, MAP 1: byte offset in LDS of the staged action words [stream_lds_words][blockDim.x] ...
+    int32_t stream_lds_words;  // ... and how many words per lane fit (0: every word is read from HBM when its steps are due)
     int32_t xcd_remap;      // workgroup b works on env block (b % 8) * (blocks / 8) + b / 8: one XCD = one contiguous env range
 };
 
@@ -50,6 +52,43 @@ __device__ __forceinline__ uint32_t gu_env_block(int32_t xcd_remap)
 {
     const uint32_t b = blockIdx.x;
     return xcd_remap ? (b & 7u) * (gridDim.x >> 3) + (b >> 3) : b;
+}
+
+// GU_POLICY_STREAM without LDS staging: steps [i0, T) of the packed stream (gu_pack_actions_kernel: word [k][env] = the two-bit
+// actions of steps 16 k .. 16 k + 15; the buffer carries GU_STREAM_PAD_WORDS spare rows, so the look-ahead never leaves it).
+// Four words are in flight per lane, each re-loaded right after it has been consumed: a word arrives three words (48 steps)
+// before its steps are due -- one word ahead is not enough for the stats-only launches (37 ns per step against ~1 us of HBM
+// latency).  `step16(word)`: sixteen unrolled steps; `step1(act)`: one step.
+template <class S16, class S1>
+__device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint32_t e4, int64_t T, int64_t i0, S16 &&step16, S1 &&step1)
+{
+    const uint32_t row32 = (uint32_t)row;
+    auto word_at = [&](int64_t k, uint32_t c) {
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void *)(pa + k * row), 0, 0xFFFFFFFFu, 0x00020000), e4,
+                                                              c * row32, 0);
+    };
+    int64_t i = i0, k = i0 >> 4;
+    if (i & 15) {  // head: the rest of a word that an earlier step began
+        const uint32_t word = word_at(k, 0);
+        for (; i < T && (i & 15); ++i) step1((word >> (2u * (uint32_t)(i & 15))) & 3u);
+        ++k;
+    }
+    uint32_t w[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) w[c] = word_at(k, c);
+    for (const int64_t full = T >> 4; k + 4 <= full; k += 4, i += 64) {
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const uint32_t word = w[c];
+            asm volatile("" ::"v"(word));  // the wait for THIS word lands here, not behind the load that follows
+            w[c] = word_at(k + 4, c);
+            step16(word);
+        }
+    }
+    for (uint32_t q = 0; i < T; ++i, ++q) {  // fewer than 64 steps are left: words w[0 ..]
+        const uint32_t sel = q >> 4, word = sel == 0 ? w[0] : sel == 1 ? w[1] : sel == 2 ? w[2] : w[3];
+        step1((word >> (2u * (q & 15u))) & 3u);
+    }
 }
 
 // AUTO: 0 = no reset; 1 = auto-reset, single start cell (branch-free selects keyed on the TERM bit of the
@@ -214,30 +253,55 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             }
         }
     } else if (POLICY == GU_POLICY_STREAM) {
-        // Action rows are read 8 at a time, one chunk AHEAD of the steps that consume them: the loads are
-        // independent of the env state, so with one wave per SIMD this is what hides their HBM latency.
-        constexpr int CH = 8;
-        int64_t i = 0;
-        uint32_t cur[CH], nxt[CH];
-        auto load_chunk = [&](uint32_t (&dst)[CH], const char *base) {
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xFFFFFFFFu, 0x00020000);
-#pragma unroll
-            for (int j = 0; j < CH; ++j) dst[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, e4, j * row32, 0);
+        // The uploaded stream arrives packed like the uniform policy's RNG words (16 two-bit actions per env and word,
+        // gu_pack_actions_kernel), always from row 0.
+        const char *pw = pa;  // the word's row base moves (64-bit), the lane offset stays e4
+        auto load_word = [&](uint32_t soff) {
+            return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void *)pw, 0, 0xFFFFFFFFu, 0x00020000), e4, soff, 0);
         };
-        if (a.T >= CH) load_chunk(cur, pa);
-        for (; i + CH <= a.T; i += CH) {
-            pa += CH * row;
-            if (i + 2 * CH <= a.T) load_chunk(nxt, pa);
+        const int64_t KW = (MAP == 1) ? a.stream_lds_words : 0;
+        if (KW) {
+            // A global load in a loop that also streams trajectory stores waits for ALL of them (one counter, out-of-order
+            // completion between the two kinds: s_waitcnt vmcnt(0)), i.e. drains the store pipeline.  So the words are
+            // fetched KW at a time (up to 1024 steps) into this lane's LDS column, and the loop reads them from there
+            // (lgkmcnt).  A lane reads only what it wrote itself: no barrier.
+            uint32_t *sw = reinterpret_cast<uint32_t *>(smem + a.stream_lds_off) + threadIdx.x;
+            const uint32_t bd = blockDim.x;
+            int64_t words_left = (a.T + 15) >> 4, i = 0;
+            while (i < a.T) {
+                const int64_t cnt = words_left < KW ? words_left : KW;
+                int64_t k = 0;
+                for (; k + 8 <= cnt; k += 8) {
+                    uint32_t w[8];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) step(cur[j] & 3u, j * row32);
-            if (TRAJ) rebase(CH);
+                    for (int j = 0; j < 8; ++j) w[j] = load_word(j * row32);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
-        }
-        for (; i < a.T; ++i) {  // tail
-            const uint32_t act = (uint32_t)(*(const int32_t *)(pa + e4)) & 3u;
-            pa += row;
-            step1(act);
+                    for (int j = 0; j < 8; ++j) sw[(k + j) * bd] = w[j];
+                    pw += 8 * row;
+                }
+                for (; k < cnt; ++k, pw += row) sw[k * bd] = load_word(0);
+                words_left -= cnt;
+                const int64_t steps = (a.T - i) < cnt * 16 ? (a.T - i) : cnt * 16;
+                uint32_t word = sw[0];
+                for (k = 0; k * 16 + 16 <= steps; ++k) {
+                    const uint32_t next = k + 1 < cnt ? sw[(k + 1) * bd] : 0u;  // one word ahead of its steps
+#pragma unroll
+                    for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                    if (TRAJ) rebase(16);
+                    word = next;
+                }
+                for (int64_t q = k * 16, j = 0; q < steps; ++q, ++j) step1((word >> (2u * (uint32_t)j)) & 3u);  // tail of the stream
+                i += steps;
+            }
+        } else {
+            gu_stream_run(
+                pa, row, e4, a.T, 0,
+                [&](uint32_t word) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                    if (TRAJ) rebase(16);
+                },
+                step1);
         }
     } else {
         // Table policies: greedy[] / the sampling thresholds are read at the post-reset position, so the lazy reset
@@ -342,7 +406,20 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
             b.pi_lds = 1;
             lds += (size_t)h->S * sizeof(uint4);
         }
-        hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 1>), dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), lds, h->stream, b);
+        auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 1>;
+        if (POLICY == GU_POLICY_STREAM && TRAJ != 0) {
+            // staged action words: as many per lane as the LDS share of a block admits at the occupancy this batch needs
+            const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, (gu_blocks(h->N, lds_bs) + 255) / 256));
+            const int64_t room = (int64_t)(160 * 1024) / per_cu - (int64_t)lds - 512;
+            int64_t kw = std::min<int64_t>({room / ((int64_t)lds_bs * 4), (int64_t)64, (a.T + 15) / 16});
+            if (kw >= 4) {
+                b.stream_lds_off = (int32_t)lds;
+                b.stream_lds_words = (int32_t)kw;
+                lds += (size_t)kw * lds_bs * 4;
+            }
+        }
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), lds, h->stream, b);
         return;
     }
     if constexpr (POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM) {

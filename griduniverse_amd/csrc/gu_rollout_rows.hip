@@ -287,32 +287,16 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             pstep(0);
             if (TRAJ) rebase(1);
         }
-    } else {  // GU_POLICY_STREAM: action rows loaded 8 at a time, one chunk ahead of the steps that consume them
-        constexpr int CH = 8;
-        first_step((uint32_t)(*(const int32_t *)(pa + e4)) & 3u);
-        pa += row;
-        int64_t i = 1;
-        uint32_t cur[CH], nxt[CH];
-        auto load_chunk = [&](uint32_t (&dst)[CH], const char *base) {
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xFFFFFFFFu, 0x00020000);
+    } else {  // GU_POLICY_STREAM: packed words of 16 two-bit actions (gu_pack_actions_kernel), see gu_stream_run
+        first_step((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void *)pa, 0, 0xFFFFFFFFu, 0x00020000), e4, 0, 0) & 3u);
+        gu_stream_run(
+            pa, row, e4, a.T, 1,
+            [&](uint32_t word) {
 #pragma unroll
-            for (int j = 0; j < CH; ++j) dst[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ra, e4, j * row32, 0);
-        };
-        if (i + CH <= a.T) load_chunk(cur, pa);
-        for (; i + CH <= a.T; i += CH) {
-            pa += CH * row;
-            if (i + 2 * CH <= a.T) load_chunk(nxt, pa);
-#pragma unroll
-            for (int j = 0; j < CH; ++j) step(cur[j] & 3u, j * row32, nothing);
-            if (TRAJ) rebase(CH);
-#pragma unroll
-            for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
-        }
-        for (; i < a.T; ++i) {
-            const uint32_t act = (uint32_t)(*(const int32_t *)(pa + e4)) & 3u;
-            pa += row;
-            step1(act);
-        }
+                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
+                if (TRAJ) rebase(16);
+            },
+            step1);
     }
     emit(rec, 0);  // the last step's record (row T - 1: every loop above leaves the row base one step behind)
     // resets performed = steps that started from a done env = (done at entry: counted in first_step) + done flags seen

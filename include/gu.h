@@ -154,7 +154,10 @@ int gu_step(gu_handle h, const int32_t *actions, uint32_t flags,
             int32_t *obs, int32_t *reward, int32_t *done);
 
 /* Device-resident action stream [T][N] for gu_step_device / GU_POLICY_STREAM.  Values are validated on the
- * device after the copy; a stream holding anything outside 0..3 is rejected as a whole (GU_ERR_INVALID). */
+ * device after the copy; a stream holding anything outside 0..3 is rejected as a whole (GU_ERR_INVALID).
+ * The upload REPLACES the stream: afterwards it holds exactly rows 0 .. T-1 (a rejected upload leaves none).
+ * Besides the int32 rows (read by the single-step launches) the device keeps the stream packed to two bits
+ * per action, 16 steps per word and env; gu_rollout(GU_POLICY_STREAM) reads that: 0.25 B, not 4 B, per env-step. */
 int gu_upload_actions(gu_handle h, const int32_t *actions, int64_t T);
 /* One step with actions row `t` of the uploaded stream; results stay in HBM (async). */
 int gu_step_device(gu_handle h, int64_t t, uint32_t flags);

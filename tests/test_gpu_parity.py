@@ -530,13 +530,14 @@ def test_c_abi_error_codes():
 
 
 def test_stream_rollout_all_lengths():
-    """The 8-row prefetch pipeline of the STREAM policy: every T around the chunk size, with and without trajectory."""
+    """The packed-word pipeline of the STREAM policy (16 two-bit actions per word, loaded one word ahead): every T around
+    the word size, with and without trajectory; a shorter upload replaces the stream."""
     meta, z = G.load_traj('rect25x30_busy')
     grid = C.Grid.from_lists(**meta)
     N = 200
     acts = z['actions'][:40, :64].repeat(4, axis=1)[:, :N].copy()
     with Engine(N, spec_of(meta), seed=3) as eng:
-        for T in (1, 7, 8, 9, 15, 16, 17, 24, 40):
+        for T in (1, 7, 8, 9, 15, 16, 17, 24, 31, 32, 33, 40):
             for traj in (True, False):
                 st = C.State(N)
                 C.reset(grid, 3, st)
@@ -552,6 +553,13 @@ def test_stream_rollout_all_lengths():
                         assert np.array_equal(got[k], want[k]), (T, k)
                 obs, rew, don = eng.read_outputs()
                 assert np.array_equal(obs, st.pos) and np.array_equal(don, st.done), T
+        eng.upload_actions(acts[:40])
+        eng.upload_actions(acts[:10])  # replaces the 40 rows: the stream now ends at row 10
+        with pytest.raises(gua.GuError):
+            eng.rollout(20, 'stream', True, trajectory=False)
+        with pytest.raises(gua.GuError):
+            eng.step_device(10)
+        eng.step_device(9)
 
 
 def test_pinned_io_paths():

@@ -498,3 +498,29 @@ def test_trajectory_buffer_is_chosen_among_candidates_and_kept_when_large_enough
     with Engine(64, spec_of(meta)) as eng:  # small buffers are simply allocated
         eng.reserve_trajectory(16)
         assert eng.trajectory_placement()[0] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,T', [(300, 2100), (1000, 1024), (70, 1025), (5000, 130)])
+def test_long_action_streams_are_staged_in_lds_in_groups(monkeypatch, N, T):
+    """GU_POLICY_STREAM with trajectory rows reads its packed action words from LDS, refilled every <= 64 words (1024
+    steps) per lane: streams longer than one group, ending on and off a group / word boundary, against the C oracle on
+    the general kernel (the row-table kernel is switched off), int32 and packed rows, then resumed with a second launch."""
+    monkeypatch.setenv('GU_ROLLOUT_ROWS', '0')
+    meta, _ = G.load_traj('c3_maze32')
+    grid, st, eng = _oracle_and_engine(meta, N, 5)
+    acts = np.random.RandomState(T).randint(0, 4, (T, N)).astype(np.int32)
+    with eng:
+        eng.reserve_trajectory(T)
+        eng.upload_actions(acts)
+        for traj in (True, 'packed', True):
+            eng.rollout(T, 'stream', True, traj, stats=True)
+            want = C.rollout(grid, 5, st, T, True, actions=acts, stats=True)
+            got = eng.read_trajectory(0, T) if traj is True else eng.read_trajectory_packed(0, T)
+            for k in got:
+                assert np.array_equal(got[k], want[k]), (traj, k)
+            ret, eps = eng.read_stats()
+            assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes'])
+            s = eng.get_state()
+            for k in ('pos', 'done', 'episode', 'tcount'):
+                assert np.array_equal(s[k], getattr(st, k)), (traj, k)

@@ -15,7 +15,7 @@ random.seed(123)
 np.random.seed(123)
 env = gua.GridUniverseEnv(grid_shape=(32, 32), random_maze=True)
 S, T = env.world.size, 1000
-for N in (65536, 4096):
+for N in (65536, 262144, 4096):
     eng = gua.Engine(N, gua.GridSpec.from_env(env), seed=1)
     eng.reset()
     eng.reserve_trajectory(T)

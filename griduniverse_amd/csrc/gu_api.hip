@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <chrono>
 #include <vector>
 
 // ---------------------------------------------------------------------------------- errors
@@ -605,6 +606,8 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done)
 // the rollout kernel: 117 .. 141 us per launch).  So a large trajectory buffer is CHOSEN: a few candidate allocations are
 // written once in the rollout's own store shape, timed with events, and the fastest one is kept.  A one-off cost of a few
 // milliseconds at reservation; GU_TRAJ_CANDIDATES=1 turns it off (default: up to 12, capped by free memory).
+static double gu_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **out)
 {
     *out = nullptr;
@@ -621,32 +624,74 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
     }
     // The write rates fall into two classes ~15 % apart.  Candidates are allocated and probed one after the other (all are
     // kept until the choice is made: a freed block would simply be handed out again); the search stops at the first one that
-    // is clearly in the fast class -- at least 10 % quicker than the slowest seen -- and otherwise keeps the quickest of `want`.
+    // is clearly in the fast class -- at least 10 % quicker than the slowest seen -- and otherwise keeps the quickest.
+    // Neighbouring allocations tend to share their class (runs of 10 .. 50 GiB of one kind, profiles/r02h_placement_map.txt), so
+    // after `want` back-to-back candidates the search goes FURTHER AFIELD: up to `far` more, each behind a spacer of `stride`
+    // GiB that is held until the end.  hipMalloc / hipFree of such blocks cost ~0.02 .. 0.3 ms, a probe ~0.3 ms.
+    int far = 32;
+    double stride_gib = 3.0;
+    if (const char *s = std::getenv("GU_TRAJ_FAR_CANDIDATES")) far = std::atoi(s);
+    if (const char *s = std::getenv("GU_TRAJ_STRIDE_GIB")) stride_gib = std::atof(s);
+    // What is allocated here is wiped by the driver when it is freed (tens of GB/s, in the background): an allocation made
+    // right after a far search can wait for that, so the search is capped at GU_TRAJ_FAR_GIB (48) GiB held in total.
+    double far_gib = 48.0;
+    if (const char *s = std::getenv("GU_TRAJ_FAR_GIB")) far_gib = std::atof(s);
+    const size_t far_cap = (size_t)(far_gib * 1073741824.0);
+    const size_t stride = (stride_gib > 0.0 && far > 0 && bytes >= ((size_t)256 << 20)) ? (size_t)(stride_gib * 1073741824.0) : 0;  // (buffers of 256 MiB and more)
     std::vector<int32_t *> cand;
+    std::vector<void *> spacers;
     std::vector<float> ms;
-    size_t best = 0;
+    size_t best = 0, held = 0;
     float worst = 0.0f;
-    for (int i = 0; i < want; ++i) {
+    double t_malloc = 0.0, t_probe = 0.0;
+    const char *dbg = std::getenv("GU_TRAJ_DEBUG");
+    const bool exhaustive = dbg && std::atoi(dbg) >= 2;  // measurement aid: probe every candidate
+    auto release = [&](int32_t *keep) {
+        for (int32_t *q : cand)
+            if (q != keep) (void)hipFree(q);
+        for (void *q : spacers) (void)hipFree(q);
+    };
+    for (int i = 0; i < want + (stride ? far : 0); ++i) {
+        if (i >= want) {  // (the first `want` fit in half of the free memory by construction)
+            if (held + stride + bytes > free_b / 2 || held + stride + bytes > far_cap) break;
+            void *sp = nullptr;
+            const double t0 = gu_now_ms();
+            if (hipMalloc(&sp, stride) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            t_malloc += gu_now_ms() - t0;
+            spacers.push_back(sp);
+            held += stride;
+        }
         int32_t *p = nullptr;
+        const double t1 = gu_now_ms();
         if (hipMalloc(&p, bytes) != hipSuccess) {
             (void)hipGetLastError();
             break;
         }
+        const double t2 = gu_now_ms();
+        t_malloc += t2 - t1;
         cand.push_back(p);
+        held += bytes;
         float t = 0.0f;
         int rc = gu_probe_trajectory_buffer(h, p, T, &t);
+        t_probe += gu_now_ms() - t2;
         if (rc != GU_OK) {
-            for (int32_t *q : cand) (void)hipFree(q);
+            release(nullptr);
             return rc;
         }
         ms.push_back(t);
         if (t < ms[best]) best = ms.size() - 1;
         worst = t > worst ? t : worst;
-        if (ms.size() >= 2 && ms[best] <= 0.9f * worst) break;
+        if (ms.size() >= 2 && ms[best] <= 0.9f * worst && !exhaustive) break;
     }
     GU_REQUIRE(!cand.empty(), GU_ERR_NOMEM, "hipMalloc of the %zu-byte trajectory buffer failed", bytes);
-    for (size_t i = 0; i < cand.size(); ++i)
-        if (i != best) (void)hipFree(cand[i]);
+    const double t_rel0 = gu_now_ms();
+    release(cand[best]);
+    if (dbg)
+        fprintf(stderr, "[gu] trajectory placement: %zu candidates, %zu spacers, malloc %.1f ms, probe %.1f ms, free %.1f ms\n", cand.size(), spacers.size(),
+                t_malloc, t_probe, gu_now_ms() - t_rel0);
     *out = cand[best];
     h->traj_candidates = (int32_t)cand.size();
     h->traj_probe_ms_best = ms[best];

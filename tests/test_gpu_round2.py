@@ -498,6 +498,22 @@ def test_trajectory_buffer_is_chosen_among_candidates_and_kept_when_large_enough
     with Engine(64, spec_of(meta)) as eng:  # small buffers are simply allocated
         eng.reserve_trajectory(16)
         assert eng.trajectory_placement()[0] == 1
+    # buffers of 256 MiB and more: when the back-to-back candidates all look alike the search continues behind spacers
+    monkeypatch.setenv('GU_TRAJ_CANDIDATES', '2')
+    monkeypatch.setenv('GU_TRAJ_FAR_CANDIDATES', '3')
+    monkeypatch.setenv('GU_TRAJ_STRIDE_GIB', '1.5')
+    N, T = 65536, 400
+    with Engine(N, spec_of(meta), seed=2) as eng:
+        eng.reset()
+        eng.reserve_trajectory(T)
+        n, best, worst = eng.trajectory_placement()
+        assert 2 <= n <= 5 and 0.0 < best <= worst
+        eng.rollout(T, 'uniform', True, True)
+        got = eng.read_trajectory(T - 1, 1)
+        st = C.State(2048)
+        C.reset(grid, 2, st)
+        want = C.rollout(grid, 2, st, T, True)
+        assert all(np.array_equal(got[k][0, :2048], want[k][T - 1]) for k in got)
 
 
 @pytest.mark.gpu

@@ -11,6 +11,7 @@
 
 #include <rccl/rccl.h>  // types and prototypes only: the library itself is loaded on first use (below)
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -60,6 +61,7 @@ const Rccl *rccl()
             beside = slash == std::string::npos ? std::string() : beside.substr(0, slash + 1);
         }
         std::vector<std::string> names;
+        if (const char *forced = std::getenv("GU_RCCL_LIB")) names.push_back(forced);  // an explicit choice comes first (also: the test double of tests/c_abi/)
         if (!beside.empty()) {
             names.push_back(beside + "librccl.so.1");
             names.push_back(beside + "librccl.so");

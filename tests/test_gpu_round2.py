@@ -540,3 +540,61 @@ def test_long_action_streams_are_staged_in_lds_in_groups(monkeypatch, N, T):
             s = eng.get_state()
             for k in ('pos', 'done', 'episode', 'tcount'):
                 assert np.array_equal(s[k], getattr(st, k)), (traj, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nranks,N', [(2, 4096), (4, 1000), (8, 32768)])
+def test_gathered_view_with_several_ranks_on_one_gpu_through_a_test_double_of_rccl(tmp_path, nranks, N):
+    """RCCL refuses two ranks on one device and only one device is ever at hand, so gu_comm_init with nranks > 1 and the
+    rank-major -> env-major unpack of gu_allgather_view had never run on hardware.  Here GU_RCCL_LIB points libgu at a test
+    double (tests/c_abi/fake_rccl.hip: ranks = threads of one process, all-gather = rendezvous + device-to-device copies);
+    every rank is an engine holding the shard [rank * N, (rank + 1) * N) of one batch.  Every rank's view must equal the
+    single-engine batch of nranks * N envs (8 x 32 768 = config 4).  Own process: the library is chosen once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = tmp_path / 'libfake_rccl.so'
+    build = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-O2', '-o', str(lib),
+                            os.path.join(root, 'tests', 'c_abi', 'fake_rccl.hip')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert build.returncode == 0, build.stdout.decode()[-2000:]
+    code = '''
+import sys, threading
+sys.path.insert(0, %r)
+import numpy as np
+import griduniverse_amd as gua
+nranks, N = %d, %d
+lava = [16 + 32 * r for r in range(24)]
+spec = gua.GridSpec(32, 32, [0], [1023], lava, [])
+whole = gua.Engine(nranks * N, spec, seed=9)
+whole.reset()
+whole.rollout(150, 'uniform', True, False)
+want = whole.read_outputs()
+shards = [gua.Engine(N, spec, seed=9, env_id0=r * N) for r in range(nranks)]
+for e in shards:
+    e.reset()
+    e.rollout(150, 'uniform', True, False)
+uid = gua.Engine.comm_unique_id()
+views, errors = [None] * nranks, []
+def run(r):
+    try:
+        shards[r].comm_init(nranks, r, uid)
+        views[r] = shards[r].allgather_view()
+        views[r] = shards[r].allgather_view()  # (a second gather reuses the communicator)
+        shards[r].comm_destroy()
+    except Exception as exc:
+        errors.append((r, repr(exc)))
+threads = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+[t.start() for t in threads]
+[t.join(120) for t in threads]
+assert not errors, errors
+for r in range(nranks):
+    assert views[r] is not None, r
+    for got, exp, name in zip(views[r], want, ('obs', 'reward', 'done')):
+        assert got.shape == (nranks * N,) and np.array_equal(got, exp), (r, name)
+assert want[2].sum() > 0
+print('VIEW-OK')
+''' % (root, nranks, N)
+    env = dict(os.environ, GU_RCCL_LIB=str(lib))
+    out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
+    assert out.returncode == 0 and b'VIEW-OK' in out.stdout, out.stdout.decode()[-3000:]

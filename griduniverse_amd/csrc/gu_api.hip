@@ -150,7 +150,7 @@ int gu_destroy(gu_handle h)
     gu_comm_free(h);
     gu_vi_free(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    void *bufs[] = {h->d_rows[0], h->d_rows[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
+    void *bufs[] = {h->d_rows[0], h->d_rows[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
                     h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -219,6 +219,11 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
         if (h->d_rows[k]) GU_HIP(hipFree(h->d_rows[k]));
         h->d_rows[k] = nullptr;
         h->rows_shift[k] = -1;
+        if (h->d_mrows[k]) GU_HIP(hipFree(h->d_mrows[k]));
+        if (h->d_mrows1[k]) GU_HIP(hipFree(h->d_mrows1[k]));
+        h->d_mrows[k] = h->d_mrows1[k] = nullptr;
+        h->mrows_K[k] = 0;
+        h->mrows_shift[k] = -1;
     }
     if (h->d_prow) GU_HIP(hipFree(h->d_prow));
     h->d_prow = nullptr;

@@ -85,6 +85,9 @@ struct gu_engine {
     // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in
     uint32_t *d_rows[2] = {nullptr, nullptr};
     int rows_shift[2] = {-1, -1};   // log2(16 * copies) the table was built for (-1: not built)
+    // K-step tables of the statistics-only uniform rollout (gu_rollout_multi.hip) and the one-step tables that go with them
+    uint32_t *d_mrows[2] = {nullptr, nullptr}, *d_mrows1[2] = {nullptr, nullptr};
+    int mrows_K[2] = {0, 0}, mrows_shift[2] = {-1, -1};  // what they were built for (K = 0: not built)
     uint32_t *d_prow = nullptr;     // rows of the table policies (greedy: [S], sampled: [S][8]), rebuilt by every launch
 
     // rollout stats

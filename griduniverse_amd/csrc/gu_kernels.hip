@@ -373,7 +373,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     }
     if (policy == GU_POLICY_SAMPLE)
         hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
-    if (gu_rollout_rows(h, a, policy, auto_mode, traj, stats)) {
+    if (gu_rollout_multi(h, a, policy, auto_mode, traj, stats) || gu_rollout_rows(h, a, policy, auto_mode, traj, stats)) {
         GU_HIP(hipGetLastError());
         h->steps_taken += (uint32_t)T;
         return GU_OK;

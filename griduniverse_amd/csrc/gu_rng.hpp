@@ -45,7 +45,9 @@ __host__ __device__ __forceinline__ uint32_t gu_rng_prefix(uint32_t seed_prefix,
     return gu_mm3_block(seed_prefix, env);
 }
 
-__host__ __device__ __forceinline__ uint32_t gu_rng_word(uint32_t prefix, uint32_t stream, uint32_t ctr)
+// The word in two halves, so that a latency-bound loop can place each half in the shadow of a different LDS round trip
+// (gu_rollout_multi.hip): gu_rng_word(p, s, c) == gu_rng_word_finish(gu_rng_word_begin(p, s, c)).
+__host__ __device__ __forceinline__ uint32_t gu_rng_word_begin(uint32_t prefix, uint32_t stream, uint32_t ctr)
 {
     uint32_t h = gu_mm3_block(prefix, (stream << 28) | (ctr & 0x0FFFFFFFu));
     uint32_t len = 16u;
@@ -66,11 +68,20 @@ __host__ __device__ __forceinline__ uint32_t gu_rng_word(uint32_t prefix, uint32
 #endif
     h ^= len;
     h ^= h >> 16;
-    h *= 0x85EBCA6Bu;
+    return h * 0x85EBCA6Bu;
+}
+
+__host__ __device__ __forceinline__ uint32_t gu_rng_word_finish(uint32_t h)
+{
     h ^= h >> 13;
     h *= 0xC2B2AE35u;
     h ^= h >> 16;
     return h;
+}
+
+__host__ __device__ __forceinline__ uint32_t gu_rng_word(uint32_t prefix, uint32_t stream, uint32_t ctr)
+{
+    return gu_rng_word_finish(gu_rng_word_begin(prefix, stream, ctr));
 }
 
 // index into starts[] for episode `ep` (multiply-shift range reduction)

@@ -476,3 +476,5 @@ void gu_rollout_greedy(gu_engine *h, const RolloutArgs &a, int auto_mode, int tr
 void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
 // the transition-row kernel (gu_rollout_rows.hip): true when it took the launch
 bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);
+// the K-step kernel (gu_rollout_multi.hip; uniform policy, no trajectory): true when it took the launch
+bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);

@@ -580,6 +580,29 @@ def capture_big_digest():
     json.dump(store, open(path, 'w'), indent=1)
 
 
+def capture_stream_digests():
+    """Caller-supplied action streams at config sizes (`RandomState(seed).randint(0, 4, (T, N))`), stepped by the
+    reference itself and kept as sha256 digests: what the STREAM policy (gu_upload_actions + gu_rollout) must reproduce.
+    The stream seed is part of the fixture; T = 1000 is not a multiple of the 16-action word of the device's packed form."""
+    path = os.path.join(OUT, 'digests.json')
+    store = json.load(open(path))
+
+    def one(name, env, seed, stream_seed, N, T, auto_reset):
+        env_ids = list(range(N))
+        actions = np.random.RandomState(stream_seed).randint(0, 4, size=(T, N)).astype(np.int32)
+        obs, rew, don, _ = rollout(env, actions, seed, env_ids, auto_reset)
+        store[name] = dict(spec_of(env), seed=int(seed), N=N, T=T, auto_reset=bool(auto_reset), stream_seed=int(stream_seed),
+                           actions='numpy.random.RandomState(stream_seed).randint(0, 4, size=(T, N)).astype(int32)',
+                           sha256=digest(obs, rew, don), sum_reward=int(rew.sum()), sum_done=int(don.sum()),
+                           sha256_final_obs=hashlib.sha256(obs[-1].astype('<i4').tobytes()).hexdigest())
+        print('digest', name, store[name]['sha256'][:16])
+
+    one('c2_open8x8_stream_4096x1000', ref_env(grid_shape=(8, 8)), 2, 1002, 4096, 1000, True)
+    one('c3_maze32_stream_4096x1000', seeded_maze_env(32, 32, 123), 123, 1003, 4096, 1000, True)
+    one('c4_lava32_stream_absorbing_4096x1000', ref_env(grid_shape=(32, 32), lava_states=lava_column_32()), 4, 1004, 4096, 1000, False)
+    json.dump(store, open(path, 'w'), indent=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     random.seed(0)
@@ -603,6 +626,8 @@ def main():
         json.dump(capture_bfs(), open(os.path.join(OUT, 'bfs.json'), 'w'), indent=1)
     if 'big' in what:
         capture_big_digest()
+    if 'stream' in what:
+        capture_stream_digests()
     if 'traj' in what:
         path = os.path.join(OUT, 'digests.json')
         store = json.load(open(path)) if os.path.exists(path) else {}

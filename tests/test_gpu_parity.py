@@ -4,6 +4,7 @@
  (c) size-independent properties (resumability, shard independence, absorbing terminals).
 Bit-exact throughout: this is integer / index work."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -88,8 +89,23 @@ def test_reference_digests(name):
     with fresh(d) as eng:
         eng.reset()
         eng.reserve_trajectory(d['T'])
-        eng.rollout(d['T'], 'uniform', d['auto_reset'])
-        out = eng.read_trajectory(0, d['T'])
+        if 'stream_seed' in d:  # a caller-supplied stream (numpy's RandomState), stepped by the reference: the STREAM policy
+            eng.upload_actions(np.random.RandomState(d['stream_seed']).randint(0, 4, size=(d['T'], d['N'])).astype(np.int32))
+            outs = []
+            for rows in ('1', '0'):  # the row-table kernel and the general kernel (packed words staged in LDS)
+                os.environ['GU_ROLLOUT_ROWS'] = rows
+                try:
+                    eng.seed(d['seed'])
+                    eng.reset()
+                    eng.rollout(d['T'], 'stream', d['auto_reset'])
+                finally:
+                    del os.environ['GU_ROLLOUT_ROWS']
+                outs.append(eng.read_trajectory(0, d['T']))
+            assert all(np.array_equal(outs[0][k], outs[1][k]) for k in outs[0])
+            out = outs[0]
+        else:
+            eng.rollout(d['T'], 'uniform', d['auto_reset'])
+            out = eng.read_trajectory(0, d['T'])
     assert digest(out['obs'], out['reward'], out['done']) == d['sha256']
     assert int(out['reward'].sum()) == d['sum_reward'] and int(out['done'].sum()) == d['sum_done']
 

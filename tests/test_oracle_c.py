@@ -117,7 +117,10 @@ def test_large_digests(name):
     grid = C.Grid.from_lists(**d)
     st = C.State(d['N'])
     C.reset(grid, d['seed'], st)
-    out = C.rollout(grid, d['seed'], st, d['T'], d['auto_reset'])
+    acts = None
+    if 'stream_seed' in d:  # a caller-supplied stream (numpy's RandomState) instead of the counter RNG's actions
+        acts = np.random.RandomState(d['stream_seed']).randint(0, 4, size=(d['T'], d['N'])).astype(np.int32)
+    out = C.rollout(grid, d['seed'], st, d['T'], d['auto_reset'], actions=acts)
     assert digest(out['obs'], out['reward'], out['done']) == d['sha256']
     assert int(out['reward'].sum()) == d['sum_reward'] and int(out['done'].sum()) == d['sum_done']
 

@@ -59,7 +59,8 @@ __device__ __forceinline__ uint32_t gu_env_block(int32_t xcd_remap)
 // Four words are in flight per lane, each re-loaded right after it has been consumed: a word arrives three words (48 steps)
 // before its steps are due -- one word ahead is not enough for the stats-only launches (37 ns per step against ~1 us of HBM
 // latency).  `step16(word)`: sixteen unrolled steps; `step1(act)`: one step.
-template <class S16, class S1>
+// TAIL16: the full words among the last < 64 steps also go through step16 (one more inlined copy of it) instead of step1.
+template <bool TAIL16 = false, class S16, class S1>
 __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint32_t e4, int64_t T, int64_t i0, S16 &&step16, S1 &&step1)
 {
     const uint32_t row32 = (uint32_t)row;
@@ -85,7 +86,14 @@ __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint3
             step16(word);
         }
     }
-    for (uint32_t q = 0; i < T; ++i, ++q) {  // fewer than 64 steps are left: words w[0 ..]
+    uint32_t q = 0;  // fewer than 64 steps are left: words w[0 ..]
+    if (TAIL16) {
+        for (; i + 16 <= T; i += 16, q += 16) {
+            const uint32_t sel = q >> 4;
+            step16(sel == 0 ? w[0] : sel == 1 ? w[1] : w[2]);
+        }
+    }
+    for (; i < T; ++i, ++q) {
         const uint32_t sel = q >> 4, word = sel == 0 ? w[0] : sel == 1 ? w[1] : sel == 2 ? w[2] : w[3];
         step1((word >> (2u * (q & 15u))) & 3u);
     }

@@ -1,9 +1,10 @@
-// gu_rollout_multi.hip -- K env-steps per LDS round trip: the uniform-policy rollout that keeps only per-env statistics
-// (no trajectory), on a K-STEP transition table.
+// gu_rollout_multi.hip -- K env-steps per LDS round trip: the uniform-policy (or caller-supplied-stream) rollout that keeps
+// only per-env statistics (no trajectory), on a K-STEP transition table.
 //
 // gu_rollout_rows.hip brought a step down to one v_and_or_b32 + one ds_read_b32; at one wave per SIMD that round trip (~90
 // clocks) IS the step.  The uniform policy's actions do not depend on the env state -- they are two-bit fields of a counter-RNG
-// word -- so the transitions of K consecutive steps can be composed ahead of time:
+// word (a caller-supplied stream is packed into the same shape by gu_upload_actions) -- so the transitions of K consecutive
+// steps can be composed ahead of time:
 //
 //     rowK[s][a1 | a2 << 2 | ..] = { LDS byte address of rowK[cell after the K steps]  : bits 0..17
 //                                    number of done flags raised by the K steps        : bits 18..20
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256) gu_build_multi_rows_kernel(const BuildMul
 
 typedef __attribute__((address_space(3))) const uint32_t *lds_u32_ptr;
 
-template <int K, bool STATS>
+template <int POLICY, int K, bool STATS>
 __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_multi_kernel(const RolloutArgs a, const int32_t auto_reset, const uint32_t *__restrict__ rows1,
                                                                         const int32_t shiftK)
 {
@@ -131,11 +132,15 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_multi_kernel(const Ro
         rec = (rec & ~GU_MROW_ADDR_MASK) | ((cell << 4) + base1);
     };
 
-    uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+    const char *pa = (const char *)a.actions;  // GU_POLICY_STREAM: packed words [ceil(T / 16) + pad][N], always from row 0
+    const uint32_t e4 = e * 4u;
+    uint32_t word = POLICY == GU_POLICY_STREAM
+                        ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void *)pa, 0, 0xFFFFFFFFu, 0x00020000), e4, 0, 0)
+                        : gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
     {
         // first step of the launch, on the per-cell planes: the stored done flag decides the lazy reset (it may disagree with
         // the cell: fresh reset onto a terminal start, gu_set_state)
-        const uint32_t act = (word >> (2u * (t & 15u))) & 3u;
+        const uint32_t act = POLICY == GU_POLICY_STREAM ? (word & 3u) : ((word >> (2u * (t & 15u))) & 3u);
         if (auto_reset && d_entry) s = a.starts[0];
         const uint32_t f0 = a.cell[s];
         s += ((f0 >> act) & 1u) ? gu_delta<false>(act, 0, a.W) : 0;
@@ -146,7 +151,25 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_multi_kernel(const Ro
     }
     int64_t rem = a.T - 1;
     const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);
-    if (__all(t == t_first)) {
+    if (POLICY == GU_POLICY_STREAM) {
+        // the caller's stream: row i of the stream is step i of the launch, so groups are aligned to the launch, and every
+        // lane is at the same position; words arrive four ahead of their steps (gu_stream_run)
+        bool in_multi = false;
+        gu_stream_run<true>(
+            pa, a.N * 4, e4, a.T, 1,
+            [&](uint32_t w16) {
+                if (!in_multi) to_multi();
+                in_multi = true;
+#pragma unroll
+                for (uint32_t j = 0; j < 16 / K; ++j) group(__builtin_amdgcn_ubfe(w16, 2 * K * j, 2 * K));
+            },
+            [&](uint32_t act) {
+                if (in_multi) to_single();
+                in_multi = false;
+                single(act);
+            });
+        if (in_multi) to_single();
+    } else if (__all(t == t_first)) {
         // every lane of the wave is at the same step count (always, unless gu_set_state installed per-env counters): the
         // position inside the RNG word is wave-uniform, the bit-field offsets of the unrolled body are constants
         uint32_t tu = t_first, have = (tu - 1u) >> 4;  // `have`: index of the word held in `word`
@@ -253,7 +276,7 @@ static bool multi_shape(const gu_engine *h, int *K, int *block, int *copies)
 // Returns true when the launch was taken by the K-step kernel.
 bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats)
 {
-    if (policy != GU_POLICY_UNIFORM || traj != 0 || auto_mode == 2 || h->n_grids != 1) return false;
+    if ((policy != GU_POLICY_UNIFORM && policy != GU_POLICY_STREAM) || traj != 0 || auto_mode == 2 || h->n_grids != 1) return false;
     const int mode = multi_mode();
     if (mode == 0 || (mode != 1 && a.T < 64)) return false;  // (short launches: the second table's staging is not worth it)
     int K = 0, bs = 0, copies = 0;
@@ -284,9 +307,9 @@ bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode
     const size_t lds = ((size_t)h->S << shift) + (size_t)h->S * 16;
     const dim3 grid(gu_blocks(h->N, bs)), block(bs);
     a.xcd_remap = a.xcd_remap && grid.x % 8 == 0;
-#define GU_MULTI_LAUNCH(KK, ST)                                                                                              \
+#define GU_MULTI_LAUNCH_P(PP, KK, ST)                                                                                        \
     do {                                                                                                                     \
-        auto kern = gu_rollout_multi_kernel<KK, ST>;                                                                         \
+        auto kern = gu_rollout_multi_kernel<PP, KK, ST>;                                                                     \
         static size_t allowed = 64 * 1024;                                                                                   \
         if (lds > allowed) {                                                                                                 \
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
@@ -294,11 +317,17 @@ bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode
         }                                                                                                                    \
         hipLaunchKernelGGL(kern, grid, block, lds, h->stream, a, which, h->d_mrows1[which], shift);                          \
     } while (0)
+#define GU_MULTI_LAUNCH(KK, ST)                                                          \
+    do {                                                                                 \
+        if (policy == GU_POLICY_STREAM) GU_MULTI_LAUNCH_P(GU_POLICY_STREAM, KK, ST);     \
+        else GU_MULTI_LAUNCH_P(GU_POLICY_UNIFORM, KK, ST);                               \
+    } while (0)
     if (K == 4) {
         if (stats) GU_MULTI_LAUNCH(4, true); else GU_MULTI_LAUNCH(4, false);
     } else {
         if (stats) GU_MULTI_LAUNCH(2, true); else GU_MULTI_LAUNCH(2, false);
     }
 #undef GU_MULTI_LAUNCH
+#undef GU_MULTI_LAUNCH_P
     return true;
 }

@@ -606,7 +606,7 @@ print('VIEW-OK')
                                           ('rect25x30_busy', ''), ('c5_maze64', '')])
 def test_k_step_kernel_equals_the_oracle(monkeypatch, name, force_k):
     """gu_rollout_multi.hip composes K consecutive transitions (K = 4 up to 64 cells, K = 2 up to ~2000; larger grids fall
-    through to the row-table kernel) for uniform-policy launches that keep only statistics.  Chains of launches of every
+    through to the row-table kernel) for uniform-policy and caller-supplied-stream launches that keep only statistics.  Chains of launches of every
     length around K and around the 16-action RNG word -- so that launches start at every offset inside a word and a group --
     with and without auto-reset, with and without stats, ragged batch sizes, shard offsets; per-env return, episodes, state,
     done compaction against the C oracle after every launch."""
@@ -621,10 +621,15 @@ def test_k_step_kernel_equals_the_oracle(monkeypatch, name, force_k):
         for auto in (True, False):
             grid, st, eng = _oracle_and_engine(meta, N, 33, env_id0=70000)
             with eng:
+                rs = np.random.RandomState(N + auto)
                 for T in (1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 33, 64, 65, 100, 257, 1000):
-                    for stats in (True, False):
-                        eng.rollout(T, 'uniform', auto, False, stats=stats)
-                        want = C.rollout(grid, 33, st, T, auto, stats=True)
+                    for stats, policy in ((True, 'uniform'), (False, 'uniform'), (True, 'stream')):
+                        acts = None
+                        if policy == 'stream':  # the caller's stream, packed on the device into the RNG word's shape
+                            acts = rs.randint(0, 4, (T, N)).astype(np.int32)
+                            eng.upload_actions(acts)
+                        eng.rollout(T, policy, auto, False, stats=stats)
+                        want = C.rollout(grid, 33, st, T, auto, actions=acts, stats=True)
                         if stats:
                             ret, eps = eng.read_stats()
                             assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes']), (name, N, auto, T)

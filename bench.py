@@ -256,6 +256,17 @@ def cpu_baseline_check_final_state(template, seed, env_id0, N, total_steps, stat
                 fields='pos, done, episode, tcount', checker='oracle/gu_oracle.c')
 
 
+def cpu_baseline_check_stats(template, seed, env_id0, T, ret, episodes, n_check=2048):
+    """Per-env return and episode count of a from-reset, statistics-only launch against the C oracle (first `n_check` envs)."""
+    from oracle import c_oracle as C
+    n = min(n_check, ret.size)
+    grid = C.Grid.from_env(template)
+    st = C.State(n, env_id0)
+    C.reset(grid, seed, st)
+    want = C.rollout(grid, seed, st, T, True, trajectory=False, stats=True)
+    return bool(np.array_equal(ret[:n], want['ret']) and np.array_equal(episodes[:n], want['episodes']))
+
+
 # --------------------------------------------------------------------------------------- timing
 class Ranks(object):
     """torch.distributed (gloo, CPU tensors) as rendezvous / barrier / reduction plumbing; a no-op for one process."""
@@ -345,6 +356,38 @@ def timed_region(eng, ranks, T, K, min_seconds, max_blocks=4000):
         kern.append(k)
     both = ranks.reduce(wall + kern, 'MAX')
     return both[:blocks], both[blocks:], wall, (blocks + 1) * K
+
+
+def other_modes(eng, template, seed, env_id0, N, T, K, check):
+    """The same workload in the two launch forms that do not stream 12 bytes per env-step (reported beside `value`, never as
+    it): per-env statistics only (return, episodes finished: no HBM stream at all, bound by the LDS round trip of the
+    K-step transition table), and one packed uint32 per env-step (4 B)."""
+    def launch_ms(**kw):
+        for _ in range(3):
+            eng.rollout(T, 'uniform', auto_reset=True, **kw)
+        eng.sync()
+        eng.timer_begin()
+        for _ in range(K):
+            eng.rollout(T, 'uniform', auto_reset=True, **kw)
+        return eng.timer_end() / K
+
+    out = {}
+    eng.seed(seed)
+    eng.reset()
+    eng.rollout(T, 'uniform', auto_reset=True, trajectory=False, stats=True)
+    ret, episodes = eng.read_stats()
+    ok = cpu_baseline_check_stats(template, seed, env_id0, T, ret, episodes) if check else None
+    ms = launch_ms(trajectory=False, stats=True)
+    out['stats_only'] = {'ms_per_launch': ms, 'value': float(N) * T / ms * 1e3, 'unit': 'env-steps/s (this rank)',
+                         'returns_vs_oracle': ok, 'mean_return_per_env': float(np.mean(ret)),
+                         'is': 'per-env return and episodes finished instead of the trajectory; first launch from reset checked '
+                               'against oracle/gu_oracle.c'}
+    if hasattr(eng, 'read_trajectory_packed'):
+        ms = launch_ms(trajectory='packed')
+        out['packed_rows'] = {'ms_per_launch': ms, 'value': float(N) * T / ms * 1e3, 'unit': 'env-steps/s (this rank)',
+                              'bytes_per_env_step': 4, 'achieved_GBps': 4.0 * N * T / ms / 1e6,
+                              'is': 'obs | reward << 16 | done << 24 in one uint32 per env-step'}
+    return out
 
 
 def spread(values):
@@ -511,6 +554,10 @@ def run(args, engine_cls=None, emit=print):
         checks['final_state_vs_oracle'] = cpu_baseline_check_final_state(template, seed, rank * N, N, launches * T, eng.get_state())
         checks['final_state_vs_oracle']['launches'] = launches
 
+    others = None
+    if not args.no_other_modes and hasattr(eng, 'read_stats'):
+        others = other_modes(eng, template, seed, rank * N, N, T, K, rank == 0 and not args.no_checks)
+
     rccl = None
     if world > 1 or args.gather_view:
         try:
@@ -562,7 +609,7 @@ def run(args, engine_cls=None, emit=print):
             'per_rank': {'ms_per_step': [v[0] / K * 1e3 for v in per_rank],
                          'value': [float(N) * T * K / v[0] for v in per_rank],
                          'is': 'every rank\'s own median block (the N = 1 run of this script reports exactly this figure as `value`)'},
-            'rccl': rccl, 'strong_c4': c4,
+            'rccl': rccl, 'strong_c4': c4, 'other_modes': others,
         }
         line.update(checks)
         if want_cpu:
@@ -586,6 +633,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-checks', action='store_true', help='skip the reference-digest / oracle checks of this run')
     ap.add_argument('--no-strong-c4', action='store_true')
+    ap.add_argument('--no-other-modes', action='store_true', help='skip the statistics-only / packed-row launches reported beside `value`')
     ap.add_argument('--gather-view', action='store_true', help='exercise the RCCL gathered view with one rank too')
     return ap.parse_args(argv)
 

@@ -41,6 +41,9 @@ class OracleEngine(object):
         self.traj = C.rollout(self.grid, self.seed_value, self.state, T, auto_reset, stats=stats)
         self.last_reward = self.traj['reward'][-1].copy()
 
+    def read_stats(self):
+        return self.traj['ret'].copy(), self.traj['episodes'].copy()
+
     def read_trajectory(self, t0, T):
         return {k: self.traj[k][t0:t0 + T] for k in ('obs', 'reward', 'done')}
 

@@ -58,6 +58,8 @@ def test_two_rank_gloo_shards_and_gathered_view(tmp_path):
     assert len(line['per_rank']['value']) == 2 and line['roofline']['traffic_measured_in_this_run'] is False
     assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
     assert line['bit_exact_vs_reference_digest'] is None  # 512 envs x 40 steps is not the captured run
+    other = line['other_modes']['stats_only']
+    assert other['returns_vs_oracle'] is True and other['value'] > 0 and 'packed_rows' not in line['other_modes']  # (the stub has no packed rows)
 
 
 def test_bench_finds_the_reference_digest_of_its_default_run():

@@ -16,17 +16,20 @@ for out in sorted(glob.glob(os.path.join(root, 'pass*.stdout'))):
         print(name, ': no data (', open(os.path.join(root, name + '.stderr')).read()[-300:].strip(), ')')
         continue
     per = defaultdict(lambda: defaultdict(float))  # dispatch id -> counter -> value
+    dur = {}                                       # dispatch id -> kernel duration in us (the profiler's own timestamps)
     for row in csv.DictReader(open(files[0])):
         if 'k3' not in row['Kernel_Name']:
             continue
         per[int(row['Dispatch_Id'])][row['Counter_Name']] += float(row['Counter_Value'])
+        dur[int(row['Dispatch_Id'])] = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3
     ids = sorted(per)
     counters = sorted({c for d in per.values() for c in d})
     print('== %s: %d dispatches, %d buffers' % (name, len(ids), len(times)))
-    print('%-8s %8s  %s' % ('buffer', 'us', '  '.join('%s' % c for c in counters)))
+    print('%-8s %8s %8s  %s' % ('buffer', 'us(evt)', 'us(krn)', '  '.join('%s' % c for c in counters)))
     for b, t in enumerate(times):
         mine = ids[4 * b + 1:4 * b + 4]  # the three timed dispatches
         if len(mine) < 3:
             break
         vals = [sum(per[i][c] for i in mine) / len(mine) for c in counters]
-        print('%-8d %8.1f  %s  %s' % (b, t, '  '.join('%.4g' % v for v in vals), 'FAST' if t < 125 else ''))
+        k = sum(dur[i] for i in mine) / len(mine)
+        print('%-8d %8.1f %8.1f  %s  %s' % (b, t, k, '  '.join('%.4g' % v for v in vals), 'FAST' if k < 125 else ''))

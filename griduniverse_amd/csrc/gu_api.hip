@@ -629,7 +629,7 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
     }
     // The write rates fall into two classes ~15 % apart.  Candidates are allocated and probed one after the other (all are
     // kept until the choice is made: a freed block would simply be handed out again); the search stops at the first one that
-    // is clearly in the fast class -- at least 10 % quicker than the slowest seen -- and otherwise keeps the quickest.
+    // is clearly in the fast class -- at least 14 % quicker than the slowest seen -- and otherwise keeps the quickest.
     // Neighbouring allocations tend to share their class (runs of 10 .. 50 GiB of one kind, profiles/r02h_placement_map.txt), so
     // after `want` back-to-back candidates the search goes FURTHER AFIELD: up to `far` more, each behind a spacer of `stride`
     // GiB that is held until the end.  hipMalloc / hipFree of such blocks cost ~0.02 .. 0.3 ms, a probe ~0.3 ms.
@@ -689,7 +689,11 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
         ms.push_back(t);
         if (t < ms[best]) best = ms.size() - 1;
         worst = t > worst ? t : worst;
-        if (ms.size() >= 2 && ms[best] <= 0.9f * worst && !exhaustive) break;
+        // (in between there are buffers 5 .. 8 % quicker than the slow class: among the back-to-back candidates only one that is
+        // clearly in the fast class, >= 14 % quicker than the slowest seen, ends the search early; one >= 10 % quicker makes the
+        // far phase unnecessary and ends it)
+        const size_t n = ms.size();
+        if (n >= 2 && !exhaustive && (ms[best] <= 0.86f * worst || (ms[best] <= 0.9f * worst && (int)n >= want))) break;
     }
     GU_REQUIRE(!cand.empty(), GU_ERR_NOMEM, "hipMalloc of the %zu-byte trajectory buffer failed", bytes);
     const double t_rel0 = gu_now_ms();

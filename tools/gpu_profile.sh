@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # kernel trace: the driver's own bench command (minus the CPU legs, which launch nothing); counters: a short timed region
 KT="python3 $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-strong-c4"
-BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-checks --no-strong-c4 --min-seconds 0.02"
+BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-checks --no-strong-c4 --no-other-modes --min-seconds 0.02"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $KT > $OUT/kt.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1

@@ -9,6 +9,9 @@ import sys
 from collections import defaultdict
 
 
+# the dominant kernel of bench.py (the general rollout kernel; NOT the row-table / K-step kernels of its `other_modes` launches)
+BENCH_KERNEL = 'gu_rollout_kernel<'
+
 def rows(pattern):
     out = []
     for p in glob.glob(pattern, recursive=True):
@@ -33,14 +36,14 @@ def main():
         stats[k] = dict(calls=len(v), total_ns=sum(v), avg_ns=sum(v) / len(v), min_ns=v[0], median_ns=v[len(v) // 2], max_ns=v[-1])
     summary['kernel_trace'] = stats
     if kt:
-        r = next(x for x in kt if 'rollout' in x['Kernel_Name'])
+        r = next(x for x in kt if BENCH_KERNEL in x['Kernel_Name'])
         summary['rollout_dispatch'] = {k: r.get(k) for k in ('Workgroup_Size_X', 'Grid_Size_X', 'VGPR_Count', 'Accum_VGPR_Count',
                                                              'SGPR_Count', 'LDS_Block_Size', 'Scratch_Size') if k in r}
     # counters: average per rollout dispatch (skip the first, which includes cold caches)
     pmc = defaultdict(list)
     for d in glob.glob(os.path.join(prof, 'pmc_*')):
         for r in rows(os.path.join(d, '**', '*counter_collection.csv')):
-            if 'rollout' in r['Kernel_Name']:
+            if BENCH_KERNEL in r['Kernel_Name']:
                 pmc[r['Counter_Name']].append(float(r['Counter_Value']))
     summary['rollout_pmc_avg_per_dispatch'] = {k: sum(v) / len(v) for k, v in sorted(pmc.items())}
     summary['rollout_pmc_samples'] = {k: len(v) for k, v in sorted(pmc.items())}

@@ -689,11 +689,9 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
         ms.push_back(t);
         if (t < ms[best]) best = ms.size() - 1;
         worst = t > worst ? t : worst;
-        // (in between there are buffers 5 .. 8 % quicker than the slow class: among the back-to-back candidates only one that is
-        // clearly in the fast class, >= 14 % quicker than the slowest seen, ends the search early; one >= 10 % quicker makes the
-        // far phase unnecessary and ends it)
-        const size_t n = ms.size();
-        if (n >= 2 && !exhaustive && (ms[best] <= 0.86f * worst || (ms[best] <= 0.9f * worst && (int)n >= want))) break;
+        // (in between there are buffers 5 .. 8 % quicker than the slow class: only a candidate that is clearly in the fast class,
+        // >= 14 % quicker than the slowest seen, ends the search early)
+        if (ms.size() >= 2 && !exhaustive && ms[best] <= 0.86f * worst) break;
     }
     GU_REQUIRE(!cand.empty(), GU_ERR_NOMEM, "hipMalloc of the %zu-byte trajectory buffer failed", bytes);
     const double t_rel0 = gu_now_ms();

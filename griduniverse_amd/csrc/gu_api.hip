@@ -613,6 +613,27 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done)
 // milliseconds at reservation; GU_TRAJ_CANDIDATES=1 turns it off (default: up to 12, capped by free memory).
 static double gu_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// EXPERIMENT, off by default (GU_TRAJ_UNCACHED=1 turns it on): the trajectory buffer with the uncached memory type (MTYPE_UC:
+// stores do not allocate in L2).  The bare store loop runs 3 .. 5 % faster on every placement class
+// (profiles/r02i_placement_flags.txt) and the rollout kernel 8 % -- 112 against 121 .. 124 us per 65 536 x 1000 launch, 5.73e11
+// env-steps/s in bench.py with the reference digest and the final state intact (profiles/r02i_uncached_ab.txt,
+// r02j_bench_line_uncached.json).  It is NOT the default because kernels that READ such a buffer can see stale bytes:
+// tests/test_gpu_mc.py::test_chunk_boundaries_do_not_change_the_result fails reproducibly when an earlier engine of the process
+// has used the same memory with the default type (cached lines of the old contents survive and uncached reads hit them;
+// poisoning a default-type buffer does not reproduce it, so it is not a read of unwritten rows).  Host copies were never
+// seen to be affected, but nothing here can flush another allocation's L2 lines, so the fast type stays opt-in.
+static hipError_t gu_traj_malloc(int32_t **p, size_t bytes)
+{
+    const char *s = std::getenv("GU_TRAJ_UNCACHED");  // read per allocation: A/B runs switch it inside one process
+    const bool uncached = s ? std::atoi(s) != 0 : GU_TRAJ_UNCACHED_DEFAULT;
+    if (uncached) {
+        const hipError_t e = hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocUncached);
+        if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
+        (void)hipGetLastError();  // a runtime without the flag: the default type
+    }
+    return hipMalloc(p, bytes);
+}
+
 static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **out)
 {
     *out = nullptr;
@@ -622,7 +643,7 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
     if (bytes < ((size_t)64 << 20) || want <= 1 || hipMemGetInfo(&free_b, &total_b) != hipSuccess) want = 1;
     while (want > 1 && (size_t)want * bytes > free_b / 2) --want;  // never hold more than half of what is free, even briefly
     if (want <= 1) {
-        GU_HIP(hipMalloc(out, bytes));
+        GU_HIP(gu_traj_malloc(out, bytes));
         h->traj_candidates = 1;
         h->traj_probe_ms_best = h->traj_probe_ms_worst = 0.0f;
         return GU_OK;
@@ -671,7 +692,7 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
         }
         int32_t *p = nullptr;
         const double t1 = gu_now_ms();
-        if (hipMalloc(&p, bytes) != hipSuccess) {
+        if (gu_traj_malloc(&p, bytes) != hipSuccess) {
             (void)hipGetLastError();
             break;
         }
@@ -717,6 +738,8 @@ int gu_reserve_trajectory(gu_handle h, int64_t T)
     h->traj_T = 0;
     int rc = gu_alloc_trajectory(h, 3 * (size_t)T * (size_t)h->N * sizeof(int32_t), T, &h->d_traj);
     if (rc != GU_OK) return rc;
+    if (const char *poison = std::getenv("GU_TRAJ_POISON"))  // debugging aid: nothing may depend on rows no rollout has written
+        if (std::atoi(poison)) GU_HIP(hipMemsetAsync(h->d_traj, 0x5A, 3 * (size_t)T * (size_t)h->N * sizeof(int32_t), h->stream));
     h->traj_T = T;
     h->traj_kind = 0;
     return GU_OK;

@@ -32,6 +32,7 @@
 #define GU_HOST_ERR_WORD 4
 #define GU_HOST_COUNT_WORD 8
 
+#define GU_TRAJ_UNCACHED_DEFAULT false  // (see gu_traj_malloc: faster, but NOT safe for kernels that read the buffer)
 #define GU_STREAM_PAD_WORDS 4  // spare rows behind the packed action stream: the rollout kernels read up to four words ahead
 
 struct gu_engine {

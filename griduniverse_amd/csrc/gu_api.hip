@@ -619,9 +619,11 @@ static double gu_now_ms() { return std::chrono::duration<double, std::milli>(std
 // env-steps/s in bench.py with the reference digest and the final state intact (profiles/r02i_uncached_ab.txt,
 // r02j_bench_line_uncached.json).  It is NOT the default because kernels that READ such a buffer can see stale bytes:
 // tests/test_gpu_mc.py::test_chunk_boundaries_do_not_change_the_result fails reproducibly when an earlier engine of the process
-// has used the same memory with the default type (cached lines of the old contents survive and uncached reads hit them;
-// poisoning a default-type buffer does not reproduce it, so it is not a read of unwritten rows).  Host copies were never
-// seen to be affected, but nothing here can flush another allocation's L2 lines, so the fast type stays opt-in.
+// has used the same memory before: the FIRST evaluation on the new buffer then differs in a few states while the host's copy
+// of the very same trajectory is correct, before and after.  Poisoning default-type buffers (trajectory and scratch) does not
+// reproduce it, so it is not a read of unwritten bytes; system-scope (sc0 sc1) loads in the readers do not cure it, so it is not
+// a stale L2 line either -- the readers get old bytes from somewhere the uncached stores did not reach (a memory-side cache
+// would fit).  Nothing in user space can flush that, so the fast type stays opt-in.
 static hipError_t gu_traj_malloc(int32_t **p, size_t bytes)
 {
     const char *s = std::getenv("GU_TRAJ_UNCACHED");  // read per allocation: A/B runs switch it inside one process

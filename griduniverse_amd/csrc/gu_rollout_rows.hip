@@ -395,7 +395,10 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     if (mode == 0) return false;
     if (mode != 1) {
         const unsigned blocks = gu_blocks(h->N, 256);
-        const unsigned int32_limit = policy == GU_POLICY_SAMPLE ? 256 : 128;
+        // (a caller-supplied stream with int32 rows: the row-table kernel reads its action words straight from HBM, and a load
+        // among streaming stores waits for all of them -- beyond 16 384 envs the general kernel, which stages the words in LDS,
+        // is the quicker one: 88 against 116 us at 32 768 envs, profiles/r02j_stream_crossover.txt)
+        const unsigned int32_limit = policy == GU_POLICY_SAMPLE ? 256 : policy == GU_POLICY_STREAM ? 64 : 128;
         if ((traj == 1 && blocks > int32_limit) || (traj == 2 && blocks > 256)) return false;
         if (policy == GU_POLICY_SAMPLE && auto_mode != 1) return false;
     }

@@ -27,6 +27,8 @@ and config 4 -- 262 144 envs on the lava grid in total, split over the ranks -- 
 ("strong_c4"), its result checked against the C oracle on every rank (and, on one GPU, against the reference digest).
 """
 import argparse
+import contextlib
+import ctypes
 import hashlib
 import json
 import os
@@ -390,6 +392,24 @@ def other_modes(eng, template, seed, env_id0, N, T, K, check):
     return out
 
 
+@contextlib.contextmanager
+def native_stdout_to_stderr():
+    """RCCL prints a banner (ROCm version, hostname, library path) to the C-level stdout when a communicator comes up, and C
+    stdio flushes it whenever it likes -- after the JSON line, when stdout is a pipe.  The driver reads ONE JSON line from
+    stdout, so everything native code prints inside this block goes to stderr instead."""
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def spread(values):
     v = np.sort(np.asarray(values, dtype=np.float64))
     return float(v[0]), float(np.median(v)), float(v[-1])
@@ -561,7 +581,8 @@ def run(args, engine_cls=None, emit=print):
     rccl = None
     if world > 1 or args.gather_view:
         try:
-            rccl = rccl_view_check(eng, engine_cls, ranks)
+            with native_stdout_to_stderr():
+                rccl = rccl_view_check(eng, engine_cls, ranks)
         except gua.GuError as err:  # reported, not fatal: the throughput line above does not depend on the collective
             rccl = dict(nranks=world, view_equals_shards=None, error=str(err))
     per_rank = ranks.gather([float(np.median(own_wall))])
@@ -616,7 +637,9 @@ def run(args, engine_cls=None, emit=print):
             base = cpu_baseline(template, seed, T)
             base['all_cores'] = all_cores
             line['cpu_baseline'] = base
+        ctypes.CDLL(None).fflush(None)  # whatever native code still holds in its stdout buffer comes BEFORE the line, never after
         emit(json.dumps(line))
+        sys.stdout.flush()
     ranks.close()
 
 

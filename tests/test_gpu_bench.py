@@ -1,0 +1,62 @@
+"""bench.py on the device, as the driver runs it (one JSON line on stdout), at sizes that finish in seconds: the contract
+fields, the checks the line carries about itself, and the 1-rank RCCL view."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), cwd=ROOT, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=900)
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_default_workload_line_carries_the_contract_and_its_own_checks():
+    """Config 3 at full size (65 536 envs x 1000 steps per launch), few launches: metric / unit / config as BASELINE.json names
+    them, value = envs x steps x launches / time, the roofline object consistent with the HIP-event launch time, the first
+    launch equal to the reference's digest, the final state equal to the oracle, and the CPU baseline beside it."""
+    line = run_bench('--gpus', '1', '--steps', '5', '--warmup', '2', '--min-seconds', '0.05', '--c4-envs', '16384', '--gather-view')
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+    assert line['metric'] == base['metric'] and line['unit'] == 'env-steps/s' and line['n_gpus'] == 1
+    assert line['steps'] == 5 and line['warmup'] == 2 and line['higher_is_better'] is True and line['scaling'] == 'weak'
+    assert line['vs_baseline'] is None and line['dtype'] == 'int32' and line['data'] == 'synthetic'
+    assert line['config']['workload'].startswith('c3: 65536 envs per GPU') and line['config']['envs_per_gpu'] == 65536
+    assert abs(line['value'] - 65536 * 1000 / (line['ms_per_step'] / 1e3)) < 1e-6 * line['value']
+    roof = line['roofline']
+    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0 and roof['traffic_measured_in_this_run'] is False
+    assert roof['algorithmic_bytes_per_launch'] == 12 * 65536 * 1000
+    assert abs(roof['achieved'] - roof['algorithmic_bytes_per_launch'] / (roof['launch_ms'] / 1e3) / 1e9) < 1e-6 * roof['achieved']
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-12 and 0.3 < roof['frac'] < 1.0
+    assert roof['launch_ms'] <= line['ms_per_step'] * 1.02  # the kernel cannot take longer than the step that contains it
+    assert line['bit_exact_vs_reference_digest'] is True and line['bit_exact_vs_oracle'] is True
+    assert line['final_state_vs_oracle']['equal'] is True and line['final_state_vs_oracle']['launches'] == line['timing']['launches_total']
+    assert line['engine'] == 'griduniverse_amd.engine.Engine'
+    cpu = line['cpu_baseline']
+    assert cpu['kind'] == 'port' and cpu['cores'] == 1 and cpu['value'] > 1e5 and cpu['unit'] == 'env-steps/s'
+    assert line['rccl']['nranks'] == 1 and line['rccl']['view_equals_shards'] is True
+    c4 = line['strong_c4']
+    assert c4['scaling'] == 'strong' and c4['total_envs'] == 16384 and c4['shards_equal_oracle'] is True
+    other = line['other_modes']
+    assert other['stats_only']['returns_vs_oracle'] is True and other['stats_only']['value'] > line['value']
+    assert other['packed_rows']['bytes_per_env_step'] == 4
+
+
+def test_other_workloads_and_switches():
+    """Config 2 (4096 envs, 8x8) with the checks, and a run with everything optional switched off."""
+    line = run_bench('--workload', 'c2', '--envs', '4096', '--steps', '3', '--warmup', '1', '--min-seconds', '0.02', '--no-strong-c4',
+                     '--no-cpu-baseline')
+    assert line['config']['envs_per_gpu'] == 4096 and line['bit_exact_vs_reference_digest'] is True  # 4096 x 1000 is a captured run
+    assert line['final_state_vs_oracle']['equal'] is True and 'cpu_baseline' not in line and line['strong_c4'] is None
+    line = run_bench('--steps', '2', '--warmup', '1', '--min-seconds', '0.02', '--no-strong-c4', '--no-cpu-baseline', '--no-checks',
+                     '--no-other-modes', '--envs', '1000', '--T', '77')
+    assert line['other_modes'] is None and 'bit_exact_vs_reference_digest' not in line and line['value'] > 0

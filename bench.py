@@ -520,7 +520,8 @@ def run(args, engine_cls=None, emit=print):
     if engine_cls is gua.Engine and _lib.is_stale():
         # a checkout whose libgu.so is missing or older than its sources: build it (one rank per node) rather than measure nothing
         if int(os.environ.get('LOCAL_RANK', '0')) == 0:
-            _lib.build()
+            with native_stdout_to_stderr():  # (make's and hipcc's chatter belongs on stderr: stdout carries the one JSON line)
+                _lib.build()
         else:
             deadline = time.time() + 900
             while _lib.is_stale() and time.time() < deadline:

@@ -279,7 +279,9 @@ class Ranks(object):
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             if not dist.is_initialized():
-                dist.init_process_group('gloo', rank=rank, world_size=world)
+                with native_stdout_to_stderr():  # gloo announces its connections on the C++ stdout
+                    dist.init_process_group('gloo', rank=rank, world_size=world)
+                    dist.barrier()
                 self.owns = True
             else:
                 self.owns = False

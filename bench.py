@@ -38,6 +38,9 @@ import time
 
 import numpy as np
 
+# RCCL between processes needs dmabuf IPC on this driver stack (the pool exports this already; harmless when it is set)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -74,3 +74,26 @@ def test_bench_finds_the_reference_digest_of_its_default_run():
         assert bench.reference_digest(name, template, seed, N, T, 64) is None
         assert bench.reference_digest(name, template, seed + 1, N, T, 0) is None
         assert bench.reference_digest(name, template, seed, N // 2, T, 0) is None
+
+
+def test_native_chatter_inside_the_collective_check_never_reaches_stdout():
+    """bench.py prints ONE JSON line on stdout.  RCCL writes a banner to the C-level stdout when a communicator comes up (and C
+    stdio flushes it after the line when stdout is a pipe), gloo announces its connections there too: whatever native code prints
+    inside bench.native_stdout_to_stderr() must land on stderr, in order, and stdout must be usable again afterwards."""
+    code = '''
+import ctypes, sys
+sys.path.insert(0, %r)
+import bench
+libc = ctypes.CDLL(None)
+print("before")
+with bench.native_stdout_to_stderr():
+    libc.puts(b"native chatter")           # buffered by C stdio: would otherwise come out at exit, AFTER everything else
+    print("python chatter inside")
+    sys.stdout.flush()
+print("after")
+''' % ROOT
+    proc = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert proc.returncode == 0, proc.stderr.decode()[-2000:]
+    assert proc.stdout.decode().split() == ['before', 'after']
+    err = proc.stderr.decode()
+    assert 'native chatter' in err and 'python chatter inside' in err

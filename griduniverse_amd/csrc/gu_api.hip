@@ -715,6 +715,9 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
         // (in between there are buffers 5 .. 8 % quicker than the slow class: only a candidate that is clearly in the fast class,
         // >= 14 % quicker than the slowest seen, ends the search early)
         if (ms.size() >= 2 && !exhaustive && ms[best] <= 0.86f * worst) break;
+        // ... or one that is fast in absolute terms (the fast class writes 6.6 .. 6.9 TB/s, the slow one 5.5 .. 5.9): where every
+        // candidate so far is fast there is no slow one to compare with
+        if (!exhaustive && (double)bytes / ((double)ms[best] * 1e-3) >= 6.5e12) break;
     }
     GU_REQUIRE(!cand.empty(), GU_ERR_NOMEM, "hipMalloc of the %zu-byte trajectory buffer failed", bytes);
     const double t_rel0 = gu_now_ms();

@@ -174,7 +174,7 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done);
 int gu_reserve_trajectory(gu_handle h, int64_t T);
 /* Where an allocation lands in HBM decides how fast it can be written (5.7 .. 6.9 TB/s for 786 MB buffers of one process), so
  * gu_reserve_trajectory tries a few candidate allocations of 64 MB and more, writes each once in the rollout's store shape and
- * keeps the fastest (GU_TRAJ_CANDIDATES=n, default up to 12, stopping at the first clearly fast one; 1 = take the first).
+ * keeps the fastest (GU_TRAJ_CANDIDATES=n, default up to 12, stopping at the first clearly fast one -- 14 % quicker than the slowest seen, or 6.5 TB/s in absolute terms; 1 = take the first).
  * Neighbouring allocations tend to share their class, so for buffers of 256 MiB and more the search then goes further afield: up
  * to GU_TRAJ_FAR_CANDIDATES (32) more, each behind a spacer of GU_TRAJ_STRIDE_GIB (3) GiB held until the choice is made; never more
  * than half of the free memory nor GU_TRAJ_FAR_GIB (48) GiB in total.  This reports what it did. */

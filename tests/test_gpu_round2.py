@@ -481,7 +481,7 @@ def test_trajectory_buffer_is_chosen_among_candidates_and_kept_when_large_enough
             assert np.array_equal(eng.reset(), C.reset(grid, 2, st))
             eng.reserve_trajectory(T)
             n, best, worst = eng.trajectory_placement()
-            assert (n == 1 and best == 0.0) if cand == '1' else (2 <= n <= 5 and 0.0 < best <= worst)
+            assert (n == 1 and best == 0.0) if cand == '1' else (1 <= n <= 5 and 0.0 < best <= worst)  # (a candidate that is fast in absolute terms ends the search)
             eng.reserve_trajectory(T // 2)  # large enough already: same buffer, same placement record
             assert eng.trajectory_placement() == (n, best, worst)
             eng.rollout(T // 2, 'uniform', True, True)
@@ -507,7 +507,7 @@ def test_trajectory_buffer_is_chosen_among_candidates_and_kept_when_large_enough
         eng.reset()
         eng.reserve_trajectory(T)
         n, best, worst = eng.trajectory_placement()
-        assert 2 <= n <= 5 and 0.0 < best <= worst
+        assert 1 <= n <= 5 and 0.0 < best <= worst
         eng.rollout(T, 'uniform', True, True)
         got = eng.read_trajectory(T - 1, 1)
         st = C.State(2048)

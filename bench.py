@@ -3,7 +3,12 @@
 
     python bench.py                       # 1 GPU, defaults finish in about a minute
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W      # one rank per GPU (what the driver runs)
+    python bench.py --gpus N              # started plainly: spawns the N ranks itself (before anything touches a GPU)
+    python bench.py --gpus N --single-process   # ONE process, one engine per device, launches issued device after device
+
+The ranks talk to each other on the host only through griduniverse_amd/rendezvous.py (a socket per rank: barrier, max-reduce,
+RCCL's 128-byte id) -- no PyTorch is imported anywhere, whichever way the script is started.
 
 One bench "step" = ONE launch of the hot path over the whole batch: `gu_rollout` advancing every env by T env-steps
 (uniform random actions from the per-env device RNG, harness auto-reset, int32 (obs, reward, done) trajectory written to
@@ -29,10 +34,14 @@ and config 4 -- 262 144 envs on the lava grid in total, split over the ranks -- 
 import argparse
 import contextlib
 import ctypes
+import glob
 import hashlib
+import importlib
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,6 +60,7 @@ from griduniverse_amd import _lib  # noqa: E402
 METRIC = 'env-steps/sec at N_envs on 32×32 grid, 1/2/4/8 MI355X; bit-exact vs CPU'
 BYTES_PER_ENV_STEP = 12       # fused rollout writing the int32 (obs, reward, done) trajectory
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBPS = 6290.0
 C4_TOTAL_ENVS = 262144        # BASELINE.json config 4
 WORKLOAD_SEED = {'c2': 2, 'c3': 123, 'c4': 4}
 REFERENCE_DIGEST = {'c2': 'c2_open8x8_4096x1000', 'c3': 'c3_maze32_65536x1000', 'c4': 'c4_lava32_262144x250'}
@@ -274,65 +284,35 @@ def cpu_baseline_check_stats(template, seed, env_id0, T, ret, episodes, n_check=
 
 # --------------------------------------------------------------------------------------- timing
 class Ranks(object):
-    """torch.distributed (gloo, CPU tensors) as rendezvous / barrier / reduction plumbing; a no-op for one process."""
+    """Host channel between the ranks: griduniverse_amd.rendezvous (one socket per rank to rank 0; torchrun-style environment,
+    no PyTorch).  A no-op for one process."""
 
     def __init__(self, rank, world):
-        self.rank, self.world, self.dist = rank, world, None
-        if world > 1:
-            import torch.distributed as dist
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            if not dist.is_initialized():
-                with native_stdout_to_stderr():  # gloo announces its connections on the C++ stdout
-                    dist.init_process_group('gloo', rank=rank, world_size=world)
-                    dist.barrier()
-                self.owns = True
-            else:
-                self.owns = False
-            self.dist = dist
+        from griduniverse_amd.rendezvous import Rendezvous
+        self.rank, self.world = rank, world
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        self.rdzv = Rendezvous(rank, world)
+        self.rdzv.barrier()
 
     def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier()
+        self.rdzv.barrier()
 
     def reduce(self, values, op):
         """Element-wise MAX / MIN over ranks of a list of floats."""
-        if self.dist is None:
-            return [float(v) for v in values]
-        import torch
-        t = torch.tensor(list(values), dtype=torch.float64)
-        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
-        return [float(v) for v in t]
+        return self.rdzv.reduce(values, op)
 
     def gather(self, values):
         """[world][len] of every rank's list of floats."""
-        if self.dist is None:
-            return [[float(v) for v in values]]
-        import torch
-        mine = torch.tensor(list(values), dtype=torch.float64)
-        every = [torch.zeros_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(every, mine)
-        return [[float(v) for v in t] for t in every]
+        return self.rdzv.gather(values)
 
     def gather_bytes(self, payload):
-        if self.dist is None:
-            return [payload]
-        import torch
-        mine = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
-        every = [torch.zeros_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(every, mine)
-        return [bytes(t.numpy().tobytes()) for t in every]
+        return self.rdzv.gather_bytes(payload)
 
     def broadcast_bytes(self, payload, src=0):
-        if self.dist is None:
-            return payload
-        import torch
-        buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
-        self.dist.broadcast(buf, src=src)
-        return bytes(buf.numpy().tobytes())
+        return self.rdzv.broadcast_bytes(payload, src)
 
     def close(self):
-        if self.dist is not None and self.owns:
-            self.dist.destroy_process_group()
+        self.rdzv.close()
 
 
 def timed_block(eng, ranks, T, K):
@@ -420,14 +400,100 @@ def spread(values):
     return float(v[0]), float(np.median(v)), float(v[-1])
 
 
-def read_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*.json), or None."""
+def read_traffic(mode, launch_ms=None):
+    """HBM bytes per launch of bench mode `mode` ('headline', 'strong_c4', 'packed_rows', 'stats_only') from the committed
+    rocprofv3 --pmc passes over THIS script (tools/gpu_profile.sh -> profiles/rollout_pmc_latest.json), with the tag and date of
+    the profile and its own kernel duration -- and a note when that duration and this run's differ by more than 5 %.
+    Counters cannot be read inside an unprofiled run: the figure is a property of the kernel and its launch shape, re-measured
+    by every profile pass, and is labelled as coming from a file."""
     path = os.path.join(ROOT, 'profiles', 'rollout_pmc_latest.json')
     try:
         with open(path) as f:
-            return json.load(f)
+            table = json.load(f)
     except (OSError, ValueError):
         return None
+    entry = table.get('modes', {}).get(mode) if 'modes' in table else (table if mode == 'headline' else None)
+    if not entry:
+        return None
+    out = dict(entry)
+    out.setdefault('tag', table.get('tag'))
+    out.setdefault('date', table.get('date'))
+    prof_us = out.get('kernel_avg_us')
+    if prof_us and launch_ms:
+        ratio = launch_ms * 1e3 / prof_us
+        out['this_run_over_profile_duration'] = ratio
+        if abs(ratio - 1.0) > 0.05:
+            out['note'] = 'kernel duration differs from the profiled run by %+.1f %% (profile %.1f us, this run %.1f us): the traffic ' \
+                          'figure is per launch and does not depend on it, the achieved rate does' % ((ratio - 1.0) * 100, prof_us, launch_ms * 1e3)
+    return out
+
+
+def device_block(engine_cls, device):
+    """What the device looked like during the run: gu_device_info (name, arch, CUs, clocks as HIP reports them) plus the sysfs
+    view of the same PCI function -- current sclk / mclk, power cap, memory and compute partition -- so that a slow run can be
+    told from a differently configured box."""
+    if not hasattr(engine_cls, 'device_info'):
+        return None
+    try:
+        info = dict(engine_cls.device_info(device))
+    except Exception as err:  # noqa: BLE001 -- reporting only
+        return {'error': str(err)}
+    pci = str(info.get('pci', '')).lower()
+    base = '/sys/bus/pci/devices/' + pci
+    sysfs = {}
+
+    def read(rel):
+        try:
+            with open(os.path.join(base, rel)) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    if pci and os.path.isdir(base):
+        for key, rel in (('memory_partition', 'current_memory_partition'), ('compute_partition', 'current_compute_partition'),
+                         ('perf_level', 'power_dpm_force_performance_level'), ('vbios', 'vbios_version'),
+                         ('gpu_busy_percent', 'gpu_busy_percent'), ('mem_busy_percent', 'mem_busy_percent')):
+            v = read(rel)
+            if v is not None:
+                sysfs[key] = v
+        for key, rel in (('sclk', 'pp_dpm_sclk'), ('mclk', 'pp_dpm_mclk'), ('fclk', 'pp_dpm_fclk')):
+            v = read(rel)
+            if v is not None:
+                levels = [ln.strip() for ln in v.splitlines() if ln.strip()]
+                sysfs[key + '_levels'] = levels
+                sysfs[key + '_current'] = next((ln.rstrip(' *').split(':', 1)[-1].strip() for ln in levels if ln.endswith('*')), None)
+        for hw in glob.glob(os.path.join(base, 'hwmon', 'hwmon*')):
+            for key, rel in (('power_cap_uW', 'power1_cap'), ('power_cap_max_uW', 'power1_cap_max'), ('power_average_uW', 'power1_average'),
+                             ('power_input_uW', 'power1_input'), ('temp_edge_mC', 'temp1_input'), ('temp_hbm_mC', 'temp3_input')):
+                try:
+                    with open(os.path.join(hw, rel)) as f:
+                        sysfs[key] = int(f.read().strip())
+                except (OSError, ValueError):
+                    pass
+    info['sysfs'] = sysfs or None
+    return info
+
+
+def placement_block(eng, post_probe_ms, launch_ms):
+    """roofline.trajectory_placement: what gu_reserve_trajectory's candidate search did for the bench buffer, per candidate, what
+    it cost, and the SAME store probe run once more on the kept buffer right after the timed region (so that "the probe said
+    0.132 ms, the kernel took 0.140" can be split into drift of the device and cost of the kernel)."""
+    if not hasattr(eng, 'trajectory_placement'):
+        return None
+    n, best, worst = eng.trajectory_placement()
+    out = {'candidates_probed': n, 'probe_ms_kept': best, 'probe_ms_slowest': worst}
+    if hasattr(eng, 'trajectory_placement_detail'):
+        out.update(eng.trajectory_placement_detail())
+    out['probe_ms_kept_after_timed_region'] = post_probe_ms
+    if post_probe_ms and best:
+        out['probe_drift'] = post_probe_ms / best
+    if post_probe_ms and launch_ms:
+        out['kernel_over_probe_after'] = launch_ms / post_probe_ms
+    out['is'] = 'gu_reserve_trajectory writes candidate allocations once in the rollout\'s store shape and keeps the fastest (where a ' \
+                'buffer lands in HBM changes its write rate by ~15 %, DESIGN.md section 6); probe_ms = one full write of the buffer ' \
+                'by a bare store loop; peak_bytes = most memory the search held; the search stops after the back-to-back candidates ' \
+                'when they are within 6 % of each other'
+    return out
 
 
 # --------------------------------------------------------------------------------------- RCCL gathered view
@@ -436,6 +502,8 @@ def rccl_view_check(eng, engine_cls, ranks):
     packed int32[3N] block.  Proves the collective saw `world` ranks: every rank's own shard digest travels over gloo and
     is compared with the digest of that rank's slice of the RCCL view."""
     world, rank = ranks.world, ranks.rank
+    if hasattr(engine_cls, 'host_channel'):  # (the oracle-backed stub of the CPU tests gathers over the host channel)
+        engine_cls.host_channel = ranks.rdzv
     uid = engine_cls.comm_unique_id() if rank == 0 else bytes(_lib.COMM_ID_BYTES)
     uid = ranks.broadcast_bytes(uid, 0)
     ranks.barrier()
@@ -508,29 +576,253 @@ def strong_c4(args, ranks, engine_cls, device):
                       + ('; whole batch sha256 == reference digest c4_lava32_262144x250' if ref is not None else ''))
 
 
+# --------------------------------------------------------------------------------------- plumbing
+def load_engine_class(args):
+    """griduniverse_amd.Engine unless --engine module:Class names another one (the CPU tests run the whole script on
+    tests/_oracle_engine.py; the JSON line always names the class that ran)."""
+    if not getattr(args, 'engine', None):
+        return gua.Engine
+    module, _, name = args.engine.partition(':')
+    return getattr(importlib.import_module(module), name)
+
+
+def ensure_library_is_current(engine_cls, local_rank=0):
+    """A checkout whose libgu.so is missing or older than its sources: build it (one rank per node) rather than measure
+    nothing.  _lib.is_stale() reads the hash from the file's bytes, so looking never maps the library."""
+    if engine_cls is not gua.Engine or not _lib.is_stale():
+        return
+    if local_rank == 0:
+        with native_stdout_to_stderr():  # (make's and hipcc's chatter belongs on stderr: stdout carries the one JSON line)
+            _lib.build()
+    else:
+        deadline = time.time() + 900
+        while _lib.is_stale() and time.time() < deadline:
+            time.sleep(2)
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): this process becomes a launcher.  It
+    starts N fresh children -- one rank each, torchrun-style environment -- BEFORE anything here has touched a GPU or loaded
+    libgu.so, relays rank 0's JSON line, and returns the worst exit code.  (Never an exec of a process that has initialised
+    the GPU: the children are ordinary subprocesses and this parent never calls into HIP.)"""
+    ensure_library_is_current(load_engine_class(args))  # a subprocess `make`: no HIP call in this process
+    with socket.socket() as sck:
+        sck.bind(('127.0.0.1', 0))
+        port = sck.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    out = procs[0].communicate()[0].decode('utf-8', 'replace')
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    worst = next((c for c in codes if c != 0), 0)
+    if worst:
+        sys.stderr.write('bench.py: rank exit codes %r\n' % (codes,))
+    return worst
+
+
+# --------------------------------------------------------------------------------------- one process, N devices
+def run_single_process(args, engine_cls=None, emit=print):
+    """SURVEY.md 8(e)'s form: ONE host process, one engine (handle + HIP stream) per device, contiguous env-index shards with
+    global env ids g * N .., every launch enqueued device after device so that the GPUs run concurrently; the single-array view
+    through ncclCommInitAll + one grouped ncclAllGather (gu_comm_init_all / gu_allgather_view_all).  Timed like the
+    multi-process form: blocks of exactly K launches PER DEVICE between device syncs of all devices; `value` = all devices'
+    env-steps / median block wall time; per_rank = every device's own HIP-event time."""
+    engine_cls = engine_cls or load_engine_class(args)
+    ensure_library_is_current(engine_cls)
+    G, N, T, K, W = args.gpus, args.envs, args.T, args.steps, args.warmup
+    seed = WORKLOAD_SEED[args.workload]
+    template, grid_desc = build_workload(args.workload)
+    want_cpu = G == 1 and not args.no_cpu_baseline
+    all_cores = cpu_baseline_all_cores(template, seed) if want_cpu else None  # forks: must precede any HIP call here
+    n_dev = max(1, _lib.device_count()) if engine_cls is gua.Engine else 1
+    devices = [g % n_dev for g in range(G)]  # identity on a G-GPU node; a smaller box rehearses the flow with shared devices
+    spec = gua.GridSpec.from_env(template)
+    engines = [engine_cls(N, spec, device=devices[g], env_id0=g * N, seed=seed) for g in range(G)]
+
+    def launch_all():
+        for e in engines:
+            e.rollout(T, 'uniform', auto_reset=True, trajectory=True)
+
+    def block():
+        for e in engines:
+            e.sync()
+        t0 = time.perf_counter()
+        for e in engines:
+            e.timer_begin()
+        for _ in range(K):
+            launch_all()
+        kernel_ms = [e.timer_end() for e in engines]  # (each waits for its own device)
+        return time.perf_counter() - t0, kernel_ms
+
+    try:
+        for e in engines:
+            e.reset()
+            e.reserve_trajectory(T)
+        launches = 1
+        launch_all()
+        checks = {}
+        if not args.no_checks:
+            first = engines[0].read_trajectory(0, T)
+            ref = reference_digest(args.workload, template, seed, N, T, 0)
+            checks['bit_exact_vs_reference_digest'] = None if ref is None else sha256_triplet(first) == ref
+            ok = bool(cpu_baseline_check_prefix(template, seed, 0, first))
+            del first
+            for g, e in enumerate(engines[1:], start=1):  # every other shard: its first envs against the oracle at ITS global ids
+                ok = ok and bool(cpu_baseline_check_prefix(template, seed, g * N, e.read_trajectory(0, T), n_check=512))
+            checks['bit_exact_vs_oracle'] = ok
+        for _ in range(W):
+            launch_all()
+        launches += W
+        probe = block()[0]
+        blocks = int(min(4000, max(3, np.ceil(args.min_seconds / max(probe, 1e-6)))))
+        wall, kern = [], []
+        for _ in range(blocks):
+            w, k = block()
+            wall.append(w)
+            kern.append(k)
+        launches += (blocks + 1) * K
+        dev_info = [device_block(engine_cls, d) for d in sorted(set(devices))]
+        post_probe = [e.probe_trajectory() if hasattr(e, 'probe_trajectory') else None for e in engines]
+        if not args.no_checks:
+            for e in engines:
+                e.sync()
+            checks['final_state_vs_oracle'] = cpu_baseline_check_final_state(template, seed, 0, N, launches * T, engines[0].get_state())
+            checks['final_state_vs_oracle']['launches'] = launches
+        # ---- the gathered view: one communicator over all devices of this process, one grouped all-gather
+        rccl = None
+        if G > 1 or args.gather_view:
+            try:
+                with native_stdout_to_stderr():
+                    t0 = time.perf_counter()
+                    engine_cls.comm_init_all(engines)
+                    init_ms = (time.perf_counter() - t0) * 1e3
+                    view = engine_cls.allgather_view_all(engines)  # first call: untimed (lazy connection set-up)
+                    laps = []
+                    for _ in range(5):
+                        t0 = time.perf_counter()
+                        view = engine_cls.allgather_view_all(engines)
+                        laps.append((time.perf_counter() - t0) * 1e3)
+                equal = all(v.size == G * N for v in view)
+                for g, e in enumerate(engines):
+                    own = e.read_outputs()
+                    equal = equal and all(np.array_equal(view[k][g * N:(g + 1) * N], own[k]) for k in range(3))
+                rccl = dict(nranks=G, comm_init_ms=init_ms, allgather_ms=float(np.median(laps)), bytes_per_rank=3 * N * 4, view_envs=G * N,
+                            view_equals_shards=bool(equal), form='ncclCommInitAll + one grouped ncclAllGather from one process',
+                            note='packed (obs|reward|done) int32[3N] block per device; view read from the first device; median of 5 '
+                                 'calls; compared slice by slice with every device\'s own shard')
+            except gua.GuError as err:  # reported, not fatal (a box with fewer devices than ranks: RCCL wants one device per rank)
+                rccl = dict(nranks=G, view_equals_shards=None, error=str(err))
+        placement = [placement_block(e, post_probe[g], float(np.median([k[g] for k in kern])) / K) for g, e in enumerate(engines)]
+    finally:
+        for e in engines:
+            e.close()
+
+    # ---- config 4, strong scaling, same form
+    c4 = None
+    if not args.no_strong_c4 and args.c4_envs % G == 0:
+        n, seed4, T_check = args.c4_envs // G, WORKLOAD_SEED['c4'], 250
+        template4, desc4 = build_workload('c4')
+        spec4 = gua.GridSpec.from_env(template4)
+        engines = [engine_cls(n, spec4, device=devices[g], env_id0=g * n, seed=seed4) for g in range(G)]
+        try:
+            for e in engines:
+                e.reset()
+                e.reserve_trajectory(max(T, T_check))
+            for e in engines:
+                e.rollout(T_check, 'uniform', auto_reset=True, trajectory=True)
+            shards_ok = all(bool(cpu_baseline_check_prefix(template4, seed4, g * n, e.read_trajectory(0, T_check), n_check=n))
+                            for g, e in enumerate(engines))
+            ref = reference_digest('c4', template4, seed4, n, T_check, 0) if G == 1 else None
+            ref_ok = None if ref is None else sha256_triplet(engines[0].read_trajectory(0, T_check)) == ref
+            for _ in range(W):
+                launch_all()
+            probe4 = block()[0]
+            blocks4 = int(min(4000, max(3, np.ceil(args.min_seconds / 2 / max(probe4, 1e-6)))))
+            wall4, kern4 = [], []
+            for _ in range(blocks4):
+                w, k = block()
+                wall4.append(w)
+                kern4.append(max(k))
+        finally:
+            for e in engines:
+                e.close()
+        w_min, w_med, w_max = spread(wall4)
+        k_med = spread(kern4)[1]
+        c4 = dict(value=float(args.c4_envs) * T * K / w_med, unit='env-steps/s', scaling='strong', total_envs=args.c4_envs, envs_per_gpu=n,
+                  n_gpus=G, env_steps_per_launch=T, steps=K, blocks=len(wall4), ms_per_step=w_med / K * 1e3, ms_per_step_min=w_min / K * 1e3,
+                  ms_per_step_max=w_max / K * 1e3, launch_ms=k_med / K, hbm_gbps_per_gpu=BYTES_PER_ENV_STEP * n * T / (k_med / K / 1e3) / 1e9,
+                  workload='c4: %s, seed %d, uniform device-RNG actions, auto-reset, int32 trajectory' % (desc4, seed4),
+                  shards_equal_oracle=bool(shards_ok), bit_exact_vs_reference_digest=ref_ok,
+                  check='first launch (250 steps from reset): every device\'s full shard trajectory == C oracle')
+        c4['traffic'] = read_traffic('strong_c4', c4['launch_ms'])
+    elif not args.no_strong_c4:
+        c4 = dict(skipped='%d envs do not divide over %d devices' % (args.c4_envs, G))
+
+    w_min, w_med, w_max = spread(wall)
+    per_dev_ms = [float(np.median([k[g] for k in kern])) / K for g in range(G)]
+    worst = [max(k) for k in kern]
+    k_min, k_med, k_max = spread(worst)
+    launch_s = k_med / 1e3 / K
+    achieved = BYTES_PER_ENV_STEP * N * T / launch_s / 1e9
+    traffic = read_traffic('headline', launch_s * 1e3)
+    steps_per_block = float(G) * N * T * K
+    line = {
+        'metric': METRIC, 'value': steps_per_block / w_med, 'unit': 'env-steps/s', 'n_gpus': G, 'steps': K, 'warmup': W,
+        'ms_per_step': w_med / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int32',
+        'data': 'synthetic',
+        'config': {'workload': '%s: %d envs per GPU on the %s, uniform random actions from the per-env device RNG, auto-reset on done, '
+                               'one launch = %d env-steps per env, int32 (obs,reward,done) trajectory written to HBM' % (args.workload, N, grid_desc, T),
+                   'envs_per_gpu': N, 'env_steps_per_launch': T, 'global_envs': G * N,
+                   'parallelism': 'env-index shards, no data-path collective; ONE host process, one engine per device, launches '
+                                  'enqueued device after device', 'devices': devices},
+        'mode': 'single-process',
+        'timing': {'blocks': blocks, 'launches_per_block': K, 'timed_seconds': float(np.sum(wall)),
+                   'value_is': 'median block (each block = exactly K launches per device between syncs of every device)',
+                   'ms_per_step_min': w_min / K * 1e3, 'ms_per_step_median': w_med / K * 1e3, 'ms_per_step_max': w_max / K * 1e3,
+                   'value_min': steps_per_block / w_max, 'value_max': steps_per_block / w_min,
+                   'launch_ms_min': k_min / K, 'launch_ms_median': k_med / K, 'launch_ms_max': k_max / K,
+                   'launch_ms_is': 'HIP-event time of a block / K on the slowest device, per block', 'launches_total': launches * G},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
+                     'traffic': None if traffic is None else traffic.get('hbm_bytes_per_launch'), 'traffic_measured_in_this_run': False,
+                     'kernel': 'gu_rollout_kernel<UNIFORM,TRAJ,LDS>', 'launch_ms': launch_s * 1e3,
+                     'algorithmic_bytes_per_launch': BYTES_PER_ENV_STEP * N * T,
+                     'traffic_source': None if traffic is None else traffic.get('source'),
+                     'vs_measured_copy_rate': achieved / HBM_COPY_GBPS, 'is': 'per device (the slowest one)',
+                     'trajectory_placement': placement},
+        'device': dev_info,
+        'engine': engine_cls.__module__ + '.' + engine_cls.__name__,
+        'per_rank': {'ms_per_step': per_dev_ms, 'value': [float(N) * T / (ms / 1e3) for ms in per_dev_ms],
+                     'is': 'every device\'s own HIP-event time per launch (median block)'},
+        'rccl': rccl, 'strong_c4': c4, 'other_modes': None,
+    }
+    line.update(checks)
+    if want_cpu:
+        base = cpu_baseline(template, seed, T)
+        base['all_cores'] = all_cores
+        line['cpu_baseline'] = base
+    ctypes.CDLL(None).fflush(None)
+    emit(json.dumps(line))
+    sys.stdout.flush()
+
+
 # --------------------------------------------------------------------------------------- the run
 def run(args, engine_cls=None, emit=print):
     """`engine_cls` exists for the 2-rank CPU test (tests/_oracle_engine.py stands in for the device); the command line
     always measures griduniverse_amd.Engine, and the JSON line names the class that ran."""
-    engine_cls = engine_cls or gua.Engine
+    engine_cls = engine_cls or load_engine_class(args)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)' % (args.gpus, world))
-    # torch (the gloo plumbing of N > 1) is imported BEFORE libgu.so is loaded: the PyTorch wheel bundles its own ROCm runtime,
-    # and the first libamdhip64 in the process is the one every later library binds to -- loading libgu first would leave
-    # two HIP runtimes in the process (gu_comm.hip copes by taking the RCCL beside its own runtime, but one runtime is cleaner)
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: start the script plainly (it spawns its ranks) or under '
+                         'torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
     ranks = Ranks(rank, world)
-    if engine_cls is gua.Engine and _lib.is_stale():
-        # a checkout whose libgu.so is missing or older than its sources: build it (one rank per node) rather than measure nothing
-        if int(os.environ.get('LOCAL_RANK', '0')) == 0:
-            with native_stdout_to_stderr():  # (make's and hipcc's chatter belongs on stderr: stdout carries the one JSON line)
-                _lib.build()
-        else:
-            deadline = time.time() + 900
-            while _lib.is_stale() and time.time() < deadline:
-                time.sleep(2)
+    ensure_library_is_current(engine_cls, local_rank)
 
     N, T, K, W = args.envs, args.T, args.steps, args.warmup
     seed = WORKLOAD_SEED[args.workload]
@@ -542,7 +834,6 @@ def run(args, engine_cls=None, emit=print):
     eng = engine_cls(N, gua.GridSpec.from_env(template), device=device, env_id0=rank * N, seed=seed)
     eng.reset()
     eng.reserve_trajectory(T)
-    placement = eng.trajectory_placement() if hasattr(eng, 'trajectory_placement') else None
 
     # ---- launch 1, from reset: checked in full
     launches = 1
@@ -565,6 +856,7 @@ def run(args, engine_cls=None, emit=print):
     wall, kern, own_wall, n_launched = timed_region(eng, ranks, T, K, args.min_seconds)
     launches += n_launched
     blocks = len(wall)
+    dev_info = device_block(engine_cls, device) if rank == 0 else None  # (clocks as they are right behind the timed launches)
 
     # ---- one instrumented block: an event after every launch (not part of `value`)
     eng.sync()
@@ -574,6 +866,8 @@ def run(args, engine_cls=None, emit=print):
         eng.timer_mark()
     per_launch = eng.timer_laps()
     launches += K
+    # ---- the bare store probe once more on the kept buffer, right after the timed launches (overwrites the rows, not the state)
+    post_probe_ms = eng.probe_trajectory() if hasattr(eng, 'probe_trajectory') else None
 
     if rank == 0 and not args.no_checks:
         eng.sync()
@@ -592,6 +886,7 @@ def run(args, engine_cls=None, emit=print):
         except gua.GuError as err:  # reported, not fatal: the throughput line above does not depend on the collective
             rccl = dict(nranks=world, view_equals_shards=None, error=str(err))
     per_rank = ranks.gather([float(np.median(own_wall))])
+    placement = placement_block(eng, post_probe_ms, float(np.median(kern)) / K)
     eng.close()
     c4 = None if args.no_strong_c4 else strong_c4(args, ranks, engine_cls, device)
 
@@ -600,7 +895,11 @@ def run(args, engine_cls=None, emit=print):
         k_min, k_med, k_max = spread(kern)
         launch_s = k_med / 1e3 / K
         achieved = BYTES_PER_ENV_STEP * N * T / launch_s / 1e9
-        traffic = read_traffic()
+        traffic = read_traffic('headline', launch_s * 1e3)
+        if c4 and 'launch_ms' in c4:
+            c4['traffic'] = read_traffic('strong_c4', c4['launch_ms'])
+        for mode in (others or {}):
+            others[mode]['traffic'] = read_traffic(mode, others[mode]['ms_per_launch'])
         steps_per_block = float(world) * N * T * K
         line = {
             'metric': METRIC, 'value': steps_per_block / w_med, 'unit': 'env-steps/s', 'n_gpus': world,
@@ -628,10 +927,11 @@ def run(args, engine_cls=None, emit=print):
                          'kernel': 'gu_rollout_kernel<UNIFORM,TRAJ,LDS>', 'launch_ms': launch_s * 1e3,
                          'algorithmic_bytes_per_launch': BYTES_PER_ENV_STEP * N * T,
                          'traffic_source': None if traffic is None else traffic.get('source'),
-                         'trajectory_placement': None if placement is None else {
-                             'candidates_probed': placement[0], 'probe_ms_kept': placement[1], 'probe_ms_slowest': placement[2],
-                             'is': 'gu_reserve_trajectory writes candidate allocations once in the rollout\'s store shape and keeps '
-                                   'the fastest: where a buffer lands in HBM changes its write rate by ~15 % (DESIGN.md section 6)'}},
+                         'traffic_profile': None if traffic is None else {k: traffic.get(k) for k in
+                                                                          ('tag', 'date', 'kernel', 'kernel_avg_us', 'this_run_over_profile_duration', 'note')},
+                         'vs_measured_copy_rate': achieved / HBM_COPY_GBPS,
+                         'trajectory_placement': placement},
+            'device': dev_info,
             'engine': engine_cls.__module__ + '.' + engine_cls.__name__,
             'per_rank': {'ms_per_step': [v[0] / K * 1e3 for v in per_rank],
                          'value': [float(N) * T * K / v[0] for v in per_rank],
@@ -664,8 +964,23 @@ def parse_args(argv=None):
     ap.add_argument('--no-strong-c4', action='store_true')
     ap.add_argument('--no-other-modes', action='store_true', help='skip the statistics-only / packed-row launches reported beside `value`')
     ap.add_argument('--gather-view', action='store_true', help='exercise the RCCL gathered view with one rank too')
+    ap.add_argument('--single-process', action='store_true',
+                    help='ONE process driving --gpus devices (one engine per device, gu_comm_init_all for the view) instead of one rank per GPU')
+    ap.add_argument('--engine', default=None, help='module:Class of the engine to run (tests only; default griduniverse_amd.Engine)')
     return ap.parse_args(argv)
 
 
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.single_process:
+        run_single_process(args)
+        return 0
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(args, argv)  # (before any HIP call and before libgu.so is loaded)
+    run(args)
+    return 0
+
+
 if __name__ == '__main__':
-    run(parse_args())
+    sys.exit(main())

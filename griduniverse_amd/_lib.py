@@ -7,12 +7,14 @@ module, so it keeps working on a machine without a GPU.
 """
 import ctypes
 import os
+import re
 import subprocess
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libgu.so')
+# GU_LIB_PATH selects another build of the same sources (the A/B tools use lib/libgu_exp.so, `make -C csrc exp`)
+LIB_PATH = os.environ.get('GU_LIB_PATH') or os.path.join(_HERE, 'lib', 'libgu.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
 GU_OK = 0
@@ -22,6 +24,14 @@ ERR_NAMES = {-1: 'GU_ERR_INVALID', -2: 'GU_ERR_HIP', -3: 'GU_ERR_NOMEM', -4: 'GU
 F_AUTO_RESET, F_TRAJECTORY, F_STATS, F_PINNED_IO, F_PACKED = 1, 2, 4, 8, 16
 POLICY_UNIFORM, POLICY_STREAM, POLICY_GREEDY, POLICY_SAMPLE = 0, 1, 2, 3
 COMM_ID_BYTES = 128
+OPT_UNSET = -2 ** 63
+# gu_set_option / gu_get_option (include/gu.h "options"): name -> id
+OPTIONS = {'rollout_block': 1, 'rollout_rows': 2, 'rows_copies': 3, 'rollout_multi': 4, 'rollout_multi_k': 5,
+           'rollout_multi_copies': 6, 'rollout_xcd': 7, 'vi_path': 8, 'mc_scratch_mb': 9, 'mc_lane_returns': 10,
+           'mc_global_walk': 11, 'step_sync': 12, 'traj_candidates': 13, 'traj_far_candidates': 14, 'traj_stride_mib': 15,
+           'traj_far_mib': 16, 'traj_probe_all': 17,
+           # experiments: refused by libgu.so, accepted by libgu_exp.so only
+           'x_traj_uncached': 100, 'x_traj_poison': 101, 'x_mc_poison': 102}
 
 _c = ctypes
 _vp, _i32, _i64, _u32, _u64, _f64 = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint32, _c.c_uint64, _c.c_double
@@ -33,6 +43,9 @@ SIGNATURES = {
     'gu_last_error': [_c.c_char_p, _c.c_size_t],
     'gu_device_count': [_c.POINTER(_c.c_int)],
     'gu_source_hash': [_c.c_char_p, _c.c_size_t],
+    'gu_device_info': [_c.c_int, _c.c_char_p, _c.c_size_t],
+    'gu_set_option': [_vp, _i32, _i64],
+    'gu_get_option': [_vp, _i32, _c.POINTER(_i64)],
     'gu_create': [_c.c_int, _i64, _i64, _c.POINTER(_vp)],
     'gu_destroy': [_vp],
     'gu_set_grid': [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32],
@@ -49,6 +62,8 @@ SIGNATURES = {
     'gu_read_outputs': [_vp, _vp, _vp, _vp],
     'gu_reserve_trajectory': [_vp, _i64],
     'gu_trajectory_placement': [_vp, _vp, _vp, _vp],
+    'gu_trajectory_placement_detail': [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    'gu_probe_trajectory': [_vp, _c.POINTER(_c.c_float)],
     'gu_rollout': [_vp, _i64, _i32, _u32],
     'gu_read_trajectory': [_vp, _i64, _i64, _vp, _vp, _vp],
     'gu_read_trajectory_packed': [_vp, _i64, _i64, _vp],
@@ -112,19 +127,29 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+_MARKER = re.compile(rb'GU_SRCHASH=([0-9a-f]{16}|unknown);GU_BUILD=(\w+);')
+
+
+def build_marker(path=None):
+    """(source hash, build kind) a libgu*.so carries in its bytes, or None when there is no such file.
+
+    Read from the FILE, never through dlopen: a library mapped once cannot be replaced in the process (glibc answers a
+    later dlopen of the same path with the old image), so looking at the hash must not map it -- otherwise
+    is_stale() -> build() -> load() in one process would keep seeing the library it set out to replace."""
+    path = path or LIB_PATH
+    try:
+        with open(path, 'rb') as f:
+            blob = f.read()
+    except OSError:
+        return None
+    m = _MARKER.search(blob)
+    return (m.group(1).decode(), m.group(2).decode()) if m else ('unknown', 'unknown')
+
+
 def built_hash():
     """The source hash compiled into libgu.so, or None when there is no library."""
-    if not os.path.exists(LIB_PATH):
-        return None
-    lib = ctypes.CDLL(LIB_PATH)
-    try:
-        fn = lib.gu_source_hash
-    except AttributeError:
-        return 'unknown'
-    fn.argtypes, fn.restype = [ctypes.c_char_p, ctypes.c_size_t], ctypes.c_int
-    buf = ctypes.create_string_buffer(64)
-    fn(buf, 64)
-    return buf.value.decode()
+    marker = build_marker()
+    return None if marker is None else marker[0]
 
 
 def is_stale():
@@ -139,16 +164,17 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise GuError(-2, 'libgu.so not found at {}; build it with `python -c "import __graft_entry__ as g; '
                               'g.build()"` or `make -C griduniverse_amd/csrc`'.format(LIB_PATH))
+        # the hash is read from the file's bytes BEFORE anything is mapped: a stale library that was dlopen'ed once would be
+        # handed back by glibc for every later dlopen of the path, and the rebuilt one could never be loaded by this process
+        built = built_hash()
+        if os.path.isdir(CSRC) and built != source_hash() and not os.environ.get('GU_ALLOW_STALE_LIB'):
+            raise GuError(-2, 'libgu.so at {} was built from other sources (built {}, on disk {}): rebuild with '
+                              '`make -C griduniverse_amd/csrc`'.format(LIB_PATH, built, source_hash()))
         lib = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
-        buf = ctypes.create_string_buffer(64)
-        lib.gu_source_hash(buf, 64)
-        if os.path.isdir(CSRC) and buf.value.decode() != source_hash() and not os.environ.get('GU_ALLOW_STALE_LIB'):
-            raise GuError(-2, 'libgu.so at {} was built from other sources (built {}, on disk {}): rebuild with '
-                              '`make -C griduniverse_amd/csrc`'.format(LIB_PATH, buf.value.decode(), source_hash()))
         _lib = lib
     return _lib
 
@@ -162,6 +188,33 @@ def last_error():
 def check(rc):
     if rc != GU_OK:
         raise GuError(rc, last_error())
+
+
+def set_default_option(name, value):
+    """Process-wide default of a launch-shape / search option (every engine without a value of its own uses it).
+    value None returns it to the built-in default.  Results never depend on options; tests and tools flip them."""
+    check(load().gu_set_option(None, OPTIONS[name], OPT_UNSET if value is None else int(value)))
+
+
+def get_default_option(name):
+    """The value in force for engines without one of their own."""
+    v = ctypes.c_int64(0)
+    check(load().gu_get_option(None, OPTIONS[name], ctypes.byref(v)))
+    return v.value
+
+
+def device_info(device=0):
+    """dict of what gu_device_info reports (name, arch, pci, cus, lds_per_cu, clocks, memory sizes)."""
+    buf = ctypes.create_string_buffer(1024)
+    rc = load().gu_device_info(int(device), buf, 1024)
+    if rc < 0:
+        check(rc)
+    out = {}
+    for item in buf.value.decode('utf-8', 'replace').split(';'):
+        if '=' in item:
+            k, v = item.split('=', 1)
+            out[k] = int(v) if v.lstrip('-').isdigit() else v
+    return out
 
 
 def device_count():

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 // ---------------------------------------------------------------------------------- errors
@@ -65,6 +66,8 @@ int gu_ensure_scratch(gu_engine *h, size_t bytes)
 
 #define GU_NEED_GRID(h) GU_REQUIRE((h)->has_grid, GU_ERR_STATE, "no grid set: call gu_set_grid first")
 
+static void gu_placement_release(gu_engine *h);  // (the registry of chosen trajectory buffers, below)
+
 extern "C" {
 
 int gu_version(void) { return GU_ABI_VERSION; }
@@ -104,9 +107,19 @@ int gu_create(int device_id, int64_t num_envs, int64_t env_id0, gu_handle *out)
     h->env_id0 = env_id0;
     h->seed = 0;
     h->seed_prefix = gu_rng_seed_prefix(0);
+    for (auto &o : h->opt) o = GU_OPT_UNSET;
+    for (auto &o : h->opt_x) o = 0;
     int rc = GU_OK;
     auto body = [&]() -> int {
         GU_HIP(hipSetDevice(device_id));
+        // launch shapes are sized from what the device reports, not from MI355X constants (a CPX partition, a CU mask or a
+        // smaller part has fewer CUs; the absolute write-rate rule of the placement search applies to gfx950 only)
+        hipDeviceProp_t prop;
+        memset(&prop, 0, sizeof prop);
+        GU_HIP(hipGetDeviceProperties(&prop, device_id));
+        if (prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+        if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) h->lds_per_cu = (int64_t)prop.maxSharedMemoryPerMultiProcessor;
+        h->gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
         GU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         GU_HIP(hipEventCreate(&h->ev_begin));
         GU_HIP(hipEventCreate(&h->ev_end));
@@ -122,7 +135,6 @@ int gu_create(int device_id, int64_t num_envs, int64_t env_id0, gu_handle *out)
         GU_HIP(hipHostMalloc(&h->h_pin, 4 * n * sizeof(int32_t), hipHostMallocDefault));
         GU_HIP(hipHostMalloc(&h->h_seq, 64, hipHostMallocDefault));
         memset(h->h_seq, 0, 64);
-        h->step_sync = std::getenv("GU_STEP_SYNC") != nullptr;  // read once: gu_step is a ~10 us hot path
         GU_HIP(hipMalloc(&h->d_blocks_done, sizeof(uint32_t)));
         GU_HIP(hipMemsetAsync(h->d_blocks_done, 0, sizeof(uint32_t), h->stream));
         GU_HIP(hipMemsetAsync(h->d_out3, 0, 3 * n * sizeof(int32_t), h->stream));
@@ -149,6 +161,7 @@ int gu_destroy(gu_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     gu_comm_free(h);
     gu_vi_free(h);
+    gu_placement_release(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     void *bufs[] = {h->d_rows[0], h->d_rows[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
                     h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy};
@@ -454,14 +467,14 @@ static int gu_step_action_error(gu_engine *h, const int32_t *actions)
 // trip instead of the runtime's completion path: 14.0 -> 10.4 us per call at up to 64 envs, 15.5 -> 12.7 at 4096.  Only
 // for batches of up to 8192 envs: the per-block system-scope fence serialises the PCIe result stream of larger ones
 // (65 536 envs: 57 us against 43 us with the ordinary synchronisation, measured in one process).  Bounded: after ~1 ms
-// of spinning, and every 1024 steps anyway, the real stream synchronisation runs (GU_STEP_SYNC=1 at gu_create forces it).
+// of spinning, and every 1024 steps anyway, the real stream synchronisation runs (GU_OPT_STEP_SYNC forces it).
 // Actions are validated by the kernel itself (an error word next to the completion word), not by a host loop.
 static int gu_step_and_wait(gu_engine *h, const int32_t *actions, uint32_t flags, int32_t *obs, int32_t *reward, int32_t *done)
 {
     int rc;
     uint32_t *err = h->h_seq + GU_HOST_ERR_WORD;
     bool finished = false;
-    if (h->N <= 8192 && h->seq_since_sync < 1024 && !h->step_sync) {
+    if (h->N <= 8192 && h->seq_since_sync < 1024 && !gu_opt(h, GU_OPT_STEP_SYNC)) {
         const uint32_t seq = ++h->seq;
         rc = gu_launch_step(h, actions, flags, obs, reward, done, h->h_seq, seq, err);
         if (rc != GU_OK) return rc;
@@ -610,78 +623,111 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done)
 // (tools/micro/store_placement.hip, profiles/r02f_store_placement.txt; this, not the device, is the "box-to-box" spread of
 // the rollout kernel: 117 .. 141 us per launch).  So a large trajectory buffer is CHOSEN: a few candidate allocations are
 // written once in the rollout's own store shape, timed with events, and the fastest one is kept.  A one-off cost of a few
-// milliseconds at reservation; GU_TRAJ_CANDIDATES=1 turns it off (default: up to 12, capped by free memory).
+// milliseconds at reservation; GU_OPT_TRAJ_CANDIDATES = 1 turns it off.  What the search may hold and when it gives up is
+// stated in include/gu.h next to gu_trajectory_placement.
 static double gu_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// EXPERIMENT, off by default (GU_TRAJ_UNCACHED=1 turns it on): the trajectory buffer with the uncached memory type (MTYPE_UC:
-// stores do not allocate in L2).  The bare store loop runs 3 .. 5 % faster on every placement class
-// (profiles/r02i_placement_flags.txt) and the rollout kernel 8 % -- 112 against 121 .. 124 us per 65 536 x 1000 launch, 5.73e11
-// env-steps/s in bench.py with the reference digest and the final state intact (profiles/r02i_uncached_ab.txt,
-// r02j_bench_line_uncached.json).  It is NOT the default because kernels that READ such a buffer can see stale bytes:
-// tests/test_gpu_mc.py::test_chunk_boundaries_do_not_change_the_result fails reproducibly when an earlier engine of the process
-// has used the same memory before: the FIRST evaluation on the new buffer then differs in a few states while the host's copy
-// of the very same trajectory is correct, before and after.  Poisoning default-type buffers (trajectory and scratch) does not
-// reproduce it, so it is not a read of unwritten bytes; system-scope (sc0 sc1) loads in the readers do not cure it, so it is not
-// a stale L2 line either -- the readers get old bytes from somewhere the uncached stores did not reach (a memory-side cache
-// would fit).  Nothing in user space can flush that, so the fast type stays opt-in.
-static hipError_t gu_traj_malloc(int32_t **p, size_t bytes)
+// Chosen trajectory buffers of this process, per device: a second engine on a device does not repeat the first one's search
+// (it knows the write rate that search ended on) and holds far less while it looks.
+struct PlacementRegistry {
+    int owners = 0;        // engines that hold a chosen (searched) trajectory buffer on the device right now
+    double rate = 0.0;     // bytes per ms of the best probe any search on the device ended on ...
+    size_t bytes = 0;      // ... and the buffer size it was measured with (rates of very different sizes do not compare)
+};
+static std::mutex g_placement_mu;
+static PlacementRegistry g_placement[64];
+
+static void gu_placement_release(gu_engine *h)
 {
-    const char *s = std::getenv("GU_TRAJ_UNCACHED");  // read per allocation: A/B runs switch it inside one process
-    const bool uncached = s ? std::atoi(s) != 0 : GU_TRAJ_UNCACHED_DEFAULT;
-    if (uncached) {
+    if (!h->traj_registered) return;
+    std::lock_guard<std::mutex> lock(g_placement_mu);
+    if (h->device >= 0 && h->device < 64 && g_placement[h->device].owners > 0) --g_placement[h->device].owners;
+    h->traj_registered = false;
+}
+
+static hipError_t gu_traj_malloc(gu_engine *h, int32_t **p, size_t bytes)
+{
+#ifdef GU_EXPERIMENTS
+    // EXPERIMENT (libgu_exp.so only): the trajectory buffer with the uncached memory type (MTYPE_UC: stores do not allocate in
+    // L2).  The rollout kernel runs 8 % faster on it -- 112 against 121 .. 124 us per 65 536 x 1000 launch
+    // (profiles/r02i_uncached_ab.txt) -- but kernels that READ such a buffer can see stale bytes
+    // (tests/test_gpu_mc.py::test_chunk_boundaries_do_not_change_the_result fails reproducibly when an earlier engine of the
+    // process has used the same memory), and nothing in user space can flush that.  A library whose
+    // contract is bit-exactness does not ship the mode: the product build has no code for it.
+    if (gu_opt(h, GU_OPT_X_TRAJ_UNCACHED)) {
         const hipError_t e = hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocUncached);
         if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
         (void)hipGetLastError();  // a runtime without the flag: the default type
     }
+#else
+    (void)h;
+#endif
     return hipMalloc(p, bytes);
 }
 
 static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **out)
 {
     *out = nullptr;
-    int want = 12;
-    if (const char *s = std::getenv("GU_TRAJ_CANDIDATES")) want = std::atoi(s);
+    h->traj_probe_ms.clear();
+    h->traj_probe_addr.clear();
+    h->traj_kept = -1;
+    h->traj_search_ms = 0.0f;
+    h->traj_peak_bytes = 0;
+    h->traj_candidates = 1;
+    h->traj_probe_ms_best = h->traj_probe_ms_worst = 0.0f;
+    const double t_start = gu_now_ms();
+    int want = (int)gu_opt(h, GU_OPT_TRAJ_CANDIDATES);
+    int far = (int)gu_opt(h, GU_OPT_TRAJ_FAR_CANDIDATES);
+    size_t stride = (size_t)gu_opt(h, GU_OPT_TRAJ_STRIDE_MIB) << 20;
+    const size_t far_cap = (size_t)gu_opt(h, GU_OPT_TRAJ_FAR_MIB) << 20;
+    const bool exhaustive = gu_opt(h, GU_OPT_TRAJ_PROBE_ALL) != 0;  // measurement aid: probe every candidate
+    // what other engines of this process already learned on the device
+    int others = 0;
+    double known_rate = 0.0;
+    if (h->device >= 0 && h->device < 64) {
+        std::lock_guard<std::mutex> lock(g_placement_mu);
+        const PlacementRegistry &r = g_placement[h->device];
+        others = r.owners;
+        if (r.rate > 0.0 && bytes >= r.bytes / 2 && bytes <= r.bytes * 2) known_rate = r.rate;
+    }
     size_t free_b = 0, total_b = 0;
     if (bytes < ((size_t)64 << 20) || want <= 1 || hipMemGetInfo(&free_b, &total_b) != hipSuccess) want = 1;
-    while (want > 1 && (size_t)want * bytes > free_b / 2) --want;  // never hold more than half of what is free, even briefly
+    // Never hold more than a third of what is free, even briefly -- an eighth, and no spacers, once another engine of the
+    // process owns a chosen buffer on the device (several engines, or several ranks of one process group, share it).
+    size_t budget = others ? free_b / 8 : free_b / 3;
+    if (others) {
+        want = want < 4 ? want : 4;
+        far = 0;
+    }
+    if (far_cap > 0 && budget > far_cap) budget = far_cap;
+    while (want > 1 && (size_t)want * bytes > budget) --want;
     if (want <= 1) {
-        GU_HIP(gu_traj_malloc(out, bytes));
-        h->traj_candidates = 1;
-        h->traj_probe_ms_best = h->traj_probe_ms_worst = 0.0f;
+        GU_HIP(gu_traj_malloc(h, out, bytes));
+        h->traj_peak_bytes = bytes;
+        h->traj_search_ms = (float)(gu_now_ms() - t_start);
         return GU_OK;
     }
-    // The write rates fall into two classes ~15 % apart.  Candidates are allocated and probed one after the other (all are
-    // kept until the choice is made: a freed block would simply be handed out again); the search stops at the first one that
-    // is clearly in the fast class -- at least 14 % quicker than the slowest seen -- and otherwise keeps the quickest.
-    // Neighbouring allocations tend to share their class (runs of 10 .. 50 GiB of one kind, profiles/r02h_placement_map.txt), so
-    // after `want` back-to-back candidates the search goes FURTHER AFIELD: up to `far` more, each behind a spacer of `stride`
-    // GiB that is held until the end.  hipMalloc / hipFree of such blocks cost ~0.02 .. 0.3 ms, a probe ~0.3 ms.
-    int far = 32;
-    double stride_gib = 3.0;
-    if (const char *s = std::getenv("GU_TRAJ_FAR_CANDIDATES")) far = std::atoi(s);
-    if (const char *s = std::getenv("GU_TRAJ_STRIDE_GIB")) stride_gib = std::atof(s);
-    // What is allocated here is wiped by the driver when it is freed (tens of GB/s, in the background): an allocation made
-    // right after a far search can wait for that, so the search is capped at GU_TRAJ_FAR_GIB (48) GiB held in total.
-    double far_gib = 48.0;
-    if (const char *s = std::getenv("GU_TRAJ_FAR_GIB")) far_gib = std::atof(s);
-    const size_t far_cap = (size_t)(far_gib * 1073741824.0);
-    const size_t stride = (stride_gib > 0.0 && far > 0 && bytes >= ((size_t)256 << 20)) ? (size_t)(stride_gib * 1073741824.0) : 0;  // (buffers of 256 MiB and more)
+    if (far <= 0 || bytes < ((size_t)256 << 20)) stride = 0;  // (spacers: buffers of 256 MiB and more)
     std::vector<int32_t *> cand;
     std::vector<void *> spacers;
-    std::vector<float> ms;
+    std::vector<float> &ms = h->traj_probe_ms;
     size_t best = 0, held = 0;
     float worst = 0.0f;
     double t_malloc = 0.0, t_probe = 0.0;
-    const char *dbg = std::getenv("GU_TRAJ_DEBUG");
-    const bool exhaustive = dbg && std::atoi(dbg) >= 2;  // measurement aid: probe every candidate
     auto release = [&](int32_t *keep) {
         for (int32_t *q : cand)
             if (q != keep) (void)hipFree(q);
         for (void *q : spacers) (void)hipFree(q);
     };
+    // absolute rule: the fast class writes 6.6 .. 6.9 TB/s on MI355X, the slow one 5.5 .. 5.9 (gfx950 with all 256 CUs only)
+    const double fast_rate = (h->gfx950 && h->n_cu == 256) ? 6.5e9 : 0.0;  // bytes per ms
     for (int i = 0; i < want + (stride ? far : 0); ++i) {
-        if (i >= want) {  // (the first `want` fit in half of the free memory by construction)
-            if (held + stride + bytes > free_b / 2 || held + stride + bytes > far_cap) break;
+        if (i >= want) {
+            // The back-to-back candidates are done.  Going further afield pays only where they showed two classes: a device
+            // on which `want` allocations in a row write within 6 % of each other is alike everywhere it was ever probed
+            // (BENCH_r02: 22 candidates over 40 GiB, 5 % apart), and the spacers cost a background wipe of all they held.
+            if (i == want && !exhaustive && (double)(worst - ms[best]) < 0.06 * (double)worst) break;
+            if (held + stride + bytes > budget) break;
             void *sp = nullptr;
             const double t0 = gu_now_ms();
             if (hipMalloc(&sp, stride) != hipSuccess) {
@@ -694,7 +740,7 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
         }
         int32_t *p = nullptr;
         const double t1 = gu_now_ms();
-        if (gu_traj_malloc(&p, bytes) != hipSuccess) {
+        if (gu_traj_malloc(h, &p, bytes) != hipSuccess) {
             (void)hipGetLastError();
             break;
         }
@@ -702,33 +748,52 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
         t_malloc += t2 - t1;
         cand.push_back(p);
         held += bytes;
+        if (held > h->traj_peak_bytes) h->traj_peak_bytes = held;
         float t = 0.0f;
         int rc = gu_probe_trajectory_buffer(h, p, T, &t);
         t_probe += gu_now_ms() - t2;
         if (rc != GU_OK) {
             release(nullptr);
+            ms.clear();
+            h->traj_probe_addr.clear();
             return rc;
         }
         ms.push_back(t);
+        h->traj_probe_addr.push_back((uint64_t)(uintptr_t)p);
         if (t < ms[best]) best = ms.size() - 1;
         worst = t > worst ? t : worst;
+        if (exhaustive) continue;
         // (in between there are buffers 5 .. 8 % quicker than the slow class: only a candidate that is clearly in the fast class,
         // >= 14 % quicker than the slowest seen, ends the search early)
-        if (ms.size() >= 2 && !exhaustive && ms[best] <= 0.86f * worst) break;
-        // ... or one that is fast in absolute terms (the fast class writes 6.6 .. 6.9 TB/s, the slow one 5.5 .. 5.9): where every
-        // candidate so far is fast there is no slow one to compare with
-        if (!exhaustive && (double)bytes / ((double)ms[best] * 1e-3) >= 6.5e12) break;
+        if (ms.size() >= 2 && ms[best] <= 0.86f * worst) break;
+        // ... or one that is fast in absolute terms: where every candidate so far is fast there is no slow one to compare with
+        if (fast_rate > 0.0 && (double)bytes / (double)ms[best] >= fast_rate) break;
+        // ... or one as fast as the buffer an earlier search of this process ended on
+        if (known_rate > 0.0 && (double)bytes / (double)ms[best] >= 0.97 * known_rate) break;
     }
     GU_REQUIRE(!cand.empty(), GU_ERR_NOMEM, "hipMalloc of the %zu-byte trajectory buffer failed", bytes);
     const double t_rel0 = gu_now_ms();
     release(cand[best]);
-    if (dbg)
-        fprintf(stderr, "[gu] trajectory placement: %zu candidates, %zu spacers, malloc %.1f ms, probe %.1f ms, free %.1f ms\n", cand.size(), spacers.size(),
-                t_malloc, t_probe, gu_now_ms() - t_rel0);
+    h->traj_search_ms = (float)(gu_now_ms() - t_start);
+    if (gu_debug())
+        fprintf(stderr, "[gu] trajectory placement: %zu candidates, %zu spacers, %.1f MiB held at most, malloc %.1f ms, probe %.1f ms, free %.1f ms\n",
+                cand.size(), spacers.size(), (double)h->traj_peak_bytes / 1048576.0, t_malloc, t_probe, gu_now_ms() - t_rel0);
     *out = cand[best];
     h->traj_candidates = (int32_t)cand.size();
+    h->traj_kept = (int32_t)best;
     h->traj_probe_ms_best = ms[best];
     h->traj_probe_ms_worst = worst;
+    if (h->device >= 0 && h->device < 64) {
+        std::lock_guard<std::mutex> lock(g_placement_mu);
+        PlacementRegistry &r = g_placement[h->device];
+        ++r.owners;
+        h->traj_registered = true;
+        const double rate = (double)bytes / (double)ms[best];
+        if (rate > r.rate || !(bytes >= r.bytes / 2 && bytes <= r.bytes * 2)) {
+            r.rate = rate;
+            r.bytes = bytes;
+        }
+    }
     return GU_OK;
 }
 
@@ -741,10 +806,13 @@ int gu_reserve_trajectory(gu_handle h, int64_t T)
     if (h->d_traj) GU_HIP(hipFree(h->d_traj));
     h->d_traj = nullptr;
     h->traj_T = 0;
+    gu_placement_release(h);
     int rc = gu_alloc_trajectory(h, 3 * (size_t)T * (size_t)h->N * sizeof(int32_t), T, &h->d_traj);
     if (rc != GU_OK) return rc;
-    if (const char *poison = std::getenv("GU_TRAJ_POISON"))  // debugging aid: nothing may depend on rows no rollout has written
-        if (std::atoi(poison)) GU_HIP(hipMemsetAsync(h->d_traj, 0x5A, 3 * (size_t)T * (size_t)h->N * sizeof(int32_t), h->stream));
+#ifdef GU_EXPERIMENTS
+    if (gu_opt(h, GU_OPT_X_TRAJ_POISON))  // debugging aid: nothing may depend on rows no rollout has written
+        GU_HIP(hipMemsetAsync(h->d_traj, 0x5A, 3 * (size_t)T * (size_t)h->N * sizeof(int32_t), h->stream));
+#endif
     h->traj_T = T;
     h->traj_kind = 0;
     return GU_OK;
@@ -759,6 +827,34 @@ int gu_trajectory_placement(gu_handle h, int32_t *candidates, float *best_ms, fl
     if (best_ms) *best_ms = h->traj_probe_ms_best;
     if (worst_ms) *worst_ms = h->traj_probe_ms_worst;
     return GU_OK;
+}
+
+int gu_trajectory_placement_detail(gu_handle h, int32_t capacity, float *probe_ms, uint64_t *address, int32_t *count, int32_t *kept,
+                                   float *search_ms, uint64_t *peak_bytes)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(h->d_traj != nullptr, GU_ERR_STATE, "no trajectory buffer: call gu_reserve_trajectory first");
+    const int32_t n = (int32_t)h->traj_probe_ms.size();
+    if (count) *count = n;
+    if (kept) *kept = h->traj_kept;
+    if (search_ms) *search_ms = h->traj_search_ms;
+    if (peak_bytes) *peak_bytes = h->traj_peak_bytes;
+    if (probe_ms || address) GU_REQUIRE(capacity >= n, GU_ERR_INVALID, "room for %d candidates, %d were probed", capacity, n);
+    for (int32_t i = 0; i < n; ++i) {
+        if (probe_ms) probe_ms[i] = h->traj_probe_ms[(size_t)i];
+        if (address) address[i] = h->traj_probe_addr[(size_t)i];
+    }
+    return GU_OK;
+}
+
+int gu_probe_trajectory(gu_handle h, float *milliseconds)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(h->d_traj != nullptr, GU_ERR_STATE, "no trajectory buffer: call gu_reserve_trajectory first");
+    GU_REQUIRE(milliseconds != nullptr, GU_ERR_INVALID, "milliseconds is NULL");
+    GU_HIP(hipStreamSynchronize(h->stream));
+    h->traj_kind = 0;  // the probe overwrites the rows
+    return gu_probe_trajectory_buffer(h, h->d_traj, h->traj_T, milliseconds);
 }
 
 int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)

@@ -9,6 +9,15 @@
 #define GU_SOURCE_HASH "unknown"
 #endif
 
+// The same hash as a marker in the file's bytes, so that the binding can read it WITHOUT mapping the library (a dlopen'ed
+// image cannot be replaced in the process: glibc hands the old one back for the same path, and a rebuild would never be seen).
+#ifdef GU_EXPERIMENTS
+#define GU_BUILD_KIND "experiments"
+#else
+#define GU_BUILD_KIND "product"
+#endif
+extern "C" __attribute__((used, visibility("default"))) const char gu_build_marker[] = "GU_SRCHASH=" GU_SOURCE_HASH ";GU_BUILD=" GU_BUILD_KIND ";";
+
 extern "C" int gu_source_hash(char *buf, size_t len)
 {
     const size_t n = strlen(GU_SOURCE_HASH);

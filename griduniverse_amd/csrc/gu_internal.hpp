@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -32,11 +33,15 @@
 #define GU_HOST_ERR_WORD 4
 #define GU_HOST_COUNT_WORD 8
 
-#define GU_TRAJ_UNCACHED_DEFAULT false  // (see gu_traj_malloc: faster, but NOT safe for kernels that read the buffer)
 #define GU_STREAM_PAD_WORDS 4  // spare rows behind the packed action stream: the rollout kernels read up to four words ahead
 
 struct gu_engine {
     int device = -1;
+    int n_cu = 256;                  // compute units of the device (hipDeviceAttributeMultiprocessorCount)
+    int64_t lds_per_cu = 160 * 1024; // LDS bytes of one CU (the most one workgroup can ask for)
+    bool gfx950 = true;              // the device the absolute figures in this library were measured on
+    int64_t opt[GU_OPT_COUNT];       // gu_set_option values of this engine (GU_OPT_UNSET: the process default applies)
+    int64_t opt_x[GU_OPT_X_COUNT];   // experiment switches (only a -DGU_EXPERIMENTS build ever sets them)
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_marks;  // gu_timer_mark pool (grows on demand, reused)
@@ -82,6 +87,12 @@ struct gu_engine {
     int traj_kind = 0;  // what the last rollout left in the buffer: 0 nothing, 1 int32 rows, 2 packed rows
     int32_t traj_candidates = 0;                // allocations tried for the buffer (gu_alloc_trajectory)
     float traj_probe_ms_best = 0.0f, traj_probe_ms_worst = 0.0f;
+    std::vector<float> traj_probe_ms;           // per candidate, in the order tried
+    std::vector<uint64_t> traj_probe_addr;
+    int32_t traj_kept = -1;                     // index of the kept candidate
+    float traj_search_ms = 0.0f;                // wall time of the search
+    uint64_t traj_peak_bytes = 0;               // most device memory the search held at once
+    bool traj_registered = false;               // counted in the per-device registry of chosen buffers
 
     // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in
     uint32_t *d_rows[2] = {nullptr, nullptr};
@@ -109,7 +120,6 @@ struct gu_engine {
     uint32_t *h_seq = nullptr;      // page-locked control words (64 bytes): [0] completion word of gu_step's host-visible
                                     // paths, [GU_HOST_ERR_WORD] raised by a kernel that met an invalid action / state,
                                     // [GU_HOST_COUNT_WORD] number of done envs written by the compaction kernel
-    bool step_sync = false;         // GU_STEP_SYNC was set when the engine was created: never spin on the completion word
     uint32_t *d_blocks_done = nullptr;  // its device-side block counter
     uint32_t seq = 0, seq_since_sync = 0;
 
@@ -170,6 +180,25 @@ int gu_fail(int code, const char *fmt, ...);
 
 int gu_use_device(gu_engine *h);
 int gu_ensure_scratch(gu_engine *h, size_t bytes);
+
+// ---- options (gu_options.hip) ----------------------------------------------------
+// The value in force for `option`: the engine's own, else the process default, else the built-in one.  A few loads; called
+// per launch.  (A -DGU_EXPERIMENTS build also consults the environment variable of the same name on every call, for the
+// A/B tools.)
+int64_t gu_opt(const gu_engine *h, int option);
+bool gu_debug();  // GU_DEBUG was set when the library was first asked (read once per process)
+
+// Raise the dynamic-LDS limit of one kernel instantiation once PER DEVICE (HIP keeps the attribute per device: a process
+// that drives several GPUs must set it on each).  `mask` is a per-instantiation static.
+template <typename K>
+static inline void gu_allow_lds(K kern, std::atomic<uint64_t> &mask, int device, size_t bytes, size_t wanted)
+{
+    if (bytes <= 64 * 1024) return;
+    const uint64_t bit = device < 64 ? (1ull << device) : 0;
+    if (bit && (mask.load(std::memory_order_relaxed) & bit)) return;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wanted);
+    if (bit) mask.fetch_or(bit, std::memory_order_relaxed);
+}
 
 // ---- kernel launchers (gu_kernels.hip) -------------------------------------------
 int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice, bool only_done);

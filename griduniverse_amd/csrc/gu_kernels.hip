@@ -365,12 +365,8 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.row_shift = 0;
     a.stream_lds_off = 0;
     a.stream_lds_words = 0;
-    const int bs = gu_rollout_block();
-    {   // XCD-aware env-block order (GU_ROLLOUT_XCD=0/1, read per launch for A/B runs; see gu_env_block)
-        const char *x = std::getenv("GU_ROLLOUT_XCD");
-        const bool want = x ? std::atoi(x) != 0 : GU_ROLLOUT_XCD_DEFAULT;
-        a.xcd_remap = want && h->n_grids == 1;
-    }
+    const int bs = gu_rollout_block(h);
+    a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)
     if (policy == GU_POLICY_SAMPLE)
         hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
     if (gu_rollout_multi(h, a, policy, auto_mode, traj, stats) || gu_rollout_rows(h, a, policy, auto_mode, traj, stats)) {

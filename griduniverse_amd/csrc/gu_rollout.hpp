@@ -390,14 +390,7 @@ static inline int gu_lds_block(const gu_engine *h, int preferred, int planes)
     return 0;
 }
 
-static inline int gu_rollout_block()
-{
-    const char *s = std::getenv("GU_ROLLOUT_BLOCK");  // read per launch: A/B runs switch it inside one process
-    const int v = s ? std::atoi(s) : 256;
-    return (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ? v : 256;
-}
-
-#define GU_ROLLOUT_XCD_DEFAULT false
+static inline int gu_rollout_block(const gu_engine *h) { return (int)gu_opt(h, GU_OPT_ROLLOUT_BLOCK); }
 
 template <int POLICY, int AUTO, int TRAJ, bool STATS>
 static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
@@ -417,8 +410,8 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
         auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 1>;
         if (POLICY == GU_POLICY_STREAM && TRAJ != 0) {
             // staged action words: as many per lane as the LDS share of a block admits at the occupancy this batch needs
-            const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, (gu_blocks(h->N, lds_bs) + 255) / 256));
-            const int64_t room = (int64_t)(160 * 1024) / per_cu - (int64_t)lds - 512;
+            const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, (gu_blocks(h->N, lds_bs) + h->n_cu - 1) / h->n_cu));
+            const int64_t room = h->lds_per_cu / per_cu - (int64_t)lds - 512;
             int64_t kw = std::min<int64_t>({room / ((int64_t)lds_bs * 4), (int64_t)64, (a.T + 15) / 16});
             if (kw >= 4) {
                 b.stream_lds_off = (int32_t)lds;
@@ -426,13 +419,13 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
                 lds += (size_t)kw * lds_bs * 4;
             }
         }
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_per_cu);
         hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), lds, h->stream, b);
         return;
     }
     if constexpr (POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM) {
         // one grid too big for two planes in 64 KiB: its flags plane alone, up to the whole 160 KB of a CU
-        if (h->n_grids == 1 && h->W <= 32767 && (size_t)h->cell_bytes <= 160 * 1024 - 512) {
+        if (h->n_grids == 1 && h->W <= 32767 && (int64_t)h->cell_bytes <= h->lds_per_cu - 512) {
             a.xcd_remap = a.xcd_remap && blocks_ok(bs);
             auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 3>;
             if (h->cell_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->cell_bytes);
@@ -441,7 +434,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
         }
         // misaligned multi-grid engine (e.g. one maze per env): private per-lane copies in LDS if 64 of them fit
         const size_t priv = 64 * ((size_t)h->cell_bytes + GU_PRIVATE_PAD);
-        if (h->n_grids > 1 && h->W <= 32767 && priv <= 160 * 1024) {
+        if (h->n_grids > 1 && h->W <= 32767 && (int64_t)priv <= h->lds_per_cu) {
             auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 2>;
             if (priv > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv);
             hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, 64)), dim3(64), priv, h->stream, a);

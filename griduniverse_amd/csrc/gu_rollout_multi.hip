@@ -245,25 +245,21 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_multi_kernel(const Ro
 }
 
 // ------------------------------------------------------------------------------------ host side
-static int multi_mode()
-{
-    const char *s = std::getenv("GU_ROLLOUT_MULTI");  // read per launch: A/B runs switch it inside one process
-    return s ? std::atoi(s) : -1;
-}
+static int multi_mode(const gu_engine *h) { return (int)gu_opt(h, GU_OPT_ROLLOUT_MULTI); }
 
 // (K, workgroup size, copies) or false: (4^K * 4 * copies + 16) bytes per cell and workgroup, as many workgroups per CU as the
 // batch needs on 256 CUs
 static bool multi_shape(const gu_engine *h, int *K, int *block, int *copies)
 {
-    const char *fk = std::getenv("GU_ROLLOUT_MULTI_K"), *fc = std::getenv("GU_ROLLOUT_MULTI_COPIES");  // diagnostics
-    const int only = fk ? std::atoi(fk) : 0, max_copies = (fc && std::atoi(fc) == 2) ? 2 : 1;  // (a second copy across the banks buys nothing: profiles/r02h_multi_ab.txt)
+    // diagnostics: force K, replicate the table (a second copy across the banks buys nothing: profiles/r02h_multi_ab.txt)
+    const int only = (int)gu_opt(h, GU_OPT_ROLLOUT_MULTI_K), max_copies = gu_opt(h, GU_OPT_ROLLOUT_MULTI_COPIES) == 2 ? 2 : 1;
     for (int bs = 256; bs <= GU_MAX_BLOCK; bs <<= 1) {
-        const int64_t blocks = (h->N + bs - 1) / bs, per_cu = (blocks + 255) / 256;
+        const int64_t blocks = (h->N + bs - 1) / bs, per_cu = (blocks + h->n_cu - 1) / h->n_cu;
         for (int k = 4; k >= 2; k -= 2) {
             if (only && only != k) continue;
             const int64_t row = (int64_t)4 << (2 * k);
             for (int c = max_copies; c >= 1; c >>= 1) {
-                if (((int64_t)h->S * (row * c + 16)) * per_cu <= 160 * 1024 - 2048) {
+                if (((int64_t)h->S * (row * c + 16)) * per_cu <= h->lds_per_cu - 2048) {
                     *K = k, *block = bs, *copies = c;
                     return true;
                 }
@@ -277,7 +273,7 @@ static bool multi_shape(const gu_engine *h, int *K, int *block, int *copies)
 bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats)
 {
     if ((policy != GU_POLICY_UNIFORM && policy != GU_POLICY_STREAM) || traj != 0 || auto_mode == 2 || h->n_grids != 1) return false;
-    const int mode = multi_mode();
+    const int mode = multi_mode(h);
     if (mode == 0 || (mode != 1 && a.T < 64)) return false;  // (short launches: the second table's staging is not worth it)
     int K = 0, bs = 0, copies = 0;
     if (!multi_shape(h, &K, &bs, &copies)) return false;
@@ -310,11 +306,8 @@ bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode
 #define GU_MULTI_LAUNCH_P(PP, KK, ST)                                                                                        \
     do {                                                                                                                     \
         auto kern = gu_rollout_multi_kernel<PP, KK, ST>;                                                                     \
-        static size_t allowed = 64 * 1024;                                                                                   \
-        if (lds > allowed) {                                                                                                 \
-            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
-            allowed = 160 * 1024;                                                                                            \
-        }                                                                                                                    \
+        static std::atomic<uint64_t> raised{0}; /* per instantiation AND per device (gu_allow_lds) */                        \
+        gu_allow_lds(kern, raised, h->device, lds, (size_t)h->lds_per_cu);                                                   \
         hipLaunchKernelGGL(kern, grid, block, lds, h->stream, a, which, h->d_mrows1[which], shift);                          \
     } while (0)
 #define GU_MULTI_LAUNCH(KK, ST)                                                          \

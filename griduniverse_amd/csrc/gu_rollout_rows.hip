@@ -324,9 +324,9 @@ static bool rows_shape(const gu_engine *h, int row_bytes, int max_copies, int *b
     // the smallest workgroup that fits, with as many copies as its LDS share admits (the copy count matters little once the
     // table is staged with wide, pipelined stores; the workgroup size does: profiles/r02e_rows_copies.txt)
     for (int bs = 256; bs <= GU_MAX_BLOCK; bs <<= 1) {
-        const int64_t blocks = (h->N + bs - 1) / bs, per_cu = (blocks + 255) / 256;
+        const int64_t blocks = (h->N + bs - 1) / bs, per_cu = (blocks + h->n_cu - 1) / h->n_cu;
         for (int c = max_copies; c >= 1; c >>= 1) {
-            if ((int64_t)h->S * row_bytes * c * per_cu <= 160 * 1024 - 2048) {
+            if ((int64_t)h->S * row_bytes * c * per_cu <= h->lds_per_cu - 2048) {
                 *block = bs;
                 *copies = c;
                 return true;
@@ -338,31 +338,23 @@ static bool rows_shape(const gu_engine *h, int row_bytes, int max_copies, int *b
 
 // copies of every row across the LDS banks: up to 8 (uniform / stream), 16 (greedy), 4 (sampled); GU_ROWS_COPIES overrides
 // (a power of two; diagnostics)
-static int rows_max_copies(int32_t policy)
+static int rows_max_copies(const gu_engine *h, int32_t policy)
 {
-    const char *s = std::getenv("GU_ROWS_COPIES");
-    const int v = s ? std::atoi(s) : 0;
+    const int v = (int)gu_opt(h, GU_OPT_ROWS_COPIES);
     if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) return v;
     return policy == GU_POLICY_GREEDY ? 16 : policy == GU_POLICY_SAMPLE ? 4 : 8;
 }
 
-static int rows_mode()
-{
-    const char *s = std::getenv("GU_ROLLOUT_ROWS");  // read per launch: A/B runs switch it inside one process
-    return s ? std::atoi(s) : -1;
-}
+static int rows_mode(const gu_engine *h) { return (int)gu_opt(h, GU_OPT_ROLLOUT_ROWS); }
 
 template <int POLICY>
-static void rows_dispatch(const RolloutArgs &a, int traj, bool stats, int auto_reset, dim3 grid, dim3 block, size_t lds, hipStream_t stream)
+static void rows_dispatch(const gu_engine *h, const RolloutArgs &a, int traj, bool stats, int auto_reset, dim3 grid, dim3 block, size_t lds, hipStream_t stream)
 {
 #define GU_ROWS_LAUNCH(TR, ST)                                                                                           \
     do {                                                                                                                 \
         auto kern = gu_rollout_rows_kernel<POLICY, TR, ST>;                                                              \
-        static size_t allowed = 64 * 1024; /* per instantiation: raise the dynamic-LDS limit once, not per launch */     \
-        if (lds > allowed) {                                                                                             \
-            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
-            allowed = 160 * 1024;                                                                                        \
-        }                                                                                                                \
+        static std::atomic<uint64_t> raised{0}; /* per instantiation and per device: raise the dynamic-LDS limit once */ \
+        gu_allow_lds(kern, raised, h->device, lds, (size_t)h->lds_per_cu);                                               \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a, auto_reset);                                               \
     } while (0)
     if (traj == 1) {
@@ -380,7 +372,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
 {
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return false;
     if (auto_mode == 2) return false;  // several start cells: the reset draws from the RNG, it cannot be tabulated
-    const int mode = rows_mode();
+    const int mode = rows_mode(h);
     // Default policy (profiles/r02b_map_ab.txt, profiles/r02d_rows_crossover.txt, profiles/r02e_policy_rows.txt; interleaved
     // A/B in one process): every launch that is bound by the dependent chain rather than by the HBM write path --
     //   stats only           : every batch size (uniform: 62 -> 40 us at 65 536 envs, 68 -> 35 us at 262 144)
@@ -398,14 +390,16 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         // (a caller-supplied stream with int32 rows: the row-table kernel reads its action words straight from HBM, and a load
         // among streaming stores waits for all of them -- beyond 16 384 envs the general kernel, which stages the words in LDS,
         // is the quicker one: 88 against 116 us at 32 768 envs, profiles/r02j_stream_crossover.txt)
-        const unsigned int32_limit = policy == GU_POLICY_SAMPLE ? 256 : policy == GU_POLICY_STREAM ? 64 : 128;
-        if ((traj == 1 && blocks > int32_limit) || (traj == 2 && blocks > 256)) return false;
+        // (measured on the 256 CUs of an MI355X; stated relative to the CU count: one workgroup per CU, a quarter, half of them)
+        const unsigned cus = (unsigned)h->n_cu;
+        const unsigned int32_limit = policy == GU_POLICY_SAMPLE ? cus : policy == GU_POLICY_STREAM ? cus / 4 : cus / 2;
+        if ((traj == 1 && blocks > int32_limit) || (traj == 2 && blocks > cus)) return false;
         if (policy == GU_POLICY_SAMPLE && auto_mode != 1) return false;
     }
     const bool table_policy = policy == GU_POLICY_GREEDY || policy == GU_POLICY_SAMPLE;
     const int row_log2 = policy == GU_POLICY_GREEDY ? 2 : policy == GU_POLICY_SAMPLE ? 5 : 4;
     int bs = 0, copies = 0;
-    if (!rows_shape(h, 1 << row_log2, rows_max_copies(policy), &bs, &copies)) return false;
+    if (!rows_shape(h, 1 << row_log2, rows_max_copies(h, policy), &bs, &copies)) return false;
     int shift = row_log2;
     while ((1 << (shift - row_log2)) < copies) ++shift;
     const int which = auto_mode ? 1 : 0;
@@ -441,10 +435,10 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     const dim3 grid(gu_blocks(h->N, bs)), block(bs);
     a.xcd_remap = a.xcd_remap && grid.x % 8 == 0;
     switch (policy) {
-    case GU_POLICY_UNIFORM: rows_dispatch<GU_POLICY_UNIFORM>(a, traj, stats, which, grid, block, lds, h->stream); break;
-    case GU_POLICY_STREAM: rows_dispatch<GU_POLICY_STREAM>(a, traj, stats, which, grid, block, lds, h->stream); break;
-    case GU_POLICY_GREEDY: rows_dispatch<GU_POLICY_GREEDY>(a, traj, stats, which, grid, block, lds, h->stream); break;
-    default: rows_dispatch<GU_POLICY_SAMPLE>(a, traj, stats, which, grid, block, lds, h->stream); break;
+    case GU_POLICY_UNIFORM: rows_dispatch<GU_POLICY_UNIFORM>(h, a, traj, stats, which, grid, block, lds, h->stream); break;
+    case GU_POLICY_STREAM: rows_dispatch<GU_POLICY_STREAM>(h, a, traj, stats, which, grid, block, lds, h->stream); break;
+    case GU_POLICY_GREEDY: rows_dispatch<GU_POLICY_GREEDY>(h, a, traj, stats, which, grid, block, lds, h->stream); break;
+    default: rows_dispatch<GU_POLICY_SAMPLE>(h, a, traj, stats, which, grid, block, lds, h->stream); break;
     }
     return true;
 }

@@ -20,6 +20,7 @@
 #include "gu_rng.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -797,11 +798,11 @@ static ViArgs vi_args(gu_engine *h, double gamma, unsigned long long *delta_key)
     return a;
 }
 
-// The single-workgroup path: grids of up to VI_PB_MAX_STATES states (GU_VI_MULTI_LAUNCH=1 forces the per-round
+// The single-workgroup path: grids of up to VI_PB_MAX_STATES states (GU_OPT_VI_PATH = 2 forces the per-round
 // launches, for the tests).  Runs up to max_rounds rounds in place on the current tables.
 static bool vi_block_eligible(const gu_engine *h)
 {
-    return h->S <= VI_PB_MAX_STATES && std::getenv("GU_VI_MULTI_LAUNCH") == nullptr;
+    return h->S <= VI_PB_MAX_STATES && gu_opt(h, GU_OPT_VI_PATH) != 2;
 }
 
 static int vi_block_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds,
@@ -845,15 +846,30 @@ static int vi_block_run(gu_engine *h, double gamma, double threshold, bool use_t
     return GU_OK;
 }
 
-// The cluster path: 4097 .. 524 288 states, one launch for the whole loop (GU_VI_CLUSTER=0 or GU_VI_MULTI_LAUNCH=1 send these
-// grids down the one-launch-per-round path instead, for the tests and A/B runs).  Runs up to max_rounds rounds; the value
-// table ends in d_v[vi_cur] (buffers swapped on an odd round count), the policy is updated in place.
-static bool vi_cluster_eligible(const gu_engine *h)
+// The cluster path: 4097 .. 524 288 states, one launch for the whole loop (GU_OPT_VI_PATH = 1 or 2 sends these grids down the
+// one-launch-per-round path instead, for the tests and A/B runs; so does a device with too few CUs for the workgroups to be
+// resident together -- a CPX partition, a CU mask, a smaller part).  Runs up to max_rounds rounds; the value table ends in
+// d_v[vi_cur] (buffers swapped on an odd round count), the policy is updated in place.
+#define GU_VI_FALLBACK 1  /* internal: the cluster launch did not complete, the tables are as they were -- take the other path */
+
+static bool vi_cluster_shape(const gu_engine *h, int *K_out, unsigned *G_out)
 {
     if (h->S <= VI_PB_MAX_STATES || h->S > VI_CL_MAX_STATES) return false;
-    if (std::getenv("GU_VI_MULTI_LAUNCH") != nullptr) return false;
-    const char *c = std::getenv("GU_VI_CLUSTER");
-    return !(c && std::atoi(c) == 0);
+    const int64_t wgs_needed = ((int64_t)h->S + VI_CL_THREADS - 1) / VI_CL_THREADS;
+    const int max_wgs = h->n_cu < VI_CL_MAX_WGS ? h->n_cu : VI_CL_MAX_WGS;  // one workgroup per CU: all resident together
+    int K = 1;
+    while (K < VI_CL_MAX_K && wgs_needed > (int64_t)K * max_wgs) K <<= 1;
+    const int64_t G = (wgs_needed + K - 1) / K;
+    if (G > max_wgs) return false;
+    if (K_out) *K_out = K;
+    if (G_out) *G_out = (unsigned)G;
+    return true;
+}
+
+static bool vi_cluster_eligible(const gu_engine *h)
+{
+    const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
+    return (path == 0 || path == 3) && vi_cluster_shape(h, nullptr, nullptr);
 }
 
 static int vi_cluster_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds,
@@ -861,25 +877,29 @@ static int vi_cluster_run(gu_engine *h, double gamma, double threshold, bool use
 {
     *rounds_done = 0;
     if (max_rounds <= 0) return GU_OK;
-    // scratch: [sync counter, timeout word, rounds_done, pad] (16 B) | delta keys [max_rounds]
+    // scratch: [sync counter, timeout word, rounds_done, pad] (16 B) | delta keys [max_rounds] | snapshot of v and pi
     const size_t key_bytes = (size_t)max_rounds * sizeof(unsigned long long);
-    const size_t total = (16 + key_bytes + 15) & ~(size_t)15;
+    const size_t snap_off = (16 + key_bytes + 15) & ~(size_t)15;
+    const size_t v_bytes = (size_t)h->S * sizeof(double);
+    const size_t total = snap_off + 5 * v_bytes;
     int rc = gu_ensure_scratch(h, total);
     if (rc != GU_OK) return rc;
     uint32_t *sync_d = (uint32_t *)h->d_scratch;
     int32_t *done_d = (int32_t *)h->d_scratch + 2;
     unsigned long long *keys_d = (unsigned long long *)((char *)h->d_scratch + 16);
-    GU_HIP(hipMemsetAsync(h->d_scratch, 0, total, h->stream));  // every polled word is zeroed before every launch
+    char *snap = (char *)h->d_scratch + snap_off;
+    GU_HIP(hipMemsetAsync(h->d_scratch, 0, snap_off, h->stream));  // every polled word is zeroed before every launch
+    // A barrier that times out (the workgroups were not resident together: another process on the device, a CU mask) leaves v
+    // written halfway through a round and the policy rows of some states updated: the launch works on a snapshot's ORIGINAL,
+    // and a timeout restores it (40 bytes per state, device to device) and hands the loop to the one-launch-per-round path.
+    GU_HIP(hipMemcpyAsync(snap, h->d_v[h->vi_cur], v_bytes, hipMemcpyDeviceToDevice, h->stream));
+    GU_HIP(hipMemcpyAsync(snap + v_bytes, h->d_pi[h->vi_cur], 4 * v_bytes, hipMemcpyDeviceToDevice, h->stream));
+    if (gu_opt(h, GU_OPT_VI_PATH) == 3) GU_HIP(hipMemsetD32Async((hipDeviceptr_t)(sync_d + 1), 1, 1, h->stream));  // tests: an injected timeout
     ViClusterArgs a{h->d_cell, h->cell_bytes, h->W, h->S, gamma, threshold, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1],
                     h->d_pi[h->vi_cur], keys_d, sync_d, done_d, max_rounds, use_threshold ? 1 : 0};
-    int n_cu = 0;
-    GU_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
-    const int64_t wgs_needed = ((int64_t)h->S + VI_CL_THREADS - 1) / VI_CL_THREADS;
-    const int max_wgs = n_cu < VI_CL_MAX_WGS ? n_cu : VI_CL_MAX_WGS;  // one workgroup per CU: all resident together
     int K = 1;
-    while (K < VI_CL_MAX_K && wgs_needed > (int64_t)K * max_wgs) K <<= 1;
-    const unsigned G = (unsigned)((wgs_needed + K - 1) / K);
-    GU_REQUIRE((int)G <= max_wgs, GU_ERR_UNSUPPORTED, "grid of %d states needs %u resident workgroups, the device has %d CUs", h->S, G, n_cu);
+    unsigned G = 0;
+    GU_REQUIRE(vi_cluster_shape(h, &K, &G), GU_ERR_UNSUPPORTED, "grid of %d states does not fit a workgroup cluster on %d CUs", h->S, h->n_cu);
     void (*kern)(const ViClusterArgs) = nullptr;
     switch (K * 2 + (greedy ? 1 : 0)) {
     case 2: kern = gu_vi_cluster_kernel<1, false>; break;
@@ -892,7 +912,13 @@ static int vi_cluster_run(gu_engine *h, double gamma, double threshold, bool use
     int32_t done = 0;
     GU_HIP(hipMemcpyAsync(&done, done_d, sizeof done, hipMemcpyDeviceToHost, h->stream));
     GU_HIP(hipStreamSynchronize(h->stream));
-    GU_REQUIRE(done >= 0, GU_ERR_HIP, "the DP cluster kernel's grid barrier timed out (its %u workgroups were not resident together)", G);
+    if (done < 0) {
+        GU_HIP(hipMemcpyAsync(h->d_v[h->vi_cur], snap, v_bytes, hipMemcpyDeviceToDevice, h->stream));
+        GU_HIP(hipMemcpyAsync(h->d_pi[h->vi_cur], snap + v_bytes, 4 * v_bytes, hipMemcpyDeviceToDevice, h->stream));
+        GU_HIP(hipStreamSynchronize(h->stream));
+        if (gu_debug()) fprintf(stderr, "[gu] DP cluster kernel: grid barrier timed out (%u workgroups not resident together); tables restored, one launch per round instead\n", G);
+        return GU_VI_FALLBACK;
+    }
     if (deltas && done > 0) {
         std::vector<unsigned long long> keys((size_t)done);
         GU_HIP(hipMemcpy(keys.data(), keys_d, (size_t)done * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -950,7 +976,8 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
     }
     if (vi_cluster_eligible(h)) {
         int32_t done = 0;
-        return vi_cluster_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
+        rc = vi_cluster_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
+        if (rc != GU_VI_FALLBACK) return rc;
     }
     GU_HIP(hipMemsetAsync(h->d_delta, 0, (size_t)iters * sizeof(unsigned long long), h->stream));
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
@@ -989,7 +1016,10 @@ int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, in
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
     if (vi_block_eligible(h)) return vi_block_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
-    if (vi_cluster_eligible(h)) return vi_cluster_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
+    if (vi_cluster_eligible(h)) {
+        rc = vi_cluster_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
+        if (rc != GU_VI_FALLBACK) return rc;
+    }
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
     const size_t smem = lds ? 2 * (size_t)h->cell_bytes : 0;
@@ -1048,7 +1078,10 @@ int gu_vi_eval_run(gu_handle h, double gamma, double threshold, int32_t max_step
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
     if (vi_block_eligible(h)) return vi_block_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
-    if (vi_cluster_eligible(h)) return vi_cluster_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
+    if (vi_cluster_eligible(h)) {
+        rc = vi_cluster_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
+        if (rc != GU_VI_FALLBACK) return rc;
+    }
     // larger grids: one evaluation launch per sweep, the host looks at the deltas once per batch
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
@@ -1168,61 +1201,76 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_vi_sweep_step_run accepts only GU_F_AUTO_RESET");
     GU_REQUIRE(iters > 0 && iters <= 1000000, GU_ERR_INVALID, "iters must be in 1..1000000");
-    int n_cu = 0;
-    GU_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     const int64_t threads = h->N > h->S ? h->N : (int64_t)h->S;
     const int64_t G = (threads + VI_CL_THREADS - 1) / VI_CL_THREADS;
-    const char *sw = std::getenv("GU_VI_CLUSTER");
-    const bool cluster = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && G <= (n_cu < VI_CL_MAX_WGS ? n_cu : VI_CL_MAX_WGS) && !(sw && std::atoi(sw) == 0);
-    if (!cluster) {  // one fused launch per round; the deltas are collected once at the end
-        std::vector<double> one((size_t)iters);
-        for (int32_t i = 0; i < iters; ++i) {
-            rc = gu_vi_sweep_step(h, gamma, flags, deltas ? &one[(size_t)i] : nullptr);
-            if (rc != GU_OK) return rc;
-        }
-        if (deltas) memcpy(deltas, one.data(), (size_t)iters * sizeof(double));
-        return GU_OK;
-    }
+    const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
+    bool cluster = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && G <= (h->n_cu < VI_CL_MAX_WGS ? h->n_cu : VI_CL_MAX_WGS) && (path == 0 || path == 3);
     const size_t key_bytes = (size_t)iters * sizeof(unsigned long long);
-    const size_t total = (16 + key_bytes + 15) & ~(size_t)15;
-    rc = gu_ensure_scratch(h, total);
-    if (rc != GU_OK) return rc;
-    uint32_t *sync_d = (uint32_t *)h->d_scratch;
-    int32_t *done_d = (int32_t *)h->d_scratch + 2;
-    unsigned long long *keys_d = (unsigned long long *)((char *)h->d_scratch + 16);
-    GU_HIP(hipMemsetAsync(h->d_scratch, 0, total, h->stream));
-    ViStepClusterArgs a{};
-    a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, 0.0, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1],
-                         h->d_pi[h->vi_cur], keys_d, sync_d, done_d, iters, 0};
-    a.pos = h->pos();
-    a.reward = h->reward();
-    a.done = h->done();
-    a.episode = h->d_episode;
-    a.starts = h->d_starts;
-    a.n_starts = (uint32_t)h->n_starts;
-    a.seed_prefix = h->seed_prefix;
-    a.env_id0 = (uint32_t)h->env_id0;
-    a.N = h->N;
-    a.flags = flags;
-    a.done_bits = h->d_done_bits;
-    hipLaunchKernelGGL(gu_vi_sweep_step_cluster_kernel, dim3((unsigned)G), dim3(VI_CL_THREADS), 2 * (size_t)h->cell_bytes, h->stream, a);
-    GU_HIP(hipGetLastError());
-    int32_t done = 0;
-    GU_HIP(hipMemcpyAsync(&done, done_d, sizeof done, hipMemcpyDeviceToHost, h->stream));
-    GU_HIP(hipStreamSynchronize(h->stream));
-    GU_REQUIRE(done >= 0, GU_ERR_HIP, "the sweep-step cluster kernel's grid barrier timed out (its %lld workgroups were not resident together)", (long long)G);
-    if (deltas) {
-        std::vector<unsigned long long> keys((size_t)iters);
-        GU_HIP(hipMemcpy(keys.data(), keys_d, key_bytes, hipMemcpyDeviceToHost));
-        for (int32_t i = 0; i < iters; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
+    const size_t snap_off = (16 + key_bytes + 15) & ~(size_t)15;
+    const size_t v_bytes = (size_t)h->S * sizeof(double), n4 = (size_t)h->N * 4, bits_bytes = (((size_t)h->N + 63) / 64) * 8;
+    if (cluster) {
+        rc = gu_ensure_scratch(h, snap_off + 5 * v_bytes + 4 * n4 + bits_bytes);
+        if (rc != GU_OK) return rc;
+        uint32_t *sync_d = (uint32_t *)h->d_scratch;
+        int32_t *done_d = (int32_t *)h->d_scratch + 2;
+        unsigned long long *keys_d = (unsigned long long *)((char *)h->d_scratch + 16);
+        char *snap = (char *)h->d_scratch + snap_off;
+        GU_HIP(hipMemsetAsync(h->d_scratch, 0, snap_off, h->stream));
+        // what a barrier timeout would leave half-advanced -- tables, positions, rewards, done flags and their ballots,
+        // episode counters -- is snapshot first (device to device), so that a timeout can hand the UNTOUCHED state to the
+        // one-launch-per-round path below
+        void *live[5] = {h->d_v[h->vi_cur], h->d_pi[h->vi_cur], h->d_out3, h->d_episode, h->d_done_bits};
+        const size_t size[5] = {v_bytes, 4 * v_bytes, 3 * n4, n4, bits_bytes};
+        size_t off = 0;
+        for (int k = 0; k < 5; off += size[k], ++k) GU_HIP(hipMemcpyAsync(snap + off, live[k], size[k], hipMemcpyDeviceToDevice, h->stream));
+        if (path == 3) GU_HIP(hipMemsetD32Async((hipDeviceptr_t)(sync_d + 1), 1, 1, h->stream));  // tests: an injected timeout
+        ViStepClusterArgs a{};
+        a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, 0.0, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1],
+                             h->d_pi[h->vi_cur], keys_d, sync_d, done_d, iters, 0};
+        a.pos = h->pos();
+        a.reward = h->reward();
+        a.done = h->done();
+        a.episode = h->d_episode;
+        a.starts = h->d_starts;
+        a.n_starts = (uint32_t)h->n_starts;
+        a.seed_prefix = h->seed_prefix;
+        a.env_id0 = (uint32_t)h->env_id0;
+        a.N = h->N;
+        a.flags = flags;
+        a.done_bits = h->d_done_bits;
+        hipLaunchKernelGGL(gu_vi_sweep_step_cluster_kernel, dim3((unsigned)G), dim3(VI_CL_THREADS), 2 * (size_t)h->cell_bytes, h->stream, a);
+        GU_HIP(hipGetLastError());
+        int32_t done = 0;
+        GU_HIP(hipMemcpyAsync(&done, done_d, sizeof done, hipMemcpyDeviceToHost, h->stream));
+        GU_HIP(hipStreamSynchronize(h->stream));
+        if (done >= 0) {
+            if (deltas) {
+                std::vector<unsigned long long> keys((size_t)iters);
+                GU_HIP(hipMemcpy(keys.data(), keys_d, key_bytes, hipMemcpyDeviceToHost));
+                for (int32_t i = 0; i < iters; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
+            }
+            if (iters & 1) {
+                double *t = h->d_v[0];
+                h->d_v[0] = h->d_v[1];
+                h->d_v[1] = t;
+            }
+            h->greedy_valid = false;
+            h->steps_taken += (uint32_t)iters;
+            return GU_OK;
+        }
+        off = 0;
+        for (int k = 0; k < 5; off += size[k], ++k) GU_HIP(hipMemcpyAsync(live[k], snap + off, size[k], hipMemcpyDeviceToDevice, h->stream));
+        GU_HIP(hipStreamSynchronize(h->stream));
+        if (gu_debug()) fprintf(stderr, "[gu] sweep-step cluster kernel: grid barrier timed out (%lld workgroups not resident together); state restored, one launch per round instead\n", (long long)G);
+        cluster = false;
     }
-    if (iters & 1) {
-        double *t = h->d_v[0];
-        h->d_v[0] = h->d_v[1];
-        h->d_v[1] = t;
+    // one fused launch per round; the deltas are collected once at the end
+    std::vector<double> one((size_t)iters);
+    for (int32_t i = 0; i < iters; ++i) {
+        rc = gu_vi_sweep_step(h, gamma, flags, deltas ? &one[(size_t)i] : nullptr);
+        if (rc != GU_OK) return rc;
     }
-    h->greedy_valid = false;
-    h->steps_taken += (uint32_t)iters;
+    if (deltas) memcpy(deltas, one.data(), (size_t)iters * sizeof(double));
     return GU_OK;
 }
 

@@ -58,6 +58,22 @@ class Engine(object):
     def __exit__(self, *exc):
         self.close()
 
+    @staticmethod
+    def device_info(device=0):
+        """dict: name, arch, pci, cus, lds_per_cu, sclk_khz, mclk_khz, bus_bits, l2_bytes, hbm_bytes, hbm_free (gu_device_info)."""
+        return _lib.device_info(device)
+
+    # ------------------------------------------------------------------ options
+    def set_option(self, name, value):
+        """Launch-shape / search option of THIS engine (include/gu.h "options"; `_lib.OPTIONS` names them); None returns
+        it to the process default.  Results never depend on options."""
+        check(self.lib.gu_set_option(self._h, _lib.OPTIONS[name], _lib.OPT_UNSET if value is None else int(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_int64(0)
+        check(self.lib.gu_get_option(self._h, _lib.OPTIONS[name], ctypes.byref(v)))
+        return v.value
+
     # ------------------------------------------------------------------ configuration
     def set_grid(self, spec):
         p = spec.planes()
@@ -180,6 +196,24 @@ class Engine(object):
         n, best, worst = ctypes.c_int32(0), ctypes.c_float(0.0), ctypes.c_float(0.0)
         check(self.lib.gu_trajectory_placement(self._h, ctypes.byref(n), ctypes.byref(best), ctypes.byref(worst)))
         return n.value, best.value, worst.value
+
+    def trajectory_placement_detail(self):
+        """Everything the placement search of the trajectory buffer tried: dict(probe_ms=[...], address=[...], kept=index,
+        search_ms=wall time of the search, peak_bytes=most device memory it held at once)."""
+        n, kept = ctypes.c_int32(0), ctypes.c_int32(-1)
+        search, peak = ctypes.c_float(0.0), ctypes.c_uint64(0)
+        check(self.lib.gu_trajectory_placement_detail(self._h, 0, None, None, ctypes.byref(n), ctypes.byref(kept),
+                                                      ctypes.byref(search), ctypes.byref(peak)))
+        ms, addr = np.zeros(max(n.value, 1), np.float32), np.zeros(max(n.value, 1), np.uint64)
+        check(self.lib.gu_trajectory_placement_detail(self._h, ms.size, ptr(ms), ptr(addr), ctypes.byref(n), None, None, None))
+        return dict(probe_ms=[float(x) for x in ms[:n.value]], address=['0x%x' % int(a) for a in addr[:n.value]],
+                    kept=kept.value, search_ms=float(search.value), peak_bytes=int(peak.value))
+
+    def probe_trajectory(self):
+        """ms of one full write of the trajectory buffer the engine holds, in the rollout's store shape (overwrites it)."""
+        ms = ctypes.c_float(0.0)
+        check(self.lib.gu_probe_trajectory(self._h, ctypes.byref(ms)))
+        return ms.value
 
     def rollout(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
         """trajectory: False / True (three int32 rows per step) / 'packed' (one uint32 per env-step)."""
@@ -370,6 +404,23 @@ class Engine(object):
 
     def comm_destroy(self):
         check(self.lib.gu_comm_destroy(self._h))
+
+    # one process, one engine per device (ncclCommInitAll + one grouped all-gather; every engine on its own device)
+    @staticmethod
+    def comm_init_all(engines):
+        handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+        check(_lib.load().gu_comm_init_all(handles, len(engines)))
+        for rank, e in enumerate(engines):
+            e.nranks, e.rank = len(engines), rank
+
+    @staticmethod
+    def allgather_view_all(engines):
+        """(obs, reward, done) of all engines' envs, env-major: one grouped RCCL all-gather, read from the first device."""
+        handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+        total = sum(e.N for e in engines)
+        obs, rew, don = (np.empty(total, np.int32) for _ in range(3))
+        check(_lib.load().gu_allgather_view_all(handles, len(engines), ptr(obs), ptr(rew), ptr(don)))
+        return obs, rew, don
 
     def allgather_view(self):
         total = self.nranks * self.N

@@ -9,8 +9,10 @@ single-device batch and stepping needs no communication at all.
 The one exchange is optional: `gathered_view()` returns the single-array (obs, reward, done)
 of ALL envs on every rank -- one RCCL all-gather of each rank's packed int32[3n] block over
 xGMI (csrc/gu_comm.hip).  RCCL's 128-byte unique id travels from rank 0 to the others over
-whatever host channel the launcher already has; by default an initialised
-`torch.distributed` process group (any backend -- gloo is fine, it is only plumbing).
+a host channel: by default the package's own socket rendezvous (rendezvous.py: torchrun-style
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, no PyTorch anywhere in the product); any
+callable `broadcast_bytes(payload, src)` will do -- `torch_broadcast_bytes` is one for callers
+that already run a `torch.distributed` process group.
 """
 import os
 
@@ -37,8 +39,14 @@ def env_launch_info():
             int(os.environ.get('WORLD_SIZE', '1')))
 
 
+def rendezvous_broadcast_bytes(payload, src=0):
+    """Broadcast a byte string from `src` over the package's socket rendezvous (created from the environment on first use)."""
+    from . import rendezvous
+    return rendezvous.broadcast_bytes(payload, src)
+
+
 def torch_broadcast_bytes(payload, src=0):
-    """Broadcast a fixed-size byte string from `src` over the default torch.distributed group."""
+    """The same over an initialised torch.distributed process group (optional; the product never imports torch itself)."""
     import torch
     import torch.distributed as dist
     buf = torch.zeros(len(payload), dtype=torch.uint8)
@@ -63,7 +71,7 @@ class ShardedVecGridUniverse(object):
     """
 
     def __init__(self, total_envs, *, rank=None, world_size=None, device=None, seed=0, auto_reset=False,
-                 broadcast_bytes=torch_broadcast_bytes, engine_factory=None, **grid_kwargs):
+                 broadcast_bytes=rendezvous_broadcast_bytes, engine_factory=None, **grid_kwargs):
         env_rank, env_local, env_world = env_launch_info()
         self.rank = env_rank if rank is None else int(rank)
         self.world_size = env_world if world_size is None else int(world_size)
@@ -173,15 +181,12 @@ class MultiDeviceVecGridUniverse(object):
         """(obs, reward, done) of all envs, env-major.  Default: one D2H copy per device, concatenated on the host.
         rccl=True: one grouped RCCL all-gather over xGMI (needs every shard on its own device), then one copy."""
         if rccl:
-            import ctypes
-            from . import _lib
-            handles = (ctypes.c_void_p * len(self.shards))(*[s.engine._h for s in self.shards])
+            engines = [s.engine for s in self.shards]
+            cls = type(engines[0])
             if not getattr(self, '_comm_all', False):
-                _lib.check(_lib.load().gu_comm_init_all(handles, len(self.shards)))
+                cls.comm_init_all(engines)
                 self._comm_all = True
-            out = [np.empty(self.total_envs, np.int32) for _ in range(3)]
-            _lib.check(_lib.load().gu_allgather_view_all(handles, len(self.shards), *[_lib.ptr(o) for o in out]))
-            return tuple(out)
+            return tuple(cls.allgather_view_all(engines))
         parts = [s.engine.read_outputs() for s in self.shards]
         return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
 

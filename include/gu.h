@@ -70,6 +70,42 @@ int gu_last_error(char *buf, size_t len);     /* copies the thread's last messag
 int gu_device_count(int *count);              /* hipGetDeviceCount */
 int gu_source_hash(char *buf, size_t len);    /* 16 hex digits identifying the sources the library was built from
                                                  (sha256 over every .hip / .hpp under csrc and include/gu.h); returns the length */
+/* "key=value;..." description of device `device_id` (name, arch, pci bus id, cus, lds_per_cu, sclk_khz, mclk_khz,
+ * bus_bits, l2_bytes, hbm_bytes, hbm_free): what bench.py prints next to its numbers.  Returns the length. */
+int gu_device_info(int device_id, char *buf, size_t len);
+
+/* ---- options -------------------------------------------------------------------
+ * Launch-shape and search parameters, per engine (h) or -- h == NULL -- as the process default every engine without a value
+ * of its own uses.  GU_OPT_UNSET as value returns an option to the built-in default.  RESULTS NEVER DEPEND ON THEM (the
+ * tests run every kernel path against the oracle by flipping them); they exist for tests and measurements.  The library
+ * reads only two environment variables: GU_RCCL_LIB (which librccl to dlopen) and GU_DEBUG (reports on stderr).
+ * Options 100+ select known-unsafe experiments and are refused (GU_ERR_UNSUPPORTED) unless the library was built with
+ * -DGU_EXPERIMENTS (make exp -> libgu_exp.so, used by tools/ only). */
+#define GU_OPT_UNSET INT64_MIN
+#define GU_OPT_ROLLOUT_BLOCK 1        /* workgroup size of the general rollout kernel: 64 .. 1024 (256)                         */
+#define GU_OPT_ROLLOUT_ROWS 2         /* transition-row kernel: 0 never, 1 wherever eligible (default: by launch shape)       */
+#define GU_OPT_ROWS_COPIES 3          /* copies of its table across the LDS banks: 1, 2, .. 32 (default: by policy)           */
+#define GU_OPT_ROLLOUT_MULTI 4        /* K-step kernel: 0 never, 1 whenever the table fits (default: launches of >= 64 steps)  */
+#define GU_OPT_ROLLOUT_MULTI_K 5      /* force K = 2 or 4                                                                     */
+#define GU_OPT_ROLLOUT_MULTI_COPIES 6 /* 2 = replicate its table across the banks                                             */
+#define GU_OPT_ROLLOUT_XCD 7          /* 1 = XCD-aware env-block order (measured slower; off)                                 */
+#define GU_OPT_VI_PATH 8              /* DP: 1 = no workgroup-cluster kernel, 2 = one launch per round on every grid size     */
+#define GU_OPT_MC_SCRATCH_MB 9        /* scratch budget of gu_mc_evaluate (2048)                                              */
+#define GU_OPT_MC_LANE_RETURNS 10     /* 1 = return sums by the per-lane kernel instead of the LDS-tiled one                  */
+#define GU_OPT_MC_GLOBAL_WALK 11      /* 1 = history walk with its counters in global memory instead of LDS                   */
+#define GU_OPT_STEP_SYNC 12           /* 1 = gu_step always waits with the stream synchronisation                             */
+#define GU_OPT_TRAJ_CANDIDATES 13     /* back-to-back candidates of the trajectory placement search (12; 1 = take the first)  */
+#define GU_OPT_TRAJ_FAR_CANDIDATES 14 /* candidates behind spacers (32; 0 = none)                                             */
+#define GU_OPT_TRAJ_STRIDE_MIB 15     /* spacer size (3072)                                                                   */
+#define GU_OPT_TRAJ_FAR_MIB 16        /* most memory the search may hold at once (49152)                                      */
+#define GU_OPT_TRAJ_PROBE_ALL 17      /* 1 = probe every candidate, no early stop (measurement aid)                           */
+#define GU_OPT_COUNT 18
+#define GU_OPT_X_TRAJ_UNCACHED 100    /* EXPERIMENT: uncached memory type for the trajectory (readers may see stale bytes)    */
+#define GU_OPT_X_TRAJ_POISON 101      /* EXPERIMENT: fill a fresh trajectory buffer with 0x5A                                 */
+#define GU_OPT_X_MC_POISON 102        /* EXPERIMENT: fill the Monte-Carlo scratch with 0x5A before every evaluation           */
+#define GU_OPT_X_COUNT 3
+int gu_set_option(gu_handle h, int32_t option, int64_t value);
+int gu_get_option(gu_handle h, int32_t option, int64_t *value);   /* the value in force (own, process default or built-in) */
 
 /* ---- lifetime ----------------------------------------------------------------
  * One engine = `num_envs` lock-stepped instances of one grid on device `device_id`;
@@ -172,13 +208,28 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done);
  * (gu_reserve_trajectory(T) first: room for at least T rows; a buffer that is already large enough is kept); with GU_F_STATS the per-env reward sum and the
  * number of episodes finished during this call are kept for gu_read_stats. */
 int gu_reserve_trajectory(gu_handle h, int64_t T);
-/* Where an allocation lands in HBM decides how fast it can be written (5.7 .. 6.9 TB/s for 786 MB buffers of one process), so
- * gu_reserve_trajectory tries a few candidate allocations of 64 MB and more, writes each once in the rollout's store shape and
- * keeps the fastest (GU_TRAJ_CANDIDATES=n, default up to 12, stopping at the first clearly fast one -- 14 % quicker than the slowest seen, or 6.5 TB/s in absolute terms; 1 = take the first).
- * Neighbouring allocations tend to share their class, so for buffers of 256 MiB and more the search then goes further afield: up
- * to GU_TRAJ_FAR_CANDIDATES (32) more, each behind a spacer of GU_TRAJ_STRIDE_GIB (3) GiB held until the choice is made; never more
- * than half of the free memory nor GU_TRAJ_FAR_GIB (48) GiB in total.  This reports what it did. */
+/* Where an allocation lands in HBM decides how fast it can be written (5.7 .. 6.9 TB/s for 786 MB buffers of one process;
+ * DESIGN.md section 6), so gu_reserve_trajectory CHOOSES a buffer of 64 MB and more: it allocates candidates one after the
+ * other, writes each once in the rollout's own store shape, and keeps the fastest.  The search
+ *   - stops at the first clearly fast candidate (14 % quicker than the slowest seen; on gfx950 also: 6.5 TB/s or more);
+ *   - gives up after GU_OPT_TRAJ_CANDIDATES (12) back-to-back candidates whose probe times lie within 6 % of each other (a
+ *     device on which every allocation is alike), else -- buffers of 256 MiB and more -- continues with up to
+ *     GU_OPT_TRAJ_FAR_CANDIDATES (32) more, each behind a spacer of GU_OPT_TRAJ_STRIDE_MIB (3072) that is held until the
+ *     choice is made;
+ *   - never holds more than a third of the device's free memory nor GU_OPT_TRAJ_FAR_MIB (48 GiB) at once, everything but the
+ *     kept buffer is freed before the call returns;
+ *   - is per-process aware: once an engine of the process owns a chosen trajectory buffer on the device, later engines
+ *     probe at most 4 back-to-back candidates, hold at most an eighth of the free memory, and stop at the first
+ *     candidate within 3 % of the rate the first search ended on.
+ * gu_trajectory_placement reports the outcome, gu_trajectory_placement_detail everything that was tried: per candidate its
+ * probe time (ms per full write) and device address (capacity entries; *count = number tried), the index of the kept one,
+ * the wall time the search took and the largest number of bytes it held at once.  Any pointer may be NULL.
+ * gu_probe_trajectory re-runs the same timed write on the buffer the engine holds NOW (it overwrites the rows: for
+ * measurements -- bench.py runs it right after its timed region to tell a drifting device from a slow kernel). */
 int gu_trajectory_placement(gu_handle h, int32_t *candidates, float *best_ms, float *worst_ms);
+int gu_trajectory_placement_detail(gu_handle h, int32_t capacity, float *probe_ms, uint64_t *address, int32_t *count,
+                                   int32_t *kept, float *search_ms, uint64_t *peak_bytes);
+int gu_probe_trajectory(gu_handle h, float *milliseconds);
 int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);
 int gu_read_trajectory_packed(gu_handle h, int64_t t0, int64_t T, uint32_t *packed);   /* [T][N] after GU_F_PACKED */

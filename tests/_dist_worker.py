@@ -1,4 +1,5 @@
-"""Worker for tests/test_multiprocess.py: launched by torch.distributed.run with world_size 2 (gloo, CPU).
+"""Worker for tests/test_multiprocess.py: launched by torch.distributed.run with world_size 2, the way the driver launches
+bench.py -- but the ranks themselves never import torch: their host channel is griduniverse_amd/rendezvous.py.
 Each rank runs its shard of a 4096-env batch on the oracle-backed engine stub, then checks the shard against
 the single-process run of the whole batch and the gathered view against the concatenation of all shards."""
 import json
@@ -10,8 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-import torch.distributed as dist  # noqa: E402
-
+from griduniverse_amd import rendezvous  # noqa: E402
 from griduniverse_amd.parallel import ShardedVecGridUniverse, env_launch_info, shard_range  # noqa: E402
 from oracle import c_oracle as C  # noqa: E402
 from tests._oracle_engine import OracleEngine  # noqa: E402
@@ -19,9 +19,10 @@ from tests._oracle_engine import OracleEngine  # noqa: E402
 
 def main():
     out_dir = sys.argv[1]
-    dist.init_process_group('gloo')
     rank, local_rank, world = env_launch_info()
-    assert (rank, world) == (dist.get_rank(), dist.get_world_size())
+    channel = rendezvous.default()  # (what ShardedVecGridUniverse uses for RCCL's id by default)
+    assert (rank, world) == (channel.rank, channel.world)
+    OracleEngine.host_channel = channel
     total, T, seed = 4096, 200, 77
     lava = [16 + 32 * r for r in range(24)]  # config-4 grid
     env = ShardedVecGridUniverse(total, seed=seed, auto_reset=True, engine_factory=OracleEngine,
@@ -43,16 +44,17 @@ def main():
                and np.array_equal(done, want['done'][-1].astype(bool)) and done.dtype == bool)
 
     # the bench.py timing reduction: MAX over ranks of a per-rank scalar
-    import torch
-    t = torch.tensor([1.0 + rank], dtype=torch.float64)
-    dist.barrier()
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ok_max = float(t[0]) == float(world)
+    channel.barrier()
+    ok_max = channel.reduce([1.0 + rank, -float(rank)], 'MAX') == [float(world), 0.0] and channel.reduce([1.0 + rank], 'MIN') == [1.0]
 
     with open(os.path.join(out_dir, 'rank%d.json' % rank), 'w') as f:
         json.dump(dict(rank=rank, world=world, ok_shard=bool(ok_shard), ok_view=bool(ok_view), ok_max=bool(ok_max),
                        ids=[int(env.global_ids()[0]), int(env.global_ids()[-1])]), f)
     env.close()
+    channel.barrier()
+    channel.close()
+    rendezvous._default = None
+    assert 'torch' not in sys.modules, 'the product\'s N > 1 path imported torch'
 
     # bench.py's multi-rank flow (blocks, max-over-ranks, gathered-view check, strong-scaling config 4) on the stub engine
     import bench
@@ -64,7 +66,7 @@ def main():
     if rank == 0:
         with open(os.path.join(out_dir, 'bench_line.json'), 'w') as f:
             f.write(lines[0])
-    dist.destroy_process_group()
+    assert 'torch' not in sys.modules, 'bench.py imported torch'
 
 
 if __name__ == '__main__':

@@ -74,30 +74,36 @@ class OracleEngine(object):
         marks, self._marks = np.asarray(self.__dict__.get('_marks', []), np.float64), []
         return np.diff(marks) * 1e3
 
-    # ---- the gathered view over gloo instead of RCCL (same packed layout as csrc/gu_comm.hip)
+    # ---- the gathered view over the host channel instead of RCCL (same packed layout as csrc/gu_comm.hip)
+    host_channel = None  # a griduniverse_amd.rendezvous.Rendezvous; set by whoever drives several ranks (bench.py, the worker)
+
     @staticmethod
     def comm_unique_id():
         return os.urandom(128)
 
     def comm_init(self, nranks, rank, unique_id):
-        import torch
-        import torch.distributed as dist
         self.nranks, self.rank, self.uid = nranks, rank, bytes(unique_id)
-        mine = torch.frombuffer(bytearray(self.uid), dtype=torch.uint8).clone()
-        everyone = [torch.zeros_like(mine) for _ in range(nranks)]
-        dist.all_gather(everyone, mine)
-        assert all(bytes(t.numpy().tobytes()) == self.uid for t in everyone), 'ranks disagree on the unique id'
+        everyone = type(self).host_channel.allgather_bytes(self.uid) if nranks > 1 else [self.uid]
+        assert len(everyone) == nranks and all(u == self.uid for u in everyone), 'ranks disagree on the unique id'
 
     def allgather_view(self):
-        import torch
-        import torch.distributed as dist
-        block = torch.from_numpy(np.concatenate(self.read_outputs()).astype(np.int32))
-        blocks = [torch.zeros_like(block) for _ in range(self.nranks)]
-        dist.all_gather(blocks, block)
-        return unpack_view(np.stack([b.numpy() for b in blocks]), self.N)
+        block = np.concatenate(self.read_outputs()).astype('<i4').tobytes()
+        blocks = type(self).host_channel.allgather_bytes(block) if self.nranks > 1 else [block]
+        return unpack_view(np.stack([np.frombuffer(b, dtype='<i4') for b in blocks]), self.N)
 
     def comm_destroy(self):
         self.uid = None
+
+    # one process, several engines (stands in for gu_comm_init_all / gu_allgather_view_all)
+    @staticmethod
+    def comm_init_all(engines):
+        for rank, e in enumerate(engines):
+            e.nranks, e.rank = len(engines), rank
+
+    @staticmethod
+    def allgather_view_all(engines):
+        blocks = [np.concatenate(e.read_outputs()).astype(np.int32) for e in engines]
+        return unpack_view(np.stack(blocks), engines[0].N)
 
     def close(self):
         pass

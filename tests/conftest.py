@@ -27,3 +27,21 @@ def _native_pieces_are_built():
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture
+def gu_option():
+    """set(name, value): process-wide default of a libgu launch-shape / search option for the rest of the test (None = the
+    built-in default); whatever the test set is put back afterwards.  (Rounds 1 and 2 flipped these through environment
+    variables; the library no longer reads any -- include/gu.h "options".)"""
+    from griduniverse_amd import _lib
+    touched = {}
+
+    def set_option(name, value):
+        if name not in touched:
+            touched[name] = None  # tests start from the built-in defaults
+        _lib.set_default_option(name, value)
+
+    yield set_option
+    for name in touched:
+        _lib.set_default_option(name, None)

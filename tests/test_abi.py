@@ -72,3 +72,68 @@ def test_library_carries_the_hash_of_the_sources_it_was_built_from(lib, tmp_path
     assert 'built from other sources' in str(err.value)
     monkeypatch.setenv('GU_ALLOW_STALE_LIB', '1')
     assert _lib.load() is not None
+
+
+def test_stale_library_then_build_then_load_in_one_process(tmp_path, monkeypatch):
+    """Looking at the hash of a present-but-stale libgu.so must not map it: otherwise the rebuilt file could never be loaded by
+    the process that rebuilt it (glibc answers a second dlopen of the same path with the image it already holds)."""
+    import shutil
+    good = open(_lib.LIB_PATH, 'rb').read()
+    marker = ('GU_SRCHASH=%s;' % _lib.source_hash()).encode()
+    assert good.count(marker) == 1
+    stale = tmp_path / 'libgu.so'
+    stale.write_bytes(good.replace(marker, b'GU_SRCHASH=0123456789abcdef;'))  # "built from other sources"
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(stale))
+    monkeypatch.setattr(_lib, '_lib', None)
+    assert _lib.built_hash() == '0123456789abcdef' and _lib.is_stale()
+    assert _lib.build_marker() == ('0123456789abcdef', 'product')
+    with pytest.raises(_lib.GuError):
+        _lib.load()  # refused: stale (and refusing did not leave the stale image behind as the loaded library)
+    assert _lib._lib is None
+    shutil.copyfile(os.path.join(ROOT, 'griduniverse_amd', 'lib', 'libgu.so'), str(stale) + '.new')  # "the rebuild"
+    os.replace(str(stale) + '.new', str(stale))
+    assert not _lib.is_stale()
+    lib = _lib.load()
+    buf = _lib.ctypes.create_string_buffer(64)
+    lib.gu_source_hash(buf, 64)
+    assert buf.value.decode() == _lib.source_hash()
+
+
+def test_options_have_defaults_ranges_and_process_wide_values(lib):
+    for name, builtin in (('rollout_block', 256), ('rollout_rows', -1), ('rollout_multi', -1), ('vi_path', 0), ('mc_scratch_mb', 2048),
+                          ('traj_candidates', 12), ('traj_far_candidates', 32), ('traj_stride_mib', 3072), ('traj_far_mib', 49152),
+                          ('step_sync', 0), ('rollout_xcd', 0), ('traj_probe_all', 0)):
+        assert _lib.get_default_option(name) == builtin, name
+    _lib.set_default_option('rollout_block', 512)
+    try:
+        assert _lib.get_default_option('rollout_block') == 512
+    finally:
+        _lib.set_default_option('rollout_block', None)
+    assert _lib.get_default_option('rollout_block') == 256
+    for name, bad in (('rollout_block', 100), ('rows_copies', 3), ('rollout_multi_k', 3), ('vi_path', 9), ('traj_candidates', 0)):
+        with pytest.raises(_lib.GuError):
+            _lib.set_default_option(name, bad)
+    assert sorted(v for v in _lib.OPTIONS.values() if v < 100) == list(range(1, 18))
+
+
+def test_the_product_library_has_no_code_for_the_unsafe_experiments(lib, monkeypatch):
+    """Round 2 shipped GU_TRAJ_UNCACHED=1 (a mode documented to make readers of the trajectory see stale bytes) one environment
+    variable away.  The product library now ignores the variable, refuses the option, and does not even import the allocator the
+    mode needs; only `make exp` (libgu_exp.so, tools/) carries it."""
+    import subprocess
+    monkeypatch.setenv('GU_TRAJ_UNCACHED', '1')
+    monkeypatch.setenv('GU_TRAJ_POISON', '1')
+    monkeypatch.setenv('GU_MC_POISON', '1')
+    for name in ('x_traj_uncached', 'x_traj_poison', 'x_mc_poison'):
+        assert _lib.get_default_option(name) == 0
+        with pytest.raises(_lib.GuError) as err:
+            _lib.set_default_option(name, 1)
+        assert err.value.code == -6
+    assert _lib.build_marker()[1] == 'product'
+    undefined = subprocess.run(['nm', '-D', '--undefined-only', _lib.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert 'hipMalloc' in undefined and 'hipExtMallocWithFlags' not in undefined
+    # the environment-only switches of rounds 1 and 2 are gone from the product library altogether
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    for gone in (b'GU_VI_MULTI_LAUNCH', b'GU_VI_CLUSTER', b'GU_TRAJ_DEBUG', b'GU_TRAJ_STRIDE_GIB', b'GU_TRAJ_FAR_GIB'):
+        assert gone not in blob, gone
+    assert b'GU_RCCL_LIB' in blob and b'GU_DEBUG' in blob  # the two process-level variables it does read

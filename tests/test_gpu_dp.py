@@ -18,14 +18,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=['one_workgroup', 'launch_per_round'])
-def vi_path(request, monkeypatch):
+def vi_path(request, gu_option):
     """Every test runs twice: grids of up to 4096 states normally take the single-workgroup kernel (v in LDS, the
-    whole iteration in one launch); GU_VI_MULTI_LAUNCH=1 sends them down the one-launch-per-round path that larger
+    whole iteration in one launch); option vi_path = 2 sends them down the one-launch-per-round path that larger
     grids use."""
-    if request.param == 'launch_per_round':
-        monkeypatch.setenv('GU_VI_MULTI_LAUNCH', '1')
-    else:
-        monkeypatch.delenv('GU_VI_MULTI_LAUNCH', raising=False)
+    gu_option('vi_path', 2 if request.param == 'launch_per_round' else None)
     return request.param
 
 
@@ -275,7 +272,7 @@ def test_vi_eval_run_is_the_host_loop_of_policy_iteration(name):
             assert v.tobytes() == v_want.tobytes() and pi.tobytes() == pi0.tobytes() == pi_want.tobytes()
 
 
-def test_one_workgroup_and_launch_per_round_agree_at_64x64(monkeypatch):
+def test_one_workgroup_and_launch_per_round_agree_at_64x64(gu_option):
     """config 5's grid through both paths: 300 rounds of value iteration, a policy-evaluation run and sweeps from a
     random policy and value table (ties, negative and positive values), compared as raw bytes."""
     import random
@@ -289,10 +286,7 @@ def test_one_workgroup_and_launch_per_round_agree_at_64x64(monkeypatch):
     v0, pi0 = rs.randn(S) * 3, rs.dirichlet(np.ones(4), S)
     out = []
     for multi in (False, True):
-        if multi:
-            monkeypatch.setenv('GU_VI_MULTI_LAUNCH', '1')
-        else:
-            monkeypatch.delenv('GU_VI_MULTI_LAUNCH', raising=False)
+        gu_option('vi_path', 2 if multi else None)
         with Engine(4, GridSpec.from_env(env)) as eng:
             res = []
             eng.vi_set(v0, pi0)
@@ -361,20 +355,20 @@ def test_random_grids_dp_property():
 
 
 @pytest.mark.parametrize('W,H', [(101, 101), (300, 300), (600, 600), (1024, 5)])
-def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, monkeypatch):
+def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, gu_option):
     """Grids of 4097 .. 524 288 states: the one-launch cluster kernel (grid barrier per round, K = 1 or 2 states per thread,
-    up to 256 workgroups) against one launch per round (GU_VI_CLUSTER=0) -- value iteration with the device-side stopping
+    up to 256 workgroups) against one launch per round (option vi_path = 1) -- value iteration with the device-side stopping
     rule, a policy-evaluation run, and sweeps from a random policy / value table with forced ties, as raw bytes."""
     if vi_path == 'launch_per_round':
-        pytest.skip('GU_VI_MULTI_LAUNCH=1 disables the cluster kernel: nothing to compare')
+        pytest.skip('vi_path = 2 disables the cluster kernel: nothing to compare')
     S = W * H
     rs = np.random.RandomState(W)
     walls = rs.choice(S, S // 5, replace=False)
     free = np.setdiff1d(np.arange(S), walls)
     spec = GridSpec(W, H, [int(free[0])], [int(x) for x in free[-3:]], [int(x) for x in free[5:9]], [int(x) for x in walls])
     out = {}
-    for cluster in ('0', '1'):
-        monkeypatch.setenv('GU_VI_CLUSTER', cluster)
+    for cluster in ('0', '1', 'timeout'):  # 'timeout': a grid-barrier timeout is injected -> tables restored, launch-per-round path
+        gu_option('vi_path', {'0': 1, '1': None, 'timeout': 3}[cluster])
         res = []
         with Engine(2, spec) as eng:
             eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
@@ -392,12 +386,12 @@ def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, monkeypatch):
             steps, deltas = eng.vi_run(1.0, 1e9, 5)  # stops after its first round
             res += [steps, deltas.tobytes(), *(x.tobytes() for x in eng.vi_get())]
         out[cluster] = res
-    assert out['0'][0] > 3 and out['0'] == out['1']
+    assert out['0'][0] > 3 and out['0'] == out['1'] and out['0'] == out['timeout']
 
 
 @pytest.mark.parametrize('name,N,auto', [('maze64_s5', 65536, True), ('maze64_s5_g097', 4096, False), ('rect6x5_g1', 100, True),
                                          ('lava4x4_g095', 3, True), ('maze32_s1', 20000, True)])
-def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, monkeypatch):
+def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, gu_option):
     """gu_vi_sweep_step_run (config 5 for many rounds: one launch of a workgroup cluster with a grid barrier per round) against
     the same number of single gu_vi_sweep_step launches: value table, policy, deltas, and every env's position / reward /
     done flag / episode count, as raw bytes; and its first rounds against the reference's value-iteration trace."""
@@ -405,9 +399,9 @@ def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, m
     S, gamma = meta['W'] * meta['H'], meta['gamma']
     iters = 23
     out = {}
-    for mode in ('single', 'run', 'run_no_cluster'):
-        if mode == 'run_no_cluster':
-            monkeypatch.setenv('GU_VI_CLUSTER', '0')
+    for mode in ('single', 'run', 'run_no_cluster', 'run_timeout'):  # (run_timeout: injected barrier timeout -> state restored, fallback)
+        if vi_path != 'launch_per_round':
+            gu_option('vi_path', {'run_no_cluster': 1, 'run_timeout': 3}.get(mode))
         with Engine(N, spec_of(meta), seed=3) as eng:
             eng.reset()
             eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
@@ -424,7 +418,8 @@ def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, m
             o = eng.read_outputs()
             out[mode] = [deltas.tobytes(), v.tobytes(), pi.tobytes(), st['pos'].tobytes(), st['done'].tobytes(), st['episode'].tobytes(),
                          o[1].tobytes(), eng.done_indices().tobytes()]
-    assert out['single'] == out['run'] == out['run_no_cluster']
+    assert out['single'] == out['run'] == out['run_no_cluster'] == out['run_timeout']
+    gu_option('vi_path', 2 if vi_path == 'launch_per_round' else None)
     with Engine(N, spec_of(meta), seed=3) as eng:  # the table part is the reference's value-iteration trace
         eng.reset()
         eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)

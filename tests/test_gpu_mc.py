@@ -116,7 +116,7 @@ def test_sample_policy_with_auto_reset_and_stats():
     assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes'])
 
 
-def test_chunk_boundaries_do_not_change_the_result(monkeypatch):
+def test_chunk_boundaries_do_not_change_the_result(gu_option):
     """The evaluation walks the episodes in chunks (scratch budget); with a 1 MiB budget 3000 episodes take dozens of
     chunks and must give the same bytes as one chunk."""
     rs = np.random.RandomState(2)
@@ -124,8 +124,8 @@ def test_chunk_boundaries_do_not_change_the_result(monkeypatch):
     spec = GridSpec(8, 8, [0, 9], [63], [20, 43], [10, 11, 12])
     pi = rs.dirichlet(np.ones(4), S)
     results = []
-    for mb in ('256', '1'):
-        monkeypatch.setenv('GU_MC_SCRATCH_MB', mb)
+    for mb in (256, 1):
+        gu_option('mc_scratch_mb', mb)
         with Engine(N, spec, seed=5) as eng:
             eng.vi_set(np.zeros(S), pi)
             first = eng.reset()
@@ -138,8 +138,8 @@ def test_chunk_boundaries_do_not_change_the_result(monkeypatch):
         assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
 
 
-@pytest.mark.parametrize('switch', ['GU_MC_LANE_RETURNS', 'GU_MC_GLOBAL_WALK'])
-def test_tiled_and_per_lane_return_kernels_agree(monkeypatch, switch):
+@pytest.mark.parametrize('switch', ['mc_lane_returns', 'mc_global_walk'])
+def test_tiled_and_per_lane_return_kernels_agree(gu_option, switch):
     """The LDS-tiled return kernel (zero-padded columns, masked discount table) against the per-lane kernel on
     global memory, and the LDS history walk against the global-memory walk, on full-length episodes
     (2048 x 1000 steps, mean length in the hundreds), every mode."""
@@ -155,11 +155,8 @@ def test_tiled_and_per_lane_return_kernels_agree(monkeypatch, switch):
     pi = rs.dirichlet(np.ones(4), S)
     modes = ((False, True, True), (True, True, True), (True, False, True), (False, True, False))
     results = []
-    for lane in ('', '1'):
-        if lane:
-            monkeypatch.setenv(switch, lane)
-        else:
-            monkeypatch.delenv(switch, raising=False)
+    for lane in (None, 1):
+        gu_option(switch, lane)
         with Engine(N, GridSpec.from_env(env), seed=21) as eng:
             eng.vi_set(np.zeros(S), pi)
             first = eng.reset()
@@ -227,7 +224,7 @@ def test_sample_policy_threshold_edge_cases(W, H):
         assert np.array_equal(got[k], want[k]), k
 
 
-def test_random_grids_mc_property():
+def test_random_grids_mc_property(gu_option):
     """Random small grids with several start cells, random stochastic policies, every update mode, random discount /
     threshold / step cap / batch size / scratch budget: sampled episodes against the C restatement and the
     evaluation against the Python restatement of monte_carlo_evaluation.  GU_FUZZ_TRIALS=N for a longer soak."""
@@ -245,7 +242,7 @@ def test_random_grids_mc_property():
         N, T, seed = int(rs.randint(1, 200)), int(rs.randint(1, 90)), int(rs.randint(0, 2 ** 40))
         gamma, thr = float(rs.choice([1.0, 0.99, 0.9, 0.5])), float(rs.choice([1e-4, 1e-2, 0.5]))
         ev, im, stn = bool(rs.randint(2)), bool(rs.randint(2)), bool(rs.randint(2))
-        os.environ['GU_MC_SCRATCH_MB'] = str(int(rs.choice([1, 2048])))
+        gu_option('mc_scratch_mb', int(rs.choice([1, 2048])))
         try:
             st = C.State(N)
             C.reset(grid, seed, st)
@@ -266,7 +263,7 @@ def test_random_grids_mc_property():
             v_want, vis_want = omc.monte_carlo_evaluation(S, eps, ev, im, stn, gamma, thr, 0.05)
             assert v.tobytes() == v_want.tobytes() and visits.tobytes() == vis_want.tobytes(), (trial, W, H, N, T, ev, im, stn, gamma, thr)
         finally:
-            os.environ.pop('GU_MC_SCRATCH_MB', None)
+            gu_option('mc_scratch_mb', None)
 
 
 def test_random_grids_table_policies_property():

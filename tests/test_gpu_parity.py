@@ -92,14 +92,11 @@ def test_reference_digests(name):
         if 'stream_seed' in d:  # a caller-supplied stream (numpy's RandomState), stepped by the reference: the STREAM policy
             eng.upload_actions(np.random.RandomState(d['stream_seed']).randint(0, 4, size=(d['T'], d['N'])).astype(np.int32))
             outs = []
-            for rows in ('1', '0'):  # the row-table kernel and the general kernel (packed words staged in LDS)
-                os.environ['GU_ROLLOUT_ROWS'] = rows
-                try:
-                    eng.seed(d['seed'])
-                    eng.reset()
-                    eng.rollout(d['T'], 'stream', d['auto_reset'])
-                finally:
-                    del os.environ['GU_ROLLOUT_ROWS']
+            for rows in (1, 0):  # the row-table kernel and the general kernel (packed words staged in LDS)
+                eng.set_option('rollout_rows', rows)
+                eng.seed(d['seed'])
+                eng.reset()
+                eng.rollout(d['T'], 'stream', d['auto_reset'])
                 outs.append(eng.read_trajectory(0, d['T']))
             assert all(np.array_equal(outs[0][k], outs[1][k]) for k in outs[0])
             out = outs[0]
@@ -304,7 +301,7 @@ def test_random_grids_property():
                 eng.upload_actions(acts)
             eng.reserve_trajectory(T)
             # int32 rows, packed rows, stats only: the last two take the transition-row kernel when the grid has one start
-            # cell (or no auto-reset); GU_ROLLOUT_ROWS=1 sends the int32 rows there too
+            # cell (or no auto-reset); option rollout_rows = 1 sends the int32 rows there too
             mode = (True, 'packed', False)[(trial // 4) % 3]
             eng.rollout(T, 'stream' if stream else 'uniform', auto, trajectory=mode, stats=True)
             got = eng.read_trajectory(0, T) if mode is True else eng.read_trajectory_packed(0, T) if mode else {}

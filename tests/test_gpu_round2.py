@@ -257,8 +257,8 @@ def test_facade_sees_edits_after_invalidate():
 
 # ------------------------------------------------------------------------------- transition-row rollout kernel
 @pytest.fixture
-def force_rows(monkeypatch):
-    monkeypatch.setenv('GU_ROLLOUT_ROWS', '1')  # read per launch: every eligible launch takes gu_rollout_rows.hip
+def force_rows(gu_option):
+    gu_option('rollout_rows', 1)  # every eligible launch takes gu_rollout_rows.hip
 
 
 def _oracle_and_engine(meta, N, seed, env_id0=0):
@@ -335,7 +335,7 @@ def test_rows_kernel_first_step_honours_a_stored_state_that_disagrees_with_the_c
                 assert all(np.array_equal(s[k], getattr(st, k)) for k in ('pos', 'done', 'episode', 'tcount'))
 
 
-def test_rows_and_general_kernel_agree_at_config_sizes(monkeypatch):
+def test_rows_and_general_kernel_agree_at_config_sizes(gu_option):
     """Config 3 at full size (65 536 envs x 1000 steps) through both kernels: identical trajectory digest, stats and state;
     and the default dispatch (rows for stats-only / packed, general for int32 rows) reproduces the reference's digest."""
     import hashlib
@@ -346,7 +346,7 @@ def test_rows_and_general_kernel_agree_at_config_sizes(monkeypatch):
     N, T = 65536, 1000
     out = {}
     for rows in ('0', '1'):
-        monkeypatch.setenv('GU_ROLLOUT_ROWS', rows)
+        gu_option('rollout_rows', int(rows))
         with Engine(N, GridSpec.from_env(env), seed=123) as eng:
             eng.reset()
             eng.reserve_trajectory(T)
@@ -361,7 +361,7 @@ def test_rows_and_general_kernel_agree_at_config_sizes(monkeypatch):
     assert out['0'][0] == out['1'][0] == G.load_json('digests.json')['c3_maze32_65536x1000']['sha256']
     assert all(np.array_equal(a, b) for a, b in zip(out['0'][1], out['1'][1]))
     assert all(np.array_equal(out['0'][2][k], out['1'][2][k]) for k in out['0'][2])
-    monkeypatch.delenv('GU_ROLLOUT_ROWS')
+    gu_option('rollout_rows', None)
     with Engine(N, GridSpec.from_env(env), seed=123) as eng:  # default dispatch: stats-only launch on the row table
         eng.reset()
         eng.rollout(T, 'uniform', True, False, stats=True)
@@ -399,11 +399,11 @@ def test_rows_kernel_on_a_single_device_generated_maze(force_rows):
 
 @pytest.mark.parametrize('rows', ['1', '0'])
 @pytest.mark.parametrize('name', ['c3_maze32', 'c4_lava32', 'c2_open8x8', 'rect25x30_busy', 'grid9x1'])
-def test_table_policies_on_the_row_table_equal_the_oracle(monkeypatch, rows, name):
-    """GU_POLICY_SAMPLE / GU_POLICY_GREEDY through the policy-row kernel (GU_ROLLOUT_ROWS=1) and through the general kernel (=0):
+def test_table_policies_on_the_row_table_equal_the_oracle(gu_option, rows, name):
+    """GU_POLICY_SAMPLE / GU_POLICY_GREEDY through the policy-row kernel (option rollout_rows = 1) and through the general kernel (= 0):
     stochastic policies with zero and one entries (thresholds at both ends of the range), one-hot policies (greedy), auto-reset
     on and off, every trajectory mode, chained launches of awkward lengths, a policy that changes between launches."""
-    monkeypatch.setenv('GU_ROLLOUT_ROWS', rows)
+    gu_option('rollout_rows', int(rows))
     meta, _ = G.load_traj(name)
     S = meta['W'] * meta['H']
     single_start = len(meta['starts']) == 1
@@ -467,7 +467,7 @@ print('VIEW-OK')
     assert out.returncode == 0 and b'VIEW-OK' in out.stdout, out.stdout.decode()[-2000:]
 
 
-def test_trajectory_buffer_is_chosen_among_candidates_and_kept_when_large_enough(monkeypatch):
+def test_trajectory_buffer_is_chosen_among_candidates_and_kept_when_large_enough(gu_option):
     """gu_reserve_trajectory probes candidate allocations for buffers of 64 MB and more and keeps the one HBM writes fastest;
     a buffer that is already large enough is kept.  Results never depend on which allocation was taken."""
     meta, _ = G.load_traj('c3_maze32')
@@ -475,7 +475,7 @@ def test_trajectory_buffer_is_chosen_among_candidates_and_kept_when_large_enough
     grid = C.Grid.from_lists(**meta)
     outs = []
     for cand in ('1', '5'):
-        monkeypatch.setenv('GU_TRAJ_CANDIDATES', cand)
+        gu_option('traj_candidates', int(cand))
         st = C.State(N)
         with Engine(N, spec_of(meta), seed=2) as eng:
             assert np.array_equal(eng.reset(), C.reset(grid, 2, st))
@@ -499,9 +499,10 @@ def test_trajectory_buffer_is_chosen_among_candidates_and_kept_when_large_enough
         eng.reserve_trajectory(16)
         assert eng.trajectory_placement()[0] == 1
     # buffers of 256 MiB and more: when the back-to-back candidates all look alike the search continues behind spacers
-    monkeypatch.setenv('GU_TRAJ_CANDIDATES', '2')
-    monkeypatch.setenv('GU_TRAJ_FAR_CANDIDATES', '3')
-    monkeypatch.setenv('GU_TRAJ_STRIDE_GIB', '1.5')
+    gu_option('traj_candidates', 2)
+    gu_option('traj_far_candidates', 3)
+    gu_option('traj_stride_mib', 1536)
+    gu_option('traj_probe_all', 1)  # (without it the search ends where two back-to-back candidates are alike or one is fast)
     N, T = 65536, 400
     with Engine(N, spec_of(meta), seed=2) as eng:
         eng.reset()
@@ -518,11 +519,11 @@ def test_trajectory_buffer_is_chosen_among_candidates_and_kept_when_large_enough
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('N,T', [(300, 2100), (1000, 1024), (70, 1025), (5000, 130)])
-def test_long_action_streams_are_staged_in_lds_in_groups(monkeypatch, N, T):
+def test_long_action_streams_are_staged_in_lds_in_groups(gu_option, N, T):
     """GU_POLICY_STREAM with trajectory rows reads its packed action words from LDS, refilled every <= 64 words (1024
     steps) per lane: streams longer than one group, ending on and off a group / word boundary, against the C oracle on
     the general kernel (the row-table kernel is switched off), int32 and packed rows, then resumed with a second launch."""
-    monkeypatch.setenv('GU_ROLLOUT_ROWS', '0')
+    gu_option('rollout_rows', 0)
     meta, _ = G.load_traj('c3_maze32')
     grid, st, eng = _oracle_and_engine(meta, N, 5)
     acts = np.random.RandomState(T).randint(0, 4, (T, N)).astype(np.int32)
@@ -604,17 +605,17 @@ print('VIEW-OK')
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,force_k', [('c2_open8x8', ''), ('c2_open8x8', '2'), ('c2_open8x8', '4 copies=2'), ('c3_maze32', '2 copies=2'), ('c3_maze32', ''), ('c4_lava32', ''), ('grid1x1', ''), ('grid9x1', ''),
                                           ('rect25x30_busy', ''), ('c5_maze64', '')])
-def test_k_step_kernel_equals_the_oracle(monkeypatch, name, force_k):
+def test_k_step_kernel_equals_the_oracle(gu_option, name, force_k):
     """gu_rollout_multi.hip composes K consecutive transitions (K = 4 up to 64 cells, K = 2 up to ~2000; larger grids fall
     through to the row-table kernel) for uniform-policy and caller-supplied-stream launches that keep only statistics.  Chains of launches of every
     length around K and around the 16-action RNG word -- so that launches start at every offset inside a word and a group --
     with and without auto-reset, with and without stats, ragged batch sizes, shard offsets; per-env return, episodes, state,
     done compaction against the C oracle after every launch."""
-    monkeypatch.setenv('GU_ROLLOUT_MULTI', '1')  # also launches shorter than the default threshold
+    gu_option('rollout_multi', 1)  # also launches shorter than the default threshold
     if force_k:
-        monkeypatch.setenv('GU_ROLLOUT_MULTI_K', force_k.split()[0])
+        gu_option('rollout_multi_k', int(force_k.split()[0]))
         if 'copies=2' in force_k:
-            monkeypatch.setenv('GU_ROLLOUT_MULTI_COPIES', '2')  # (diagnostic layout: the table replicated across the LDS banks)
+            gu_option('rollout_multi_copies', 2)  # (diagnostic layout: the table replicated across the LDS banks)
     meta, _ = G.load_traj(name)
     single_start = len(meta['starts']) == 1
     for N in (1, 65, 1000):
@@ -644,10 +645,10 @@ def test_k_step_kernel_equals_the_oracle(monkeypatch, name, force_k):
 
 
 @pytest.mark.gpu
-def test_k_step_kernel_with_stored_states_and_per_env_step_counts(monkeypatch):
+def test_k_step_kernel_with_stored_states_and_per_env_step_counts(gu_option):
     """A stored state may disagree with its cell (done = 1 on an open cell, done = 0 on a terminal one, a terminal start), and
     gu_set_state can give every env its own step count: first step on the planes, then the per-lane schedule."""
-    monkeypatch.setenv('GU_ROLLOUT_MULTI', '1')
+    gu_option('rollout_multi', 1)
     meta, _ = G.load_traj('c4_lava32')
     N = 700
     for starts in ([0], [16]):
@@ -676,14 +677,14 @@ def test_k_step_kernel_with_stored_states_and_per_env_step_counts(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_k_step_rows_and_general_kernels_agree_at_config_size(monkeypatch):
+def test_k_step_rows_and_general_kernels_agree_at_config_size(gu_option):
     """Config 3 at full size, statistics only, through the K-step, the row-table and the general kernel: identical returns,
     episode counts and final states."""
     meta, _ = G.load_traj('c3_maze32')
     outs = []
     for multi, rows in (('1', '1'), ('0', '1'), ('0', '0')):
-        monkeypatch.setenv('GU_ROLLOUT_MULTI', multi)
-        monkeypatch.setenv('GU_ROLLOUT_ROWS', rows)
+        gu_option('rollout_multi', int(multi))
+        gu_option('rollout_rows', int(rows))
         with Engine(65536, spec_of(meta), seed=123) as eng:
             eng.reset()
             for T in (1000, 999):

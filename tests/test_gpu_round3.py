@@ -1,0 +1,172 @@
+"""Round 3 on the device: per-engine options, the capped / process-aware trajectory placement search and what it reports,
+gu_probe_trajectory, gu_device_info, several engines of one process on one device (LDS limits per device), and bench.py started
+plainly with --gpus 2 and with --single-process (two ranks / two engines sharing the one GPU of the box)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import griduniverse_amd as gua
+from griduniverse_amd import Engine, GridSpec, _lib
+from oracle import c_oracle as C
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def spec_of(meta):
+    return GridSpec(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'])
+
+
+def test_options_are_per_engine_with_a_process_default(gu_option):
+    """Two engines of one process on different kernel paths at the same time (the environment switches of rounds 1 / 2 could not do
+    that), identical results; an engine's own value wins over the process default, None hands it back."""
+    meta, _ = G.load_traj('c3_maze32')
+    N, T = 4096, 300
+    with Engine(N, spec_of(meta), seed=11) as a, Engine(N, spec_of(meta), seed=11) as b:
+        assert a.get_option('rollout_rows') == -1 and a.get_option('rollout_block') == 256
+        a.set_option('rollout_rows', 0)
+        a.set_option('rollout_multi', 0)      # a: the general kernel for everything
+        b.set_option('rollout_rows', 1)       # b: the transition-row kernel wherever eligible
+        b.set_option('rollout_block', 512)
+        gu_option('rollout_block', 128)       # process default: a uses it, b keeps its own 512
+        assert a.get_option('rollout_block') == 128 and b.get_option('rollout_block') == 512
+        outs = []
+        for e in (a, b):
+            e.reset()
+            e.reserve_trajectory(T)
+            e.rollout(T, 'uniform', True, True, stats=True)
+            outs.append((e.read_trajectory(0, T), e.read_stats(), e.get_state()))
+        for k in ('obs', 'reward', 'done'):
+            assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+        assert all(np.array_equal(x, y) for x, y in zip(outs[0][1], outs[1][1]))
+        assert all(np.array_equal(outs[0][2][k], outs[1][2][k]) for k in outs[0][2])
+        grid, st = C.Grid.from_lists(**meta), C.State(N)
+        C.reset(grid, 11, st)
+        want = C.rollout(grid, 11, st, T, True)
+        assert all(np.array_equal(outs[0][0][k], want[k]) for k in want)
+        b.set_option('rollout_block', None)
+        assert b.get_option('rollout_block') == 128
+        with pytest.raises(gua.GuError):
+            a.set_option('x_traj_uncached', 1)  # compiled out of the product library
+
+
+def test_placement_search_reports_every_candidate_and_later_engines_hold_less(gu_option):
+    """gu_trajectory_placement_detail: per-candidate probe time and address, the kept index, the wall time and the peak bytes
+    of the search; the search gives up after the back-to-back candidates when they are alike (no far phase then); a second
+    engine of the process on the device probes at most four candidates and holds at most an eighth of the free memory; results
+    never depend on the choice; gu_probe_trajectory re-times the kept buffer."""
+    meta, _ = G.load_traj('c3_maze32')
+    N, T = 65536, 400  # 3 x 105 MB planes = 315 MB: far candidates allowed (>= 256 MiB)
+    grid = C.Grid.from_lists(**meta)
+    gu_option('traj_candidates', 3)
+    gu_option('traj_far_candidates', 2)
+    gu_option('traj_stride_mib', 512)
+    with Engine(N, spec_of(meta), seed=2) as first:
+        first.reset()
+        first.reserve_trajectory(T)
+        d = first.trajectory_placement_detail()
+        n, best, worst = first.trajectory_placement()
+        assert n == len(d['probe_ms']) == len(d['address']) and 1 <= n <= 5 and 0 <= d['kept'] < n
+        assert abs(d['probe_ms'][d['kept']] - best) < 1e-6 and abs(max(d['probe_ms']) - worst) < 1e-6 and best == min(d['probe_ms'])
+        assert len(set(d['address'])) == n and d['search_ms'] > 0
+        bytes_one = 3 * N * T * 4
+        assert bytes_one <= d['peak_bytes'] <= 3 * bytes_one + 2 * (512 << 20) + 2 * bytes_one
+        spread = (worst - best) / worst
+        if n > 3:
+            assert spread >= 0.06 - 1e-6 or best <= 0.86 * worst  # the far phase runs only where the first candidates showed two classes
+        again = first.probe_trajectory()
+        assert 0.5 * best < again < 2.0 * best
+        first.rollout(T, 'uniform', True, True)
+        st = C.State(2048)
+        C.reset(grid, 2, st)
+        want = C.rollout(grid, 2, st, T, True)
+        got = first.read_trajectory(T - 1, 1)
+        assert all(np.array_equal(got[k][0, :2048], want[k][T - 1]) for k in got)
+        # a second engine of the same process on the same device: restricted search
+        gu_option('traj_candidates', 12)
+        gu_option('traj_far_candidates', 32)
+        free = _lib.device_info(0)['hbm_free']
+        with Engine(N, spec_of(meta), seed=2) as second:
+            second.reset()
+            second.reserve_trajectory(T)
+            d2 = second.trajectory_placement_detail()
+            assert 1 <= len(d2['probe_ms']) <= 4 and d2['peak_bytes'] <= max(bytes_one, free // 8 + bytes_one)
+            second.rollout(T, 'uniform', True, True)
+            got2 = second.read_trajectory(T - 1, 1)
+            assert all(np.array_equal(got2[k], got[k]) for k in got)
+    with Engine(64, spec_of(meta)) as small:  # small buffers are simply allocated
+        small.reserve_trajectory(16)
+        d = small.trajectory_placement_detail()
+        assert d['probe_ms'] == [] and d['kept'] == -1 and d['peak_bytes'] == 3 * 64 * 16 * 4
+
+
+def test_device_info_names_the_device():
+    info = _lib.device_info(0)
+    assert str(info['arch']).startswith('gfx950') and info['cus'] >= 1 and info['lds_per_cu'] >= 65536
+    assert info['hbm_bytes'] > 2 ** 34 and 0 < info['hbm_free'] <= info['hbm_bytes'] and len(str(info['pci'])) >= 7
+    assert Engine.device_info(0)['name'] == info['name']
+
+
+def test_several_engines_of_one_process_with_large_lds_tables():
+    """parallel.MultiDeviceVecGridUniverse on [0, 0, 0] (the box has one GPU; on a node the same code puts each engine on its own
+    device, where the dynamic-LDS limit of a kernel has to be raised once PER DEVICE -- the latch is a per-device mask now):
+    statistics-only launches on a 32x32 grid need 80 KiB of LDS for the K = 2 table; all shards against the oracle."""
+    from griduniverse_amd.parallel import MultiDeviceVecGridUniverse
+    meta, _ = G.load_traj('c3_maze32')
+    total, T = 3 * 1024, 500
+    env = MultiDeviceVecGridUniverse(total, [0, 0, 0], seed=5, auto_reset=True, template=spec_of(meta))
+    try:
+        env.reset()
+        out = env.rollout(T, trajectory=False, stats=True)
+        grid, st = C.Grid.from_lists(**meta), C.State(total)
+        C.reset(grid, 5, st)
+        want = C.rollout(grid, 5, st, T, True, trajectory=False, stats=True)
+        assert np.array_equal(out['ret'], want['ret']) and np.array_equal(out['episodes'], want['episodes'])
+        view = env.view()
+        assert np.array_equal(view[0], st.pos) and np.array_equal(view[2], st.done)
+    finally:
+        env.close()
+
+
+def _bench(*args):
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=1200)
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+SMALL = ['--envs', '16384', '--T', '200', '--steps', '3', '--warmup', '1', '--min-seconds', '0.05', '--c4-envs', '16384', '--no-cpu-baseline']
+
+
+def test_bench_started_plainly_with_two_ranks_on_the_one_gpu():
+    """`python bench.py --gpus 2`, no launcher: two rank processes (sharing device 0 here), rank 0's one line; RCCL itself refuses
+    two ranks on one device, which the line reports instead of dying."""
+    line = _bench('--gpus', '2', *SMALL)
+    assert line['n_gpus'] == 2 and len(line['per_rank']['value']) == 2 and line['engine'] == 'griduniverse_amd.engine.Engine'
+    assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
+    assert line['rccl']['nranks'] == 2 and (line['rccl'].get('view_equals_shards') is True or 'error' in line['rccl'])
+    assert line['strong_c4']['n_gpus'] == 2 and line['strong_c4']['shards_equal_oracle'] is True
+    assert line['device']['arch'].startswith('gfx950') and line['roofline']['trajectory_placement'] is not None
+
+
+def test_bench_single_process_form_on_the_one_gpu():
+    """--single-process --gpus 2: one process, two engines (both on device 0 here), launches enqueued engine after engine; the
+    gu_comm_init_all view needs one device per engine and is reported as refused on this box."""
+    line = _bench('--gpus', '2', '--single-process', *SMALL)
+    assert line['n_gpus'] == 2 and line['mode'] == 'single-process' and line['config']['devices'] == [0, 0]
+    assert len(line['per_rank']['value']) == 2 and line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
+    assert line['rccl']['nranks'] == 2 and ('error' in line['rccl'] or line['rccl']['view_equals_shards'] is True)
+    assert line['strong_c4']['shards_equal_oracle'] is True and len(line['roofline']['trajectory_placement']) == 2
+    line = _bench('--gpus', '1', '--single-process', '--gather-view', *SMALL)
+    assert line['n_gpus'] == 1 and line['rccl']['view_equals_shards'] is True and line['rccl']['nranks'] == 1

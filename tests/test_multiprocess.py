@@ -1,5 +1,6 @@
-"""N > 1 path on CPU: two processes, gloo, launched the way the driver launches bench.py
-(python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 ...)."""
+"""N > 1 path on CPU: two processes launched the way the driver launches bench.py (python -m torch.distributed.run
+--nproc-per-node 2 --master-addr 127.0.0.1 ...), bench.py started plainly with --gpus 2 (it spawns its ranks), and the
+single-process form -- all on the oracle-backed stub engine; the ranks' host channel is griduniverse_amd/rendezvous.py."""
 import json
 import os
 import socket
@@ -32,7 +33,7 @@ def test_unpack_view_layout():
         assert np.array_equal(don[r * n:(r + 1) * n], blocks[r, 2 * n:])
 
 
-def test_two_rank_gloo_shards_and_gathered_view(tmp_path):
+def test_two_rank_shards_and_gathered_view_under_torch_distributed_run(tmp_path):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -56,10 +57,91 @@ def test_two_rank_gloo_shards_and_gathered_view(tmp_path):
     c4 = line['strong_c4']
     assert c4['scaling'] == 'strong' and c4['total_envs'] == 2048 and c4['envs_per_gpu'] == 1024 and c4['shards_equal_oracle'] is True
     assert len(line['per_rank']['value']) == 2 and line['roofline']['traffic_measured_in_this_run'] is False
+    assert 'device' in line and 'trajectory_placement' in line['roofline']
     assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
     assert line['bit_exact_vs_reference_digest'] is None  # 512 envs x 40 steps is not the captured run
     other = line['other_modes']['stats_only']
     assert other['returns_vs_oracle'] is True and other['value'] > 0 and 'packed_rows' not in line['other_modes']  # (the stub has no packed rows)
+
+
+STUB = ['--engine', 'tests._oracle_engine:OracleEngine', '--envs', '512', '--T', '40', '--steps', '2', '--warmup', '1',
+        '--min-seconds', '0.02', '--c4-envs', '2048']
+
+
+def _one_json_line(proc):
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def _scrubbed_env():
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_started_plainly_with_gpus_2_spawns_its_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` without torch.distributed.run (the way the driver starts --gpus 1): the script launches its two
+    ranks itself and relays rank 0's line."""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + STUB, env=_scrubbed_env(), cwd=ROOT,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    line = _one_json_line(proc)
+    assert line['n_gpus'] == 2 and len(line['per_rank']['value']) == 2 and line['engine'] == 'tests._oracle_engine.OracleEngine'
+    assert line['rccl']['nranks'] == 2 and line['rccl']['view_equals_shards'] is True and line['rccl']['view_envs'] == 1024
+    assert line['strong_c4']['n_gpus'] == 2 and line['strong_c4']['envs_per_gpu'] == 1024 and line['strong_c4']['shards_equal_oracle'] is True
+    assert line['config']['global_envs'] == 1024 and line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
+    assert abs(line['value'] - 1024 * 40 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-6 * line['value']
+
+
+def test_bench_single_process_form_drives_two_engines_and_prints_one_line():
+    """--single-process: one host process, one engine per device, launches enqueued device after device, the view through the
+    comm_init_all form."""
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--single-process'] + STUB, env=_scrubbed_env(),
+                          cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    line = _one_json_line(proc)
+    assert line['n_gpus'] == 2 and line['mode'] == 'single-process' and len(line['per_rank']['value']) == 2
+    assert line['config']['global_envs'] == 1024 and line['config']['devices'] == [0, 0]
+    assert line['rccl']['nranks'] == 2 and line['rccl']['view_equals_shards'] is True and line['rccl']['view_envs'] == 1024
+    assert line['strong_c4']['n_gpus'] == 2 and line['strong_c4']['total_envs'] == 2048 and line['strong_c4']['shards_equal_oracle'] is True
+    assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
+    assert abs(line['value'] - 1024 * 40 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-6 * line['value']
+
+
+def test_bench_and_the_sharded_product_path_import_no_torch():
+    """north_star: host code has no PyTorch.  Importing bench.py, building a rendezvous and the sharded classes pulls in no torch."""
+    code = ('import sys; sys.path.insert(0, %r); import bench; from griduniverse_amd import parallel, rendezvous; '
+            'r = rendezvous.Rendezvous(0, 1); r.barrier(); assert r.reduce([1.0, 2.0], "MAX") == [1.0, 2.0]; '
+            'assert "torch" not in sys.modules, "torch was imported"' % ROOT)
+    proc = subprocess.run([sys.executable, '-c', code], env=_scrubbed_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert proc.returncode == 0, proc.stderr.decode()[-2000:]
+
+
+def test_rendezvous_collectives_three_ranks_over_tcp_and_unix():
+    """barrier / broadcast / gather / reduce of griduniverse_amd.rendezvous with three ranks, on both transports."""
+    code = '''
+import os, sys
+sys.path.insert(0, %r)
+from griduniverse_amd.rendezvous import Rendezvous
+r = Rendezvous()
+r.barrier()
+assert r.broadcast_bytes(b"id-%%d" %% r.rank, 1) == b"id-1"
+assert r.gather([float(r.rank), 7.0]) == [[0.0, 7.0], [1.0, 7.0], [2.0, 7.0]]
+assert r.reduce([float(r.rank)], "MAX") == [2.0] and r.reduce([float(r.rank)], "MIN") == [0.0] and r.reduce([1.0], "SUM") == [3.0]
+assert r.gather_bytes(bytes([r.rank]) * (r.rank + 1)) == [b"\\x00", b"\\x01\\x01", b"\\x02\\x02\\x02"]
+r.close()
+''' % ROOT
+    for transport in ('auto', 'tcp'):
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        procs = [subprocess.Popen([sys.executable, '-c', code], stderr=subprocess.PIPE,
+                                  env=dict(_scrubbed_env(), RANK=str(r), WORLD_SIZE='3', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                                           GU_RDZV=transport)) for r in (2, 0, 1)]
+        for p in procs:
+            err = p.communicate(timeout=120)[1]
+            assert p.returncode == 0, err.decode()[-2000:]
 
 
 def test_bench_finds_the_reference_digest_of_its_default_run():

@@ -4,7 +4,15 @@
 the reference's signature and arithmetic (float64, bit-exact given the same episodes) but generates
 all `num_episodes` episodes in ONE fused rollout launch -- env e is episode e, actions sampled from
 `policy[state]` by the per-env device RNG -- and reduces them on the device (csrc/gu_mc.hip).
+
+`rng='numpy'` is the drop-in mode: the episodes are the ones the REFERENCE would draw -- start cells from the stdlib's
+global `random`, actions from numpy's global stream, one `np.random.choice(4, p=policy[obs])` per step, episodes strictly one
+after the other (monte_carlo.py:20, 46-52) -- so that `random.seed(k); np.random.seed(k); monte_carlo_evaluation(...)` returns
+the reference's value function byte for byte and leaves both global streams where the reference leaves them.
 """
+import bisect
+import random  # noqa: F401  (the facade's reset() draws from it, like the reference's)
+
 import numpy as np
 
 from .utils import engine_of
@@ -49,16 +57,91 @@ def _check_visited_policy_rows(policy, first, obs, done):
         raise ValueError('probabilities are not non-negative' if (row < 0).any() else 'probabilities do not sum to 1')
 
 
+def _choice_error(row):
+    """The ValueError np.random.choice(4, p=row) raises for a row that is no distribution (numpy's legacy `choice`), or None."""
+    row = np.asarray(row, dtype=np.float64)
+    total = float(np.sum(row))
+    if np.isnan(total):
+        return 'probabilities contain NaN'
+    if (row < 0).any():
+        return 'probabilities are not non-negative'
+    if abs(total - 1.0) > np.sqrt(np.finfo(np.float64).eps):
+        return 'probabilities do not sum to 1'
+    return None
+
+
+def reference_rng_episodes(policy, env, num_episodes, max_steps_per_episode=1000):
+    """The episodes the reference's `run_episode` would generate, drawn from the SAME global streams in the same order: per
+    episode one `random.choice(starting_states)` (env.reset(), core/envs/griduniverse_env.py:189), then per step one uniform of
+    numpy's global RandomState turned into an action the way `np.random.choice(4, p=policy[obs])` does it -- cdf = p.cumsum(),
+    cdf /= cdf[-1], cdf.searchsorted(u, side='right') -- until done or the step cap (monte_carlo.py:15-25).  Transitions come
+    from the (state, action) table the look-ahead kernel computed for the grid.  The uniforms of an episode are drawn in one
+    block and the stream is then put back to exactly as many draws as the episode used.
+    Returns (first_state int32[N], actions int32[T, N] zero-padded, lengths int32[N], the last episode's state list and
+    whether it ended on a terminal step)."""
+    nxt, _, don = env._transition_table(True)
+    nxt_l, don_l = nxt.tolist(), don.tolist()
+    p = np.asarray(policy, dtype=np.float64)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        cdf = p.cumsum(axis=1)
+        cdf /= cdf[:, -1:]
+    cdf_l = cdf.tolist()
+    bad = [_choice_error(row) for row in p] if not (np.isfinite(p).all() and (p >= 0).all()
+                                                    and (np.abs(p.sum(axis=1) - 1.0) <= 1e-9).all()) else None
+    cap = int(max_steps_per_episode)
+    first, acts, lengths, states, done = [], [], [], [], False
+    for _ in range(int(num_episodes)):
+        s = env.reset()
+        first.append(s)
+        states = [s]
+        before = np.random.get_state()
+        u = np.random.random_sample(cap).tolist()
+        row = []
+        error = None
+        done = False
+        for t in range(cap):
+            if bad is not None and bad[s] is not None:
+                error = bad[s]  # (np.random.choice validates p BEFORE it draws)
+                break
+            a = bisect.bisect_right(cdf_l[s], u[t])
+            row.append(a)
+            done = don_l[s][a]
+            s = nxt_l[s][a]
+            states.append(s)
+            if done:
+                break
+        np.random.set_state(before)
+        if row:
+            np.random.random_sample(len(row))  # the stream has advanced by exactly the draws the episode made
+        if error is not None:
+            raise ValueError(error)
+        acts.append(row)
+        lengths.append(len(row))
+    T = max(1, max(lengths) if lengths else 1)
+    actions = np.zeros((T, len(acts)), np.int32)
+    for e, row in enumerate(acts):
+        actions[:len(row), e] = row
+    return np.asarray(first, np.int32), actions, np.asarray(lengths, np.int32), states, bool(done)
+
+
 def monte_carlo_evaluation(policy, env, every_visit=False, incremental_mean=True, stationary_env=True,
                            discount_factor=0.99, threshold=0.0001, alpha=0.001, num_episodes=100, *,
-                           max_steps_per_episode=1000, seed=0, return_details=False):
+                           max_steps_per_episode=1000, seed=0, return_details=False, rng='device'):
     """Value function of `policy` from `num_episodes` sampled episodes (monte_carlo.py:29-99).
 
     Episodes are processed in index order, so the result equals the reference's sequential loop fed
     with the same episodes.  Extra keyword-only arguments: the step cap of each episode (run_episode's
-    default 1000), the RNG seed of the batch, and `return_details` to also get the visit counters and
-    the raw trajectory."""
+    default 1000), the RNG seed of the batch, `return_details` to also get the visit counters and
+    the raw trajectory, and `rng`: 'device' (default: every episode sampled by its own counter-RNG stream inside one fused
+    launch) or 'numpy' (the reference's own draws from the global `random` / `np.random` streams: the returned array is then
+    byte-identical to the reference's for the same seeds; `seed` is unused)."""
     from ..vec_env import VecGridUniverse
+    if rng not in ('device', 'numpy'):
+        raise ValueError("rng must be 'device' or 'numpy'")
+    numpy_rng = rng == 'numpy'
+    if numpy_rng:
+        # host side first (it is what consumes the global streams, and it may raise like np.random.choice does)
+        first_np, actions_np, lengths_np, last_states, last_done = reference_rng_episodes(policy, env, num_episodes, max_steps_per_episode)
     device = getattr(engine_of(env), 'device', 0)
     # the batch engine of the previous call on this env is kept (creating one costs a few ms of allocations, the
     # evaluation itself well under one): re-seeding restores exactly the state of a fresh engine
@@ -76,15 +159,28 @@ def monte_carlo_evaluation(policy, env, every_visit=False, incremental_mean=True
             env._episode_batch = (key, batch)
     try:
         eng = batch.engine
-        eng.vi_set(np.zeros(env.world.size), policy)
-        first = batch.reset()
-        T = int(max_steps_per_episode)
-        eng.reserve_trajectory(T)
-        eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
+        if numpy_rng:
+            # the reference's episodes, replayed on the device: start cells installed, actions as a caller-supplied stream,
+            # no auto-reset (an env past its terminal step is absorbing and its rows are not read), reduced by gu_mc_evaluate
+            T = int(actions_np.shape[0])
+            first = first_np
+            eng.set_state(pos=first, done=np.zeros(first.size, np.int32))
+            eng.upload_actions(actions_np)
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'stream', auto_reset=False, trajectory=True)
+        else:
+            eng.vi_set(np.zeros(env.world.size), policy)
+            first = batch.reset()
+            T = int(max_steps_per_episode)
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'sample', auto_reset=False, trajectory=True)
         pw, keep = discount_table(discount_factor, threshold, T)
         value, visits = eng.mc_evaluate(T, first, pw, keep, every_visit, incremental_mean, stationary_env, alpha)
+        if numpy_rng and hasattr(env, '_drop_engine'):
+            # the reference's env ends up where its last episode ended (run_episode steps the instance itself)
+            env.reset_to_trail(last_states, last_done)
         rows = np.asarray(policy, dtype=np.float64)
-        if not (np.isfinite(rows).all() and (rows >= 0).all()
+        if not numpy_rng and not (np.isfinite(rows).all() and (rows >= 0).all()
                 and (np.abs(rows.sum(axis=1) - 1.0) <= np.sqrt(np.finfo(np.float64).eps)).all()):
             traj = eng.read_trajectory(0, T)  # rare path: some row is no distribution -- did an episode draw from it?
             _check_visited_policy_rows(rows, first, traj['obs'], traj['done'])

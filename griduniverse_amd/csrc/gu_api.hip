@@ -163,7 +163,7 @@ int gu_destroy(gu_handle h)
     gu_vi_free(h);
     gu_placement_release(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    void *bufs[] = {h->d_rows[0], h->d_rows[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
+    void *bufs[] = {h->d_kind, h->d_rows[0], h->d_rows[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
                     h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -188,7 +188,7 @@ static inline bool plane_bit(const uint32_t *rows, int32_t wpr, int32_t x, int32
 // appended to `cell` / `raw`.
 static void compile_planes(int32_t W, int32_t H, int32_t wpr, const uint32_t *wall_rows, const uint32_t *goal_rows,
                            const uint32_t *lava_rows, const uint32_t *rplus_rows, const uint32_t *rminus_rows,
-                           uint8_t *cell, uint8_t *raw, int32_t cell_bytes)
+                           uint8_t *cell, uint8_t *raw, uint8_t *kind, int32_t cell_bytes)
 {
     auto wall = [&](int32_t x, int32_t y) { return plane_bit(wall_rows, wpr, x, y); };
     for (int32_t y = 0; y < H; ++y) {
@@ -210,6 +210,7 @@ static void compile_planes(int32_t W, int32_t H, int32_t wpr, const uint32_t *wa
             cell[s] = (term ? 0 : open) | t;                                         // env:145-146 absorbing
             const int8_t r = rminus ? -10 : (rplus ? 10 : -1);                       // env:80-90
             raw[(size_t)cell_bytes + s] = cell[(size_t)cell_bytes + s] = (uint8_t)r;
+            kind[s] = goal ? 3 : lava ? 2 : wall(x, y) ? 1 : 0;                      // core/envs/rendering.py:119-133
         }
     }
 }
@@ -218,15 +219,15 @@ static void compile_planes(int32_t W, int32_t H, int32_t wpr, const uint32_t *wa
 
 // Upload compiled planes of `n_grids` grids ([g][flags|reward]) and their start tables; resets env state.
 int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const std::vector<uint8_t> &cell,
-                     const std::vector<uint8_t> &raw, const std::vector<int32_t> &starts, const std::vector<int32_t> &n_starts,
-                     int32_t max_starts)
+                     const std::vector<uint8_t> &raw, const std::vector<uint8_t> &kind, const std::vector<int32_t> &starts,
+                     const std::vector<int32_t> &n_starts, int32_t max_starts)
 {
     const int32_t S = W * H;
     const int32_t cell_bytes = (S + 15) & ~15;
     GU_HIP(hipStreamSynchronize(h->stream));
-    for (void *p : {(void *)h->d_cell, (void *)h->d_cell_raw, (void *)h->d_starts, (void *)h->d_nstarts, (void *)h->d_greedy})
+    for (void *p : {(void *)h->d_cell, (void *)h->d_cell_raw, (void *)h->d_kind, (void *)h->d_starts, (void *)h->d_nstarts, (void *)h->d_greedy})
         if (p) GU_HIP(hipFree(p));
-    h->d_cell = h->d_cell_raw = h->d_greedy = nullptr;
+    h->d_cell = h->d_cell_raw = h->d_kind = h->d_greedy = nullptr;
     h->d_starts = h->d_nstarts = nullptr;
     for (int k = 0; k < 2; ++k) {  // the transition-row tables belong to the old grid
         if (h->d_rows[k]) GU_HIP(hipFree(h->d_rows[k]));
@@ -251,6 +252,10 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
     if (!cell.empty()) {  // empty = the caller fills the planes on the device (gu_generate_mazes)
         GU_HIP(hipMemcpy(h->d_cell, cell.data(), plane_bytes, hipMemcpyHostToDevice));
         GU_HIP(hipMemcpy(h->d_cell_raw, raw.data(), plane_bytes, hipMemcpyHostToDevice));
+    }
+    if (!kind.empty()) {
+        GU_HIP(hipMalloc(&h->d_kind, kind.size()));
+        GU_HIP(hipMemcpy(h->d_kind, kind.data(), kind.size(), hipMemcpyHostToDevice));
     }
     GU_HIP(hipMemset(h->d_greedy, 0, cell_bytes));
     GU_HIP(hipMemcpy(h->d_starts, starts.data(), starts.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -312,16 +317,17 @@ int gu_set_grids(gu_handle h, int32_t n_grids, int32_t W, int32_t H, int32_t wor
             GU_REQUIRE(st >= 0 && st < S, GU_ERR_INVALID, "grid %d: starting state %d outside the grid", g, st);
         }
     }
-    std::vector<uint8_t> cell(2 * (size_t)cell_bytes * n_grids, 0), raw(2 * (size_t)cell_bytes * n_grids, 0);
+    std::vector<uint8_t> cell(2 * (size_t)cell_bytes * n_grids, 0), raw(2 * (size_t)cell_bytes * n_grids, 0), kind((size_t)cell_bytes * n_grids, 0);
     const size_t plane_words = (size_t)H * words_per_row;
     for (int32_t g = 0; g < n_grids; ++g)
         compile_planes(W, H, words_per_row, wall_rows + g * plane_words, goal_rows + g * plane_words, lava_rows + g * plane_words,
                        rplus_rows ? rplus_rows + g * plane_words : nullptr, rminus_rows ? rminus_rows + g * plane_words : nullptr,
-                       cell.data() + 2 * (size_t)cell_bytes * g, raw.data() + 2 * (size_t)cell_bytes * g, cell_bytes);
+                       cell.data() + 2 * (size_t)cell_bytes * g, raw.data() + 2 * (size_t)cell_bytes * g, kind.data() + (size_t)cell_bytes * g,
+                       cell_bytes);
     std::vector<int32_t> st(starts, starts + (size_t)n_grids * max_starts), ns(n_starts, n_starts + n_grids);
     for (int32_t g = 0; g < n_grids; ++g)  // pad unused slots with a valid cell
         for (int32_t i = ns[(size_t)g]; i < max_starts; ++i) st[(size_t)g * max_starts + i] = st[(size_t)g * max_starts];
-    return gu_install_grids(h, n_grids, W, H, cell, raw, st, ns, max_starts);
+    return gu_install_grids(h, n_grids, W, H, cell, raw, kind, st, ns, max_starts);
 }
 
 int gu_set_grid(gu_handle h, int32_t W, int32_t H, int32_t words_per_row, const uint32_t *wall_rows,

@@ -56,6 +56,10 @@ struct gu_engine {
     int32_t cell_bytes = 0;          // S rounded up to 16
     uint8_t *d_cell = nullptr;       // absorbing-aware planes    [2 * cell_bytes]
     uint8_t *d_cell_raw = nullptr;   // care_about_terminal=False [2 * cell_bytes]
+    uint8_t *d_kind = nullptr;       // [n_grids][cell_bytes] texture class of every cell as the reference's viewer picks it
+                                     // (rendering.py:119-133: goal, else lava, else wall, else ground = 3, 2, 1, 0) -- the flags
+                                     // cannot tell a goal+lava cell from a lava cell; nullptr for device-generated mazes (no
+                                     // overlaps there: the flags decide)
     uint64_t delta_lut = 0;          // int16 x 4: {-W, +1, +W, -1} (valid when W <= 32767)
     int32_t *d_starts = nullptr;     // [n_grids][max_starts]
     int32_t *d_nstarts = nullptr;    // [n_grids]
@@ -220,8 +224,8 @@ int gu_launch_greedy_table(gu_engine *h);
 
 // ---- grids (gu_api.hip / gu_maze.hip) ----------------------------------------------
 int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const std::vector<uint8_t> &cell,
-                     const std::vector<uint8_t> &raw, const std::vector<int32_t> &starts, const std::vector<int32_t> &n_starts,
-                     int32_t max_starts);
+                     const std::vector<uint8_t> &raw, const std::vector<uint8_t> &kind, const std::vector<int32_t> &starts,
+                     const std::vector<int32_t> &n_starts, int32_t max_starts);
 
 // ---- RCCL (gu_comm.hip) ----------------------------------------------------------
 void gu_comm_free(gu_engine *h);

@@ -139,7 +139,7 @@ extern "C" int gu_generate_mazes(gu_handle h, int32_t n_grids, int32_t W, int32_
     GU_REQUIRE(2 * (int64_t)cell_bytes * n_grids < (1ll << 31), GU_ERR_UNSUPPORTED, "%d grids of %d cells exceed 2 GiB of records", n_grids, S);
     std::vector<uint8_t> no_planes;  // allocate + set metadata through the common path; planes are filled on the device
     std::vector<int32_t> st((size_t)n_grids, 0), ns((size_t)n_grids, 1);
-    rc = gu_install_grids(h, n_grids, W, H, no_planes, no_planes, st, ns, 1);
+    rc = gu_install_grids(h, n_grids, W, H, no_planes, no_planes, no_planes, st, ns, 1);
     if (rc != GU_OK) return rc;
     h->has_grid = false;
     const size_t wall_bytes = ((size_t)n_grids * S + 15) & ~(size_t)15, stack_bytes = ((size_t)n_grids * rooms_max * 2 + 15) & ~(size_t)15;

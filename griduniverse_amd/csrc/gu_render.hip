@@ -2,25 +2,38 @@
 //
 // The reference draws its 'graphic' mode with pyglet textures in a window (core/envs/rendering.py:236-343) -- a GUI
 // that cannot exist on a headless GPU box.  This kernel produces the equivalent information as plain RGB arrays,
-// one thread per pixel: floor / wall / goal / lava tiles from the engine's per-cell flags, a thin grid line on the
-// top and left edge of every cell, and the agent as an inset square on its current cell.  There is no reference
-// image to be bit-exact with; the colour rules below ARE the specification (restated in tests/test_gpu_render.py).
+// one thread per pixel: ground / wall / goal / lava tiles, a thin grid line on the top and left edge of every cell, and
+// the agent as an inset square on its current cell.  WHICH of the four textures a cell gets, and the geometry of the
+// policy arrows, are the reference's and are pinned to it (tests/golden/arrows.json: the viewer's tile loop and its
+// render_policy_arrows, lifted from the parsed module and run without a window; oracle/render.py restates them and the
+// rasterisation rule below).  The four flat colours stand in for the textures (core/resources, OUT OF SCOPE) and, like
+// the grid line and the agent square, are build-defined.
 #include "gu_internal.hpp"
 
 struct RenderArgs {
     const uint8_t *cell;   // [G][flags | reward] (absorbing map: flags carry TERM / reward code / WALL)
+    const uint8_t *kind;   // [G][cell_bytes] texture class of the reference's viewer, or nullptr (device mazes: from the flags)
     const int32_t *pos;    // [N]
     uint8_t *rgb;          // [n][H*px][W*px][3]
     int64_t env0, n_envs, group, grid_stride;
     int32_t W, H, px, n_grids;
 };
 
-__device__ __forceinline__ void gu_tile_colour(uint32_t f, uint8_t &r, uint8_t &g, uint8_t &b)
+// Which texture a cell gets is the reference's rule (core/envs/rendering.py:119-133: goal, else lava, else wall, else ground;
+// pinned by tests/golden/arrows.json "tiles"); the COLOURS stand in for its four textures and are build-defined.
+__device__ __forceinline__ uint32_t gu_tile_kind(const uint8_t *kind, uint32_t f, int64_t index)
 {
-    if (f & GU_CELL_WALL) { r = 64; g = 64; b = 64; }                       // wall
-    else if (f & GU_CELL_RMINUS) { r = 220; g = 60; b = 30; }               // lava (wins over goal, like the reward)
-    else if (f & (GU_CELL_RPLUS | GU_CELL_TERM)) { r = 40; g = 180; b = 60; }  // goal
-    else { r = 220; g = 220; b = 220; }                                     // floor
+    if (kind) return kind[index];
+    // device-generated mazes: one goal, no lava, the goal never on a wall -- the flags are unambiguous
+    return (f & GU_CELL_TERM) ? ((f & GU_CELL_RMINUS) ? 2u : 3u) : (f & GU_CELL_WALL) ? 1u : 0u;
+}
+
+__device__ __forceinline__ void gu_tile_colour(uint32_t k, uint8_t &r, uint8_t &g, uint8_t &b)
+{
+    if (k == 3u) { r = 40; g = 180; b = 60; }        // goal   (wbs_texture_05_resized_green.jpg)
+    else if (k == 2u) { r = 220; g = 60; b = 30; }   // lava   (lava-resized.jpg)
+    else if (k == 1u) { r = 64; g = 64; b = 64; }    // wall   (wbs_texture_05_resized_wall.jpg)
+    else { r = 220; g = 220; b = 220; }              // ground (wbs_texture_05_resized.jpg)
 }
 
 __global__ void __launch_bounds__(256) gu_render_kernel(const RenderArgs a)
@@ -33,10 +46,11 @@ __global__ void __launch_bounds__(256) gu_render_kernel(const RenderArgs a)
     const int32_t y = (int32_t)(p / wpx), x = (int32_t)(p % wpx);
     const int32_t cy = y / a.px, cx = x / a.px, iy = y % a.px, ix = x % a.px;
     const int64_t e = a.env0 + k;
-    const uint8_t *flags = a.cell + (a.n_grids > 1 ? (e / a.group) * a.grid_stride : 0);
+    const int64_t grid = a.n_grids > 1 ? e / a.group : 0;
+    const uint8_t *flags = a.cell + grid * a.grid_stride;
     const int32_t s = cy * a.W + cx;
     uint8_t r, g, b;
-    gu_tile_colour(flags[s], r, g, b);
+    gu_tile_colour(gu_tile_kind(a.kind, flags[s], grid * (a.grid_stride / 2) + s), r, g, b);
     if (a.px >= 4 && (iy == 0 || ix == 0)) { r = r * 3 / 4; g = g * 3 / 4; b = b * 3 / 4; }  // grid line
     const int32_t lo = a.px / 4, hi = a.px - a.px / 4;
     if (s == a.pos[e] && iy >= lo && iy < hi && ix >= lo && ix < hi) { r = 40; g = 90; b = 220; }  // agent
@@ -56,6 +70,7 @@ __global__ void __launch_bounds__(256) gu_render_kernel(const RenderArgs a)
 //   head :  2 L px < 52 t <= 2 (L + 5) px,      52 |u| <= 2 (L + 5) px - 52 t
 struct PolicyRenderArgs {
     const uint8_t *cell;
+    const uint8_t *kind;
     const double *pi;  // [S][4]
     uint8_t *rgb;      // [H*px][W*px][3]
     int32_t W, H, px;
@@ -72,7 +87,7 @@ __global__ void __launch_bounds__(256) gu_render_policy_kernel(const PolicyRende
     const int32_t s = cy * a.W + cx;
     const uint32_t f = a.cell[s];
     uint8_t r, g, b;
-    gu_tile_colour(f, r, g, b);
+    gu_tile_colour(gu_tile_kind(a.kind, f, s), r, g, b);
     if (a.px >= 4 && (iy == 0 || ix == 0)) { r = r * 3 / 4; g = g * 3 / 4; b = b * 3 / 4; }  // grid line
     if (!(f & (GU_CELL_TERM | GU_CELL_WALL))) {
         const int64_t X = 2 * ix + 1 - a.px, Y = a.px - (2 * iy + 1);  // doubled, y up
@@ -111,7 +126,7 @@ extern "C" int gu_render_policy_rgb(gu_handle h, int32_t cell_px, uint8_t *rgb)
     GU_REQUIRE(pixels * 3 <= (1ll << 32), GU_ERR_INVALID, "%lld pixels are too many for one call", (long long)pixels);
     rc = gu_ensure_scratch(h, (size_t)pixels * 3);
     if (rc != GU_OK) return rc;
-    PolicyRenderArgs a{h->d_cell, h->d_pi[h->vi_cur], (uint8_t *)h->d_scratch, h->W, h->H, cell_px};
+    PolicyRenderArgs a{h->d_cell, h->d_kind, h->d_pi[h->vi_cur], (uint8_t *)h->d_scratch, h->W, h->H, cell_px};
     hipLaunchKernelGGL(gu_render_policy_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, h->stream, a);
     GU_HIP(hipGetLastError());
     GU_HIP(hipMemcpyAsync(rgb, h->d_scratch, (size_t)pixels * 3, hipMemcpyDeviceToHost, h->stream));
@@ -131,7 +146,7 @@ extern "C" int gu_render_rgb(gu_handle h, int64_t env0, int64_t n_envs, int32_t 
     GU_REQUIRE(pixels * 3 <= (1ll << 32), GU_ERR_INVALID, "%lld pixels are too many for one call", (long long)pixels);
     rc = gu_ensure_scratch(h, (size_t)pixels * 3);
     if (rc != GU_OK) return rc;
-    RenderArgs a{h->d_cell, h->pos(), (uint8_t *)h->d_scratch, env0, n_envs, h->group, 2 * (int64_t)h->cell_bytes,
+    RenderArgs a{h->d_cell, h->d_kind, h->pos(), (uint8_t *)h->d_scratch, env0, n_envs, h->group, 2 * (int64_t)h->cell_bytes,
                  h->W, h->H, cell_px, h->n_grids};
     hipLaunchKernelGGL(gu_render_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, h->stream, a);
     GU_HIP(hipGetLastError());

@@ -234,6 +234,15 @@ class GridUniverseEnv(object):
             trail.pop(0)
         return nxt, tab[1][state][action], done, self.info
 
+    def reset_to_trail(self, states, done):
+        """Put the instance where an episode that visited `states` (reset state first) left the reference's: current /
+        previous state, done flag, and the (x, y) trail of the steps taken (env:176-185 per step, capped at 500)."""
+        self.done = bool(done)
+        self._state = int(states[-1])
+        self.previous_state = int(states[-2]) if len(states) > 1 else int(states[-1])
+        self.last_n_states = [self.world[int(s)] for s in states[1:][-self.num_previous_states_to_store:]]
+        self._pos_dirty = True
+
     def step_on_device(self, action):
         """The same step executed by gu_step_kernel on the engine's N = 1 batch (kernel launch + page-locked I/O);
         kept for parity tests of the kernel path through the facade."""

@@ -89,7 +89,8 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_ROLLOUT_MULTI_K 5      /* force K = 2 or 4                                                                     */
 #define GU_OPT_ROLLOUT_MULTI_COPIES 6 /* 2 = replicate its table across the banks                                             */
 #define GU_OPT_ROLLOUT_XCD 7          /* 1 = XCD-aware env-block order (measured slower; off)                                 */
-#define GU_OPT_VI_PATH 8              /* DP: 1 = no workgroup-cluster kernel, 2 = one launch per round on every grid size     */
+#define GU_OPT_VI_PATH 8              /* DP: 1 = no workgroup-cluster kernel, 2 = one launch per round on every grid size,
+                                         3 = cluster kernel with an INJECTED grid-barrier timeout (tests of the fallback)    */
 #define GU_OPT_MC_SCRATCH_MB 9        /* scratch budget of gu_mc_evaluate (2048)                                              */
 #define GU_OPT_MC_LANE_RETURNS 10     /* 1 = return sums by the per-lane kernel instead of the LDS-tiled one                  */
 #define GU_OPT_MC_GLOBAL_WALK 11      /* 1 = history walk with its counters in global memory instead of LDS                   */
@@ -304,13 +305,18 @@ int gu_mc_evaluate(gu_handle h, int64_t T, const int32_t *first_state, int32_t e
 int gu_shortest_paths(gu_handle h, int32_t max_path, int8_t *path, int32_t *path_len, int32_t *terminal);
 
 /* ---- headless RGB frames (stands in for the pyglet window of core/envs/rendering.py:236-343) -----------------
- * rgb[n_envs][H*cell_px][W*cell_px][3] uint8 for envs env0 .. env0+n_envs-1: floor / wall / goal / lava tiles, a grid
- * line on the top and left edge of each cell (cell_px >= 4), the agent as an inset square on its cell. */
+ * rgb[n_envs][H*cell_px][W*cell_px][3] uint8 for envs env0 .. env0+n_envs-1: ground / wall / goal / lava tiles -- which of
+ * the four a cell gets follows the viewer's rule (rendering.py:119-133: goal, else lava, else wall, else ground); the flat
+ * colours that stand in for its textures are build-defined -- a grid line on the top and left edge of each cell
+ * (cell_px >= 4), the agent as an inset square on its cell. */
 int gu_render_rgb(gu_handle h, int64_t env0, int64_t n_envs, int32_t cell_px, uint8_t *rgb);
 /* The policy-arrow figure of Viewer.render_policy_arrows (core/envs/rendering.py:159-212) for the current policy table
  * (gu_vi_set / gu_vi_run ...): rgb[H*cell_px][W*cell_px][3], the tiles of grid 0 plus, on every state that is neither
- * terminal nor a wall, one arrow per action with probability >= 0.1 (shaft round(p*20), head 5 x 5, on the
- * reference's 52-pixel tile; scaled by cell_px / 52). */
+ * terminal nor a wall, one arrow per action with probability >= 0.1: shaft from the tile centre, round(p*20) long
+ * (half to even), head a triangle of half-width 5 and height 5 on its end, on the reference's 52-pixel tile.
+ * Rasterisation (the reference leaves it to OpenGL): coordinates scale by cell_px / 52 about the tile centre; a pixel is
+ * painted when its centre lies within max(1, cell_px / 26) / 2 of the shaft segment, or inside the head triangle (edges
+ * included, the base edge excluded).  Probabilities are expected in [0, 1] (an arrow never leaves its tile then). */
 int gu_render_policy_rgb(gu_handle h, int32_t cell_px, uint8_t *rgb);
 
 /* ---- page-locked host memory -----------------------------------------------------

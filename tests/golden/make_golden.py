@@ -427,6 +427,46 @@ def capture_mc():
               'terminal %.2f' % np.mean([e[2] for e in episodes]))
 
 
+def capture_mc_numpy_rng():
+    """monte_carlo_evaluation of the REAL reference exactly as a user calls it: its own run_episode, actions drawn with
+    np.random.choice from numpy's GLOBAL stream (core/algorithms/monte_carlo.py:20), start cells with the stdlib's
+    random.choice (core/envs/griduniverse_env.py:189), both seeded right before the call.  Stored: the returned value function
+    (raw float64) per flag combination, plus the next draw of both global streams afterwards (how much each consumed)."""
+    import core.algorithms.monte_carlo as ref_mc
+    rs = np.random.RandomState(12)
+    cases = [('maze8_uniform', lambda: seeded_maze_env(8, 8, 1), None, 25, 31),
+             ('lava4x4_dirichlet', lambda: ref_env(lava_states=[5, 6, 9]), 'dirichlet', 40, 32),
+             ('rect6x5_multistart', lambda: ref_env(grid_shape=(6, 5), goal_states=[29, 8], lava_states=[13], walls=[7, 14, 20],
+                                                    initial_state=[0, 3, 27]), 'sparse', 30, 33)]
+    combos = [dict(every_visit=ev, incremental_mean=im, stationary_env=st)
+              for ev in (False, True) for im, st in ((True, True), (True, False), (False, True))]
+    for name, make, kind, episodes, seed in cases:
+        env = make()
+        S = env.world.size
+        if kind is None:
+            policy = np.ones((S, 4)) / 4
+        else:
+            policy = rs.dirichlet(np.ones(4) * 0.7, S)
+            if kind == 'sparse':  # rows with exact zeros and ones: thresholds at both ends of the cumulative table
+                policy[::5] = np.eye(4)[rs.randint(0, 4, len(policy[::5]))]
+                policy[1::7] = [0.5, 0.0, 0.5, 0.0]
+        arrays = dict(policy=policy)
+        meta = dict(spec_of(env), seed=seed, num_episodes=episodes, runs=[])
+        for gamma, thr, alpha in ((0.99, 1e-4, 0.001), (0.9, 1e-3, 0.05)):
+            for c in combos:
+                random.seed(seed)
+                np.random.seed(seed)
+                with quiet():
+                    v = ref_mc.monte_carlo_evaluation(policy, env, discount_factor=gamma, threshold=thr, alpha=alpha,
+                                                      num_episodes=episodes, **c)
+                key = 'v_%d' % len(meta['runs'])
+                arrays[key] = v
+                meta['runs'].append(dict(c, discount_factor=gamma, threshold=thr, alpha=alpha, key=key,
+                                         next_numpy_uniform=float(np.random.random_sample()), next_stdlib_uniform=random.random()))
+        np.savez_compressed(os.path.join(OUT, 'mcnp_%s.npz' % name), meta=json.dumps(meta), **arrays)
+        print('mcnp', name, 'S', S, 'episodes', episodes, 'runs', len(meta['runs']))
+
+
 # ----------------------------------------------------------------------------- G10
 def reference_path_search():
     """The reference's breadth-first path search lives inside the `if __name__ == '__main__':` demo loop of
@@ -512,6 +552,141 @@ def capture_bfs():
 
 
 # ----------------------------------------------------------------------------- G2
+# ----------------------------------------------------------------------------- G11
+def capture_arrows():
+    """Policy-arrow geometry and tile kinds of the reference's pyglet viewer, without a window.
+
+    core/envs/rendering.py imports pyglet / OpenGL at module level and Viewer.__init__ opens a window, so neither the module nor
+    the class can be used headless.  What is lifted out of the PARSED module (ast; nothing of it is imported or copied):
+      * the method definitions Viewer.get_x_y_pix_location (:153-157) and Viewer.render_policy_arrows (:159-212), compiled
+        unchanged into a class whose instances get the attributes __init__ would have computed (tile_dim = width of the ground
+        texture + padding 1, :74-75; num_extra_tiles 4, :89; pix_grid_height, :117; x_distance_to_move set to 0 -- a pure
+        translation) and whose free names `Line` / `FilledPolygon` record their arguments instead of drawing;
+      * the `for i, (x, y) in enumerate(self.env.world)` statement of Viewer.__init__ (:119-133) that decides which texture
+        every cell gets (goal, else lava, else wall, else ground), run with a `pyglet.sprite.Sprite` that records its image.
+    Recorded per case: the policy, the geoms in the order the reference adds them (arrow head, then shaft, per state and action;
+    coordinates relative to the state's tile origin, y up as in GL), and the tile kind of every state."""
+    import ast
+    from PIL import Image
+    path = os.path.join(REF, 'core', 'envs', 'rendering.py')
+    tree = ast.parse(open(path).read(), path)
+    viewer = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'Viewer')
+    methods = {n.name: n for n in viewer.body if isinstance(n, ast.FunctionDef)}
+    lifted = ast.ClassDef(name='LiftedViewer', bases=[], keywords=[], decorator_list=[],
+                          body=[methods['get_x_y_pix_location'], methods['render_policy_arrows']])
+    tile_loop = next(n for n in ast.walk(methods['__init__']) if isinstance(n, ast.For)
+                     and isinstance(n.iter, ast.Call) and getattr(n.iter.func, 'id', '') == 'enumerate')
+    wrapper = ast.parse('def place_tiles(self, background):\n    pass\n').body[0]
+    wrapper.body = [tile_loop]
+    module = ast.Module(body=[lifted, wrapper], type_ignores=[])
+    code = compile(ast.fix_missing_locations(module), path, 'exec')
+
+    class Line(object):
+        def __init__(self, start, end):
+            self.kind, self.start, self.end = 'line', start, end
+
+    class FilledPolygon(object):
+        def __init__(self, v):
+            self.kind, self.v = 'polygon', v
+
+    class Sprite(object):
+        def __init__(self, img, x=0, y=0, batch=None, group=None):
+            self.img, self.x, self.y = img, x, y
+
+    class Namespace(object):
+        pass
+    pyglet_stub = Namespace()
+    pyglet_stub.sprite = Namespace()
+    pyglet_stub.sprite.Sprite = Sprite
+    ns = dict(np=np, Line=Line, FilledPolygon=FilledPolygon, pyglet=pyglet_stub)
+    exec(code, ns)
+    ground_width = Image.open(os.path.join(REF, 'core', 'resources', 'wbs_texture_05_resized.jpg')).size[0]
+    padding = 1
+
+    def viewer_for(env):
+        v = ns['LiftedViewer']()
+        v.env = env
+        v.padding = padding
+        v.tile_dim = ground_width + padding                  # :74-75
+        v.num_extra_tiles = 4                                # :89
+        v.x_distance_to_move = 0                             # (:106 centres the grid in the window: a translation)
+        v.pix_grid_height = env.y_max * v.tile_dim + (v.num_extra_tiles // 2) * v.tile_dim   # :117
+        v.geoms = []
+        v.add_geom = lambda geom: v.geoms.append(geom)  # (:232-233; render_policy_arrows rebinds self.geoms first, :161)
+        for kind in ('terminal_goal', 'terminal_lava', 'wall', 'ground'):
+            setattr(v, kind + '_sprites', [])
+            setattr(v, kind + '_img', kind)
+        v.batch = None
+        return v
+
+    def case(name, env, policy, note=''):
+        v = viewer_for(env)
+        S = env.world.size
+        origin = {}
+        for s_, (x, y) in enumerate(env.world):
+            origin[s_] = v.get_x_y_pix_location(x, y)
+        centre_to_state = {(ox + v.tile_dim // 2, oy + v.tile_dim // 2): s_ for s_, (ox, oy) in origin.items()}
+        v.render_policy_arrows(np.asarray(policy, dtype=np.float64))
+        geoms, pending = [], None
+        for g in v.geoms:  # the reference adds the head, then the shaft of the same arrow
+            if g.kind == 'polygon':
+                pending = g
+                continue
+            s_ = centre_to_state[tuple(int(c) for c in g.start)]
+            ox, oy = origin[s_]
+            rel = lambda pt: [int(pt[0]) - ox, int(pt[1]) - oy]  # noqa: E731
+            geoms.append(dict(state=s_, head=[rel(p_) for p_ in pending.v], start=rel(g.start), end=rel(g.end)))
+            pending = None
+        ns['place_tiles'](v, None)
+        kinds = [None] * S
+        for kind in ('terminal_goal', 'terminal_lava', 'wall', 'ground'):
+            for sp in getattr(v, kind + '_sprites'):
+                s_ = next(k for k, o in origin.items() if o == (sp.x, sp.y))
+                assert kinds[s_] is None
+                kinds[s_] = {'terminal_goal': 'goal', 'terminal_lava': 'lava', 'wall': 'wall', 'ground': 'ground'}[kind]
+        assert None not in kinds
+        out = spec_of(env)
+        out.update(name=name, note=note, policy=[[float(p_) for p_ in row] for row in np.asarray(policy, dtype=np.float64)],
+                   geoms=geoms, tiles=kinds)
+        print('arrows', name, 'S', S, 'arrows', len(geoms), 'tiles', {k: kinds.count(k) for k in sorted(set(kinds))})
+        return out
+
+    rs = np.random.RandomState(52)
+    cases = []
+    # a 6 x 4 grid with every overlap the texture rule has to decide: goal+lava (7), goal+wall (13), lava+wall (9), plain ones
+    quirk = ref_env(grid_shape=(6, 4), goal_states=[23, 7, 13], lava_states=[7, 9, 16], walls=[2, 3, 14, 13, 9])
+    S = quirk.world.size
+    pi = rs.dirichlet(np.ones(4) * 0.6, S)
+    pi[0] = [1, 0, 0, 0]
+    pi[1] = [0, 1, 0, 0]
+    pi[4] = [0, 0, 0, 1]
+    pi[5] = [0.25, 0.25, 0.25, 0.25]
+    pi[6] = [0.5, 0.5, 0, 0]
+    pi[8] = [0.099, 0.101, 0.4, 0.4]            # just below / above the 0.1 cut
+    pi[10] = [0.1, 0.1, 0.1, 0.7]               # p == 0.1 exactly is drawn (the test is `< 0.1`)
+    pi[11] = [0.125, 0.375, 0.3, 0.2]           # round half to even: 2.5 -> 2, 7.5 -> 8
+    pi[12] = [0.175, 0.225, 0.275, 0.325]       # 3.5, 4.5, 5.5, 6.5 as far as float64 has them
+    pi[15] = [0.025, 0.975, 0.0, 0.0]
+    pi[17] = [0.0, 0.0, 1.0, 0.0]
+    cases.append(case('quirk6x4', quirk, pi, 'overlapping goal / lava / wall cells; the 0.1 cut; round-half-even lengths; one-hot and uniform rows'))
+    default = ref_env()
+    cases.append(case('default4x4_uniform', default, np.ones((16, 4)) / 4, 'the policy examples/griduniverse_alg_examples.py starts from'))
+    with quiet():
+        level = GridUniverseEnv(custom_world_fp=os.path.join(LEVELS, 'test_env.txt'))
+    S = level.world.size
+    cases.append(case('test_env_3x8_dirichlet', level, rs.dirichlet(np.ones(4), S), 'non-square level (two starts, lava, walls)'))
+    maze = seeded_maze_env(11, 11, 3)
+    S = maze.world.size
+    greedy = np.zeros((S, 4))
+    greedy[np.arange(S), rs.randint(0, 4, S)] = 1.0
+    cases.append(case('maze11_onehot', maze, greedy, 'a deterministic policy on a generator maze'))
+    return dict(tile_dim=ground_width + padding, ground_texture_width=ground_width, padding=padding, arrow_base_length_full_prob=20,
+                arrow_width=5, arrow_height=5, cases=cases,
+                source='core/envs/rendering.py: Viewer.get_x_y_pix_location, Viewer.render_policy_arrows and the tile loop of '
+                       'Viewer.__init__, lifted with ast and executed against the real reference env; coordinates are GL pixels '
+                       'relative to the tile origin (bottom-left corner of the tile, y up)')
+
+
 def capture_trajectories():
     digests = {}
     # C1: run_default_griduniverse() shape -- 1 env, 1000 random steps, reset on done
@@ -607,7 +782,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     random.seed(0)
     np.random.seed(0)
-    what = {a.split('=')[0] for a in sys.argv[1:]} or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'bfs'}  # plus 'big' (slow) on request
+    what = {a.split('=')[0] for a in sys.argv[1:]} or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'mcnp', 'bfs', 'arrows'}  # plus 'big' (slow) on request
     if 'kat' in what:
         json.dump(capture_kats(), open(os.path.join(OUT, 'kat.json'), 'w'), indent=1)
     if 'err' in what:
@@ -622,8 +797,12 @@ def main():
         capture_dp()
     if 'mc' in what:
         capture_mc()
+    if 'mcnp' in what:
+        capture_mc_numpy_rng()
     if 'bfs' in what:
         json.dump(capture_bfs(), open(os.path.join(OUT, 'bfs.json'), 'w'), indent=1)
+    if 'arrows' in what:
+        json.dump(capture_arrows(), open(os.path.join(OUT, 'arrows.json'), 'w'))
     if 'big' in what:
         capture_big_digest()
     if 'stream' in what:

@@ -327,3 +327,65 @@ def test_policy_rows_that_are_no_distribution_raise_like_np_random_choice():
     with pytest.raises(ValueError, match='not non-negative'):
         mc.monte_carlo_evaluation(pi, env, num_episodes=32, max_steps_per_episode=60)
     env.close()
+
+
+def mcnp_names():
+    import glob
+    import os
+    return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(G.GOLDEN, 'mcnp_*.npz')))
+
+
+@pytest.mark.parametrize('name', mcnp_names())
+def test_reference_rng_mode_returns_the_reference_value_function(name):
+    """rng='numpy': `random.seed(k); np.random.seed(k); monte_carlo_evaluation(policy, env, ...)` of the REAL reference (its own
+    run_episode drawing np.random.choice from the global stream, start cells from the stdlib's) against the same call on the
+    engine: the returned array byte for byte, for 2 x 6 flag combinations per grid, and both global streams left exactly where
+    the reference leaves them (the next uniform of each)."""
+    import random
+    meta, z = G.load_npz('mcnp', name)
+    env = gua.GridUniverseEnv(grid_shape=(meta['W'], meta['H']), initial_state=meta['starts'], goal_states=meta['goals'],
+                              lava_states=meta['lava'], walls=meta['walls'])
+    assert mcnp_names() and len(meta['runs']) == 12
+    np_state, py_state = np.random.get_state(), random.getstate()
+    try:
+        for run in meta['runs']:
+            random.seed(meta['seed'])
+            np.random.seed(meta['seed'])
+            v = mc.monte_carlo_evaluation(z['policy'], env, every_visit=run['every_visit'], incremental_mean=run['incremental_mean'],
+                                          stationary_env=run['stationary_env'], discount_factor=run['discount_factor'],
+                                          threshold=run['threshold'], alpha=run['alpha'], num_episodes=meta['num_episodes'], rng='numpy')
+            assert v.tobytes() == z[run['key']].tobytes(), (name, run)
+            assert float(np.random.random_sample()) == run['next_numpy_uniform'] and random.random() == run['next_stdlib_uniform']
+        # the instance is left where the last episode ended, like the reference's (run_episode steps the env itself)
+        random.seed(meta['seed'])
+        np.random.seed(meta['seed'])
+        want_states = None
+        for _ in range(meta['num_episodes']):
+            want_states, _, want_done = mc.run_episode(z['policy'], env)
+        want = (env.current_state, env.previous_state, env.done, list(env.last_n_states))
+        random.seed(meta['seed'])
+        np.random.seed(meta['seed'])
+        mc.monte_carlo_evaluation(z['policy'], env, num_episodes=meta['num_episodes'], rng='numpy')
+        assert (env.current_state, env.previous_state, env.done, list(env.last_n_states)) == want and want[0] == want_states[-1]
+    finally:
+        np.random.set_state(np_state)
+        random.setstate(py_state)
+        env.close()
+
+
+def test_reference_rng_mode_raises_like_np_random_choice():
+    """A policy row that is no distribution raises ValueError only when an episode draws from it (np.random.choice validates p
+    before drawing), with numpy's message."""
+    env = gua.GridUniverseEnv(grid_shape=(4, 1), goal_states=[3])
+    pi = np.ones((4, 4)) / 4
+    pi[3] = [2, 2, 2, 2]          # terminal state: never drawn from
+    assert mc.monte_carlo_evaluation(pi, env, num_episodes=3, rng='numpy').shape == (4,)
+    pi[1] = [0.5, 0.6, 0.0, 0.0]
+    with pytest.raises(ValueError, match='do not sum to 1'):
+        mc.monte_carlo_evaluation(pi, env, num_episodes=20, rng='numpy')
+    pi[1] = [1.5, -0.5, 0.0, 0.0]
+    with pytest.raises(ValueError, match='not non-negative'):
+        mc.monte_carlo_evaluation(pi, env, num_episodes=20, rng='numpy')
+    with pytest.raises(ValueError):
+        mc.monte_carlo_evaluation(np.ones((4, 4)) / 4, env, num_episodes=2, rng='mt')
+    env.close()

@@ -1,5 +1,6 @@
-"""Headless RGB frames rendered on the device (gu_render_rgb): the colour rules of csrc/gu_render.hip restated in
-numpy and compared pixel for pixel, for a single grid, a multi-grid engine and the facade's render('rgb_array')."""
+"""Headless RGB frames rendered on the device.  Which texture a cell gets and the geometry of the policy arrows are the
+reference viewer's and are checked against tests/golden/arrows.json (captured from its own method bodies); the flat colours,
+the grid line and the agent square are build-defined and restated here."""
 import numpy as np
 import pytest
 
@@ -60,58 +61,58 @@ def test_facade_rgb_array_mode():
     assert tuple(frame[8, 8]) == FLOOR and tuple(frame[24, 8]) == AGENT
 
 
-def expected_policy_frame(spec, pi, px):
-    """csrc/gu_render.hip: gu_render_policy_kernel restated (integer arithmetic on doubled, tile-centred coordinates)."""
-    W, H = spec.W, spec.H
-    img = expected_frame(spec, -1, px)
-    terminal = np.asarray(spec.goal, bool) | np.asarray(spec.lava, bool)
-    shaft = max(1, px // 26)
-    for s in range(W * H):
-        if terminal[s] or spec.wall[s]:
-            continue
-        cy, cx = divmod(s, W)
-        for iy in range(px):
-            for ix in range(px):
-                X, Y = 2 * ix + 1 - px, px - (2 * iy + 1)
-                on = False
-                for act in range(4):
-                    p = pi[s, act]
-                    if not p >= 0.1:
-                        continue
-                    L = int(min(np.rint(p * 20.0), 1000.0))
-                    t = (Y, X, -Y, -X)[act]
-                    u = abs(Y if act & 1 else X)
-                    base, tip = 2 * L * px, 2 * (L + 5) * px
-                    on |= t >= 0 and 52 * t <= base and u <= shaft
-                    on |= base < 52 * t <= tip and 52 * u <= tip - 52 * t
-                if on:
-                    img[cy * px + iy, cx * px + ix] = (20, 20, 20)
-    return img
+@pytest.mark.parametrize('px', [52, 16, 26, 3])
+def test_policy_arrow_frames_equal_the_rasterised_reference_geometry(px):
+    """tests/golden/arrows.json holds what the reference's own Viewer.render_policy_arrows and tile loop produced (head triangles,
+    shafts, texture class per cell; make_golden.py lifts the method bodies and runs them without a window).  Those primitives,
+    rasterised by the rule include/gu.h states (oracle/render.py), must equal gu_render_policy_rgb pixel for pixel: at the
+    reference's own 52-pixel tile and scaled (16, 26 -- where shaft ends fall on pixel centres -- and 3)."""
+    from oracle import render as R
+    from tests import _golden as G
+    for case in G.load_json('arrows.json')['cases']:
+        W, H = case['W'], case['H']
+        spec = GridSpec(W, H, case['starts'], case['goals'], case['lava'], case['walls'], case['reward'])
+        pi = np.array(case['policy'], dtype=np.float64)
+        with Engine(2, spec) as eng:
+            eng.vi_set(np.zeros(W * H), pi)
+            frame = eng.render_policy_rgb(px)
+        want = R.policy_frame(W, H, case['tiles'], case['geoms'], px)
+        assert frame.shape == want.shape == (H * px, W * px, 3)
+        assert np.array_equal(frame, want), (case['name'], px, np.argwhere((frame != want).any(axis=2))[:5])
+        if px == 52:  # arrows are really there
+            assert (frame == 20).all(axis=2).sum() > 30 * len(case['geoms'])
 
 
-@pytest.mark.parametrize('px', [3, 16, 52])
-def test_policy_arrow_frames(px):
-    rs = np.random.RandomState(px)
-    W, H = 6, 4
-    S = W * H
-    spec = GridSpec(W, H, [0], [S - 1, 7], [9], [2, 3, 14])
-    pi = rs.dirichlet(np.ones(4) * 0.6, S)
-    pi[1] = [1, 0, 0, 0]
-    pi[4] = [0, 0, 0, 1]
-    pi[5] = [0.25, 0.25, 0.25, 0.25]
-    pi[6] = [0.5, 0.5, 0, 0]
-    pi[8] = [0.099, 0.101, 0.4, 0.4]
-    pi[10] = [np.nan, 2.0, 0, -1]
-    pi[11] = [0.125, 0.375, 0.3, 0.2]  # round-half-even: 2.5 -> 2, 7.5 -> 8
-    with Engine(2, spec) as eng:
-        eng.vi_set(np.zeros(S), pi)
-        frame = eng.render_policy_rgb(px)
-        assert frame.shape == (H * px, W * px, 3)
-        assert np.array_equal(frame, expected_policy_frame(spec, pi, px))
-        if px >= 16:  # an arrow is really there: the one-hot UP policy of state 1 paints above the centre, not below
-            tile = frame[0:px, px:2 * px]
-            dark = (tile == 20).all(axis=2)
-            assert dark[:px // 2].sum() > 3 and dark[px // 2 + 1:].sum() == 0
-    env = gua.GridUniverseEnv(grid_shape=(W, H), goal_states=[S - 1, 7], lava_states=[9], walls=[2, 3, 14])
-    assert np.array_equal(env.render_policy_arrows(pi, mode='rgb_array', cell_px=px), expected_policy_frame(spec, pi, px))
+def test_tiles_follow_the_viewers_texture_rule_where_cell_kinds_overlap():
+    """goal+lava and goal+wall cells show the goal texture, lava+wall the lava one (rendering.py:119-133; arrows.json 'tiles'),
+    in frames of the engine and of the facade; the agent square sits on its cell."""
+    from oracle import render as R
+    from tests import _golden as G
+    case = next(c for c in G.load_json('arrows.json')['cases'] if c['name'] == 'quirk6x4')
+    W, H = case['W'], case['H']
+    spec = GridSpec(W, H, case['starts'], case['goals'], case['lava'], case['walls'], case['reward'])
+    with Engine(3, spec, seed=4) as eng:
+        eng.reset()
+        eng.rollout(3, 'uniform', True, trajectory=False)
+        pos = eng.get_state()['pos']
+        frames = eng.render_rgb(0, 3, 8)
+        for e in range(3):
+            assert np.array_equal(frames[e], R.tile_frame(W, H, case['tiles'], 8, agent=int(pos[e]))), e
+    env = gua.GridUniverseEnv(grid_shape=(W, H), goal_states=case['goals'], lava_states=case['lava'], walls=case['walls'])
+    assert np.array_equal(env.render(mode='rgb_array'), R.tile_frame(W, H, case['tiles'], 16, agent=0))
+    pi = np.array(case['policy'])
+    assert np.array_equal(env.render_policy_arrows(pi, mode='rgb_array', cell_px=52), R.policy_frame(W, H, case['tiles'], case['geoms'], 52))
     env.close()
+
+
+def test_policy_rows_outside_the_reference_domain():
+    """NaN draws nothing (the reference raises on it), probabilities above 1 stay inside their tile (the reference's arrow would
+    cross into the neighbour): documented divergences outside [0, 1]; the frame stays well-formed."""
+    W, H = 3, 1
+    spec = GridSpec(W, H, [0], [2], [], [])
+    pi = np.array([[np.nan, 0.0, 0.0, 0.0], [0.0, 2.0, 0.0, -1.0], [0.25, 0.25, 0.25, 0.25]])
+    with Engine(1, spec) as eng:
+        eng.vi_set(np.zeros(3), pi)
+        frame = eng.render_policy_rgb(52)
+    dark = (frame == 20).all(axis=2)
+    assert dark[:, :52].sum() == 0 and dark[:, 52:104].sum() > 0 and dark[:, 104:].sum() == 0  # (state 2 is terminal: no arrows)

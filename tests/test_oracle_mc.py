@@ -39,3 +39,55 @@ def test_sampled_episodes_reproduce(name):
             nxt = C.look_step_ahead(grid, [s], [a])[0][0]
             assert nxt == z['obs'][t, e]
             s = int(nxt)
+
+
+def test_reference_rng_episode_generator_on_an_oracle_table_reproduces_the_reference():
+    """The HOST half of monte_carlo_evaluation(rng='numpy') -- drawing the reference's episodes from the global `random` /
+    `np.random` streams (algorithms/monte_carlo.py: reference_rng_episodes) -- needs only a transition table; here the table
+    comes from the oracle env instead of the look-ahead kernel, the episodes are reduced by the oracle's evaluation, and the
+    result must be the value function the REAL reference returned for the same seeds (tests/golden/mcnp_*.npz), with both
+    global streams left where the reference leaves them."""
+    import glob
+    import os
+    import random
+
+    import numpy as np
+
+    from griduniverse_amd.algorithms.monte_carlo import reference_rng_episodes
+    from oracle import mc as omc
+    from oracle.ref_env import OracleGridUniverseEnv
+    from tests import _golden as G
+
+    names = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(G.GOLDEN, 'mcnp_*.npz')))
+    assert len(names) >= 3
+    np_state, py_state = np.random.get_state(), random.getstate()
+    try:
+        for name in names:
+            meta, z = G.load_npz('mcnp', name)
+            env = OracleGridUniverseEnv(grid_shape=(meta['W'], meta['H']), initial_state=meta['starts'], goal_states=meta['goals'],
+                                        lava_states=meta['lava'], walls=meta['walls'])
+            S = meta['W'] * meta['H']
+            table = [[env.look_step_ahead(s, a) for a in range(4)] for s in range(S)]
+            env._transition_table = lambda care, t=table: (np.array([[c[0] for c in row] for row in t]),
+                                                           np.array([[c[1] for c in row] for row in t]),
+                                                           np.array([[c[2] for c in row] for row in t]))
+            for run in meta['runs'][::3]:
+                random.seed(meta['seed'])
+                np.random.seed(meta['seed'])
+                first, actions, lengths, last_states, last_done = reference_rng_episodes(z['policy'], env, meta['num_episodes'])
+                assert float(np.random.random_sample()) == run['next_numpy_uniform'] and random.random() == run['next_stdlib_uniform']
+                episodes = []
+                for e in range(meta['num_episodes']):
+                    s, states, rewards = int(first[e]), [int(first[e])], []
+                    for t in range(int(lengths[e])):
+                        s, r, d = table[s][int(actions[t, e])]
+                        states.append(s)
+                        rewards.append(r)
+                    episodes.append((states, rewards, d))
+                assert episodes[-1][0] == last_states and episodes[-1][2] == last_done
+                v, _ = omc.monte_carlo_evaluation(S, episodes, run['every_visit'], run['incremental_mean'], run['stationary_env'],
+                                                  run['discount_factor'], run['threshold'], run['alpha'])
+                assert v.tobytes() == z[run['key']].tobytes(), (name, run)
+    finally:
+        np.random.set_state(np_state)
+        random.setstate(py_state)

@@ -12,6 +12,23 @@ from collections import defaultdict
 # the dominant kernel of bench.py (the general rollout kernel; NOT the row-table / K-step kernels of its `other_modes` launches)
 BENCH_KERNEL = 'gu_rollout_kernel<'
 
+# every launch form the bench line reports, recognised by kernel name and launch size (threads): the headline (config 3,
+# 65 536 envs), the strong-scaling config-4 line (262 144 envs on one GPU), packed rows (row-table kernel), statistics only
+# (K-step kernel)
+MODES = {
+    'headline': lambda name, grid: 'gu_rollout_kernel<' in name and grid == 65536,
+    'strong_c4': lambda name, grid: 'gu_rollout_kernel<' in name and grid == 262144,
+    'packed_rows': lambda name, grid: 'gu_rollout_rows_kernel<' in name and grid == 65536,
+    'stats_only': lambda name, grid: 'gu_rollout_multi_kernel<' in name and grid == 65536,
+}
+
+
+def mode_of(name, grid):
+    for mode, match in MODES.items():
+        if match(name, int(grid)):
+            return mode
+    return None
+
 def rows(pattern):
     out = []
     for p in glob.glob(pattern, recursive=True):
@@ -48,16 +65,47 @@ def main():
     summary['rollout_pmc_avg_per_dispatch'] = {k: sum(v) / len(v) for k, v in sorted(pmc.items())}
     summary['rollout_pmc_samples'] = {k: len(v) for k, v in sorted(pmc.items())}
     avg = summary['rollout_pmc_avg_per_dispatch']
-    if 'WRITE_SIZE' in avg:
-        # MI355X_MICROARCH.md "HBM": WRITE_SIZE and FETCH_SIZE are in KiB; on gfx950 FETCH_SIZE reports half
-        # of a coalesced read stream, so it is doubled; WRITE_SIZE reads the bytes exactly.  Calibration in
-        # our own access pattern: the kernel's known write volume is 12 B x N x T + state write-back.
-        wr = avg['WRITE_SIZE'] * 1024.0
-        rd = 2.0 * avg.get('FETCH_SIZE', 0.0) * 1024.0
-        summary['hbm'] = dict(write_bytes=wr, read_bytes_corrected=rd, hbm_bytes_per_launch=wr + rd,
-                              source='rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes), tag %s; '
-                                     'bytes = WRITE_SIZE*1024 + 2*FETCH_SIZE*1024' % tag)
-        json.dump(summary['hbm'], open(os.path.join(dest, 'rollout_pmc_latest.json'), 'w'), indent=1)
+    # ---- per bench mode: HBM traffic from the WRITE_SIZE / FETCH_SIZE passes, kernel duration from the kernel-trace pass
+    # MI355X_MICROARCH.md "HBM": WRITE_SIZE and FETCH_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a coalesced
+    # read stream, so it is doubled; WRITE_SIZE reads the bytes exactly.  Calibration in our own access pattern: the
+    # headline kernel's known write volume is 12 B x N x T + state write-back.
+    per_mode = defaultdict(lambda: defaultdict(list))
+    names = {}
+    for d in glob.glob(os.path.join(prof, 'pmc_write')) + glob.glob(os.path.join(prof, 'pmc_fetch')):
+        for r in rows(os.path.join(d, '**', '*counter_collection.csv')):
+            mode = mode_of(r['Kernel_Name'], r['Grid_Size'])
+            if mode and r['Counter_Name'] in ('WRITE_SIZE', 'FETCH_SIZE'):
+                per_mode[mode][r['Counter_Name']].append(float(r['Counter_Value']))
+                names[mode] = r['Kernel_Name']
+    durations = defaultdict(list)
+    for r in kt:
+        mode = mode_of(r['Kernel_Name'], r['Grid_Size_X'])
+        if mode:
+            durations[mode].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    modes = {}
+    for mode, counters in per_mode.items():
+        if 'WRITE_SIZE' not in counters:
+            continue
+        wr = sum(counters['WRITE_SIZE']) / len(counters['WRITE_SIZE']) * 1024.0
+        fetch = counters.get('FETCH_SIZE', [])
+        rd = 2.0 * (sum(fetch) / len(fetch) if fetch else 0.0) * 1024.0
+        entry = dict(write_bytes=wr, read_bytes_corrected=rd, hbm_bytes_per_launch=wr + rd, kernel=names[mode][:120],
+                     dispatches_counted=len(counters['WRITE_SIZE']))
+        if durations.get(mode):
+            entry['kernel_avg_us'] = sum(durations[mode]) / len(durations[mode]) / 1e3
+            entry['kernel_dispatches_timed'] = len(durations[mode])
+        modes[mode] = entry
+    if modes:
+        import datetime
+        source = ('rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes over bench.py, every launch form of the line), tag %s; '
+                  'bytes = WRITE_SIZE*1024 + 2*FETCH_SIZE*1024; kernel_avg_us from the --kernel-trace pass of the same tag' % tag)
+        table = dict(tag=tag, date=datetime.date.today().isoformat(), source=source, modes=modes)
+        if 'headline' in modes:  # (the flat form older readers of the file expect)
+            table.update({k: modes['headline'][k] for k in ('write_bytes', 'read_bytes_corrected', 'hbm_bytes_per_launch')})
+        for entry in modes.values():
+            entry['source'] = source
+        summary['hbm'] = table
+        json.dump(table, open(os.path.join(dest, 'rollout_pmc_latest.json'), 'w'), indent=1)
     for p in glob.glob(os.path.join(prof, 'kt', '**', '*kernel_stats.csv'), recursive=True):
         open(os.path.join(dest, '%s_rocprofv3_kernel_stats.csv' % tag), 'w').write(open(p).read())
     json.dump(summary, open(os.path.join(dest, '%s_rocprof_summary.json' % tag), 'w'), indent=1)

@@ -411,9 +411,13 @@ int gu_reset_done(gu_handle h)
 }
 
 // ---------------------------------------------------------------------------------- step
-// Page-locked ranges the step kernel may dereference directly (GU_F_PINNED_IO).  A pointer is looked up with the runtime
-// once; afterwards a call costs a few compares.  gu_host_free bumps the generation, which empties every engine's cache.
+// Page-locked ranges the step kernel may dereference directly (GU_F_PINNED_IO).  Only memory that gu_host_alloc handed out
+// is remembered (the library sees it freed, in gu_host_free, which bumps the generation and so empties every thread's
+// cache): a call on such a buffer costs a few compares.  Memory the caller pinned by other means (hipHostRegister, a
+// framework's pinned tensors) can be unpinned or freed behind the library's back, so it is asked about on EVERY call.
 static std::atomic<uint32_t> g_pinned_generation{1};
+static std::mutex g_host_alloc_mu;
+static std::vector<std::pair<uintptr_t, uintptr_t>> g_host_allocs;  // [lo, hi) of every live gu_host_alloc block
 
 struct PinnedRanges {
     uint32_t generation = 0;
@@ -433,6 +437,19 @@ static int gu_require_pinned(const void *p, size_t bytes, const char *what)
     const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
     for (int i = 0; i < g_pinned.n; ++i)
         if (lo >= g_pinned.lo[i] && hi <= g_pinned.hi[i]) return GU_OK;
+    {   // one of the library's own blocks?  then it stays valid until gu_host_free (which bumps the generation)
+        std::lock_guard<std::mutex> lock(g_host_alloc_mu);
+        for (const auto &r : g_host_allocs)
+            if (lo >= r.first && lo < r.second) {
+                if (hi > r.second)
+                    return gu_fail(GU_ERR_INVALID, "GU_F_PINNED_IO: %s (%p + %zu bytes) runs past the end of its page-locked allocation", what, p, bytes);
+                const int slot = g_pinned.n < 4 ? g_pinned.n++ : 0;
+                g_pinned.lo[slot] = r.first;
+                g_pinned.hi[slot] = r.second;
+                return GU_OK;
+            }
+    }
+    // foreign memory: asked about on every call, never cached
     hipPointerAttribute_t attr;
     memset(&attr, 0, sizeof attr);
     if (hipPointerGetAttributes(&attr, p) != hipSuccess || attr.type != hipMemoryTypeHost) {
@@ -451,9 +468,6 @@ static int gu_require_pinned(const void *p, size_t bytes, const char *what)
     } else {
         (void)hipGetLastError();
     }
-    const int slot = g_pinned.n < 4 ? g_pinned.n++ : 0;
-    g_pinned.lo[slot] = base;
-    g_pinned.hi[slot] = base + size;
     return GU_OK;
 }
 
@@ -1023,12 +1037,22 @@ int gu_host_alloc(size_t bytes, void **ptr)
     GU_REQUIRE(ptr != nullptr && bytes > 0, GU_ERR_INVALID, "ptr is NULL or bytes == 0");
     *ptr = nullptr;
     GU_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lock(g_host_alloc_mu);
+    g_host_allocs.emplace_back((uintptr_t)*ptr, (uintptr_t)*ptr + bytes);
     return GU_OK;
 }
 
 int gu_host_free(void *ptr)
 {
     g_pinned_generation.fetch_add(1, std::memory_order_acq_rel);  // validated GU_F_PINNED_IO ranges are looked up again
+    {
+        std::lock_guard<std::mutex> lock(g_host_alloc_mu);
+        for (size_t i = 0; i < g_host_allocs.size(); ++i)
+            if (g_host_allocs[i].first == (uintptr_t)ptr) {
+                g_host_allocs.erase(g_host_allocs.begin() + (long)i);
+                break;
+            }
+    }
     if (ptr) GU_HIP(hipHostFree(ptr));
     return GU_OK;
 }

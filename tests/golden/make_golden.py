@@ -467,6 +467,18 @@ def capture_mc_numpy_rng():
         print('mcnp', name, 'S', S, 'episodes', episodes, 'runs', len(meta['runs']))
 
 
+# ----------------------------------------------------------------------------- G12
+def capture_driver():
+    """tests/golden/driver_flow.py (a whole driver in the style of the reference's examples) on the REAL reference."""
+    import core.algorithms.monte_carlo as ref_mc
+    sys.path.insert(0, HERE)
+    from driver_flow import driver_flow
+    with quiet():
+        out = driver_flow(GridUniverseEnv, ref_utils, ref_dp, ref_mc)
+    np.savez_compressed(os.path.join(OUT, 'driver_alg_examples.npz'), **out)
+    print('driver', {k: v.shape for k, v in out.items()})
+
+
 # ----------------------------------------------------------------------------- G10
 def reference_path_search():
     """The reference's breadth-first path search lives inside the `if __name__ == '__main__':` demo loop of
@@ -782,7 +794,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     random.seed(0)
     np.random.seed(0)
-    what = {a.split('=')[0] for a in sys.argv[1:]} or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'mcnp', 'bfs', 'arrows'}  # plus 'big' (slow) on request
+    what = {a.split('=')[0] for a in sys.argv[1:]} or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'mcnp', 'driver', 'bfs', 'arrows'}  # plus 'big' (slow) on request
     if 'kat' in what:
         json.dump(capture_kats(), open(os.path.join(OUT, 'kat.json'), 'w'), indent=1)
     if 'err' in what:
@@ -799,6 +811,8 @@ def main():
         capture_mc()
     if 'mcnp' in what:
         capture_mc_numpy_rng()
+    if 'driver' in what:
+        capture_driver()
     if 'bfs' in what:
         json.dump(capture_bfs(), open(os.path.join(OUT, 'bfs.json'), 'w'), indent=1)
     if 'arrows' in what:

@@ -62,3 +62,33 @@ def test_reference_style_driver_through_the_import_shim(capsys):
         sys.path.pop(0)
         for k in [k for k in sys.modules if k == 'core' or k.startswith('core.')]:
             del sys.modules[k]
+
+
+def test_whole_driver_through_the_import_shim_equals_the_reference_run():
+    """tests/golden/driver_flow.py -- policy-evaluation sweeps, greedy improvement, policy iteration, value iteration, a greedy
+    run, run_episode and monte_carlo_evaluation on two seeded generator mazes, the flow of examples/griduniverse_alg_examples.py
+    -- was run on the REAL reference (make_golden.py: capture_driver).  The same function on the engine, through the reference's
+    own import paths (compat/): every array it produces is byte-identical -- mazes, float64 tables, trajectories, the Monte-Carlo
+    value function (the shim defaults to the reference's random draws), where the env is left, where both global streams are."""
+    sys.path.insert(0, os.path.join(ROOT, 'compat'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    np_state, py_state = np.random.get_state(), random.getstate()
+    try:
+        from driver_flow import driver_flow
+        GridUniverseEnv = importlib.import_module('core.envs.griduniverse_env').GridUniverseEnv
+        mc = importlib.import_module('core.algorithms.monte_carlo')
+        utils = importlib.import_module('core.algorithms.utils')
+        dp = importlib.import_module('core.algorithms.dynamic_programming')
+        got = driver_flow(GridUniverseEnv, utils, dp, mc)
+        want = np.load(os.path.join(ROOT, 'tests', 'golden', 'driver_alg_examples.npz'))
+        assert sorted(got) == sorted(want.files)
+        for k in want.files:
+            assert got[k].dtype == want[k].dtype and got[k].tobytes() == want[k].tobytes(), k
+        assert want['greedy_run'][-1] == 1 and want['episode_states'].size > 10  # (the run reached the goal; a real episode)
+    finally:
+        np.random.set_state(np_state)
+        random.setstate(py_state)
+        sys.path.pop(0)
+        sys.path.pop(0)
+        for k in [k for k in sys.modules if k == 'core' or k.startswith('core.') or k == 'driver_flow']:
+            del sys.modules[k]

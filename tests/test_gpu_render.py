@@ -14,21 +14,12 @@ WALL, LAVA, GOAL, FLOOR, AGENT = (64, 64, 64), (220, 60, 30), (40, 180, 60), (22
 
 
 def expected_frame(spec, pos, px):
-    W, H = spec.W, spec.H
-    img = np.zeros((H * px, W * px, 3), np.uint8)
-    for s in range(W * H):
-        colour = WALL if spec.wall[s] else LAVA if spec.reward[s] == -10 else GOAL if (spec.reward[s] == 10 or spec.goal[s] or spec.lava[s]) else FLOOR
-        y, x = divmod(s, W)
-        tile = np.empty((px, px, 3), np.uint8)
-        tile[:] = colour
-        if px >= 4:
-            tile[0, :] = np.array(colour) * 3 // 4
-            tile[:, 0] = np.array(colour) * 3 // 4
-        if s == pos:
-            lo, hi = px // 4, px - px // 4
-            tile[lo:hi, lo:hi] = AGENT
-        img[y * px:(y + 1) * px, x * px:(x + 1) * px] = tile
-    return img
+    """Tiles by the viewer's texture rule (goal, else lava, else wall, else ground: oracle/render.py, pinned to arrows.json) in the
+    build's palette, grid line, agent square."""
+    from oracle import render as R
+    S = spec.W * spec.H
+    kinds = R.tile_kinds(S, np.flatnonzero(spec.goal).tolist(), np.flatnonzero(spec.lava).tolist(), np.flatnonzero(spec.wall).tolist())
+    return R.tile_frame(spec.W, spec.H, kinds, px, agent=pos)
 
 
 @pytest.mark.parametrize('px', [1, 4, 9, 16])

@@ -82,6 +82,7 @@ def main():
         mode = mode_of(r['Kernel_Name'], r['Grid_Size_X'])
         if mode:
             durations[mode].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+            names.setdefault(mode, r['Kernel_Name'])
     modes = {}
     for mode, counters in per_mode.items():
         if 'WRITE_SIZE' not in counters:
@@ -110,6 +111,14 @@ def main():
         open(os.path.join(dest, '%s_rocprofv3_kernel_stats.csv' % tag), 'w').write(open(p).read())
     json.dump(summary, open(os.path.join(dest, '%s_rocprof_summary.json' % tag), 'w'), indent=1)
     with open(os.path.join(dest, '%s_kernel_stats.txt' % tag), 'w') as f:
+        # the rollout kernel serves two launch sizes of the line (65 536 envs: the headline; 262 144: strong_c4): split first
+        f.write('%-90s %6s %12s %12s %12s %12s\n' % ('bench launch form (kernel x launch size)', 'calls', 'avg_us', 'min_us', 'median_us', 'max_us'))
+        for mode in MODES:
+            v = sorted(durations.get(mode, []))
+            if v:
+                f.write('%-90s %6d %12.2f %12.2f %12.2f %12.2f\n' % ('%s: %s' % (mode, names.get(mode, ''))[:90], len(v), sum(v) / len(v) / 1e3,
+                                                                   v[0] / 1e3, v[len(v) // 2] / 1e3, v[-1] / 1e3))
+        f.write('\n')
         f.write('%-90s %6s %12s %12s %12s %12s\n' % ('kernel', 'calls', 'avg_us', 'min_us', 'median_us', 'max_us'))
         for k, s in sorted(stats.items(), key=lambda kv: -kv[1]['total_ns']):
             f.write('%-90s %6d %12.2f %12.2f %12.2f %12.2f\n' % (k[:90], s['calls'], s['avg_ns'] / 1e3, s['min_ns'] / 1e3,

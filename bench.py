@@ -40,9 +40,11 @@ import importlib
 import json
 import os
 import random
+import shutil
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -426,6 +428,71 @@ def read_traffic(mode, launch_ms=None):
             out['note'] = 'kernel duration differs from the profiled run by %+.1f %% (profile %.1f us, this run %.1f us): the traffic ' \
                           'figure is per launch and does not depend on it, the achieved rate does' % ((ratio - 1.0) * 100, prof_us, launch_ms * 1e3)
     return out
+
+
+def under_a_profiler():
+    """True when this process already runs under rocprofv3 (tools/gpu_profile.sh): no nested counter passes then."""
+    return 'rocprof' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+
+
+def live_traffic(args, N, T, budget_s=150):
+    """HBM bytes per launch of the headline kernel MEASURED FOR THIS RUN: two short child runs of this very script under
+    `rocprofv3 --pmc` -- WRITE_SIZE and FETCH_SIZE in separate passes, counters only (no trace domain), as
+    MI355X_MICROARCH.md's HBM section prescribes -- on the same device, right after the timed region.  Each child launches the
+    bench kernel a few times on the bench workload (`--pmc-child`); the counter rows of `gu_rollout_kernel<...>` dispatches of
+    this launch size are averaged (the first launch, with cold caches, excluded).  bytes = WRITE_SIZE * 1024 + 2 * FETCH_SIZE *
+    1024 (both counters are in KiB; on gfx950 FETCH_SIZE reports half of a coalesced read stream).  None when rocprofv3 is not
+    there, takes too long or reports nothing -- the committed profile's figure is used then, and labelled so."""
+    import csv
+    tool = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if tool is None or under_a_profiler():
+        return None
+    work = tempfile.mkdtemp(prefix='gu_pmc_', dir='/tmp')
+    t0 = time.time()
+    sums = {}
+    try:
+        for counter in ('WRITE_SIZE', 'FETCH_SIZE'):
+            out = os.path.join(work, counter)
+            cmd = [tool, '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__),
+                   '--pmc-child', '--envs', str(N), '--T', str(T), '--workload', args.workload]
+            left = budget_s - (time.time() - t0)
+            if left < 20:
+                return None
+            proc = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                  timeout=left)
+            values = []
+            for path in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
+                with open(path, newline='') as f:
+                    for row in csv.DictReader(f):
+                        if 'gu_rollout_kernel<' in row['Kernel_Name'] and int(row['Grid_Size']) == N and row['Counter_Name'] == counter:
+                            values.append((int(row['Dispatch_Id']), float(row['Counter_Value'])))
+            values = [v for _, v in sorted(values)][1:]  # (the first launch writes into cold caches)
+            if proc.returncode != 0 or not values:
+                return None
+            sums[counter] = (sum(values) / len(values), len(values))
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    wr, rd = sums['WRITE_SIZE'][0] * 1024.0, 2.0 * sums['FETCH_SIZE'][0] * 1024.0
+    return dict(hbm_bytes_per_launch=wr + rd, write_bytes=wr, read_bytes_corrected=rd, dispatches_counted=sums['WRITE_SIZE'][1],
+                seconds=time.time() - t0,
+                source='rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE: two child runs of this script (bench.py --pmc-child: the bench kernel on the '
+                       'bench workload, %d launches counted each) on this device right after the timed region; bytes = WRITE_SIZE*1024 + '
+                       '2*FETCH_SIZE*1024' % sums['WRITE_SIZE'][1])
+
+
+def pmc_child(args):
+    """`bench.py --pmc-child` (started by live_traffic under rocprofv3 --pmc): the bench kernel, nine launches, nothing else."""
+    template, _ = build_workload(args.workload)
+    eng = gua.Engine(args.envs, gua.GridSpec.from_env(template), device=0, env_id0=0, seed=WORKLOAD_SEED[args.workload])
+    eng.set_option('traj_candidates', 1)  # (no placement search under the profiler: every probe launch would be counted too)
+    eng.reset()
+    eng.reserve_trajectory(args.T)
+    for _ in range(9):
+        eng.rollout(args.T, 'uniform', auto_reset=True, trajectory=True)
+    eng.sync()
+    eng.close()
 
 
 def device_block(engine_cls, device):
@@ -896,6 +963,9 @@ def run(args, engine_cls=None, emit=print):
         launch_s = k_med / 1e3 / K
         achieved = BYTES_PER_ENV_STEP * N * T / launch_s / 1e9
         traffic = read_traffic('headline', launch_s * 1e3)
+        measured = None
+        if world == 1 and engine_cls is gua.Engine and not args.no_live_traffic:
+            measured = live_traffic(args, N, T)
         if c4 and 'launch_ms' in c4:
             c4['traffic'] = read_traffic('strong_c4', c4['launch_ms'])
         for mode in (others or {}):
@@ -922,11 +992,14 @@ def run(args, engine_cls=None, emit=print):
                        'launches_total': launches},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS,
-                         'traffic': None if traffic is None else traffic.get('hbm_bytes_per_launch'),
-                         'traffic_measured_in_this_run': False,
+                         'traffic': measured['hbm_bytes_per_launch'] if measured else None if traffic is None else traffic.get('hbm_bytes_per_launch'),
+                         'traffic_measured_in_this_run': bool(measured),
+                         'traffic_over_algorithmic': (measured['hbm_bytes_per_launch'] if measured else (traffic or {}).get('hbm_bytes_per_launch', 0.0))
+                         / float(BYTES_PER_ENV_STEP * N * T) or None,
                          'kernel': 'gu_rollout_kernel<UNIFORM,TRAJ,LDS>', 'launch_ms': launch_s * 1e3,
                          'algorithmic_bytes_per_launch': BYTES_PER_ENV_STEP * N * T,
-                         'traffic_source': None if traffic is None else traffic.get('source'),
+                         'traffic_source': measured['source'] if measured else None if traffic is None else traffic.get('source'),
+                         'traffic_live': measured,
                          'traffic_profile': None if traffic is None else {k: traffic.get(k) for k in
                                                                           ('tag', 'date', 'kernel', 'kernel_avg_us', 'this_run_over_profile_duration', 'note')},
                          'vs_measured_copy_rate': achieved / HBM_COPY_GBPS,
@@ -966,6 +1039,9 @@ def parse_args(argv=None):
     ap.add_argument('--gather-view', action='store_true', help='exercise the RCCL gathered view with one rank too')
     ap.add_argument('--single-process', action='store_true',
                     help='ONE process driving --gpus devices (one engine per device, gu_comm_init_all for the view) instead of one rank per GPU')
+    ap.add_argument('--no-live-traffic', action='store_true',
+                    help='do not measure roofline.traffic with two short rocprofv3 --pmc child runs (1 GPU only); use the committed profile')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--engine', default=None, help='module:Class of the engine to run (tests only; default griduniverse_amd.Engine)')
     return ap.parse_args(argv)
 
@@ -973,6 +1049,9 @@ def parse_args(argv=None):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
+    if args.pmc_child:
+        pmc_child(args)
+        return 0
     if args.single_process:
         run_single_process(args)
         return 0

@@ -33,7 +33,10 @@ def test_default_workload_line_carries_the_contract_and_its_own_checks():
     assert line['config']['workload'].startswith('c3: 65536 envs per GPU') and line['config']['envs_per_gpu'] == 65536
     assert abs(line['value'] - 65536 * 1000 / (line['ms_per_step'] / 1e3)) < 1e-6 * line['value']
     roof = line['roofline']
-    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0 and roof['traffic_measured_in_this_run'] is False
+    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
+    # HBM traffic measured for THIS run: two short rocprofv3 --pmc child runs of the script (WRITE_SIZE, FETCH_SIZE) after the timed region
+    assert roof['traffic_measured_in_this_run'] is True and roof['traffic_live']['dispatches_counted'] >= 4
+    assert 0.98 < roof['traffic'] / roof['algorithmic_bytes_per_launch'] < 1.03 and abs(roof['traffic_over_algorithmic'] - roof['traffic'] / roof['algorithmic_bytes_per_launch']) < 1e-12
     assert roof['algorithmic_bytes_per_launch'] == 12 * 65536 * 1000
     assert abs(roof['achieved'] - roof['algorithmic_bytes_per_launch'] / (roof['launch_ms'] / 1e3) / 1e9) < 1e-6 * roof['achieved']
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-12 and 0.3 < roof['frac'] < 1.0
@@ -54,9 +57,10 @@ def test_default_workload_line_carries_the_contract_and_its_own_checks():
 def test_other_workloads_and_switches():
     """Config 2 (4096 envs, 8x8) with the checks, and a run with everything optional switched off."""
     line = run_bench('--workload', 'c2', '--envs', '4096', '--steps', '3', '--warmup', '1', '--min-seconds', '0.02', '--no-strong-c4',
-                     '--no-cpu-baseline')
+                     '--no-cpu-baseline', '--no-live-traffic')
+    assert line['roofline']['traffic_measured_in_this_run'] is False  # (the committed profile's figure, labelled as such)
     assert line['config']['envs_per_gpu'] == 4096 and line['bit_exact_vs_reference_digest'] is True  # 4096 x 1000 is a captured run
     assert line['final_state_vs_oracle']['equal'] is True and 'cpu_baseline' not in line and line['strong_c4'] is None
     line = run_bench('--steps', '2', '--warmup', '1', '--min-seconds', '0.02', '--no-strong-c4', '--no-cpu-baseline', '--no-checks',
-                     '--no-other-modes', '--envs', '1000', '--T', '77')
+                     '--no-other-modes', '--envs', '1000', '--T', '77', '--no-live-traffic')
     assert line['other_modes'] is None and 'bit_exact_vs_reference_digest' not in line and line['value'] > 0

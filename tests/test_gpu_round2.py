@@ -439,7 +439,7 @@ def test_table_policies_on_the_row_table_equal_the_oracle(gu_option, rows, name)
 def test_rccl_is_taken_from_the_rocm_stack_libgu_runs_on(order):
     """A process may hold two ROCm stacks (the system one and the copy a PyTorch wheel bundles).  Whichever order they are
     loaded in, the gathered view must come up: gu_comm.hip takes the librccl next to the libamdhip64 that serves its own HIP
-    calls.  (bench.py's N > 1 flow imports torch for its gloo plumbing.)"""
+    calls.  (A caller that imports torch brings that second stack; bench.py itself no longer does.)"""
     import subprocess
     import sys
     code = '''

@@ -146,7 +146,7 @@ def _bench(*args):
     return json.loads(lines[0])
 
 
-SMALL = ['--envs', '16384', '--T', '200', '--steps', '3', '--warmup', '1', '--min-seconds', '0.05', '--c4-envs', '16384', '--no-cpu-baseline']
+SMALL = ['--envs', '16384', '--T', '200', '--steps', '3', '--warmup', '1', '--min-seconds', '0.05', '--c4-envs', '16384', '--no-cpu-baseline', '--no-live-traffic']
 
 
 def test_bench_started_plainly_with_two_ranks_on_the_one_gpu():

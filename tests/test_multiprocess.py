@@ -47,7 +47,7 @@ def test_two_rank_shards_and_gathered_view_under_torch_distributed_run(tmp_path)
     assert [r['ids'] for r in results] == [[0, 2047], [2048, 4095]]
     for r in results:
         assert r['world'] == 2 and r['ok_shard'] and r['ok_view'] and r['ok_max'], r
-    # the JSON line of bench.py's N = 2 flow (same script, oracle-backed stub engine, gloo instead of RCCL)
+    # the JSON line of bench.py's N = 2 flow (same script, oracle-backed stub engine, the host channel instead of RCCL)
     line = json.load(open(os.path.join(str(tmp_path), 'bench_line.json')))
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['engine'] == 'tests._oracle_engine.OracleEngine'
     assert line['config']['global_envs'] == 1024 and line['steps'] == 2 and line['timing']['blocks'] >= 3
@@ -160,7 +160,7 @@ def test_bench_finds_the_reference_digest_of_its_default_run():
 
 def test_native_chatter_inside_the_collective_check_never_reaches_stdout():
     """bench.py prints ONE JSON line on stdout.  RCCL writes a banner to the C-level stdout when a communicator comes up (and C
-    stdio flushes it after the line when stdout is a pipe), gloo announces its connections there too: whatever native code prints
+    stdio flushes it after the line when stdout is a pipe), and so may any other native library: whatever native code prints
     inside bench.native_stdout_to_stderr() must land on stderr, in order, and stdout must be usable again afterwards."""
     code = '''
 import ctypes, sys

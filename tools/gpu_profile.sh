@@ -7,11 +7,11 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # kernel trace: the driver's own bench command (minus the CPU legs, which launch nothing); counters: a short timed region
-KT="python3 $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
-BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-checks --no-strong-c4 --no-other-modes --min-seconds 0.02"
+KT="python3 $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic"
+BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-checks --no-strong-c4 --no-other-modes --min-seconds 0.02 --no-live-traffic"
 # HBM traffic for EVERY launch form the line reports (headline, strong_c4, packed rows, statistics only): summarize_profile.py
 # tells them apart by kernel name and launch size
-TRAFFIC="python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-checks --min-seconds 0.02"
+TRAFFIC="python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-checks --min-seconds 0.02 --no-live-traffic"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $KT > $OUT/kt.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $TRAFFIC > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $TRAFFIC > $OUT/pmc_fetch.log 2>&1

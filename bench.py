@@ -541,6 +541,21 @@ def device_block(engine_cls, device):
     return info
 
 
+def pacing_block(eng):
+    """roofline.store_pacing: what the rollout kernel's rate limiter was calibrated to for the bench launch (idle turns of ~33 clocks
+    every 4 steps), and the launch time the calibration itself measured without and with it."""
+    if not hasattr(eng, 'rollout_pacing'):
+        return None
+    info = eng.rollout_pacing('uniform', True)
+    if info is None:
+        return {'calibrated': False}
+    info['calibrated'] = True
+    info['is'] = 'the HBM write path collapses when it is over-driven (5.7 TB/s on most allocations): waves that have put down their ' \
+                 'rows idle `turns` x ~33 clocks every 4 steps, an amount found by timing the kernel itself on this engine and buffer ' \
+                 '(state snapshot and put back); ms_unpaced / ms_paced are the calibration\'s own per-launch times (DESIGN.md section 6)'
+    return info
+
+
 def placement_block(eng, post_probe_ms, launch_ms):
     """roofline.trajectory_placement: what gu_reserve_trajectory's candidate search did for the bench buffer, per candidate, what
     it cost, and the SAME store probe run once more on the kept buffer right after the timed region (so that "the probe said
@@ -785,6 +800,7 @@ def run_single_process(args, engine_cls=None, emit=print):
             except gua.GuError as err:  # reported, not fatal (a box with fewer devices than ranks: RCCL wants one device per rank)
                 rccl = dict(nranks=G, view_equals_shards=None, error=str(err))
         placement = [placement_block(e, post_probe[g], float(np.median([k[g] for k in kern])) / K) for g, e in enumerate(engines)]
+        pacing = [pacing_block(e) for e in engines]
     finally:
         for e in engines:
             e.close()
@@ -860,7 +876,7 @@ def run_single_process(args, engine_cls=None, emit=print):
                      'algorithmic_bytes_per_launch': BYTES_PER_ENV_STEP * N * T,
                      'traffic_source': None if traffic is None else traffic.get('source'),
                      'vs_measured_copy_rate': achieved / HBM_COPY_GBPS, 'is': 'per device (the slowest one)',
-                     'trajectory_placement': placement},
+                     'store_pacing': pacing, 'trajectory_placement': placement},
         'device': dev_info,
         'engine': engine_cls.__module__ + '.' + engine_cls.__name__,
         'per_rank': {'ms_per_step': per_dev_ms, 'value': [float(N) * T / (ms / 1e3) for ms in per_dev_ms],
@@ -954,6 +970,7 @@ def run(args, engine_cls=None, emit=print):
             rccl = dict(nranks=world, view_equals_shards=None, error=str(err))
     per_rank = ranks.gather([float(np.median(own_wall))])
     placement = placement_block(eng, post_probe_ms, float(np.median(kern)) / K)
+    pacing = pacing_block(eng)
     eng.close()
     c4 = None if args.no_strong_c4 else strong_c4(args, ranks, engine_cls, device)
 
@@ -1003,6 +1020,7 @@ def run(args, engine_cls=None, emit=print):
                          'traffic_profile': None if traffic is None else {k: traffic.get(k) for k in
                                                                           ('tag', 'date', 'kernel', 'kernel_avg_us', 'this_run_over_profile_duration', 'note')},
                          'vs_measured_copy_rate': achieved / HBM_COPY_GBPS,
+                         'store_pacing': pacing,
                          'trajectory_placement': placement},
             'device': dev_info,
             'engine': engine_cls.__module__ + '.' + engine_cls.__name__,

@@ -171,6 +171,8 @@ int gu_destroy(gu_handle h)
     if (h->h_seq) (void)hipHostFree(h->h_seq);
     if (h->d_blocks_done) (void)hipFree(h->d_blocks_done);
     for (hipEvent_t ev : h->ev_marks) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : h->ev_cal)
+        if (ev) (void)hipEventDestroy(ev);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -242,6 +244,7 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
     if (h->d_prow) GU_HIP(hipFree(h->d_prow));
     h->d_prow = nullptr;
     h->has_grid = false;
+    for (auto &p : h->pace) p.known = false;  // (another grid: another chain length)
     gu_vi_free(h);
     const size_t plane_bytes = 2 * (size_t)cell_bytes * n_grids;
     GU_HIP(hipMalloc(&h->d_cell, plane_bytes));
@@ -904,6 +907,22 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
         if (flags & (GU_F_TRAJECTORY | GU_F_PACKED)) h->traj_kind = (flags & GU_F_PACKED) ? 2 : 1;
     }
     return rc;
+}
+
+int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *turns, float *ms_unpaced, float *ms_paced,
+                      int32_t *evaluated, float *calibration_ms)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(policy_kind >= GU_POLICY_UNIFORM && policy_kind <= GU_POLICY_SAMPLE, GU_ERR_INVALID, "unknown policy kind %d", policy_kind);
+    const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->all_single_start ? 1 : 2) : 0;
+    const gu_engine::PaceRecord &rec = h->pace[policy_kind * 3 + auto_mode];
+    GU_REQUIRE(rec.known && rec.buffer == (const void *)h->d_traj, GU_ERR_STATE, "no pacing calibration for this launch kind on the current trajectory buffer");
+    if (turns) *turns = (int32_t)rec.turns;
+    if (ms_unpaced) *ms_unpaced = rec.ms_unpaced;
+    if (ms_paced) *ms_paced = rec.ms_paced;
+    if (evaluated) *evaluated = rec.evaluated;
+    if (calibration_ms) *calibration_ms = rec.calibration_ms;
+    return GU_OK;
 }
 
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done)

@@ -98,6 +98,18 @@ struct gu_engine {
     uint64_t traj_peak_bytes = 0;               // most device memory the search held at once
     bool traj_registered = false;               // counted in the per-device registry of chosen buffers
 
+    // store pacing of the general rollout kernel's int32-row launches (gu_rollout.hpp: gu_idle), calibrated per launch kind
+    // [policy * 3 + auto mode] on the trajectory buffer in use
+    struct PaceRecord {
+        bool known = false;
+        const void *buffer = nullptr;  // the trajectory buffer the calibration ran on
+        int64_t T = 0;                 // ... and the launch length
+        uint32_t turns = 0;            // idle turns every GU_PACE_EVERY steps (0: none)
+        float ms_unpaced = 0.0f, ms_paced = 0.0f, calibration_ms = 0.0f;
+        int32_t evaluated = 0;         // candidates timed
+    } pace[12];
+    hipEvent_t ev_cal[2] = {nullptr, nullptr};
+
     // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in
     uint32_t *d_rows[2] = {nullptr, nullptr};
     int rows_shift[2] = {-1, -1};   // log2(16 * copies) the table was built for (-1: not built)
@@ -216,6 +228,10 @@ int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const 
                         int32_t *d_next, int32_t *d_reward, int32_t *d_done);
 int gu_launch_done_compact(gu_engine *h);
 int gu_probe_trajectory_buffer(gu_engine *h, int32_t *buf, int64_t T, float *ms);  // one timed full write, rollout store shape
+// Device-to-device copy by a kernel on the engine's stream (bytes a multiple of 4): the snapshots that the pace calibration and the
+// DP cluster launches take of the engine's state, and put back, stay on the kernel path (ordered with the launches around them,
+// no copy-engine round trip for a few hundred KB).
+int gu_device_copy(gu_engine *h, void *dst, const void *src, size_t bytes);
 
 // ---- tabular DP launchers (gu_vi.hip) --------------------------------------------
 int gu_vi_alloc(gu_engine *h);

@@ -22,7 +22,11 @@
 // every step for no gain.
 #include "gu_rollout.hpp"
 
+#include <chrono>
+#include <cstdio>
+
 #include <algorithm>
+#include <vector>
 
 // ------------------------------------------------------------------------------------
 // reset: GridUniverseEnv._reset (env:187-193) for the masked / done envs
@@ -326,6 +330,172 @@ int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, i
     return GU_OK;
 }
 
+__global__ void __launch_bounds__(256) gu_copy_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t words)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int gu_device_copy(gu_engine *h, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return GU_OK;
+    GU_REQUIRE(bytes % 4 == 0 && ((uintptr_t)dst | (uintptr_t)src) % 4 == 0, GU_ERR_INVALID, "gu_device_copy: %zu bytes / unaligned", bytes);
+    const size_t words = bytes / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, (size_t)h->n_cu * 8);
+    hipLaunchKernelGGL(gu_copy_kernel, dim3(blocks), dim3(256), 0, h->stream, (uint32_t *)dst, (const uint32_t *)src, words);
+    GU_HIP(hipGetLastError());
+    return GU_OK;
+}
+
+static void gu_rollout_general(gu_engine *h, const RolloutArgs &a, int32_t policy, int auto_mode, int traj, bool stats, int bs)
+{
+    switch (policy) {
+    case GU_POLICY_UNIFORM: gu_rollout_uniform(h, a, auto_mode, traj, stats, bs); break;
+    case GU_POLICY_STREAM: gu_rollout_stream(h, a, auto_mode, traj, stats, bs); break;
+    case GU_POLICY_GREEDY: gu_rollout_greedy(h, a, auto_mode, traj, stats, bs); break;
+    default: gu_rollout_sample(h, a, auto_mode, traj, stats, bs); break;
+    }
+}
+
+// How many idle turns (gu_idle, every GU_PACE_EVERY steps) make THIS launch kind fastest on THIS trajectory buffer: the kernel
+// itself is timed -- full-length launches on the engine's own state, which is snapshot first and put back afterwards (positions,
+// rewards, done flags and their ballots, episode counters; the step counter lives on the host and is not advanced), so a
+// calibrated engine continues exactly where an uncalibrated one would.  time(turns) is a plateau (collapsed), a cliff, then a
+// ramp (bound by the idling itself): a geometric ladder finds the region, a finer one between the best point's neighbours the
+// optimum, and the choice is then moved a little to the right -- the cliff is on the left.  ~25 candidates x 3 launches, once per
+// (policy, auto-reset mode, buffer).
+static int gu_calibrate_pace(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, bool stats, int bs, gu_engine::PaceRecord *rec)
+{
+    const auto t_start = std::chrono::steady_clock::now();
+    const size_t n4 = (size_t)h->N * 4, bits = (((size_t)h->N + 63) / 64) * 8;
+    int rc = gu_ensure_scratch(h, 4 * n4 + bits);
+    if (rc != GU_OK) return rc;
+    char *snap = (char *)h->d_scratch;
+    void *live[3] = {h->d_out3, h->d_episode, h->d_done_bits};
+    const size_t size[3] = {3 * n4, n4, bits};
+    size_t off = 0;
+    for (int k = 0; k < 3; off += size[k], ++k)
+        if ((rc = gu_device_copy(h, snap + off, live[k], size[k])) != GU_OK) return rc;
+    for (hipEvent_t &ev : h->ev_cal)
+        if (!ev) GU_HIP(hipEventCreate(&ev));
+    static const int MAX_TURNS = 1024;
+    std::vector<float> times(MAX_TURNS + 2, 0.0f);
+    int evaluated = 0;
+    // The device must be at its working clocks first: a calibration right after start-up, on a GPU still ramping up from idle,
+    // sees a slower transition chain, chooses too little idle time -- and the launch collapses once the clocks are up (the first
+    // engine of a process: 6 turns chosen, 140 us per launch instead of 120).  Unpaced launches until two successive pairs agree
+    // within 1 % (at most ~60 launches).
+    a.pace = 0;
+    {
+        float prev = 0.0f;
+        int agree = 0;
+        for (int w = 0; w < 30 && agree < 2; ++w) {
+            GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
+            gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);
+            gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);
+            GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
+            GU_HIP(hipEventSynchronize(h->ev_cal[1]));
+            float ms = 0.0f;
+            GU_HIP(hipEventElapsedTime(&ms, h->ev_cal[0], h->ev_cal[1]));
+            agree = (prev > 0.0f && ms < 1.01f * prev && prev < 1.01f * ms) ? agree + 1 : 0;
+            prev = ms;
+        }
+    }
+    auto time_of = [&](int turns, float *ms) -> int {
+        if (times[turns] > 0.0f) {
+            *ms = times[turns];
+            return GU_OK;
+        }
+        a.pace = gu_pace_word(turns);
+        gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);  // (also settles the caches into their steady state)
+        GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
+        gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);
+        gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);
+        GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
+        GU_HIP(hipEventSynchronize(h->ev_cal[1]));
+        GU_HIP(hipGetLastError());
+        GU_HIP(hipEventElapsedTime(ms, h->ev_cal[0], h->ev_cal[1]));
+        *ms *= 0.5f;
+        times[turns] = *ms;
+        ++evaluated;
+        return GU_OK;
+    };
+    // coarse: 0 and a geometric ladder (ratio ~1.25: the good window is about a tenth of its own position wide, wherever it lies --
+    // ~10 turns with one wave per SIMD, ~100 with four)
+    std::vector<int> grid = {0};
+    for (double g = 4.0; g < MAX_TURNS + 0.5; g *= 1.25)
+        if ((int)g > grid.back()) grid.push_back((int)g);
+    int best_g = 0;
+    float best = 0.0f, t = 0.0f;
+    for (size_t g = 0; g < grid.size(); ++g) {
+        if ((rc = time_of(grid[g], &t)) != GU_OK) return rc;
+        if (g == 0 || t < best) best = t, best_g = (int)g;
+        if ((int)g >= best_g + 2 && t > 1.5f * best) break;  // well up the ramp: larger values only idle longer
+    }
+    // fine: between the best grid point's neighbours, every value (narrow gaps) or a ladder of ratio ~1.06
+    const int lo = best_g > 0 ? grid[(size_t)best_g - 1] + 1 : 0;
+    const int hi = (size_t)best_g + 1 < grid.size() ? grid[(size_t)best_g + 1] - 1 : grid[(size_t)best_g];
+    int best_turns = grid[(size_t)best_g];
+    for (double f = lo; f <= hi + 0.5; f = (hi - lo <= 12) ? f + 1.0 : std::max(f + 1.0, f * 1.06)) {
+        const int turns = (int)f;
+        if ((rc = time_of(turns, &t)) != GU_OK) return rc;
+        if (t < best) best = t, best_turns = turns;
+    }
+    // Away from the cliff: a calibration launch right at the edge can still be fast while the steady state is not (the collapse
+    // has hysteresis).  `cliff` = the largest timed value below the best that is clearly collapsed; keep at least ~5 % (and one
+    // turn) of distance from it, if that costs less than 4 %.
+    if (best_turns > 0) {
+        int cliff = -1;
+        for (int k = best_turns - 1; k >= 0; --k)
+            if (times[k] > 1.06f * best) {
+                cliff = k;
+                break;
+            }
+        const int safe = cliff < 0 ? best_turns : std::max(best_turns, (int)(cliff * 1.05) + 2);
+        if (safe != best_turns && safe <= MAX_TURNS) {
+            if ((rc = time_of(safe, &t)) != GU_OK) return rc;
+            if (t <= 1.04f * best) best_turns = safe, best = t;
+        }
+    }
+    if (times[0] <= 1.01f * best) best_turns = 0, best = times[0];  // no gain worth the name: no pacing
+    off = 0;
+    for (int k = 0; k < 3; off += size[k], ++k)
+        if ((rc = gu_device_copy(h, live[k], snap + off, size[k])) != GU_OK) return rc;
+    GU_HIP(hipStreamSynchronize(h->stream));
+    rec->known = true;
+    rec->buffer = h->d_traj;
+    rec->T = a.T;
+    rec->turns = (uint32_t)best_turns;
+    rec->ms_unpaced = times[0];
+    rec->ms_paced = best;
+    rec->evaluated = evaluated;
+    rec->calibration_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    if (gu_debug())
+        fprintf(stderr, "[gu] store pacing (policy %d, auto %d, %lld x %lld): %d idle turns per %d steps, %.4f -> %.4f ms per launch, %d candidates in %.1f ms\n",
+                policy, auto_mode, (long long)h->N, (long long)a.T, best_turns, GU_PACE_EVERY, times[0], best, evaluated, rec->calibration_ms);
+    return GU_OK;
+}
+
+// The pace of this launch: option GU_OPT_ROLLOUT_PACE when set (0 = none), else the calibrated value for this launch kind on
+// this buffer -- calibrated now if it is not known yet.  Launches that cannot be bound by the HBM write path (less than 128 MB of
+// rows, or fewer workgroups than half the CUs) are not paced and not calibrated.
+static int gu_pace_for(gu_engine *h, const RolloutArgs &a, int32_t policy, int auto_mode, bool stats, int bs, uint32_t *pace)
+{
+    *pace = 0;
+    const int64_t opt = gu_opt(h, GU_OPT_ROLLOUT_PACE);
+    if (opt >= 0) {
+        *pace = gu_pace_word(opt);
+        return GU_OK;
+    }
+    if ((double)h->N * (double)a.T * 12.0 < 128e6 || (int64_t)gu_blocks(h->N, bs) * 2 < h->n_cu) return GU_OK;
+    gu_engine::PaceRecord &rec = h->pace[policy * 3 + auto_mode];
+    if (!rec.known || rec.buffer != (const void *)h->d_traj || a.T > 2 * rec.T || 2 * a.T < rec.T) {
+        int rc = gu_calibrate_pace(h, a, policy, auto_mode, stats, bs, &rec);
+        if (rc != GU_OK) return rc;
+    }
+    *pace = gu_pace_word(rec.turns);
+    return GU_OK;
+}
+
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
 {
     const int traj = (flags & GU_F_PACKED) ? 2 : ((flags & GU_F_TRAJECTORY) ? 1 : 0);
@@ -366,6 +536,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.stream_lds_off = 0;
     a.stream_lds_words = 0;
     const int bs = gu_rollout_block(h);
+    a.pace = 0;
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)
     if (policy == GU_POLICY_SAMPLE)
         hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
@@ -374,13 +545,12 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
         h->steps_taken += (uint32_t)T;
         return GU_OK;
     }
-    switch (policy) {
-    case GU_POLICY_UNIFORM: gu_rollout_uniform(h, a, auto_mode, traj, stats, bs); break;
-    case GU_POLICY_STREAM: gu_rollout_stream(h, a, auto_mode, traj, stats, bs); break;
-    case GU_POLICY_GREEDY: gu_rollout_greedy(h, a, auto_mode, traj, stats, bs); break;
-    case GU_POLICY_SAMPLE: gu_rollout_sample(h, a, auto_mode, traj, stats, bs); break;
-    default: return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
+    if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
+    if (traj == 1) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: gu_idle)
+        int rc = gu_pace_for(h, a, policy, auto_mode, stats, bs, &a.pace);
+        if (rc != GU_OK) return rc;
     }
+    gu_rollout_general(h, a, policy, auto_mode, traj, stats, bs);
     GU_HIP(hipGetLastError());
     h->steps_taken += (uint32_t)T;
     return GU_OK;

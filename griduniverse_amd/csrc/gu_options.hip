@@ -32,11 +32,12 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_MC_LANE_RETURNS", 0, 0, 1},
     {"GU_MC_GLOBAL_WALK", 0, 0, 1},
     {"GU_STEP_SYNC", 0, 0, 1},
-    {"GU_TRAJ_CANDIDATES", 12, 1, 64},
-    {"GU_TRAJ_FAR_CANDIDATES", 32, 0, 256},
+    {"GU_TRAJ_CANDIDATES", 4, 1, 64},
+    {"GU_TRAJ_FAR_CANDIDATES", 0, 0, 256},
     {"GU_TRAJ_STRIDE_MIB", 3072, 0, 1 << 20},
     {"GU_TRAJ_FAR_MIB", 49152, 0, 1 << 22},
     {"GU_TRAJ_PROBE_ALL", 0, 0, 1},
+    {"GU_ROLLOUT_PACE", -1, -1, 0xFFFF},
 };
 const char *g_spec_x[GU_OPT_X_COUNT] = {"GU_TRAJ_UNCACHED", "GU_TRAJ_POISON", "GU_MC_POISON"};
 

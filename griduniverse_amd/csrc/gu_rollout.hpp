@@ -42,7 +42,60 @@ struct RolloutArgs {
     int32_t stream_lds_off; // GU_POLICY_STREAM, MAP 1: byte offset in LDS of the staged action words [stream_lds_words][blockDim.x] ...
     int32_t stream_lds_words;  // ... and how many words per lane fit (0: every word is read from HBM when its steps are due)
     int32_t xcd_remap;      // workgroup b works on env block (b % 8) * (blocks / 8) + b / 8: one XCD = one contiguous env range
+    uint32_t pace;          // int32-row launches: idle turns (gu_idle) after every chunk of 16 (8) steps -- the rate limiter of the
+                            // store stream; chosen per engine and launch kind by gu_launch_rollout's calibration, 0 = none
 };
+
+// Idle for `turns` turns of a three-instruction scalar loop (~33 clocks a turn: the loop IS its branch penalty).  No memory
+// traffic, no vector work; the other waves of the SIMD keep issuing.
+//
+// WHY (round 3; tools/micro/store_pacing.hip, tools/pace_ab.py, profiles/r03d_*): the HBM write path of an MI355X shows
+// CONGESTION COLLAPSE.  65 536 lanes that hand their three rows per step to the memory system as fast as it will take them -- the
+// transition chain needs ~200 clocks per step, the memory ~280 -- keep every queue on the way full, and the sustained rate then
+// DROPS: to 5.7 TB/s on most allocations (round 2's "slow class"), 6.6 on some.  The same stores offered just below the memory's
+// capacity go through at 6.6 .. 7.0 TB/s on EVERY allocation: the bare store loop with one 176-clock gap per step 110 .. 116 us on
+// twelve buffers that take 115 .. 139 us unpaced; this kernel with ~90 idle clocks per step 119 .. 124 us on buffers that take
+// 139 .. 142 us without (and 111 .. 113 instead of 120 on the "fast" ones with ~75).  So a wave that has put down its rows waits a
+// little before it goes on.  Only the average rate matters, not the spacing inside a step (three stores back to back + one gap
+// do as well as three evenly spaced ones) -- but the window is narrow: a tenth too little idle time and the collapse is back, a
+// tenth too much and the launch is bound by its own idling.  Hence:
+//  * the amount is CALIBRATED per engine, trajectory buffer and launch kind by timing this very kernel (gu_launch_rollout:
+//    gu_calibrate_pace), not derived from clock rates;
+//  * it is spent every GU_PACE_EVERY = 4 steps: a run-time delay cannot be fine-grained per step -- one loop turn is 33 clocks, a
+//    computed jump into a run of s_nop costs ~110 clocks before the first one, a clock read per step (s_memtime and a deadline) costs
+//    more than it saves (146 us) -- while per chunk of 16 steps the bursts in between are long enough to bring the collapse back
+//    (best 120 .. 135 us).  Every fourth step: 8 clocks of granularity per step, 119 .. 124 us on every buffer.
+#ifndef GU_PACE_EVERY
+#define GU_PACE_EVERY 4
+#endif
+// `pace` = busy turns | sleeping turns << 8.  A busy turn is one pass of a three-instruction scalar loop (~33 clocks: the loop
+// IS its branch penalty): fine-grained, but it occupies the scalar issue port, which the other waves of the SIMD share -- with
+// four waves per SIMD (262 144 envs) hundreds of busy turns made the launch slower (658 against 582 us).  A sleeping turn puts
+// an `s_sleep 1` (64 clocks off the issue ports) into the loop: ~97 clocks, ~3 busy turns.  gu_pace_word() splits an amount.
+__device__ __forceinline__ void gu_idle(uint32_t pace)
+{
+    uint32_t c;
+    asm volatile("s_and_b32 %0, %1, 0xff\n"
+                 "s_cmp_eq_u32 %0, 0\n"
+                 "s_cbranch_scc1 2f\n"
+                 "1:\n"
+                 "s_sub_u32 %0, %0, 1\n"
+                 "s_cmp_lg_u32 %0, 0\n"
+                 "s_cbranch_scc1 1b\n"
+                 "2:\n"
+                 "s_lshr_b32 %0, %1, 8\n"
+                 "s_cmp_eq_u32 %0, 0\n"
+                 "s_cbranch_scc1 4f\n"
+                 "3:\n"
+                 "s_sleep 1\n"
+                 "s_sub_u32 %0, %0, 1\n"
+                 "s_cmp_lg_u32 %0, 0\n"
+                 "s_cbranch_scc1 3b\n"
+                 "4:"
+                 : "=&s"(c)
+                 : "s"(pace)
+                 : "scc", "memory");
+}
 
 // Workgroups are handed to the 8 XCDs round-robin (workgroup b -> XCD b % 8), so neighbouring env blocks would be
 // written by different XCDs, through different L2s.  With the remap every XCD owns one contiguous eighth of the batch:
@@ -244,7 +297,10 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             for (; i + 16 <= a.T; i += 16, t += 16) {  // body: 16 steps per word, fully unrolled
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                for (uint32_t j = 0; j < 16; ++j) {
+                    step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                    if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
+                }
                 if (TRAJ) rebase(16);
             }
             if (i < a.T) {  // tail
@@ -294,7 +350,10 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                 for (k = 0; k * 16 + 16 <= steps; ++k) {
                     const uint32_t next = k + 1 < cnt ? sw[(k + 1) * bd] : 0u;  // one word ahead of its steps
 #pragma unroll
-                    for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                    for (uint32_t j = 0; j < 16; ++j) {
+                        step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                        if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
+                    }
                     if (TRAJ) rebase(16);
                     word = next;
                 }
@@ -306,7 +365,10 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                 pa, row, e4, a.T, 0,
                 [&](uint32_t word) {
 #pragma unroll
-                    for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                    for (uint32_t j = 0; j < 16; ++j) {
+                        step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                        if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
+                    }
                     if (TRAJ) rebase(16);
                 },
                 step1);
@@ -350,7 +412,10 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             int64_t i = 0;
             for (; i + 8 <= a.T; i += 8) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tstep(j * row32);
+                for (int j = 0; j < 8; ++j) {
+                    tstep(j * row32);
+                    if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
+                }
                 if (TRAJ) rebase(8);
             }
             for (; i < a.T; ++i) {
@@ -378,6 +443,16 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
 // ------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------
+// gu_idle's argument for an idle amount of `turns` busy-turn equivalents (~33 clocks each) every GU_PACE_EVERY steps: busy turns
+// alone up to 15, beyond that sleeping turns (3 equivalents each) plus the remainder.
+static inline uint32_t gu_pace_word(int64_t turns)
+{
+    if (turns <= 0) return 0u;
+    if (turns <= 15) return (uint32_t)turns;
+    const int64_t sleeping = turns / 3 > 0xFFFF ? 0xFFFF : turns / 3;
+    return (uint32_t)(turns - 3 * (turns / 3)) | (uint32_t)(sleeping << 8);
+}
+
 static inline unsigned gu_blocks(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
 // Largest block size <= preferred for which every block uses one grid (0 = none: use the L2 variant)

@@ -471,6 +471,7 @@ __global__ void __launch_bounds__(VI_CL_THREADS) gu_vi_cluster_kernel(const ViCl
                     break;
                 }
             }
+            if (__hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) timed_out = 1u;  // (someone else gave up)
             round_key = __hip_atomic_load(a.delta_key + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();  // the other waves load only behind the polling lane's match
@@ -607,6 +608,7 @@ __global__ void __launch_bounds__(VI_CL_THREADS) gu_vi_sweep_step_cluster_kernel
                     break;
                 }
             }
+            if (__hip_atomic_load(a.vi.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) timed_out = 1u;  // (someone else gave up)
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -892,8 +894,8 @@ static int vi_cluster_run(gu_engine *h, double gamma, double threshold, bool use
     // A barrier that times out (the workgroups were not resident together: another process on the device, a CU mask) leaves v
     // written halfway through a round and the policy rows of some states updated: the launch works on a snapshot's ORIGINAL,
     // and a timeout restores it (40 bytes per state, device to device) and hands the loop to the one-launch-per-round path.
-    GU_HIP(hipMemcpyAsync(snap, h->d_v[h->vi_cur], v_bytes, hipMemcpyDeviceToDevice, h->stream));
-    GU_HIP(hipMemcpyAsync(snap + v_bytes, h->d_pi[h->vi_cur], 4 * v_bytes, hipMemcpyDeviceToDevice, h->stream));
+    if ((rc = gu_device_copy(h, snap, h->d_v[h->vi_cur], v_bytes)) != GU_OK) return rc;
+    if ((rc = gu_device_copy(h, snap + v_bytes, h->d_pi[h->vi_cur], 4 * v_bytes)) != GU_OK) return rc;
     if (gu_opt(h, GU_OPT_VI_PATH) == 3) GU_HIP(hipMemsetD32Async((hipDeviceptr_t)(sync_d + 1), 1, 1, h->stream));  // tests: an injected timeout
     ViClusterArgs a{h->d_cell, h->cell_bytes, h->W, h->S, gamma, threshold, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1],
                     h->d_pi[h->vi_cur], keys_d, sync_d, done_d, max_rounds, use_threshold ? 1 : 0};
@@ -909,12 +911,15 @@ static int vi_cluster_run(gu_engine *h, double gamma, double threshold, bool use
     }
     hipLaunchKernelGGL(kern, dim3(G), dim3(VI_CL_THREADS), 0, h->stream, a);
     GU_HIP(hipGetLastError());
-    int32_t done = 0;
-    GU_HIP(hipMemcpyAsync(&done, done_d, sizeof done, hipMemcpyDeviceToHost, h->stream));
+    // rounds_done is written by ONE workgroup, and a timeout need not be unanimous (the workgroup that arrives last finds the
+    // counter complete and goes on while the others have given up): the timeout word, raised by whoever gives up, decides.
+    int32_t ctl[4] = {0, 0, 0, 0};  // [arrival counter, timeout word, rounds_done, pad]
+    GU_HIP(hipMemcpyAsync(ctl, h->d_scratch, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
     GU_HIP(hipStreamSynchronize(h->stream));
+    const int32_t done = ctl[1] ? -1 : ctl[2];
     if (done < 0) {
-        GU_HIP(hipMemcpyAsync(h->d_v[h->vi_cur], snap, v_bytes, hipMemcpyDeviceToDevice, h->stream));
-        GU_HIP(hipMemcpyAsync(h->d_pi[h->vi_cur], snap + v_bytes, 4 * v_bytes, hipMemcpyDeviceToDevice, h->stream));
+        if ((rc = gu_device_copy(h, h->d_v[h->vi_cur], snap, v_bytes)) != GU_OK) return rc;
+        if ((rc = gu_device_copy(h, h->d_pi[h->vi_cur], snap + v_bytes, 4 * v_bytes)) != GU_OK) return rc;
         GU_HIP(hipStreamSynchronize(h->stream));
         if (gu_debug()) fprintf(stderr, "[gu] DP cluster kernel: grid barrier timed out (%u workgroups not resident together); tables restored, one launch per round instead\n", G);
         return GU_VI_FALLBACK;
@@ -1222,7 +1227,8 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
         void *live[5] = {h->d_v[h->vi_cur], h->d_pi[h->vi_cur], h->d_out3, h->d_episode, h->d_done_bits};
         const size_t size[5] = {v_bytes, 4 * v_bytes, 3 * n4, n4, bits_bytes};
         size_t off = 0;
-        for (int k = 0; k < 5; off += size[k], ++k) GU_HIP(hipMemcpyAsync(snap + off, live[k], size[k], hipMemcpyDeviceToDevice, h->stream));
+        for (int k = 0; k < 5; off += size[k], ++k)
+            if ((rc = gu_device_copy(h, snap + off, live[k], size[k])) != GU_OK) return rc;
         if (path == 3) GU_HIP(hipMemsetD32Async((hipDeviceptr_t)(sync_d + 1), 1, 1, h->stream));  // tests: an injected timeout
         ViStepClusterArgs a{};
         a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, 0.0, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1],
@@ -1240,9 +1246,10 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
         a.done_bits = h->d_done_bits;
         hipLaunchKernelGGL(gu_vi_sweep_step_cluster_kernel, dim3((unsigned)G), dim3(VI_CL_THREADS), 2 * (size_t)h->cell_bytes, h->stream, a);
         GU_HIP(hipGetLastError());
-        int32_t done = 0;
-        GU_HIP(hipMemcpyAsync(&done, done_d, sizeof done, hipMemcpyDeviceToHost, h->stream));
+        int32_t ctl[4] = {0, 0, 0, 0};  // [arrival counter, timeout word, rounds_done, pad]: the timeout word decides (see vi_cluster_run)
+        GU_HIP(hipMemcpyAsync(ctl, h->d_scratch, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
         GU_HIP(hipStreamSynchronize(h->stream));
+        const int32_t done = ctl[1] ? -1 : ctl[2];
         if (done >= 0) {
             if (deltas) {
                 std::vector<unsigned long long> keys((size_t)iters);
@@ -1259,7 +1266,8 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
             return GU_OK;
         }
         off = 0;
-        for (int k = 0; k < 5; off += size[k], ++k) GU_HIP(hipMemcpyAsync(live[k], snap + off, size[k], hipMemcpyDeviceToDevice, h->stream));
+        for (int k = 0; k < 5; off += size[k], ++k)
+            if ((rc = gu_device_copy(h, live[k], snap + off, size[k])) != GU_OK) return rc;
         GU_HIP(hipStreamSynchronize(h->stream));
         if (gu_debug()) fprintf(stderr, "[gu] sweep-step cluster kernel: grid barrier timed out (%lld workgroups not resident together); state restored, one launch per round instead\n", (long long)G);
         cluster = false;

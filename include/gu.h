@@ -100,7 +100,8 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_TRAJ_STRIDE_MIB 15     /* spacer size (3072)                                                                   */
 #define GU_OPT_TRAJ_FAR_MIB 16        /* most memory the search may hold at once (49152)                                      */
 #define GU_OPT_TRAJ_PROBE_ALL 17      /* 1 = probe every candidate, no early stop (measurement aid)                           */
-#define GU_OPT_COUNT 18
+#define GU_OPT_ROLLOUT_PACE 18        /* store pacing of int32-row launches: idle turns every 4 steps; -1 = calibrate (default), 0 = none */
+#define GU_OPT_COUNT 19
 #define GU_OPT_X_TRAJ_UNCACHED 100    /* EXPERIMENT: uncached memory type for the trajectory (readers may see stale bytes)    */
 #define GU_OPT_X_TRAJ_POISON 101      /* EXPERIMENT: fill a fresh trajectory buffer with 0x5A                                 */
 #define GU_OPT_X_MC_POISON 102        /* EXPERIMENT: fill the Monte-Carlo scratch with 0x5A before every evaluation           */
@@ -232,6 +233,16 @@ int gu_trajectory_placement_detail(gu_handle h, int32_t capacity, float *probe_m
                                    int32_t *kept, float *search_ms, uint64_t *peak_bytes);
 int gu_probe_trajectory(gu_handle h, float *milliseconds);
 int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
+/* Store pacing.  The HBM write path shows congestion collapse: lanes that hand their rows to the memory system as fast as it will
+ * take them are served at 5.7 TB/s on most allocations, the same stores offered just below the memory's capacity at 6.6 .. 7.0 on
+ * every one.  Launches with GU_F_TRAJECTORY of 128 MB of rows and more therefore idle a few clocks every
+ * four steps; how many is CALIBRATED the first time a launch kind (policy, auto-reset) runs on a trajectory buffer, by timing the
+ * kernel itself on the engine's own state (snapshot before, put back after: results never depend on it; that first gu_rollout is
+ * synchronous and takes ~20 launches longer).  GU_OPT_ROLLOUT_PACE fixes the amount instead (0 = none).  This reports what the
+ * calibration found for a launch kind: idle turns (~33 clocks each) per 4 steps, ms per launch without and with them, candidates
+ * timed, ms spent calibrating.  GU_ERR_STATE when that kind has not been calibrated (not launched yet, or too small to pace). */
+int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *turns, float *ms_unpaced, float *ms_paced,
+                      int32_t *evaluated, float *calibration_ms);
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);
 int gu_read_trajectory_packed(gu_handle h, int64_t t0, int64_t T, uint32_t *packed);   /* [T][N] after GU_F_PACKED */
 int gu_read_stats(gu_handle h, int64_t *reward_sum, int32_t *episodes);

@@ -170,3 +170,47 @@ def test_bench_single_process_form_on_the_one_gpu():
     assert line['strong_c4']['shards_equal_oracle'] is True and len(line['roofline']['trajectory_placement']) == 2
     line = _bench('--gpus', '1', '--single-process', '--gather-view', *SMALL)
     assert line['n_gpus'] == 1 and line['rccl']['view_equals_shards'] is True and line['rccl']['nranks'] == 1
+
+
+def test_store_pacing_is_calibrated_on_the_engines_own_state_and_never_changes_a_result(gu_option):
+    """The rollout kernel rate-limits its int32-row store stream (idle turns every 4 steps).  How many is
+    calibrated by timing the kernel itself on the engine's own state, which is snapshot and put back: an engine that calibrated
+    continues exactly where one that never did would -- trajectory, state, episode counters, done list; fixed amounts (busy turns,
+    sleeping turns) give the same bytes too; launches too small to be bound by HBM are neither paced nor calibrated."""
+    meta, _ = G.load_traj('c3_maze32')
+    N, T = 65536, 300  # 236 MB of rows per launch: paced
+    outs = {}
+    for pace in (0, None, 5, 40):
+        gu_option('rollout_pace', pace)
+        with Engine(N, spec_of(meta), seed=9) as eng:
+            eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T // 3, 'uniform', True, True)       # a shorter launch first (under the 128 MB bar: never paced)
+            assert eng.rollout_pacing() is None
+            eng.rollout(T, 'uniform', True, True, stats=True)  # (calibrates when pace is None)
+            info = eng.rollout_pacing()
+            if pace is None:
+                assert info is not None and info['evaluated'] >= 8 and info['ms_unpaced'] > 0 and 0 < info['ms_paced'] <= info['ms_unpaced'] * 1.001
+                assert 0 <= info['turns'] <= 1024 and info['calibration_ms'] > 0
+            else:
+                assert info is None  # a fixed amount: nothing to calibrate
+            eng.rollout(T, 'uniform', True, True, stats=True)
+            tr = eng.read_trajectory(0, T)
+            st = eng.get_state()
+            outs[pace] = (tr['obs'], tr['reward'], tr['done'], st['pos'], st['done'], st['episode'], st['tcount'], eng.read_stats()[0], eng.done_indices())
+    for pace in (None, 5, 40):
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[pace])), pace
+    grid, st = C.Grid.from_lists(**meta), C.State(2048)
+    C.reset(grid, 9, st)
+    C.rollout(grid, 9, st, T // 3 + T, True, trajectory=False)
+    want = C.rollout(grid, 9, st, T, True)
+    assert all(np.array_equal(outs[None][i][:, :2048], want[k]) for i, k in enumerate(('obs', 'reward', 'done')))
+    # a caller-supplied stream and a table policy are calibrated as launch kinds of their own
+    gu_option('rollout_pace', None)
+    with Engine(N, spec_of(meta), seed=9) as eng:
+        eng.reset()
+        eng.reserve_trajectory(T)
+        S = meta['W'] * meta['H']
+        eng.vi_set(np.zeros(S), np.random.RandomState(1).dirichlet(np.ones(4), S))
+        eng.rollout(T, 'sample', False, True)
+        assert eng.rollout_pacing('sample', False) is not None and eng.rollout_pacing('uniform', True) is None

@@ -915,8 +915,14 @@ int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t 
     GU_ENTER(h);
     GU_REQUIRE(policy_kind >= GU_POLICY_UNIFORM && policy_kind <= GU_POLICY_SAMPLE, GU_ERR_INVALID, "unknown policy kind %d", policy_kind);
     const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->all_single_start ? 1 : 2) : 0;
-    const gu_engine::PaceRecord &rec = h->pace[policy_kind * 3 + auto_mode];
-    GU_REQUIRE(rec.known && rec.buffer == (const void *)h->d_traj, GU_ERR_STATE, "no pacing calibration for this launch kind on the current trajectory buffer");
+    // (the general kernel's record, else the transition-row kernel's: a launch kind of one engine runs on one of the two)
+    const gu_engine::PaceRecord *found = nullptr;
+    for (int base : {0, 12}) {
+        const gu_engine::PaceRecord &cand = h->pace[base + policy_kind * 3 + auto_mode];
+        if (!found && cand.known && cand.buffer == (const void *)h->d_traj) found = &cand;
+    }
+    GU_REQUIRE(found != nullptr, GU_ERR_STATE, "no pacing calibration for this launch kind on the current trajectory buffer");
+    const gu_engine::PaceRecord &rec = *found;
     if (turns) *turns = (int32_t)rec.turns;
     if (ms_unpaced) *ms_unpaced = rec.ms_unpaced;
     if (ms_paced) *ms_paced = rec.ms_paced;

@@ -107,7 +107,7 @@ struct gu_engine {
         uint32_t turns = 0;            // idle turns every GU_PACE_EVERY steps (0: none)
         float ms_unpaced = 0.0f, ms_paced = 0.0f, calibration_ms = 0.0f;
         int32_t evaluated = 0;         // candidates timed
-    } pace[12];
+    } pace[24];  // [policy * 3 + auto mode] for the general kernel, + 12 for the transition-row kernel
     hipEvent_t ev_cal[2] = {nullptr, nullptr};
 
     // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in

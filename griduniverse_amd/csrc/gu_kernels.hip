@@ -24,8 +24,10 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
+#include <functional>
 #include <vector>
 
 // ------------------------------------------------------------------------------------
@@ -330,6 +332,9 @@ int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, i
     return GU_OK;
 }
 
+static double gu_wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double g_last_rollout_ms[64];  // per device: when this process last launched a rollout there (is the device at its working clocks?)
+
 __global__ void __launch_bounds__(256) gu_copy_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t words)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -360,10 +365,10 @@ static void gu_rollout_general(gu_engine *h, const RolloutArgs &a, int32_t polic
 // itself is timed -- full-length launches on the engine's own state, which is snapshot first and put back afterwards (positions,
 // rewards, done flags and their ballots, episode counters; the step counter lives on the host and is not advanced), so a
 // calibrated engine continues exactly where an uncalibrated one would.  time(turns) is a plateau (collapsed), a cliff, then a
-// ramp (bound by the idling itself): a geometric ladder finds the region, a finer one between the best point's neighbours the
-// optimum, and the choice is then moved a little to the right -- the cliff is on the left.  ~25 candidates x 3 launches, once per
-// (policy, auto-reset mode, buffer).
-static int gu_calibrate_pace(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, bool stats, int bs, gu_engine::PaceRecord *rec)
+// ramp (bound by the idling itself): a geometric ladder finds the region, a fine scan DOWN the ramp from the healthy side finds the
+// floor, and the choice keeps one step of distance from the cliff on the left.  ~100 launches, once per (policy, auto-reset mode,
+// buffer).
+static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::function<void(uint32_t)> &launch, gu_engine::PaceRecord *rec)
 {
     const auto t_start = std::chrono::steady_clock::now();
     const size_t n4 = (size_t)h->N * 4, bits = (((size_t)h->N + 63) / 64) * 8;
@@ -380,41 +385,59 @@ static int gu_calibrate_pace(gu_engine *h, RolloutArgs a, int32_t policy, int au
     static const int MAX_TURNS = 1024;
     std::vector<float> times(MAX_TURNS + 2, 0.0f);
     int evaluated = 0;
-    // The device must be at its working clocks first: a calibration right after start-up, on a GPU still ramping up from idle,
-    // sees a slower transition chain, chooses too little idle time -- and the launch collapses once the clocks are up (the first
-    // engine of a process: 6 turns chosen, 140 us per launch instead of 120).  Unpaced launches until two successive pairs agree
-    // within 1 % (at most ~60 launches).
-    a.pace = 0;
+    // The device must be at its working clocks first.  A calibration right after start-up, on a GPU still ramping up from idle,
+    // sees a slower transition chain and chooses too little idle time -- and the launch collapses once the clocks are up (5 .. 7
+    // turns chosen instead of 10 .. 11, frac 0.73 .. 0.78 instead of 0.82 in the timed region that followed; with 56 ms of launches
+    // first: 0.82 three times out of three, profiles/r03f_pace_warmup.txt).  The ramp is gradual -- successive launches agree within
+    // 1 % all along it -- so: unpaced launches until the mean of the last 16 agrees with the mean of the 16 before within 0.4 %, for
+    // at least 30 ms when the device has not been running rollouts in the last 50 ms, 150 ms at most.
     {
-        float prev = 0.0f;
-        int agree = 0;
-        for (int w = 0; w < 30 && agree < 2; ++w) {
+        const bool cold = h->device < 0 || h->device >= 64 || gu_wall_ms() - g_last_rollout_ms[h->device] > 50.0;
+        const double w0 = gu_wall_ms(), at_least = cold ? 30.0 : 0.0;
+        std::vector<float> pairs;
+        for (;;) {
             GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
-            gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);
-            gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);
+            launch(0u);
+            launch(0u);
             GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
             GU_HIP(hipEventSynchronize(h->ev_cal[1]));
             float ms = 0.0f;
             GU_HIP(hipEventElapsedTime(&ms, h->ev_cal[0], h->ev_cal[1]));
-            agree = (prev > 0.0f && ms < 1.01f * prev && prev < 1.01f * ms) ? agree + 1 : 0;
-            prev = ms;
+            pairs.push_back(ms);
+            const size_t n = pairs.size();
+            const double waited = gu_wall_ms() - w0;
+            bool stable = false;
+            if (n >= 16) {
+                double last = 0.0, before = 0.0;
+                for (size_t k = 0; k < 8; ++k) last += pairs[n - 1 - k], before += pairs[n - 9 - k];
+                stable = last <= 1.004 * before && before <= 1.004 * last;
+            }
+            if ((stable && waited >= at_least) || waited > 150.0) break;
         }
     }
+    // One measurement of a candidate: a launch to settle, then `reps` timed ones.  Near the cliff the collapsed and the healthy state
+    // are BISTABLE (a candidate just below it can measure fast once and run collapsed ever after: 6 turns, 124 us in a calibration,
+    // 136 us in the timed region that followed), which is why the fine scan below comes down from the healthy side and the choice
+    // keeps a step of distance.
+    auto measure = [&](int turns, int reps, float *ms) -> int {
+        const uint32_t word = gu_pace_word(turns);
+        launch(word);
+        GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
+        for (int r = 0; r < reps; ++r) launch(word);
+        GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
+        GU_HIP(hipEventSynchronize(h->ev_cal[1]));
+        GU_HIP(hipGetLastError());
+        GU_HIP(hipEventElapsedTime(ms, h->ev_cal[0], h->ev_cal[1]));
+        *ms /= (float)reps;
+        return GU_OK;
+    };
     auto time_of = [&](int turns, float *ms) -> int {
         if (times[turns] > 0.0f) {
             *ms = times[turns];
             return GU_OK;
         }
-        a.pace = gu_pace_word(turns);
-        gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);  // (also settles the caches into their steady state)
-        GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
-        gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);
-        gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);
-        GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
-        GU_HIP(hipEventSynchronize(h->ev_cal[1]));
-        GU_HIP(hipGetLastError());
-        GU_HIP(hipEventElapsedTime(ms, h->ev_cal[0], h->ev_cal[1]));
-        *ms *= 0.5f;
+        int rc2 = measure(turns, 2, ms);
+        if (rc2 != GU_OK) return rc2;
         times[turns] = *ms;
         ++evaluated;
         return GU_OK;
@@ -431,54 +454,79 @@ static int gu_calibrate_pace(gu_engine *h, RolloutArgs a, int32_t policy, int au
         if (g == 0 || t < best) best = t, best_g = (int)g;
         if ((int)g >= best_g + 2 && t > 1.5f * best) break;  // well up the ramp: larger values only idle longer
     }
-    // fine: between the best grid point's neighbours, every value (narrow gaps) or a ladder of ratio ~1.06
-    const int lo = best_g > 0 ? grid[(size_t)best_g - 1] + 1 : 0;
-    const int hi = (size_t)best_g + 1 < grid.size() ? grid[(size_t)best_g + 1] - 1 : grid[(size_t)best_g];
-    int best_turns = grid[(size_t)best_g];
-    for (double f = lo; f <= hi + 0.5; f = (hi - lo <= 12) ? f + 1.0 : std::max(f + 1.0, f * 1.06)) {
-        const int turns = (int)f;
-        if ((rc = time_of(turns, &t)) != GU_OK) return rc;
-        if (t < best) best = t, best_turns = turns;
+    // fine, DESCENDING from the healthy side: between the best ladder point's neighbours, every value (narrow gaps) or a ladder of
+    // ratio ~1.06, each entered from a larger amount -- i.e. from a state that was not collapsed -- and timed over four launches.
+    // Down the ramp the time falls until the memory's capacity or the cliff is reached; two values in a row 8 % above the running
+    // minimum mean the cliff is behind us.
+    const int lo = best_g > 0 ? grid[(size_t)best_g - 1] : 0;
+    const int hi = (size_t)best_g + 1 < grid.size() ? grid[(size_t)best_g + 1] : grid[(size_t)best_g];
+    std::vector<int> fine;
+    for (double f = hi; f >= lo - 0.5; f = (hi - lo <= 16) ? f - 1.0 : std::min(f - 1.0, f / 1.06)) fine.push_back((int)f);
+    if (fine.empty() || fine.back() != lo) fine.push_back(lo);
+    std::vector<float> fine_ms(fine.size(), 0.0f);
+    float floor_ms = 0.0f;
+    int at_floor = 0, above = 0;
+    for (size_t k = 0; k < fine.size(); ++k) {
+        if ((rc = measure(fine[k], 4, &t)) != GU_OK) return rc;
+        ++evaluated;
+        fine_ms[k] = t;
+        times[fine[k]] = t;
+        if (k == 0 || t < floor_ms) floor_ms = t, at_floor = (int)k, above = 0;
+        else if (t > 1.08f * floor_ms && ++above >= 2) break;
     }
-    // Away from the cliff: a calibration launch right at the edge can still be fast while the steady state is not (the collapse
-    // has hysteresis).  `cliff` = the largest timed value below the best that is clearly collapsed; keep at least ~5 % (and one
-    // turn) of distance from it, if that costs less than 4 %.
-    if (best_turns > 0) {
-        int cliff = -1;
-        for (int k = best_turns - 1; k >= 0; --k)
-            if (times[k] > 1.06f * best) {
-                cliff = k;
-                break;
-            }
-        const int safe = cliff < 0 ? best_turns : std::max(best_turns, (int)(cliff * 1.05) + 2);
-        if (safe != best_turns && safe <= MAX_TURNS) {
-            if ((rc = time_of(safe, &t)) != GU_OK) return rc;
-            if (t <= 1.04f * best) best_turns = safe, best = t;
+    // The choice.  Coming down from the healthy side is optimistic: the healthy state survives a little below the amount at which
+    // a COLLAPSED stream recovers (hysteresis), and a timed region is not that kind -- a launch after a pause, a neighbour on the
+    // device, and the stream is collapsed and stays so (10 turns chosen this way: blocks of 20 launches at 0.120 and at 0.136 ms in
+    // one run).  The amount to keep is the smallest one that gets OUT of the collapse by itself: going up from just below the
+    // floor, each candidate is entered from the collapsed state (two unpaced launches), given two launches to settle and timed
+    // over four; the first within 4 % of the floor is it.
+    int pick = at_floor;
+    if (at_floor > 0 && fine_ms[(size_t)at_floor - 1] <= 1.03f * floor_ms) pick = at_floor - 1;  // (fallback: a step to the right)
+    for (int k = std::min<int>(at_floor + 1, (int)fine.size() - 1); k >= 0; --k) {
+        if (fine[(size_t)k] == 0) continue;
+        launch(0u);
+        launch(0u);
+        const uint32_t word = gu_pace_word(fine[(size_t)k]);
+        launch(word);
+        if ((rc = measure(fine[(size_t)k], 4, &t)) != GU_OK) return rc;
+        ++evaluated;
+        if (t <= 1.04f * floor_ms) {
+            pick = k;
+            fine_ms[(size_t)k] = t;
+            break;
         }
     }
-    if (times[0] <= 1.01f * best) best_turns = 0, best = times[0];  // no gain worth the name: no pacing
+    int best_turns = fine[(size_t)pick];
+    best = fine_ms[(size_t)pick];
+    if (best_turns > 0) {  // against no pacing at all, measured the same way
+        if ((rc = measure(0, 4, &t)) != GU_OK) return rc;
+        times[0] = t;
+        if (t <= 1.01f * best) best_turns = 0, best = t;
+    }
     off = 0;
     for (int k = 0; k < 3; off += size[k], ++k)
         if ((rc = gu_device_copy(h, live[k], snap + off, size[k])) != GU_OK) return rc;
     GU_HIP(hipStreamSynchronize(h->stream));
     rec->known = true;
     rec->buffer = h->d_traj;
-    rec->T = a.T;
+    rec->T = T;
     rec->turns = (uint32_t)best_turns;
     rec->ms_unpaced = times[0];
     rec->ms_paced = best;
     rec->evaluated = evaluated;
     rec->calibration_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     if (gu_debug())
-        fprintf(stderr, "[gu] store pacing (policy %d, auto %d, %lld x %lld): %d idle turns per %d steps, %.4f -> %.4f ms per launch, %d candidates in %.1f ms\n",
-                policy, auto_mode, (long long)h->N, (long long)a.T, best_turns, GU_PACE_EVERY, times[0], best, evaluated, rec->calibration_ms);
+        fprintf(stderr, "[gu] store pacing (%s kernel, policy %d, auto %d, %lld x %lld): %d idle turns per %d steps, %.4f -> %.4f ms per launch, %d candidates in %.1f ms\n",
+                slot >= 12 ? "row-table" : "general", (slot % 12) / 3, slot % 3, (long long)h->N, (long long)T, best_turns, GU_PACE_EVERY, times[0], best, evaluated,
+                rec->calibration_ms);
     return GU_OK;
 }
 
 // The pace of this launch: option GU_OPT_ROLLOUT_PACE when set (0 = none), else the calibrated value for this launch kind on
-// this buffer -- calibrated now if it is not known yet.  Launches that cannot be bound by the HBM write path (less than 128 MB of
-// rows, or fewer workgroups than half the CUs) are not paced and not calibrated.
-static int gu_pace_for(gu_engine *h, const RolloutArgs &a, int32_t policy, int auto_mode, bool stats, int bs, uint32_t *pace)
+// this buffer -- calibrated now if it is not known yet.  `slot` = policy * 3 + auto mode (+ 12 for the transition-row kernel);
+// `launch(word)` enqueues the launch with that idle word.  Launches that cannot be bound by the HBM write path (less than 128 MB
+// of rows, or fewer workgroups than half the CUs) are not paced and not calibrated.
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, const std::function<void(uint32_t)> &launch, uint32_t *pace)
 {
     *pace = 0;
     const int64_t opt = gu_opt(h, GU_OPT_ROLLOUT_PACE);
@@ -486,13 +534,14 @@ static int gu_pace_for(gu_engine *h, const RolloutArgs &a, int32_t policy, int a
         *pace = gu_pace_word(opt);
         return GU_OK;
     }
-    if ((double)h->N * (double)a.T * 12.0 < 128e6 || (int64_t)gu_blocks(h->N, bs) * 2 < h->n_cu) return GU_OK;
-    gu_engine::PaceRecord &rec = h->pace[policy * 3 + auto_mode];
-    if (!rec.known || rec.buffer != (const void *)h->d_traj || a.T > 2 * rec.T || 2 * a.T < rec.T) {
-        int rc = gu_calibrate_pace(h, a, policy, auto_mode, stats, bs, &rec);
+    if ((double)h->N * (double)T * 12.0 < 128e6 || (int64_t)blocks * 2 < h->n_cu) return GU_OK;
+    gu_engine::PaceRecord &rec = h->pace[slot];
+    if (!rec.known || rec.buffer != (const void *)h->d_traj || T > 2 * rec.T || 2 * T < rec.T) {
+        int rc = gu_calibrate_pace(h, slot, T, launch, &rec);
         if (rc != GU_OK) return rc;
     }
     *pace = gu_pace_word(rec.turns);
+    if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
     return GU_OK;
 }
 
@@ -540,17 +589,32 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)
     if (policy == GU_POLICY_SAMPLE)
         hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
-    if (gu_rollout_multi(h, a, policy, auto_mode, traj, stats) || gu_rollout_rows(h, a, policy, auto_mode, traj, stats)) {
+    if (gu_rollout_multi(h, a, policy, auto_mode, traj, stats)) {
         GU_HIP(hipGetLastError());
         h->steps_taken += (uint32_t)T;
         return GU_OK;
     }
+    {
+        int rows_rc = GU_OK;
+        if (gu_rollout_rows(h, a, policy, auto_mode, traj, stats, &rows_rc)) {
+            if (rows_rc != GU_OK) return rows_rc;
+            GU_HIP(hipGetLastError());
+            h->steps_taken += (uint32_t)T;
+            if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
+            return GU_OK;
+        }
+    }
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
     if (traj == 1) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: gu_idle)
-        int rc = gu_pace_for(h, a, policy, auto_mode, stats, bs, &a.pace);
+        RolloutArgs c = a;
+        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, gu_blocks(h->N, bs), [&](uint32_t word) {
+            c.pace = word;
+            gu_rollout_general(h, c, policy, auto_mode, 1, stats, bs);
+        }, &a.pace);
         if (rc != GU_OK) return rc;
     }
     gu_rollout_general(h, a, policy, auto_mode, traj, stats, bs);
+    if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
     GU_HIP(hipGetLastError());
     h->steps_taken += (uint32_t)T;
     return GU_OK;

@@ -550,7 +550,9 @@ void gu_rollout_uniform(gu_engine *h, const RolloutArgs &a, int auto_mode, int t
 void gu_rollout_stream(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
 void gu_rollout_greedy(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
 void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
-// the transition-row kernel (gu_rollout_rows.hip): true when it took the launch
-bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);
+// the transition-row kernel (gu_rollout_rows.hip): true when it took the launch (*rc: what its pace calibration returned)
+bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats, int *rc);
+// store pacing (gu_kernels.hip): the idle word of an int32-row launch, calibrated on first use
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, const std::function<void(uint32_t)> &launch, uint32_t *pace);
 // the K-step kernel (gu_rollout_multi.hip; uniform policy, no trajectory): true when it took the launch
 bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);

@@ -244,7 +244,10 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             for (; i + 16 <= a.T; i += 16, t += 16) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
+                for (uint32_t j = 0; j < 16; ++j) {
+                    step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
+                    if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);  // (gu_rollout.hpp)
+                }
                 if (TRAJ) rebase(16);
             }
             if (i < a.T) {
@@ -280,7 +283,10 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         };
         for (; i + 8 <= a.T; i += 8) {
 #pragma unroll
-            for (uint32_t j = 0; j < 8; ++j) pstep(j * row32);
+            for (uint32_t j = 0; j < 8; ++j) {
+                pstep(j * row32);
+                if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
+            }
             if (TRAJ) rebase(8);
         }
         for (; i < a.T; ++i) {
@@ -293,7 +299,10 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             pa, row, e4, a.T, 1,
             [&](uint32_t word) {
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
+                for (uint32_t j = 0; j < 16; ++j) {
+                    step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
+                    if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
+                }
                 if (TRAJ) rebase(16);
             },
             step1);
@@ -323,6 +332,8 @@ static bool rows_shape(const gu_engine *h, int row_bytes, int max_copies, int *b
     if (h->n_grids != 1) return false;
     // the smallest workgroup that fits, with as many copies as its LDS share admits (the copy count matters little once the
     // table is staged with wide, pipelined stores; the workgroup size does: profiles/r02e_rows_copies.txt)
+    // (128- and 64-thread workgroups, which spread a 32 768-env launch over all CUs instead of half of them, are no faster: 70 .. 72 us
+    // either way, profiles/r03h_rows_block.txt)
     for (int bs = 256; bs <= GU_MAX_BLOCK; bs <<= 1) {
         const int64_t blocks = (h->N + bs - 1) / bs, per_cu = (blocks + h->n_cu - 1) / h->n_cu;
         for (int c = max_copies; c >= 1; c >>= 1) {
@@ -368,8 +379,9 @@ static void rows_dispatch(const gu_engine *h, const RolloutArgs &a, int traj, bo
 }
 
 // Returns true when the launch was taken by the row-table kernel.
-bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats)
+bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats, int *rc)
 {
+    *rc = GU_OK;
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return false;
     if (auto_mode == 2) return false;  // several start cells: the reset draws from the RNG, it cannot be tabulated
     const int mode = rows_mode(h);
@@ -434,11 +446,22 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     const size_t lds = ((size_t)h->S << row_log2) << (shift - row_log2);
     const dim3 grid(gu_blocks(h->N, bs)), block(bs);
     a.xcd_remap = a.xcd_remap && grid.x % 8 == 0;
-    switch (policy) {
-    case GU_POLICY_UNIFORM: rows_dispatch<GU_POLICY_UNIFORM>(h, a, traj, stats, which, grid, block, lds, h->stream); break;
-    case GU_POLICY_STREAM: rows_dispatch<GU_POLICY_STREAM>(h, a, traj, stats, which, grid, block, lds, h->stream); break;
-    case GU_POLICY_GREEDY: rows_dispatch<GU_POLICY_GREEDY>(h, a, traj, stats, which, grid, block, lds, h->stream); break;
-    default: rows_dispatch<GU_POLICY_SAMPLE>(h, a, traj, stats, which, grid, block, lds, h->stream); break;
+    auto launch = [&](const RolloutArgs &args) {
+        switch (policy) {
+        case GU_POLICY_UNIFORM: rows_dispatch<GU_POLICY_UNIFORM>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
+        case GU_POLICY_STREAM: rows_dispatch<GU_POLICY_STREAM>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
+        case GU_POLICY_GREEDY: rows_dispatch<GU_POLICY_GREEDY>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
+        default: rows_dispatch<GU_POLICY_SAMPLE>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
+        }
+    };
+    if (traj == 1) {  // int32 rows: the store stream is rate-limited here too (gu_rollout.hpp: gu_idle; calibrated on first use)
+        RolloutArgs c = a;
+        *rc = gu_pace_for(h, 12 + policy * 3 + auto_mode, a.T, grid.x, [&](uint32_t word) {
+            c.pace = word;
+            launch(c);
+        }, &a.pace);
+        if (*rc != GU_OK) return true;
     }
+    launch(a);
     return true;
 }

@@ -95,8 +95,8 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_MC_LANE_RETURNS 10     /* 1 = return sums by the per-lane kernel instead of the LDS-tiled one                  */
 #define GU_OPT_MC_GLOBAL_WALK 11      /* 1 = history walk with its counters in global memory instead of LDS                   */
 #define GU_OPT_STEP_SYNC 12           /* 1 = gu_step always waits with the stream synchronisation                             */
-#define GU_OPT_TRAJ_CANDIDATES 13     /* back-to-back candidates of the trajectory placement search (12; 1 = take the first)  */
-#define GU_OPT_TRAJ_FAR_CANDIDATES 14 /* candidates behind spacers (32; 0 = none)                                             */
+#define GU_OPT_TRAJ_CANDIDATES 13     /* back-to-back candidates of the trajectory placement search (4; 1 = take the first)   */
+#define GU_OPT_TRAJ_FAR_CANDIDATES 14 /* candidates behind spacers (0 = none, the default)                                       */
 #define GU_OPT_TRAJ_STRIDE_MIB 15     /* spacer size (3072)                                                                   */
 #define GU_OPT_TRAJ_FAR_MIB 16        /* most memory the search may hold at once (49152)                                      */
 #define GU_OPT_TRAJ_PROBE_ALL 17      /* 1 = probe every candidate, no early stop (measurement aid)                           */
@@ -210,14 +210,14 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done);
  * (gu_reserve_trajectory(T) first: room for at least T rows; a buffer that is already large enough is kept); with GU_F_STATS the per-env reward sum and the
  * number of episodes finished during this call are kept for gu_read_stats. */
 int gu_reserve_trajectory(gu_handle h, int64_t T);
-/* Where an allocation lands in HBM decides how fast it can be written (5.7 .. 6.9 TB/s for 786 MB buffers of one process;
- * DESIGN.md section 6), so gu_reserve_trajectory CHOOSES a buffer of 64 MB and more: it allocates candidates one after the
- * other, writes each once in the rollout's own store shape, and keeps the fastest.  The search
+/* Where an allocation lands in HBM changes how fast it can be written (round 2: 5.7 .. 6.9 TB/s for 786 MB buffers of one process
+ * with an unthrottled store stream; since the rollout kernel rate-limits its stores -- see gu_rollout_pacing -- 6.4 .. 6.6 against
+ * 6.8 .. 7.1), so gu_reserve_trajectory CHOOSES a buffer of 64 MB and more: it allocates candidates one after
+ * the other, writes each once in the rollout's own store shape, and keeps the fastest.  The search
  *   - stops at the first clearly fast candidate (14 % quicker than the slowest seen; on gfx950 also: 6.5 TB/s or more);
- *   - gives up after GU_OPT_TRAJ_CANDIDATES (12) back-to-back candidates whose probe times lie within 6 % of each other (a
- *     device on which every allocation is alike), else -- buffers of 256 MiB and more -- continues with up to
- *     GU_OPT_TRAJ_FAR_CANDIDATES (32) more, each behind a spacer of GU_OPT_TRAJ_STRIDE_MIB (3072) that is held until the
- *     choice is made;
+ *   - looks at GU_OPT_TRAJ_CANDIDATES (4) back-to-back candidates; only when GU_OPT_TRAJ_FAR_CANDIDATES (0) is set and those were
+ *     at least 6 % apart does it continue -- buffers of 256 MiB and more -- with that many more, each behind a spacer of
+ *     GU_OPT_TRAJ_STRIDE_MIB (3072) that is held until the choice is made;
  *   - never holds more than a third of the device's free memory nor GU_OPT_TRAJ_FAR_MIB (48 GiB) at once, everything but the
  *     kept buffer is freed before the call returns;
  *   - is per-process aware: once an engine of the process owns a chosen trajectory buffer on the device, later engines

@@ -21,6 +21,9 @@ np.random.seed(123)
 env = gua.GridUniverseEnv(grid_shape=(32, 32), random_maze=True)
 spec = gua.GridSpec.from_env(env)
 _lib.set_default_option('traj_candidates', 1)
+import os
+if os.environ.get('PACE_AB_NO_ROWS'):
+    _lib.set_default_option('rollout_rows', 0)  # the general kernel also where the transition-row kernel would take the launch
 engines = []
 for b in range(n_buf):
     eng = gua.Engine(N, spec, seed=123)

@@ -4,16 +4,26 @@
 // Round 2 found (profiles/r02g_store_sleep_spacing.txt) that the bare three-store loop runs at 113..117 us per 65 536 x 1000
 // launch on buffers of the SLOW write-rate class (134..136 us unpaced) once an `s_sleep 1` separates the three stores -- and that
 // the same sleeps made the rollout kernel slower.  This file measures, per buffer of one process (so that both classes show up):
-//   bare<G>     : the bare loop, the three stores of a step separated by G idle cycles (s_nop; G = 64 is s_sleep 1)
+//   bare<G>     : the bare loop, the three stores of a step separated by G idle clocks (s_nop)
+//   burst<G>    : the bare loop, three stores back to back and ONE gap of G clocks per step
 //   cells       : the product-shaped rollout step (per-cell byte planes in LDS, uniform RNG actions), stores as the compiler
 //                 places them (= back to back at the end of the step)
-//   paced<G>    : the same step with its stores SPREAD OVER the step: obs as soon as the new position is known (before the LDS
-//                 round trip of the flags read), done when the flags have arrived, reward after G more idle cycles
+//   tail<G>     : cells + one idle gap of G clocks at the end of every step (a pure rate limiter)
+//   paced / spread / pipe : the stores spread over the step (LDS waits or fixed gaps between them; the rows of step t - 1 during step t)
+//   tailx       : tail + a workgroup barrier per step and / or the XCD-aware block order
+//   timer, timer2 : a per-wave deadline on the shader clock (s_memtime), read on / off the critical path
+// FINDINGS (profiles/r03d_store_pacing_*.txt): only the average rate matters (burst 176 = bare g64 = 110 .. 116 us on every buffer
+// against 115 .. 139 us unpaced); the window is narrow (burst 160: collapse on slow buffers again; burst 192: 118 .. 121 everywhere);
+// LDS waits do not pace well; fixed gaps that idle the wave while its own chain waits are too expensive (pipe); a clock read per
+// step costs more than it saves; a barrier per step works in this micro-kernel (122 .. 125 us everywhere) but not in the product's
+// 16-way unrolled body.  What the product does with this: csrc/gu_rollout.hpp, gu_idle.
 // All rollout variants must produce the same checksum.
-//   hipcc --offload-arch=gfx950 -O3 -o store_pacing store_pacing.hip && ./store_pacing [buffers]
+//   hipcc --offload-arch=gfx950 -O3 -o store_pacing store_pacing.hip && ./store_pacing [buffers] [gaps|pipe|rate|timer|sync]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <string>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -431,24 +441,48 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     Args a{};
     a.cells = dc; a.checksum = dsum; a.N = N; a.T = T; a.start = 0;
-    const char *names[] = {"bare g0", "burst 176", "cells", "tail 32", "tmr2 240", "tmr2 256", "tmr2 264", "tmr2 272", "tmr2 280", "tmr2 288", "tmr2 296",
-                           "tmr2 312", "t2ph 256", "t2ph 264", "t2ph 272", "t2ph 280", "t2ph 288", "t2ph 296", "t2ph 312", "tmr2 100"};
-    const int n_var = 20, first_rollout = 2;
-    auto run = [&](int w) {
-        dim3 g(N / 256), b(256);
-        const int periods[] = {240, 256, 264, 272, 280, 288, 296, 312, 256, 264, 272, 280, 288, 296, 312, 100};
-        if (w >= 4) {
-            a.period = periods[w - 4];
-            a.phase = w >= 12 && w < 19;
-        }
-        switch (w) {
-        case 0: k_bare<0><<<g, b>>>(a); break;
-        case 1: k_burst<176><<<g, b>>>(a); break;
-        case 2: k_cells<<<g, b>>>(a); break;
-        case 3: k_tail<32><<<g, b>>>(a); break;
-        default: k_timer2<<<g, b>>>(a); break;
-        }
-    };
+    // variant sets (the profiles/r03d_store_pacing_*.txt files, in the order they were recorded); first_rollout: where the variants
+    // that compute the rollout -- and must agree on its checksum -- begin
+    struct Variant { const char *name; std::function<void(dim3, dim3)> launch; };
+#define BARE(G) {"bare g" #G, [&](dim3 g, dim3 b) { k_bare<G><<<g, b>>>(a); }}
+#define BURST(G) {"burst " #G, [&](dim3 g, dim3 b) { k_burst<G><<<g, b>>>(a); }}
+#define TAIL(G) {"tail " #G, [&](dim3 g, dim3 b) { k_tail<G><<<g, b>>>(a); }}
+#define PACED(G, M) {"paced" #M " g" #G, [&](dim3 g, dim3 b) { k_paced<G, M><<<g, b>>>(a); }}
+#define PIPE(A, B, C) {"pipe " #A "/" #B "/" #C, [&](dim3 g, dim3 b) { k_pipe<A, B, C><<<g, b>>>(a); }}
+#define SPREAD(A, B) {"spread " #A "/" #B, [&](dim3 g, dim3 b) { k_spread<A, B><<<g, b>>>(a); }}
+#define TAILX(NAME, G, SY, XC) {NAME " " #G, [&](dim3 g, dim3 b) { k_tailx<G, SY, XC><<<g, b>>>(a); }}
+#define TIMER(K, NAME, P, PH) {NAME " " #P, [&](dim3 g, dim3 b) { a.period = P; a.phase = PH; K<<<g, b>>>(a); }}
+    const Variant v_cells{"cells", [&](dim3 g, dim3 b) { k_cells<<<g, b>>>(a); }};
+    const std::string set = argc > 2 ? argv[2] : "rate";
+    std::vector<Variant> v;
+    int first_rollout = 0;
+    if (set == "gaps") {          // 1: idle gaps between the three stores, LDS waits as gaps
+        v = {BARE(0), BARE(16), BARE(32), BARE(48), BARE(64), BARE(96), v_cells, PACED(0, 0), PACED(16, 0), PACED(32, 0), PACED(48, 0), PACED(64, 0),
+             PACED(0, 1), PACED(16, 1), PACED(32, 1), PACED(48, 1)};
+        first_rollout = 6;
+    } else if (set == "pipe") {   // 2: the stores of step t - 1 spread over step t with fixed gaps
+        v = {BARE(0), BARE(64), v_cells, PACED(32, 1), PIPE(64, 64, 64), PIPE(64, 64, 32), PIPE(64, 64, 0), PIPE(48, 48, 48), PIPE(80, 80, 0),
+             PIPE(56, 56, 56), PIPE(72, 72, 24)};
+        first_rollout = 2;
+    } else if (set == "rate") {   // 3: is it the smoothness or the rate?
+        v = {BARE(0), BARE(64), BURST(192), BURST(176), BURST(160), BURST(128), BURST(224), v_cells, TAIL(8), TAIL(16), TAIL(24), TAIL(32), TAIL(40),
+             TAIL(48), TAIL(64), TAIL(96), SPREAD(0, 0), SPREAD(32, 32), SPREAD(48, 48), SPREAD(64, 64), SPREAD(96, 0), SPREAD(0, 96)};
+        first_rollout = 7;
+    } else if (set == "timer") {  // 4, 6: a clock deadline per step (s_memtime), read on and off the critical path
+        v = {BARE(0), BURST(176), v_cells, TAIL(32), TIMER(k_timer, "timer", 236, 0), TIMER(k_timer, "timer", 260, 0), TIMER(k_timer, "timer", 276, 0),
+             TIMER(k_timer, "timer", 300, 0), TIMER(k_timer, "tmr ph", 276, 1), TIMER(k_timer2, "tmr2", 100, 0), TIMER(k_timer2, "tmr2", 264, 0),
+             TIMER(k_timer2, "tmr2", 280, 0), TIMER(k_timer2, "tmr2", 296, 0), TIMER(k_timer2, "t2ph", 280, 1)};
+        first_rollout = 2;
+    } else {                      // 5 ("sync"): a workgroup barrier per step, the XCD-aware block order
+        v = {BARE(0), BURST(176), v_cells, TAIL(16), TAIL(32), TAILX("sync", 0, true, false), TAILX("sync", 8, true, false), TAILX("sync", 16, true, false),
+             TAILX("sync", 32, true, false), TAILX("xcd", 0, false, true), TAILX("xcd", 16, false, true), TAILX("xcd", 32, false, true),
+             TAILX("sync+xcd", 0, true, true), TAILX("sync+xcd", 16, true, true), TAILX("sync+xcd", 32, true, true), TAIL(40), TAIL(48)};
+        first_rollout = 2;
+    }
+    const int n_var = (int)v.size();
+    std::vector<const char *> names;
+    for (const Variant &x : v) names.push_back(x.name);
+    auto run = [&](int w) { v[(size_t)w].launch(dim3(N / 256), dim3(256)); };
     // correctness: every rollout variant leaves the same checksum
     a.obs = bufs[0]; a.rew = bufs[0] + plane; a.don = bufs[0] + 2 * plane;
     unsigned long long want = 0;

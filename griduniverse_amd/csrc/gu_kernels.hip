@@ -524,23 +524,60 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
 
 // The pace of this launch: option GU_OPT_ROLLOUT_PACE when set (0 = none), else the calibrated value for this launch kind on
 // this buffer -- calibrated now if it is not known yet.  `slot` = policy * 3 + auto mode (+ 12 for the transition-row kernel);
-// `launch(word)` enqueues the launch with that idle word.  Launches that cannot be bound by the HBM write path (less than 128 MB
-// of rows, or fewer workgroups than half the CUs) are not paced and not calibrated.
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, const std::function<void(uint32_t)> &launch, uint32_t *pace)
+// `launch(parts, word)` enqueues the batch as `parts` launches in a row with that idle word.  Launches that cannot be bound by the
+// HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs) are not paced and not calibrated.
+// `split_parts` > 1: the batch holds more than one wave per SIMD.  There the limiter has nothing to work with -- with four waves
+// per SIMD the kernel is issue-bound within a few per cent of the memory's capacity, every idle turn costs more than it gains, and
+// the stream still collapses on most allocations (262 144 envs: 580 us on slow buffers, 483 on fast ones, paced or not) -- but
+// the SAME batch as `split_parts` launches in a row of one wave per SIMD each, each rate-limited, does not: both forms are
+// calibrated and the faster one is kept (GU_OPT_ROLLOUT_SPLIT: 0 = never split, n = always n parts).
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_parts, const std::function<void(int, uint32_t)> &launch,
+                uint32_t *pace, int *parts)
 {
     *pace = 0;
+    *parts = 1;
+    const int64_t split_opt = gu_opt(h, GU_OPT_ROLLOUT_SPLIT);
+    if (split_opt == 0) split_parts = 1;
+    else if (split_opt > 0) split_parts = (int)std::min<int64_t>(split_opt, blocks);
     const int64_t opt = gu_opt(h, GU_OPT_ROLLOUT_PACE);
     if (opt >= 0) {
         *pace = gu_pace_word(opt);
+        *parts = split_opt > 0 ? split_parts : 1;
         return GU_OK;
     }
-    if ((double)h->N * (double)T * 12.0 < 128e6 || (int64_t)blocks * 2 < h->n_cu) return GU_OK;
+    if ((double)h->N * (double)T * 12.0 < 128e6 || (int64_t)blocks * 2 < h->n_cu) {
+        *parts = split_opt > 0 ? split_parts : 1;
+        return GU_OK;
+    }
     gu_engine::PaceRecord &rec = h->pace[slot];
-    if (!rec.known || rec.buffer != (const void *)h->d_traj || T > 2 * rec.T || 2 * T < rec.T) {
-        int rc = gu_calibrate_pace(h, slot, T, launch, &rec);
-        if (rc != GU_OK) return rc;
+    if (!rec.known || rec.buffer != (const void *)h->d_traj || T > 2 * rec.T || 2 * T < rec.T || (split_opt > 0 && rec.parts != split_parts) ||
+        (split_opt == 0 && rec.parts != 1)) {
+        int rc = GU_OK;
+        if (split_opt <= 0) {
+            rc = gu_calibrate_pace(h, slot, T, [&](uint32_t word) { launch(1, word); }, &rec);
+            if (rc != GU_OK) return rc;
+            rec.parts = 1;
+        }
+        if (split_parts > 1) {
+            gu_engine::PaceRecord split;
+            rc = gu_calibrate_pace(h, slot, T, [&](uint32_t word) { launch(split_parts, word); }, &split);
+            if (rc != GU_OK) return rc;
+            split.parts = split_parts;
+            if (gu_debug())
+                fprintf(stderr, "[gu] store pacing: %d launches in a row %.4f ms against one launch %.4f ms\n", split_parts, split.ms_paced,
+                        split_opt > 0 ? 0.0f : rec.ms_paced);
+            if (split_opt > 0 || split.ms_paced < 0.98f * rec.ms_paced) {
+                const float one = split_opt > 0 ? split.ms_unpaced : rec.ms_unpaced, spent = split_opt > 0 ? 0.0f : rec.calibration_ms;
+                const int32_t seen = split_opt > 0 ? 0 : rec.evaluated;
+                rec = split;
+                rec.ms_unpaced = one;  // (what the batch takes as ONE unpaced launch, when that was measured)
+                rec.calibration_ms += spent;
+                rec.evaluated += seen;
+            }
+        }
     }
     *pace = gu_pace_word(rec.turns);
+    *parts = rec.parts;
     if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
     return GU_OK;
 }
@@ -586,6 +623,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.stream_lds_words = 0;
     const int bs = gu_rollout_block(h);
     a.pace = 0;
+    a.block0 = a.blocks = 0;
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)
     if (policy == GU_POLICY_SAMPLE)
         hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
@@ -606,14 +644,27 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     }
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
     if (traj == 1) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: gu_idle)
+        // (a batch of more than one wave per SIMD may run as several launches in a row: gu_pace_for)
+        const unsigned blocks = gu_blocks(h->N, bs);
+        const int split = (h->n_grids == 1 && (int64_t)blocks > h->n_cu) ? (int)((blocks + h->n_cu - 1) / h->n_cu) : 1;
         RolloutArgs c = a;
-        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, gu_blocks(h->N, bs), [&](uint32_t word) {
+        auto launch = [&](int parts, uint32_t word) {
             c.pace = word;
-            gu_rollout_general(h, c, policy, auto_mode, 1, stats, bs);
-        }, &a.pace);
+            const unsigned per = (blocks + (unsigned)parts - 1) / (unsigned)parts;
+            for (int p = 0; p < parts; ++p) {
+                c.block0 = parts > 1 ? (unsigned)p * per : 0u;
+                c.blocks = parts > 1 ? std::min(per, blocks - (unsigned)p * per) : 0u;
+                if (parts > 1 && c.block0 >= blocks) break;
+                gu_rollout_general(h, c, policy, auto_mode, 1, stats, bs);
+            }
+        };
+        int parts = 1;
+        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, blocks, split, launch, &a.pace, &parts);
         if (rc != GU_OK) return rc;
+        launch(parts, a.pace);
+    } else {
+        gu_rollout_general(h, a, policy, auto_mode, traj, stats, bs);
     }
-    gu_rollout_general(h, a, policy, auto_mode, traj, stats, bs);
     if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
     GU_HIP(hipGetLastError());
     h->steps_taken += (uint32_t)T;

@@ -42,8 +42,10 @@ struct RolloutArgs {
     int32_t stream_lds_off; // GU_POLICY_STREAM, MAP 1: byte offset in LDS of the staged action words [stream_lds_words][blockDim.x] ...
     int32_t stream_lds_words;  // ... and how many words per lane fit (0: every word is read from HBM when its steps are due)
     int32_t xcd_remap;      // workgroup b works on env block (b % 8) * (blocks / 8) + b / 8: one XCD = one contiguous env range
-    uint32_t pace;          // int32-row launches: idle turns (gu_idle) after every chunk of 16 (8) steps -- the rate limiter of the
-                            // store stream; chosen per engine and launch kind by gu_launch_rollout's calibration, 0 = none
+    uint32_t pace;          // int32-row launches: idle word (gu_idle) spent every GU_PACE_EVERY steps -- the rate limiter of the store
+                            // stream; chosen per engine and launch kind by gu_launch_rollout's calibration, 0 = none
+    uint32_t block0, blocks;  // general kernel: this launch covers workgroups block0 .. block0 + blocks - 1 of the batch (blocks = 0:
+                            // all of it) -- a batch of more than one wave per SIMD may run as several launches in a row (below)
 };
 
 // Idle for `turns` turns of a three-instruction scalar loop (~33 clocks a turn: the loop IS its branch penalty).  No memory
@@ -101,8 +103,9 @@ __device__ __forceinline__ void gu_idle(uint32_t pace)
 // written by different XCDs, through different L2s.  With the remap every XCD owns one contiguous eighth of the batch:
 // its L2 then writes back 8x longer contiguous runs of every trajectory row.  (No reuse is at stake -- this is about the
 // write stream's locality.)  Needs a block count divisible by 8.
-__device__ __forceinline__ uint32_t gu_env_block(int32_t xcd_remap)
+__device__ __forceinline__ uint32_t gu_env_block(int32_t xcd_remap, uint32_t block0 = 0)
 {
+    if (block0) return blockIdx.x + block0;  // (a part of the batch: parts are never remapped)
     const uint32_t b = blockIdx.x;
     return xcd_remap ? (b & 7u) * (gridDim.x >> 3) + (b >> 3) : b;
 }
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         for (int32_t i = threadIdx.x; i < a.S; i += blockDim.x) thr_lds[i] = a.pi_thr[i];
         __syncthreads();
     }
-    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * blockDim.x + threadIdx.x;  // (remap only on single-grid engines)
+    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap, a.block0) * blockDim.x + threadIdx.x;  // (remap only on single-grid engines)
     if (e64 >= a.N) return;
     const uint32_t e = (uint32_t)e64;
     LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, e, m);
@@ -471,7 +474,8 @@ template <int POLICY, int AUTO, int TRAJ, bool STATS>
 static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
 {
     RolloutArgs a = a_in;
-    auto blocks_ok = [&](int block) { return gu_blocks(h->N, block) % 8 == 0; };
+    auto blocks_ok = [&](int block) { return a.blocks == 0 && gu_blocks(h->N, block) % 8 == 0; };
+    auto n_blocks = [&](int block) { return a.blocks ? a.blocks : gu_blocks(h->N, block); };  // (a.blocks is in units of `bs`)
     const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
     const int lds_bs = gu_lds_block(h, bs, planes);
     if (lds_bs) {
@@ -485,7 +489,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
         auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 1>;
         if (POLICY == GU_POLICY_STREAM && TRAJ != 0) {
             // staged action words: as many per lane as the LDS share of a block admits at the occupancy this batch needs
-            const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, (gu_blocks(h->N, lds_bs) + h->n_cu - 1) / h->n_cu));
+            const int64_t per_cu = std::min<int64_t>(8, std::max<int64_t>(1, ((int64_t)n_blocks(lds_bs) + h->n_cu - 1) / h->n_cu));
             const int64_t room = h->lds_per_cu / per_cu - (int64_t)lds - 512;
             int64_t kw = std::min<int64_t>({room / ((int64_t)lds_bs * 4), (int64_t)64, (a.T + 15) / 16});
             if (kw >= 4) {
@@ -495,7 +499,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
             }
         }
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_per_cu);
-        hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, lds_bs)), dim3(lds_bs), lds, h->stream, b);
+        hipLaunchKernelGGL(kern, dim3(n_blocks(lds_bs)), dim3(lds_bs), lds, h->stream, b);
         return;
     }
     if constexpr (POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM) {
@@ -504,7 +508,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
             a.xcd_remap = a.xcd_remap && blocks_ok(bs);
             auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 3>;
             if (h->cell_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->cell_bytes);
-            hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, bs)), dim3(bs), (size_t)h->cell_bytes, h->stream, a);
+            hipLaunchKernelGGL(kern, dim3(n_blocks(bs)), dim3(bs), (size_t)h->cell_bytes, h->stream, a);
             return;
         }
         // misaligned multi-grid engine (e.g. one maze per env): private per-lane copies in LDS if 64 of them fit
@@ -517,7 +521,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
         }
     }
     a.xcd_remap = a.xcd_remap && h->n_grids == 1 && blocks_ok(bs);
-    hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 0>), dim3(gu_blocks(h->N, bs)), dim3(bs), 0, h->stream, a);
+    hipLaunchKernelGGL((gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 0>), dim3(n_blocks(bs)), dim3(bs), 0, h->stream, a);
 }
 
 template <int POLICY, int AUTO>
@@ -553,6 +557,7 @@ void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int tr
 // the transition-row kernel (gu_rollout_rows.hip): true when it took the launch (*rc: what its pace calibration returned)
 bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats, int *rc);
 // store pacing (gu_kernels.hip): the idle word of an int32-row launch, calibrated on first use
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, const std::function<void(uint32_t)> &launch, uint32_t *pace);
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_parts, const std::function<void(int, uint32_t)> &launch,
+                uint32_t *pace, int *parts);
 // the K-step kernel (gu_rollout_multi.hip; uniform policy, no trajectory): true when it took the launch
 bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);

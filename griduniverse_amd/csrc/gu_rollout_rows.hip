@@ -456,10 +456,11 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     };
     if (traj == 1) {  // int32 rows: the store stream is rate-limited here too (gu_rollout.hpp: gu_idle; calibrated on first use)
         RolloutArgs c = a;
-        *rc = gu_pace_for(h, 12 + policy * 3 + auto_mode, a.T, grid.x, [&](uint32_t word) {
+        int parts = 1;
+        *rc = gu_pace_for(h, 12 + policy * 3 + auto_mode, a.T, grid.x, 1, [&](int, uint32_t word) {
             c.pace = word;
             launch(c);
-        }, &a.pace);
+        }, &a.pace, &parts);
         if (*rc != GU_OK) return true;
     }
     launch(a);

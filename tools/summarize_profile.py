@@ -69,31 +69,78 @@ def main():
     # MI355X_MICROARCH.md "HBM": WRITE_SIZE and FETCH_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a coalesced
     # read stream, so it is doubled; WRITE_SIZE reads the bytes exactly.  Calibration in our own access pattern: the
     # headline kernel's known write volume is 12 B x N x T + state write-back.
-    per_mode = defaultdict(lambda: defaultdict(list))
+    # bench.py's order of work tells the launch forms apart where kernel name and launch size do not: the headline launches come
+    # first, then `other_modes` (K-step and row-table kernels), then strong_c4 -- whose pacing calibration also tries the batch as
+    # several launches of one wave per SIMD in a row (65 536 lanes each, like the headline's).  Per form the LAST dispatches count
+    # (same launch size as the very last one): calibration launches, over-idled on purpose, and strong_c4's shorter first launch
+    # come before them.  A strong_c4 that runs split is its part x the number of parts.
+    C4_ENVS = 262144
+    TAIL = 8
+
+    def classify(records, tail=TAIL):
+        """records: [(dispatch id, kernel name, grid size, value)] -> {mode: [values per batch launch, steady launches only]}"""
+        records = sorted(records)
+        marker = next((i for i, n, g, v in records if 'gu_rollout_multi_kernel<' in n or 'gu_rollout_rows_kernel<' in n), None)
+        seq = defaultdict(list)
+        for i, n, g, v in records:
+            if 'gu_rollout_multi_kernel<' in n:
+                names['stats_only'] = n
+                if g == 65536:
+                    seq['stats_only'].append((g, v))
+            elif 'gu_rollout_rows_kernel<' in n:
+                names['packed_rows'] = n
+                if g == 65536:
+                    seq['packed_rows'].append((g, v))
+            elif 'gu_rollout_kernel<' in n:
+                names.setdefault('general', n)
+                if marker is None or i < marker:
+                    if g == 65536:
+                        seq['headline'].append((g, v))
+                elif g and C4_ENVS % g == 0 and g >= 65536:
+                    seq['strong_c4'].append((g, v))
+        out = {}
+        for mode, items in seq.items():
+            last_grid = items[-1][0]
+            steady = []
+            for g, v in reversed(items):
+                if g != last_grid or len(steady) == tail:
+                    break
+                steady.append(v)
+            factor = C4_ENVS // last_grid if mode == 'strong_c4' else 1
+            if mode == 'strong_c4':
+                names['strong_c4_parts'] = factor
+            out[mode] = [v * factor for v in reversed(steady)]
+        return out
+
+    def median(v):
+        v = sorted(v)
+        return v[len(v) // 2]
+
     names = {}
-    for d in glob.glob(os.path.join(prof, 'pmc_write')) + glob.glob(os.path.join(prof, 'pmc_fetch')):
-        for r in rows(os.path.join(d, '**', '*counter_collection.csv')):
-            mode = mode_of(r['Kernel_Name'], r['Grid_Size'])
-            if mode and r['Counter_Name'] in ('WRITE_SIZE', 'FETCH_SIZE'):
-                per_mode[mode][r['Counter_Name']].append(float(r['Counter_Value']))
-                names[mode] = r['Kernel_Name']
-    durations = defaultdict(list)
-    for r in kt:
-        mode = mode_of(r['Kernel_Name'], r['Grid_Size_X'])
-        if mode:
-            durations[mode].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
-            names.setdefault(mode, r['Kernel_Name'])
+    per_mode = defaultdict(dict)
+    for counter, d in (('WRITE_SIZE', 'pmc_write'), ('FETCH_SIZE', 'pmc_fetch')):
+        recs = [(int(r['Dispatch_Id']), r['Kernel_Name'], int(r['Grid_Size']), float(r['Counter_Value']))
+                for r in rows(os.path.join(prof, d, '**', '*counter_collection.csv')) if r['Counter_Name'] == counter]
+        for mode, values in classify(recs).items():
+            per_mode[mode][counter] = values
+    dur = classify([(int(r['Dispatch_Id']), r['Kernel_Name'], int(r['Grid_Size_X']), float(int(r['End_Timestamp']) - int(r['Start_Timestamp']))) for r in kt], tail=400)
+    durations = {mode: [int(x) for x in v] for mode, v in dur.items()}
+    for mode in ('headline', 'strong_c4'):
+        names[mode] = names.get('general', '')
     modes = {}
     for mode, counters in per_mode.items():
         if 'WRITE_SIZE' not in counters:
             continue
-        wr = sum(counters['WRITE_SIZE']) / len(counters['WRITE_SIZE']) * 1024.0
+        wr = median(counters['WRITE_SIZE']) * 1024.0
         fetch = counters.get('FETCH_SIZE', [])
-        rd = 2.0 * (sum(fetch) / len(fetch) if fetch else 0.0) * 1024.0
-        entry = dict(write_bytes=wr, read_bytes_corrected=rd, hbm_bytes_per_launch=wr + rd, kernel=names[mode][:120],
-                     dispatches_counted=len(counters['WRITE_SIZE']))
+        rd = 2.0 * (median(fetch) if fetch else 0.0) * 1024.0
+        entry = dict(write_bytes=wr, read_bytes_corrected=rd, hbm_bytes_per_launch=wr + rd, kernel=names.get(mode, '')[:120],
+                     dispatches_counted=len(counters['WRITE_SIZE']), statistic='median of the last %d dispatches of the form' % TAIL)
+        if mode == 'strong_c4' and names.get('strong_c4_parts', 1) > 1:
+            entry['launches_in_a_row'] = names['strong_c4_parts']
         if durations.get(mode):
             entry['kernel_avg_us'] = sum(durations[mode]) / len(durations[mode]) / 1e3
+            entry['kernel_median_us'] = median(durations[mode]) / 1e3
             entry['kernel_dispatches_timed'] = len(durations[mode])
         modes[mode] = entry
     if modes:
@@ -112,11 +159,11 @@ def main():
     json.dump(summary, open(os.path.join(dest, '%s_rocprof_summary.json' % tag), 'w'), indent=1)
     with open(os.path.join(dest, '%s_kernel_stats.txt' % tag), 'w') as f:
         # the rollout kernel serves two launch sizes of the line (65 536 envs: the headline; 262 144: strong_c4): split first
-        f.write('%-90s %6s %12s %12s %12s %12s\n' % ('bench launch form (kernel x launch size)', 'calls', 'avg_us', 'min_us', 'median_us', 'max_us'))
+        f.write('%-90s %6s %12s %12s %12s %12s\n' % ('bench launch form (steady launches: the last of each form)', 'calls', 'avg_us', 'min_us', 'median_us', 'max_us'))
         for mode in MODES:
             v = sorted(durations.get(mode, []))
             if v:
-                f.write('%-90s %6d %12.2f %12.2f %12.2f %12.2f\n' % ('%s: %s' % (mode, names.get(mode, ''))[:90], len(v), sum(v) / len(v) / 1e3,
+                f.write('%-90s %6d %12.2f %12.2f %12.2f %12.2f\n' % ('%s: %s' % (mode, str(names.get(mode, '')))[:90], len(v), sum(v) / len(v) / 1e3,
                                                                    v[0] / 1e3, v[len(v) // 2] / 1e3, v[-1] / 1e3))
         f.write('\n')
         f.write('%-90s %6s %12s %12s %12s %12s\n' % ('kernel', 'calls', 'avg_us', 'min_us', 'median_us', 'max_us'))

@@ -643,6 +643,9 @@ def strong_c4(args, ranks, engine_cls, device):
         for _ in range(args.warmup):
             eng.rollout(args.T, 'uniform', auto_reset=True, trajectory=True)
         wall, kern, _, _ = timed_region(eng, ranks, args.T, args.steps, args.min_seconds / 2)
+        pacing = pacing_block(eng)
+        if pacing:
+            pacing.pop('is', None)  # (explained once, in roofline.store_pacing)
     finally:
         eng.close()
     w_min, w_med, w_max = spread(wall)
@@ -653,7 +656,7 @@ def strong_c4(args, ranks, engine_cls, device):
                 ms_per_step_min=w_min / K * 1e3, ms_per_step_max=w_max / K * 1e3, launch_ms=k_med / K,
                 hbm_gbps_per_gpu=BYTES_PER_ENV_STEP * n * args.T / (k_med / K / 1e3) / 1e9,
                 workload='c4: %s, seed %d, uniform device-RNG actions, auto-reset, int32 trajectory' % (desc, seed),
-                shards_equal_oracle=bool(shards_ok), bit_exact_vs_reference_digest=ref_ok,
+                shards_equal_oracle=bool(shards_ok), bit_exact_vs_reference_digest=ref_ok, store_pacing=pacing,
                 check='first launch (250 steps from reset): every rank\'s full shard trajectory == C oracle'
                       + ('; whole batch sha256 == reference digest c4_lava32_262144x250' if ref is not None else ''))
 

@@ -169,6 +169,19 @@ __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint3
 //       latency-bound modes, the length of the dependent chain is; profiles/r02b_map_ab.txt.  What shortens the chain is the
 //       transition-row table of gu_rollout_rows.hip.)
 #define GU_PRIVATE_PAD 16
+// Cache-policy bits of the trajectory stores (buffer_store aux: 1 = sc0, 2 = nt, 16 = sc1).  The int32 rows go out with sc1:
+// written through at device scope instead of staying dirty in the L2 until they are evicted -- the rows are never read again
+// by the launch, and the memory then sees them in the order the waves issue them, not in the L2's eviction order.  Measured
+// on 24 buffers per variant, processes interleaved (profiles/r03k_store_scope.txt): rate-limited launch 119.4 us without,
+// 116.4 with sc1, 115.3 with sc0 + sc1, 119.2 with nt alone; sustained over 50 launches with sc1 113 .. 114 us on every
+// buffer of the slow kind (6.9 TB/s), 107 .. 108 on fast ones.  The packed row (4 B per env-step) is not bound by the write
+// path and keeps the default policy.
+#ifndef GU_STORE_AUX
+#define GU_STORE_AUX 16
+#endif
+#ifndef GU_STORE_AUX_PACKED
+#define GU_STORE_AUX_PACKED 0
+#endif
 #define GU_MAX_BLOCK 1024
 // TRAJ: 0 = no trajectory; 1 = int32 obs / reward / done rows (12 B per env-step);
 //       2 = ONE packed uint32 row: obs | (reward & 0xFF) << 16 | done << 24 (4 B per env-step, grids up to 65 536 cells)
@@ -252,9 +265,13 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             // (profiles/r01e_auto_form_ab.txt).
             const bool was_done = flags & GU_CELL_TERM;
             ep += was_done;
+#ifdef GU_X_NOCHAIN  /* timing experiment only (wrong results): the move does not wait for the cell record of the last one */
+            s = gu_move(s, start0_flags, act, delta) & 1023;
+#else
             s = was_done ? start0 : s;
             flags = was_done ? start0_flags : flags;
             s = gu_move(s, flags, act, delta);
+#endif
         } else {
             if (AUTO == 2) {
                 if (d) {
@@ -273,11 +290,11 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             fin += (int32_t)d;
         }
         if (TRAJ == 1) {
-            __builtin_amdgcn_raw_buffer_store_b32(s, ro, e4, soff, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(r, rr, e4, soff, 0);
-            __builtin_amdgcn_raw_buffer_store_b32((int32_t)d, rd, e4, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(s, ro, e4, soff, GU_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(r, rr, e4, soff, GU_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32((int32_t)d, rd, e4, soff, GU_STORE_AUX);
         } else if (TRAJ == 2) {
-            __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)s | (((uint32_t)r & 0xFFu) << 16) | (d << 24)), ro, e4, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)s | (((uint32_t)r & 0xFFu) << 16) | (d << 24)), ro, e4, soff, GU_STORE_AUX_PACKED);
         }
     };
     auto step1 = [&](uint32_t act) {  // one step, then advance the resource base by one row

@@ -175,11 +175,11 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         if (TRAJ) {
             const int32_t cell = (int32_t)__builtin_amdgcn_ubfe(rec - lds_base, (uint32_t)shift, 20u - (uint32_t)shift);
             if (TRAJ == 1) {
-                __builtin_amdgcn_raw_buffer_store_b32(cell, ro, e4, soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(r, rr, e4, soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b32((int32_t)dn, rd, e4, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(cell, ro, e4, soff, GU_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(r, rr, e4, soff, GU_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32((int32_t)dn, rd, e4, soff, GU_STORE_AUX);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)cell | (((uint32_t)r & 0xFFu) << 16) | (dn << 24)), ro, e4, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)cell | (((uint32_t)r & 0xFFu) << 16) | (dn << 24)), ro, e4, soff, GU_STORE_AUX_PACKED);
             }
         }
     };

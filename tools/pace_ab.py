@@ -3,6 +3,7 @@
 allocation it gets (no placement search), so both write-rate classes show up.  Per buffer: the bare store probe, us per launch
 unpaced (option rollout_pace = 0), with the calibrated pace (the default), and what the calibration found.
     python tools/pace_ab.py [n_buffers] [envs] [fixed pace values ...]"""
+import os
 import random
 import sys
 
@@ -15,13 +16,15 @@ from griduniverse_amd import _lib  # noqa: E402
 n_buf = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 fixed = [int(x, 0) for x in sys.argv[3:]]
-T, K = 1000, 10
+T, K = 1000, int(os.environ.get('PACE_AB_K', '10'))
 random.seed(123)
 np.random.seed(123)
 env = gua.GridUniverseEnv(grid_shape=(32, 32), random_maze=True)
 spec = gua.GridSpec.from_env(env)
 _lib.set_default_option('traj_candidates', 1)
 import os
+if os.environ.get('PACE_AB_ROWS'):
+    _lib.set_default_option('rollout_rows', 1)  # the transition-row kernel wherever it is eligible
 if os.environ.get('PACE_AB_NO_ROWS'):
     _lib.set_default_option('rollout_rows', 0)  # the general kernel also where the transition-row kernel would take the launch
 engines = []

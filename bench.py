@@ -542,17 +542,18 @@ def device_block(engine_cls, device):
 
 
 def pacing_block(eng):
-    """roofline.store_pacing: what the rollout kernel's rate limiter was calibrated to for the bench launch (idle turns of ~33 clocks
-    every 4 steps), and the launch time the calibration itself measured without and with it."""
+    """roofline.store_pacing: what the rollout kernel's rate limiter was calibrated to for the bench launch (the waves' schedule: 10 ns
+    ticks per 16 steps), and the launch time the calibration itself measured without and with it."""
     if not hasattr(eng, 'rollout_pacing'):
         return None
     info = eng.rollout_pacing('uniform', True)
     if info is None:
         return {'calibrated': False}
     info['calibrated'] = True
-    info['is'] = 'the HBM write path collapses when it is over-driven (5.7 TB/s on most allocations): waves that have put down their ' \
-                 'rows idle `turns` x ~33 clocks every 4 steps, an amount found by timing the kernel itself on this engine and buffer ' \
-                 '(state snapshot and put back); ms_unpaced / ms_paced are the calibration\'s own per-launch times (DESIGN.md section 6)'
+    info['is'] = 'the HBM write path collapses when it is over-driven (5.7 TB/s on most allocations): every wave keeps a schedule -- its ' \
+                 'next 16 steps begin no earlier than `period` ticks of 10 ns after the last ones were due, late waves do not wait --, a ' \
+                 'period found by timing the kernel itself on this engine and buffer (state snapshot and put back); ms_unpaced / ' \
+                 'ms_paced are the calibration\'s own per-launch times (DESIGN.md section 6)'
     return info
 
 

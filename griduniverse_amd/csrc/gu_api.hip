@@ -909,7 +909,7 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
     return rc;
 }
 
-int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *turns, float *ms_unpaced, float *ms_paced,
+int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
                       int32_t *evaluated, float *calibration_ms, int32_t *parts)
 {
     GU_ENTER(h);
@@ -923,7 +923,7 @@ int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t 
     }
     GU_REQUIRE(found != nullptr, GU_ERR_STATE, "no pacing calibration for this launch kind on the current trajectory buffer");
     const gu_engine::PaceRecord &rec = *found;
-    if (turns) *turns = (int32_t)rec.turns;
+    if (period) *period = (int32_t)rec.period;
     if (ms_unpaced) *ms_unpaced = rec.ms_unpaced;
     if (ms_paced) *ms_paced = rec.ms_paced;
     if (evaluated) *evaluated = rec.evaluated;

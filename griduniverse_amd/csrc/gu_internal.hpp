@@ -98,13 +98,13 @@ struct gu_engine {
     uint64_t traj_peak_bytes = 0;               // most device memory the search held at once
     bool traj_registered = false;               // counted in the per-device registry of chosen buffers
 
-    // store pacing of the general rollout kernel's int32-row launches (gu_rollout.hpp: gu_idle), calibrated per launch kind
+    // store pacing of the general rollout kernel's int32-row launches (gu_rollout.hpp: GuPacer), calibrated per launch kind
     // [policy * 3 + auto mode] on the trajectory buffer in use
     struct PaceRecord {
         bool known = false;
         const void *buffer = nullptr;  // the trajectory buffer the calibration ran on
         int64_t T = 0;                 // ... and the launch length
-        uint32_t turns = 0;            // idle turns every GU_PACE_EVERY steps (0: none)
+        uint32_t period = 0;           // the waves' schedule: 10 ns ticks per 16 steps (0: no limiter)
         int32_t parts = 1;             // the batch runs as this many launches in a row (general kernel, more than one wave per SIMD)
         float ms_unpaced = 0.0f, ms_paced = 0.0f, calibration_ms = 0.0f;
         int32_t evaluated = 0;         // candidates timed
@@ -203,7 +203,7 @@ int gu_ensure_scratch(gu_engine *h, size_t bytes);
 // per launch.  (A -DGU_EXPERIMENTS build also consults the environment variable of the same name on every call, for the
 // A/B tools.)
 int64_t gu_opt(const gu_engine *h, int option);
-bool gu_debug();  // GU_DEBUG was set when the library was first asked (read once per process)
+int gu_debug();  // GU_DEBUG's level when the library was first asked (read once per process): 1 = one line per search / calibration, 2 = every candidate
 
 // Raise the dynamic-LDS limit of one kernel instantiation once PER DEVICE (HIP keeps the attribute per device: a process
 // that drives several GPUs must set it on each).  `mask` is a per-instantiation static.

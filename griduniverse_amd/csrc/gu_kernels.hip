@@ -361,13 +361,16 @@ static void gu_rollout_general(gu_engine *h, const RolloutArgs &a, int32_t polic
     }
 }
 
-// How many idle turns (gu_idle, every GU_PACE_EVERY steps) make THIS launch kind fastest on THIS trajectory buffer: the kernel
-// itself is timed -- full-length launches on the engine's own state, which is snapshot first and put back afterwards (positions,
-// rewards, done flags and their ballots, episode counters; the step counter lives on the host and is not advanced), so a
-// calibrated engine continues exactly where an uncalibrated one would.  time(turns) is a plateau (collapsed), a cliff, then a
-// ramp (bound by the idling itself): a geometric ladder finds the region, a fine scan DOWN the ramp from the healthy side finds the
-// floor, and the choice keeps one step of distance from the cliff on the left.  ~100 launches, once per (policy, auto-reset mode,
-// buffer).
+// Which schedule (GuPacer: 10 ns ticks per 16 steps) makes THIS launch kind fastest on THIS trajectory buffer: the kernel itself is
+// timed -- full-length launches on the engine's own state, which is snapshot first and put back afterwards (positions, rewards,
+// done flags and their ballots, episode counters; the step counter lives on the host and is not advanced), so a calibrated engine
+// continues exactly where an uncalibrated one would.  Launch time follows the schedule (period x groups + a constant) down to
+// the memory's capacity; below it the waves fall behind, first gracefully, then the launch collapses (the cliff).  The search:
+// down from the period that equals the unpaced launch time in steps of 4 % until the time jumps, then up from the collapsed
+// side in steps of 1 %, every candidate entered from a COLLAPSED stream (two unpaced launches first) -- the period to keep is
+// the shortest one that gets out of the collapse by itself, because a timed region is not kind either (a pause, a neighbour on
+// the device, and a stream that only holds while it is healthy is collapsed for good).  ~80 launches, once per (policy,
+// auto-reset mode, buffer).
 static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::function<void(uint32_t)> &launch, gu_engine::PaceRecord *rec)
 {
     const auto t_start = std::chrono::steady_clock::now();
@@ -382,15 +385,11 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
         if ((rc = gu_device_copy(h, snap + off, live[k], size[k])) != GU_OK) return rc;
     for (hipEvent_t &ev : h->ev_cal)
         if (!ev) GU_HIP(hipEventCreate(&ev));
-    static const int MAX_TURNS = 1024;
-    std::vector<float> times(MAX_TURNS + 2, 0.0f);
     int evaluated = 0;
     // The device must be at its working clocks first.  A calibration right after start-up, on a GPU still ramping up from idle,
-    // sees a slower transition chain and chooses too little idle time -- and the launch collapses once the clocks are up (5 .. 7
-    // turns chosen instead of 10 .. 11, frac 0.73 .. 0.78 instead of 0.82 in the timed region that followed; with 56 ms of launches
-    // first: 0.82 three times out of three, profiles/r03f_pace_warmup.txt).  The ramp is gradual -- successive launches agree within
-    // 1 % all along it -- so: unpaced launches until the mean of the last 16 agrees with the mean of the 16 before within 0.4 %, for
-    // at least 30 ms when the device has not been running rollouts in the last 50 ms, 150 ms at most.
+    // sees a slower kernel and a different cliff (profiles/r03f_pace_warmup.txt).  The ramp is gradual -- successive launches agree
+    // within 1 % all along it -- so: unpaced launches until the mean of the last 16 agrees with the mean of the 16 before within
+    // 0.4 %, for at least 30 ms when the device has not been running rollouts in the last 50 ms, 150 ms at most.
     {
         const bool cold = h->device < 0 || h->device >= 64 || gu_wall_ms() - g_last_rollout_ms[h->device] > 50.0;
         const double w0 = gu_wall_ms(), at_least = cold ? 30.0 : 0.0;
@@ -415,93 +414,67 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
             if ((stable && waited >= at_least) || waited > 150.0) break;
         }
     }
-    // One measurement of a candidate: a launch to settle, then `reps` timed ones.  Near the cliff the collapsed and the healthy state
-    // are BISTABLE (a candidate just below it can measure fast once and run collapsed ever after: 6 turns, 124 us in a calibration,
-    // 136 us in the timed region that followed), which is why the fine scan below comes down from the healthy side and the choice
-    // keeps a step of distance.
-    auto measure = [&](int turns, int reps, float *ms) -> int {
-        const uint32_t word = gu_pace_word(turns);
-        launch(word);
+    // One measurement: `collapse` unpaced launches (to enter from the collapsed state), `settle` launches with the period, then
+    // `reps` timed ones.
+    auto measure = [&](uint32_t period, int collapse, int settle, int reps, float *ms) -> int {
+        for (int r = 0; r < collapse; ++r) launch(0u);
+        for (int r = 0; r < settle; ++r) launch(period);
         GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
-        for (int r = 0; r < reps; ++r) launch(word);
+        for (int r = 0; r < reps; ++r) launch(period);
         GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
         GU_HIP(hipEventSynchronize(h->ev_cal[1]));
         GU_HIP(hipGetLastError());
         GU_HIP(hipEventElapsedTime(ms, h->ev_cal[0], h->ev_cal[1]));
         *ms /= (float)reps;
-        return GU_OK;
-    };
-    auto time_of = [&](int turns, float *ms) -> int {
-        if (times[turns] > 0.0f) {
-            *ms = times[turns];
-            return GU_OK;
-        }
-        int rc2 = measure(turns, 2, ms);
-        if (rc2 != GU_OK) return rc2;
-        times[turns] = *ms;
         ++evaluated;
         return GU_OK;
     };
-    // coarse: 0 and a geometric ladder (ratio ~1.25: the good window is about a tenth of its own position wide, wherever it lies --
-    // ~10 turns with one wave per SIMD, ~100 with four)
-    std::vector<int> grid = {0};
-    for (double g = 4.0; g < MAX_TURNS + 0.5; g *= 1.25)
-        if ((int)g > grid.back()) grid.push_back((int)g);
-    int best_g = 0;
-    float best = 0.0f, t = 0.0f;
-    for (size_t g = 0; g < grid.size(); ++g) {
-        if ((rc = time_of(grid[g], &t)) != GU_OK) return rc;
-        if (g == 0 || t < best) best = t, best_g = (int)g;
-        if ((int)g >= best_g + 2 && t > 1.5f * best) break;  // well up the ramp: larger values only idle longer
+    float unpaced = 0.0f, t = 0.0f;
+    if ((rc = measure(0u, 0, 1, 4, &unpaced)) != GU_OK) return rc;
+    const double groups = (double)T / 16.0;
+    // down: the period whose schedule equals the unpaced launch, then 4 % less each time, until two points in a row lie 5 % above
+    // the best one (the cliff is behind us) or the schedule is down to half the unpaced time (this launch is not bound by the
+    // write path)
+    std::vector<uint32_t> tried;
+    std::vector<float> tried_ms;
+    float best = unpaced;
+    int above = 0;
+    for (double period = (double)unpaced * 1e5 / groups; period >= 1.0 && period * groups > 0.5e5 * (double)unpaced; period *= 0.96) {
+        const uint32_t p = (uint32_t)(period + 0.5);
+        if (!tried.empty() && p >= tried.back()) continue;
+        if ((rc = measure(p, 0, 1, 3, &t)) != GU_OK) return rc;
+        tried.push_back(p);
+        tried_ms.push_back(t);
+        if (gu_debug() > 1) fprintf(stderr, "[gu]   period %u: %.4f ms\n", p, t);
+        if (t < best) best = t, above = 0;
+        else if (t > 1.05f * best && ++above >= 2) break;
     }
-    // fine, DESCENDING from the healthy side: between the best ladder point's neighbours, every value (narrow gaps) or a ladder of
-    // ratio ~1.06, each entered from a larger amount -- i.e. from a state that was not collapsed -- and timed over four launches.
-    // Down the ramp the time falls until the memory's capacity or the cliff is reached; two values in a row 8 % above the running
-    // minimum mean the cliff is behind us.
-    const int lo = best_g > 0 ? grid[(size_t)best_g - 1] : 0;
-    const int hi = (size_t)best_g + 1 < grid.size() ? grid[(size_t)best_g + 1] : grid[(size_t)best_g];
-    std::vector<int> fine;
-    for (double f = hi; f >= lo - 0.5; f = (hi - lo <= 16) ? f - 1.0 : std::min(f - 1.0, f / 1.06)) fine.push_back((int)f);
-    if (fine.empty() || fine.back() != lo) fine.push_back(lo);
-    std::vector<float> fine_ms(fine.size(), 0.0f);
-    float floor_ms = 0.0f;
-    int at_floor = 0, above = 0;
-    for (size_t k = 0; k < fine.size(); ++k) {
-        if ((rc = measure(fine[k], 4, &t)) != GU_OK) return rc;
-        ++evaluated;
-        fine_ms[k] = t;
-        times[fine[k]] = t;
-        if (k == 0 || t < floor_ms) floor_ms = t, at_floor = (int)k, above = 0;
-        else if (t > 1.08f * floor_ms && ++above >= 2) break;
-    }
-    // The choice.  Coming down from the healthy side is optimistic: the healthy state survives a little below the amount at which
-    // a COLLAPSED stream recovers (hysteresis), and a timed region is not that kind -- a launch after a pause, a neighbour on the
-    // device, and the stream is collapsed and stays so (10 turns chosen this way: blocks of 20 launches at 0.120 and at 0.136 ms in
-    // one run).  The amount to keep is the smallest one that gets OUT of the collapse by itself: going up from just below the
-    // floor, each candidate is entered from the collapsed state (two unpaced launches), given two launches to settle and timed
-    // over four; the first within 4 % of the floor is it.
-    int pick = at_floor;
-    if (at_floor > 0 && fine_ms[(size_t)at_floor - 1] <= 1.03f * floor_ms) pick = at_floor - 1;  // (fallback: a step to the right)
-    for (int k = std::min<int>(at_floor + 1, (int)fine.size() - 1); k >= 0; --k) {
-        if (fine[(size_t)k] == 0) continue;
-        launch(0u);
-        launch(0u);
-        const uint32_t word = gu_pace_word(fine[(size_t)k]);
-        launch(word);
-        if ((rc = measure(fine[(size_t)k], 4, &t)) != GU_OK) return rc;
-        ++evaluated;
-        if (t <= 1.04f * floor_ms) {
-            pick = k;
-            fine_ms[(size_t)k] = t;
-            break;
+    // up from the collapsed side in steps of 1 %: the first period that recovers to within 2 % of the best launch seen and HOLDS it
+    // over 12 launches is kept, plus 1 % (four launches after the recovery say little: at the edge the stream holds for a few
+    // launches and is collapsed again within twenty -- 108 us in the calibration, 115 .. 122 in the 50 launches that followed)
+    uint32_t pick = 0;
+    float pick_ms = unpaced;
+    if (!tried.empty()) {
+        size_t k_best = 0;
+        for (size_t k = 0; k < tried.size(); ++k)
+            if (tried_ms[k] < tried_ms[k_best]) k_best = k;
+        const size_t k_low = std::min(tried.size() - 1, k_best + 1);  // one step below the best point: in the cliff or at its edge
+        const double lo = (double)tried[k_low], hi = k_best > 0 ? (double)tried[k_best - 1] : (double)tried[k_best] * 1.05;
+        for (double period = lo * 1.01; period <= hi * 1.0001; period *= 1.01) {
+            const uint32_t p = (uint32_t)(period + 0.5);
+            if ((rc = measure(p, 2, 2, 12, &t)) != GU_OK) return rc;
+            if (gu_debug() > 1) fprintf(stderr, "[gu]   period %u from the collapsed state: %.4f ms (best %.4f)\n", p, t, best);
+            if (t <= 1.02f * best) {
+                pick = (uint32_t)(period * 1.01 + 0.5), pick_ms = t;
+                break;
+            }
         }
+        if (!pick) pick = k_best > 0 ? tried[k_best - 1] : tried[k_best], pick_ms = k_best > 0 ? tried_ms[k_best - 1] : tried_ms[k_best];
     }
-    int best_turns = fine[(size_t)pick];
-    best = fine_ms[(size_t)pick];
-    if (best_turns > 0) {  // against no pacing at all, measured the same way
-        if ((rc = measure(0, 4, &t)) != GU_OK) return rc;
-        times[0] = t;
-        if (t <= 1.01f * best) best_turns = 0, best = t;
+    if (pick) {  // against no limiter at all, measured the same way
+        if ((rc = measure(0u, 0, 1, 4, &t)) != GU_OK) return rc;
+        unpaced = std::min(unpaced, t);
+        if (unpaced <= 1.01f * pick_ms) pick = 0, pick_ms = unpaced;
     }
     off = 0;
     for (int k = 0; k < 3; off += size[k], ++k)
@@ -510,27 +483,26 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
     rec->known = true;
     rec->buffer = h->d_traj;
     rec->T = T;
-    rec->turns = (uint32_t)best_turns;
-    rec->ms_unpaced = times[0];
-    rec->ms_paced = best;
+    rec->period = pick;
+    rec->ms_unpaced = unpaced;
+    rec->ms_paced = pick_ms;
     rec->evaluated = evaluated;
     rec->calibration_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     if (gu_debug())
-        fprintf(stderr, "[gu] store pacing (%s kernel, policy %d, auto %d, %lld x %lld): %d idle turns per %d steps, %.4f -> %.4f ms per launch, %d candidates in %.1f ms\n",
-                slot >= 12 ? "row-table" : "general", (slot % 12) / 3, slot % 3, (long long)h->N, (long long)T, best_turns, GU_PACE_EVERY, times[0], best, evaluated,
+        fprintf(stderr, "[gu] store pacing (%s kernel, policy %d, auto %d, %lld x %lld): %u ticks of 10 ns per 16 steps, %.4f -> %.4f ms per launch, %d candidates in %.1f ms\n",
+                slot >= 12 ? "row-table" : "general", (slot % 12) / 3, slot % 3, (long long)h->N, (long long)T, pick, unpaced, pick_ms, evaluated,
                 rec->calibration_ms);
     return GU_OK;
 }
 
-// The pace of this launch: option GU_OPT_ROLLOUT_PACE when set (0 = none), else the calibrated value for this launch kind on
-// this buffer -- calibrated now if it is not known yet.  `slot` = policy * 3 + auto mode (+ 12 for the transition-row kernel);
-// `launch(parts, word)` enqueues the batch as `parts` launches in a row with that idle word.  Launches that cannot be bound by the
-// HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs) are not paced and not calibrated.
-// `split_parts` > 1: the batch holds more than one wave per SIMD.  There the limiter has nothing to work with -- with four waves
-// per SIMD the kernel is issue-bound within a few per cent of the memory's capacity, every idle turn costs more than it gains, and
-// the stream still collapses on most allocations (262 144 envs: 580 us on slow buffers, 483 on fast ones, paced or not) -- but
-// the SAME batch as `split_parts` launches in a row of one wave per SIMD each, each rate-limited, does not: both forms are
-// calibrated and the faster one is kept (GU_OPT_ROLLOUT_SPLIT: 0 = never split, n = always n parts).
+// The schedule of this launch: option GU_OPT_ROLLOUT_PACE when set (0 = none, n = that many 10 ns ticks per 16 steps), else the
+// calibrated period for this launch kind on this buffer -- calibrated now if it is not known yet.  `slot` = policy * 3 + auto mode
+// (+ 12 for the transition-row kernel); `launch(parts, period)` enqueues the batch as `parts` launches in a row with that
+// period.  Launches that cannot be bound by the HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs)
+// are not paced and not calibrated.
+// `split_parts` > 1: the batch holds more than one wave per SIMD.  The SAME batch as `split_parts` launches in a row of one wave
+// per SIMD each, each rate-limited, can be faster than one launch: both forms are calibrated and the faster one is kept
+// (GU_OPT_ROLLOUT_SPLIT: 0 = never split, n = always n parts).
 int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_parts, const std::function<void(int, uint32_t)> &launch,
                 uint32_t *pace, int *parts)
 {
@@ -541,7 +513,7 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_pa
     else if (split_opt > 0) split_parts = (int)std::min<int64_t>(split_opt, blocks);
     const int64_t opt = gu_opt(h, GU_OPT_ROLLOUT_PACE);
     if (opt >= 0) {
-        *pace = gu_pace_word(opt);
+        *pace = (uint32_t)opt;
         *parts = split_opt > 0 ? split_parts : 1;
         return GU_OK;
     }
@@ -576,7 +548,7 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_pa
             }
         }
     }
-    *pace = gu_pace_word(rec.turns);
+    *pace = rec.period;
     *parts = rec.parts;
     if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
     return GU_OK;
@@ -643,7 +615,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
         }
     }
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
-    if (traj == 1) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: gu_idle)
+    if (traj == 1) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: GuPacer)
         // (a batch of more than one wave per SIMD may run as several launches in a row: gu_pace_for)
         const unsigned blocks = gu_blocks(h->N, bs);
         const int split = (h->n_grids == 1 && (int64_t)blocks > h->n_cu) ? (int)((blocks + h->n_cu - 1) / h->n_cu) : 1;

@@ -37,7 +37,7 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_TRAJ_STRIDE_MIB", 3072, 0, 1 << 20},
     {"GU_TRAJ_FAR_MIB", 49152, 0, 1 << 22},
     {"GU_TRAJ_PROBE_ALL", 0, 0, 1},
-    {"GU_ROLLOUT_PACE", -1, -1, 0xFFFF},
+    {"GU_ROLLOUT_PACE", -1, -1, 0xFFFFF},
     {"GU_ROLLOUT_SPLIT", -1, -1, 1024},
 };
 const char *g_spec_x[GU_OPT_X_COUNT] = {"GU_TRAJ_UNCACHED", "GU_TRAJ_POISON", "GU_MC_POISON"};
@@ -88,13 +88,13 @@ int64_t gu_opt(const gu_engine *h, int option)
     return d != GU_OPT_UNSET ? d : g_spec[option].builtin;
 }
 
-bool gu_debug()
+int gu_debug()
 {
-    static const bool on = [] {
+    static const int level = [] {
         const char *s = std::getenv("GU_DEBUG");
-        return s && std::atoi(s) != 0;
+        return s ? std::atoi(s) : 0;
     }();
-    return on;
+    return level;
 }
 
 extern "C" {

@@ -42,62 +42,48 @@ struct RolloutArgs {
     int32_t stream_lds_off; // GU_POLICY_STREAM, MAP 1: byte offset in LDS of the staged action words [stream_lds_words][blockDim.x] ...
     int32_t stream_lds_words;  // ... and how many words per lane fit (0: every word is read from HBM when its steps are due)
     int32_t xcd_remap;      // workgroup b works on env block (b % 8) * (blocks / 8) + b / 8: one XCD = one contiguous env range
-    uint32_t pace;          // int32-row launches: idle word (gu_idle) spent every GU_PACE_EVERY steps -- the rate limiter of the store
-                            // stream; chosen per engine and launch kind by gu_launch_rollout's calibration, 0 = none
+    uint32_t pace;          // int32-row launches: the waves' schedule (GuPacer), 10 ns ticks per 16 steps -- the rate limiter of the
+                            // store stream; chosen per engine and launch kind by gu_launch_rollout's calibration, 0 = none
     uint32_t block0, blocks;  // general kernel: this launch covers workgroups block0 .. block0 + blocks - 1 of the batch (blocks = 0:
                             // all of it) -- a batch of more than one wave per SIMD may run as several launches in a row (below)
 };
 
-// Idle for `turns` turns of a three-instruction scalar loop (~33 clocks a turn: the loop IS its branch penalty).  No memory
-// traffic, no vector work; the other waves of the SIMD keep issuing.
+// The rate limiter of the int32-row store stream: every wave keeps a SCHEDULE.  `pace` = ticks of the constant 100 MHz clock
+// (s_memrealtime, 10 ns) per 16 steps; a wave may begin its next group of steps no earlier than its own start + steps done x
+// pace / 16, and does not wait at all when it is late.
 //
-// WHY (round 3; tools/micro/store_pacing.hip, tools/pace_ab.py, profiles/r03d_*): the HBM write path of an MI355X shows
-// CONGESTION COLLAPSE.  65 536 lanes that hand their three rows per step to the memory system as fast as it will take them -- the
-// transition chain needs ~200 clocks per step, the memory ~280 -- keep every queue on the way full, and the sustained rate then
-// DROPS: to 5.7 TB/s on most allocations (round 2's "slow class"), 6.6 on some.  The same stores offered just below the memory's
-// capacity go through at 6.6 .. 7.0 TB/s on EVERY allocation: the bare store loop with one 176-clock gap per step 110 .. 116 us on
-// twelve buffers that take 115 .. 139 us unpaced; this kernel with ~90 idle clocks per step 119 .. 124 us on buffers that take
-// 139 .. 142 us without (and 111 .. 113 instead of 120 on the "fast" ones with ~75).  So a wave that has put down its rows waits a
-// little before it goes on.  Only the average rate matters, not the spacing inside a step (three stores back to back + one gap
-// do as well as three evenly spaced ones) -- but the window is narrow: a tenth too little idle time and the collapse is back, a
-// tenth too much and the launch is bound by its own idling.  Hence:
-//  * the amount is CALIBRATED per engine, trajectory buffer and launch kind by timing this very kernel (gu_launch_rollout:
-//    gu_calibrate_pace), not derived from clock rates;
-//  * it is spent every GU_PACE_EVERY = 4 steps: a run-time delay cannot be fine-grained per step -- one loop turn is 33 clocks, a
-//    computed jump into a run of s_nop costs ~110 clocks before the first one, a clock read per step (s_memtime and a deadline) costs
-//    more than it saves (146 us) -- while per chunk of 16 steps the bursts in between are long enough to bring the collapse back
-//    (best 120 .. 135 us).  Every fourth step: 8 clocks of granularity per step, 119 .. 124 us on every buffer.
-#ifndef GU_PACE_EVERY
-#define GU_PACE_EVERY 4
-#endif
-// `pace` = busy turns | sleeping turns << 8.  A busy turn is one pass of a three-instruction scalar loop (~33 clocks: the loop
-// IS its branch penalty): fine-grained, but it occupies the scalar issue port, which the other waves of the SIMD share -- with
-// four waves per SIMD (262 144 envs) hundreds of busy turns made the launch slower (658 against 582 us).  A sleeping turn puts
-// an `s_sleep 1` (64 clocks off the issue ports) into the loop: ~97 clocks, ~3 busy turns.  gu_pace_word() splits an amount.
-__device__ __forceinline__ void gu_idle(uint32_t pace)
-{
-    uint32_t c;
-    asm volatile("s_and_b32 %0, %1, 0xff\n"
-                 "s_cmp_eq_u32 %0, 0\n"
-                 "s_cbranch_scc1 2f\n"
-                 "1:\n"
-                 "s_sub_u32 %0, %0, 1\n"
-                 "s_cmp_lg_u32 %0, 0\n"
-                 "s_cbranch_scc1 1b\n"
-                 "2:\n"
-                 "s_lshr_b32 %0, %1, 8\n"
-                 "s_cmp_eq_u32 %0, 0\n"
-                 "s_cbranch_scc1 4f\n"
-                 "3:\n"
-                 "s_sleep 1\n"
-                 "s_sub_u32 %0, %0, 1\n"
-                 "s_cmp_lg_u32 %0, 0\n"
-                 "s_cbranch_scc1 3b\n"
-                 "4:"
-                 : "=&s"(c)
-                 : "s"(pace)
-                 : "scc", "memory");
-}
+// WHY (round 3; tools/micro/store_pacing.hip, write_ceiling.hip, store_deadline.hip, tools/pace_ab.py, profiles/r03d_*, r03k_*):
+// the HBM write path of an MI355X shows CONGESTION COLLAPSE.  65 536 lanes that hand their three rows per step to the memory
+// system as fast as it will take them keep every queue on the way full, and the sustained rate then DROPS: to 5.7 TB/s on most
+// allocations (round 2's "slow class"), 6.6 on some.  The same stores offered just below the memory's capacity go through at
+// 7.2 .. 7.5 TB/s on EVERY allocation.  The first limiter (until r03j) idled a fixed number of scalar-loop turns every four
+// steps: it works only while no wave is ever held up -- every wave idles the same amount whether it is ahead or behind, so
+// waves that were blocked stay behind, the rows in flight spread out and the collapse feeds itself; its best setting was the
+// one at which the waves' own pace equalled the memory's (113 .. 116 us per 65 536 x 1000 launch on slow allocations), one turn
+// of 33 clocks less and the launch collapsed.  A schedule has neither problem: late waves catch up, the waves stay within a
+// few rows of each other, and the period has a resolution of 0.6 % (one tick in ~170).  Same kernel, same buffers: 107 .. 110 us
+// (7.2 .. 7.35 TB/s) on slow allocations, 105 .. 107 on fast ones.  One clock read per 16 steps: a read per step costs more than
+// it saves (s_memtime per step: 146 us), per 16 steps it is not measurable.
+//  * the period is CALIBRATED per engine, trajectory buffer and launch kind by timing this very kernel (gu_launch_rollout:
+//    gu_calibrate_pace): launch time follows the schedule down to the memory's capacity, then jumps (the cliff);
+//  * 100 MHz, not the shader clock (s_memtime runs at the engine clock, which moves with load and power).
+struct GuPacer {
+    uint64_t due;
+    uint32_t ticks;
+    __device__ __forceinline__ void start(uint32_t pace)
+    {
+        ticks = pace;
+        due = pace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    }
+    // `steps` steps have just been done (rows stored): wait until their time is up
+    __device__ __forceinline__ void after(uint32_t steps)
+    {
+        if (ticks) {
+            due += (ticks * steps) >> 4;
+            while ((int64_t)(__builtin_amdgcn_s_memrealtime() - due) < 0) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+};
 
 // Workgroups are handed to the 8 XCDs round-robin (workgroup b -> XCD b % 8), so neighbouring env blocks would be
 // written by different XCDs, through different L2s.  With the remap every XCD owns one contiguous eighth of the batch:
@@ -310,18 +296,19 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         if (__all(t_lane == t_first)) {
             uint32_t t = t_first;
             int64_t i = 0;
+            GuPacer pacer;
+            pacer.start(TRAJ == 1 ? a.pace : 0u);
             if (t & 15u) {  // head: finish the current word
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
                 for (; i < a.T && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
+                pacer.after((uint32_t)i);
             }
             for (; i + 16 <= a.T; i += 16, t += 16) {  // body: 16 steps per word, fully unrolled
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) {
-                    step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
-                    if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
-                }
+                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
                 if (TRAJ) rebase(16);
+                pacer.after(16);
             }
             if (i < a.T) {  // tail
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
@@ -340,6 +327,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         // The uploaded stream arrives packed like the uniform policy's RNG words (16 two-bit actions per env and word,
         // gu_pack_actions_kernel), always from row 0.
         const char *pw = pa;  // the word's row base moves (64-bit), the lane offset stays e4
+        GuPacer pacer;
+        pacer.start(TRAJ == 1 ? a.pace : 0u);
         auto load_word = [&](uint32_t soff) {
             return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void *)pw, 0, 0xFFFFFFFFu, 0x00020000), e4, soff, 0);
         };
@@ -370,11 +359,9 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                 for (k = 0; k * 16 + 16 <= steps; ++k) {
                     const uint32_t next = k + 1 < cnt ? sw[(k + 1) * bd] : 0u;  // one word ahead of its steps
 #pragma unroll
-                    for (uint32_t j = 0; j < 16; ++j) {
-                        step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
-                        if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
-                    }
+                    for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
                     if (TRAJ) rebase(16);
+                    pacer.after(16);
                     word = next;
                 }
                 for (int64_t q = k * 16, j = 0; q < steps; ++q, ++j) step1((word >> (2u * (uint32_t)j)) & 3u);  // tail of the stream
@@ -385,11 +372,9 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                 pa, row, e4, a.T, 0,
                 [&](uint32_t word) {
 #pragma unroll
-                    for (uint32_t j = 0; j < 16; ++j) {
-                        step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
-                        if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
-                    }
+                    for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
                     if (TRAJ) rebase(16);
+                    pacer.after(16);
                 },
                 step1);
         }
@@ -399,6 +384,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         // word of the NEXT step is hashed while this step's threshold read is in flight (it does not depend on s).
         uint32_t t = t_lane;
         uint32_t word = POLICY == GU_POLICY_SAMPLE ? gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t) : 0u;
+        GuPacer pacer;
+        pacer.start(TRAJ == 1 ? a.pace : 0u);
         auto run = [&](auto thr_at) {
             auto tstep = [&](uint32_t soff) {
                 if (AUTO == 1) {
@@ -432,11 +419,9 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             int64_t i = 0;
             for (; i + 8 <= a.T; i += 8) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    tstep(j * row32);
-                    if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
-                }
+                for (int j = 0; j < 8; ++j) tstep(j * row32);
                 if (TRAJ) rebase(8);
+                pacer.after(8);
             }
             for (; i < a.T; ++i) {
                 tstep(0);
@@ -463,16 +448,6 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
 // ------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------
-// gu_idle's argument for an idle amount of `turns` busy-turn equivalents (~33 clocks each) every GU_PACE_EVERY steps: busy turns
-// alone up to 15, beyond that sleeping turns (3 equivalents each) plus the remainder.
-static inline uint32_t gu_pace_word(int64_t turns)
-{
-    if (turns <= 0) return 0u;
-    if (turns <= 15) return (uint32_t)turns;
-    const int64_t sleeping = turns / 3 > 0xFFFF ? 0xFFFF : turns / 3;
-    return (uint32_t)(turns - 3 * (turns / 3)) | (uint32_t)(sleeping << 8);
-}
-
 static inline unsigned gu_blocks(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
 // Largest block size <= preferred for which every block uses one grid (0 = none: use the L2 variant)
@@ -573,7 +548,7 @@ void gu_rollout_greedy(gu_engine *h, const RolloutArgs &a, int auto_mode, int tr
 void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
 // the transition-row kernel (gu_rollout_rows.hip): true when it took the launch (*rc: what its pace calibration returned)
 bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats, int *rc);
-// store pacing (gu_kernels.hip): the idle word of an int32-row launch, calibrated on first use
+// store pacing (gu_kernels.hip): the schedule of an int32-row launch (ticks per 16 steps), calibrated on first use
 int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_parts, const std::function<void(int, uint32_t)> &launch,
                 uint32_t *pace, int *parts);
 // the K-step kernel (gu_rollout_multi.hip; uniform policy, no trajectory): true when it took the launch

@@ -223,6 +223,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         emit(prev, soff);
     };
     auto nothing = [] {};
+    GuPacer pacer;
+    pacer.start(TRAJ == 1 ? a.pace : 0u);
     auto step1 = [&](uint32_t x) {
         step(x, 0, nothing);
         if (TRAJ) rebase(1);
@@ -240,15 +242,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             if (t & 15u) {  // head: finish the current word
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
                 for (; i < a.T && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
+                pacer.after((uint32_t)i);
             }
             for (; i + 16 <= a.T; i += 16, t += 16) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) {
-                    step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
-                    if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);  // (gu_rollout.hpp)
-                }
+                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
                 if (TRAJ) rebase(16);
+                pacer.after(16);  // (gu_rollout.hpp: GuPacer)
             }
             if (i < a.T) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
@@ -283,11 +284,9 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         };
         for (; i + 8 <= a.T; i += 8) {
 #pragma unroll
-            for (uint32_t j = 0; j < 8; ++j) {
-                pstep(j * row32);
-                if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
-            }
+            for (uint32_t j = 0; j < 8; ++j) pstep(j * row32);
             if (TRAJ) rebase(8);
+            pacer.after(8);
         }
         for (; i < a.T; ++i) {
             pstep(0);
@@ -299,11 +298,9 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             pa, row, e4, a.T, 1,
             [&](uint32_t word) {
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) {
-                    step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
-                    if (TRAJ == 1 && (j & (GU_PACE_EVERY - 1)) == GU_PACE_EVERY - 1 && a.pace) gu_idle(a.pace);
-                }
+                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
                 if (TRAJ) rebase(16);
+                pacer.after(16);
             },
             step1);
     }
@@ -454,7 +451,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         default: rows_dispatch<GU_POLICY_SAMPLE>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
         }
     };
-    if (traj == 1) {  // int32 rows: the store stream is rate-limited here too (gu_rollout.hpp: gu_idle; calibrated on first use)
+    if (traj == 1) {  // int32 rows: the store stream is rate-limited here too (gu_rollout.hpp: GuPacer; calibrated on first use)
         RolloutArgs c = a;
         int parts = 1;
         *rc = gu_pace_for(h, 12 + policy * 3 + auto_mode, a.T, grid.x, 1, [&](int, uint32_t word) {

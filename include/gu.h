@@ -100,7 +100,7 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_TRAJ_STRIDE_MIB 15     /* spacer size (3072)                                                                   */
 #define GU_OPT_TRAJ_FAR_MIB 16        /* most memory the search may hold at once (49152)                                      */
 #define GU_OPT_TRAJ_PROBE_ALL 17      /* 1 = probe every candidate, no early stop (measurement aid)                           */
-#define GU_OPT_ROLLOUT_PACE 18        /* store pacing of int32-row launches: idle turns every 4 steps; -1 = calibrate (default), 0 = none */
+#define GU_OPT_ROLLOUT_PACE 18        /* store pacing of int32-row launches: 10 ns ticks per 16 steps; -1 = calibrate (default), 0 = none */
 #define GU_OPT_ROLLOUT_SPLIT 19       /* int32-row launches of more than one wave per SIMD as n launches in a row: -1 = calibrate
                                          (default), 0 = never, n = always n                                                   */
 #define GU_OPT_COUNT 20
@@ -213,8 +213,8 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done);
  * number of episodes finished during this call are kept for gu_read_stats. */
 int gu_reserve_trajectory(gu_handle h, int64_t T);
 /* Where an allocation lands in HBM changes how fast it can be written (round 2: 5.7 .. 6.9 TB/s for 786 MB buffers of one process
- * with an unthrottled store stream; since the rollout kernel rate-limits its stores -- see gu_rollout_pacing -- 6.4 .. 6.6 against
- * 6.8 .. 7.1), so gu_reserve_trajectory CHOOSES a buffer of 64 MB and more: it allocates candidates one after
+ * with an unthrottled store stream; since the rollout kernel rate-limits its stores -- see gu_rollout_pacing -- 7.2 .. 7.3 against
+ * 7.4 .. 7.5), so gu_reserve_trajectory CHOOSES a buffer of 64 MB and more: it allocates candidates one after
  * the other, writes each once in the rollout's own store shape, and keeps the fastest.  The search
  *   - stops at the first clearly fast candidate (14 % quicker than the slowest seen; on gfx950 also: 6.5 TB/s or more);
  *   - looks at GU_OPT_TRAJ_CANDIDATES (4) back-to-back candidates; only when GU_OPT_TRAJ_FAR_CANDIDATES (0) is set and those were
@@ -236,16 +236,17 @@ int gu_trajectory_placement_detail(gu_handle h, int32_t capacity, float *probe_m
 int gu_probe_trajectory(gu_handle h, float *milliseconds);
 int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 /* Store pacing.  The HBM write path shows congestion collapse: lanes that hand their rows to the memory system as fast as it will
- * take them are served at 5.7 TB/s on most allocations, the same stores offered just below the memory's capacity at 6.6 .. 7.0 on
- * every one.  Launches with GU_F_TRAJECTORY of 128 MB of rows and more therefore idle a few clocks every
- * four steps; how many is CALIBRATED the first time a launch kind (policy, auto-reset) runs on a trajectory buffer, by timing the
- * kernel itself on the engine's own state (snapshot before, put back after: results never depend on it; that first gu_rollout is
- * synchronous and takes ~20 launches longer).  GU_OPT_ROLLOUT_PACE fixes the amount instead (0 = none).  This reports what the
- * calibration found for a launch kind: idle turns (~33 clocks each) per 4 steps, ms per launch without and with them, candidates
- * timed, ms spent calibrating, and `parts`: a batch of more than one wave per SIMD (where idling has nothing to work with) is also
- * tried as several launches in a row of one wave per SIMD each, each rate-limited, and runs that way when it is faster
- * (GU_OPT_ROLLOUT_SPLIT).  GU_ERR_STATE when that kind has not been calibrated (not launched yet, or too small to pace). */
-int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *turns, float *ms_unpaced, float *ms_paced,
+ * take them are served at 5.7 TB/s on most allocations, the same stores offered just below the memory's capacity at 7.2 .. 7.5 on
+ * every one.  Launches with GU_F_TRAJECTORY of 128 MB of rows and more therefore keep a SCHEDULE: a wave
+ * begins its next 16 steps no earlier than `period` ticks of the 100 MHz clock (10 ns) after the last ones were due, and never
+ * waits when it is late.  The period is CALIBRATED the first time a launch kind (policy, auto-reset) runs on a trajectory buffer,
+ * by timing the kernel itself on the engine's own state (snapshot before, put back after: results never depend on it; that first
+ * gu_rollout is synchronous and takes ~80 launches longer).  GU_OPT_ROLLOUT_PACE fixes the period instead (0 = no limiter).
+ * This reports what the calibration found for a launch kind: the period, ms per launch without and with the limiter, candidates
+ * timed, ms spent calibrating, and `parts`: a batch of more than one wave per SIMD is also tried as several launches in a row of
+ * one wave per SIMD each, each rate-limited, and runs that way when it is faster (GU_OPT_ROLLOUT_SPLIT).  GU_ERR_STATE when that
+ * kind has not been calibrated (not launched yet, or too small to pace). */
+int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
                       int32_t *evaluated, float *calibration_ms, int32_t *parts);
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);
 int gu_read_trajectory_packed(gu_handle h, int64_t t0, int64_t T, uint32_t *packed);   /* [T][N] after GU_F_PACKED */

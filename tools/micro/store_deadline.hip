@@ -1,0 +1,170 @@
+// store_deadline.hip -- a rate limiter that keeps the waves ON A SCHEDULE instead of idling a fixed amount (tuning evidence, not
+// product code; round 3)
+//
+// write_ceiling.hip: rate-limited, the bare store stream of the bench launch sustains 7.4 .. 7.6 TB/s on every buffer while it is
+// blocked at its stores half of the time; the product-shaped step sustains 6.7 .. 7.0 and only when it is never blocked (its best idle
+// amount is the one at which the waves' own pace equals the memory's; one turn less and the launch collapses).  Idea: what a
+// blocked product-shaped kernel loses is the lockstep of its waves (every wave idles the same amount whether it is ahead or behind,
+// so waves that were held up stay behind, the rows in flight spread out, and the memory sees ever more rows at once).  A deadline
+// does not have that problem: wave w may start group k (16 steps) no earlier than start_w + k * period on the shader clock, and
+// does not wait at all when it is late.
+//   turns    : gu_idle every 4 steps (the product's limiter)
+//   deadline : one clock read per 16 steps (s_memtime / s_memrealtime) and s_sleep until the group's time has come
+// The step is write_ceiling.hip's k_prod<15> (byte cell table, the product's arithmetic, 16 steps unrolled, scalar row offsets, sc1).
+//   hipcc --offload-arch=gfx950 -O3 -o store_deadline store_deadline.hip && ./store_deadline [buffers]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ void idle(uint32_t pace)
+{
+    uint32_t c;
+    asm volatile("s_and_b32 %0, %1, 0xff\n s_cmp_eq_u32 %0, 0\n s_cbranch_scc1 2f\n 1:\n s_sub_u32 %0, %0, 1\n s_cmp_lg_u32 %0, 0\n s_cbranch_scc1 1b\n 2:\n"
+                 "s_lshr_b32 %0, %1, 8\n s_cmp_eq_u32 %0, 0\n s_cbranch_scc1 4f\n 3:\n s_sleep 1\n s_sub_u32 %0, %0, 1\n s_cmp_lg_u32 %0, 0\n s_cbranch_scc1 3b\n 4:"
+                 : "=&s"(c) : "s"(pace) : "scc", "memory");
+}
+
+// MODE 0: turns every 4 steps; 1: deadline per 16 steps on s_memtime; 2: deadline per 16 steps on s_memrealtime (100 MHz);
+// 3: deadline per 4 steps on s_memtime
+template <int MODE>
+__device__ __forceinline__ uint64_t now()
+{
+    return MODE == 2 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_prod(int *base, size_t plane, int N, int T, uint32_t pace, unsigned long long *ticks)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t cell[2048];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+        const int x = i & 31, y = i >> 5;
+        const bool term = (x == 31 && y == 31) || (x == 16 && y > 3 && y < 28);
+        uint8_t open = (y > 0 ? 1 : 0) | (x < 31 ? 2 : 0) | (y < 31 ? 4 : 0) | (x > 0 ? 8 : 0);
+        if (((i * 2654435761u) >> 24) < 64 && i > 0) open &= 0x5;
+        cell[i] = term ? 16 : open;
+        cell[1024 + i] = (uint8_t)(int8_t)(term ? 10 : -1);
+    }
+    __syncthreads();
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x, off = e * 4u;
+    const uint64_t lut = (uint64_t)(uint16_t)(int16_t)(-32) | (1ull << 16) | (32ull << 32) | (0xFFFFull << 48);
+    int s = 0, r = -1, d = 0;
+    uint32_t flags = cell[0], word = 0;
+    char *p = (char *)base;
+    const uint32_t row = (uint32_t)N * 4u;
+    const uint64_t t0 = now<MODE>();
+    uint64_t due = t0;
+    auto wait_until_due = [&]() {
+        due += pace;
+        while ((int64_t)(now<MODE>() - due) < 0) __builtin_amdgcn_s_sleep(1);
+    };
+    for (int t = 0; t < T; t += 16, p += (size_t)row * 16) {
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p, 0, 0xFFFFFFFFu, 0x00020000),
+                                     rr = __builtin_amdgcn_make_buffer_rsrc(p + plane * 4, 0, 0xFFFFFFFFu, 0x00020000),
+                                     rd = __builtin_amdgcn_make_buffer_rsrc(p + 2 * plane * 4, 0, 0xFFFFFFFFu, 0x00020000);
+        uint32_t h = (e * 0x9E3779B9u) ^ (uint32_t)(t >> 4);
+        h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+        word = h;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t act = __builtin_amdgcn_ubfe(word, 2 * j, 2);
+            const int delta = __builtin_amdgcn_sbfe((int)(uint32_t)(lut >> (act << 4)), 0, 16);
+            const bool was_done = flags & 16u;
+            s = was_done ? 0 : s;
+            flags = was_done ? (uint32_t)cell[0] : flags;
+            s = __mul24((int)__builtin_amdgcn_ubfe(flags, act, 1), delta) + s;
+            flags = cell[s];
+            r = (int8_t)cell[1024 + s];
+            d = (int)((flags >> 4) & 1u);
+            __builtin_amdgcn_raw_buffer_store_b32(s, ro, off, j * row, 16);
+            __builtin_amdgcn_raw_buffer_store_b32(r, rr, off, j * row, 16);
+            __builtin_amdgcn_raw_buffer_store_b32(d, rd, off, j * row, 16);
+            if (MODE == 0 && (j & 3) == 3 && pace) idle(pace);
+            if (MODE == 3 && (j & 3) == 3 && pace) wait_until_due();
+        }
+        if ((MODE == 1 || MODE == 2) && pace) wait_until_due();
+    }
+    if (e == 0) *ticks = now<MODE>() - t0;
+}
+
+int main(int argc, char **argv)
+{
+    const int N = 65536, T = 992;
+    const int buffers = argc > 1 ? atoi(argv[1]) : 5;
+    const size_t plane = (size_t)N * 1000, bytes = 3 * (size_t)N * T * 4;
+    std::vector<int *> bufs;
+    for (int b = 0; b < buffers; ++b) {
+        int *p = nullptr;
+        if (hipMalloc(&p, 3 * plane * 4) != hipSuccess) break;
+        bufs.push_back(p);
+    }
+    unsigned long long *dticks;
+    CK(hipMalloc(&dticks, 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto launch = [&](int mode, int *buf, uint32_t pace) {
+        const dim3 g(N / 256), b(256);
+        if (mode == 0) k_prod<0><<<g, b>>>(buf, plane, N, T, pace, dticks);
+        else if (mode == 1) k_prod<1><<<g, b>>>(buf, plane, N, T, pace, dticks);
+        else if (mode == 2) k_prod<2><<<g, b>>>(buf, plane, N, T, pace, dticks);
+        else k_prod<3><<<g, b>>>(buf, plane, N, T, pace, dticks);
+    };
+    auto timed = [&](int mode, int *buf, uint32_t pace, int reps) {
+        launch(mode, buf, pace);
+        launch(mode, buf, pace);
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) launch(mode, buf, pace);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms / reps * 1e3f;
+    };
+    for (int i = 0; i < 300; ++i) launch(0, bufs[0], 0u);
+    CK(hipDeviceSynchronize());
+    printf("%zu buffers; %.0f MB per launch; us per launch (TB/s)\n", bufs.size(), bytes / 1e6);
+    const char *names[] = {"turns per 4 steps", "deadline per 16 steps, s_memtime", "deadline per 16 steps, s_memrealtime", "deadline per 4 steps, s_memtime"};
+    for (size_t b = 0; b < bufs.size(); ++b) {
+        int *buf = bufs[b];
+        const float t0 = timed(0, buf, 0u, 8);
+        printf("buffer %zu: unpaced %.1f us\n", b, t0);
+        {  // the product's limiter: sustained time per idle amount
+            printf("  %-40s", names[0]);
+            float best = 1e9f;
+            int at = 0;
+            for (int turns = 14; turns >= 6; --turns) {
+                const float t = timed(0, buf, (uint32_t)turns, 30);
+                printf(" %d:%.1f", turns, t);
+                if (t < best) best = t, at = turns;
+            }
+            printf("  -> %.1f @%d (%.2f)\n", best, at, bytes / (best * 1e-6) / 1e12);
+        }
+        for (int mode = 1; mode <= 3; ++mode) {
+            // ticks of an unpaced launch on this clock -> ticks per group at that rate; scan the period downwards from 1.05 x
+            launch(mode, buf, 0u);
+            CK(hipDeviceSynchronize());
+            unsigned long long ticks = 0;
+            CK(hipMemcpy(&ticks, dticks, 8, hipMemcpyDeviceToHost));
+            const int groups = mode == 3 ? T / 4 : T / 16;
+            const double per_group = (double)ticks / groups;  // ticks per group of wave 0 in an unpaced launch
+            printf("  %-40s (%llu ticks per unpaced launch)", names[mode], ticks);
+            float best = 1e9f;
+            double at = 0;
+            for (double f = 1.30; f >= 0.699; f -= 0.02) {  // the period as a fraction of that
+                const uint32_t period = (uint32_t)(per_group * f + 0.5);
+                if (!period) continue;
+                const float t = timed(mode, buf, period, 30);
+                printf(" %.2f:%.1f", f, t);
+                if (t < best) best = t, at = f;
+            }
+            printf("  -> %.1f @%.2f (%.2f)\n", best, at, bytes / (best * 1e-6) / 1e12);
+        }
+        fflush(stdout);
+    }
+    return 0;
+}

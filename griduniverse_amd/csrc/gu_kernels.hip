@@ -499,7 +499,7 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
 // calibrated period for this launch kind on this buffer -- calibrated now if it is not known yet.  `slot` = policy * 3 + auto mode
 // (+ 12 for the transition-row kernel); `launch(parts, period)` enqueues the batch as `parts` launches in a row with that
 // period.  Launches that cannot be bound by the HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs)
-// are not paced and not calibrated.
+// or launches of fewer than 64 steps are not paced and not calibrated.
 // `split_parts` > 1: the batch holds more than one wave per SIMD.  The SAME batch as `split_parts` launches in a row of one wave
 // per SIMD each, each rate-limited, can be faster than one launch: both forms are calibrated and the faster one is kept
 // (GU_OPT_ROLLOUT_SPLIT: 0 = never split, n = always n parts).
@@ -517,7 +517,7 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_pa
         *parts = split_opt > 0 ? split_parts : 1;
         return GU_OK;
     }
-    if ((double)h->N * (double)T * 12.0 < 128e6 || (int64_t)blocks * 2 < h->n_cu) {
+    if ((double)h->N * (double)T * 12.0 < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64) {  // (T < 64: fewer than four groups to schedule)
         *parts = split_opt > 0 ? split_parts : 1;
         return GU_OK;
     }
@@ -530,7 +530,11 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_pa
             if (rc != GU_OK) return rc;
             rec.parts = 1;
         }
-        if (split_parts > 1) {
+        // (with the schedule limiter one launch of several waves per SIMD paces well -- 262 144 envs: 7.2 TB/s -- so the split form
+        // is only looked at when the single launch stayed below 6.2 TB/s and the batch is at most 8 waves per SIMD, or when the option
+        // asks for it)
+        const double one_tbps = rec.ms_paced > 0.0f ? (double)h->N * (double)T * 12.0 / ((double)rec.ms_paced * 1e9) : 0.0;
+        if (split_parts > 1 && (split_opt > 0 || (one_tbps < 6.2 && split_parts <= 8))) {
             gu_engine::PaceRecord split;
             rc = gu_calibrate_pace(h, slot, T, [&](uint32_t word) { launch(split_parts, word); }, &split);
             if (rc != GU_OK) return rc;

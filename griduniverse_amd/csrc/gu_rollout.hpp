@@ -160,13 +160,13 @@ __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint3
 // by the launch, and the memory then sees them in the order the waves issue them, not in the L2's eviction order.  Measured
 // on 24 buffers per variant, processes interleaved (profiles/r03k_store_scope.txt): rate-limited launch 119.4 us without,
 // 116.4 with sc1, 115.3 with sc0 + sc1, 119.2 with nt alone; sustained over 50 launches with sc1 113 .. 114 us on every
-// buffer of the slow kind (6.9 TB/s), 107 .. 108 on fast ones.  The packed row (4 B per env-step) is not bound by the write
-// path and keeps the default policy.
+// buffer of the slow kind (6.9 TB/s), 107 .. 108 on fast ones.  The packed row (4 B per env-step, transition-row kernel: 48 us
+// per 65 536 x 1000 launch) gains too: 1.35e12 -> 1.44e12 env-steps/s, three runs each (profiles/r03m_packed_sc1.txt).
 #ifndef GU_STORE_AUX
 #define GU_STORE_AUX 16
 #endif
 #ifndef GU_STORE_AUX_PACKED
-#define GU_STORE_AUX_PACKED 0
+#define GU_STORE_AUX_PACKED 16
 #endif
 #define GU_MAX_BLOCK 1024
 // TRAJ: 0 = no trajectory; 1 = int32 obs / reward / done rows (12 B per env-step);
@@ -300,6 +300,13 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             pacer.start(TRAJ == 1 ? a.pace : 0u);
             if (t & 15u) {  // head: finish the current word
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+                for (; i < a.T && (t & 7u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
+                if ((t & 15u) == 8u && i + 8 <= a.T) {  // the word's second half as one unrolled block (launches of 1000 steps begin here every other time)
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) step(__builtin_amdgcn_ubfe(word, 16 + 2 * j, 2), j * row32);
+                    if (TRAJ) rebase(8);
+                    i += 8, t += 8;
+                }
                 for (; i < a.T && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
                 pacer.after((uint32_t)i);
             }
@@ -312,7 +319,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             }
             if (i < a.T) {  // tail
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
-                for (uint32_t j = 0; i < a.T; ++i, ++j) step1((word >> (2u * j)) & 3u);
+                uint32_t j = 0;
+                if (i + 8 <= a.T) {  // its first half as one unrolled block
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; ++k) step(__builtin_amdgcn_ubfe(word, 2 * k, 2), k * row32);
+                    if (TRAJ) rebase(8);
+                    i += 8, j = 8;
+                }
+                for (; i < a.T; ++i, ++j) step1((word >> (2u * j)) & 3u);
             }
         } else {
             uint32_t t = t_lane;

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """The rollout kernel with and without its store pacing on MANY trajectory buffers of one process -- each engine takes the first
 allocation it gets (no placement search), so both write-rate classes show up.  Per buffer: the bare store probe, us per launch
-unpaced (option rollout_pace = 0), with the calibrated pace (the default), and what the calibration found.
-    python tools/pace_ab.py [n_buffers] [envs] [fixed pace values ...]"""
+unpaced (option rollout_pace = 0), with the calibrated schedule (the default), what the calibration found, and the launch time at
+fixed periods (10 ns ticks per 16 steps).  PACE_AB_K = launches per figure (10), PACE_AB_ROWS / PACE_AB_NO_ROWS force / forbid the
+transition-row kernel, GU_LIB_PATH another build of the library (make variant ...).
+    python tools/pace_ab.py [n_buffers] [envs] [fixed periods ...]"""
 import os
 import random
 import sys

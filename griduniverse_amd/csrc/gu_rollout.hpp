@@ -176,6 +176,20 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
 {
     constexpr bool LDS = MAP == 1 || MAP == 3;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // this lane's state is asked for BEFORE the grid is staged, so that the two round trips to memory overlap (at the start of a
+    // launch the loads queue behind what is left of the previous launch's stores: ~1 us each)
+    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap, a.block0) * blockDim.x + threadIdx.x;  // (remap only on single-grid engines)
+    const bool live = e64 < a.N;
+    const uint32_t e = (uint32_t)e64;
+    int32_t s = 0, r = 0;
+    uint32_t d = 0, ep = 0, tcount0 = 0;
+    if (live) {
+        s = a.pos[e];
+        r = a.reward[e];
+        d = (uint32_t)a.done[e];
+        ep = a.episode[e];
+        tcount0 = a.tcount[e];
+    }
     CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem, a.gs, MAP == 3 ? 1 : 2);
     const uint8_t *greedy = a.greedy;
     if (MAP == 1 && POLICY == GU_POLICY_GREEDY) {
@@ -193,9 +207,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         for (int32_t i = threadIdx.x; i < a.S; i += blockDim.x) thr_lds[i] = a.pi_thr[i];
         __syncthreads();
     }
-    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap, a.block0) * blockDim.x + threadIdx.x;  // (remap only on single-grid engines)
-    if (e64 >= a.N) return;
-    const uint32_t e = (uint32_t)e64;
+    if (!live) return;
     LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, e, m);
     if (MAP == 2) {  // copy this lane's own flags plane (which also carries the reward code) into its LDS slice
         uint8_t *mine = smem + threadIdx.x * (a.cell_bytes + GU_PRIVATE_PAD);
@@ -204,11 +216,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         m.f = mine;
     }
 
-    int32_t s = a.pos[e];
-    int32_t r = a.reward[e];
-    uint32_t d = (uint32_t)a.done[e];
-    uint32_t ep = a.episode[e];
-    const uint32_t t_lane = a.tcount[e] + a.steps_taken;
+    const uint32_t t_lane = tcount0 + a.steps_taken;
     const uint32_t prefix = gu_rng_prefix(a.seed_prefix, a.env_id0 + e);
     uint32_t flags = m.f[s];
     int32_t ret = 0, fin = 0;
@@ -315,7 +323,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
 #pragma unroll
                 for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
                 if (TRAJ) rebase(16);
-                pacer.after(16);
+                if (i + 16 < a.T) pacer.after(16);  // (nothing to wait for behind the last group)
             }
             if (i < a.T) {  // tail
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
@@ -435,7 +443,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
 #pragma unroll
                 for (int j = 0; j < 8; ++j) tstep(j * row32);
                 if (TRAJ) rebase(8);
-                pacer.after(8);
+                if (i + 8 < a.T) pacer.after(8);
             }
             for (; i < a.T; ++i) {
                 tstep(0);

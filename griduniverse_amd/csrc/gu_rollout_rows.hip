@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
 #pragma unroll
                 for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
                 if (TRAJ) rebase(16);
-                pacer.after(16);  // (gu_rollout.hpp: GuPacer)
+                if (i + 16 < a.T) pacer.after(16);  // (gu_rollout.hpp: GuPacer)
             }
             if (i < a.T) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
 #pragma unroll
             for (uint32_t j = 0; j < 8; ++j) pstep(j * row32);
             if (TRAJ) rebase(8);
-            pacer.after(8);
+            if (i + 8 < a.T) pacer.after(8);
         }
         for (; i < a.T; ++i) {
             pstep(0);

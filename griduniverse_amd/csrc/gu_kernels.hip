@@ -499,7 +499,7 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
 // calibrated period for this launch kind on this buffer -- calibrated now if it is not known yet.  `slot` = policy * 3 + auto mode
 // (+ 12 for the transition-row kernel); `launch(parts, period)` enqueues the batch as `parts` launches in a row with that
 // period.  Launches that cannot be bound by the HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs)
-// or launches of fewer than 64 steps are not paced and not calibrated.
+// launches of fewer than 64 steps, and batches of more than four waves per SIMD are not paced and not calibrated.
 // `split_parts` > 1: the batch holds more than one wave per SIMD.  The SAME batch as `split_parts` launches in a row of one wave
 // per SIMD each, each rate-limited, can be faster than one launch: both forms are calibrated and the faster one is kept
 // (GU_OPT_ROLLOUT_SPLIT: 0 = never split, n = always n parts).
@@ -517,7 +517,10 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_pa
         *parts = split_opt > 0 ? split_parts : 1;
         return GU_OK;
     }
-    if ((double)h->N * (double)T * 12.0 < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64) {  // (T < 64: fewer than four groups to schedule)
+    // (T < 64: fewer than four groups to schedule.  More than four waves per SIMD -- 524 288 envs and more on 256 CUs --: a per-wave
+    // schedule found nothing to gain there, 0.96 .. 0.98 ms = 6.4 .. 6.6 TB/s with and without, and a batch that does not fit the
+    // device at once is not on one schedule anyway; profiles/r03n_batch_sizes.txt)
+    if ((double)h->N * (double)T * 12.0 < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024) {
         *parts = split_opt > 0 ? split_parts : 1;
         return GU_OK;
     }

@@ -237,7 +237,7 @@ int gu_probe_trajectory(gu_handle h, float *milliseconds);
 int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 /* Store pacing.  The HBM write path shows congestion collapse: lanes that hand their rows to the memory system as fast as it will
  * take them are served at 5.7 TB/s on most allocations, the same stores offered just below the memory's capacity at 7.2 .. 7.5 on
- * every one.  Launches with GU_F_TRAJECTORY of 128 MB of rows and 64 steps and more therefore keep a SCHEDULE: a wave
+ * every one.  Launches with GU_F_TRAJECTORY of 128 MB of rows and 64 steps and more (up to four waves per SIMD) keep a SCHEDULE: a wave
  * begins its next 16 steps no earlier than `period` ticks of the 100 MHz clock (10 ns) after the last ones were due, and never
  * waits when it is late.  The period is CALIBRATED the first time a launch kind (policy, auto-reset) runs on a trajectory buffer,
  * by timing the kernel itself on the engine's own state (snapshot before, put back after: results never depend on it; that first

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -94,11 +95,13 @@ int main(int argc, char **argv)
 {
     const int N = 65536, T = 992;
     const int buffers = argc > 1 ? atoi(argv[1]) : 5;
-    const size_t plane = (size_t)N * 1000, bytes = 3 * (size_t)N * T * 4;
+    size_t plane = (size_t)N * 1000;  // (ints; + a skew when argv[2] = "skew")
+    const size_t bytes = 3 * (size_t)N * T * 4;
+    const bool skew_mode = argc > 2 && std::string(argv[2]) == "skew";
     std::vector<int *> bufs;
     for (int b = 0; b < buffers; ++b) {
         int *p = nullptr;
-        if (hipMalloc(&p, 3 * plane * 4) != hipSuccess) break;
+        if (hipMalloc(&p, 3 * plane * 4 + (64u << 20)) != hipSuccess) break;
         bufs.push_back(p);
     }
     unsigned long long *dticks;
@@ -129,6 +132,36 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
     printf("%zu buffers; %.0f MB per launch; us per launch (TB/s)\n", bufs.size(), bytes / 1e6);
     const char *names[] = {"turns per 4 steps", "deadline per 16 steps, s_memtime", "deadline per 16 steps, s_memrealtime", "deadline per 4 steps, s_memtime"};
+    if (skew_mode) {
+        // the three planes 250 MiB apart (the product's layout) against planes skewed by a few KB .. MB: does it matter which
+        // channels the three rows of a step fall on?  Schedule limiter (s_memrealtime per 16 steps), period scanned, 30 launches each
+        const size_t skews[] = {0, 1024, 4096, 4096 + 256, 16384 + 1024, 65536 + 4096, 262144 + 16384, (1u << 20) + 65536, (2u << 20) / 3 / 256 * 256, (5u << 20) + 4096};
+        printf("%-10s", "skew B");
+        for (size_t b = 0; b < bufs.size(); ++b) printf("  buffer %zu: unpaced -> best @period", b);
+        printf("\n");
+        for (size_t skew : skews) {
+            plane = (size_t)N * 1000 + skew / 4;
+            printf("%-10zu", skew);
+            for (int *buf : bufs) {
+                const float t0 = timed(0, buf, 0u, 8);
+                launch(2, buf, 0u);
+                CK(hipDeviceSynchronize());
+                unsigned long long ticks = 0;
+                CK(hipMemcpy(&ticks, dticks, 8, hipMemcpyDeviceToHost));
+                const double per_group = (double)ticks / (T / 16);
+                float best = 1e9f;
+                double at = 0;
+                for (double f = 1.16; f >= 0.939; f -= 0.02) {
+                    const float t = timed(2, buf, (uint32_t)(per_group * f + 0.5), 30);
+                    if (t < best) best = t, at = per_group * f;
+                }
+                printf("  %6.1f -> %6.1f @%3.0f       ", t0, best, at);
+            }
+            printf("\n");
+            fflush(stdout);
+        }
+        return 0;
+    }
     for (size_t b = 0; b < bufs.size(); ++b) {
         int *buf = bufs[b];
         const float t0 = timed(0, buf, 0u, 8);

@@ -259,13 +259,9 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             // (profiles/r01e_auto_form_ab.txt).
             const bool was_done = flags & GU_CELL_TERM;
             ep += was_done;
-#ifdef GU_X_NOCHAIN  /* timing experiment only (wrong results): the move does not wait for the cell record of the last one */
-            s = gu_move(s, start0_flags, act, delta) & 1023;
-#else
             s = was_done ? start0 : s;
             flags = was_done ? start0_flags : flags;
             s = gu_move(s, flags, act, delta);
-#endif
         } else {
             if (AUTO == 2) {
                 if (d) {

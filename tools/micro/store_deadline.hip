@@ -38,8 +38,9 @@ __device__ __forceinline__ uint64_t now()
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256) k_prod(int *base, size_t plane, int N, int T, uint32_t pace, unsigned long long *ticks)
+__global__ void __launch_bounds__(256) k_prod(int *base, size_t plane, int N, int T, uint32_t pace_in, unsigned long long *ticks)
 {
+    uint32_t pace = pace_in;
     __shared__ __attribute__((aligned(16))) uint8_t cell[2048];
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
         const int x = i & 31, y = i >> 5;
@@ -57,7 +58,9 @@ __global__ void __launch_bounds__(256) k_prod(int *base, size_t plane, int N, in
     char *p = (char *)base;
     const uint32_t row = (uint32_t)N * 4u;
     const uint64_t t0 = now<MODE>();
-    uint64_t due = t0;
+    const uint32_t credit = (pace >> 20) * 8u;  // ticks the schedule starts in the past (experiment "credit": a launch begins by catching up)
+    pace &= 0xFFFFFu;
+    uint64_t due = t0 - credit;
     auto wait_until_due = [&]() {
         due += pace;
         while ((int64_t)(now<MODE>() - due) < 0) __builtin_amdgcn_s_sleep(1);
@@ -132,6 +135,32 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
     printf("%zu buffers; %.0f MB per launch; us per launch (TB/s)\n", bufs.size(), bytes / 1e6);
     const char *names[] = {"turns per 4 steps", "deadline per 16 steps, s_memtime", "deadline per 16 steps, s_memrealtime", "deadline per 4 steps, s_memtime"};
+    if (argc > 2 && std::string(argv[2]) == "credit") {
+        // the schedule of every launch begins `credit` in the past: its first groups run unthrottled until they have caught up, which
+        // is what a schedule that continues across launches would do after the gap between two launches
+        const int credits[] = {0, 100, 200, 300, 400, 600};  // ticks of 10 ns
+        for (size_t b = 0; b < bufs.size(); ++b) {
+            int *buf = bufs[b];
+            const float t0 = timed(0, buf, 0u, 8);
+            launch(2, buf, 0u);
+            CK(hipDeviceSynchronize());
+            unsigned long long ticks = 0;
+            CK(hipMemcpy(&ticks, dticks, 8, hipMemcpyDeviceToHost));
+            const double per_group = (double)ticks / (T / 16);
+            printf("buffer %zu: unpaced %.1f us; per credit (us) and period: us per launch over 30 launches\n", b, t0);
+            for (int credit : credits) {
+                printf("  credit %3.0f us:", credit / 100.0);
+                for (double f = 1.12; f >= 0.959; f -= 0.02) {
+                    const uint32_t period = (uint32_t)(per_group * f + 0.5);
+                    const float t = timed(2, buf, period | ((uint32_t)(credit / 8) << 20), 30);
+                    printf(" %u:%.1f", period, t);
+                }
+                printf("\n");
+            }
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (skew_mode) {
         // the three planes 250 MiB apart (the product's layout) against planes skewed by a few KB .. MB: does it matter which
         // channels the three rows of a step fall on?  Schedule limiter (s_memrealtime per 16 steps), period scanned, 30 launches each

@@ -224,6 +224,15 @@ def test_store_pacing_is_calibrated_on_the_engines_own_state_and_never_changes_a
     for split in (3, 5, 257):
         assert all(np.array_equal(a, b) for a, b in zip(ragged[0], ragged[split])), split
     gu_option('rollout_split', None)
+    # launches of fewer than 64 steps and batches of more than four waves per SIMD keep no schedule (nothing to gain there)
+    cus = Engine.device_info(0)['cus']
+    gu_option('rollout_pace', None)
+    for n_big, t_big in ((65536, 48), (cus * 1024 + 256, 64)):
+        with Engine(n_big, spec_of(meta), seed=9) as eng:
+            eng.reset()
+            eng.reserve_trajectory(t_big)
+            eng.rollout(t_big, 'uniform', True, True)
+            assert eng.rollout_pacing() is None, (n_big, t_big)
     # a caller-supplied stream and a table policy are calibrated as launch kinds of their own
     gu_option('rollout_pace', None)
     with Engine(N, spec_of(meta), seed=9) as eng:

@@ -80,7 +80,10 @@ struct GuPacer {
     {
         if (ticks) {
             due += (ticks * steps) >> 4;
-            while ((int64_t)(__builtin_amdgcn_s_memrealtime() - due) < 0) __builtin_amdgcn_s_sleep(1);
+            // (bounded: an `s_sleep 1` takes ~30 ns = 3 ticks, so a wait of one period ends within ticks / 3 turns; a clock that does
+            // not advance must slow the launch down, not hang it)
+            for (uint32_t turn = 0; turn < 2u * ticks + 64u && (int64_t)(__builtin_amdgcn_s_memrealtime() - due) < 0; ++turn)
+                __builtin_amdgcn_s_sleep(1);
         }
     }
 };

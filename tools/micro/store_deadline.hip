@@ -161,6 +161,53 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (argc > 2 && std::string(argv[2]) == "pitch") {
+        // the row pitch: 65 536 columns x 4 B = 2^18 B (the product's) against padded pitches -- does the power-of-two distance between
+        // the rows in flight cost write rate?  Schedule limiter, period scanned, 30 launches per figure
+        const int pads[] = {0, 64, 256, 1024, 4096};  // ints (3 planes x 1000 rows x pad must fit the 64 MB of slack behind each buffer)
+        printf("%-10s", "pad B");
+        for (size_t b = 0; b < bufs.size(); ++b) printf("  buffer %zu: unpaced -> best @period", b);
+        printf("\n");
+        for (int pad : pads) {
+            const int pitch = N + pad;
+            plane = (size_t)pitch * 1000;
+            printf("%-10d", pad * 4);
+            for (int *buf : bufs) {
+                auto launch_p = [&](int mode, uint32_t pace) {
+                    if (mode == 0) k_prod<0><<<dim3(N / 256), dim3(256)>>>(buf, plane, pitch, T, pace, dticks);
+                    else k_prod<2><<<dim3(N / 256), dim3(256)>>>(buf, plane, pitch, T, pace, dticks);
+                };
+                auto timed_p = [&](int mode, uint32_t pace, int reps) {
+                    launch_p(mode, pace);
+                    launch_p(mode, pace);
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < reps; ++i) launch_p(mode, pace);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipGetLastError());
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    return ms / reps * 1e3f;
+                };
+                const float t0 = timed_p(0, 0u, 8);
+                launch_p(2, 0u);
+                CK(hipDeviceSynchronize());
+                unsigned long long ticks = 0;
+                CK(hipMemcpy(&ticks, dticks, 8, hipMemcpyDeviceToHost));
+                const double per_group = (double)ticks / (T / 16);
+                float best = 1e9f;
+                double at = 0;
+                for (double f = 1.16; f >= 0.939; f -= 0.02) {
+                    const float t = timed_p(2, (uint32_t)(per_group * f + 0.5), 30);
+                    if (t < best) best = t, at = per_group * f;
+                }
+                printf("  %6.1f -> %6.1f @%3.0f       ", t0, best, at);
+            }
+            printf("\n");
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (skew_mode) {
         // the three planes 250 MiB apart (the product's layout) against planes skewed by a few KB .. MB: does it matter which
         // channels the three rows of a step fall on?  Schedule limiter (s_memrealtime per 16 steps), period scanned, 30 launches each

@@ -910,7 +910,7 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
 }
 
 int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
-                      int32_t *evaluated, float *calibration_ms, int32_t *parts)
+                      int32_t *evaluated, float *calibration_ms)
 {
     GU_ENTER(h);
     GU_REQUIRE(policy_kind >= GU_POLICY_UNIFORM && policy_kind <= GU_POLICY_SAMPLE, GU_ERR_INVALID, "unknown policy kind %d", policy_kind);
@@ -928,7 +928,6 @@ int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t 
     if (ms_paced) *ms_paced = rec.ms_paced;
     if (evaluated) *evaluated = rec.evaluated;
     if (calibration_ms) *calibration_ms = rec.calibration_ms;
-    if (parts) *parts = rec.parts;
     return GU_OK;
 }
 

@@ -105,7 +105,6 @@ struct gu_engine {
         const void *buffer = nullptr;  // the trajectory buffer the calibration ran on
         int64_t T = 0;                 // ... and the launch length
         uint32_t period = 0;           // the waves' schedule: 10 ns ticks per 16 steps (0: no limiter)
-        int32_t parts = 1;             // the batch runs as this many launches in a row (general kernel, more than one wave per SIMD)
         float ms_unpaced = 0.0f, ms_paced = 0.0f, calibration_ms = 0.0f;
         int32_t evaluated = 0;         // candidates timed
     } pace[24];  // [policy * 3 + auto mode] for the general kernel, + 12 for the transition-row kernel

@@ -497,66 +497,30 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
 
 // The schedule of this launch: option GU_OPT_ROLLOUT_PACE when set (0 = none, n = that many 10 ns ticks per 16 steps), else the
 // calibrated period for this launch kind on this buffer -- calibrated now if it is not known yet.  `slot` = policy * 3 + auto mode
-// (+ 12 for the transition-row kernel); `launch(parts, period)` enqueues the batch as `parts` launches in a row with that
-// period.  Launches that cannot be bound by the HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs)
-// launches of fewer than 64 steps, and batches of more than four waves per SIMD are not paced and not calibrated.
-// `split_parts` > 1: the batch holds more than one wave per SIMD.  The SAME batch as `split_parts` launches in a row of one wave
-// per SIMD each, each rate-limited, can be faster than one launch: both forms are calibrated and the faster one is kept
-// (GU_OPT_ROLLOUT_SPLIT: 0 = never split, n = always n parts).
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_parts, const std::function<void(int, uint32_t)> &launch,
-                uint32_t *pace, int *parts)
+// (+ 12 for the transition-row kernel); `launch(period)` enqueues the launch with that period.  Launches that cannot be bound by
+// the HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs), launches of fewer than 64 steps, and
+// batches of more than four waves per SIMD are not paced and not calibrated.
+// (Until r03o a batch of more than one wave per SIMD was also tried as several launches in a row of one wave per SIMD each: the
+// idle-turn limiter had nothing to work with at four waves per SIMD.  The schedule has -- 262 144 envs in ONE launch 0.44 .. 0.48 ms,
+// as four launches in a row 0.56 .. 0.59, profiles/r03o_c4_split.txt -- and that form is gone.)
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, const std::function<void(uint32_t)> &launch, uint32_t *pace)
 {
     *pace = 0;
-    *parts = 1;
-    const int64_t split_opt = gu_opt(h, GU_OPT_ROLLOUT_SPLIT);
-    if (split_opt == 0) split_parts = 1;
-    else if (split_opt > 0) split_parts = (int)std::min<int64_t>(split_opt, blocks);
     const int64_t opt = gu_opt(h, GU_OPT_ROLLOUT_PACE);
     if (opt >= 0) {
         *pace = (uint32_t)opt;
-        *parts = split_opt > 0 ? split_parts : 1;
         return GU_OK;
     }
     // (T < 64: fewer than four groups to schedule.  More than four waves per SIMD -- 524 288 envs and more on 256 CUs --: a per-wave
     // schedule found nothing to gain there, 0.96 .. 0.98 ms = 6.4 .. 6.6 TB/s with and without, and a batch that does not fit the
     // device at once is not on one schedule anyway; profiles/r03n_batch_sizes.txt)
-    if ((double)h->N * (double)T * 12.0 < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024) {
-        *parts = split_opt > 0 ? split_parts : 1;
-        return GU_OK;
-    }
+    if ((double)h->N * (double)T * 12.0 < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024) return GU_OK;
     gu_engine::PaceRecord &rec = h->pace[slot];
-    if (!rec.known || rec.buffer != (const void *)h->d_traj || T > 2 * rec.T || 2 * T < rec.T || (split_opt > 0 && rec.parts != split_parts) ||
-        (split_opt == 0 && rec.parts != 1)) {
-        int rc = GU_OK;
-        if (split_opt <= 0) {
-            rc = gu_calibrate_pace(h, slot, T, [&](uint32_t word) { launch(1, word); }, &rec);
-            if (rc != GU_OK) return rc;
-            rec.parts = 1;
-        }
-        // (with the schedule limiter one launch of several waves per SIMD paces well -- 262 144 envs: 7.2 TB/s -- so the split form
-        // is only looked at when the single launch stayed below 6.2 TB/s and the batch is at most 8 waves per SIMD, or when the option
-        // asks for it)
-        const double one_tbps = rec.ms_paced > 0.0f ? (double)h->N * (double)T * 12.0 / ((double)rec.ms_paced * 1e9) : 0.0;
-        if (split_parts > 1 && (split_opt > 0 || (one_tbps < 6.2 && split_parts <= 8))) {
-            gu_engine::PaceRecord split;
-            rc = gu_calibrate_pace(h, slot, T, [&](uint32_t word) { launch(split_parts, word); }, &split);
-            if (rc != GU_OK) return rc;
-            split.parts = split_parts;
-            if (gu_debug())
-                fprintf(stderr, "[gu] store pacing: %d launches in a row %.4f ms against one launch %.4f ms\n", split_parts, split.ms_paced,
-                        split_opt > 0 ? 0.0f : rec.ms_paced);
-            if (split_opt > 0 || split.ms_paced < 0.98f * rec.ms_paced) {
-                const float one = split_opt > 0 ? split.ms_unpaced : rec.ms_unpaced, spent = split_opt > 0 ? 0.0f : rec.calibration_ms;
-                const int32_t seen = split_opt > 0 ? 0 : rec.evaluated;
-                rec = split;
-                rec.ms_unpaced = one;  // (what the batch takes as ONE unpaced launch, when that was measured)
-                rec.calibration_ms += spent;
-                rec.evaluated += seen;
-            }
-        }
+    if (!rec.known || rec.buffer != (const void *)h->d_traj || T > 2 * rec.T || 2 * T < rec.T) {
+        const int rc = gu_calibrate_pace(h, slot, T, launch, &rec);
+        if (rc != GU_OK) return rc;
     }
     *pace = rec.period;
-    *parts = rec.parts;
     if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
     return GU_OK;
 }
@@ -602,7 +566,6 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.stream_lds_words = 0;
     const int bs = gu_rollout_block(h);
     a.pace = 0;
-    a.block0 = a.blocks = 0;
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)
     if (policy == GU_POLICY_SAMPLE)
         hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
@@ -623,24 +586,13 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     }
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
     if (traj == 1) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: GuPacer)
-        // (a batch of more than one wave per SIMD may run as several launches in a row: gu_pace_for)
-        const unsigned blocks = gu_blocks(h->N, bs);
-        const int split = (h->n_grids == 1 && (int64_t)blocks > h->n_cu) ? (int)((blocks + h->n_cu - 1) / h->n_cu) : 1;
         RolloutArgs c = a;
-        auto launch = [&](int parts, uint32_t word) {
-            c.pace = word;
-            const unsigned per = (blocks + (unsigned)parts - 1) / (unsigned)parts;
-            for (int p = 0; p < parts; ++p) {
-                c.block0 = parts > 1 ? (unsigned)p * per : 0u;
-                c.blocks = parts > 1 ? std::min(per, blocks - (unsigned)p * per) : 0u;
-                if (parts > 1 && c.block0 >= blocks) break;
-                gu_rollout_general(h, c, policy, auto_mode, 1, stats, bs);
-            }
-        };
-        int parts = 1;
-        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, blocks, split, launch, &a.pace, &parts);
+        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, gu_blocks(h->N, bs), [&](uint32_t period) {
+            c.pace = period;
+            gu_rollout_general(h, c, policy, auto_mode, 1, stats, bs);
+        }, &a.pace);
         if (rc != GU_OK) return rc;
-        launch(parts, a.pace);
+        gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);
     } else {
         gu_rollout_general(h, a, policy, auto_mode, traj, stats, bs);
     }

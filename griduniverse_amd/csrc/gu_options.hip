@@ -38,7 +38,6 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_TRAJ_FAR_MIB", 49152, 0, 1 << 22},
     {"GU_TRAJ_PROBE_ALL", 0, 0, 1},
     {"GU_ROLLOUT_PACE", -1, -1, 0xFFFFF},
-    {"GU_ROLLOUT_SPLIT", -1, -1, 1024},
 };
 const char *g_spec_x[GU_OPT_X_COUNT] = {"GU_TRAJ_UNCACHED", "GU_TRAJ_POISON", "GU_MC_POISON"};
 

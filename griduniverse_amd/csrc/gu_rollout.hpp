@@ -44,8 +44,6 @@ struct RolloutArgs {
     int32_t xcd_remap;      // workgroup b works on env block (b % 8) * (blocks / 8) + b / 8: one XCD = one contiguous env range
     uint32_t pace;          // int32-row launches: the waves' schedule (GuPacer), 10 ns ticks per 16 steps -- the rate limiter of the
                             // store stream; chosen per engine and launch kind by gu_launch_rollout's calibration, 0 = none
-    uint32_t block0, blocks;  // general kernel: this launch covers workgroups block0 .. block0 + blocks - 1 of the batch (blocks = 0:
-                            // all of it) -- a batch of more than one wave per SIMD may run as several launches in a row (below)
 };
 
 // The rate limiter of the int32-row store stream: every wave keeps a SCHEDULE.  `pace` = ticks of the constant 100 MHz clock
@@ -92,9 +90,8 @@ struct GuPacer {
 // written by different XCDs, through different L2s.  With the remap every XCD owns one contiguous eighth of the batch:
 // its L2 then writes back 8x longer contiguous runs of every trajectory row.  (No reuse is at stake -- this is about the
 // write stream's locality.)  Needs a block count divisible by 8.
-__device__ __forceinline__ uint32_t gu_env_block(int32_t xcd_remap, uint32_t block0 = 0)
+__device__ __forceinline__ uint32_t gu_env_block(int32_t xcd_remap)
 {
-    if (block0) return blockIdx.x + block0;  // (a part of the batch: parts are never remapped)
     const uint32_t b = blockIdx.x;
     return xcd_remap ? (b & 7u) * (gridDim.x >> 3) + (b >> 3) : b;
 }
@@ -181,7 +178,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // this lane's state is asked for BEFORE the grid is staged, so that the two round trips to memory overlap (at the start of a
     // launch the loads queue behind what is left of the previous launch's stores: ~1 us each)
-    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap, a.block0) * blockDim.x + threadIdx.x;  // (remap only on single-grid engines)
+    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * blockDim.x + threadIdx.x;  // (remap only on single-grid engines)
     const bool live = e64 < a.N;
     const uint32_t e = (uint32_t)e64;
     int32_t s = 0, r = 0;
@@ -487,8 +484,8 @@ template <int POLICY, int AUTO, int TRAJ, bool STATS>
 static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
 {
     RolloutArgs a = a_in;
-    auto blocks_ok = [&](int block) { return a.blocks == 0 && gu_blocks(h->N, block) % 8 == 0; };
-    auto n_blocks = [&](int block) { return a.blocks ? a.blocks : gu_blocks(h->N, block); };  // (a.blocks is in units of `bs`)
+    auto blocks_ok = [&](int block) { return gu_blocks(h->N, block) % 8 == 0; };
+    auto n_blocks = [&](int block) { return gu_blocks(h->N, block); };
     const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
     const int lds_bs = gu_lds_block(h, bs, planes);
     if (lds_bs) {
@@ -570,7 +567,6 @@ void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int tr
 // the transition-row kernel (gu_rollout_rows.hip): true when it took the launch (*rc: what its pace calibration returned)
 bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats, int *rc);
 // store pacing (gu_kernels.hip): the schedule of an int32-row launch (ticks per 16 steps), calibrated on first use
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int split_parts, const std::function<void(int, uint32_t)> &launch,
-                uint32_t *pace, int *parts);
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, const std::function<void(uint32_t)> &launch, uint32_t *pace);
 // the K-step kernel (gu_rollout_multi.hip; uniform policy, no trajectory): true when it took the launch
 bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);

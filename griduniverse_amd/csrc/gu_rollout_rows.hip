@@ -453,11 +453,10 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     };
     if (traj == 1) {  // int32 rows: the store stream is rate-limited here too (gu_rollout.hpp: GuPacer; calibrated on first use)
         RolloutArgs c = a;
-        int parts = 1;
-        *rc = gu_pace_for(h, 12 + policy * 3 + auto_mode, a.T, grid.x, 1, [&](int, uint32_t word) {
-            c.pace = word;
+        *rc = gu_pace_for(h, 12 + policy * 3 + auto_mode, a.T, grid.x, [&](uint32_t period) {
+            c.pace = period;
             launch(c);
-        }, &a.pace, &parts);
+        }, &a.pace);
         if (*rc != GU_OK) return true;
     }
     launch(a);

@@ -224,16 +224,16 @@ class Engine(object):
     def rollout_pacing(self, policy='uniform', auto_reset=True):
         """What the store-pacing calibration found for this launch kind on the current trajectory buffer (include/gu.h:
         gu_rollout_pacing): dict(period=the waves' schedule in 10 ns ticks per 16 steps (0: no limiter), ms_unpaced, ms_paced, evaluated,
-        calibration_ms, parts), or None when the
+        calibration_ms), or None when the
         kind has not been calibrated (not launched yet, or too small to be paced)."""
-        period, n, parts = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(1)
+        period, n = ctypes.c_int32(0), ctypes.c_int32(0)
         a, b, c = ctypes.c_float(0.0), ctypes.c_float(0.0), ctypes.c_float(0.0)
         rc = self.lib.gu_rollout_pacing(self._h, _POLICIES[policy], _lib.F_AUTO_RESET if auto_reset else 0, ctypes.byref(period),
-                                        ctypes.byref(a), ctypes.byref(b), ctypes.byref(n), ctypes.byref(c), ctypes.byref(parts))
+                                        ctypes.byref(a), ctypes.byref(b), ctypes.byref(n), ctypes.byref(c))
         if rc == -4:
             return None
         check(rc)
-        return dict(period=period.value, ms_unpaced=a.value, ms_paced=b.value, evaluated=n.value, calibration_ms=c.value, parts=parts.value)
+        return dict(period=period.value, ms_unpaced=a.value, ms_paced=b.value, evaluated=n.value, calibration_ms=c.value)
 
     def read_trajectory(self, t0, T, pinned=False):
         """Rows t0..t0+T-1 of the trajectory as obs/reward/done int32[T, N].  pinned=True returns views of

@@ -113,7 +113,7 @@ def test_options_have_defaults_ranges_and_process_wide_values(lib):
     for name, bad in (('rollout_block', 100), ('rows_copies', 3), ('rollout_multi_k', 3), ('vi_path', 9), ('traj_candidates', 0)):
         with pytest.raises(_lib.GuError):
             _lib.set_default_option(name, bad)
-    assert sorted(v for v in _lib.OPTIONS.values() if v < 100) == list(range(1, 20))
+    assert sorted(v for v in _lib.OPTIONS.values() if v < 100) == list(range(1, 19))
 
 
 def test_the_product_library_has_no_code_for_the_unsafe_experiments(lib, monkeypatch):

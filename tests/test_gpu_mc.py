@@ -300,9 +300,8 @@ def test_random_grids_table_policies_property():
             eng.vi_set(np.zeros(S), pi)
             eng.reset()
             eng.reserve_trajectory(T)
-            if kind is True:  # int32 rows: forced store pacing / split launches / kernel choice never change a byte
+            if kind is True:  # int32 rows: forced store pacing / kernel choice never change a byte
                 eng.set_option('rollout_pace', (None, 0, int(rs.randint(1, 600)))[trial % 3])
-                eng.set_option('rollout_split', (None, 0, 2, int(rs.randint(3, 9)))[(trial // 3) % 4])
                 eng.set_option('rollout_rows', (None, 0, 1)[(trial // 12) % 3])
             eng.rollout(T, 'greedy' if greedy else 'sample', auto_reset=auto, trajectory=kind, stats=True)
             if kind:

@@ -304,10 +304,9 @@ def test_random_grids_property():
             # cell (or no auto-reset); option rollout_rows = 1 sends the int32 rows there too
             mode = (True, 'packed', False)[(trial // 4) % 3]
             if mode is True:
-                # int32 rows: forced store pacing (a schedule of 1 .. 600 ticks of 10 ns per 16 steps), the batch as several launches
-                # in a row, and the general kernel where the row-table kernel would take the launch -- none of it may change a byte
+                # int32 rows: forced store pacing (a schedule of 1 .. 600 ticks of 10 ns per 16 steps), and the general kernel where the
+                # row-table kernel would take the launch -- none of it may change a byte
                 eng.set_option('rollout_pace', (None, 0, int(rs.randint(1, 600)))[trial % 3])
-                eng.set_option('rollout_split', (None, 0, 2, int(rs.randint(3, 9)))[(trial // 3) % 4])
                 eng.set_option('rollout_rows', (None, 0, 1)[(trial // 12) % 3])
             eng.rollout(T, 'stream' if stream else 'uniform', auto, trajectory=mode, stats=True)
             got = eng.read_trajectory(0, T) if mode is True else eng.read_trajectory_packed(0, T) if mode else {}

@@ -206,12 +206,10 @@ def test_store_pacing_is_calibrated_on_the_engines_own_state_and_never_changes_a
     C.rollout(grid, 9, st, T // 3 + T, True, trajectory=False)
     want = C.rollout(grid, 9, st, T, True)
     assert all(np.array_equal(outs[None][i][:, :2048], want[k]) for i, k in enumerate(('obs', 'reward', 'done')))
-    # the same batch as several launches in a row (what a batch of more than one wave per SIMD may be calibrated to): forced here,
-    # with and without a schedule, on a batch whose last workgroup is ragged
+    # a batch whose last workgroup is ragged, with and without a schedule
     N2 = 65536 + 100
     ragged = {}
-    for split, pace in ((0, 0), (3, 0), (5, 150), (257, 60)):
-        gu_option('rollout_split', split)
+    for pace in (0, 150, 60):
         gu_option('rollout_pace', pace)
         with Engine(N2, spec_of(meta), seed=9, env_id0=1000) as eng:
             eng.reset()
@@ -220,10 +218,9 @@ def test_store_pacing_is_calibrated_on_the_engines_own_state_and_never_changes_a
             eng.rollout(T // 2, 'uniform', True, True, stats=True)
             tr = eng.read_trajectory(0, T // 2)
             st = eng.get_state()
-            ragged[split] = (tr['obs'], tr['reward'], tr['done'], st['pos'], st['episode'], eng.read_stats()[0], eng.read_stats()[1], eng.done_indices())
-    for split in (3, 5, 257):
-        assert all(np.array_equal(a, b) for a, b in zip(ragged[0], ragged[split])), split
-    gu_option('rollout_split', None)
+            ragged[pace] = (tr['obs'], tr['reward'], tr['done'], st['pos'], st['episode'], eng.read_stats()[0], eng.read_stats()[1], eng.done_indices())
+    for pace in (150, 60):
+        assert all(np.array_equal(a, b) for a, b in zip(ragged[0], ragged[pace])), pace
     # launches of fewer than 64 steps and batches of more than four waves per SIMD keep no schedule (nothing to gain there)
     cus = Engine.device_info(0)['cus']
     gu_option('rollout_pace', None)

@@ -73,7 +73,7 @@ def main():
     # first, then `other_modes` (K-step and row-table kernels), then strong_c4 -- whose pacing calibration also tries the batch as
     # several launches of one wave per SIMD in a row (65 536 lanes each, like the headline's).  Per form the LAST dispatches count
     # (same launch size as the very last one): calibration launches, over-idled on purpose, and strong_c4's shorter first launch
-    # come before them.  A strong_c4 that runs split is its part x the number of parts.
+    # come before them.  (Until r03o a strong_c4 batch could run as several launches in a row: its part x the number of parts.)
     C4_ENVS = 262144
     TAIL = 8
 

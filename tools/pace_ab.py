@@ -2,7 +2,7 @@
 """The rollout kernel with and without its store pacing on MANY trajectory buffers of one process -- each engine takes the first
 allocation it gets (no placement search), so both write-rate classes show up.  Per buffer: the bare store probe, us per launch
 unpaced (option rollout_pace = 0), with the calibrated schedule (the default), what the calibration found, and the launch time at
-fixed periods (10 ns ticks per 16 steps).  PACE_AB_K = launches per figure (10), PACE_AB_BLOCK = workgroup size, PACE_AB_ROWS / PACE_AB_NO_ROWS force / forbid the
+fixed periods (10 ns ticks per 16 steps).  PACE_AB_K = launches per figure (10), PACE_AB_BLOCK = workgroup size, PACE_AB_XCD = XCD-aware block order, PACE_AB_ROWS / PACE_AB_NO_ROWS force / forbid the
 transition-row kernel, GU_LIB_PATH another build of the library (make variant ...).
     python tools/pace_ab.py [n_buffers] [envs] [fixed periods ...]"""
 import os
@@ -25,6 +25,8 @@ env = gua.GridUniverseEnv(grid_shape=(32, 32), random_maze=True)
 spec = gua.GridSpec.from_env(env)
 _lib.set_default_option('traj_candidates', 1)
 import os
+if os.environ.get('PACE_AB_XCD'):
+    _lib.set_default_option('rollout_xcd', 1)  # XCD-aware env-block order
 if os.environ.get('PACE_AB_BLOCK'):
     _lib.set_default_option('rollout_block', int(os.environ['PACE_AB_BLOCK']))  # workgroup size of the general kernel
 if os.environ.get('PACE_AB_ROWS'):

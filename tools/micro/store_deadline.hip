@@ -37,6 +37,8 @@ __device__ __forceinline__ uint64_t now()
     return MODE == 2 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
 }
 
+__device__ unsigned long long *g_marks;  // "spread": per wave, the 100 MHz clock when it has done half / all of its steps
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_prod(int *base, size_t plane, int N, int T, uint32_t pace_in, unsigned long long *ticks)
 {
@@ -90,7 +92,9 @@ __global__ void __launch_bounds__(256) k_prod(int *base, size_t plane, int N, in
             if (MODE == 3 && (j & 3) == 3 && pace) wait_until_due();
         }
         if ((MODE == 1 || MODE == 2) && pace) wait_until_due();
+        if (g_marks && t + 16 == (T / 32) * 16 && (threadIdx.x & 63) == 0) g_marks[2 * (e >> 6)] = __builtin_amdgcn_s_memrealtime();
     }
+    if (g_marks && (threadIdx.x & 63) == 0) g_marks[2 * (e >> 6) + 1] = __builtin_amdgcn_s_memrealtime();
     if (e == 0) *ticks = now<MODE>() - t0;
 }
 
@@ -204,6 +208,41 @@ int main(int argc, char **argv)
                 printf("  %6.1f -> %6.1f @%3.0f       ", t0, best, at);
             }
             printf("\n");
+            fflush(stdout);
+        }
+        return 0;
+    }
+    if (argc > 2 && std::string(argv[2]) == "spread") {
+        // how far apart are the waves?  Per wave the clock at half time and at the end; per setting the range (max - min) over the
+        // 1024 waves of the last of 12 launches, in us and in rows (a row of all three planes is written every launch time / 992)
+        unsigned long long *marks = nullptr;
+        CK(hipMalloc(&marks, 2 * 1024 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_marks), &marks, sizeof marks));
+        std::vector<unsigned long long> hm(2048);
+        for (size_t b = 0; b < bufs.size(); ++b) {
+            int *buf = bufs[b];
+            launch(2, buf, 0u);
+            CK(hipDeviceSynchronize());
+            unsigned long long ticks = 0;
+            CK(hipMemcpy(&ticks, dticks, 8, hipMemcpyDeviceToHost));
+            const double per_group = (double)ticks / (T / 16);
+            struct { const char *name; int mode; uint32_t pace; } settings[] = {
+                {"unthrottled", 0, 0u}, {"idle turns 10 per 4 steps", 0, 10u}, {"idle turns 8", 0, 8u},
+                {"schedule 1.08", 2, (uint32_t)(per_group * 1.08)}, {"schedule 1.02", 2, (uint32_t)(per_group * 1.02)}, {"schedule 0.94 (too short)", 2, (uint32_t)(per_group * 0.94)}};
+            printf("buffer %zu\n", b);
+            for (auto &st : settings) {
+                const float t = timed(st.mode, buf, st.pace, 12);
+                CK(hipMemcpy(hm.data(), marks, 2048 * 8, hipMemcpyDeviceToHost));
+                unsigned long long lo[2] = {~0ull, ~0ull}, hi[2] = {0, 0};
+                for (int w = 0; w < 1024; ++w)
+                    for (int k = 0; k < 2; ++k) {
+                        lo[k] = std::min(lo[k], hm[2 * w + k]);
+                        hi[k] = std::max(hi[k], hm[2 * w + k]);
+                    }
+                const double us_mid = (hi[0] - lo[0]) / 100.0, us_end = (hi[1] - lo[1]) / 100.0, row_us = t / T;
+                printf("  %-28s %6.1f us per launch; waves apart at half time %5.1f us = %4.0f rows, at the end %5.1f us = %4.0f rows\n", st.name, t, us_mid, us_mid / row_us,
+                       us_end, us_end / row_us);
+            }
             fflush(stdout);
         }
         return 0;

@@ -155,15 +155,17 @@ __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint3
 //       latency-bound modes, the length of the dependent chain is; profiles/r02b_map_ab.txt.  What shortens the chain is the
 //       transition-row table of gu_rollout_rows.hip.)
 #define GU_PRIVATE_PAD 16
-// Cache-policy bits of the trajectory stores (buffer_store aux: 1 = sc0, 2 = nt, 16 = sc1).  The int32 rows go out with sc1:
-// written through at device scope instead of staying dirty in the L2 until they are evicted -- the rows are never read again
-// by the launch, and the memory then sees them in the order the waves issue them, not in the L2's eviction order.  Measured
-// on 24 buffers per variant, processes interleaved (profiles/r03k_store_scope.txt): rate-limited launch 119.4 us without,
-// 116.4 with sc1, 115.3 with sc0 + sc1, 119.2 with nt alone; sustained over 50 launches with sc1 113 .. 114 us on every
-// buffer of the slow kind (6.9 TB/s), 107 .. 108 on fast ones.  The packed row (4 B per env-step, transition-row kernel: 48 us
-// per 65 536 x 1000 launch) gains too: 1.35e12 -> 1.44e12 env-steps/s, three runs each (profiles/r03m_packed_sc1.txt).
+// Cache-policy bits of the trajectory stores (buffer_store aux: 1 = sc0, 2 = nt, 16 = sc1).  The int32 rows go out with sc1 + nt:
+// written through at device scope instead of staying dirty in the L2 until they are evicted, and marked as streaming -- the rows
+// are never read again by the launch, and the memory then sees them in the order the waves issue them, not in the L2's eviction
+// order.  Measured with library variants, 24 buffers each, processes interleaved.  Under the first (idle-turn) limiter
+// (profiles/r03k_store_scope.txt): 119.4 us without, 116.4 with sc1, 115.3 with sc0 + sc1, 119.2 with nt alone, 116.1 with all
+// three.  Under the schedule limiter (profiles/r03p_store_scope_schedule.txt, two boxes): default policy 114.4, nt alone 110.5, sc1
+// 110.7 / 109.0, sc0 + sc1 110.3, sc1 + nt 107.6 / 108.1, all three 108.2 -- on slow allocations sc1 111.2 .. 111.5 against 107.8 ..
+// 108.2 with sc1 + nt, on fast ones no difference (107.1 / 107.7).  The packed row (4 B per env-step, transition-row kernel: 45 us
+// per 65 536 x 1000 launch) gains from sc1 too: 1.35e12 -> 1.44e12 env-steps/s, three runs each (profiles/r03m_packed_sc1.txt).
 #ifndef GU_STORE_AUX
-#define GU_STORE_AUX 16
+#define GU_STORE_AUX 18
 #endif
 #ifndef GU_STORE_AUX_PACKED
 #define GU_STORE_AUX_PACKED 16

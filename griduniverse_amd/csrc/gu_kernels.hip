@@ -371,6 +371,9 @@ static void gu_rollout_general(gu_engine *h, const RolloutArgs &a, int32_t polic
 // the shortest one that gets out of the collapse by itself, because a timed region is not kind either (a pause, a neighbour on
 // the device, and a stream that only holds while it is healthy is collapsed for good).  ~80 launches, once per (policy,
 // auto-reset mode, buffer).
+#ifndef GU_PACE_MARGIN
+#define GU_PACE_MARGIN 1.01  /* the kept period over the first one that recovered and held */
+#endif
 static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::function<void(uint32_t)> &launch, gu_engine::PaceRecord *rec)
 {
     const auto t_start = std::chrono::steady_clock::now();
@@ -465,7 +468,7 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
             if ((rc = measure(p, 2, 2, 12, &t)) != GU_OK) return rc;
             if (gu_debug() > 1) fprintf(stderr, "[gu]   period %u from the collapsed state: %.4f ms (best %.4f)\n", p, t, best);
             if (t <= 1.02f * best) {
-                pick = (uint32_t)(period * 1.01 + 0.5), pick_ms = t;
+                pick = (uint32_t)(period * GU_PACE_MARGIN + 0.5), pick_ms = t;
                 break;
             }
         }

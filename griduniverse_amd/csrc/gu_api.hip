@@ -163,7 +163,7 @@ int gu_destroy(gu_handle h)
     gu_vi_free(h);
     gu_placement_release(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    void *bufs[] = {h->d_kind, h->d_rows[0], h->d_rows[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
+    void *bufs[] = {h->d_kind, h->d_rows[0], h->d_rows[1], h->d_rows2[0], h->d_rows2[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
                     h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -235,6 +235,9 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
         if (h->d_rows[k]) GU_HIP(hipFree(h->d_rows[k]));
         h->d_rows[k] = nullptr;
         h->rows_shift[k] = -1;
+        if (h->d_rows2[k]) GU_HIP(hipFree(h->d_rows2[k]));
+        h->d_rows2[k] = nullptr;
+        h->rows2_built[k] = false;
         if (h->d_mrows[k]) GU_HIP(hipFree(h->d_mrows[k]));
         if (h->d_mrows1[k]) GU_HIP(hipFree(h->d_mrows1[k]));
         h->d_mrows[k] = h->d_mrows1[k] = nullptr;
@@ -917,9 +920,14 @@ int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t 
     const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->all_single_start ? 1 : 2) : 0;
     // (the general kernel's record, else the transition-row kernel's: a launch kind of one engine runs on one of the two)
     const gu_engine::PaceRecord *found = nullptr;
-    for (int base : {0, 12}) {
-        const gu_engine::PaceRecord &cand = h->pace[base + policy_kind * 3 + auto_mode];
-        if (!found && cand.known && cand.buffer == (const void *)h->d_traj) found = &cand;
+    if (flags & GU_F_PACKED) {  // packed rows: the transition-row kernel's record of its own
+        const gu_engine::PaceRecord &cand = h->pace[24 + policy_kind * 3 + auto_mode];
+        if (cand.known && cand.buffer == (const void *)h->d_traj) found = &cand;
+    } else {
+        for (int base : {0, 12}) {
+            const gu_engine::PaceRecord &cand = h->pace[base + policy_kind * 3 + auto_mode];
+            if (!found && cand.known && cand.buffer == (const void *)h->d_traj) found = &cand;
+        }
     }
     GU_REQUIRE(found != nullptr, GU_ERR_STATE, "no pacing calibration for this launch kind on the current trajectory buffer");
     const gu_engine::PaceRecord &rec = *found;

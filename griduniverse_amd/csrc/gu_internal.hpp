@@ -107,12 +107,14 @@ struct gu_engine {
         uint32_t period = 0;           // the waves' schedule: 10 ns ticks per 16 steps (0: no limiter)
         float ms_unpaced = 0.0f, ms_paced = 0.0f, calibration_ms = 0.0f;
         int32_t evaluated = 0;         // candidates timed
-    } pace[24];  // [policy * 3 + auto mode] for the general kernel, + 12 for the transition-row kernel
+    } pace[36];  // [policy * 3 + auto mode] for the general kernel, + 12 for the transition-row kernel's int32 rows, + 24 for its packed rows
     hipEvent_t ev_cal[2] = {nullptr, nullptr};
 
     // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in
     uint32_t *d_rows[2] = {nullptr, nullptr};
     int rows_shift[2] = {-1, -1};   // log2(16 * copies) the table was built for (-1: not built)
+    uint32_t *d_rows2[2] = {nullptr, nullptr};  // pair tables (two steps per round trip) + the one-step table that goes with them
+    bool rows2_built[2] = {false, false};
     // K-step tables of the statistics-only uniform rollout (gu_rollout_multi.hip) and the one-step tables that go with them
     uint32_t *d_mrows[2] = {nullptr, nullptr}, *d_mrows1[2] = {nullptr, nullptr};
     int mrows_K[2] = {0, 0}, mrows_shift[2] = {-1, -1};  // what they were built for (K = 0: not built)

@@ -493,20 +493,21 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
     rec->calibration_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     if (gu_debug())
         fprintf(stderr, "[gu] store pacing (%s kernel, policy %d, auto %d, %lld x %lld): %u ticks of 10 ns per 16 steps, %.4f -> %.4f ms per launch, %d candidates in %.1f ms\n",
-                slot >= 12 ? "row-table" : "general", (slot % 12) / 3, slot % 3, (long long)h->N, (long long)T, pick, unpaced, pick_ms, evaluated,
+                slot >= 24 ? "row-table (packed rows)" : slot >= 12 ? "row-table" : "general", (slot % 12) / 3, slot % 3, (long long)h->N, (long long)T, pick, unpaced, pick_ms, evaluated,
                 rec->calibration_ms);
     return GU_OK;
 }
 
 // The schedule of this launch: option GU_OPT_ROLLOUT_PACE when set (0 = none, n = that many 10 ns ticks per 16 steps), else the
 // calibrated period for this launch kind on this buffer -- calibrated now if it is not known yet.  `slot` = policy * 3 + auto mode
-// (+ 12 for the transition-row kernel); `launch(period)` enqueues the launch with that period.  Launches that cannot be bound by
+// (+ 12 for the transition-row kernel's int32 rows, + 24 for its packed rows, `row_bytes` = 12 / 4 per env-step); `launch(period)`
+// enqueues the launch with that period.  Launches that cannot be bound by
 // the HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs), launches of fewer than 64 steps, and
 // batches of more than four waves per SIMD are not paced and not calibrated.
 // (Until r03o a batch of more than one wave per SIMD was also tried as several launches in a row of one wave per SIMD each: the
 // idle-turn limiter had nothing to work with at four waves per SIMD.  The schedule has -- 262 144 envs in ONE launch 0.44 .. 0.48 ms,
 // as four launches in a row 0.56 .. 0.59, profiles/r03o_c4_split.txt -- and that form is gone.)
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, const std::function<void(uint32_t)> &launch, uint32_t *pace)
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, const std::function<void(uint32_t)> &launch, uint32_t *pace)
 {
     *pace = 0;
     const int64_t opt = gu_opt(h, GU_OPT_ROLLOUT_PACE);
@@ -517,7 +518,7 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, const std::f
     // (T < 64: fewer than four groups to schedule.  More than four waves per SIMD -- 524 288 envs and more on 256 CUs --: a per-wave
     // schedule found nothing to gain there, 0.96 .. 0.98 ms = 6.4 .. 6.6 TB/s with and without, and a batch that does not fit the
     // device at once is not on one schedule anyway; profiles/r03n_batch_sizes.txt)
-    if ((double)h->N * (double)T * 12.0 < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024) return GU_OK;
+    if ((double)h->N * (double)T * (double)row_bytes < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024) return GU_OK;
     gu_engine::PaceRecord &rec = h->pace[slot];
     if (!rec.known || rec.buffer != (const void *)h->d_traj || T > 2 * rec.T || 2 * T < rec.T) {
         const int rc = gu_calibrate_pace(h, slot, T, launch, &rec);
@@ -564,6 +565,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.T = T;
     a.gs = gu_grid_sel(h);
     a.rows = nullptr;
+    a.rows2 = nullptr;
     a.row_shift = 0;
     a.stream_lds_off = 0;
     a.stream_lds_words = 0;
@@ -590,7 +592,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
     if (traj == 1) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: GuPacer)
         RolloutArgs c = a;
-        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, gu_blocks(h->N, bs), [&](uint32_t period) {
+        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, gu_blocks(h->N, bs), 12, [&](uint32_t period) {
             c.pace = period;
             gu_rollout_general(h, c, policy, auto_mode, 1, stats, bs);
         }, &a.pace);

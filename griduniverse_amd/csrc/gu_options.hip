@@ -21,7 +21,7 @@ struct OptSpec {
 const OptSpec g_spec[GU_OPT_COUNT] = {
     {nullptr, 0, 0, 0},
     {"GU_ROLLOUT_BLOCK", 256, 64, 1024},
-    {"GU_ROLLOUT_ROWS", -1, -1, 1},
+    {"GU_ROLLOUT_ROWS", -1, -1, 2},
     {"GU_ROWS_COPIES", 0, 0, 32},
     {"GU_ROLLOUT_MULTI", -1, -1, 1},
     {"GU_ROLLOUT_MULTI_K", 0, 0, 4},

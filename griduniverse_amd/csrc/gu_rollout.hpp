@@ -38,6 +38,7 @@ struct RolloutArgs {
     int64_t N, T;
     GridSel gs;
     const uint32_t *rows;   // transition-row table [S][4] (gu_rollout_rows.hip)
+    const uint32_t *rows2;  // ... or its pair table [S][16][2] followed by a one-step table [S][4] (two steps per LDS round trip)
     int32_t row_shift;      // log2(16 * copies) of that table
     int32_t stream_lds_off; // GU_POLICY_STREAM, MAP 1: byte offset in LDS of the staged action words [stream_lds_words][blockDim.x] ...
     int32_t stream_lds_words;  // ... and how many words per lane fit (0: every word is read from HBM when its steps are due)
@@ -569,6 +570,6 @@ void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int tr
 // the transition-row kernel (gu_rollout_rows.hip): true when it took the launch (*rc: what its pace calibration returned)
 bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats, int *rc);
 // store pacing (gu_kernels.hip): the schedule of an int32-row launch (ticks per 16 steps), calibrated on first use
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, const std::function<void(uint32_t)> &launch, uint32_t *pace);
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, const std::function<void(uint32_t)> &launch, uint32_t *pace);
 // the K-step kernel (gu_rollout_multi.hip; uniform policy, no trajectory): true when it took the launch
 bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);

@@ -88,7 +88,45 @@ __global__ void __launch_bounds__(256) gu_build_policy_rows_kernel(const BuildPo
                         gu_row_record(a.cell, a.cell_bytes, base, 2, a.W, a.row_shift), gu_row_record(a.cell, a.cell_bytes, base, 3, a.W, a.row_shift));
 }
 
+// PAIR tables (uniform policy / caller-supplied stream, launches that write rows): TWO env-steps per LDS round trip.  The actions
+// of these policies do not depend on the env state, so the transitions of two consecutive steps compose ahead of time like the
+// K-step tables of gu_rollout_multi.hip -- but here every step leaves a trajectory row behind, so an entry keeps BOTH records:
+//
+//     pair[s][a1 | a2 << 2] = { record reached by a1 from s,  record reached by a2 from there }          (8 bytes, 128 per cell)
+//
+// each in the format above with the cell's PAIR row as its address.  One ds_read_b64 then advances an env by two steps, and the
+// two records are emitted beside the chain as before.  Steps that do not fill a pair of an action word (the first step of a
+// launch, the steps up to the next 16-step word, the last T mod 16) run on a one-step table of the same record format that sits
+// behind the pair table in LDS (144 bytes per cell in all: grids of up to ~1100 cells, one workgroup per CU).  What it buys:
+// launches bound by the dependent chain, not by the write path -- packed rows at 65 536 envs, int32 rows at a config-4 shard of
+// 32 768 envs (profiles/r03r_pair_rows.txt).
+__device__ __forceinline__ uint32_t gu_row_record(const uint8_t *cell, int32_t cell_bytes, int32_t base, uint32_t act, int32_t W, int32_t row_shift);
+
+struct BuildPairRowsArgs {
+    const uint8_t *cell;
+    int32_t cell_bytes, S, W, start0, auto_reset;
+    uint32_t *rows2;  // [S][16][2] pair records, then [S][4] one-step records (row_shift 7)
+};
+
+#define GU_PAIR_SHIFT 7
+
+__global__ void __launch_bounds__(256) gu_build_pair_rows_kernel(const BuildPairRowsArgs a)
+{
+    const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.S * 16) return;
+    const int32_t s = idx >> 4;
+    const uint32_t a1 = (uint32_t)idx & 3u, a2 = ((uint32_t)idx >> 2) & 3u;
+    const int32_t b1 = (a.auto_reset && (a.cell[s] & GU_CELL_TERM)) ? a.start0 : s;  // lazy `if done: env.reset()` (env:187-193)
+    const uint32_t r1 = gu_row_record(a.cell, a.cell_bytes, b1, a1, a.W, GU_PAIR_SHIFT);
+    const int32_t n1 = (int32_t)((r1 & GU_ROW_ADDR_MASK) >> GU_PAIR_SHIFT);
+    const int32_t b2 = (a.auto_reset && (a.cell[n1] & GU_CELL_TERM)) ? a.start0 : n1;
+    const uint32_t r2 = gu_row_record(a.cell, a.cell_bytes, b2, a2, a.W, GU_PAIR_SHIFT);
+    reinterpret_cast<uint2 *>(a.rows2)[idx] = make_uint2(r1, r2);
+}
+
 typedef __attribute__((address_space(3))) const uint32_t *lds_u32_ptr;
+typedef uint32_t gu_v2u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const gu_v2u *lds_v2u_ptr;
 typedef uint32_t gu_v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const gu_v4u *lds_v4u_ptr;
 
@@ -98,11 +136,12 @@ struct RowBytes {
     static constexpr int log2 = POLICY == GU_POLICY_GREEDY ? 2 : POLICY == GU_POLICY_SAMPLE ? 5 : 4;
 };
 
-template <int POLICY, int TRAJ, bool STATS>
+template <int POLICY, int TRAJ, bool STATS, bool PAIR = false>
 __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const RolloutArgs a, const int32_t auto_reset)
 {
+    static_assert(!PAIR || POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM, "pair tables: policies whose actions do not depend on the state");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int32_t shift = a.row_shift;         // log2(row bytes * copies)
+    const int32_t shift = PAIR ? GU_PAIR_SHIFT : a.row_shift;  // log2(row bytes * copies)
     const int32_t copies_log2 = shift - RowBytes<POLICY>::log2;
     // LDS address of the staged table: folded into every record (0 in practice: this kernel has no static LDS), so that a
     // record's address bits are the raw ds_read address and no base is added on the dependent chain
@@ -111,7 +150,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         // Staging, 16 bytes per thread and iteration, consecutive threads -> consecutive LDS addresses; unrolled so that eight
         // loads are in flight before the first store (one load's L2 latency per iteration made this the launch's fixed cost:
         // 15 us for 128 KB of greedy rows copied dword by dword).
-        const int32_t units = (a.S << shift) >> 4;  // 16-byte units of the LDS image
+        const int32_t units = PAIR ? a.S * 9 : (a.S << shift) >> 4;  // 16-byte units of the LDS image (PAIR: 128 + 16 bytes per cell)
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         const uint4 *g4 = reinterpret_cast<const uint4 *>(a.rows);
 #pragma unroll 8
@@ -126,6 +165,9 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
                 const int32_t c = (u >> 1) >> copies_log2;
                 v = g4[2 * c + (u & 1)];
                 if (u & 1) v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
+            } else if (PAIR) {  // the global image is the LDS image: pair table, then the one-step table
+                v = reinterpret_cast<const uint4 *>(a.rows2)[u];
+                v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
             } else {
                 v = g4[u >> copies_log2];
                 v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
@@ -137,7 +179,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
     const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * blockDim.x + threadIdx.x;
     if (e64 >= a.N) return;
     const uint32_t e = (uint32_t)e64;
-    const uint32_t lane_copy = (threadIdx.x & ((1u << copies_log2) - 1u)) << RowBytes<POLICY>::log2;  // this lane's copy of every row
+    const uint32_t lane_copy = PAIR ? 0u : (threadIdx.x & ((1u << copies_log2) - 1u)) << RowBytes<POLICY>::log2;  // this lane's copy of every row
+    const uint32_t base1 = lds_base + ((uint32_t)a.S << GU_PAIR_SHIFT);  // PAIR: the one-step table behind the pair table
 
     int32_t s = a.pos[e];
     uint32_t d = (uint32_t)a.done[e];
@@ -215,19 +258,50 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             between();
         } else {
             between();
-            uint32_t actoff = lane_copy | (x << 2);  // off the chain (the action does not depend on the env state)
-            asm("" : "+v"(actoff));                  // keep it ONE value: otherwise the three-way OR is re-associated onto the chain
-            const uint32_t addr = (prev & GU_ROW_ADDR_MASK) | actoff;  // v_and_or_b32: the only vector op between two LDS reads
-            rec = *(lds_u32_ptr)(uintptr_t)addr;
+            if (PAIR) {  // (a step outside the pairs: its 16-byte row of the one-step table; records carry PAIR-row addresses)
+                rec = *(lds_u32_ptr)(uintptr_t)(base1 + (((prev & GU_ROW_ADDR_MASK) - lds_base) >> 3) + (x << 2));
+            } else {
+                uint32_t actoff = lane_copy | (x << 2);  // off the chain (the action does not depend on the env state)
+                asm("" : "+v"(actoff));                  // keep it ONE value: otherwise the three-way OR is re-associated onto the chain
+                const uint32_t addr = (prev & GU_ROW_ADDR_MASK) | actoff;  // v_and_or_b32: the only vector op between two LDS reads
+                rec = *(lds_u32_ptr)(uintptr_t)addr;
+            }
         }
         emit(prev, soff);
     };
     auto nothing = [] {};
     GuPacer pacer;
-    pacer.start(TRAJ == 1 ? a.pace : 0u);
+    pacer.start(TRAJ ? a.pace : 0u);
     auto step1 = [&](uint32_t x) {
         step(x, 0, nothing);
         if (TRAJ) rebase(1);
+    };
+    // the 16 steps of one action word.  PAIR: eight round trips of two steps each; the records of a pair are emitted one round
+    // trip late, behind the issue of the next read (rows base .. base + 15, the last record stays pending like everywhere here)
+    auto word16 = [&](uint32_t word) {
+        if (PAIR) {
+            uint32_t r1[8], r2[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) {
+                const uint32_t prev = q ? r2[q - 1] : rec;
+                uint32_t off = __builtin_amdgcn_ubfe(word, 4 * q, 4) << 3;  // off the chain
+                asm("" : "+v"(off));
+                const gu_v2u pr = *(lds_v2u_ptr)(uintptr_t)((prev & GU_ROW_ADDR_MASK) | off);
+                r1[q] = pr.x;
+                r2[q] = pr.y;
+                if (q == 0) {
+                    emit(rec, 0);
+                } else {
+                    emit(r1[q - 1], (2 * q - 1) * row32);
+                    emit(r2[q - 1], (2 * q) * row32);
+                }
+            }
+            emit(r1[7], 15 * row32);
+            rec = r2[7];
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
+        }
     };
 
     if (POLICY == GU_POLICY_UNIFORM) {
@@ -246,8 +320,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             }
             for (; i + 16 <= a.T; i += 16, t += 16) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
-#pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
+                word16(word);
                 if (TRAJ) rebase(16);
                 if (i + 16 < a.T) pacer.after(16);  // (gu_rollout.hpp: GuPacer)
             }
@@ -297,8 +370,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         gu_stream_run(
             pa, row, e4, a.T, 1,
             [&](uint32_t word) {
-#pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
+                word16(word);
                 if (TRAJ) rebase(16);
                 pacer.after(16);
             },
@@ -355,12 +427,12 @@ static int rows_max_copies(const gu_engine *h, int32_t policy)
 
 static int rows_mode(const gu_engine *h) { return (int)gu_opt(h, GU_OPT_ROLLOUT_ROWS); }
 
-template <int POLICY>
+template <int POLICY, bool PAIR = false>
 static void rows_dispatch(const gu_engine *h, const RolloutArgs &a, int traj, bool stats, int auto_reset, dim3 grid, dim3 block, size_t lds, hipStream_t stream)
 {
 #define GU_ROWS_LAUNCH(TR, ST)                                                                                           \
     do {                                                                                                                 \
-        auto kern = gu_rollout_rows_kernel<POLICY, TR, ST>;                                                              \
+        auto kern = gu_rollout_rows_kernel<POLICY, TR, ST, PAIR>;                                                        \
         static std::atomic<uint64_t> raised{0}; /* per instantiation and per device: raise the dynamic-LDS limit once */ \
         gu_allow_lds(kern, raised, h->device, lds, (size_t)h->lds_per_cu);                                               \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a, auto_reset);                                               \
@@ -394,7 +466,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     //                          is bound by its ~45 vector instructions, half of them the MurmurHash3 of its RNG word, not by
     //                          the LDS round trips the row table saves
     if (mode == 0) return false;
-    if (mode != 1) {
+    if (mode != 1 && mode != 2) {
         const unsigned blocks = gu_blocks(h->N, 256);
         // (a caller-supplied stream with int32 rows: the row-table kernel reads its action words straight from HBM, and a load
         // among streaming stores waits for all of them -- beyond 16 384 envs the general kernel, which stages the words in LDS,
@@ -439,21 +511,55 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         }
         a.rows = h->d_rows[which];
     }
+    // Pair tables (two steps per LDS round trip) where they pay: state-independent actions, PACKED rows (int32 rows are as fast or
+    // faster on the one-step table -- 58 .. 61 against 65 us at 32 768 envs, 110 against 115 at 65 536: six stores and two records'
+    // worth of unpacking per round trip cost what the shorter chain saves, and those launches are close to the write path's rate
+    // anyway; without rows the K-step kernel of gu_rollout_multi.hip is the tool), one 256-lane workgroup per CU at most (144 bytes
+    // of LDS per cell).  GU_OPT_ROLLOUT_ROWS = 2 keeps the one-step table (A/B, tests).  profiles/r03r_pair_rows.txt
+    bool pair = !table_policy && traj == 2 && mode != 2 && gu_blocks(h->N, 256) <= (unsigned)h->n_cu && (int64_t)h->S * 144 <= h->lds_per_cu - 2048 &&
+                ((int64_t)h->S << GU_PAIR_SHIFT) <= (int64_t)GU_ROW_ADDR_MASK;
+    if (pair) {
+        if (!h->d_rows2[which]) {
+            if (hipMalloc(&h->d_rows2[which], (size_t)h->S * 144) != hipSuccess) {
+                (void)hipGetLastError();
+                pair = false;
+            }
+            h->rows2_built[which] = false;
+        }
+        if (pair && !h->rows2_built[which]) {
+            BuildPairRowsArgs b2{h->d_cell, h->cell_bytes, h->S, h->W, h->start0, which, h->d_rows2[which]};
+            hipLaunchKernelGGL(gu_build_pair_rows_kernel, dim3((unsigned)((h->S * 16 + 255) / 256)), dim3(256), 0, h->stream, b2);
+            BuildRowsArgs b1{h->d_cell, h->cell_bytes, h->S, h->W, h->start0, which, GU_PAIR_SHIFT, h->d_rows2[which] + (size_t)h->S * 32};
+            hipLaunchKernelGGL(gu_build_rows_kernel, dim3((unsigned)((h->S + 255) / 256)), dim3(256), 0, h->stream, b1);
+            h->rows2_built[which] = true;
+        }
+        if (pair) {
+            a.rows2 = h->d_rows2[which];
+            bs = 256;
+            shift = GU_PAIR_SHIFT;
+        }
+    }
     a.row_shift = shift;
-    const size_t lds = ((size_t)h->S << row_log2) << (shift - row_log2);
+    const size_t lds = pair ? (size_t)h->S * 144 : ((size_t)h->S << row_log2) << (shift - row_log2);
     const dim3 grid(gu_blocks(h->N, bs)), block(bs);
     a.xcd_remap = a.xcd_remap && grid.x % 8 == 0;
     auto launch = [&](const RolloutArgs &args) {
         switch (policy) {
-        case GU_POLICY_UNIFORM: rows_dispatch<GU_POLICY_UNIFORM>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
-        case GU_POLICY_STREAM: rows_dispatch<GU_POLICY_STREAM>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
+        case GU_POLICY_UNIFORM:
+            if (pair) rows_dispatch<GU_POLICY_UNIFORM, true>(h, args, traj, stats, which, grid, block, lds, h->stream);
+            else rows_dispatch<GU_POLICY_UNIFORM>(h, args, traj, stats, which, grid, block, lds, h->stream);
+            break;
+        case GU_POLICY_STREAM:
+            if (pair) rows_dispatch<GU_POLICY_STREAM, true>(h, args, traj, stats, which, grid, block, lds, h->stream);
+            else rows_dispatch<GU_POLICY_STREAM>(h, args, traj, stats, which, grid, block, lds, h->stream);
+            break;
         case GU_POLICY_GREEDY: rows_dispatch<GU_POLICY_GREEDY>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
         default: rows_dispatch<GU_POLICY_SAMPLE>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
         }
     };
-    if (traj == 1) {  // int32 rows: the store stream is rate-limited here too (gu_rollout.hpp: GuPacer; calibrated on first use)
+    if (traj) {  // rows to write: the store stream is rate-limited here too (gu_rollout.hpp: GuPacer; calibrated on first use)
         RolloutArgs c = a;
-        *rc = gu_pace_for(h, 12 + policy * 3 + auto_mode, a.T, grid.x, [&](uint32_t period) {
+        *rc = gu_pace_for(h, (traj == 1 ? 12 : 24) + policy * 3 + auto_mode, a.T, grid.x, traj == 1 ? 12 : 4, [&](uint32_t period) {
             c.pace = period;
             launch(c);
         }, &a.pace);

@@ -221,14 +221,14 @@ class Engine(object):
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | tflag | (_lib.F_STATS if stats else 0)
         check(self.lib.gu_rollout(self._h, int(T), _POLICIES[policy], flags))
 
-    def rollout_pacing(self, policy='uniform', auto_reset=True):
+    def rollout_pacing(self, policy='uniform', auto_reset=True, packed=False):
         """What the store-pacing calibration found for this launch kind on the current trajectory buffer (include/gu.h:
         gu_rollout_pacing): dict(period=the waves' schedule in 10 ns ticks per 16 steps (0: no limiter), ms_unpaced, ms_paced, evaluated,
         calibration_ms), or None when the
         kind has not been calibrated (not launched yet, or too small to be paced)."""
         period, n = ctypes.c_int32(0), ctypes.c_int32(0)
         a, b, c = ctypes.c_float(0.0), ctypes.c_float(0.0), ctypes.c_float(0.0)
-        rc = self.lib.gu_rollout_pacing(self._h, _POLICIES[policy], _lib.F_AUTO_RESET if auto_reset else 0, ctypes.byref(period),
+        rc = self.lib.gu_rollout_pacing(self._h, _POLICIES[policy], (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_PACKED if packed else 0), ctypes.byref(period),
                                         ctypes.byref(a), ctypes.byref(b), ctypes.byref(n), ctypes.byref(c))
         if rc == -4:
             return None

@@ -83,7 +83,8 @@ int gu_device_info(int device_id, char *buf, size_t len);
  * -DGU_EXPERIMENTS (make exp -> libgu_exp.so, used by tools/ only). */
 #define GU_OPT_UNSET INT64_MIN
 #define GU_OPT_ROLLOUT_BLOCK 1        /* workgroup size of the general rollout kernel: 64 .. 1024 (256)                         */
-#define GU_OPT_ROLLOUT_ROWS 2         /* transition-row kernel: 0 never, 1 wherever eligible (default: by launch shape)       */
+#define GU_OPT_ROLLOUT_ROWS 2         /* transition-row kernel: 0 never, 1 wherever eligible, 2 = 1 without its pair tables
+                                         (default: by launch shape)                                                           */
 #define GU_OPT_ROWS_COPIES 3          /* copies of its table across the LDS banks: 1, 2, .. 32 (default: by policy)           */
 #define GU_OPT_ROLLOUT_MULTI 4        /* K-step kernel: 0 never, 1 whenever the table fits (default: launches of >= 64 steps)  */
 #define GU_OPT_ROLLOUT_MULTI_K 5      /* force K = 2 or 4                                                                     */

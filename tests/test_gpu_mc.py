@@ -302,7 +302,7 @@ def test_random_grids_table_policies_property():
             eng.reserve_trajectory(T)
             if kind is True:  # int32 rows: forced store pacing / kernel choice never change a byte
                 eng.set_option('rollout_pace', (None, 0, int(rs.randint(1, 600)))[trial % 3])
-                eng.set_option('rollout_rows', (None, 0, 1)[(trial // 12) % 3])
+                eng.set_option('rollout_rows', (None, 0, 1, 2)[(trial // 12) % 4])
             eng.rollout(T, 'greedy' if greedy else 'sample', auto_reset=auto, trajectory=kind, stats=True)
             if kind:
                 got = eng.read_trajectory_packed(0, T) if kind == 'packed' else eng.read_trajectory(0, T)

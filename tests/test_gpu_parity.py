@@ -307,7 +307,7 @@ def test_random_grids_property():
                 # int32 rows: forced store pacing (a schedule of 1 .. 600 ticks of 10 ns per 16 steps), and the general kernel where the
                 # row-table kernel would take the launch -- none of it may change a byte
                 eng.set_option('rollout_pace', (None, 0, int(rs.randint(1, 600)))[trial % 3])
-                eng.set_option('rollout_rows', (None, 0, 1)[(trial // 12) % 3])
+                eng.set_option('rollout_rows', (None, 0, 1, 2)[(trial // 12) % 4])
             eng.rollout(T, 'stream' if stream else 'uniform', auto, trajectory=mode, stats=True)
             got = eng.read_trajectory(0, T) if mode is True else eng.read_trajectory_packed(0, T) if mode else {}
             ret, eps = eng.read_stats()

@@ -345,7 +345,7 @@ def test_rows_and_general_kernel_agree_at_config_sizes(gu_option):
     env = gua.GridUniverseEnv(grid_shape=(32, 32), random_maze=True)
     N, T = 65536, 1000
     out = {}
-    for rows in ('0', '1'):
+    for rows in ('0', '1', '2'):  # general kernel / row-table kernel with its pair tables (two steps per round trip) / with the one-step table
         gu_option('rollout_rows', int(rows))
         with Engine(N, GridSpec.from_env(env), seed=123) as eng:
             eng.reset()
@@ -358,9 +358,10 @@ def test_rows_and_general_kernel_agree_at_config_sizes(gu_option):
             st = eng.get_state()
             out[rows] = (h.hexdigest(), eng.read_stats(), st)
             del tr
-    assert out['0'][0] == out['1'][0] == G.load_json('digests.json')['c3_maze32_65536x1000']['sha256']
-    assert all(np.array_equal(a, b) for a, b in zip(out['0'][1], out['1'][1]))
-    assert all(np.array_equal(out['0'][2][k], out['1'][2][k]) for k in out['0'][2])
+    assert out['0'][0] == out['1'][0] == out['2'][0] == G.load_json('digests.json')['c3_maze32_65536x1000']['sha256']
+    for other in ('1', '2'):
+        assert all(np.array_equal(a, b) for a, b in zip(out['0'][1], out[other][1]))
+        assert all(np.array_equal(out['0'][2][k], out[other][2][k]) for k in out['0'][2])
     gu_option('rollout_rows', None)
     with Engine(N, GridSpec.from_env(env), seed=123) as eng:  # default dispatch: stats-only launch on the row table
         eng.reset()

@@ -239,3 +239,49 @@ def test_store_pacing_is_calibrated_on_the_engines_own_state_and_never_changes_a
         eng.vi_set(np.zeros(S), np.random.RandomState(1).dirichlet(np.ones(4), S))
         eng.rollout(T, 'sample', False, True)
         assert eng.rollout_pacing('sample', False) is not None and eng.rollout_pacing('uniform', True) is None
+
+
+def test_pair_tables_leave_the_same_rows_as_the_one_step_table_and_the_general_kernel(gu_option):
+    """gu_rollout_rows.hip's pair tables (two env-steps per LDS round trip; uniform policy and caller-supplied streams, launches that
+    write rows, one workgroup per CU at most): every launch shape through the pair tables (option rollout_rows = 1), the one-step
+    table (= 2) and the general kernel (= 0) -- int32 and packed rows, with and without auto-reset, step counts that leave heads and
+    tails around the 16-step action words, two launches in a row (the second starts inside a word), per-env statistics, final state."""
+    meta, _ = G.load_traj('c4_lava32')
+    rs = np.random.RandomState(5)
+    cases = [(4096, 1000, 'uniform'), (4100, 777, 'uniform'), (2048, 17, 'uniform'), (3000, 33, 'stream'), (4096, 250, 'stream')]
+    for N, T, policy in cases:
+        acts = rs.randint(0, 4, size=(T, N)).astype(np.int32) if policy == 'stream' else None
+        for auto in (True, False):
+            for traj in (True, 'packed'):
+                outs = {}
+                for rows in (0, 1, 2):
+                    gu_option('rollout_rows', rows)
+                    with Engine(N, spec_of(meta), seed=21, env_id0=7) as eng:
+                        eng.reset()
+                        if acts is not None:
+                            eng.upload_actions(acts)
+                        eng.reserve_trajectory(T)
+                        eng.rollout(T // 3 + 1, policy, auto, trajectory=traj, stats=True)  # the next launch starts inside an action word
+                        if acts is not None:
+                            eng.upload_actions(acts)
+                        eng.rollout(T, policy, auto, trajectory=traj, stats=True)
+                        tr = eng.read_trajectory(0, T) if traj is True else eng.read_trajectory_packed(0, T)
+                        st = eng.get_state()
+                        outs[rows] = [tr[k] for k in sorted(tr)] + [st[k] for k in sorted(st)] + list(eng.read_stats()) + [eng.done_indices()]
+                for rows in (1, 2):
+                    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[rows])), (N, T, policy, auto, traj, rows)
+    gu_option('rollout_rows', None)
+    # the default dispatch at a config-4 shard (32 768 envs, int32 rows) and for packed rows at 65 536 envs is the pair path: oracle
+    grid = C.Grid.from_lists(**meta)
+    for N, traj in ((32768, True), (65536, 'packed')):
+        T = 200
+        with Engine(N, spec_of(meta), seed=4) as eng:
+            eng.reset()
+            eng.reserve_trajectory(T)
+            eng.rollout(T, 'uniform', True, trajectory=traj)
+            got = eng.read_trajectory(0, T) if traj is True else eng.read_trajectory_packed(0, T, unpack=True)
+        st = C.State(2048, N - 2048)
+        C.reset(grid, 4, st)
+        want = C.rollout(grid, 4, st, T, True)
+        for k in ('obs', 'reward', 'done'):
+            assert np.array_equal(got[k][:, N - 2048:], want[k]), (N, traj, k)

@@ -30,7 +30,7 @@ if os.environ.get('PACE_AB_XCD'):
 if os.environ.get('PACE_AB_BLOCK'):
     _lib.set_default_option('rollout_block', int(os.environ['PACE_AB_BLOCK']))  # workgroup size of the general kernel
 if os.environ.get('PACE_AB_ROWS'):
-    _lib.set_default_option('rollout_rows', 1)  # the transition-row kernel wherever it is eligible
+    _lib.set_default_option('rollout_rows', int(os.environ['PACE_AB_ROWS']))  # 1: the transition-row kernel wherever eligible, 2: without its pair tables
 if os.environ.get('PACE_AB_NO_ROWS'):
     _lib.set_default_option('rollout_rows', 0)  # the general kernel also where the transition-row kernel would take the launch
 engines = []

@@ -43,11 +43,11 @@ struct RolloutArgs {
     int32_t stream_lds_off; // GU_POLICY_STREAM, MAP 1: byte offset in LDS of the staged action words [stream_lds_words][blockDim.x] ...
     int32_t stream_lds_words;  // ... and how many words per lane fit (0: every word is read from HBM when its steps are due)
     int32_t xcd_remap;      // workgroup b works on env block (b % 8) * (blocks / 8) + b / 8: one XCD = one contiguous env range
-    uint32_t pace;          // int32-row launches: the waves' schedule (GuPacer), 10 ns ticks per 16 steps -- the rate limiter of the
+    uint32_t pace;          // launches that write rows: the waves' schedule (GuPacer), 10 ns ticks per 16 steps -- the rate limiter of the
                             // store stream; chosen per engine and launch kind by gu_launch_rollout's calibration, 0 = none
 };
 
-// The rate limiter of the int32-row store stream: every wave keeps a SCHEDULE.  `pace` = ticks of the constant 100 MHz clock
+// The rate limiter of the trajectory store stream (int32 rows; packed rows on the transition-row kernel): every wave keeps a SCHEDULE.  `pace` = ticks of the constant 100 MHz clock
 // (s_memrealtime, 10 ns) per 16 steps; a wave may begin its next group of steps no earlier than its own start + steps done x
 // pace / 16, and does not wait at all when it is late.
 //
@@ -569,7 +569,7 @@ void gu_rollout_greedy(gu_engine *h, const RolloutArgs &a, int auto_mode, int tr
 void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
 // the transition-row kernel (gu_rollout_rows.hip): true when it took the launch (*rc: what its pace calibration returned)
 bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats, int *rc);
-// store pacing (gu_kernels.hip): the schedule of an int32-row launch (ticks per 16 steps), calibrated on first use
+// store pacing (gu_kernels.hip): the schedule of a launch that writes rows (ticks per 16 steps), calibrated on first use
 int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, const std::function<void(uint32_t)> &launch, uint32_t *pace);
 // the K-step kernel (gu_rollout_multi.hip; uniform policy, no trajectory): true when it took the launch
 bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);

@@ -101,7 +101,7 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_TRAJ_STRIDE_MIB 15     /* spacer size (3072)                                                                   */
 #define GU_OPT_TRAJ_FAR_MIB 16        /* most memory the search may hold at once (49152)                                      */
 #define GU_OPT_TRAJ_PROBE_ALL 17      /* 1 = probe every candidate, no early stop (measurement aid)                           */
-#define GU_OPT_ROLLOUT_PACE 18        /* store pacing of int32-row launches: 10 ns ticks per 16 steps; -1 = calibrate (default), 0 = none */
+#define GU_OPT_ROLLOUT_PACE 18        /* store pacing of launches that write rows: 10 ns ticks per 16 steps; -1 = calibrate (default), 0 = none */
 #define GU_OPT_COUNT 19
 #define GU_OPT_X_TRAJ_UNCACHED 100    /* EXPERIMENT: uncached memory type for the trajectory (readers may see stale bytes)    */
 #define GU_OPT_X_TRAJ_POISON 101      /* EXPERIMENT: fill a fresh trajectory buffer with 0x5A                                 */
@@ -236,14 +236,14 @@ int gu_probe_trajectory(gu_handle h, float *milliseconds);
 int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 /* Store pacing.  The HBM write path shows congestion collapse: lanes that hand their rows to the memory system as fast as it will
  * take them are served at 5.7 TB/s on most allocations, the same stores offered just below the memory's capacity at 7.2 .. 7.5 on
- * every one.  Launches with GU_F_TRAJECTORY of 128 MB of rows and 64 steps and more (up to four
- * waves per SIMD) keep a SCHEDULE: a wave begins its next 16 steps no earlier than `period` ticks of the 100 MHz clock (10 ns) after the last ones were due, and never
+ * every one.  Launches with GU_F_TRAJECTORY (and GU_F_PACKED launches on the transition-row kernel) of 128 MB of rows
+ * and 64 steps and more (up to four waves per SIMD) keep a SCHEDULE: a wave begins its next 16 steps no earlier than `period` ticks of the 100 MHz clock (10 ns) after the last ones were due, and never
  * waits when it is late.  The period is CALIBRATED the first time a launch kind (policy, auto-reset) runs on a trajectory buffer,
  * by timing the kernel itself on the engine's own state (snapshot before, put back after: results never depend on it; that first
  * gu_rollout is synchronous and takes ~80 launches longer).  GU_OPT_ROLLOUT_PACE fixes the period instead (0 = no limiter).
  * This reports what the calibration found for a launch kind: the period, ms per launch without and with the limiter, candidates
  * timed, ms spent calibrating.  GU_ERR_STATE when that kind has not been calibrated (not launched yet, or not a launch that is
- * paced). */
+ * paced).  `flags` with GU_F_PACKED asks for the packed-row launches' record. */
 int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
                       int32_t *evaluated, float *calibration_ms);
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);

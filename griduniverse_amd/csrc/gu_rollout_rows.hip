@@ -473,9 +473,12 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         // is the quicker one: 88 against 116 us at 32 768 envs, profiles/r02j_stream_crossover.txt)
         // (measured on the 256 CUs of an MI355X; stated relative to the CU count: one workgroup per CU, a quarter, half of them)
         const unsigned cus = (unsigned)h->n_cu;
-        const unsigned int32_limit = policy == GU_POLICY_SAMPLE ? cus : policy == GU_POLICY_STREAM ? cus / 4 : cus / 2;
+        // (round 3, under the schedule limiter, 65 536 envs with int32 rows, profiles/r03s_rows_vs_general.txt: greedy with auto-reset
+        // 108 .. 111 us here against 119 .. 120 on the general kernel, whose step then has two dependent LDS reads; sampled without
+        // auto-reset 135 against 142; uniform / stream / greedy without auto-reset: the same on both, they stay where they were)
+        const unsigned int32_limit = (policy == GU_POLICY_SAMPLE || (policy == GU_POLICY_GREEDY && auto_mode == 1)) ? cus : policy == GU_POLICY_STREAM ? cus / 4 : cus / 2;
         if ((traj == 1 && blocks > int32_limit) || (traj == 2 && blocks > cus)) return false;
-        if (policy == GU_POLICY_SAMPLE && auto_mode != 1) return false;
+        if (policy == GU_POLICY_SAMPLE && auto_mode != 1 && traj != 1) return false;
     }
     const bool table_policy = policy == GU_POLICY_GREEDY || policy == GU_POLICY_SAMPLE;
     const int row_log2 = policy == GU_POLICY_GREEDY ? 2 : policy == GU_POLICY_SAMPLE ? 5 : 4;

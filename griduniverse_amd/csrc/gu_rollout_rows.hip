@@ -476,9 +476,13 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         // (round 3, under the schedule limiter, 65 536 envs with int32 rows, profiles/r03s_rows_vs_general.txt: greedy with auto-reset
         // 108 .. 111 us here against 119 .. 120 on the general kernel, whose step then has two dependent LDS reads; sampled without
         // auto-reset 135 against 142; uniform / stream / greedy without auto-reset: the same on both, they stay where they were)
-        const unsigned int32_limit = (policy == GU_POLICY_SAMPLE || (policy == GU_POLICY_GREEDY && auto_mode == 1)) ? cus : policy == GU_POLICY_STREAM ? cus / 4 : cus / 2;
+        // (the whole table, 8192 .. 65 536 envs x four policy kinds x int32 / packed rows on both kernels: profiles/r03s_rows_crossover.txt.
+        // A caller-supplied stream with int32 rows used to leave this kernel at 16 384 envs -- its action words are read straight
+        // from HBM among the streaming stores --; with sc1 + nt stores it is the quicker one up to 32 768 like the uniform policy:
+        // 60 .. 61 against 66 .. 71 us)
+        const unsigned int32_limit = (policy == GU_POLICY_SAMPLE || (policy == GU_POLICY_GREEDY && auto_mode == 1)) ? cus : cus / 2;
         if ((traj == 1 && blocks > int32_limit) || (traj == 2 && blocks > cus)) return false;
-        if (policy == GU_POLICY_SAMPLE && auto_mode != 1 && traj != 1) return false;
+        if (policy == GU_POLICY_SAMPLE && auto_mode != 1 && traj == 0) return false;
     }
     const bool table_policy = policy == GU_POLICY_GREEDY || policy == GU_POLICY_SAMPLE;
     const int row_log2 = policy == GU_POLICY_GREEDY ? 2 : policy == GU_POLICY_SAMPLE ? 5 : 4;

@@ -29,7 +29,7 @@ OPT_UNSET = -2 ** 63
 OPTIONS = {'rollout_block': 1, 'rollout_rows': 2, 'rows_copies': 3, 'rollout_multi': 4, 'rollout_multi_k': 5,
            'rollout_multi_copies': 6, 'rollout_xcd': 7, 'vi_path': 8, 'mc_scratch_mb': 9, 'mc_lane_returns': 10,
            'mc_global_walk': 11, 'step_sync': 12, 'traj_candidates': 13, 'traj_far_candidates': 14, 'traj_stride_mib': 15,
-           'traj_far_mib': 16, 'traj_probe_all': 17, 'rollout_pace': 18,
+           'traj_far_mib': 16, 'traj_probe_all': 17, 'rollout_pace': 18, 'vi_xcd_block': 19,
            # experiments: refused by libgu.so, accepted by libgu_exp.so only
            'x_traj_uncached': 100, 'x_traj_poison': 101, 'x_mc_poison': 102}
 
@@ -81,6 +81,7 @@ SIGNATURES = {
     'gu_vi_get': [_vp, _vp, _vp],
     'gu_vi_sweep_step': [_vp, _f64, _u32, _vp],
     'gu_vi_sweep_step_run': [_vp, _f64, _i32, _u32, _vp],
+    'gu_vi_last_form': [_vp],
     'gu_mc_evaluate': [_vp, _i64, _vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp],
     'gu_shortest_paths': [_vp, _i32, _vp, _vp, _vp],
     'gu_render_rgb': [_vp, _i64, _i64, _i32, _vp],

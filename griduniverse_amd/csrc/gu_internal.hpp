@@ -155,6 +155,7 @@ struct gu_engine {
     double *d_delta = nullptr;      // per-block maxima + final
     uint8_t *d_greedy = nullptr;    // first-argmax action per state [cell_bytes]
     bool greedy_valid = false;
+    int vi_run_form = 0;            // which form the last gu_vi_sweep_step_run took: 1 per XCD, 2 chip-wide cluster, 3 one launch per round
 
     // RCCL
     void *comm = nullptr;  // ncclComm_t
@@ -239,6 +240,16 @@ int gu_device_copy(gu_engine *h, void *dst, const void *src, size_t bytes);
 int gu_vi_alloc(gu_engine *h);
 void gu_vi_free(gu_engine *h);
 int gu_launch_greedy_table(gu_engine *h);
+
+// ---- config 5 synchronised per XCD (gu_vi_xcd.hip) --------------------------------
+struct GuXcdPlan {
+    int block = 0, K = 0;      // threads per workgroup, states per thread at most
+    unsigned G = 0;            // workgroups
+    size_t lds = 0, slots_bytes = 0, vx_bytes = 0, ax_bytes = 0;  // dynamic LDS; scratch: barrier slots, value copies, action tables
+};
+struct ViStepXcdArgs;
+bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan);
+int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a);
 
 // ---- grids (gu_api.hip / gu_maze.hip) ----------------------------------------------
 int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const std::vector<uint8_t> &cell,

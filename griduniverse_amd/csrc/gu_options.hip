@@ -27,7 +27,7 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_ROLLOUT_MULTI_K", 0, 0, 4},
     {"GU_ROLLOUT_MULTI_COPIES", 1, 1, 2},
     {"GU_ROLLOUT_XCD", 0, 0, 1},
-    {"GU_VI_PATH", 0, 0, 3},
+    {"GU_VI_PATH", 0, 0, 5},
     {"GU_MC_SCRATCH_MB", 2048, 1, 1 << 20},
     {"GU_MC_LANE_RETURNS", 0, 0, 1},
     {"GU_MC_GLOBAL_WALK", 0, 0, 1},
@@ -38,6 +38,7 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_TRAJ_FAR_MIB", 49152, 0, 1 << 22},
     {"GU_TRAJ_PROBE_ALL", 0, 0, 1},
     {"GU_ROLLOUT_PACE", -1, -1, 0xFFFFF},
+    {"GU_VI_XCD_BLOCK", 0, 0, 1024},
 };
 const char *g_spec_x[GU_OPT_X_COUNT] = {"GU_TRAJ_UNCACHED", "GU_TRAJ_POISON", "GU_MC_POISON"};
 
@@ -54,6 +55,7 @@ void defaults_init()
 }
 
 bool block_size_ok(int64_t v) { return v == 64 || v == 128 || v == 256 || v == 512 || v == 1024; }
+bool xcd_block_ok(int64_t v) { return v == 0 || v == 256 || v == 512 || v == 1024; }
 
 }  // namespace
 
@@ -79,7 +81,7 @@ int64_t gu_opt(const gu_engine *h, int option)
         if (c && std::atoi(c) == 0) return 1;
     } else if (const char *s = std::getenv(g_spec[option].name)) {
         const int64_t v = std::atoll(s);
-        if (v >= g_spec[option].lo && v <= g_spec[option].hi && (option != GU_OPT_ROLLOUT_BLOCK || block_size_ok(v))) return v;
+        if (v >= g_spec[option].lo && v <= g_spec[option].hi && (option != GU_OPT_ROLLOUT_BLOCK || block_size_ok(v)) && (option != GU_OPT_VI_XCD_BLOCK || xcd_block_ok(v))) return v;
     }
 #endif
     if (h && h->opt[option] != GU_OPT_UNSET) return h->opt[option];
@@ -118,6 +120,7 @@ int gu_set_option(gu_handle h, int32_t option, int64_t value)
     if (value != GU_OPT_UNSET) {
         GU_REQUIRE(value >= sp.lo && value <= sp.hi, GU_ERR_INVALID, "option %s: %lld outside %lld .. %lld", sp.name, (long long)value,
                    (long long)sp.lo, (long long)sp.hi);
+        if (option == GU_OPT_VI_XCD_BLOCK) GU_REQUIRE(xcd_block_ok(value), GU_ERR_INVALID, "option %s: %lld is not 0, 256, 512 or 1024", sp.name, (long long)value);
         if (option == GU_OPT_ROLLOUT_BLOCK) GU_REQUIRE(block_size_ok(value), GU_ERR_INVALID, "option %s: %lld is not 64, 128, 256, 512 or 1024", sp.name, (long long)value);
         if (option == GU_OPT_ROWS_COPIES) GU_REQUIRE((value & (value - 1)) == 0, GU_ERR_INVALID, "option %s: %lld is not a power of two", sp.name, (long long)value);
         if (option == GU_OPT_ROLLOUT_MULTI_K) GU_REQUIRE(value == 0 || value == 2 || value == 4, GU_ERR_INVALID, "option %s: K is 2 or 4", sp.name);

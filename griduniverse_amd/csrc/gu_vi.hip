@@ -18,6 +18,7 @@
 // states ("pull" evaluation), which needs no grid-wide barrier inside the launch.
 #include "gu_internal.hpp"
 #include "gu_rng.hpp"
+#include "gu_vi.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -27,105 +28,6 @@
 
 #define VI_BLOCK 256
 #define VI_RUN_BATCH 64  // rounds queued per host look of gu_vi_run (must not exceed the 4096 delta slots)
-
-struct ViMap {
-    const uint8_t *f;  // flags plane (OPEN bits 0..3, TERM bit 4)
-    const int8_t *r;   // reward plane
-};
-
-__device__ __forceinline__ int32_t vi_delta(uint32_t a, int32_t W)
-{
-    const int32_t sign = (int32_t)(a & 2u) - 1;
-    return (a & 1u) ? -sign : sign * W;
-}
-
-__device__ __forceinline__ double vi_reward(const ViMap &m, int32_t s) { return (double)m.r[s]; }
-
-__device__ __forceinline__ int32_t vi_next(int32_t s, uint32_t flags, uint32_t a, int32_t W)
-{
-    return ((flags >> a) & 1u) ? s + vi_delta(a, W) : s;
-}
-
-// V1 for one state
-__device__ __forceinline__ double vi_eval_state(const ViMap &cell, int32_t W, double gamma, const double *__restrict__ v,
-                                                const double *__restrict__ pi, int32_t s)
-{
-    const uint32_t rec = cell.f[s];
-    double acc = __dadd_rn(0.0, vi_reward(cell, s));
-#pragma unroll
-    for (uint32_t a = 0; a < 4; ++a) {
-        const int32_t n = vi_next(s, rec, a, W);
-        acc = __dadd_rn(acc, __dmul_rn(pi[4 * s + a], __dmul_rn(gamma, v[n])));
-    }
-    return acc;
-}
-
-// Ties of np.around(q, 8) (utils.py:66-68).  around8(x) = rint(x * 1e8) / 1e8 and the division is a function of the
-// integer k = rint(x * 1e8) alone, so equal k give equal around8.  Conversely, while |k| < 2^25 * 1e8 the quotients of
-// two different integers are at least 1e-8 apart and an ulp there is at most 2^-27 < 1e-8, so they round to
-// different float64: equality of around8 IS equality of k, and the five IEEE divisions (a third of the round's
-// arithmetic) are only needed beyond |q| = 3.3e7 or for NaN.
-__device__ __forceinline__ uint32_t vi_tie_mask(const double q[4], double qmax)
-{
-    double k[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) k[a] = rint(__dmul_rn(q[a], 100000000.0));
-    const double kmax = rint(__dmul_rn(qmax, 100000000.0));
-    const double lim = 3355443200000000.0;  // 2^25 * 1e8 (exactly representable, < 2^53)
-    const bool small = fabs(k[0]) < lim && fabs(k[1]) < lim && fabs(k[2]) < lim && fabs(k[3]) < lim;  // false on NaN
-    uint32_t mask = 0;
-    if (small) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) mask |= (uint32_t)(k[a] == kmax) << a;
-    } else {
-        const double rmax = __ddiv_rn(kmax, 100000000.0);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) mask |= (uint32_t)(__ddiv_rn(k[a], 100000000.0) == rmax) << a;
-    }
-    return mask;
-}
-
-__device__ __forceinline__ double vi_share(uint32_t mask)
-{
-    const int ties = __popc(mask);
-    return (ties == 1) ? 1.0 : (ties == 2) ? 0.5 : (ties == 3) ? (1.0 / 3.0) : 0.25;
-}
-
-// V2 for one state given a functor returning v'(n): bit a of the result = action a ties for the maximum
-// (0 for a terminal state: its row is all zeros, utils.py:62-63)
-template <typename VNew>
-__device__ __forceinline__ uint32_t vi_greedy_mask(const ViMap &cell, int32_t W, double gamma, VNew vnew, int32_t s)
-{
-    const uint32_t rec = cell.f[s];
-    double q[4];
-#pragma unroll
-    for (uint32_t a = 0; a < 4; ++a) {
-        const int32_t n = vi_next(s, rec, a, W);
-        const double rn = vi_reward(cell, n);
-        q[a] = __dadd_rn(0.0, __dadd_rn(rn, __dmul_rn(gamma, vnew(n))));
-    }
-    double qmax = q[0];
-#pragma unroll
-    for (int a = 1; a < 4; ++a) qmax = (q[a] > qmax) ? q[a] : qmax;
-    const uint32_t mask = vi_tie_mask(q, qmax);
-    return (rec & GU_CELL_TERM) ? 0u : mask;
-}
-
-template <typename VNew>
-__device__ __forceinline__ void vi_greedy_state(const ViMap &cell, int32_t W, double gamma, VNew vnew, int32_t s, double out[4])
-{
-    const uint32_t mask = vi_greedy_mask(cell, W, gamma, vnew, s);
-    const double share = vi_share(mask);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) out[a] = ((mask >> a) & 1u) ? share : 0.0;
-}
-
-// order-preserving double -> uint64 key so that max(double) is an integer atomicMax
-__device__ __forceinline__ unsigned long long vi_key(double x)
-{
-    unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
 
 __device__ __forceinline__ void vi_block_max_to_global(double mine, bool valid, unsigned long long *out)
 {
@@ -141,18 +43,6 @@ __device__ __forceinline__ void vi_block_max_to_global(double mine, bool valid, 
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) k = wave_key[w] > k ? wave_key[w] : k;
         atomicMax(out, k);
     }
-}
-
-template <bool LDS>
-__device__ __forceinline__ ViMap vi_stage(const uint8_t *__restrict__ g, int32_t cell_bytes, uint8_t *smem)
-{
-    if (LDS) {
-        for (int32_t i = threadIdx.x * 16; i < 2 * cell_bytes; i += blockDim.x * 16)
-            *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(g + i);
-        __syncthreads();
-        return ViMap{smem, reinterpret_cast<const int8_t *>(smem + cell_bytes)};
-    }
-    return ViMap{g, reinterpret_cast<const int8_t *>(g + cell_bytes)};
 }
 
 struct ViArgs {
@@ -197,12 +87,6 @@ __global__ void __launch_bounds__(VI_BLOCK) gu_vi_greedy_kernel(const ViArgs a)
     const double *vn = a.v_new;
     vi_greedy_state(cell, a.W, a.gamma, [vn](int32_t n) { return vn[n]; }, s, row);
     *reinterpret_cast<double4 *>(a.pi_new + 4 * s) = make_double4(row[0], row[1], row[2], row[3]);
-}
-
-__device__ __forceinline__ double vi_unkey_dev(unsigned long long k)
-{
-    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
-    return __longlong_as_double((long long)b);
 }
 
 // One value-iteration round (V1, delta, V2: dynamic_programming.py:15-20) in ONE launch: the greedy update needs
@@ -367,31 +251,8 @@ __global__ void __launch_bounds__(VI_PB_THREADS) gu_vi_block_kernel(const ViBloc
 #define VI_CL_MAX_WGS 256
 #define VI_CL_MAX_K 2  /* states per thread: 4 would spill at the 128 registers of a 1024-thread workgroup */
 #define VI_CL_MAX_STATES (VI_CL_MAX_WGS * VI_CL_THREADS * VI_CL_MAX_K)
-#define VI_CL_SPIN_LIMIT (1u << 22)
 
-typedef unsigned long long vi_u64;
 
-struct ViClusterArgs {
-    const uint8_t *cell;
-    int32_t cell_bytes, W, S;
-    double gamma, threshold;
-    double *v0, *v1;                 // double-buffered value table; v0 holds the current values at entry
-    double *pi;                      // [S][4], updated in place when GREEDY and at least one round ran
-    vi_u64 *delta_key;               // [max_rounds], zeroed before the launch
-    uint32_t *sync;                  // [0] arrival counter, [1] timeout word; zeroed before the launch
-    int32_t *rounds_done;
-    int32_t max_rounds, use_threshold;
-};
-
-__device__ __forceinline__ double vi_ld_agent(const double *p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const vi_u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-__device__ __forceinline__ void vi_st_agent(double *p, double x)
-{
-    __hip_atomic_store(reinterpret_cast<vi_u64 *>(p), (vi_u64)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 template <int K, bool GREEDY>
 __global__ void __launch_bounds__(VI_CL_THREADS) gu_vi_cluster_kernel(const ViClusterArgs a)
@@ -527,17 +388,6 @@ __global__ void __launch_bounds__(VI_CL_THREADS) gu_vi_cluster_kernel(const ViCl
 // Against one gu_vi_sweep_step launch per round a round costs the barrier (~3 us) instead of a kernel boundary plus the
 // pull evaluations (7.4 us per launch at config 5).  Same inter-workgroup protocol as gu_vi_cluster_kernel.
 // ------------------------------------------------------------------------------------
-struct ViStepClusterArgs {
-    ViClusterArgs vi;                // max_rounds = iters, use_threshold unused
-    int32_t *pos, *reward, *done;
-    uint32_t *episode;
-    const int32_t *starts;
-    uint32_t n_starts, seed_prefix, env_id0;
-    int64_t N;
-    uint32_t flags;
-    uint64_t *done_bits;
-};
-
 __global__ void __launch_bounds__(VI_CL_THREADS) gu_vi_sweep_step_cluster_kernel(const ViStepClusterArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1209,68 +1059,92 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
     const int64_t threads = h->N > h->S ? h->N : (int64_t)h->S;
     const int64_t G = (threads + VI_CL_THREADS - 1) / VI_CL_THREADS;
     const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
-    bool cluster = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && G <= (h->n_cu < VI_CL_MAX_WGS ? h->n_cu : VI_CL_MAX_WGS) && (path == 0 || path == 3);
-    const size_t key_bytes = (size_t)iters * sizeof(unsigned long long);
-    const size_t snap_off = (16 + key_bytes + 15) & ~(size_t)15;
-    const size_t v_bytes = (size_t)h->S * sizeof(double), n4 = (size_t)h->N * 4, bits_bytes = (((size_t)h->N + 63) / 64) * 8;
-    if (cluster) {
-        rc = gu_ensure_scratch(h, snap_off + 5 * v_bytes + 4 * n4 + bits_bytes);
+    // Three forms, fastest first: ONE launch synchronised per XCD (gu_vi_xcd.hip), ONE launch with a chip-wide barrier per round,
+    // one launch per round.  The one-launch forms work on a snapshot's ORIGINAL: a form that gives up (every spin in them is bounded)
+    // leaves half-advanced state, which is put back before the next form runs.
+    GuXcdPlan xp{};
+    const bool try_xcd = (path == 0 || path == 5) && gu_vi_xcd_plan(h, &xp);
+    const bool try_cluster = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && G <= (h->n_cu < VI_CL_MAX_WGS ? h->n_cu : VI_CL_MAX_WGS) &&
+                             (path == 0 || path == 3 || path == 4 || path == 5);
+    if (try_xcd || try_cluster) {
+        // scratch: header (64 B) | delta keys [iters] | barrier slots of the per-XCD form | snapshot | the per-XCD value copies and action tables
+        const size_t key_bytes = (size_t)iters * sizeof(unsigned long long);
+        const size_t slots_off = (64 + key_bytes + 255) & ~(size_t)255;
+        const size_t snap_off = slots_off + (try_xcd ? xp.slots_bytes : 0);
+        const size_t v_bytes = (size_t)h->S * sizeof(double), n4 = (size_t)h->N * 4, bits_bytes = (((size_t)h->N + 63) / 64) * 8;
+        const size_t snap_bytes = (5 * v_bytes + 4 * n4 + bits_bytes + 255) & ~(size_t)255;
+        rc = gu_ensure_scratch(h, snap_off + snap_bytes + (try_xcd ? xp.vx_bytes + xp.ax_bytes : 0));
         if (rc != GU_OK) return rc;
-        uint32_t *sync_d = (uint32_t *)h->d_scratch;
+        uint32_t *hdr_d = (uint32_t *)h->d_scratch;
         int32_t *done_d = (int32_t *)h->d_scratch + 2;
-        unsigned long long *keys_d = (unsigned long long *)((char *)h->d_scratch + 16);
+        unsigned long long *keys_d = (unsigned long long *)((char *)h->d_scratch + 64);
         char *snap = (char *)h->d_scratch + snap_off;
-        GU_HIP(hipMemsetAsync(h->d_scratch, 0, snap_off, h->stream));
-        // what a barrier timeout would leave half-advanced -- tables, positions, rewards, done flags and their ballots,
-        // episode counters -- is snapshot first (device to device), so that a timeout can hand the UNTOUCHED state to the
-        // one-launch-per-round path below
+        // what a form that gives up would leave half-advanced -- tables, positions, rewards, done flags and their ballots,
+        // episode counters -- is snapshot first (device to device)
         void *live[5] = {h->d_v[h->vi_cur], h->d_pi[h->vi_cur], h->d_out3, h->d_episode, h->d_done_bits};
         const size_t size[5] = {v_bytes, 4 * v_bytes, 3 * n4, n4, bits_bytes};
         size_t off = 0;
         for (int k = 0; k < 5; off += size[k], ++k)
             if ((rc = gu_device_copy(h, snap + off, live[k], size[k])) != GU_OK) return rc;
-        if (path == 3) GU_HIP(hipMemsetD32Async((hipDeviceptr_t)(sync_d + 1), 1, 1, h->stream));  // tests: an injected timeout
-        ViStepClusterArgs a{};
-        a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, 0.0, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1],
-                             h->d_pi[h->vi_cur], keys_d, sync_d, done_d, iters, 0};
-        a.pos = h->pos();
-        a.reward = h->reward();
-        a.done = h->done();
-        a.episode = h->d_episode;
-        a.starts = h->d_starts;
-        a.n_starts = (uint32_t)h->n_starts;
-        a.seed_prefix = h->seed_prefix;
-        a.env_id0 = (uint32_t)h->env_id0;
-        a.N = h->N;
-        a.flags = flags;
-        a.done_bits = h->d_done_bits;
-        hipLaunchKernelGGL(gu_vi_sweep_step_cluster_kernel, dim3((unsigned)G), dim3(VI_CL_THREADS), 2 * (size_t)h->cell_bytes, h->stream, a);
-        GU_HIP(hipGetLastError());
-        int32_t ctl[4] = {0, 0, 0, 0};  // [arrival counter, timeout word, rounds_done, pad]: the timeout word decides (see vi_cluster_run)
-        GU_HIP(hipMemcpyAsync(ctl, h->d_scratch, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
-        GU_HIP(hipStreamSynchronize(h->stream));
-        const int32_t done = ctl[1] ? -1 : ctl[2];
-        if (done >= 0) {
-            if (deltas) {
-                std::vector<unsigned long long> keys((size_t)iters);
-                GU_HIP(hipMemcpy(keys.data(), keys_d, key_bytes, hipMemcpyDeviceToHost));
-                for (int32_t i = 0; i < iters; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
+        for (int form = 0; form < 2; ++form) {  // 0: per XCD, 1: chip-wide
+            if (form == 0 ? !try_xcd : !try_cluster) continue;
+            GU_HIP(hipMemsetAsync(h->d_scratch, 0, form == 0 ? snap_off : slots_off, h->stream));  // every polled word is zeroed before every launch
+            ViStepXcdArgs a{};
+            a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, 0.0, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1],
+                                 h->d_pi[h->vi_cur], keys_d, hdr_d, done_d, iters, 0};
+            a.pos = h->pos();
+            a.reward = h->reward();
+            a.done = h->done();
+            a.episode = h->d_episode;
+            a.starts = h->d_starts;
+            a.n_starts = (uint32_t)h->n_starts;
+            a.seed_prefix = h->seed_prefix;
+            a.env_id0 = (uint32_t)h->env_id0;
+            a.N = h->N;
+            a.flags = flags;
+            a.done_bits = h->d_done_bits;
+            if (form == 0) {
+                a.slots = (vi_u64 *)((char *)h->d_scratch + slots_off);
+                a.vx = (double *)(snap + snap_bytes);
+                a.ax = (uint8_t *)(snap + snap_bytes + xp.vx_bytes);
+                a.work_bytes = (uint32_t)(xp.vx_bytes + xp.ax_bytes);
+                a.inject_failure = path == 5;  // tests: the per-XCD form gives up
+                if ((rc = gu_vi_xcd_launch(h, xp, a)) != GU_OK) return rc;
+            } else {
+                if (path == 3) GU_HIP(hipMemsetD32Async((hipDeviceptr_t)(hdr_d + 1), 1, 1, h->stream));  // tests: an injected timeout
+                hipLaunchKernelGGL(gu_vi_sweep_step_cluster_kernel, dim3((unsigned)G), dim3(VI_CL_THREADS), 2 * (size_t)h->cell_bytes, h->stream,
+                                   static_cast<const ViStepClusterArgs &>(a));
+                GU_HIP(hipGetLastError());
             }
-            if (iters & 1) {
-                double *t = h->d_v[0];
-                h->d_v[0] = h->d_v[1];
-                h->d_v[1] = t;
+            // rounds_done is written by ONE workgroup, and giving up need not be unanimous: the fallback word, raised by whoever
+            // gives up, decides (see vi_cluster_run)
+            int32_t ctl[4] = {0, 0, 0, 0};  // [arrival counter, fallback word, rounds_done, -]
+            GU_HIP(hipMemcpyAsync(ctl, h->d_scratch, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
+            GU_HIP(hipStreamSynchronize(h->stream));
+            if (!ctl[1] && ctl[2] == iters) {
+                if (deltas) {
+                    std::vector<unsigned long long> keys((size_t)iters);
+                    GU_HIP(hipMemcpy(keys.data(), keys_d, key_bytes, hipMemcpyDeviceToHost));
+                    for (int32_t i = 0; i < iters; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
+                }
+                if (iters & 1) {
+                    double *t = h->d_v[0];
+                    h->d_v[0] = h->d_v[1];
+                    h->d_v[1] = t;
+                }
+                h->greedy_valid = false;
+                h->steps_taken += (uint32_t)iters;
+                h->vi_run_form = form == 0 ? 1 : 2;
+                return GU_OK;
             }
-            h->greedy_valid = false;
-            h->steps_taken += (uint32_t)iters;
-            return GU_OK;
+            off = 0;
+            for (int k = 0; k < 5; off += size[k], ++k)
+                if ((rc = gu_device_copy(h, live[k], snap + off, size[k])) != GU_OK) return rc;
+            GU_HIP(hipStreamSynchronize(h->stream));
+            if (gu_debug())
+                fprintf(stderr, "[gu] sweep-step %s kernel gave up (workgroups not resident together, or clusters too uneven); state restored, next form\n",
+                        form == 0 ? "per-XCD" : "chip-wide cluster");
         }
-        off = 0;
-        for (int k = 0; k < 5; off += size[k], ++k)
-            if ((rc = gu_device_copy(h, live[k], snap + off, size[k])) != GU_OK) return rc;
-        GU_HIP(hipStreamSynchronize(h->stream));
-        if (gu_debug()) fprintf(stderr, "[gu] sweep-step cluster kernel: grid barrier timed out (%lld workgroups not resident together); state restored, one launch per round instead\n", (long long)G);
-        cluster = false;
     }
     // one fused launch per round; the deltas are collected once at the end
     std::vector<double> one((size_t)iters);
@@ -1279,7 +1153,10 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
         if (rc != GU_OK) return rc;
     }
     if (deltas) memcpy(deltas, one.data(), (size_t)iters * sizeof(double));
+    h->vi_run_form = 3;
     return GU_OK;
 }
+
+int gu_vi_last_form(gu_handle h) { return h ? h->vi_run_form : 0; }
 
 }  // extern "C"

@@ -335,11 +335,16 @@ class Engine(object):
         return d.value if want_delta else None
 
     def vi_sweep_step_run(self, gamma=1.0, iters=1, auto_reset=False):
-        """`iters` rounds of {V1 + V2 sweep; every env steps greedily on the updated policy} -- one launch when table and
-        batch fit a workgroup cluster.  Returns the per-round deltas."""
+        """`iters` rounds of {V1 + V2 sweep; every env steps greedily on the updated policy} -- one launch (synchronised per XCD, or
+        chip-wide) when table and batch fit the resident workgroups, see vi_last_form().  Returns the per-round deltas."""
         deltas = np.empty(int(iters), np.float64)
         check(self.lib.gu_vi_sweep_step_run(self._h, float(gamma), int(iters), _lib.F_AUTO_RESET if auto_reset else 0, ptr(deltas)))
         return deltas
+
+    def vi_last_form(self):
+        """Which form the last vi_sweep_step_run took: 1 = one launch synchronised per XCD, 2 = one launch with a chip-wide
+        barrier per round, 3 = one launch per round (0: none yet)."""
+        return int(self.lib.gu_vi_last_form(self._h))
 
     def mc_evaluate(self, T, first_state, discount_pow, keep, every_visit=False, incremental_mean=True,
                     stationary_env=True, alpha=0.001):

@@ -91,7 +91,9 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_ROLLOUT_MULTI_COPIES 6 /* 2 = replicate its table across the banks                                             */
 #define GU_OPT_ROLLOUT_XCD 7          /* 1 = XCD-aware env-block order (measured slower; off)                                 */
 #define GU_OPT_VI_PATH 8              /* DP: 1 = no workgroup-cluster kernel, 2 = one launch per round on every grid size,
-                                         3 = cluster kernel with an INJECTED grid-barrier timeout (tests of the fallback)    */
+                                         3 = chip-wide cluster kernel with an INJECTED grid-barrier timeout (tests of the
+                                         fallback), 4 = no per-XCD form of gu_vi_sweep_step_run (the chip-wide cluster kernel
+                                         instead), 5 = its per-XCD form gives up at once (INJECTED; tests of the fallback)   */
 #define GU_OPT_MC_SCRATCH_MB 9        /* scratch budget of gu_mc_evaluate (2048)                                              */
 #define GU_OPT_MC_LANE_RETURNS 10     /* 1 = return sums by the per-lane kernel instead of the LDS-tiled one                  */
 #define GU_OPT_MC_GLOBAL_WALK 11      /* 1 = history walk with its counters in global memory instead of LDS                   */
@@ -102,7 +104,8 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_TRAJ_FAR_MIB 16        /* most memory the search may hold at once (49152)                                      */
 #define GU_OPT_TRAJ_PROBE_ALL 17      /* 1 = probe every candidate, no early stop (measurement aid)                           */
 #define GU_OPT_ROLLOUT_PACE 18        /* store pacing of launches that write rows: 10 ns ticks per 16 steps; -1 = calibrate (default), 0 = none */
-#define GU_OPT_COUNT 19
+#define GU_OPT_VI_XCD_BLOCK 19        /* workgroup size of the per-XCD form of gu_vi_sweep_step_run: 256, 512, 1024 (0 = by batch size) */
+#define GU_OPT_COUNT 20
 #define GU_OPT_X_TRAJ_UNCACHED 100    /* EXPERIMENT: uncached memory type for the trajectory (readers may see stale bytes)    */
 #define GU_OPT_X_TRAJ_POISON 101      /* EXPERIMENT: fill a fresh trajectory buffer with 0x5A                                 */
 #define GU_OPT_X_MC_POISON 102        /* EXPERIMENT: fill the Monte-Carlo scratch with 0x5A before every evaluation           */
@@ -283,9 +286,13 @@ int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int3
  * gu_vi_get   : download v / pi (either may be NULL)
  * gu_vi_sweep_step : config 5 -- ONE launch that performs one V1+V2 sweep AND one env
  *               step in which every agent acts greedily on the updated policy.
- * gu_vi_sweep_step_run : `iters` such rounds; when the table and the batch fit one workgroup cluster (max(S, N) <= 1024 x
- *               the device's CUs, S <= 32 767) the whole loop is ONE launch with a grid barrier per round, otherwise one
- *               launch per round.  deltas[iters] optional. */
+ * gu_vi_sweep_step_run : `iters` such rounds.  Three forms, fastest first: (1) ONE launch synchronised per XCD -- every XCD
+ *               sweeps the whole table with its own workgroups and steps its share of the agents, nothing a round needs
+ *               leaves the XCD's L2 (table + planes within one workgroup's LDS, one workgroup per CU at most); (2) ONE launch
+ *               of a workgroup cluster with a chip-wide barrier per round (max(S, N) <= 1024 x the device's CUs,
+ *               S <= 32 767); (3) one launch per round.  A form that cannot hold its workgroups resident together gives up
+ *               (bounded spins), the state is put back, the next form runs.  deltas[iters] optional.
+ * gu_vi_last_form : which of the three the last gu_vi_sweep_step_run of this engine took (1, 2, 3; 0 = none yet). */
 int gu_vi_set(gu_handle h, const double *v, const double *pi);
 int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update, double *deltas);
 int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, int32_t *steps_done, double *deltas);
@@ -294,6 +301,7 @@ int gu_vi_greedy(gu_handle h, double gamma);
 int gu_vi_get(gu_handle h, double *v, double *pi);
 int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta);
 int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flags, double *deltas);
+int gu_vi_last_form(gu_handle h);
 
 /* ---- Monte-Carlo policy evaluation: core/algorithms/monte_carlo.py:29-99 ----------------
  * Consumes the trajectory rows 0..T-1 of the last gu_rollout (run WITHOUT auto-reset: env e is

@@ -390,18 +390,22 @@ def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, gu_option):
 
 
 @pytest.mark.parametrize('name,N,auto', [('maze64_s5', 65536, True), ('maze64_s5_g097', 4096, False), ('rect6x5_g1', 100, True),
-                                         ('lava4x4_g095', 3, True), ('maze32_s1', 20000, True)])
+                                         ('lava4x4_g095', 3, True), ('maze32_s1', 20000, True), ('maze64_s5', 262144, True)])
 def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, gu_option):
-    """gu_vi_sweep_step_run (config 5 for many rounds: one launch of a workgroup cluster with a grid barrier per round) against
-    the same number of single gu_vi_sweep_step launches: value table, policy, deltas, and every env's position / reward /
-    done flag / episode count, as raw bytes; and its first rounds against the reference's value-iteration trace."""
+    """gu_vi_sweep_step_run (config 5 for many rounds in ONE launch: synchronised per XCD, or a workgroup cluster with a chip-wide
+    barrier per round) against the same number of single gu_vi_sweep_step launches: value table, policy, deltas, and every env's
+    position / reward / done flag / episode count, as raw bytes; and its first rounds against the reference's value-iteration
+    trace.  Every form, every workgroup size of the per-XCD form, and both injected give-ups (state restored, next form)."""
     meta, z = G.load_dp(name)
     S, gamma = meta['W'] * meta['H'], meta['gamma']
     iters = 23
-    out = {}
-    for mode in ('single', 'run', 'run_no_cluster', 'run_timeout'):  # (run_timeout: injected barrier timeout -> state restored, fallback)
+    out, form = {}, {}
+    modes = {'single': None, 'run': None, 'run_xcd_256': None, 'run_xcd_512': None, 'run_xcd_1024': None, 'run_chip_wide': 4,
+             'run_no_cluster': 1, 'run_timeout': 3, 'run_xcd_gives_up': 5}
+    for mode, path in modes.items():
         if vi_path != 'launch_per_round':
-            gu_option('vi_path', {'run_no_cluster': 1, 'run_timeout': 3}.get(mode))
+            gu_option('vi_path', path)
+        gu_option('vi_xcd_block', int(mode[8:]) if mode.startswith('run_xcd_') and mode[8:].isdigit() else None)
         with Engine(N, spec_of(meta), seed=3) as eng:
             eng.reset()
             eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
@@ -411,6 +415,7 @@ def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, g
                 deltas = eng.vi_sweep_step_run(gamma, iters, auto_reset=auto)
                 deltas = np.concatenate([deltas, eng.vi_sweep_step_run(gamma, 2, auto_reset=auto)])  # even + odd round counts
                 eng.vi_sweep_step_run(gamma, 1, auto_reset=auto)
+                form[mode] = eng.vi_last_form()
             if mode == 'single':
                 deltas = np.concatenate([deltas, [eng.vi_sweep_step(gamma, auto_reset=auto) for _ in range(3)]])[:iters + 2]
             v, pi = eng.vi_get()
@@ -418,7 +423,15 @@ def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, g
             o = eng.read_outputs()
             out[mode] = [deltas.tobytes(), v.tobytes(), pi.tobytes(), st['pos'].tobytes(), st['done'].tobytes(), st['episode'].tobytes(),
                          o[1].tobytes(), eng.done_indices().tobytes()]
-    assert out['single'] == out['run'] == out['run_no_cluster'] == out['run_timeout']
+    gu_option('vi_xcd_block', None)
+    for mode in modes:
+        assert out[mode] == out['single'], mode
+    if vi_path == 'launch_per_round':
+        assert set(form.values()) == {3}
+    else:
+        # (262 144 envs need 1024-thread workgroups to stay at one per CU: the smaller sizes then decline and the chip-wide form runs)
+        assert form['run'] == 1 and form['run_xcd_1024'] == 1 and form['run_xcd_256'] == (1 if N <= 65536 else 2), form
+        assert form['run_chip_wide'] == 2 and form['run_xcd_gives_up'] == 2 and form['run_no_cluster'] == 3 and form['run_timeout'] == 3, form
     gu_option('vi_path', 2 if vi_path == 'launch_per_round' else None)
     with Engine(N, spec_of(meta), seed=3) as eng:  # the table part is the reference's value-iteration trace
         eng.reset()

@@ -53,23 +53,27 @@ __device__ __forceinline__ void vi_st_l2(vi_u64 *p, vi_u64 x) { __hip_atomic_sto
 __device__ __forceinline__ vi_u64 vi_ld_l2(const vi_u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t vi_ld_word(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Maximum over each ROW of 16 lanes, left in the row's last lane (lanes 15, 31, 47, 63): four DPP row shifts per half of the key
-// -- register moves inside the SIMD, no LDS round trips (a 64-bit __shfl butterfly over the wave costs ~700 clocks of dependent
-// ds_bpermute traffic; an LDS atomic per lane is turned into a 64-turn scalar loop by the compiler's atomic optimizer: 7300)
-__device__ __forceinline__ vi_u64 vi_row_max(vi_u64 k)
+// Maximum over the wave, left in its LAST lane (lane 63): DPP row shifts inside each row of 16 lanes, then the two row broadcasts
+// of the gfx9 family -- register moves inside the SIMD, no LDS round trips.  (A 64-bit __shfl butterfly costs ~700 clocks of
+// dependent ds_bpermute traffic.  An LDS atomicMax per lane is turned by the compiler's atomic optimizer into a scalar loop over
+// the active lanes at ~100 clocks per lane: 7300 clocks for a full wave, and still 3400 for the 32 lanes that hold a cluster's
+// slot keys -- in ONE workgroup, for which the whole cluster then waits every round.)
+__device__ __forceinline__ vi_u64 vi_wave_max_last(vi_u64 k)
 {
-#define VI_ROW_STEP(ctrl)                                                                                   \
-    {                                                                                                       \
-        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, ctrl, 0xF, 0xF, false);          \
-        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), ctrl, 0xF, 0xF, false);  \
-        const vi_u64 o_ = ((vi_u64)hi_ << 32) | lo_;                                                        \
-        k = o_ > k ? o_ : k;                                                                                \
+#define VI_DPP_STEP(ctrl, rows)                                                                                          \
+    {                                                                                                                    \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, ctrl, rows, 0xF, false);         \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), ctrl, rows, 0xF, false); \
+        const vi_u64 o_ = ((vi_u64)hi_ << 32) | lo_;                                                                     \
+        k = o_ > k ? o_ : k;                                                                                             \
     }
-    VI_ROW_STEP(0x111)  // row_shr:1 (lanes without a source read 0: keys are never below 1)
-    VI_ROW_STEP(0x112)  // row_shr:2
-    VI_ROW_STEP(0x114)  // row_shr:4
-    VI_ROW_STEP(0x118)  // row_shr:8
-#undef VI_ROW_STEP
+    VI_DPP_STEP(0x111, 0xF)  // row_shr:1 (a lane without a source reads 0: keys are never below 1)
+    VI_DPP_STEP(0x112, 0xF)  // row_shr:2
+    VI_DPP_STEP(0x114, 0xF)  // row_shr:4
+    VI_DPP_STEP(0x118, 0xF)  // row_shr:8      -> lane 15 of every row holds the row's maximum
+    VI_DPP_STEP(0x142, 0xA)  // row_bcast:15   -> rows 1 and 3 take in the last lane of rows 0 and 2
+    VI_DPP_STEP(0x143, 0xC)  // row_bcast:31   -> rows 2 and 3 take in lane 31
+#undef VI_DPP_STEP
     return k;
 }
 
@@ -236,7 +240,10 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
             }
             return;
         }
-        if (keeps_deltas && wave == 0 && polls) atomicMax(&wg_key[2 + par], (khi & 0xFFFFFFFF00000000ull) | (klo >> 32));
+        if (keeps_deltas && wave == 0) {  // the round's delta: the maximum of the members' keys
+            const vi_u64 k = vi_wave_max_last(polls ? (khi & 0xFFFFFFFF00000000ull) | (klo >> 32) : 0ull);
+            if (lane == 63) wg_key[2 + par] = k;
+        }
         // Straight-line, unpredicated loads: a load or an LDS write inside a divergent branch makes the compiler wait for every
         // load in flight at the branch (a first version ran its eight loads ONE AFTER THE OTHER, 450 clocks each).  A lane without
         // an item loads from beyond the buffer's size (the bounds check returns zeros without a memory access) and writes to a
@@ -300,9 +307,9 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
                 }
             }
             VI_STAMP(0);
-            // the workgroup's maximum: DPP within rows of 16 lanes, then one LDS atomic per row; the barrier below orders them
-            key = vi_row_max(key);
-            if ((lane & 15) == 15 && key) atomicMax(&wg_key[par], key);
+            // the workgroup's maximum: DPP over the wave, then one LDS atomic by its last lane; the barrier below orders them
+            key = vi_wave_max_last(key);
+            if (lane == 63 && key) atomicMax(&wg_key[par], key);
             VI_STAMP(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2 ...
         }

@@ -245,7 +245,7 @@ int gu_launch_greedy_table(gu_engine *h);
 struct GuXcdPlan {
     int block = 0, K = 0;      // threads per workgroup, states per thread at most
     unsigned G = 0;            // workgroups
-    size_t lds = 0, slots_bytes = 0, vx_bytes = 0, ax_bytes = 0;  // dynamic LDS; scratch: barrier slots, value copies, action tables
+    size_t lds = 0, slots_bytes = 0, work_bytes = 0;  // dynamic LDS; scratch: delta-key slots (all XCCs), granule buffers (per XCC)
 };
 struct ViStepXcdArgs;
 bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan);

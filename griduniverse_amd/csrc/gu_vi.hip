@@ -1067,13 +1067,13 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
     const bool try_cluster = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && G <= (h->n_cu < VI_CL_MAX_WGS ? h->n_cu : VI_CL_MAX_WGS) &&
                              (path == 0 || path == 3 || path == 4 || path == 5);
     if (try_xcd || try_cluster) {
-        // scratch: header (64 B) | delta keys [iters] | barrier slots of the per-XCD form | snapshot | the per-XCD value copies and action tables
+        // scratch: header (64 B) | delta keys [iters] | delta-key slots of the per-XCD form | snapshot | the per-XCD granule buffers
         const size_t key_bytes = (size_t)iters * sizeof(unsigned long long);
         const size_t slots_off = (64 + key_bytes + 255) & ~(size_t)255;
         const size_t snap_off = slots_off + (try_xcd ? xp.slots_bytes : 0);
         const size_t v_bytes = (size_t)h->S * sizeof(double), n4 = (size_t)h->N * 4, bits_bytes = (((size_t)h->N + 63) / 64) * 8;
         const size_t snap_bytes = (5 * v_bytes + 4 * n4 + bits_bytes + 255) & ~(size_t)255;
-        rc = gu_ensure_scratch(h, snap_off + snap_bytes + (try_xcd ? xp.vx_bytes + xp.ax_bytes : 0));
+        rc = gu_ensure_scratch(h, snap_off + snap_bytes + (try_xcd ? 8 * xp.work_bytes : 0));
         if (rc != GU_OK) return rc;
         uint32_t *hdr_d = (uint32_t *)h->d_scratch;
         int32_t *done_d = (int32_t *)h->d_scratch + 2;
@@ -1105,9 +1105,9 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
             a.done_bits = h->d_done_bits;
             if (form == 0) {
                 a.slots = (vi_u64 *)((char *)h->d_scratch + slots_off);
-                a.vx = (double *)(snap + snap_bytes);
-                a.ax = (uint8_t *)(snap + snap_bytes + xp.vx_bytes);
-                a.work_bytes = (uint32_t)(xp.vx_bytes + xp.ax_bytes);
+                a.gx = (uint8_t *)(snap + snap_bytes);
+                a.work_bytes = (uint32_t)xp.work_bytes;
+                GU_HIP(hipMemsetAsync(a.gx, 0, 8 * xp.work_bytes, h->stream));  // every word that crosses workgroups is tagged with its round: no tag of an earlier launch may be left
                 a.inject_failure = path == 5;  // tests: the per-XCD form gives up
                 if ((rc = gu_vi_xcd_launch(h, xp, a)) != GU_OK) return rc;
             } else {

@@ -168,9 +168,9 @@ struct ViStepClusterArgs {
 // before the launch: [0] workgroups registered, [1] fallback word, [2] rounds done, [3] 1 + XCC id of workgroup 0,
 // [4 .. 11] workgroups registered per XCC.
 struct ViStepXcdArgs : ViStepClusterArgs {
-    vi_u64 *slots;            // [8 XCC][2 parities][64 members][2] barrier slots, zeroed before the launch
-    double *vx;               // [8 XCC][2 parities][S rounded up to 2] the clusters' private copies of the new values ...
-    uint8_t *ax;              // ... and, behind them in the same allocation, [8 XCC][2 parities][cell_bytes] of the greedy actions
-    uint32_t work_bytes;      // bytes of both, from vx
+    vi_u64 *slots;            // [8 XCC][4: round & 3][64 members][2] tagged delta-key slots, zeroed before the launch
+    uint8_t *gx;              // [8 XCC][work_bytes] the clusters' private granule buffers, zeroed before the launch:
+                              //   [2 parities][S] value granules of 16 bytes | [2 parities][ceil(S / 32)] action items of 16 bytes
+    uint32_t work_bytes;      // bytes per XCC
     uint32_t inject_failure;  // tests: every workgroup gives up at once
 };

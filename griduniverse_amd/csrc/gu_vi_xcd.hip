@@ -6,9 +6,10 @@
 //
 // gu_vi_sweep_step_cluster_kernel (gu_vi.hip) runs this with ONE copy of the table shared by every workgroup of the chip:
 // a round there is V1 -> write-through store of v' -> barrier over all workgroups on 8 XCDs whose L2s are not coherent with
-// each other (every shared byte crosses the fabric) -> V2 + agent step: 5.25 us per round at config 5, of which the
-// arithmetic is < 0.5 us.  Here EVERY XCD sweeps the WHOLE table redundantly (4096 states at 64x64: nothing next to 65 536
-// agents) with its own workgroups and steps its own share of the agents, so nothing a round needs ever leaves the XCD:
+// each other (every shared byte crosses the fabric) -> V2 + agent step (each agent re-deriving its action from four values):
+// 5.2 us per round at config 5, of which the arithmetic is < 0.5 us.  Here EVERY XCD sweeps the WHOLE table redundantly (4096
+// states at 64x64: nothing next to 65 536 agents) with its own workgroups and steps its own share of the agents, so nothing a
+// round needs ever leaves the XCD, and there is NO barrier between workgroups at all -- the data carries its own round number:
 //
 //   cluster      = the workgroups that read the same HW_REG_XCC_ID; each claims a rank in its cluster at start (one returning
 //                  atomic per workgroup + ONE chip-wide arrival wait per launch, so that every cluster knows its size).
@@ -16,17 +17,24 @@
 //                  the observed round-robin placement (blocks b and b + 8 share an XCD) gives equal clusters.
 //   state chunk  = cluster of n workgroups, workgroup `rank` owns states [rank * chunk, (rank + 1) * chunk), chunk =
 //                  ceil(S / n) rounded up to whole waves; K states per thread at most (a cluster too small for that gives up).
-//   value table  = every workgroup keeps the WHOLE table in LDS (V1, V2 and the agents' four neighbour values are LDS reads);
-//                  the new values travel through a per-XCD double-buffered copy in global memory that only this XCD ever
-//                  touches: 8-byte stores that stay in the XCD's L2 (`sc0`), every storing wave drains (`s_waitcnt vmcnt(0)`
-//                  = the L2 has them), workgroup barrier, and after the cluster barrier every workgroup reloads the table with
-//                  16-byte L1-bypassing loads (`sc1`: served by that same L2).
-//   cluster barrier = one 16-byte slot per workgroup and round parity in that same L2, {delta key high | round, delta key low |
-//                  round}: a workgroup's first lane stores its slot, the lanes of its first wave poll the cluster's slots (L1-
-//                  bypassing 8-byte loads) until every tag is this round's.  A torn slot shows a wrong tag and is polled again;
-//                  a slot of parity p is rewritten only two rounds later, which its owner cannot reach before every member
-//                  has passed the barrier in between.  No atomics, no fabric traffic, and the round's delta (the maximum over
-//                  states of v - v', dynamic_programming.py:17) arrives with the barrier.
+//   what crosses = per round a workgroup needs from the others (a) the new values of ONE GRID ROW either side of its chunk -- a
+//                  state's successors are itself, s +- 1 and s +- W -- and (b) the greedy action of EVERY state, which its agents
+//                  look up (2 bits per state; an agent re-deriving its action from the values would need the whole float64 table
+//                  in every workgroup and ~100 more float64 instructions per wave and round).  The actions of round r are known
+//                  only after V2 of round r: they travel with the values of round r + 1, and the agents run ONE ROUND BEHIND the
+//                  tables (they feed nothing back into them); a last exchange after the loop delivers the last actions.
+//   granules     = every word that crosses carries the round: a value is two 8-byte words {high half | tag}, {low half | tag}
+//                  (16 bytes per state), sixteen actions are one word {32 action bits | tag}; tag = round + 1, buffers zeroed
+//                  before the launch, double-buffered by round parity.  A consumer loads what it needs (16-byte L1-bypassing
+//                  loads, served by the XCD's L2 the stores went to) and looks at the tags: wrong tag = not there yet or half
+//                  there, load again.  8-byte words are single-copy atomic, so a word with the right tag IS the word of that
+//                  round.  No flag, no drain of the stores, no second hop -- a round costs ONE store-to-load latency.
+//   overwriting  = a buffer of parity p is rewritten two rounds later.  To store round r + 2 a workgroup must have finished its
+//                  fetch of round r + 1, which contains words EVERY member stored in its own round r + 1, i.e. after that
+//                  member's fetch of round r was complete: nobody still wants the words of round r.
+//   deltas       = the per-round maximum of v - v' (dynamic_programming.py:17) is reduced per workgroup (DPP + one LDS atomic),
+//                  posted in a tagged slot (four deep) and collected one round late by workgroup 0 of the cluster that writes the
+//                  tables -- off everybody's critical path.
 //
 // The same float64 operations in the same order per state as every other DP kernel of the library, hence the same bits; the
 // agents of all clusters see identical tables, so which cluster steps which env is invisible in the results.  Every spin is
@@ -36,6 +44,8 @@
 #include "gu_rng.hpp"
 #include "gu_vi.hpp"
 
+#include <type_traits>
+
 #define VI_XCD_MAX_XCC 8
 #define VI_XCD_SLOTS 64                      /* workgroups of one cluster at most */
 #define VI_XCD_GETREG_XCC_ID (20 | (3 << 11)) /* s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4) */
@@ -43,6 +53,10 @@
 // cache policy of the loads that fetch the members' chunks (buffer_load aux: 2 = nt, 16 = sc1, 17 = sc0 sc1; each bypasses this CU's L1)
 #ifndef VI_XCD_LOAD_AUX
 #define VI_XCD_LOAD_AUX 16
+#endif
+// ... and of the stores of the value granules (1 = sc0: write-back, the line stays in this XCD's L2)
+#ifndef VI_XCD_STORE_AUX
+#define VI_XCD_STORE_AUX 1
 #endif
 
 typedef uint32_t vi_u32x4 __attribute__((ext_vector_type(4)));
@@ -99,10 +113,9 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     __shared__ vi_u64 wg_key[4];
     __shared__ uint32_t info[4];  // [0] XCC id, [1] rank in the cluster, [2] members, [3] bit 0: failed, bit 1: this cluster writes the tables
     const ViMap cell = vi_stage<true>(a.vi.cell, a.vi.cell_bytes, smem);  // the agents gather records of arbitrary cells
-    double *vL = reinterpret_cast<double *>(smem + 2 * a.vi.cell_bytes);  // [S2 + 2] this workgroup's copy of the value table (+ a spare slot)
+    double *vL = reinterpret_cast<double *>(smem + 2 * a.vi.cell_bytes);  // [S2 + 2] values: the own chunk and a grid row either side are kept current (+ a spare slot); then the action words
     const int32_t tid = threadIdx.x, B = blockDim.x, S = a.vi.S, W = a.vi.W;
     const int32_t S2 = (S + 1) & ~1, cb = a.vi.cell_bytes;
-    const uint8_t *actL = smem + 2 * cb + S2 * 8 + 16;  // [cell_bytes] greedy action per state under the policy of the round before
     const double gamma = a.vi.gamma;
     uint32_t *hdr = a.vi.sync;  // [0] workgroups registered, [1] fallback word, [3] 1 + XCC id of workgroup 0, [4 .. 11] members per XCC
 
@@ -126,7 +139,8 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
             members = vi_ld_word(hdr + 4 + xcc);
             writes = vi_ld_word(hdr + 3) == xcc + 1u;
             const int64_t chunk = ((((int64_t)S + members - 1) / members) + 63) & ~(int64_t)63;
-            bad = rank >= VI_XCD_SLOTS || members > VI_XCD_SLOTS || chunk > (int64_t)K * B;
+            const int64_t items = 2 * (int64_t)(W < S ? W : S) + (((S + 15) >> 4) + 1) / 2;  // what one thread's four fetch items must cover
+            bad = rank >= VI_XCD_SLOTS || members > VI_XCD_SLOTS || chunk > (int64_t)K * B || items > 4 * (int64_t)B;
         }
         if (bad || a.inject_failure) {
             bad = 1u;
@@ -142,9 +156,8 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     const bool writes_tables = (info[3] & 2u) != 0;
     bool failed = (info[3] & 1u) != 0;
     const int32_t chunk = (int32_t)(((((int64_t)S + members - 1) / members) + 63) & ~(int64_t)63);
-    vi_u64 *slots = a.slots + (size_t)xcc * 2 * VI_XCD_SLOTS * 2;                         // [parity][member][2]
-    double *vx = a.vx + (size_t)xcc * 2 * S2;                                             // [parity][S2]
-    uint8_t *ax = a.ax + (size_t)xcc * 2 * cb;                                            // [parity][cell_bytes]
+    vi_u64 *slots = a.slots + (size_t)xcc * 4 * VI_XCD_SLOTS * 2;   // [round & 3][member][2]
+    uint8_t *gx = a.gx + (size_t)xcc * a.work_bytes;                // this cluster's granules: [2][S] values | [2][n_aw] action items
 
     // ---- per-state constants, the initial table, the own env ----
     int32_t st[K];    // the thread's states (-1: none)
@@ -187,7 +200,7 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     bool wave_has_states = false;  // (wave-uniform: the states of a chunk are dealt to whole waves)
 #pragma unroll
     for (int j = 0; j < K; ++j) wave_has_states = wave_has_states || __any(st[j] >= 0);
-    if (tid < 4) wg_key[tid] = 0ull;  // [0, 1] this workgroup's delta key by round parity, [2, 3] the cluster's (workgroup 0 of the writing cluster)
+    if (tid < 4) wg_key[tid] = 0ull;  // this workgroup's delta key, by round & 3
     __syncthreads();
 #ifdef GU_VI_XCD_STAMPS
     uint64_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -195,101 +208,150 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     const uint64_t stamp_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const bool keeps_deltas = writes_tables && rank == 0;
-    // What a round fetches, in 16-byte items: the new values of the own chunk and of one grid row either side of it -- every
-    // state a V1 / V2 of the chunk reads (a state's successors are itself, s +- 1 and s +- W) -- and the action table.
+    // What a round fetches, in 16-byte items: the value granules of one grid row either side of the own chunk (the chunk's own
+    // values go from registers to LDS), then the action words, two per item.
     const int32_t lo = (int32_t)rank * chunk, hi = lo + chunk < S ? lo + chunk : S;
-    const int32_t iv0 = (lo - W > 0 ? lo - W : 0) >> 1, iv1 = ((hi + W < S2 ? hi + W : S2) + 1) >> 1;
-    const int32_t nv = lo < S ? iv1 - iv0 : 0, na = cb >> 4;
-    const uint32_t off_v = (uint32_t)(reinterpret_cast<const char *>(vx) - reinterpret_cast<const char *>(a.vx));
-    const uint32_t off_a = (uint32_t)(reinterpret_cast<const char *>(ax) - reinterpret_cast<const char *>(a.vx));
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.vx, 0, a.work_bytes, 0x00020000);
-    const uint32_t lds_v = 2u * (uint32_t)cb, lds_a = lds_v + (uint32_t)S2 * 8u + 16u, lds_spare = lds_v + (uint32_t)S2 * 8u;
-    // One cluster barrier: post this workgroup's slot for `tag`, wait until every member's slot shows it, fetch.  Polling is per
-    // WAVE (the lanes of every wave read the members' slots): no workgroup barrier between the poll and the loads that depend on it.
-    auto exchange = [&](uint32_t par, uint32_t tag, bool with_v, bool with_act) {
-        vi_u64 *slot = slots + (size_t)par * VI_XCD_SLOTS * 2;
-        if (tid == 0) {
-            const vi_u64 mine = wg_key[par];
-            wg_key[par] = 0ull;  // (next written two rounds on, two workgroup barriers away)
-            vi_st_l2(slot + 2 * rank, (mine & 0xFFFFFFFF00000000ull) | tag);
-            vi_st_l2(slot + 2 * rank + 1, (mine << 32) | tag);
+    const int32_t below0 = lo - W > 0 ? lo - W : 0, n_below = lo < S ? lo - below0 : 0;    // states [below0, lo)
+    const int32_t n_above = lo < S ? (hi + W < S ? hi + W : S) - hi : 0;                     // states [hi, hi + n_above)
+    const int32_t n_words = (S + 15) >> 4, n_aw = (n_words + 1) >> 1;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)gx, 0, a.work_bytes, 0x00020000);
+    const uint32_t lds_v = 2u * (uint32_t)cb, lds_spare = lds_v + (uint32_t)S2 * 8u, lds_a = lds_spare + 16u;
+    const uint32_t gv_bytes = (uint32_t)S * 16u, aw_off = 2u * gv_bytes, aw_bytes = (uint32_t)n_aw * 16u;  // [2][S] granules | [2][n_aw] action items
+    // The items this thread fetches are the same every round: source (parity 0), destination in LDS and kind are worked out ONCE
+    // (computed inside the loop, the selects and bounds of this bookkeeping were three quarters of the fetch's 1900 clocks).
+    // kind: 0 = none, 1 = value granule, 2 = action item with two words, 3 = action item whose second word does not exist.
+    const int32_t n_items = n_below + n_above + n_aw;
+    uint32_t it_src[4], it_dst[4], it_kind[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int32_t x = m * B + tid, n_v = n_below + n_above;
+        const int32_t s = x < n_below ? below0 + x : hi + (x - n_below);  // the state of a value item
+        const int32_t w = x - n_v;                                        // the index of an action item
+        it_kind[m] = x >= n_items ? 0u : x < n_v ? 1u : (2 * w + 1 < n_words) ? 2u : 3u;
+        it_src[m] = it_kind[m] == 1u ? (uint32_t)s * 16u : aw_off + (uint32_t)w * 16u;
+        it_dst[m] = it_kind[m] == 0u ? lds_spare : it_kind[m] == 1u ? lds_v + (uint32_t)s * 8u : lds_a + (uint32_t)w * 8u;
+    }
+    // One exchange: fetch the halo granules (with_v) and the action words (with_act) tagged `tag` from the buffers of parity
+    // `par`, reloading until every tag is there.  Straight-line, unpredicated loads: a load or an LDS write inside a divergent
+    // branch makes the compiler wait for every load in flight at the branch (a first version ran its eight loads ONE AFTER THE
+    // OTHER, 450 clocks each).  A lane without an item loads from beyond the buffer's size (the bounds check returns zeros
+    // without a memory access) and writes to a spare 16 bytes behind the table.
+    const int32_t n_batches = (n_items + B - 1) / B;  // 16-byte loads per thread (uniform over the workgroup): 1 at config 5
+    auto fetch_n = [&](auto batches, uint32_t par, uint32_t tag, bool with_v, bool with_act) {
+        constexpr int NB = decltype(batches)::value;
+        uint32_t src[NB];
+        bool on[NB];
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            on[m] = it_kind[m] == 1u ? with_v : (it_kind[m] != 0u && with_act);
+            src[m] = on[m] ? it_src[m] + par * (it_kind[m] == 1u ? gv_bytes : aw_bytes) : 0xFFFFFFF0u;
         }
-        const bool polls = (uint32_t)lane < members;
-        vi_u64 khi = 0ull, klo = 0ull;
+        vi_u32x4 t[NB];
         uint32_t spins = 0, bad = 0u;
         for (;;) {
-            if (polls) {
-                khi = vi_ld_l2(slot + 2 * lane);
-                klo = vi_ld_l2(slot + 2 * lane + 1);
-            }
-            if (__all(!polls || ((uint32_t)khi == tag && (uint32_t)klo == tag))) break;
+#pragma unroll
+            for (int m = 0; m < NB; ++m) t[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, src[m], 0, VI_XCD_LOAD_AUX);
+            bool ok = true;
+#pragma unroll
+            for (int m = 0; m < NB; ++m) ok = ok && (!on[m] || (t[m].x == tag && (t[m].z == tag || it_kind[m] == 3u)));
+            if (__all(ok)) break;
             if (++spins > VI_CL_SPIN_LIMIT || ((spins & 255u) == 0u && vi_ld_word(hdr + 1))) {
                 bad = 1u;
                 break;
             }
-            if (spins > 4u) __builtin_amdgcn_s_sleep(1);
+            if (spins > 8u) __builtin_amdgcn_s_sleep(1);
         }
 #ifdef GU_VI_XCD_STAMPS
         stamp_acc[10] += spins;
 #endif
-        VI_STAMP(4);
-        if (bad) {
-            if (lane == 0) {
-                __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicOr(&info[3], 1u);
-            }
-            return;
-        }
-        if (keeps_deltas && wave == 0) {  // the round's delta: the maximum of the members' keys
-            const vi_u64 k = vi_wave_max_last(polls ? (khi & 0xFFFFFFFF00000000ull) | (klo >> 32) : 0ull);
-            if (lane == 63) wg_key[2 + par] = k;
-        }
-        // Straight-line, unpredicated loads: a load or an LDS write inside a divergent branch makes the compiler wait for every
-        // load in flight at the branch (a first version ran its eight loads ONE AFTER THE OTHER, 450 clocks each).  A lane without
-        // an item loads from beyond the buffer's size (the bounds check returns zeros without a memory access) and writes to a
-        // spare 16 bytes behind the table.
-#ifdef VI_XCD_EXPERIMENT  // timing experiments of the diagnostic build (results are WRONG): 1 = no action table, 2 = no values fetched
-        if (VI_XCD_EXPERIMENT == 1) with_act = false;
-        if (VI_XCD_EXPERIMENT == 2) with_v = false;
-#endif
-        const int32_t n_v = with_v ? nv : 0, total = n_v + (with_act ? na : 0);
-        const uint32_t src_v = off_v + par * (uint32_t)S2 * 8u + (uint32_t)iv0 * 16u, src_a = off_a + par * (uint32_t)cb;
-        for (int32_t base = 0; base < total; base += 4 * B) {
-            vi_u32x4 t[4];
-            uint32_t dst[4];
+        // a value granule {tag, high half} {tag, low half} becomes one double, an action item two 32-bit words of 16 actions
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int32_t x = base + m * B + tid;
-                const bool is_v = x < n_v, valid = x < total;
-                const uint32_t src = is_v ? src_v + (uint32_t)x * 16u : src_a + (uint32_t)(x - n_v) * 16u;
-                dst[m] = !valid ? lds_spare : is_v ? lds_v + (uint32_t)(iv0 + x) * 16u : lds_a + (uint32_t)(x - n_v) * 16u;
-                t[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, valid ? src : 0xFFFFFFF0u, 0, VI_XCD_LOAD_AUX);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) *reinterpret_cast<vi_u32x4 *>(smem + dst[m]) = t[m];
+        for (int m = 0; m < NB; ++m) {
+            const bool is_v = it_kind[m] == 1u;
+            *reinterpret_cast<uint2 *>(smem + (on[m] ? it_dst[m] : lds_spare)) = make_uint2(is_v ? t[m].w : t[m].y, is_v ? t[m].y : t[m].w);
+        }
+        if (bad && lane == 0) {
+            __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(&info[3], 1u);
         }
     };
-    // every agent takes the step of round `r - 1`: the greedy action of its cell (np.argmax of its policy row: the first maximum;
-    // examples/griduniverse_alg_examples.py:76) is in the action table the state's owner published
+    auto fetch = [&](uint32_t par, uint32_t tag, bool with_v, bool with_act) {
+        if (n_batches <= 1) fetch_n(std::integral_constant<int, 1>{}, par, tag, with_v, with_act);
+        else if (n_batches == 2) fetch_n(std::integral_constant<int, 2>{}, par, tag, with_v, with_act);
+        else fetch_n(std::integral_constant<int, 4>{}, par, tag, with_v, with_act);
+    };
+    // this wave's sixteen-action words of parity `par`: lanes 0 .. 3 assemble them from two ballots and store them
+    auto publish_actions = [&](uint32_t par, uint32_t tag, const uint32_t act[K]) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int32_t s_first = lo + (wave << 6) + j * B;  // the state of lane 0 (chunks and waves are whole multiples of 64)
+            const uint64_t b0 = __ballot((act[j] & 1u) != 0u), b1 = __ballot((act[j] & 2u) != 0u);
+            if (lane < 4 && (wave << 6) + j * B < chunk && s_first + 16 * lane < S) {
+                uint32_t e = (uint32_t)(b0 >> (16 * lane)) & 0xFFFFu, o = (uint32_t)(b1 >> (16 * lane)) & 0xFFFFu;
+                e = (e | (e << 8)) & 0x00FF00FFu, o = (o | (o << 8)) & 0x00FF00FFu;  // spread 16 bits over the even positions of 32
+                e = (e | (e << 4)) & 0x0F0F0F0Fu, o = (o | (o << 4)) & 0x0F0F0F0Fu;
+                e = (e | (e << 2)) & 0x33333333u, o = (o | (o << 2)) & 0x33333333u;
+                e = (e | (e << 1)) & 0x55555555u, o = (o | (o << 1)) & 0x55555555u;
+                const uint32_t word = (uint32_t)(s_first >> 4) + (uint32_t)lane;
+                vi_st_l2(reinterpret_cast<vi_u64 *>(gx + aw_off + par * aw_bytes) + word, ((vi_u64)(e | (o << 1)) << 32) | tag);
+            }
+        }
+    };
+    // every agent takes the step of the round before: the greedy action of its cell (np.argmax of its policy row: the first
+    // maximum; examples/griduniverse_alg_examples.py:76) is in the action table the state's owner published
+    const uint32_t *actL = reinterpret_cast<const uint32_t *>(smem + lds_a);
     auto agents = [&]() {
         if (own_env) {
             if ((a.flags & GU_F_AUTO_RESET) && e_done) {  // lazy `if done: env.reset()`
                 e_pos = a.starts[gu_rng_start_index(e_prefix, e_ep, a.n_starts)];
                 ++e_ep;
             }
-            e_pos = vi_next(e_pos, cell.f[e_pos], actL[e_pos], W);
+            const uint32_t act = (actL[e_pos >> 4] >> (2 * (e_pos & 15))) & 3u;
+            e_pos = vi_next(e_pos, cell.f[e_pos], act, W);
             e_rew = cell.r[e_pos];
             e_done = (cell.f[e_pos] >> GU_CELL_TERM_BIT) & 1;
         }
     };
+    // workgroup 0 of the writing cluster: the delta of round `rr` = the maximum of the members' keys, from their slots.  The slots
+    // are LOADED before the round's fetch and looked at behind it, so that the two round trips overlap.
+    vi_u64 d_hi = 0ull, d_lo = 0ull;
+    auto delta_load = [&](int32_t rr) {
+        const vi_u64 *slot = slots + (size_t)((uint32_t)rr & 3u) * VI_XCD_SLOTS * 2;
+        if ((uint32_t)lane < members) {
+            d_hi = vi_ld_l2(slot + 2 * lane);
+            d_lo = vi_ld_l2(slot + 2 * lane + 1);
+        }
+    };
+    auto delta_finish = [&](int32_t rr) {
+        const uint32_t tag = (uint32_t)rr + 1u;
+        const bool polls = (uint32_t)lane < members;
+        uint32_t spins = 0;
+        // (normally there at the first look: the slots of round rr were posted before anything of round rr + 1 was stored)
+        while (!__all(!polls || ((uint32_t)d_hi == tag && (uint32_t)d_lo == tag))) {
+            if (++spins > VI_CL_SPIN_LIMIT || ((spins & 255u) == 0u && vi_ld_word(hdr + 1))) {
+                if (lane == 0) {
+                    __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicOr(&info[3], 1u);
+                }
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            delta_load(rr);
+        }
+        const vi_u64 k = vi_wave_max_last(polls ? (d_hi & 0xFFFFFFFF00000000ull) | (d_lo >> 32) : 0ull);
+#ifndef GU_VI_XCD_STAMPS
+        if (lane == 63) a.vi.delta_key[rr] = k;
+#else
+        asm volatile("" ::"v"(k));
+#endif
+    };
     uint32_t act_prev[K];  // greedy action of the thread's states under the policy of the round before
+    double v_new[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) act_prev[j] = 0u;
+    for (int j = 0; j < K; ++j) act_prev[j] = 0u, v_new[j] = 0.0;
     int r = 0;
     for (; r < a.vi.max_rounds && !failed; ++r) {
-        const uint32_t par = (uint32_t)r & 1u;
-        double *vxr = vx + (size_t)par * S2;
-        uint8_t *axr = ax + (size_t)par * cb;
+        const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;
         if (wave_has_states) {
             vi_u64 key = 0ull;
 #pragma unroll
@@ -300,35 +362,49 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
 #pragma unroll
                     for (uint32_t act = 0; act < 4; ++act)
                         acc = __dadd_rn(acc, __dmul_rn(p[j][act], __dmul_rn(gamma, vL[vi_next(s, rec[j], act, W)])));
-                    vi_st_l2(reinterpret_cast<vi_u64 *>(vxr + s), (vi_u64)__double_as_longlong(acc));
-                    axr[s] = (uint8_t)act_prev[j];  // (the action of round r - 1 travels with the values of round r)
+                    v_new[j] = acc;
+                    const vi_u64 bits = (vi_u64)__double_as_longlong(acc);
+                    vi_u32x4 g;
+                    g.x = tag, g.y = (uint32_t)(bits >> 32), g.z = tag, g.w = (uint32_t)bits;
+                    __builtin_amdgcn_raw_buffer_store_b128(g, rs, par * gv_bytes + (uint32_t)s * 16u, 0, VI_XCD_STORE_AUX);
                     const vi_u64 k = vi_key(__dsub_rn(vL[s], acc));  // signed, dynamic_programming.py:17
                     key = k > key ? k : key;
                 }
             }
+            if (r > 0) publish_actions(par, tag, act_prev);  // (the actions of round r - 1 travel with the values of round r)
             VI_STAMP(0);
-            // the workgroup's maximum: DPP over the wave, then one LDS atomic by its last lane; the barrier below orders them
+            // the workgroup's delta key: DPP over the wave, then one LDS atomic by its last lane; the barrier below orders them
             key = vi_wave_max_last(key);
-            if (lane == 63 && key) atomicMax(&wg_key[par], key);
+            if (lane == 63 && key) atomicMax(&wg_key[r & 3], key);
             VI_STAMP(1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2 ...
         }
-        VI_STAMP(2);
-        __syncthreads();  // ... and so have every other wave's of the workgroup; nobody reads vL or actL any more
+        __syncthreads();  // nobody reads the old values or actions in LDS any more; the workgroup's key is complete
         VI_STAMP(3);
-        exchange(par, (uint32_t)r + 1u, true, r > 0);
+        if (tid == 0) {  // post the key (read one round late by the workgroup that collects the deltas)
+            vi_u64 *slot = slots + (size_t)((uint32_t)r & 3u) * VI_XCD_SLOTS * 2;
+            const vi_u64 mine = wg_key[r & 3];
+            wg_key[r & 3] = 0ull;  // (next written four rounds on)
+            vi_st_l2(slot + 2 * rank, (mine & 0xFFFFFFFF00000000ull) | tag);
+            vi_st_l2(slot + 2 * rank + 1, (mine << 32) | tag);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (st[j] >= 0) vL[st[j]] = v_new[j];
+        const bool collects = keeps_deltas && wave == 0 && r > 0;
+        if (collects) delta_load(r - 1);
+        fetch(par, tag, true, r > 0);
         VI_STAMP(6);
+        if (collects) delta_finish(r - 1);
+#ifdef GU_VI_XCD_STAMPS
+        VI_STAMP(1);   // (delta_finish alone: added to the key phase)
+        fetch(par, tag, true, r > 0);  // probe: the same fetch once more, everything certainly there
+        VI_STAMP(4);
+#endif
         __syncthreads();
         VI_STAMP(7);
         if (info[3] & 1u) {
             failed = true;
             break;
-        }
-        if (keeps_deltas && tid == 0) {
-#ifndef GU_VI_XCD_STAMPS
-            a.vi.delta_key[r] = wg_key[2 + par];
-#endif
-            wg_key[2 + par] = 0ull;
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {  // V2 (utils.py:55-72) on v'
@@ -354,18 +430,28 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
         asm volatile("" ::"v"(e_pos), "v"(e_rew), "v"(e_done), "v"(p[0][0]));  // the round ends here, not wherever its results are needed
 #endif
         VI_STAMP(9);
-    }
-    if (!failed && r > 0) {  // the agents' step of the last round: its action table alone crosses the cluster
-        const uint32_t par = (uint32_t)r & 1u;
-        uint8_t *axr = ax + (size_t)par * cb;
-        if (wave_has_states) {
-#pragma unroll
-            for (int j = 0; j < K; ++j)
-                if (st[j] >= 0) axr[st[j]] = (uint8_t)act_prev[j];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GU_VI_XCD_STAMPS
+        {   // latency probes (diagnostic build only): one dependent load of a word nobody writes, L1-bypassing and plain
+            const uint64_t t0_ = __builtin_amdgcn_s_memtime();
+            const uint32_t x_ = vi_ld_word(hdr + 12);
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(x_) : "memory");
+            const uint64_t t1_ = __builtin_amdgcn_s_memtime();
+            const uint32_t y_ = *reinterpret_cast<volatile const uint32_t *>(hdr + 13 + (x_ & 1u));
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(y_) : "memory");
+            const uint64_t t2_ = __builtin_amdgcn_s_memtime();
+            stamp_acc[2] += t1_ - t0_;
+            stamp_acc[5] += t2_ - t1_;
+            stamp_last = t2_;
         }
+#endif
+    }
+    if (!failed && r > 0) {  // the agents' step of the last round: its actions alone cross the cluster
+        const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;
+        if (wave_has_states) publish_actions(par, tag, act_prev);
         __syncthreads();
-        exchange(par, (uint32_t)r + 1u, false, true);
+        if (keeps_deltas && wave == 0) delta_load(r - 1);
+        fetch(par, tag, false, true);
+        if (keeps_deltas && wave == 0) delta_finish(r - 1);
         __syncthreads();
         if (info[3] & 1u) failed = true;
         else agents();
@@ -406,8 +492,9 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
 bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan)
 {
     if (h->n_grids != 1 || h->S > GU_MAX_LDS_CELLS || h->n_cu < VI_XCD_MAX_XCC) return false;
-    const int64_t S2 = ((int64_t)h->S + 1) & ~(int64_t)1;
-    const size_t lds = 3 * (size_t)h->cell_bytes + (size_t)S2 * sizeof(double) + 16;  // planes | values | spare slot of the fetch | actions
+    const int64_t S2 = ((int64_t)h->S + 1) & ~(int64_t)1, n_words = ((int64_t)h->S + 15) / 16, n_aw = (n_words + 1) / 2;
+    // planes | values | spare slot of the fetch | action words
+    const size_t lds = 2 * (size_t)h->cell_bytes + (size_t)S2 * sizeof(double) + 16 + (size_t)n_aw * 8;
     if ((int64_t)lds + 1024 > h->lds_per_cu) return false;
     const int64_t forced = gu_opt(h, GU_OPT_VI_XCD_BLOCK);
     const int max_wgs = h->n_cu;
@@ -424,7 +511,8 @@ bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan)
         const int64_t per_xcc = G / VI_XCD_MAX_XCC > 0 ? G / VI_XCD_MAX_XCC : 1;  // the smallest cluster under round-robin placement
         if ((G + VI_XCD_MAX_XCC - 1) / VI_XCD_MAX_XCC > VI_XCD_SLOTS) return false;
         const int64_t chunk = ((((int64_t)h->S + per_xcc - 1) / per_xcc) + 63) & ~(int64_t)63;
-        const int K = chunk <= B ? 1 : chunk <= 2 * B ? 2 : 0;
+        const int64_t items = 2 * (int64_t)(h->W < h->S ? h->W : h->S) + n_aw;  // halo granules + action items: four per thread at most
+        const int K = items > 4 * B ? 0 : chunk <= B ? 1 : chunk <= 2 * B ? 2 : 0;
         if (K == 0) {
             if (forced) return false;
             continue;
@@ -433,9 +521,8 @@ bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan)
         plan->G = (unsigned)G;
         plan->K = K;
         plan->lds = lds;
-        plan->slots_bytes = (size_t)VI_XCD_MAX_XCC * 2 * VI_XCD_SLOTS * 2 * sizeof(vi_u64);
-        plan->vx_bytes = (size_t)VI_XCD_MAX_XCC * 2 * (size_t)S2 * sizeof(double);
-        plan->ax_bytes = (size_t)VI_XCD_MAX_XCC * 2 * (size_t)h->cell_bytes;
+        plan->slots_bytes = (size_t)VI_XCD_MAX_XCC * 4 * VI_XCD_SLOTS * 2 * sizeof(vi_u64);
+        plan->work_bytes = ((2 * (size_t)h->S * 16 + 2 * (size_t)n_aw * 16) + 255) & ~(size_t)255;
         return true;
     }
     return false;

@@ -17,8 +17,8 @@ sys.path.insert(0, ROOT)
 import griduniverse_amd as gua  # noqa: E402
 from griduniverse_amd import _lib  # noqa: E402
 
-PHASES = ['V1 (LDS reads, f64 chain, stores issued)', 'delta key: DPP row maximum + LDS atomic', 'drain of the stores (vmcnt 0)', 'workgroup barrier 1',
-          'slot posted, members polled', '-', 'fetch: chunk + halo values, action table -> LDS', 'workgroup barrier 2', 'V2', 'agent step']
+PHASES = ['V1 (LDS reads, f64 chain, granules stored, action words published)', 'delta key: DPP maximum + one LDS atomic', '(probe) one dependent sc1 load of an idle word', 'workgroup barrier 1',
+          '(probe) the same fetch once more', '(probe) one dependent plain load of an idle word', 'fetch: halo granules + action words, reloaded until tagged -> LDS', 'workgroup barrier 2', 'V2', 'agent step']
 
 
 def main():

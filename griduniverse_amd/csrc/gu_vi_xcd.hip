@@ -110,7 +110,6 @@ template <int K>
 __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStepXcdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ vi_u64 wg_key[4];
     __shared__ uint32_t info[4];  // [0] XCC id, [1] rank in the cluster, [2] members, [3] bit 0: failed, bit 1: this cluster writes the tables
     const ViMap cell = vi_stage<true>(a.vi.cell, a.vi.cell_bytes, smem);  // the agents gather records of arbitrary cells
     double *vL = reinterpret_cast<double *>(smem + 2 * a.vi.cell_bytes);  // [S2 + 2] values: the own chunk and a grid row either side are kept current (+ a spare slot); then the action words
@@ -159,7 +158,9 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     vi_u64 *slots = a.slots + (size_t)xcc * 4 * VI_XCD_SLOTS * 2;   // [round & 3][member][2]
     uint8_t *gx = a.gx + (size_t)xcc * a.work_bytes;                // this cluster's granules: [2][S] values | [2][n_aw] action items
 
-    // ---- per-state constants, the initial table, the own env ----
+    const int32_t lo = (int32_t)rank * chunk, hi = lo + chunk < S ? lo + chunk : S;  // this workgroup's states [lo, hi)
+
+    // ---- per-state constants, the initial table, the own envs ----
     int32_t st[K];    // the thread's states (-1: none)
     uint32_t rec[K], rn[K];
     int32_t r_own[K];
@@ -183,24 +184,42 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
         }
     }
     for (int32_t i = tid; i < S2; i += B) vL[i] = i < S ? a.vi.v0[i] : 0.0;
-    const int64_t gid = (int64_t)blockIdx.x * B + tid;
-    const bool own_env = gid < a.N;
-    int32_t e_pos = 0, e_rew = 0, e_done = 0;
-    uint32_t e_ep = 0, e_prefix = 0;
-    if (own_env) {
-        e_pos = a.pos[gid];
-        e_rew = a.reward[gid];
-        e_done = a.done[gid];
-        e_ep = a.episode[gid];
-        e_prefix = gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)gid);
+    // Division of labour inside the workgroup: the waves that own states carry the round's critical path (V1, V2).  When at
+    // most half of the waves do, they carry NO agents: every other wave steps two blocks of 64 envs (two independent gather
+    // chains that interleave) and one of them reduces the workgroup's delta keys -- both beside the critical path, not on it.
+    const int32_t waves = B >> 6, wave = tid >> 6, lane = tid & 63;
+    const int32_t own_states = lo < S ? (chunk < S - lo ? chunk : S - lo) : 0;                // states of this workgroup
+    const int32_t state_waves = K == 1 ? (own_states + 63) >> 6 : (own_states > 0 ? waves : 0);
+    const bool split = K == 1 && 2 * state_waves <= waves;
+    const bool has_envs = !split || wave >= state_waves;  // (wave-uniform)
+    int64_t gid[2];
+    bool own_env[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int32_t block = split ? 2 * (wave - state_waves) + e : wave;  // which 64 envs of the workgroup's B
+        const bool mine = split ? (wave >= state_waves && block < waves) : e == 0;
+        gid[e] = (int64_t)blockIdx.x * B + (int64_t)block * 64 + lane;
+        own_env[e] = mine && gid[e] < a.N;
     }
+    int32_t e_pos[2] = {0, 0}, e_rew[2] = {0, 0}, e_done[2] = {0, 0};
+    uint32_t e_ep[2] = {0u, 0u}, e_prefix[2] = {0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        if (own_env[e]) {
+            e_pos[e] = a.pos[gid[e]];
+            e_rew[e] = a.reward[gid[e]];
+            e_done[e] = a.done[gid[e]];
+            e_ep[e] = a.episode[gid[e]];
+            e_prefix[e] = gu_rng_prefix(a.seed_prefix, a.env_id0 + (uint32_t)gid[e]);
+        }
     __syncthreads();
 
-    const int32_t wave = tid >> 6, lane = tid & 63;
     bool wave_has_states = false;  // (wave-uniform: the states of a chunk are dealt to whole waves)
 #pragma unroll
     for (int j = 0; j < K; ++j) wave_has_states = wave_has_states || __any(st[j] >= 0);
-    if (tid < 4) wg_key[tid] = 0ull;  // this workgroup's delta key, by round & 3
+    vi_u64 *lane_key = reinterpret_cast<vi_u64 *>(smem + ((2u * (uint32_t)cb + (uint32_t)S2 * 8u + 16u + (uint32_t)((((S + 15) >> 4) + 1) >> 1) * 8u + 15u) & ~15u));  // [2][B] the lanes' delta keys, by round parity
+    for (int32_t i = tid; i < 2 * B; i += B) lane_key[i] = 0ull;       // (a lane without a state never writes its entry)
+    const int32_t key_wave = split ? state_waves : 0;                 // the wave that reduces them
     __syncthreads();
 #ifdef GU_VI_XCD_STAMPS
     uint64_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -210,7 +229,6 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     const bool keeps_deltas = writes_tables && rank == 0;
     // What a round fetches, in 16-byte items: the value granules of one grid row either side of the own chunk (the chunk's own
     // values go from registers to LDS), then the action words, two per item.
-    const int32_t lo = (int32_t)rank * chunk, hi = lo + chunk < S ? lo + chunk : S;
     const int32_t below0 = lo - W > 0 ? lo - W : 0, n_below = lo < S ? lo - below0 : 0;    // states [below0, lo)
     const int32_t n_above = lo < S ? (hi + W < S ? hi + W : S) - hi : 0;                     // states [hi, hi + n_above)
     const int32_t n_words = (S + 15) >> 4, n_aw = (n_words + 1) >> 1;
@@ -301,16 +319,20 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     // maximum; examples/griduniverse_alg_examples.py:76) is in the action table the state's owner published
     const uint32_t *actL = reinterpret_cast<const uint32_t *>(smem + lds_a);
     auto agents = [&]() {
-        if (own_env) {
-            if ((a.flags & GU_F_AUTO_RESET) && e_done) {  // lazy `if done: env.reset()`
-                e_pos = a.starts[gu_rng_start_index(e_prefix, e_ep, a.n_starts)];
-                ++e_ep;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (own_env[e] && (a.flags & GU_F_AUTO_RESET) && e_done[e]) {  // lazy `if done: env.reset()`
+                e_pos[e] = a.starts[gu_rng_start_index(e_prefix[e], e_ep[e], a.n_starts)];
+                ++e_ep[e];
             }
-            const uint32_t act = (actL[e_pos >> 4] >> (2 * (e_pos & 15))) & 3u;
-            e_pos = vi_next(e_pos, cell.f[e_pos], act, W);
-            e_rew = cell.r[e_pos];
-            e_done = (cell.f[e_pos] >> GU_CELL_TERM_BIT) & 1;
-        }
+        // (unpredicated: a lane without an env walks cell 0; two independent chains of three dependent LDS gathers)
+        uint32_t act[2], rec_e[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) act[e] = (actL[e_pos[e] >> 4] >> (2 * (e_pos[e] & 15))) & 3u, rec_e[e] = cell.f[e_pos[e]];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) e_pos[e] = vi_next(e_pos[e], rec_e[e], act[e], W);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) e_rew[e] = cell.r[e_pos[e]], e_done[e] = (cell.f[e_pos[e]] >> GU_CELL_TERM_BIT) & 1;
     };
     // workgroup 0 of the writing cluster: the delta of round `rr` = the maximum of the members' keys, from their slots.  The slots
     // are LOADED before the round's fetch and looked at behind it, so that the two round trips overlap.
@@ -373,19 +395,25 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
             }
             if (r > 0) publish_actions(par, tag, act_prev);  // (the actions of round r - 1 travel with the values of round r)
             VI_STAMP(0);
-            // the workgroup's delta key: DPP over the wave, then one LDS atomic by its last lane; the barrier below orders them
-            key = vi_wave_max_last(key);
-            if (lane == 63 && key) atomicMax(&wg_key[r & 3], key);
+            // the thread's delta key goes to LDS as it is; the workgroup's maximum is taken behind the barrier, by a wave that
+            // owns no states where there is one (one ds_write here instead of ~50 DPP / compare / select instructions)
+            lane_key[(r & 1) * B + tid] = key;
             VI_STAMP(1);
         }
-        __syncthreads();  // nobody reads the old values or actions in LDS any more; the workgroup's key is complete
+        __syncthreads();  // nobody reads the old values or actions in LDS any more; the lanes' keys are in LDS
         VI_STAMP(3);
-        if (tid == 0) {  // post the key (read one round late by the workgroup that collects the deltas)
-            vi_u64 *slot = slots + (size_t)((uint32_t)r & 3u) * VI_XCD_SLOTS * 2;
-            const vi_u64 mine = wg_key[r & 3];
-            wg_key[r & 3] = 0ull;  // (next written four rounds on)
-            vi_st_l2(slot + 2 * rank, (mine & 0xFFFFFFFF00000000ull) | tag);
-            vi_st_l2(slot + 2 * rank + 1, (mine << 32) | tag);
+        if (wave == key_wave) {  // post the workgroup's key (read one round late by the workgroup that collects the deltas)
+            vi_u64 mine = 0ull;
+            for (int32_t i = lane; i < (K == 1 ? state_waves * 64 : B); i += 64) {
+                const vi_u64 k = lane_key[(r & 1) * B + i];
+                mine = k > mine ? k : mine;
+            }
+            mine = vi_wave_max_last(mine);
+            if (lane == 63) {
+                vi_u64 *slot = slots + (size_t)((uint32_t)r & 3u) * VI_XCD_SLOTS * 2;
+                vi_st_l2(slot + 2 * rank, (mine & 0xFFFFFFFF00000000ull) | tag);
+                vi_st_l2(slot + 2 * rank + 1, (mine << 32) | tag);
+            }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j)
@@ -425,9 +453,9 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
             }
         }
         VI_STAMP(8);
-        if (r > 0) agents();
+        if (r > 0 && has_envs) agents();
 #ifdef GU_VI_XCD_STAMPS
-        asm volatile("" ::"v"(e_pos), "v"(e_rew), "v"(e_done), "v"(p[0][0]));  // the round ends here, not wherever its results are needed
+        asm volatile("" ::"v"(e_pos[0]), "v"(e_rew[0]), "v"(e_done[1]), "v"(p[0][0]));  // the round ends here, not wherever its results are needed
 #endif
         VI_STAMP(9);
 #ifdef GU_VI_XCD_STAMPS
@@ -454,7 +482,7 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
         if (keeps_deltas && wave == 0) delta_finish(r - 1);
         __syncthreads();
         if (info[3] & 1u) failed = true;
-        else agents();
+        else if (has_envs) agents();
     }
 #ifdef GU_VI_XCD_STAMPS
     if (keeps_deltas && tid == 0 && a.vi.max_rounds >= 12) {
@@ -474,14 +502,17 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
             }
         }
     }
-    if (own_env) {
-        a.pos[gid] = e_pos;
-        a.reward[gid] = e_rew;
-        a.done[gid] = e_done;
-        a.episode[gid] = e_ep;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (own_env[e]) {
+            a.pos[gid[e]] = e_pos[e];
+            a.reward[gid[e]] = e_rew[e];
+            a.done[gid[e]] = e_done[e];
+            a.episode[gid[e]] = e_ep[e];
+        }
+        const uint64_t bits = __ballot(own_env[e] && e_done[e] != 0);
+        if (lane == 0 && own_env[e]) a.done_bits[gid[e] >> 6] = bits;
     }
-    const uint64_t bits = __ballot(own_env && e_done != 0);
-    if ((tid & 63) == 0 && own_env) a.done_bits[gid >> 6] = bits;
     if (blockIdx.x == 0 && tid == 0) *a.vi.rounds_done = failed ? -1 : r;
 }
 
@@ -493,8 +524,8 @@ bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan)
 {
     if (h->n_grids != 1 || h->S > GU_MAX_LDS_CELLS || h->n_cu < VI_XCD_MAX_XCC) return false;
     const int64_t S2 = ((int64_t)h->S + 1) & ~(int64_t)1, n_words = ((int64_t)h->S + 15) / 16, n_aw = (n_words + 1) / 2;
-    // planes | values | spare slot of the fetch | action words
-    const size_t lds = 2 * (size_t)h->cell_bytes + (size_t)S2 * sizeof(double) + 16 + (size_t)n_aw * 8;
+    // planes | values | spare slot of the fetch | action words | the lanes' delta keys [2][threads]
+    const size_t lds = ((2 * (size_t)h->cell_bytes + (size_t)S2 * sizeof(double) + 16 + (size_t)n_aw * 8 + 15) & ~(size_t)15) + 2 * 1024 * sizeof(vi_u64);
     if ((int64_t)lds + 1024 > h->lds_per_cu) return false;
     const int64_t forced = gu_opt(h, GU_OPT_VI_XCD_BLOCK);
     const int max_wgs = h->n_cu;

@@ -368,28 +368,36 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
 #endif
     };
     uint32_t act_prev[K];  // greedy action of the thread's states under the policy of the round before
-    double v_new[K];
+    double v_new[K];       // the states' current values
+    double gv[K][4];       // gamma * value of the four successors
 #pragma unroll
-    for (int j = 0; j < K; ++j) act_prev[j] = 0u, v_new[j] = 0.0;
+    for (int j = 0; j < K; ++j) {
+        act_prev[j] = 0u;
+        v_new[j] = st[j] >= 0 ? vL[st[j]] : 0.0;
+#pragma unroll
+        for (uint32_t act = 0; act < 4; ++act) gv[j][act] = st[j] >= 0 ? __dmul_rn(gamma, vL[vi_next(st[j], rec[j], act, W)]) : 0.0;
+    }
     int r = 0;
     for (; r < a.vi.max_rounds && !failed; ++r) {
         const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;
         if (wave_has_states) {
             vi_u64 key = 0ull;
 #pragma unroll
-            for (int j = 0; j < K; ++j) {  // V1 (utils.py:15-27) on the LDS copy of the old values
+            for (int j = 0; j < K; ++j) {  // V1 (utils.py:15-27)
                 const int32_t s = st[j];
                 if (s >= 0) {
-                    double acc = __dadd_rn(0.0, (double)r_own[j]);
+                    // (0.0 + R == R: an integer converted to double is never -0.  gamma * v[next] was formed by V2 of the round
+                    // before -- same table, same successor -- and is still in registers: V1 reads nothing from LDS)
+                    double acc = (double)r_own[j];
 #pragma unroll
-                    for (uint32_t act = 0; act < 4; ++act)
-                        acc = __dadd_rn(acc, __dmul_rn(p[j][act], __dmul_rn(gamma, vL[vi_next(s, rec[j], act, W)])));
+                    for (uint32_t act = 0; act < 4; ++act) acc = __dadd_rn(acc, __dmul_rn(p[j][act], gv[j][act]));
+                    const double v_old = v_new[j];
                     v_new[j] = acc;
                     const vi_u64 bits = (vi_u64)__double_as_longlong(acc);
                     vi_u32x4 g;
                     g.x = tag, g.y = (uint32_t)(bits >> 32), g.z = tag, g.w = (uint32_t)bits;
                     __builtin_amdgcn_raw_buffer_store_b128(g, rs, par * gv_bytes + (uint32_t)s * 16u, 0, VI_XCD_STORE_AUX);
-                    const vi_u64 k = vi_key(__dsub_rn(vL[s], acc));  // signed, dynamic_programming.py:17
+                    const vi_u64 k = vi_key(__dsub_rn(v_old, acc));  // signed, dynamic_programming.py:17
                     key = k > key ? k : key;
                 }
             }
@@ -438,14 +446,30 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
         for (int j = 0; j < K; ++j) {  // V2 (utils.py:55-72) on v'
             const int32_t s = st[j];
             if (s >= 0) {
-                double q[4];
+                // q[a] = 0.0 + (R[next] + gamma * v'[next]) without the `0.0 +`: the sum of a non-zero integer and anything is never
+                // -0, so the addition is the identity.  Ties of np.around(q, 8) through k = rint(q * 1e8) as in vi_tie_mask; the k of
+                // the largest q is the largest k (x -> rint(x * 1e8) is monotone), so the maximum is taken over the k and the chain
+                // of compares and selects over q runs only where the divisions decide (|q| >= 3.3e7, or NaN).
+                double q[4], k[4];
 #pragma unroll
-                for (uint32_t act = 0; act < 4; ++act)
-                    q[act] = __dadd_rn(0.0, __dadd_rn((double)(int8_t)(rn[j] >> (8 * act)), __dmul_rn(gamma, vL[vi_next(s, rec[j], act, W)])));
-                double qmax = q[0];
+                for (uint32_t act = 0; act < 4; ++act) {
+                    gv[j][act] = __dmul_rn(gamma, vL[vi_next(s, rec[j], act, W)]);
+                    q[act] = __dadd_rn((double)(int8_t)(rn[j] >> (8 * act)), gv[j][act]);
+                    k[act] = rint(__dmul_rn(q[act], 100000000.0));
+                }
+                const double kmax = fmax(fmax(k[0], k[1]), fmax(k[2], k[3]));
+                const double kabs = fmax(fmax(fabs(k[0]), fabs(k[1])), fmax(fabs(k[2]), fabs(k[3])));
+                uint32_t mask = 0u;
 #pragma unroll
-                for (int act = 1; act < 4; ++act) qmax = (q[act] > qmax) ? q[act] : qmax;
-                const uint32_t mask = (rec[j] & GU_CELL_TERM) ? 0u : vi_tie_mask(q, qmax);
+                for (int act = 0; act < 4; ++act) mask |= (uint32_t)(k[act] == kmax) << act;
+                const bool any_nan = k[0] != k[0] || k[1] != k[1] || k[2] != k[2] || k[3] != k[3];
+                if (!(kabs < 3355443200000000.0) || any_nan) {  // 2^25 * 1e8 (proof: gu_vi.hpp, vi_tie_mask)
+                    double qmax = q[0];
+#pragma unroll
+                    for (int act = 1; act < 4; ++act) qmax = (q[act] > qmax) ? q[act] : qmax;
+                    mask = vi_tie_mask(q, qmax);
+                }
+                if (rec[j] & GU_CELL_TERM) mask = 0u;
                 const double share = vi_share(mask);
 #pragma unroll
                 for (int act = 0; act < 4; ++act) p[j][act] = ((mask >> act) & 1u) ? share : 0.0;

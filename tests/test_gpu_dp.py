@@ -440,3 +440,42 @@ def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, g
         v, pi = eng.vi_get()
         assert d.tolist() == meta['deltas']
         assert v.tobytes() == z['vi_v_%d' % meta['iters']].tobytes() and pi.tobytes() == z['vi_pi_%d' % meta['iters']].tobytes()
+
+
+@pytest.mark.parametrize('name,N', [('maze64_s5', 65536), ('maze32_s1_g099', 3000), ('rect6x5_g1', 700), ('maze11_s3_g09', 64)])
+@pytest.mark.parametrize('values', ['ties', 'huge', 'nonfinite'])
+def test_sweep_step_run_forms_agree_on_random_tables(name, N, values, vi_path, gu_option):
+    """Every form of gu_vi_sweep_step_run from RANDOM tables: exact ties of np.around(q, 8), values beyond 3.3e7 (where the tie
+    test needs its IEEE divisions) and infinities / NaN -- the per-XCD form takes the maximum over rint(q * 1e8) instead of over q
+    and drops the reference's `0.0 +` where it is provably the identity; its bytes must not notice."""
+    if vi_path == 'launch_per_round':
+        pytest.skip('vi_path = 2 leaves one form: nothing to compare')
+    meta, _ = G.load_dp(name)
+    S = meta['W'] * meta['H']
+    rs = np.random.RandomState(11)
+    out, form = {}, {}
+    for gamma in (1.0, 0.9):
+        pi = rs.dirichlet(np.ones(4), S)
+        v = rs.standard_normal(S) * 50
+        v[::7] = np.round(v[::7])
+        if values == 'huge':
+            v[::5] *= 1e7
+            v[3::11] = 4e15
+        if values == 'nonfinite':
+            v[5::13] = np.inf
+            v[6::17] = -np.inf
+            v[7::19] = np.nan
+        for mode, path in (('per_xcd', None), ('chip_wide', 4), ('per_launch', 1)):
+            gu_option('vi_path', path)
+            with Engine(N, spec_of(meta), seed=3) as eng:
+                eng.reset()
+                eng.vi_set(v, pi)
+                with np.errstate(all='ignore'):
+                    deltas = np.concatenate([eng.vi_sweep_step_run(gamma, 7, auto_reset=True), eng.vi_sweep_step_run(gamma, 2, auto_reset=True)])
+                form[mode] = eng.vi_last_form()
+                vv, pp = eng.vi_get()
+                st = eng.get_state()
+                out[mode] = [deltas.tobytes(), vv.tobytes(), pp.tobytes(), st['pos'].tobytes(), st['done'].tobytes(), st['episode'].tobytes(),
+                             eng.read_outputs()[1].tobytes()]
+        assert out['per_xcd'] == out['chip_wide'] == out['per_launch'], (gamma, [a == b for a, b in zip(out['per_xcd'], out['per_launch'])])
+    assert form == {'per_xcd': 1, 'chip_wide': 2, 'per_launch': 3}

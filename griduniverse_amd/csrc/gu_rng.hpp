@@ -84,6 +84,38 @@ __host__ __device__ __forceinline__ uint32_t gu_rng_word(uint32_t prefix, uint32
     return gu_rng_word_finish(gu_rng_word_begin(prefix, stream, ctr));
 }
 
+// Stream 2, the words behind the inverse-CDF samples of a table policy (oracle/gu_rng.py: sample_word): ONE hashed word per FOUR
+// steps, the words of the three steps behind it by a multiply-free bijection (xorshift32 step + Weyl increment).  A hash per
+// step was what bound the sampled rollout: five quarter-rate 32-bit multiplies, ~80 clocks of issue time per step against the
+// ~30 of the rest of the step.
+__host__ __device__ __forceinline__ uint32_t gu_rng_sample_next(uint32_t x)
+{
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    return x + 0x9E3779B9u;
+}
+
+__host__ __device__ __forceinline__ uint32_t gu_rng_sample_word(uint32_t prefix, uint32_t t)
+{
+    uint32_t w = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t >> 2);
+    for (uint32_t i = 0; i < (t & 3u); ++i) w = gu_rng_sample_next(w);
+    return w;
+}
+
+// The word of step t + 1 from the word of step t.  Device: the hash is behind a WAVE-UNIFORM test, so a wave whose lanes are at
+// one step count (every launch that did not start from a per-env gu_set_state) hashes once in four steps.
+__device__ __forceinline__ uint32_t gu_rng_sample_advance(uint32_t prefix, uint32_t t, uint32_t word)
+{
+    uint32_t next = gu_rng_sample_next(word);
+    const bool fresh = ((t + 1u) & 3u) == 0u;
+    if (__builtin_amdgcn_ballot_w64(fresh)) {
+        const uint32_t hashed = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, (t + 1u) >> 2);
+        next = fresh ? hashed : next;
+    }
+    return next;
+}
+
 // index into starts[] for episode `ep` (multiply-shift range reduction)
 __host__ __device__ __forceinline__ uint32_t gu_rng_start_index(uint32_t prefix, uint32_t ep, uint32_t n_starts)
 {

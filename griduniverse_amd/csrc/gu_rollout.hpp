@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         // is explicit here.  8 steps per resource rebase (scalar row offsets, as on the uniform path); the sampling
         // word of the NEXT step is hashed while this step's threshold read is in flight (it does not depend on s).
         uint32_t t = t_lane;
-        uint32_t word = POLICY == GU_POLICY_SAMPLE ? gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t) : 0u;
+        uint32_t word = POLICY == GU_POLICY_SAMPLE ? gu_rng_sample_word(prefix, t) : 0u;
         GuPacer pacer;
         pacer.start(TRAJ == 1 ? a.pace : 0u);
         auto run = [&](auto thr_at) {
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                     // inverse CDF of pi[s] on one uniform 32-bit word (RNG stream 2, counter = step count), as integer
                     // thresholds (gu_pi_threshold_kernel)
                     const uint4 q = thr_at(s);
-                    const uint32_t next_word = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t + 1u);
+                    const uint32_t next_word = gu_rng_sample_advance(prefix, t, word);
                     act = gu_sample_action(word, q);
                     word = next_word;
                 }

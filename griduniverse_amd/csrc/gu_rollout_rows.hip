@@ -19,7 +19,7 @@
 // Table policies use the same idea with policy-dependent rows, rebuilt by every launch (the policy table may have changed):
 //   GU_POLICY_GREEDY  row[s]    = the one record reached by the greedy action of the (post-reset) cell: 4 bytes, up to 32
 //                                 copies; a step is v_and_or_b32 + ds_read_b32
-//   GU_POLICY_SAMPLE  row[s]    = { inverse-CDF thresholds of pi[cell] (uint4, gu_pi_threshold_kernel) | the four next
+//   GU_POLICY_SAMPLE  row[s]    = { inverse-CDF thresholds of pi[cell], SORTED (uint4, from gu_pi_threshold_kernel) | the four next
 //                                 records }: 32 bytes, up to 4 copies; a step is ONE round trip for two ds_read_b128, the three
 //                                 threshold compares and a three-select pick of the next record (the general kernel: a
 //                                 threshold gather, the compares, the move, and a second gather for the record)
@@ -82,10 +82,25 @@ __global__ void __launch_bounds__(256) gu_build_policy_rows_kernel(const BuildPo
         a.rows[s] = gu_row_record(a.cell, a.cell_bytes, base, a.greedy[base], a.W, a.row_shift);
         return;
     }
+    // The step's action is  #{k : word >= thr_k} - never  (gu_sample_action; thresholds no word can reach are stored as 0 and
+    // counted in `never`).  A count does not care about the order of its thresholds: with them SORTED, "word >= the c-th" implies
+    // "word >= every one before it", and the record of count c can be picked by three chained selects -- 3 compares + 3 selects
+    // on the step's dependent chain instead of the count, its carry adds, and a two-level select on the action's bits (21
+    // instructions with their wait states).  The records are stored BY COUNT: entry c = the record of action c - never.
     uint4 *out = reinterpret_cast<uint4 *>(a.rows + 8 * (int64_t)s);
-    out[0] = a.thr[base];
-    out[1] = make_uint4(gu_row_record(a.cell, a.cell_bytes, base, 0, a.W, a.row_shift), gu_row_record(a.cell, a.cell_bytes, base, 1, a.W, a.row_shift),
-                        gu_row_record(a.cell, a.cell_bytes, base, 2, a.W, a.row_shift), gu_row_record(a.cell, a.cell_bytes, base, 3, a.W, a.row_shift));
+    const uint4 q = a.thr[base];
+    uint32_t t0 = q.x, t1 = q.y, t2 = q.z;
+    if (t0 > t1) { const uint32_t x = t0; t0 = t1; t1 = x; }
+    if (t1 > t2) { const uint32_t x = t1; t1 = t2; t2 = x; }
+    if (t0 > t1) { const uint32_t x = t0; t0 = t1; t1 = x; }
+    out[0] = make_uint4(t0, t1, t2, q.w);
+    uint32_t rec[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) {
+        const uint32_t act = c >= q.w ? (c - q.w > 3u ? 3u : c - q.w) : 0u;  // (a count below `never` cannot occur)
+        rec[c] = gu_row_record(a.cell, a.cell_bytes, base, act, a.W, a.row_shift);
+    }
+    out[1] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
 }
 
 // PAIR tables (uniform policy / caller-supplied stream, launches that write rows): TWO env-steps per LDS round trip.  The actions
@@ -250,9 +265,12 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             __builtin_amdgcn_sched_barrier(0);  // the two reads are issued BEFORE the ~17 vector ops of the hash, not behind them
             between();
             __builtin_amdgcn_sched_barrier(0);
-            const uint32_t act = gu_sample_action(x, make_uint4(q.x, q.y, q.z, q.w));
-            const uint32_t lo = (act & 1u) ? nx.y : nx.x, hi = (act & 1u) ? nx.w : nx.z;
-            rec = (act & 2u) ? hi : lo;
+            uint32_t sel = nx.x;  // sorted thresholds, records by count (gu_build_policy_rows_kernel)
+            sel = x >= q.x ? nx.y : sel;
+            sel = x >= q.y ? nx.z : sel;
+            rec = x >= q.z ? nx.w : sel;
+            asm volatile("" ::"v"(q.w));  // keep the unused fourth word of the read live up to here: the compiler otherwise takes its
+                                          // register for the hash's temporaries and has to WAIT for the read before the hash can start
         } else if (POLICY == GU_POLICY_GREEDY) {
             rec = *(lds_u32_ptr)(uintptr_t)((prev & GU_ROW_ADDR_MASK) | lane_copy);
             between();
@@ -339,18 +357,18 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
     } else if (POLICY == GU_POLICY_GREEDY || POLICY == GU_POLICY_SAMPLE) {
         // first step on the planes; the policy is consulted at the post-reset cell
         uint32_t t = t_lane;
-        uint32_t word = POLICY == GU_POLICY_SAMPLE ? gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t) : 0u;
+        uint32_t word = POLICY == GU_POLICY_SAMPLE ? gu_rng_sample_word(prefix, t) : 0u;
         {
             const int32_t at = (auto_reset && d) ? a.starts[0] : s;
             first_step(POLICY == GU_POLICY_GREEDY ? (uint32_t)a.greedy[at] : gu_sample_action(word, a.pi_thr[at]));
         }
+        if (POLICY == GU_POLICY_SAMPLE) word = gu_rng_sample_advance(prefix, t, word);
         ++t;
-        if (POLICY == GU_POLICY_SAMPLE) word = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t);
         int64_t i = 1;
         auto pstep = [&](uint32_t soff) {  // the word of the NEXT step is hashed while this step's reads are in flight
             uint32_t next_word = 0u;
             step(word, soff, [&] {
-                if (POLICY == GU_POLICY_SAMPLE) next_word = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t + 1u);
+                if (POLICY == GU_POLICY_SAMPLE) next_word = gu_rng_sample_advance(prefix, t, word);
             });
             word = next_word;
             ++t;

@@ -34,6 +34,8 @@ def lib():
         _lib = ctypes.CDLL(build())
         _lib.gu_oracle_rng_word.restype = ctypes.c_uint32
         _lib.gu_oracle_rng_word.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        _lib.gu_oracle_rng_sample_word.restype = ctypes.c_uint32
+        _lib.gu_oracle_rng_sample_word.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
         _lib.gu_oracle_rng_action.restype = ctypes.c_int32
         _lib.gu_oracle_rng_action.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
         _lib.gu_oracle_rng_start.restype = ctypes.c_int32

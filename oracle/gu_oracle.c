@@ -129,10 +129,24 @@ void gu_oracle_reset(const gu_oracle_grid *g, uint64_t seed, int64_t env_id0, in
     }
 }
 
+/* the word behind the sampled action of step t (oracle/gu_rng.py: sample_word): one hashed word of stream 2 per four steps,
+ * the three behind it by xorshift32 + a Weyl increment */
+uint32_t gu_oracle_rng_sample_word(uint64_t seed, uint32_t env, uint32_t t)
+{
+    uint32_t w = gu_oracle_rng_word(seed, env, 2, t >> 2);
+    for (uint32_t i = 0; i < (t & 3u); ++i) {
+        w ^= w << 13;
+        w ^= w >> 17;
+        w ^= w << 5;
+        w += 0x9E3779B9u;
+    }
+    return w;
+}
+
 /* inverse-CDF sample of pi[s][0..3] on RNG stream 2 (oracle/gu_rng.py: sampled_action) */
 int32_t gu_oracle_rng_sample(uint64_t seed, uint32_t env, uint32_t t, const double *p)
 {
-    double u = (double)gu_oracle_rng_word(seed, env, 2, t) / 4294967296.0;
+    double u = (double)gu_oracle_rng_sample_word(seed, env, t) / 4294967296.0;
     volatile double c0 = p[0];
     volatile double c1 = c0 + p[1];
     volatile double c2 = c1 + p[2];

@@ -36,7 +36,6 @@ import contextlib
 import ctypes
 import glob
 import hashlib
-import importlib
 import json
 import os
 import random
@@ -64,7 +63,7 @@ BYTES_PER_ENV_STEP = 12       # fused rollout writing the int32 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBPS = 6290.0
 C4_TOTAL_ENVS = 262144        # BASELINE.json config 4
-WORKLOAD_SEED = {'c2': 2, 'c3': 123, 'c4': 4}
+WORKLOAD_SEED = {'c2': 2, 'c3': 123, 'c4': 4, 'c5': 5}
 REFERENCE_DIGEST = {'c2': 'c2_open8x8_4096x1000', 'c3': 'c3_maze32_65536x1000', 'c4': 'c4_lava32_262144x250'}
 
 
@@ -80,6 +79,10 @@ def build_workload(name):
         return env, '32x32 open grid, start 0, goal 1023, lava column [16+32r, r<24]'
     if name == 'c2':
         return gua.GridUniverseEnv(grid_shape=(8, 8)), 'default 8x8 grid'
+    if name == 'c5':
+        random.seed(5)
+        np.random.seed(5)
+        return gua.GridUniverseEnv(grid_shape=(64, 64), random_maze=True), '64x64 generator maze (random.seed(5); np.random.seed(5))'
     raise SystemExit('unknown workload ' + name)
 
 
@@ -284,6 +287,172 @@ def cpu_baseline_check_stats(template, seed, env_id0, T, ret, episodes, n_check=
     return bool(np.array_equal(ret[:n], want['ret']) and np.array_equal(episodes[:n], want['episodes']))
 
 
+def cpu_baseline_check_c5(template, seed, gamma, rounds, v, pi, state, rewards):
+    """Config 5 against the C oracle: `rounds` x { V1 + V2 sweep (value_iteration_step, itself pinned to the reference's
+    value-iteration trace by tests/test_oracle_c.py); every env steps greedily on the updated policy (np.argmax of its row,
+    examples/griduniverse_alg_examples.py:76), lazy reset first } from reset with zero values and the uniform policy --
+    tables as raw bytes, every env's position / done flag / episode count and last reward."""
+    from oracle import c_oracle as C
+    grid = C.Grid.from_env(template)
+    S, N = template.world.size, state['pos'].size
+    st = C.State(N)
+    C.reset(grid, seed, st)
+    v_o, pi_o = np.zeros(S), np.ones((S, 4)) / 4
+    want = None
+    for _ in range(rounds):
+        v_o, pi_o, _ = C.value_iteration_step(grid, gamma, pi_o, v_o)
+        acts = np.argmax(pi_o, axis=1).astype(np.int32)
+        if st.done.any():
+            C.reset(grid, seed, st, mask=st.done.astype(bool))
+        want = C.rollout(grid, seed, st, 1, False, actions=acts[st.pos][None, :])
+    return bool(v.tobytes() == v_o.tobytes() and pi.tobytes() == pi_o.tobytes() and np.array_equal(state['pos'], st.pos)
+                and np.array_equal(state['done'], st.done) and np.array_equal(state['episode'], st.episode)
+                and np.array_equal(rewards, want['reward'][0]))
+
+
+# --------------------------------------------------------------------------------------- the other BASELINE configs
+def baseline_configs(engine_cls, device, K, check):
+    """BASELINE.json configs 2, 4 (one shard of eight) and 5 on this GPU, beside the headline (config 3) -- never as `value`.
+    Each entry: workload, us per launch (or per round), env-steps/s, the bound it claims with a stated floor, its own parity bit."""
+    out = {}
+    T = 1000
+    clock_ghz = None
+    try:
+        clock_ghz = float(engine_cls.device_info(device).get('sclk_khz', 0)) / 1e6 or None
+    except Exception:  # noqa: BLE001 -- reporting only
+        pass
+
+    def rows(eng, policy='uniform'):
+        for _ in range(3):
+            eng.rollout(T, policy, auto_reset=True, trajectory=True)
+        eng.sync()
+        eng.timer_begin()
+        for _ in range(K):
+            eng.rollout(T, policy, auto_reset=True, trajectory=True)
+        return eng.timer_end() / K
+
+    # ---- config 2: 4096 envs, default 8x8 grid
+    template, desc = build_workload('c2')
+    N, seed = 4096, WORKLOAD_SEED['c2']
+    eng = engine_cls(N, gua.GridSpec.from_env(template), device=device, env_id0=0, seed=seed)
+    try:
+        eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
+        ok = None
+        if check:
+            got = eng.read_trajectory(0, T)
+            ref = reference_digest('c2', template, seed, N, T, 0)
+            ok = sha256_triplet(got) == ref if ref is not None else bool(cpu_baseline_check_prefix(template, seed, 0, got))
+            del got
+        ms = rows(eng)
+    finally:
+        eng.close()
+    cyc = None if clock_ghz is None else ms * 1e3 * clock_ghz * 1e3 / T
+    out['c2'] = dict(workload='c2: %d envs on the %s, seed %d, uniform device-RNG actions, auto-reset, int32 trajectory, %d env-steps per launch' % (N, desc, seed, T),
+                     us_per_launch=ms * 1e3, env_steps_per_s=float(N) * T / ms * 1e3, hbm_gbps=BYTES_PER_ENV_STEP * N * T / ms / 1e6,
+                     frac_of_hbm_peak=BYTES_PER_ENV_STEP * N * T / ms / 1e6 / HBM_PEAK_GBPS,
+                     bound='latency: 64 waves on 1024 SIMDs, each a chain of %d dependent steps (one LDS round trip + one vector op per step, '
+                           'gu_rollout_rows_kernel); the HBM stream is 49 MB per launch' % T,
+                     cycles_per_step=cyc, floor_us='%d steps x ~85 shader clocks (ds_read_b32 issue -> use, MI355X_MICROARCH.md) = %.0f us at the clock '
+                                                   'HIP reports, + ~5 us of table staging and the first step' % (T, T * 85 / ((clock_ghz or 2.4) * 1e3)),
+                     bit_exact=ok, check='first launch from reset == the reference digest c2_open8x8_4096x1000 (tests/golden/digests.json)')
+
+    # ---- config 4, one shard of eight: 32 768 envs with global ids 32768 .. 65535 on the lava grid
+    template, desc = build_workload('c4')
+    N, seed = C4_TOTAL_ENVS // 8, WORKLOAD_SEED['c4']
+    eng = engine_cls(N, gua.GridSpec.from_env(template), device=device, env_id0=N, seed=seed)
+    try:
+        eng.reset()
+        eng.reserve_trajectory(T)
+        eng.rollout(250, 'uniform', auto_reset=True, trajectory=True)
+        ok = bool(cpu_baseline_check_prefix(template, seed, N, eng.read_trajectory(0, 250), n_check=N)) if check else None
+        ms = rows(eng)
+    finally:
+        eng.close()
+    out['c4_shard'] = dict(workload='c4, shard 1 of 8: %d envs (global ids %d ..) on the %s, seed %d, uniform device-RNG actions, auto-reset, int32 '
+                                    'trajectory, %d env-steps per launch' % (N, N, desc, seed, T),
+                           us_per_launch=ms * 1e3, env_steps_per_s=float(N) * T / ms * 1e3, hbm_gbps=BYTES_PER_ENV_STEP * N * T / ms / 1e6,
+                           frac_of_hbm_peak=BYTES_PER_ENV_STEP * N * T / ms / 1e6 / HBM_PEAK_GBPS,
+                           bound='between the dependent chain (512 waves: half a wave per SIMD) and the HBM write stream (393 MB per launch)',
+                           floor_us='393 MB / 8 TB/s = 49 us (HBM); %d steps x ~85 clocks = %.0f us (chain)' % (T, T * 85 / ((clock_ghz or 2.4) * 1e3)),
+                           eight_shards_env_steps_per_s_if_scaling_were_perfect=8.0 * N * T / ms * 1e3,
+                           bit_exact=ok, check='first launch (250 steps from reset): the whole shard == C oracle at its global env ids')
+
+    # ---- config 5: 65 536 envs, 64x64 maze, one V1 + V2 sweep fused with one greedy env step per round
+    if hasattr(engine_cls, 'vi_sweep_step_run'):
+        template, desc = build_workload('c5')
+        N, seed, gamma, S = 65536, WORKLOAD_SEED['c5'], 1.0, 64 * 64
+        eng = engine_cls(N, gua.GridSpec.from_env(template), device=device, env_id0=0, seed=seed)
+        try:
+            ok, n_check = None, 12
+            if check:
+                eng.reset()
+                eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+                eng.vi_sweep_step_run(gamma, n_check, auto_reset=True)
+                v, pi = eng.vi_get()
+                ok = cpu_baseline_check_c5(template, seed, gamma, n_check, v, pi, eng.get_state(), eng.read_outputs()[1])
+            rounds, per_round = 2000, []
+            for rep in range(4):
+                eng.reset()
+                eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+                eng.sync()
+                t0 = time.perf_counter()
+                eng.vi_sweep_step_run(gamma, rounds, auto_reset=True)
+                if rep:
+                    per_round.append((time.perf_counter() - t0) / rounds)
+            form = eng.vi_last_form()
+        finally:
+            eng.close()
+        us = float(np.median(per_round)) * 1e6
+        out['c5'] = dict(workload='c5: %d envs on the %s, gamma %.1f: per round one V1 + V2 sweep of the %d-state tables (float64, bit-exact) fused with one '
+                                  'greedy env step of every env; %d rounds in ONE launch' % (N, desc, gamma, S, rounds),
+                         us_per_round=us, env_steps_per_s=N / us * 1e6, state_updates_per_s=S / us * 1e6,
+                         form={1: 'one launch synchronised per XCD (self-tagged granules, no barrier between workgroups)',
+                               2: 'one launch, chip-wide barrier per round', 3: 'one launch per round'}.get(form, str(form)),
+                         timing='host wall time of one gu_vi_sweep_step_run call / rounds (snapshot, launch and read-back of the deltas included), median of 3',
+                         bound='latency: per round one store -> L2 -> load hop inside the XCD and two dependent float64 chains (V1, V2: ~35-clock '
+                               'dependent-issue latency per float64 operation on gfx950); the round moves 64 KB of value granules per XCD, nothing '
+                               'near any bandwidth limit',
+                         floor_us='V1 (6 dependent float64 operations) + V2 (8) at ~38 clocks each + one L2 store-to-load hop (~600 clocks) + two workgroup '
+                                  'barriers = ~1300 clocks = 0.55 us at 2.4 GHz',
+                         bit_exact=ok, check='%d rounds from reset (zero values, uniform policy): tables as raw bytes and every env\'s position / done / '
+                                             'episode / reward == C oracle (value_iteration_step + greedy step)' % n_check)
+    return out
+
+
+def topology_block(engine_cls):
+    """What the node looks like, for the first run on more than one GPU to be self-diagnosing: HIP's device count, every
+    device's PCI id, the xGMI link matrix as sysfs (or rocm-smi) shows it, the RCCL library the gathered view would load."""
+    out = {}
+    try:
+        n = _lib.device_count() if engine_cls is gua.Engine else 1
+        out['hip_device_count'] = n
+        out['devices'] = []
+        for d in range(n):
+            info = engine_cls.device_info(d) if hasattr(engine_cls, 'device_info') else {}
+            out['devices'].append({k: info.get(k) for k in ('name', 'arch', 'pci', 'cus') if k in info})
+    except Exception as err:  # noqa: BLE001 -- reporting only
+        out['error'] = str(err)
+    links = {}
+    for path in sorted(glob.glob('/sys/class/kfd/kfd/topology/nodes/*/io_links/*/properties')):
+        try:
+            props = dict(line.split(None, 1) for line in open(path).read().splitlines() if ' ' in line)
+        except OSError:
+            continue
+        if props.get('type', '').strip() == '11':  # HSA_IOLINK_TYPE_XGMI
+            node = path.split('/nodes/')[1].split('/')[0]
+            links.setdefault(node, []).append(dict(to=props.get('node_to', '').strip(), weight=props.get('weight', '').strip(),
+                                                   max_bandwidth=props.get('max_bandwidth', '').strip()))
+    out['xgmi_links_by_kfd_node'] = links or None
+    out['xgmi_hives'] = sorted({open(p).read().strip() for p in glob.glob('/sys/class/drm/card*/device/xgmi_hive_info/xgmi_hive_id')
+                                if os.access(p, os.R_OK)}) or None
+    rccl = os.environ.get('GU_RCCL_LIB') or '/opt/rocm/lib/librccl.so'
+    out['rccl_library'] = os.path.realpath(rccl) if os.path.exists(rccl) else None
+    out['visible_devices_env'] = {k: os.environ[k] for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES') if k in os.environ}
+    return out
+
+
 # --------------------------------------------------------------------------------------- timing
 class Ranks(object):
     """Host channel between the ranks: griduniverse_amd.rendezvous (one socket per rank to rank 0; torchrun-style environment,
@@ -293,7 +462,7 @@ class Ranks(object):
         from griduniverse_amd.rendezvous import Rendezvous
         self.rank, self.world = rank, world
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        self.rdzv = Rendezvous(rank, world)
+        self.rdzv = Rendezvous(rank, world, join_timeout=float(os.environ.get('GU_RDZV_JOIN_TIMEOUT', '600')))
         self.rdzv.barrier()
 
     def barrier(self):
@@ -371,6 +540,25 @@ def other_modes(eng, template, seed, env_id0, N, T, K, check):
                          'returns_vs_oracle': ok, 'mean_return_per_env': float(np.mean(ret)),
                          'is': 'per-env return and episodes finished instead of the trajectory; first launch from reset checked '
                                'against oracle/gu_oracle.c'}
+    if hasattr(eng, 'vi_set'):  # the sampled table policy (the producer of Monte-Carlo evaluation): actions ~ pi[s] by inverse CDF on RNG stream 2
+        S = template.world.size
+        eng.vi_set(np.zeros(S), np.random.RandomState(1).dirichlet(np.ones(4), S))
+
+        def sample_ms(**kw):
+            for _ in range(3):
+                eng.rollout(T, 'sample', auto_reset=True, **kw)
+            eng.sync()
+            eng.timer_begin()
+            for _ in range(K):
+                eng.rollout(T, 'sample', auto_reset=True, **kw)
+            return eng.timer_end() / K
+        ms = sample_ms(trajectory=True)
+        out['rollout_sample_policy_traj'] = {'ms_per_launch': ms, 'value': float(N) * T / ms * 1e3, 'unit': 'env-steps/s (this rank)',
+                                             'bytes_per_env_step': BYTES_PER_ENV_STEP, 'achieved_GBps': BYTES_PER_ENV_STEP * float(N) * T / ms / 1e6,
+                                             'frac_of_hbm_peak': BYTES_PER_ENV_STEP * float(N) * T / ms / 1e6 / HBM_PEAK_GBPS,
+                                             'is': 'actions sampled from a random stochastic policy table (Dirichlet(1) rows) instead of uniform; int32 rows'}
+        ms = sample_ms(trajectory=False, stats=True)
+        out['rollout_sample_policy_stats_only'] = {'ms_per_launch': ms, 'value': float(N) * T / ms * 1e3, 'unit': 'env-steps/s (this rank)'}
     if hasattr(eng, 'read_trajectory_packed'):
         ms = launch_ms(trajectory='packed')
         out['packed_rows'] = {'ms_per_launch': ms, 'value': float(N) * T / ms * 1e3, 'unit': 'env-steps/s (this rank)',
@@ -458,8 +646,20 @@ def live_traffic(args, N, T, budget_s=150):
             left = budget_s - (time.time() - t0)
             if left < 20:
                 return None
-            proc = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                                  timeout=left)
+            # (its own session: if rocprofv3 spawns the program instead of exec'ing it, a timeout must take the whole group down)
+            child = subprocess.Popen(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                     start_new_session=True)
+            try:
+                child.wait(timeout=left)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+                child.wait()
+                return None
+            proc = child
             values = []
             for path in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
                 with open(path, newline='') as f:
@@ -479,7 +679,7 @@ def live_traffic(args, N, T, budget_s=150):
                 seconds=time.time() - t0,
                 source='rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE: two child runs of this script (bench.py --pmc-child: the bench kernel on the '
                        'bench workload, %d launches counted each) on this device right after the timed region; bytes = WRITE_SIZE*1024 + '
-                       '2*FETCH_SIZE*1024' % sums['WRITE_SIZE'][1])
+                       '2*FETCH_SIZE*1024 (FETCH_SIZE x 2: on gfx950 the counter tallies 128-byte read requests at 64 bytes, MI355X_MICROARCH.md "HBM")' % sums['WRITE_SIZE'][1])
 
 
 def pmc_child(args):
@@ -663,15 +863,6 @@ def strong_c4(args, ranks, engine_cls, device):
 
 
 # --------------------------------------------------------------------------------------- plumbing
-def load_engine_class(args):
-    """griduniverse_amd.Engine unless --engine module:Class names another one (the CPU tests run the whole script on
-    tests/_oracle_engine.py; the JSON line always names the class that ran)."""
-    if not getattr(args, 'engine', None):
-        return gua.Engine
-    module, _, name = args.engine.partition(':')
-    return getattr(importlib.import_module(module), name)
-
-
 def ensure_library_is_current(engine_cls, local_rank=0):
     """A checkout whose libgu.so is missing or older than its sources: build it (one rank per node) rather than measure
     nothing.  _lib.is_stale() reads the hash from the file's bytes, so looking never maps the library."""
@@ -686,26 +877,71 @@ def ensure_library_is_current(engine_cls, local_rank=0):
             time.sleep(2)
 
 
-def spawn_ranks(args, argv):
+def spawn_ranks(args, argv, engine_cls=None, script=None):
     """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): this process becomes a launcher.  It
-    starts N fresh children -- one rank each, torchrun-style environment -- BEFORE anything here has touched a GPU or loaded
-    libgu.so, relays rank 0's JSON line, and returns the worst exit code.  (Never an exec of a process that has initialised
-    the GPU: the children are ordinary subprocesses and this parent never calls into HIP.)"""
-    ensure_library_is_current(load_engine_class(args))  # a subprocess `make`: no HIP call in this process
+    starts N fresh children -- one rank each, torchrun-style environment, each the leader of its own process group -- BEFORE
+    anything here has touched a GPU or loaded libgu.so, relays rank 0's JSON line, and returns the worst exit code.  (Never an
+    exec of a process that has initialised the GPU: the children are ordinary subprocesses and this parent never calls into HIP.)
+    EVERY child is watched: the first one that dies with an error takes the others down with it at once -- the survivors would
+    otherwise sit in the rendezvous until its timeout, silently, holding their GPUs -- and SIGTERM / SIGINT to the launcher
+    (an outer `timeout`) are passed on to all of them."""
+    import signal
+    import threading
+
+    ensure_library_is_current(engine_cls or gua.Engine)  # a subprocess `make`: no HIP call in this process
     with socket.socket() as sck:
         sck.bind(('127.0.0.1', 0))
         port = sck.getsockname()[1]
+    script = script or os.path.abspath(__file__)
+    token = os.urandom(16).hex()  # the ranks of THIS launch (griduniverse_amd/rendezvous.py turns away anyone else)
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
-    out = procs[0].communicate()[0].decode('utf-8', 'replace')
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out)
-    sys.stdout.flush()
-    worst = next((c for c in codes if c != 0), 0)
+
+    def kill_all(sig=signal.SIGTERM):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(signum, _frame):
+        kill_all(signal.SIGTERM)
+        time.sleep(0.5)
+        kill_all(signal.SIGKILL)
+        sys.exit(128 + signum)
+
+    previous = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
+    out = []
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GU_RDZV_JOIN_TIMEOUT=os.environ.get('GU_RDZV_JOIN_TIMEOUT', '120'), GU_RDZV_TOKEN=token)
+            procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, start_new_session=True,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+        reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        failed = None
+        while any(p.poll() is None for p in procs):
+            failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)), None)
+            if failed is not None:
+                sys.stderr.write('bench.py: rank %d exited with code %d: stopping the other ranks\n' % failed)
+                kill_all(signal.SIGTERM)
+                deadline = time.time() + 5
+                while time.time() < deadline and any(p.poll() is None for p in procs):
+                    time.sleep(0.05)
+                kill_all(signal.SIGKILL)
+                break
+            time.sleep(0.05)
+        codes = [p.wait() for p in procs]
+        reader.join(timeout=5)
+    finally:
+        kill_all(signal.SIGKILL)
+        for sig, handler in previous.items():
+            signal.signal(sig, handler)
+    if out and failed is None:
+        sys.stdout.write(out[0].decode('utf-8', 'replace'))
+        sys.stdout.flush()
+    worst = failed[1] if failed is not None else next((c for c in codes if c != 0), 0)
     if worst:
         sys.stderr.write('bench.py: rank exit codes %r\n' % (codes,))
     return worst
@@ -718,7 +954,7 @@ def run_single_process(args, engine_cls=None, emit=print):
     through ncclCommInitAll + one grouped ncclAllGather (gu_comm_init_all / gu_allgather_view_all).  Timed like the
     multi-process form: blocks of exactly K launches PER DEVICE between device syncs of all devices; `value` = all devices'
     env-steps / median block wall time; per_rank = every device's own HIP-event time."""
-    engine_cls = engine_cls or load_engine_class(args)
+    engine_cls = engine_cls or gua.Engine
     ensure_library_is_current(engine_cls)
     G, N, T, K, W = args.gpus, args.envs, args.T, args.steps, args.warmup
     seed = WORKLOAD_SEED[args.workload]
@@ -875,7 +1111,7 @@ def run_single_process(args, engine_cls=None, emit=print):
                    'launch_ms_min': k_min / K, 'launch_ms_median': k_med / K, 'launch_ms_max': k_max / K,
                    'launch_ms_is': 'HIP-event time of a block / K on the slowest device, per block', 'launches_total': launches * G},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                     'traffic': None if traffic is None else traffic.get('hbm_bytes_per_launch'), 'traffic_measured_in_this_run': False,
+                     'traffic': None if traffic is None else traffic.get('hbm_bytes_per_launch'), 'traffic_measured_by_child_runs': False,
                      'kernel': 'gu_rollout_kernel<UNIFORM,TRAJ,LDS>', 'launch_ms': launch_s * 1e3,
                      'algorithmic_bytes_per_launch': BYTES_PER_ENV_STEP * N * T,
                      'traffic_source': None if traffic is None else traffic.get('source'),
@@ -899,9 +1135,9 @@ def run_single_process(args, engine_cls=None, emit=print):
 
 # --------------------------------------------------------------------------------------- the run
 def run(args, engine_cls=None, emit=print):
-    """`engine_cls` exists for the 2-rank CPU test (tests/_oracle_engine.py stands in for the device); the command line
-    always measures griduniverse_amd.Engine, and the JSON line names the class that ran."""
-    engine_cls = engine_cls or load_engine_class(args)
+    """`engine_cls` exists for the CPU tests (tests/_bench_stub.py passes tests/_oracle_engine.py, which stands in for the
+    device); this script's own command line can only measure griduniverse_amd.Engine, and the JSON line names the class that ran."""
+    engine_cls = engine_cls or gua.Engine
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -977,6 +1213,9 @@ def run(args, engine_cls=None, emit=print):
     pacing = pacing_block(eng)
     eng.close()
     c4 = None if args.no_strong_c4 else strong_c4(args, ranks, engine_cls, device)
+    configs = None
+    if world == 1 and not args.no_configs:
+        configs = baseline_configs(engine_cls, device, K, not args.no_checks)
 
     if rank == 0:
         w_min, w_med, w_max = spread(wall)
@@ -1013,8 +1252,11 @@ def run(args, engine_cls=None, emit=print):
                        'launches_total': launches},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS,
+                         'frac_wall': BYTES_PER_ENV_STEP * N * T / (w_med / K) / 1e9 / HBM_PEAK_GBPS,
+                         'frac_is': 'frac: algorithmic bytes / the kernels\' own HIP-event time per launch; frac_wall: / ms_per_step, the wall '
+                                    'time the driver\'s clock sees (barriers and launch overhead included)',
                          'traffic': measured['hbm_bytes_per_launch'] if measured else None if traffic is None else traffic.get('hbm_bytes_per_launch'),
-                         'traffic_measured_in_this_run': bool(measured),
+                         'traffic_measured_by_child_runs': bool(measured),
                          'traffic_over_algorithmic': (measured['hbm_bytes_per_launch'] if measured else (traffic or {}).get('hbm_bytes_per_launch', 0.0))
                          / float(BYTES_PER_ENV_STEP * N * T) or None,
                          'kernel': 'gu_rollout_kernel<UNIFORM,TRAJ,LDS>', 'launch_ms': launch_s * 1e3,
@@ -1031,7 +1273,8 @@ def run(args, engine_cls=None, emit=print):
             'per_rank': {'ms_per_step': [v[0] / K * 1e3 for v in per_rank],
                          'value': [float(N) * T * K / v[0] for v in per_rank],
                          'is': 'every rank\'s own median block (the N = 1 run of this script reports exactly this figure as `value`)'},
-            'rccl': rccl, 'strong_c4': c4, 'other_modes': others,
+            'rccl': rccl, 'strong_c4': c4, 'other_modes': others, 'configs': configs,
+            'topology': topology_block(engine_cls),
         }
         line.update(checks)
         if want_cpu:
@@ -1057,6 +1300,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-checks', action='store_true', help='skip the reference-digest / oracle checks of this run')
     ap.add_argument('--no-strong-c4', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip BASELINE configs 2, 4 (one shard) and 5 reported beside `value` (1 GPU only)')
     ap.add_argument('--no-other-modes', action='store_true', help='skip the statistics-only / packed-row launches reported beside `value`')
     ap.add_argument('--gather-view', action='store_true', help='exercise the RCCL gathered view with one rank too')
     ap.add_argument('--single-process', action='store_true',
@@ -1064,22 +1308,23 @@ def parse_args(argv=None):
     ap.add_argument('--no-live-traffic', action='store_true',
                     help='do not measure roofline.traffic with two short rocprofv3 --pmc child runs (1 GPU only); use the committed profile')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--engine', default=None, help='module:Class of the engine to run (tests only; default griduniverse_amd.Engine)')
     return ap.parse_args(argv)
 
 
-def main(argv=None):
+def main(argv=None, engine_cls=None, script=None):
+    """`engine_cls` / `script`: the CPU tests' entry (tests/_bench_stub.py) runs this very flow on the oracle-backed stub engine;
+    `script` is what a plain --gpus N start re-launches as its ranks."""
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
     if args.pmc_child:
         pmc_child(args)
         return 0
     if args.single_process:
-        run_single_process(args)
+        run_single_process(args, engine_cls)
         return 0
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        return spawn_ranks(args, argv)  # (before any HIP call and before libgu.so is loaded)
-    run(args)
+        return spawn_ranks(args, argv, engine_cls, script)  # (before any HIP call and before libgu.so is loaded)
+    run(args, engine_cls)
     return 0
 
 

@@ -19,7 +19,18 @@ import socket
 import struct
 import time
 
-_MAGIC = b'GURDZV1\0'
+_MAGIC = b'GURDZV2\0'
+
+
+def _token():
+    """16 bytes every rank of ONE launch shares (GU_RDZV_TOKEN, hex, set by whoever starts the ranks: bench.py's launcher does);
+    zeros when the launcher set none.  Rank 0 turns away a hello with another token: a stray or hostile local process that
+    finds the socket cannot take a rank's place."""
+    try:
+        raw = bytes.fromhex(os.environ.get('GU_RDZV_TOKEN', ''))
+    except ValueError:
+        raw = b''
+    return (raw + bytes(16))[:16]
 
 
 def _recv_exact(sock, n):
@@ -54,34 +65,46 @@ def _address():
 class Rendezvous(object):
     """rank / world from the arguments or the torchrun-style environment; a no-op for one process."""
 
-    def __init__(self, rank=None, world=None, timeout=600.0):
+    def __init__(self, rank=None, world=None, timeout=600.0, join_timeout=None):
+        """`join_timeout`: how long to wait for every rank to JOIN (default: `timeout`); a launcher that starts and watches its
+        ranks itself passes something short, so that a rank that never came up is an error within a minute or two."""
         self.rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
         self.world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else int(world)
         self.peers, self.sock, self.listener = [], None, None
         if self.world <= 1:
             return
         family, address = _address()
-        deadline = time.time() + timeout
+        join_timeout = timeout if join_timeout is None else float(join_timeout)
+        deadline = time.time() + join_timeout
         if self.rank == 0:
             self.listener = socket.socket(family, socket.SOCK_STREAM)
             if family == socket.AF_INET:
                 self.listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             self.listener.bind(address)
             self.listener.listen(self.world)
-            self.listener.settimeout(timeout)
             slots = [None] * self.world
             while sum(s is not None for s in slots[1:]) < self.world - 1:
-                conn, _ = self.listener.accept()
-                conn.settimeout(timeout)
+                self.listener.settimeout(max(0.05, deadline - time.time()))
                 try:
-                    hello = _recv_exact(conn, len(_MAGIC) + 8)
+                    conn, _ = self.listener.accept()
+                except socket.timeout:
+                    raise TimeoutError('rendezvous: %d of %d ranks joined within %.0f s' % (1 + sum(s is not None for s in slots[1:]), self.world, join_timeout))
+                if family == socket.AF_UNIX and hasattr(socket, 'SO_PEERCRED'):  # only this user's processes may claim a rank
+                    cred = conn.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize('3i'))
+                    if struct.unpack('3i', cred)[1] != os.getuid():
+                        conn.close()
+                        continue
+                conn.settimeout(5.0)  # the hello is 16 bytes sent right after connect: a silent peer must not stall the others
+                try:
+                    hello = _recv_exact(conn, len(_MAGIC) + 8 + 16)
                 except (ConnectionError, OSError):
                     conn.close()  # a caller that gave up (or something else that found the socket)
                     continue
-                peer, peer_world = struct.unpack('<II', hello[len(_MAGIC):])
-                if hello[:len(_MAGIC)] != _MAGIC or peer_world != self.world or not 0 < peer < self.world or slots[peer] is not None:
+                peer, peer_world = struct.unpack('<II', hello[len(_MAGIC):len(_MAGIC) + 8])
+                if hello[:len(_MAGIC)] != _MAGIC or hello[len(_MAGIC) + 8:] != _token() or peer_world != self.world or not 0 < peer < self.world or slots[peer] is not None:
                     conn.close()  # not one of ours (or a leftover of another run): ignore it
                     continue
+                conn.settimeout(timeout)
                 self._tune(conn, family)
                 slots[peer] = conn
             self.peers = slots
@@ -96,7 +119,7 @@ class Rendezvous(object):
                     s.connect(address)
                     s.settimeout(max(1.0, deadline - time.time()))
                     self._tune(s, family)
-                    s.sendall(_MAGIC + struct.pack('<II', self.rank, self.world))
+                    s.sendall(_MAGIC + struct.pack('<II', self.rank, self.world) + _token())
                     if _recv_exact(s, len(_MAGIC)) != _MAGIC:
                         raise ConnectionError('unexpected answer')
                     break

@@ -35,7 +35,7 @@ def test_default_workload_line_carries_the_contract_and_its_own_checks():
     roof = line['roofline']
     assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
     # HBM traffic measured for THIS run: two short rocprofv3 --pmc child runs of the script (WRITE_SIZE, FETCH_SIZE) after the timed region
-    assert roof['traffic_measured_in_this_run'] is True and roof['traffic_live']['dispatches_counted'] >= 4
+    assert roof['traffic_measured_by_child_runs'] is True and roof['traffic_live']['dispatches_counted'] >= 4
     assert 0.98 < roof['traffic'] / roof['algorithmic_bytes_per_launch'] < 1.03 and abs(roof['traffic_over_algorithmic'] - roof['traffic'] / roof['algorithmic_bytes_per_launch']) < 1e-12
     assert roof['algorithmic_bytes_per_launch'] == 12 * 65536 * 1000
     assert abs(roof['achieved'] - roof['algorithmic_bytes_per_launch'] / (roof['launch_ms'] / 1e3) / 1e9) < 1e-6 * roof['achieved']
@@ -52,15 +52,29 @@ def test_default_workload_line_carries_the_contract_and_its_own_checks():
     other = line['other_modes']
     assert other['stats_only']['returns_vs_oracle'] is True and other['stats_only']['value'] > line['value']
     assert other['packed_rows']['bytes_per_env_step'] == 4
+    assert other['rollout_sample_policy_traj']['bytes_per_env_step'] == 12 and 0.3 < other['rollout_sample_policy_traj']['frac_of_hbm_peak'] < 1.0
+    # frac_wall: the same bytes over the wall time per launch the driver's clock sees
+    assert abs(roof['frac_wall'] - 12 * 65536 * 1000 / (line['ms_per_step'] / 1e3) / 1e9 / 8000.0) < 1e-9 and roof['frac_wall'] <= roof['frac'] * 1.02
+    # every other BASELINE config beside the headline, each with its own parity bit
+    cfg = line['configs']
+    assert set(cfg) == {'c2', 'c4_shard', 'c5'}
+    for name in cfg:
+        assert cfg[name]['bit_exact'] is True and cfg[name]['env_steps_per_s'] > 1e9 and cfg[name]['bound'] and cfg[name]['floor_us'], name
+    assert cfg['c2']['workload'].startswith('c2: 4096 envs') and cfg['c4_shard']['workload'].startswith('c4, shard 1 of 8: 32768 envs')
+    assert cfg['c5']['form'].startswith('one launch synchronised per XCD') and cfg['c5']['us_per_round'] < 3.0
+    for name in ('c2', 'c4_shard'):
+        assert cfg[name]['hbm_gbps'] < 8000.0
+    topo = line['topology']
+    assert topo['hip_device_count'] >= 1 and topo['devices'][0]['pci'] and topo['rccl_library']
 
 
 def test_other_workloads_and_switches():
     """Config 2 (4096 envs, 8x8) with the checks, and a run with everything optional switched off."""
     line = run_bench('--workload', 'c2', '--envs', '4096', '--steps', '3', '--warmup', '1', '--min-seconds', '0.02', '--no-strong-c4',
                      '--no-cpu-baseline', '--no-live-traffic')
-    assert line['roofline']['traffic_measured_in_this_run'] is False  # (the committed profile's figure, labelled as such)
+    assert line['roofline']['traffic_measured_by_child_runs'] is False  # (the committed profile's figure, labelled as such)
     assert line['config']['envs_per_gpu'] == 4096 and line['bit_exact_vs_reference_digest'] is True  # 4096 x 1000 is a captured run
     assert line['final_state_vs_oracle']['equal'] is True and 'cpu_baseline' not in line and line['strong_c4'] is None
     line = run_bench('--steps', '2', '--warmup', '1', '--min-seconds', '0.02', '--no-strong-c4', '--no-cpu-baseline', '--no-checks',
-                     '--no-other-modes', '--envs', '1000', '--T', '77', '--no-live-traffic')
-    assert line['other_modes'] is None and 'bit_exact_vs_reference_digest' not in line and line['value'] > 0
+                     '--no-other-modes', '--envs', '1000', '--T', '77', '--no-live-traffic', '--no-configs')
+    assert line['other_modes'] is None and line['configs'] is None and 'bit_exact_vs_reference_digest' not in line and line['value'] > 0

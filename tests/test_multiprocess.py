@@ -56,7 +56,7 @@ def test_two_rank_shards_and_gathered_view_under_torch_distributed_run(tmp_path)
     assert line['rccl']['nranks'] == 2 and line['rccl']['view_equals_shards'] is True and line['rccl']['view_envs'] == 1024
     c4 = line['strong_c4']
     assert c4['scaling'] == 'strong' and c4['total_envs'] == 2048 and c4['envs_per_gpu'] == 1024 and c4['shards_equal_oracle'] is True
-    assert len(line['per_rank']['value']) == 2 and line['roofline']['traffic_measured_in_this_run'] is False
+    assert len(line['per_rank']['value']) == 2 and line['roofline']['traffic_measured_by_child_runs'] is False
     assert 'device' in line and 'trajectory_placement' in line['roofline']
     assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
     assert line['bit_exact_vs_reference_digest'] is None  # 512 envs x 40 steps is not the captured run
@@ -64,7 +64,8 @@ def test_two_rank_shards_and_gathered_view_under_torch_distributed_run(tmp_path)
     assert other['returns_vs_oracle'] is True and other['value'] > 0 and 'packed_rows' not in line['other_modes']  # (the stub has no packed rows)
 
 
-STUB = ['--engine', 'tests._oracle_engine:OracleEngine', '--envs', '512', '--T', '40', '--steps', '2', '--warmup', '1',
+BENCH_ON_STUB = os.path.join(ROOT, 'tests', '_bench_stub.py')  # bench.main(..., engine_cls=OracleEngine)
+STUB = ['--envs', '512', '--T', '40', '--steps', '2', '--warmup', '1',
         '--min-seconds', '0.02', '--c4-envs', '2048']
 
 
@@ -85,7 +86,7 @@ def _scrubbed_env():
 def test_bench_started_plainly_with_gpus_2_spawns_its_ranks_and_prints_one_line():
     """`python bench.py --gpus 2` without torch.distributed.run (the way the driver starts --gpus 1): the script launches its two
     ranks itself and relays rank 0's line."""
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + STUB, env=_scrubbed_env(), cwd=ROOT,
+    proc = subprocess.run([sys.executable, BENCH_ON_STUB, '--gpus', '2'] + STUB, env=_scrubbed_env(), cwd=ROOT,
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     line = _one_json_line(proc)
     assert line['n_gpus'] == 2 and len(line['per_rank']['value']) == 2 and line['engine'] == 'tests._oracle_engine.OracleEngine'
@@ -98,7 +99,7 @@ def test_bench_started_plainly_with_gpus_2_spawns_its_ranks_and_prints_one_line(
 def test_bench_single_process_form_drives_two_engines_and_prints_one_line():
     """--single-process: one host process, one engine per device, launches enqueued device after device, the view through the
     comm_init_all form."""
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--single-process'] + STUB, env=_scrubbed_env(),
+    proc = subprocess.run([sys.executable, BENCH_ON_STUB, '--gpus', '2', '--single-process'] + STUB, env=_scrubbed_env(),
                           cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     line = _one_json_line(proc)
     assert line['n_gpus'] == 2 and line['mode'] == 'single-process' and len(line['per_rank']['value']) == 2
@@ -179,3 +180,44 @@ print("after")
     assert proc.stdout.decode().split() == ['before', 'after']
     err = proc.stderr.decode()
     assert 'native chatter' in err and 'python chatter inside' in err
+
+
+def test_bench_cannot_be_pointed_at_another_engine_from_its_command_line():
+    """The script that produces the contract number has no switch that swaps the thing measured: `--engine` is gone; the CPU
+    tests reach the stub engine through tests/_bench_stub.py -> bench.main(argv, engine_cls=...)."""
+    import bench
+    with pytest.raises(SystemExit):
+        bench.parse_args(['--engine', 'tests._oracle_engine:OracleEngine'])
+    assert 'engine' not in vars(bench.parse_args([]))
+    assert 'import_module' not in open(os.path.join(ROOT, 'bench.py')).read()
+
+
+@pytest.mark.parametrize('form', ['ranks', 'single-process'])
+def test_eight_gpu_preflight_on_the_stub_engine(form):
+    """The driver's 8-GPU run, rehearsed without an 8-GPU node: `--gpus 8` started plainly (eight rank processes over the socket
+    rendezvous) and with --single-process, config 4 at its full 262 144 envs = 32 768 per rank."""
+    extra = ['--single-process'] if form == 'single-process' else []
+    proc = subprocess.run([sys.executable, BENCH_ON_STUB, '--gpus', '8'] + extra + ['--envs', '256', '--T', '24', '--steps', '2', '--warmup', '1',
+                                                                                    '--min-seconds', '0.02', '--c4-envs', '262144'],
+                          env=_scrubbed_env(), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    line = _one_json_line(proc)
+    assert line['n_gpus'] == 8 and len(line['per_rank']['value']) == 8 and len(line['per_rank']['ms_per_step']) == 8
+    assert line['config']['global_envs'] == 8 * 256 and line['scaling'] == 'weak'
+    assert line['strong_c4']['envs_per_gpu'] == 32768 and line['strong_c4']['total_envs'] == 262144 and line['strong_c4']['n_gpus'] == 8
+    assert line['strong_c4']['shards_equal_oracle'] is True
+    assert line['rccl']['nranks'] == 8 and line['rccl']['view_equals_shards'] is True and line['rccl']['view_envs'] == 8 * 256
+    assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
+    if form == 'ranks':
+        assert line['topology']['rccl_library'] is None or line['topology']['rccl_library'].endswith('.so') or '.so.' in line['topology']['rccl_library']
+
+
+def test_a_rank_that_dies_takes_the_launch_down_at_once():
+    """spawn_ranks watches EVERY child: rank 1 exiting with an error before it joins the rendezvous must end the launch within
+    seconds with that exit code -- not leave rank 0 waiting in accept() for the rendezvous timeout with its GPU held."""
+    import time
+    env = dict(_scrubbed_env(), GU_TEST_DIE_RANK='1')
+    t0 = time.time()
+    proc = subprocess.run([sys.executable, BENCH_ON_STUB, '--gpus', '2'] + STUB, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=120)
+    assert proc.returncode == 3 and time.time() - t0 < 60, (proc.returncode, time.time() - t0)
+    assert proc.stdout.strip() == b'' and b'rank 1 exited with code 3' in proc.stderr

@@ -747,9 +747,13 @@ def pacing_block(eng):
     if not hasattr(eng, 'rollout_pacing'):
         return None
     info = eng.rollout_pacing('uniform', True)
+    totals = eng.rollout_pacing_totals() if hasattr(eng, 'rollout_pacing_totals') else None
     if info is None:
-        return {'calibrated': False}
+        return {'calibrated': False, 'totals': totals}
     info['calibrated'] = True
+    info['requested'] = 'bench.py asks for the search before its warm-up launches (gu_rollout_calibrate); an engine left to itself runs without a ' \
+                        'limiter until it has issued 1024 launches of a kind, or takes over a period this process found earlier after a six-launch check'
+    info['totals'] = totals
     info['is'] = 'the HBM write path collapses when it is over-driven (5.7 TB/s on most allocations): every wave keeps a schedule -- its ' \
                  'next 16 steps begin no earlier than `period` ticks of 10 ns after the last ones were due, late waves do not wait --, a ' \
                  'period found by timing the kernel itself on this engine and buffer (state snapshot and put back); ms_unpaced / ' \
@@ -841,6 +845,7 @@ def strong_c4(args, ranks, engine_cls, device):
         ref = reference_digest('c4', template, seed, n, T_check, rank * n) if world == 1 else None
         ref_ok = None if ref is None else sha256_triplet(got) == ref
         del got
+        getattr(eng, 'calibrate_rollout', eng.rollout)(args.T, 'uniform', auto_reset=True, trajectory=True)  # (the pacing search, up front)
         for _ in range(args.warmup):
             eng.rollout(args.T, 'uniform', auto_reset=True, trajectory=True)
         wall, kern, _, _ = timed_region(eng, ranks, args.T, args.steps, args.min_seconds / 2)
@@ -986,7 +991,8 @@ def run_single_process(args, engine_cls=None, emit=print):
             e.reset()
             e.reserve_trajectory(T)
         launches = 1
-        launch_all()
+        for e in engines:  # (the store-pacing search up front, see run(); the launch itself is the first one from reset)
+            getattr(e, 'calibrate_rollout', e.rollout)(T, 'uniform', auto_reset=True, trajectory=True)
         checks = {}
         if not args.no_checks:
             first = engines[0].read_trajectory(0, T)
@@ -1158,9 +1164,12 @@ def run(args, engine_cls=None, emit=print):
     eng.reset()
     eng.reserve_trajectory(T)
 
-    # ---- launch 1, from reset: checked in full
+    # ---- launch 1, from reset: checked in full.  (A benchmark issues thousands of launches: it asks for the store-pacing search
+    # up front -- by default an engine runs without a limiter until it has issued 1024 launches of a kind; the search works on a
+    # snapshot of the state and puts it back, so this IS the first launch from reset, whatever the search found.)
     launches = 1
-    eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
+    first_launch = getattr(eng, 'calibrate_rollout', eng.rollout)
+    first_launch(T, 'uniform', auto_reset=True, trajectory=True)
     eng.sync()
     checks = {}
     if rank == 0 and not args.no_checks:

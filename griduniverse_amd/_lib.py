@@ -66,6 +66,8 @@ SIGNATURES = {
     'gu_probe_trajectory': [_vp, _c.POINTER(_c.c_float)],
     'gu_rollout': [_vp, _i64, _i32, _u32],
     'gu_rollout_pacing': [_vp, _i32, _u32, _vp, _vp, _vp, _vp, _vp],
+    'gu_rollout_calibrate': [_vp, _i64, _i32, _u32],
+    'gu_rollout_pacing_totals': [_vp, _vp, _vp, _vp, _vp, _vp],
     'gu_read_trajectory': [_vp, _i64, _i64, _vp, _vp, _vp],
     'gu_read_trajectory_packed': [_vp, _i64, _i64, _vp],
     'gu_read_stats': [_vp, _vp, _vp],

@@ -912,6 +912,36 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
     return rc;
 }
 
+int gu_rollout_calibrate(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
+{
+    if (!h) return gu_fail(GU_ERR_INVALID, "null handle");
+    h->pace_requested = true;  // (read by gu_pace_for: search now instead of waiting for the launch count)
+    const int rc = gu_rollout(h, T, policy_kind, flags);
+    h->pace_requested = false;
+    return rc;
+}
+
+int gu_rollout_pacing_totals(gu_handle h, float *calibration_ms, int32_t *launches_spent, int32_t *kinds_paced, int32_t *kinds_from_cache,
+                             int32_t *kinds_waiting)
+{
+    GU_ENTER(h);
+    float ms = 0.0f;
+    int32_t spent = 0, paced = 0, cached = 0, waiting = 0;
+    for (const gu_engine::PaceRecord &r : h->pace) {
+        ms += r.calibration_ms;
+        spent += r.launches_spent;
+        paced += r.known ? 1 : 0;
+        cached += (r.known && r.from_cache) ? 1 : 0;
+        waiting += (!r.known && r.launches_seen > 0) ? 1 : 0;
+    }
+    if (calibration_ms) *calibration_ms = ms;
+    if (launches_spent) *launches_spent = spent;
+    if (kinds_paced) *kinds_paced = paced;
+    if (kinds_from_cache) *kinds_from_cache = cached;
+    if (kinds_waiting) *kinds_waiting = waiting;
+    return GU_OK;
+}
+
 int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
                       int32_t *evaluated, float *calibration_ms)
 {

@@ -105,10 +105,16 @@ struct gu_engine {
         const void *buffer = nullptr;  // the trajectory buffer the calibration ran on
         int64_t T = 0;                 // ... and the launch length
         uint32_t period = 0;           // the waves' schedule: 10 ns ticks per 16 steps (0: no limiter)
-        float ms_unpaced = 0.0f, ms_paced = 0.0f, calibration_ms = 0.0f;
+        float ms_unpaced = 0.0f, ms_paced = 0.0f, calibration_ms = 0.0f;  // calibration_ms: summed over everything this slot ever spent
         int32_t evaluated = 0;         // candidates timed
+        unsigned blocks = 0;           // workgroups of the launch the record belongs to
+        int32_t launches_seen = 0;     // launches of this kind issued without a limiter, waiting for the search to be worth it
+        int32_t launches_spent = 0;    // full-size launches the calibration (search or check) issued, summed
+        bool cache_checked = false;    // the process-wide cache has been consulted for this launch shape
+        bool from_cache = false;       // the period is an earlier engine's, checked here
     } pace[36];  // [policy * 3 + auto mode] for the general kernel, + 12 for the transition-row kernel's int32 rows, + 24 for its packed rows
     hipEvent_t ev_cal[2] = {nullptr, nullptr};
+    bool pace_requested = false;   // inside gu_rollout_calibrate: search now
 
     // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in
     uint32_t *d_rows[2] = {nullptr, nullptr};

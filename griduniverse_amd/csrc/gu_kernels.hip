@@ -28,6 +28,9 @@
 
 #include <algorithm>
 #include <functional>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 // ------------------------------------------------------------------------------------
@@ -374,7 +377,33 @@ static void gu_rollout_general(gu_engine *h, const RolloutArgs &a, int32_t polic
 #ifndef GU_PACE_MARGIN
 #define GU_PACE_MARGIN 1.01  /* the kept period over the first one that recovered and held */
 #endif
-static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::function<void(uint32_t)> &launch, gu_engine::PaceRecord *rec)
+// What a calibration cost this process, by launch shape: a later engine of the same shape on the same device does not search again,
+// it CHECKS the period found then with six launches (three without the limiter, three with it) and keeps it when it still wins.
+struct GuPaceKey {
+    int device, slot, row_bytes;
+    int64_t N, T_class;
+    unsigned blocks;
+    bool operator<(const GuPaceKey &o) const
+    {
+        return std::tie(device, slot, row_bytes, N, T_class, blocks) < std::tie(o.device, o.slot, o.row_bytes, o.N, o.T_class, o.blocks);
+    }
+};
+struct GuPaceCached {
+    uint32_t period;
+    float ms_unpaced, ms_paced;
+};
+static std::mutex g_pace_mutex;
+static std::map<GuPaceKey, GuPaceCached> g_pace_cache;
+static int64_t gu_pace_T_class(int64_t T)
+{
+    int64_t c = 0;
+    while ((T >> c) > 1) ++c;
+    return c;  // launches within a factor of two of each other share a period (the schedule is per 16 steps)
+}
+
+// `hint`: a period this process found earlier for the same launch shape -- validate it instead of searching.
+static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::function<void(uint32_t)> &launch, gu_engine::PaceRecord *rec,
+                             const GuPaceCached *hint = nullptr)
 {
     const auto t_start = std::chrono::steady_clock::now();
     const size_t n4 = (size_t)h->N * 4, bits = (((size_t)h->N + 63) / 64) * 8;
@@ -386,9 +415,65 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
     size_t off = 0;
     for (int k = 0; k < 3; off += size[k], ++k)
         if ((rc = gu_device_copy(h, snap + off, live[k], size[k])) != GU_OK) return rc;
+    // whatever happens below -- a HIP error in the middle of the search included -- the engine's state goes back to the snapshot
+    struct Restore {
+        gu_engine *h;
+        char *snap;
+        void **live;
+        const size_t *size;
+        bool armed = true;
+        int run()
+        {
+            armed = false;
+            size_t o = 0;
+            for (int k = 0; k < 3; o += size[k], ++k) {
+                const int r = gu_device_copy(h, live[k], snap + o, size[k]);
+                if (r != GU_OK) return r;
+            }
+            return hipStreamSynchronize(h->stream) == hipSuccess ? GU_OK : GU_ERR_HIP;
+        }
+        ~Restore()
+        {
+            if (armed) (void)run();
+        }
+    } restore{h, snap, live, size};
     for (hipEvent_t &ev : h->ev_cal)
         if (!ev) GU_HIP(hipEventCreate(&ev));
-    int evaluated = 0;
+    int evaluated = 0, launches = 0;
+    if (hint) {  // six launches: does the period found earlier still beat no limiter on THIS engine's buffer?
+        auto timed = [&](uint32_t period, float *ms) -> int {
+            launch(period);
+            GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
+            launch(period);
+            launch(period);
+            GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
+            GU_HIP(hipEventSynchronize(h->ev_cal[1]));
+            GU_HIP(hipGetLastError());
+            GU_HIP(hipEventElapsedTime(ms, h->ev_cal[0], h->ev_cal[1]));
+            *ms /= 2.0f;
+            launches += 3;
+            return GU_OK;
+        };
+        float without = 0.0f, with = 0.0f;
+        if ((rc = timed(0u, &without)) != GU_OK) return rc;
+        if ((rc = timed(hint->period, &with)) != GU_OK) return rc;
+        if ((rc = restore.run()) != GU_OK) return rc;
+        const bool keep = hint->period == 0u ? true : with <= 0.995f * without;
+        rec->known = keep;
+        rec->from_cache = keep;
+        rec->buffer = h->d_traj;
+        rec->T = T;
+        rec->period = keep ? hint->period : 0u;
+        rec->ms_unpaced = without;
+        rec->ms_paced = keep && hint->period ? with : without;
+        rec->evaluated = 2;
+        rec->launches_spent += launches;
+        rec->calibration_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        if (gu_debug())
+            fprintf(stderr, "[gu] store pacing: period %u of an earlier engine of this shape %s (%.4f ms without, %.4f with; %d launches)\n", hint->period,
+                    keep ? "kept" : "REJECTED here: a search follows when the launch count warrants it", without, with, launches);
+        return GU_OK;
+    }
     // The device must be at its working clocks first.  A calibration right after start-up, on a GPU still ramping up from idle,
     // sees a slower kernel and a different cliff (profiles/r03f_pace_warmup.txt).  The ramp is gradual -- successive launches agree
     // within 1 % all along it -- so: unpaced launches until the mean of the last 16 agrees with the mean of the 16 before within
@@ -401,6 +486,7 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
             GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
             launch(0u);
             launch(0u);
+            launches += 2;
             GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
             GU_HIP(hipEventSynchronize(h->ev_cal[1]));
             float ms = 0.0f;
@@ -430,6 +516,7 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
         GU_HIP(hipEventElapsedTime(ms, h->ev_cal[0], h->ev_cal[1]));
         *ms /= (float)reps;
         ++evaluated;
+        launches += collapse + settle + reps;
         return GU_OK;
     };
     float unpaced = 0.0f, t = 0.0f;
@@ -479,18 +566,17 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
         unpaced = std::min(unpaced, t);
         if (unpaced <= 1.01f * pick_ms) pick = 0, pick_ms = unpaced;
     }
-    off = 0;
-    for (int k = 0; k < 3; off += size[k], ++k)
-        if ((rc = gu_device_copy(h, live[k], snap + off, size[k])) != GU_OK) return rc;
-    GU_HIP(hipStreamSynchronize(h->stream));
+    if ((rc = restore.run()) != GU_OK) return rc;
     rec->known = true;
+    rec->from_cache = false;
     rec->buffer = h->d_traj;
     rec->T = T;
     rec->period = pick;
     rec->ms_unpaced = unpaced;
     rec->ms_paced = pick_ms;
     rec->evaluated = evaluated;
-    rec->calibration_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    rec->launches_spent += launches;
+    rec->calibration_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     if (gu_debug())
         fprintf(stderr, "[gu] store pacing (%s kernel, policy %d, auto %d, %lld x %lld): %u ticks of 10 ns per 16 steps, %.4f -> %.4f ms per launch, %d candidates in %.1f ms\n",
                 slot >= 24 ? "row-table (packed rows)" : slot >= 12 ? "row-table" : "general", (slot % 12) / 3, slot % 3, (long long)h->N, (long long)T, pick, unpaced, pick_ms, evaluated,
@@ -507,6 +593,17 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
 // (Until r03o a batch of more than one wave per SIMD was also tried as several launches in a row of one wave per SIMD each: the
 // idle-turn limiter had nothing to work with at four waves per SIMD.  The schedule has -- 262 144 envs in ONE launch 0.44 .. 0.48 ms,
 // as four launches in a row 0.56 .. 0.59, profiles/r03o_c4_split.txt -- and that form is gone.)
+// WHEN it is calibrated (round 4).  The search costs ~100 full-size launches and saves ~10 % of each later one: it pays for itself
+// only after a few thousand launches of that kind.  So, with GU_OPT_ROLLOUT_PACE at its default (-1):
+//   * a period this PROCESS already found for the same launch shape (device, batch, length class, policy, auto-reset, kernel, row bytes,
+//     workgroups) is checked with six launches and kept when it still beats no limiter;
+//   * otherwise the launch kind runs WITHOUT a limiter until the engine has issued GU_PACE_LAZY_LAUNCHES launches of it, and is
+//     searched then;
+//   * gu_rollout_calibrate asks for the search now (a benchmark, a long-running service at start-up); GU_OPT_ROLLOUT_PACE = -2 makes
+//     the first launch of every kind do so (the behaviour of round 3).
+#ifndef GU_PACE_LAZY_LAUNCHES
+#define GU_PACE_LAZY_LAUNCHES 1024
+#endif
 int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, const std::function<void(uint32_t)> &launch, uint32_t *pace)
 {
     *pace = 0;
@@ -520,9 +617,41 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_byte
     // device at once is not on one schedule anyway; profiles/r03n_batch_sizes.txt)
     if ((double)h->N * (double)T * (double)row_bytes < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024) return GU_OK;
     gu_engine::PaceRecord &rec = h->pace[slot];
-    if (!rec.known || rec.buffer != (const void *)h->d_traj || T > 2 * rec.T || 2 * T < rec.T) {
-        const int rc = gu_calibrate_pace(h, slot, T, launch, &rec);
-        if (rc != GU_OK) return rc;
+    const bool current = rec.known && rec.buffer == (const void *)h->d_traj && rec.blocks == blocks && !(T > 2 * rec.T || 2 * T < rec.T);
+    if (!current) {
+        if (rec.buffer != (const void *)h->d_traj || rec.blocks != blocks || T > 2 * rec.T || 2 * T < rec.T) {  // another launch shape: start over
+            rec.known = false;
+            rec.cache_checked = false;
+            rec.launches_seen = 0;
+            rec.buffer = h->d_traj;
+            rec.blocks = blocks;
+            rec.T = T;
+        }
+        const GuPaceKey key{h->device, slot, row_bytes, h->N, gu_pace_T_class(T), blocks};
+        if (!rec.cache_checked) {
+            rec.cache_checked = true;
+            GuPaceCached cached{};
+            bool have = false;
+            {
+                std::lock_guard<std::mutex> lock(g_pace_mutex);
+                auto it = g_pace_cache.find(key);
+                if (it != g_pace_cache.end()) cached = it->second, have = true;
+            }
+            if (have) {
+                const int rc = gu_calibrate_pace(h, slot, T, launch, &rec, &cached);
+                if (rc != GU_OK) return rc;
+                rec.blocks = blocks;
+            }
+        }
+        if (!rec.known) {
+            const bool now = opt == -2 || h->pace_requested || ++rec.launches_seen > GU_PACE_LAZY_LAUNCHES;
+            if (!now) return GU_OK;  // no limiter yet
+            const int rc = gu_calibrate_pace(h, slot, T, launch, &rec);
+            if (rc != GU_OK) return rc;
+            rec.blocks = blocks;
+            std::lock_guard<std::mutex> lock(g_pace_mutex);
+            g_pace_cache[key] = GuPaceCached{rec.period, rec.ms_unpaced, rec.ms_paced};
+        }
     }
     *pace = rec.period;
     if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();

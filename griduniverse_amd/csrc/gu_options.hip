@@ -37,7 +37,7 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_TRAJ_STRIDE_MIB", 3072, 0, 1 << 20},
     {"GU_TRAJ_FAR_MIB", 49152, 0, 1 << 22},
     {"GU_TRAJ_PROBE_ALL", 0, 0, 1},
-    {"GU_ROLLOUT_PACE", -1, -1, 0xFFFFF},
+    {"GU_ROLLOUT_PACE", -1, -2, 0xFFFFF},
     {"GU_VI_XCD_BLOCK", 0, 0, 1024},
 };
 const char *g_spec_x[GU_OPT_X_COUNT] = {"GU_TRAJ_UNCACHED", "GU_TRAJ_POISON", "GU_MC_POISON"};
@@ -125,8 +125,13 @@ int gu_set_option(gu_handle h, int32_t option, int64_t value)
         if (option == GU_OPT_ROWS_COPIES) GU_REQUIRE((value & (value - 1)) == 0, GU_ERR_INVALID, "option %s: %lld is not a power of two", sp.name, (long long)value);
         if (option == GU_OPT_ROLLOUT_MULTI_K) GU_REQUIRE(value == 0 || value == 2 || value == 4, GU_ERR_INVALID, "option %s: K is 2 or 4", sp.name);
     }
-    if (h) h->opt[option] = value;
-    else g_default[option].store(value, std::memory_order_relaxed);
+    if (h) {
+        h->opt[option] = value;
+        // a launch-shape option may change which kernel a launch kind runs on: what the store pacing learned is looked at again
+        for (gu_engine::PaceRecord &r : h->pace) r.known = false, r.cache_checked = false, r.launches_seen = 0, r.buffer = nullptr;
+    } else {
+        g_default[option].store(value, std::memory_order_relaxed);
+    }
     return GU_OK;
 }
 

@@ -221,6 +221,21 @@ class Engine(object):
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | tflag | (_lib.F_STATS if stats else 0)
         check(self.lib.gu_rollout(self._h, int(T), _POLICIES[policy], flags))
 
+    def calibrate_rollout(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
+        """rollout(...) with the store-pacing search for this launch kind made NOW if the kind is paced and has no period yet
+        (include/gu.h: gu_rollout_calibrate).  By default the search waits until an engine has issued 1024 launches of a kind --
+        it costs ~100 launches and saves ~10 % of each later one; a benchmark or a long-running service calls this once."""
+        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_STATS if stats else 0)
+        flags |= _lib.F_PACKED if trajectory == 'packed' else (_lib.F_TRAJECTORY if trajectory else 0)
+        check(self.lib.gu_rollout_calibrate(self._h, int(T), _POLICIES[policy], flags))
+
+    def rollout_pacing_totals(self):
+        """Over all launch kinds of this engine: dict(calibration_ms, launches_spent, kinds_paced, kinds_from_cache, kinds_waiting)."""
+        ms = ctypes.c_float(0.0)
+        n = [ctypes.c_int32(0) for _ in range(4)]
+        check(self.lib.gu_rollout_pacing_totals(self._h, ctypes.byref(ms), *[ctypes.byref(x) for x in n]))
+        return dict(calibration_ms=ms.value, launches_spent=n[0].value, kinds_paced=n[1].value, kinds_from_cache=n[2].value, kinds_waiting=n[3].value)
+
     def rollout_pacing(self, policy='uniform', auto_reset=True, packed=False):
         """What the store-pacing calibration found for this launch kind on the current trajectory buffer (include/gu.h:
         gu_rollout_pacing): dict(period=the waves' schedule in 10 ns ticks per 16 steps (0: no limiter), ms_unpaced, ms_paced, evaluated,

@@ -103,7 +103,8 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_TRAJ_STRIDE_MIB 15     /* spacer size (3072)                                                                   */
 #define GU_OPT_TRAJ_FAR_MIB 16        /* most memory the search may hold at once (49152)                                      */
 #define GU_OPT_TRAJ_PROBE_ALL 17      /* 1 = probe every candidate, no early stop (measurement aid)                           */
-#define GU_OPT_ROLLOUT_PACE 18        /* store pacing of launches that write rows: 10 ns ticks per 16 steps; -1 = calibrate (default), 0 = none */
+#define GU_OPT_ROLLOUT_PACE 18        /* store pacing of launches that write rows: 10 ns ticks per 16 steps; -1 = calibrate when it pays
+                                         (default, see gu_rollout_pacing), -2 = at the first launch, 0 = none */
 #define GU_OPT_VI_XCD_BLOCK 19        /* workgroup size of the per-XCD form of gu_vi_sweep_step_run: 256, 512, 1024 (0 = by batch size) */
 #define GU_OPT_COUNT 20
 #define GU_OPT_X_TRAJ_UNCACHED 100    /* EXPERIMENT: uncached memory type for the trajectory (readers may see stale bytes)    */
@@ -240,13 +241,26 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 /* Store pacing.  The HBM write path shows congestion collapse: lanes that hand their rows to the memory system as fast as it will
  * take them are served at 5.7 TB/s on most allocations, the same stores offered just below the memory's capacity at 7.2 .. 7.5 on
  * every one.  Launches with GU_F_TRAJECTORY (and GU_F_PACKED launches on the transition-row kernel) of 128 MB of rows
- * and 64 steps and more (up to four waves per SIMD) keep a SCHEDULE: a wave begins its next 16 steps no earlier than `period` ticks of the 100 MHz clock (10 ns) after the last ones were due, and never
- * waits when it is late.  The period is CALIBRATED the first time a launch kind (policy, auto-reset) runs on a trajectory buffer,
- * by timing the kernel itself on the engine's own state (snapshot before, put back after: results never depend on it; that first
- * gu_rollout is synchronous and takes ~80 launches longer).  GU_OPT_ROLLOUT_PACE fixes the period instead (0 = no limiter).
- * This reports what the calibration found for a launch kind: the period, ms per launch without and with the limiter, candidates
- * timed, ms spent calibrating.  GU_ERR_STATE when that kind has not been calibrated (not launched yet, or not a launch that is
- * paced).  `flags` with GU_F_PACKED asks for the packed-row launches' record. */
+ * and 64 steps and more (up to four waves per SIMD) can keep a SCHEDULE: a wave begins its next 16 steps no earlier than `period` ticks of the 100 MHz clock (10 ns) after the last ones were due, and never
+ * waits when it is late.  The period is found by timing the kernel itself on the engine's own state (snapshot before, put back
+ * after -- on every exit path: results never depend on it), ~100 full-size launches.  That pays for itself after a few thousand
+ * launches, so with GU_OPT_ROLLOUT_PACE at its default (-1) a launch kind (policy, auto-reset, kernel, row bytes) runs WITHOUT a
+ * limiter until
+ *   - this PROCESS has already searched the same launch shape on the same device (another engine, or this one before its buffer
+ *     changed): that period is CHECKED with six launches and kept when it still beats no limiter; or
+ *   - the engine has issued 1024 launches of that kind: the search runs then (that one gu_rollout is synchronous and ~100
+ *     launches longer); or
+ *   - gu_rollout_calibrate is called: gu_rollout with the search made NOW when the kind has no period yet (what a benchmark or a
+ *     long-running service does once at start-up).
+ * GU_OPT_ROLLOUT_PACE = -2 searches at the first launch of every kind (round 3's behaviour), 0 = never a limiter, n = that period.
+ * gu_rollout_pacing reports what was found for a launch kind: the period, ms per launch without and with the limiter, candidates
+ * timed, ms spent calibrating (GU_ERR_STATE when that kind has no period: not launched yet, still waiting, or not a launch that is
+ * paced; `flags` with GU_F_PACKED asks for the packed-row launches' record).  gu_rollout_pacing_totals: over ALL launch kinds of the
+ * engine -- ms and full-size launches spent calibrating (searches and checks), kinds with a period, how many of those periods
+ * came from the process-wide cache, kinds still running without a limiter and counting. */
+int gu_rollout_calibrate(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
+int gu_rollout_pacing_totals(gu_handle h, float *calibration_ms, int32_t *launches_spent, int32_t *kinds_paced, int32_t *kinds_from_cache,
+                             int32_t *kinds_waiting);
 int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
                       int32_t *evaluated, float *calibration_ms);
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);

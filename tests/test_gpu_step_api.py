@@ -1,0 +1,215 @@
+"""The C ABI's step / state surface on the device: actions and states validated by the kernels that consume them, the done ballots every done[]-writing kernel leaves, page-locked I/O pointers, the 24-bit move limit, RNG counters beyond 2^28, get_cells."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from griduniverse_amd import _lib
+from griduniverse_amd.engine import Engine
+from griduniverse_amd.grid import GridSpec
+from oracle import c_oracle as C
+from tests import _golden as G
+import griduniverse_amd as gua
+
+pytestmark = pytest.mark.gpu
+
+def spec_of(meta):
+    return GridSpec(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'])
+
+
+@pytest.mark.parametrize('N', [300, 20000])  # completion-word path (<= 8192 envs) and stream-sync path
+@pytest.mark.parametrize('pinned', [False, True])
+def test_invalid_action_is_caught_by_the_kernel_and_only_that_env_stays(N, pinned):
+    meta, _ = G.load_traj('c4_lava32')
+    grid = C.Grid.from_lists(**meta)
+    st = C.State(N)
+    rs = np.random.RandomState(N)
+    with Engine(N, spec_of(meta), seed=5) as eng:
+        assert np.array_equal(eng.reset(), C.reset(grid, 5, st))
+        C.rollout(grid, 5, st, 40, True)
+        eng.rollout(40, 'uniform', True, trajectory=False)
+        before = eng.get_state()
+        rew_before = eng.read_outputs()[1]
+        acts = rs.randint(0, 4, N).astype(np.int32)
+        bad = np.array([7, N // 2, N - 1])
+        acts[bad] = [4, -1, 1 << 20]
+
+        def call():
+            if pinned:
+                eng.pinned_actions[:] = acts
+                return eng.step_pinned(auto_reset=True)
+            return eng.step(acts, auto_reset=True)
+        with pytest.raises(gua.GuError) as err:
+            call()
+        assert 'action 4 of env 7 outside 0..3' in str(err.value) and err.value.code == -1
+        # envs with valid actions stepped exactly like the oracle; the offenders did not move, count or reset
+        good = np.ones(N, bool)
+        good[bad] = False
+        want = C.rollout(grid, 5, st, 1, True, actions=np.where(good, acts, 0)[None, :])
+        after = eng.get_state()
+        out = eng.read_outputs()
+        for k, w in (('pos', st.pos), ('done', st.done), ('episode', st.episode)):
+            assert np.array_equal(after[k][good], w[good]), k
+            assert np.array_equal(after[k][bad], before[k][bad]), k
+        assert np.array_equal(out[1][good], want['reward'][0][good]) and np.array_equal(out[1][bad], rew_before[bad])
+        assert np.all(after['tcount'][good] == 41) and np.all(after['tcount'][bad] == 40)
+        # the error word is re-armed: the next valid step succeeds and equals the oracle for the good envs
+        acts2 = rs.randint(0, 4, N).astype(np.int32)
+        if pinned:
+            eng.pinned_actions[:] = acts2
+            obs = eng.step_pinned(auto_reset=True)[0].copy()
+        else:
+            obs = eng.step(acts2, auto_reset=True)[0]
+        want2 = C.rollout(grid, 5, st, 1, True, actions=acts2[None, :])
+        assert np.array_equal(obs[good], want2['obs'][0][good])
+        # done ballots stay current through all of this
+        assert np.array_equal(eng.done_indices(), np.flatnonzero(eng.get_state()['done']))
+
+
+def test_uploaded_action_stream_is_validated_on_the_device():
+    meta, _ = G.load_traj('c2_open8x8')
+    N, T = 1000, 33
+    acts = np.random.RandomState(0).randint(0, 4, (T, N)).astype(np.int32)
+    with Engine(N, spec_of(meta), seed=1) as eng:
+        eng.upload_actions(acts)
+        eng.step_device(T - 1)
+        acts[20, 999] = 9
+        with pytest.raises(gua.GuError) as err:
+            eng.upload_actions(acts)
+        assert 'action 9 at flat index %d' % (20 * N + 999) in str(err.value)
+        with pytest.raises(gua.GuError):  # the rejected stream is not usable
+            eng.step_device(0)
+        acts[20, 999] = 3
+        eng.upload_actions(acts)
+        eng.step_device(0)
+        # look_step_ahead: out-of-grid states / bad actions raise from the kernel's error word
+        with pytest.raises(gua.GuError) as err:
+            eng.look_step_ahead([0, 64, 3], [1, 1, 1])
+        assert 'state 64 outside the grid' in str(err.value)
+        with pytest.raises(gua.GuError) as err:
+            eng.look_step_ahead([0, 5, 3], [1, 1, 5])
+        assert 'action 5 outside 0..3' in str(err.value)
+        nxt, _, _ = eng.look_step_ahead([0, 5], [1, 2])
+        assert nxt.tolist() == [1, 13]
+
+
+def test_done_ballots_follow_every_kernel_that_writes_done():
+    """gu_done_indices is ONE compaction launch over ballot words kept current by step / rollout / reset / sweep-step."""
+    meta, _ = G.load_traj('c4_lava32')
+    for N in (1, 63, 65, 1000, 70000):
+        grid = C.Grid.from_lists(**meta)
+        st = C.State(N)
+        with Engine(N, spec_of(meta), seed=3) as eng:
+            assert len(eng.done_indices()) == 0
+            eng.reset()
+            C.reset(grid, 3, st)
+            for T, auto in ((37, False), (5, True), (64, False)):
+                C.rollout(grid, 3, st, T, auto)
+                eng.rollout(T, 'uniform', auto, trajectory=False)
+                assert np.array_equal(eng.done_indices(), np.flatnonzero(st.done)), (N, T)
+            assert N < 1000 or st.done.any()
+            acts = (np.arange(N) % 4).astype(np.int32)
+            C.rollout(grid, 3, st, 1, False, actions=acts[None, :])
+            eng.step(acts)
+            assert np.array_equal(eng.done_indices(), np.flatnonzero(st.done))
+            mask = np.arange(N) % 2 == 0
+            C.reset(grid, 3, st, mask=mask)
+            eng.reset(mask)
+            assert np.array_equal(eng.done_indices(), np.flatnonzero(st.done))
+            eng.reset_done()
+            assert len(eng.done_indices()) == 0
+            flags = (np.arange(N) % 5 == 0).astype(np.int32)
+            eng.set_state(done=flags)  # host-installed flags: the ballot pass runs once
+            assert np.array_equal(eng.done_indices(), np.flatnonzero(flags))
+            S = meta['W'] * meta['H']
+            eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+            eng.vi_sweep_step(0.9, auto_reset=True)
+            assert np.array_equal(eng.done_indices(), np.flatnonzero(eng.get_state()['done']))
+
+
+def test_pinned_io_rejects_pageable_memory_instead_of_faulting():
+    meta, _ = G.load_traj('c2_open8x8')
+    N = 256
+    with Engine(N, spec_of(meta), seed=1) as eng:
+        eng.reset()
+        lib = eng.lib
+        acts = np.zeros(N, np.int32)
+        out = [np.empty(N, np.int32) for _ in range(3)]
+        rc = lib.gu_step(eng._h, _lib.ptr(acts), _lib.F_PINNED_IO, *[_lib.ptr(o) for o in out])
+        assert rc == -1 and 'not page-locked' in _lib.last_error()
+        pin = _lib.PinnedArray((4, N))
+        pin.array[0] = 1
+        p = [pin.array[k].ctypes.data_as(ctypes.c_void_p) for k in range(4)]
+        assert lib.gu_step(eng._h, p[0], _lib.F_PINNED_IO, p[1], p[2], p[3]) == 0
+        assert np.all(pin.array[1] == 1)
+        # actions page-locked, an output not
+        rc = lib.gu_step(eng._h, p[0], _lib.F_PINNED_IO, p[1], _lib.ptr(out[1]), p[3])
+        assert rc == -1 and 'reward' in _lib.last_error()
+        # a range that runs past the end of the allocation
+        tail = ctypes.c_void_p(pin.array.ctypes.data + 4 * N * 4 - 16)
+        assert lib.gu_step(eng._h, p[0], _lib.F_PINNED_IO, tail, None, None) == -1
+        # still healthy afterwards
+        assert lib.gu_step(eng._h, p[0], _lib.F_PINNED_IO, p[1], p[2], p[3]) == 0
+        assert np.all(pin.array[1] == 2)
+        pin.free()
+
+
+def test_grid_wider_than_the_24_bit_move_is_refused():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.gu_create(0, 64, 0, ctypes.byref(h)))
+    try:
+        W, H = (1 << 23) + 1, 2
+        wpr = (W + 31) // 32
+        zeros = np.zeros((H, wpr), np.uint32)
+        goal = zeros.copy()
+        goal[1, 0] = 2
+        starts = np.zeros(1, np.int32)
+        rc = lib.gu_set_grid(h, W, H, wpr, _lib.ptr(zeros), _lib.ptr(goal), _lib.ptr(zeros), None, None, _lib.ptr(starts), 1)
+        assert rc == -6 and '8 388 607' in _lib.last_error()
+        # the widest supported grid still moves up and down correctly (arithmetic path, no LDS)
+        W = (1 << 23) - 1
+        wpr = (W + 31) // 32
+        zeros = np.zeros((H, wpr), np.uint32)
+        goal = zeros.copy()
+        goal[1, 0] = 2
+        starts[0] = W - 5
+        _lib.check(lib.gu_set_grid(h, W, H, wpr, _lib.ptr(zeros), _lib.ptr(goal), _lib.ptr(zeros), None, None, _lib.ptr(starts), 1))
+        obs = np.empty(64, np.int32)
+        for a, want in ((2, 2 * W - 5), (2, 2 * W - 5), (1, 2 * W - 4), (0, W - 4), (0, W - 4), (3, W - 5)):
+            acts = np.full(64, a, np.int32)
+            _lib.check(lib.gu_step(h, _lib.ptr(acts), 0, _lib.ptr(obs), None, None))
+            assert np.all(obs == want), (a, want, obs[0])
+    finally:
+        lib.gu_destroy(h)
+
+
+def test_sampled_stream_does_not_repeat_beyond_2_pow_28_steps():
+    meta, _ = G.load_traj('c2_open8x8')
+    N, T, S = 512, 40, 64
+    pi = np.random.RandomState(3).dirichlet(np.ones(4), S)
+    grid = C.Grid.from_lists(**meta)
+    rows = {}
+    for t0 in (5, (1 << 28) - 7, (1 << 28) + 5, (3 << 28) + 5):
+        st = C.State(N)
+        with Engine(N, spec_of(meta), seed=9) as eng:
+            eng.vi_set(np.zeros(S), pi)
+            assert np.array_equal(eng.reset(), C.reset(grid, 9, st))
+            st.tcount[:] = t0
+            eng.set_state(tcount=st.tcount)
+            eng.reserve_trajectory(T)
+            for policy, kw in (('sample', dict(pi=pi)), ('uniform', {})):
+                eng.rollout(T, policy, True)
+                got = eng.read_trajectory(0, T)
+                want = C.rollout(grid, 9, st, T, True, **kw)
+                assert all(np.array_equal(got[k], want[k]) for k in got), (t0, policy)
+                if policy == 'sample':
+                    rows[t0] = got['obs'].copy()
+    assert not np.array_equal(rows[5], rows[(1 << 28) + 5]) and not np.array_equal(rows[(1 << 28) + 5], rows[(3 << 28) + 5])
+
+
+def test_get_cells_with_a_start_list_longer_than_the_grid():
+    spec = GridSpec(2, 1, [0, 0, 0, 1, 0], [1], [], [])
+    with Engine(8, spec) as eng:
+        flags, reward, starts = eng.get_cells()
+        assert starts.tolist() == [0, 0, 0, 1, 0] and reward.tolist() == [-1, 10]

@@ -56,14 +56,14 @@ for b, eng in enumerate(engines):
     probe = eng.probe_trajectory() * 1e3
     eng.set_option('rollout_pace', 0)
     unpaced = timed(eng)
-    eng.set_option('rollout_pace', None)
+    eng.set_option('rollout_pace', -2)
     paced = timed(eng)
     info = eng.rollout_pacing()
     row = []
     for p in fixed:
         eng.set_option('rollout_pace', p)
         row.append(timed(eng))
-    eng.set_option('rollout_pace', None)
+    eng.set_option('rollout_pace', -2)
     print('%-4d %8.1f %9.1f %9.1f  %s' % (b, probe, unpaced, paced, info) + ''.join(' %7.1f' % v for v in row), flush=True)
 # pacing never changes a result: same seed, same launch, with and without
 keys = []

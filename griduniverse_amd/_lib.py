@@ -87,6 +87,8 @@ SIGNATURES = {
     'gu_mc_evaluate': [_vp, _i64, _vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp],
     'gu_shortest_paths': [_vp, _i32, _vp, _vp, _vp],
     'gu_render_rgb': [_vp, _i64, _i64, _i32, _vp],
+    'gu_trail_enable': [_vp, _i32],
+    'gu_trail_read': [_vp, _i64, _i64, _vp, _vp],
     'gu_render_policy_rgb': [_vp, _i32, _vp],
     'gu_host_alloc': [_c.c_size_t, _c.POINTER(_vp)],
     'gu_host_free': [_vp],

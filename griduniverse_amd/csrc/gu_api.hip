@@ -161,6 +161,7 @@ int gu_destroy(gu_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     gu_comm_free(h);
     gu_vi_free(h);
+    gu_trail_free(h);
     gu_placement_release(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     void *bufs[] = {h->d_kind, h->d_rows[0], h->d_rows[1], h->d_rows2[0], h->d_rows2[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,

@@ -163,6 +163,13 @@ struct gu_engine {
     bool greedy_valid = false;
     int vi_run_form = 0;            // which form the last gu_vi_sweep_step_run took: 1 per XCD, 2 chip-wide cluster, 3 one launch per round
 
+    // agent trail (gu_trail.hip): off unless gu_trail_enable was called
+    int32_t trail_cap = 0;             // entries per env (0: off)
+    int32_t *d_trail = nullptr;        // [N][trail_cap] ring of cells
+    int32_t *d_trail_len = nullptr, *d_trail_head = nullptr;  // [N] each (one allocation)
+    uint8_t *d_trail_done = nullptr;   // [N] done flag behind the last append
+    uint32_t *d_trail_alpha = nullptr; // [trail_cap] alpha of the i-th newest entry, 16 fractional bits
+
     // RCCL
     void *comm = nullptr;  // ncclComm_t
     int32_t nranks = 0, rank = 0;
@@ -256,6 +263,12 @@ struct GuXcdPlan {
 struct ViStepXcdArgs;
 bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan);
 int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a);
+
+// ---- agent trail (gu_trail.hip): no-ops while the trail is off ----------------------
+int gu_trail_after_step(gu_engine *h, uint32_t flags);
+int gu_trail_before_reset(gu_engine *h, const uint8_t *d_mask, bool only_done);
+int gu_trail_after_rollout(gu_engine *h, int64_t T, int traj, bool auto_reset);
+void gu_trail_free(gu_engine *h);
 
 // ---- grids (gu_api.hip / gu_maze.hip) ----------------------------------------------
 int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const std::vector<uint8_t> &cell,

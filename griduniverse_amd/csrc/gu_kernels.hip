@@ -312,6 +312,8 @@ __global__ void __launch_bounds__(1024) gu_done_compact_kernel(const uint64_t *_
 // ------------------------------------------------------------------------------------
 int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice, bool only_done)
 {
+    int trail_rc = gu_trail_before_reset(h, d_mask, only_done);  // (reads the done flags the reset is about to clear)
+    if (trail_rc != GU_OK) return trail_rc;
     ResetArgs a{h->pos(), h->done(), h->d_episode, h->d_starts, d_mask, d_choice, h->d_done_bits,
                 (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, only_done ? 1 : 0, gu_grid_sel(h)};
     hipLaunchKernelGGL(gu_reset_kernel, dim3(gu_blocks(h->N, GU_BLOCK)), dim3(GU_BLOCK), 0, h->stream, a);
@@ -332,7 +334,7 @@ int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, i
         hipLaunchKernelGGL(gu_step_kernel<false>, dim3(gu_blocks(h->N, GU_BLOCK)), dim3(GU_BLOCK), 0, h->stream, a);
     GU_HIP(hipGetLastError());
     h->steps_taken += 1;
-    return GU_OK;
+    return gu_trail_after_step(h, flags);
 }
 
 static double gu_wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -593,7 +595,7 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
 // (Until r03o a batch of more than one wave per SIMD was also tried as several launches in a row of one wave per SIMD each: the
 // idle-turn limiter had nothing to work with at four waves per SIMD.  The schedule has -- 262 144 envs in ONE launch 0.44 .. 0.48 ms,
 // as four launches in a row 0.56 .. 0.59, profiles/r03o_c4_split.txt -- and that form is gone.)
-// WHEN it is calibrated (round 4).  The search costs ~100 full-size launches and saves ~10 % of each later one: it pays for itself
+// WHEN it is calibrated (round 4).  The search costs a few hundred full-size launches (374 = 52 ms at the headline size) and saves ~10 % of each later one: it pays for itself
 // only after a few thousand launches of that kind.  So, with GU_OPT_ROLLOUT_PACE at its default (-1):
 //   * a period this PROCESS already found for the same launch shape (device, batch, length class, policy, auto-reset, kernel, row bytes,
 //     workgroups) is checked with six launches and kept when it still beats no limiter;
@@ -664,6 +666,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     const bool stats = flags & GU_F_STATS;
     const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->all_single_start ? 1 : 2) : 0;
     const int64_t rows = traj ? h->traj_T * h->N : 0;
+    GU_REQUIRE(!h->trail_cap || traj, GU_ERR_UNSUPPORTED, "the agent trail is on (gu_trail_enable): a rollout must write rows (GU_F_TRAJECTORY or GU_F_PACKED) to feed it");
     RolloutArgs a{};
     a.cell = h->d_cell;
     a.greedy = h->d_greedy;
@@ -706,7 +709,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     if (gu_rollout_multi(h, a, policy, auto_mode, traj, stats)) {
         GU_HIP(hipGetLastError());
         h->steps_taken += (uint32_t)T;
-        return GU_OK;
+        return gu_trail_after_rollout(h, T, traj, auto_mode != 0);
     }
     {
         int rows_rc = GU_OK;
@@ -715,7 +718,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
             GU_HIP(hipGetLastError());
             h->steps_taken += (uint32_t)T;
             if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
-            return GU_OK;
+            return gu_trail_after_rollout(h, T, traj, auto_mode != 0);
         }
     }
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
@@ -733,7 +736,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
     GU_HIP(hipGetLastError());
     h->steps_taken += (uint32_t)T;
-    return GU_OK;
+    return gu_trail_after_rollout(h, T, traj, auto_mode != 0);
 }
 
 int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const int32_t *d_actions, bool care,

@@ -7,7 +7,9 @@
 // policy arrows, are the reference's and are pinned to it (tests/golden/arrows.json: the viewer's tile loop and its
 // render_policy_arrows, lifted from the parsed module and run without a window; oracle/render.py restates them and the
 // rasterisation rule below).  The four flat colours stand in for the textures (core/resources, OUT OF SCOPE) and, like
-// the grid line and the agent square, are build-defined.
+// the grid line and the agent square, are build-defined.  With gu_trail_enable the frame also carries the viewer's agent trail
+// (rendering.py:287-311): which cells, which alpha, which order are the reference's (tests/golden/trail.json); the blend is the
+// integer rule stated in the kernel.
 #include "gu_internal.hpp"
 
 struct RenderArgs {
@@ -17,6 +19,10 @@ struct RenderArgs {
     uint8_t *rgb;          // [n][H*px][W*px][3]
     int64_t env0, n_envs, group, grid_stride;
     int32_t W, H, px, n_grids;
+    // agent trail (gu_trail.hip; nullptr / 0 when off)
+    const int32_t *trail, *trail_len, *trail_head;
+    const uint32_t *trail_alpha;
+    int32_t trail_cap;
 };
 
 // Which texture a cell gets is the reference's rule (core/envs/rendering.py:119-133: goal, else lava, else wall, else ground;
@@ -54,6 +60,29 @@ __global__ void __launch_bounds__(256) gu_render_kernel(const RenderArgs a)
     if (a.px >= 4 && (iy == 0 || ix == 0)) { r = r * 3 / 4; g = g * 3 / 4; b = b * 3 / 4; }  // grid line
     const int32_t lo = a.px / 4, hi = a.px - a.px / 4;
     if (s == a.pos[e] && iy >= lo && iy < hi && ix >= lo && ix < hi) { r = 40; g = 90; b = 220; }  // agent
+    // The agent's trail (rendering.py:287-311), drawn last like there: newest entry first, every entry a quad over its tile with
+    // alpha 0.3 * 0.96^(i + 1), entries on the agent's current cell skipped (their alpha step is still taken).  The quad's corner
+    // colours are the reference's -- red, yellow, green, blue from the bottom-left corner counter-clockwise (glColor4f clamps
+    // 0xFF to 1) -- interpolated bilinearly at the pixel centre; blended in integer arithmetic, 16 fractional bits of alpha,
+    // rounded to nearest per entry: c = (c * (65536 - A) + colour * A + 32768) >> 16.
+    if (a.trail_cap && s != a.pos[e]) {
+        const int32_t len = a.trail_len[e], head = a.trail_head[e];
+        const uint32_t two = 2u * (uint32_t)a.px, u = 2u * (uint32_t)ix + 1u, v = 2u * (uint32_t)(a.px - 1 - iy) + 1u;  // doubled, y up
+        const uint32_t cr = (255u * (two - v) + (uint32_t)a.px) / two;                       // red + yellow on the bottom edge
+        const uint32_t cg = (255u * u + (uint32_t)a.px) / two;                               // yellow + green on the right edge
+        const uint32_t cb = (255u * (two - u) * v + two * two / 2u) / (two * two);           // blue in the top-left corner
+        uint32_t R = r, G = g, B = b;
+        for (int32_t k = 0; k < len; ++k) {
+            int32_t slot = head - 1 - k;
+            slot += slot < 0 ? a.trail_cap : 0;
+            if (a.trail[e * a.trail_cap + slot] != s) continue;
+            const uint32_t A = a.trail_alpha[k];
+            R = (R * (65536u - A) + cr * A + 32768u) >> 16;
+            G = (G * (65536u - A) + cg * A + 32768u) >> 16;
+            B = (B * (65536u - A) + cb * A + 32768u) >> 16;
+        }
+        r = (uint8_t)R, g = (uint8_t)G, b = (uint8_t)B;
+    }
     uint8_t *out = a.rgb + 3 * i;
     out[0] = r;
     out[1] = g;
@@ -147,7 +176,7 @@ extern "C" int gu_render_rgb(gu_handle h, int64_t env0, int64_t n_envs, int32_t 
     rc = gu_ensure_scratch(h, (size_t)pixels * 3);
     if (rc != GU_OK) return rc;
     RenderArgs a{h->d_cell, h->d_kind, h->pos(), (uint8_t *)h->d_scratch, env0, n_envs, h->group, 2 * (int64_t)h->cell_bytes,
-                 h->W, h->H, cell_px, h->n_grids};
+                 h->W, h->H, cell_px, h->n_grids, h->d_trail, h->d_trail_len, h->d_trail_head, h->d_trail_alpha, h->trail_cap};
     hipLaunchKernelGGL(gu_render_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, h->stream, a);
     GU_HIP(hipGetLastError());
     GU_HIP(hipMemcpyAsync(rgb, h->d_scratch, (size_t)pixels * 3, hipMemcpyDeviceToHost, h->stream));

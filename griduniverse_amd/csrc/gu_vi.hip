@@ -1016,6 +1016,7 @@ int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta)
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_vi_sweep_step accepts only GU_F_AUTO_RESET");
+    GU_REQUIRE(!h->trail_cap, GU_ERR_UNSUPPORTED, "the agent trail is on (gu_trail_enable): the fused sweep + step launches do not feed it");
     GU_HIP(hipMemsetAsync(h->d_delta, 0, sizeof(unsigned long long), h->stream));
     ViStepArgs a{};
     a.vi = vi_args(h, gamma, (unsigned long long *)h->d_delta);
@@ -1055,6 +1056,7 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_vi_sweep_step_run accepts only GU_F_AUTO_RESET");
+    GU_REQUIRE(!h->trail_cap, GU_ERR_UNSUPPORTED, "the agent trail is on (gu_trail_enable): the fused sweep + step launches do not feed it");
     GU_REQUIRE(iters > 0 && iters <= 1000000, GU_ERR_INVALID, "iters must be in 1..1000000");
     const int64_t threads = h->N > h->S ? h->N : (int64_t)h->S;
     const int64_t G = (threads + VI_CL_THREADS - 1) / VI_CL_THREADS;

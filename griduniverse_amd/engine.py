@@ -224,7 +224,7 @@ class Engine(object):
     def calibrate_rollout(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
         """rollout(...) with the store-pacing search for this launch kind made NOW if the kind is paced and has no period yet
         (include/gu.h: gu_rollout_calibrate).  By default the search waits until an engine has issued 1024 launches of a kind --
-        it costs ~100 launches and saves ~10 % of each later one; a benchmark or a long-running service calls this once."""
+        it costs a few hundred launches (~50 ms at the headline size) and saves ~10 % of each later one; a benchmark or a long-running service calls this once."""
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_STATS if stats else 0)
         flags |= _lib.F_PACKED if trajectory == 'packed' else (_lib.F_TRAJECTORY if trajectory else 0)
         check(self.lib.gu_rollout_calibrate(self._h, int(T), _POLICIES[policy], flags))
@@ -399,6 +399,19 @@ class Engine(object):
         out = np.empty((int(n_envs), H * cell_px, W * cell_px, 3), np.uint8)
         check(self.lib.gu_render_rgb(self._h, int(env0), int(n_envs), int(cell_px), ptr(out)))
         return out
+
+    def trail_enable(self, capacity=500):
+        """Keep the reference viewer's agent trail per env (env:92-93, 182-184, 190: the cell after every step, newest `capacity`
+        <= 500, emptied by reset) and blend it into render_rgb frames (rendering.py:287-311); 0 switches it off again."""
+        check(self.lib.gu_trail_enable(self._h, int(capacity)))
+        self._trail_cap = int(capacity)
+
+    def trail_read(self, env0=0, n_envs=1):
+        """The trails of envs env0 .. env0 + n_envs - 1 as lists of cells, oldest first (the reference's last_n_states as states)."""
+        cap = getattr(self, '_trail_cap', 0)
+        cells, length = np.empty((int(n_envs), max(cap, 1)), np.int32), np.empty(int(n_envs), np.int32)
+        check(self.lib.gu_trail_read(self._h, int(env0), int(n_envs), ptr(cells), ptr(length)))
+        return [cells[k, :length[k]].tolist() for k in range(int(n_envs))]
 
     # ------------------------------------------------------------------ stream / timing
     def sync(self):

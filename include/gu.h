@@ -243,12 +243,12 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
  * every one.  Launches with GU_F_TRAJECTORY (and GU_F_PACKED launches on the transition-row kernel) of 128 MB of rows
  * and 64 steps and more (up to four waves per SIMD) can keep a SCHEDULE: a wave begins its next 16 steps no earlier than `period` ticks of the 100 MHz clock (10 ns) after the last ones were due, and never
  * waits when it is late.  The period is found by timing the kernel itself on the engine's own state (snapshot before, put back
- * after -- on every exit path: results never depend on it), ~100 full-size launches.  That pays for itself after a few thousand
+ * after -- on every exit path: results never depend on it), a few hundred full-size launches (warm-up ramp, two scans).  That pays for itself after a few thousand
  * launches, so with GU_OPT_ROLLOUT_PACE at its default (-1) a launch kind (policy, auto-reset, kernel, row bytes) runs WITHOUT a
  * limiter until
  *   - this PROCESS has already searched the same launch shape on the same device (another engine, or this one before its buffer
  *     changed): that period is CHECKED with six launches and kept when it still beats no limiter; or
- *   - the engine has issued 1024 launches of that kind: the search runs then (that one gu_rollout is synchronous and ~100
+ *   - the engine has issued 1024 launches of that kind: the search runs then (that one gu_rollout is synchronous and a few hundred
  *     launches longer); or
  *   - gu_rollout_calibrate is called: gu_rollout with the search made NOW when the kind has no period yet (what a benchmark or a
  *     long-running service does once at start-up).
@@ -346,6 +346,16 @@ int gu_shortest_paths(gu_handle h, int32_t max_path, int8_t *path, int32_t *path
  * colours that stand in for its textures are build-defined -- a grid line on the top and left edge of each cell
  * (cell_px >= 4), the agent as an inset square on its cell. */
 int gu_render_rgb(gu_handle h, int64_t env0, int64_t n_envs, int32_t cell_px, uint8_t *rgb);
+/* The agent trail: core/envs/griduniverse_env.py:92-93, 182-184, 190 (`last_n_states`: the cell the agent is on after every
+ * step, newest 500 kept, emptied by reset) + core/envs/rendering.py:287-311 (every frame: newest first, a quad over the entry's
+ * tile with alpha 0.3 * 0.96^(i + 1), entries on the agent's current cell skipped).  OFF by default; gu_trail_enable(capacity
+ * 1 .. 500; 0 = off again) makes the step / reset / rollout launches keep a ring per env -- small kernels of their own behind the
+ * launch; a rollout must then write rows (GU_F_TRAJECTORY or GU_F_PACKED), the fused sweep + step launches are refused --
+ * and gu_render_rgb blend it over the tiles: corner colours red, yellow, green, blue (bottom-left, counter-clockwise) interpolated
+ * bilinearly at the pixel centre, c = (c * (65536 - A) + colour * A + 32768) >> 16 per entry with A = round(alpha * 65536).
+ * gu_trail_read: cells[n_envs][capacity] oldest first (-1 beyond length[k]), like the reference's list of states. */
+int gu_trail_enable(gu_handle h, int32_t capacity);
+int gu_trail_read(gu_handle h, int64_t env0, int64_t n_envs, int32_t *cells, int32_t *length);
 /* The policy-arrow figure of Viewer.render_policy_arrows (core/envs/rendering.py:159-212) for the current policy table
  * (gu_vi_set / gu_vi_run ...): rgb[H*cell_px][W*cell_px][3], the tiles of grid 0 plus, on every state that is neither
  * terminal nor a wall, one arrow per action with probability >= 0.1: shaft from the tile centre, round(p*20) long

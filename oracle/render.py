@@ -2,7 +2,8 @@
 of csrc/gu_render.hip.  Only tests/ may import this.  Pinned by tests/golden/arrows.json (tests/test_oracle_render.py), which
 tests/golden/make_golden.py captured by running the reference's own method bodies without a window.
 
-Reference: core/envs/rendering.py -- `Viewer.__init__` :119-133 (texture per cell), `Viewer.render_policy_arrows` :159-212.
+Reference: core/envs/rendering.py -- `Viewer.__init__` :119-133 (texture per cell), `Viewer.render_policy_arrows` :159-212, the agent
+trail of `Viewer.render` :287-311 (pinned by tests/golden/trail.json, captured the same way).
 """
 import numpy as np
 
@@ -107,4 +108,36 @@ def policy_frame(W, H, kinds, geoms, px):
     for s, gs in by_state.items():
         y, x = divmod(s, W)
         img[y * px:(y + 1) * px, x * px:(x + 1) * px][rasterise(gs, px)] = ARROW_COLOUR
+    return img
+
+
+# ---- the agent trail (rendering.py:287-311 over env.last_n_states, env:92-93, 182-184, 190) ----
+TRAIL_ALPHA0 = 0.3      # a = 0.3 (:289)
+TRAIL_DISCOUNT = 0.96   # discount = 0.96 (:290); `a *= discount` BEFORE every entry (:295), skipped ones included
+TRAIL_CORNERS = ((255, 0, 0), (255, 255, 0), (0, 255, 0), (0, 0, 255))  # glColor4f at (x0, y0), (x0 + t, y0), (x0 + t, y0 + t), (x0, y0 + t), y up
+
+
+def trail_quads(last_states, current):
+    """[(state of the tile, alpha)] in drawing order: newest entry first, entries on the agent's current cell skipped (:296-297)."""
+    a, out = TRAIL_ALPHA0, []
+    for s in reversed(list(last_states)):
+        a *= TRAIL_DISCOUNT
+        if s == current:
+            continue
+        out.append((int(s), a))
+    return out
+
+
+def blend_trail(img, W, px, quads):
+    """csrc/gu_render.hip's integer rule, in place: corner colours interpolated bilinearly at the pixel centre (doubled coordinates,
+    y up), c = (c * (65536 - A) + colour * A + 32768) >> 16 per quad, A = round(alpha * 65536)."""
+    two = 2 * px
+    iy, ix = np.mgrid[0:px, 0:px]
+    u, v = 2 * ix + 1, 2 * (px - 1 - iy) + 1
+    colour = np.stack([(255 * (two - v) + px) // two, (255 * u + px) // two, (255 * (two - u) * v + two * two // 2) // (two * two)], axis=-1).astype(np.int64)
+    for s, alpha in quads:
+        y, x = divmod(int(s), W)
+        A = int(alpha * 65536.0 + 0.5)
+        tile = img[y * px:(y + 1) * px, x * px:(x + 1) * px].astype(np.int64)
+        img[y * px:(y + 1) * px, x * px:(x + 1) * px] = ((tile * (65536 - A) + colour * A + 32768) >> 16).astype(np.uint8)
     return img

@@ -699,6 +699,91 @@ def capture_arrows():
                        'relative to the tile origin (bottom-left corner of the tile, y up)')
 
 
+def capture_trail():
+    """The agent trail of the reference's viewer (core/envs/rendering.py:287-311), without a window: the statements `a = 0.3`,
+    `discount = 0.96`, `padding = 10` and the `for i, (x, y) in enumerate(self.env.last_n_states[::-1])` loop are lifted out of the
+    PARSED Viewer.render (ast; nothing is imported or copied) into a function whose free names glColor4f / glVertex2i record their
+    arguments, next to the lifted Viewer.get_x_y_pix_location.  It runs against the real reference env, whose own step() / reset()
+    keep `last_n_states` (env:92-93, 182-184, 190).  Recorded per case: the actions (-1 = reset()), the env's final state, its
+    last_n_states as states, and the quads in the order the reference emits them: (state of the tile, alpha)."""
+    import ast
+    from PIL import Image
+    path = os.path.join(REF, 'core', 'envs', 'rendering.py')
+    tree = ast.parse(open(path).read(), path)
+    viewer = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'Viewer')
+    methods = {n.name: n for n in viewer.body if isinstance(n, ast.FunctionDef)}
+
+    def is_trail_loop(n):
+        return (isinstance(n, ast.For) and isinstance(n.iter, ast.Call) and getattr(n.iter.func, 'id', '') == 'enumerate'
+                and 'last_n_states' in ast.dump(n.iter))
+    host = next(m for m in methods.values() if any(is_trail_loop(n) for n in ast.walk(m)))
+    loop = next(n for n in ast.walk(host) if is_trail_loop(n))
+    setup = [n for n in host.body if isinstance(n, ast.Assign) and len(n.targets) == 1 and getattr(n.targets[0], 'id', '') in ('a', 'discount', 'padding')]
+    assert [n.targets[0].id for n in setup] == ['a', 'discount', 'padding'], 'the trail loop\'s constants moved'
+    wrapper = ast.parse('def draw_trail(self):\n    pass\n').body[0]
+    wrapper.body = setup + [loop]
+    lifted = ast.ClassDef(name='LiftedViewer', bases=[], keywords=[], decorator_list=[], body=[methods['get_x_y_pix_location'], wrapper])
+    code = compile(ast.fix_missing_locations(ast.Module(body=[lifted], type_ignores=[])), path, 'exec')
+    calls = []
+    ns = dict(np=np, glColor4f=lambda *c: calls.append(('colour',) + tuple(c)), glVertex2i=lambda *v: calls.append(('vertex',) + tuple(int(k) for k in v)))
+    exec(code, ns)
+    ground_width = Image.open(os.path.join(REF, 'core', 'resources', 'wbs_texture_05_resized.jpg')).size[0]
+
+    def case(name, env, actions, note=''):
+        with quiet():
+            start_state = int(env.reset())  # (a multi-start level draws it from the global RNG: recorded, forced in the tests)
+            for a_ in actions:
+                if a_ < 0:
+                    assert len(env.starting_states) == 1
+                    env.reset()
+                else:
+                    env.step(int(a_))
+        v = ns['LiftedViewer']()
+        v.env = env
+        v.tile_dim = ground_width + 1
+        v.num_extra_tiles = 4
+        v.x_distance_to_move = 0
+        v.pix_grid_height = env.y_max * v.tile_dim + (v.num_extra_tiles // 2) * v.tile_dim
+        origin = {v.get_x_y_pix_location(x, y): s_ for s_, (x, y) in enumerate(env.world)}
+        del calls[:]
+        v.draw_trail()
+        quads, corner_colours = [], None
+        assert len(calls) % 8 == 0
+        for k in range(0, len(calls), 8):
+            group = calls[k:k + 8]
+            assert [g[0] for g in group] == ['colour', 'vertex'] * 4
+            colours = [list(g[1:4]) for g in group[0::2]]
+            alphas = {g[4] for g in group[0::2]}
+            verts = [g[1:] for g in group[1::2]]
+            assert len(alphas) == 1
+            ox, oy = verts[0]
+            assert verts == [(ox, oy), (ox + v.tile_dim, oy), (ox + v.tile_dim, oy + v.tile_dim), (ox, oy + v.tile_dim)]
+            assert corner_colours in (None, colours)
+            corner_colours = colours
+            quads.append([origin[(ox, oy)], float(alphas.pop())])
+        world = {(int(x), int(y)): s_ for s_, (x, y) in enumerate(env.world)}
+        out = spec_of(env)
+        out.update(name=name, note=note, actions=[int(a_) for a_ in actions], start_state=start_state, current_state=int(env.current_state),
+                   last_n_states=[world[(int(x), int(y))] for x, y in env.last_n_states], quads=quads, corner_colours=corner_colours)
+        print('trail', name, 'steps', len(actions), 'kept', len(env.last_n_states), 'quads', len(quads))
+        return out
+
+    rs = np.random.RandomState(77)
+    cases = [case('default4x4_walk', ref_env(), [1, 1, 2, 3, 0, 1, 2, 2, 3, 3, 0, 1], 'revisits cells, ends next to where it has been'),
+             case('default4x4_bumping', ref_env(), [3, 3, 0, 0, 1, 3, 1, 3], 'steps into the border: the current cell is entered several times and always skipped'),
+             case('lava4x4_reset', ref_env(lava_states=[5]), [1, 2, -1, 2, 2, 1, 1], 'walks into lava, the harness resets: the trail starts over'),
+             case('open8x8_long', ref_env(grid_shape=(8, 8), goal_states=[63], walls=[27, 28]), [int(a_) for a_ in rs.randint(0, 4, 700) if True][:560],
+                  'more than 500 steps without reaching a terminal state is not guaranteed: see last_n_states for what was kept')]
+    with quiet():
+        level = GridUniverseEnv(custom_world_fp=os.path.join(LEVELS, 'test_env.txt'))
+    cases.append(case('test_env_3x8', level, [2, 2, 1, 2, 3, 2, 2, 0, 0, 1], 'non-square level'))
+    return dict(tile_dim=ground_width + 1, alpha0=0.3, discount=0.96, cases=cases,
+                source='core/envs/rendering.py: the trail loop of Viewer.render and Viewer.get_x_y_pix_location, lifted with ast and executed '
+                       'against the real reference env after its own step() / reset() calls; quads = [state of the tile, alpha] in drawing order; '
+                       'corner_colours = the glColor4f arguments (r, g, b) at the quad\'s vertices (x0, y0), (x0 + tile, y0), (x0 + tile, y0 + tile), '
+                       '(x0, y0 + tile), GL coordinates (y up); GL clamps 0xFF to 1.0')
+
+
 def capture_trajectories():
     digests = {}
     # C1: run_default_griduniverse() shape -- 1 env, 1000 random steps, reset on done
@@ -794,7 +879,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     random.seed(0)
     np.random.seed(0)
-    what = {a.split('=')[0] for a in sys.argv[1:]} or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'mcnp', 'driver', 'bfs', 'arrows'}  # plus 'big' (slow) on request
+    what = {a.split('=')[0] for a in sys.argv[1:]} or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'mcnp', 'driver', 'bfs', 'arrows', 'trail'}  # plus 'big' (slow) on request
     if 'kat' in what:
         json.dump(capture_kats(), open(os.path.join(OUT, 'kat.json'), 'w'), indent=1)
     if 'err' in what:
@@ -817,6 +902,8 @@ def main():
         json.dump(capture_bfs(), open(os.path.join(OUT, 'bfs.json'), 'w'), indent=1)
     if 'arrows' in what:
         json.dump(capture_arrows(), open(os.path.join(OUT, 'arrows.json'), 'w'))
+    if 'trail' in what:
+        json.dump(capture_trail(), open(os.path.join(OUT, 'trail.json'), 'w'))
     if 'big' in what:
         capture_big_digest()
     if 'stream' in what:

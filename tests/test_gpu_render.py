@@ -107,3 +107,75 @@ def test_policy_rows_outside_the_reference_domain():
         frame = eng.render_policy_rgb(52)
     dark = (frame == 20).all(axis=2)
     assert dark[:, :52].sum() == 0 and dark[:, 52:104].sum() > 0 and dark[:, 104:].sum() == 0  # (state 2 is terminal: no arrows)
+
+
+@pytest.mark.parametrize('px', [52, 16])
+def test_agent_trail_equals_the_reference_quads_and_the_stated_blend(px):
+    """tests/golden/trail.json: the quads the reference's own trail loop (core/envs/rendering.py:287-311, lifted with ast) emitted
+    after the reference env's own step() / reset() calls -- which tile, which alpha, in which order.  The engine with
+    gu_trail_enable(500), driven by the same actions through gu_step / gu_reset, must keep the same last_n_states, and its frame
+    must be those quads blended over the tiles by the integer rule include/gu.h states (oracle/render.blend_trail).  The same
+    walk as ONE rollout on an uploaded action stream (int32 and packed rows), and an auto-reset walk step by step against one
+    rollout, must leave the same rings."""
+    import json
+    import os
+
+    from oracle import render as R
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trail.json')))
+    for case in gold['cases']:
+        spec = GridSpec(case['W'], case['H'], case['starts'], case['goals'], case['lava'], case['walls'])
+        S, N = case['W'] * case['H'], 3
+        kinds = R.tile_kinds(S, case['goals'], case['lava'], case['walls'])
+        choice = np.full(N, case['starts'].index(case['start_state']), np.int32)
+        with Engine(N, spec, seed=1) as eng:
+            with pytest.raises(gua.GuError):
+                eng.trail_read(0, 1)  # off by default
+            eng.trail_enable(500)
+            eng.reset(start_choice=choice)
+            for a in case['actions']:
+                if a < 0:
+                    eng.reset()
+                else:
+                    eng.step(np.full(N, a, np.int32))
+            pos = eng.get_state()['pos']
+            assert pos.tolist() == [case['current_state']] * N
+            assert eng.trail_read(0, N) == [case['last_n_states']] * N, case['name']
+            want = R.blend_trail(R.tile_frame(case['W'], case['H'], kinds, px, agent=case['current_state']), case['W'], px,
+                                 [(s, a) for s, a in case['quads']])
+            frames = eng.render_rgb(0, N, px)
+            for e in range(N):
+                assert np.array_equal(frames[e], want), (case['name'], e)
+            # a rollout that keeps no rows cannot feed the trail; the fused sweep + step launches neither
+            with pytest.raises(gua.GuError):
+                eng.rollout(4, 'uniform', True, trajectory=False, stats=True)
+            eng.trail_enable(0)
+            assert np.array_equal(eng.render_rgb(0, 1, px)[0], R.tile_frame(case['W'], case['H'], kinds, px, agent=case['current_state']))
+        if -1 in case['actions']:
+            continue
+        # the same walk as one rollout on the uploaded stream: int32 rows, then packed rows
+        acts = np.repeat(np.asarray(case['actions'], np.int32)[:, None], N, axis=1)
+        for traj in (True, 'packed'):
+            with Engine(N, spec, seed=1) as eng:
+                eng.trail_enable(500)
+                eng.reset(start_choice=choice)
+                eng.upload_actions(acts)
+                eng.reserve_trajectory(len(acts))
+                eng.rollout(len(acts), 'stream', False, trajectory=traj)
+                assert eng.trail_read(0, N) == [case['last_n_states']] * N, (case['name'], traj)
+    # auto-reset: the lazy reset of the step after a done empties the ring -- step by step against one rollout of the same launch
+    spec = GridSpec(4, 4, [0], [15], [5], [])
+    T, N = 300, 130
+    rings = {}
+    for how in ('steps', 'rollout'):
+        with Engine(N, spec, seed=9) as eng:
+            eng.trail_enable(40)
+            eng.reset()
+            eng.reserve_trajectory(T)
+            if how == 'rollout':
+                eng.rollout(T, 'uniform', True, trajectory=True)
+            else:
+                for _ in range(T):
+                    eng.rollout(1, 'uniform', True, trajectory=True)
+            rings[how] = eng.trail_read(0, N)
+            assert all(len(r) <= 40 for r in rings[how]) and any(len(r) < 40 for r in rings[how]) and any(len(r) == 40 for r in rings[how])
+    assert rings['steps'] == rings['rollout']

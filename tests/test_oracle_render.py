@@ -37,3 +37,34 @@ def test_rasterisation_rule_at_the_reference_tile_size():
         assert R.rasterise(geoms, px)[:px // 2].sum() > 0 and R.rasterise(geoms, px)[(px + 1) // 2:].sum() == 0
     assert np.array_equal(R.rasterise(R.arrow_geoms([[0, 0, 1.0, 0]], 1, [], [], []), 52), m[::-1])
     assert np.array_equal(R.rasterise(R.arrow_geoms([[0, 1.0, 0, 0]], 1, [], [], []), 52), m.T[:, ::-1])
+
+
+def test_trail_quads_equal_the_reference():
+    """tests/golden/trail.json: what the reference's own trail loop (rendering.py:287-311, lifted with ast) emitted after the
+    reference env's own step() / reset() calls.  The oracle env keeps the same last_n_states (cap 500, emptied by reset), and
+    oracle/render.trail_quads restates the loop: same tiles, same alphas (float64, exactly), same order."""
+    import json
+    import os
+
+    from oracle import render as R
+    from oracle.ref_env import OracleGridUniverseEnv
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trail.json')))
+    assert (gold['alpha0'], gold['discount']) == (R.TRAIL_ALPHA0, R.TRAIL_DISCOUNT) and len(gold['cases']) >= 5
+    for case in gold['cases']:
+        env = OracleGridUniverseEnv(grid_shape=(case['W'], case['H']), initial_state=list(case['starts']), goal_states=list(case['goals']),
+                                    lava_states=list(case['lava']), walls=list(case['walls']))
+        env.reset()
+        env.current_state = env.previous_state = env.initial_state = case['start_state']  # (a multi-start level draws it from the global RNG)
+        for a in case['actions']:
+            env.reset() if a < 0 else env.step(a)
+        world = {(int(x), int(y)): s for s, (x, y) in enumerate(env.world)}
+        kept = [world[(int(x), int(y))] for x, y in env.last_n_states]
+        assert env.current_state == case['current_state'] and kept == case['last_n_states'], case['name']
+        quads = R.trail_quads(kept, env.current_state)
+        assert [[s, a] for s, a in quads] == case['quads'], case['name']
+        assert [list(c) for c in R.TRAIL_CORNERS] == case['corner_colours']
+    # the blend rule at its edges: alpha 0 leaves the tile, the corner pixels of a large tile approach the corner colours
+    img = np.full((52, 52, 3), 200, np.uint8)
+    assert np.array_equal(R.blend_trail(img.copy(), 1, 52, [(0, 0.0)]), img)
+    full = R.blend_trail(np.zeros((52, 52, 3), np.uint8), 1, 52, [(0, 1.0)])
+    assert tuple(full[51, 0]) == (253, 2, 2) and tuple(full[51, 51]) == (253, 253, 0) and tuple(full[0, 51]) == (2, 253, 2) and tuple(full[0, 0]) == (2, 2, 250)

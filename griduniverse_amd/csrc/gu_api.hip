@@ -647,7 +647,7 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done)
 // ---------------------------------------------------------------------------------- rollout
 // Where a large buffer lands in HBM decides how fast it can be written: the SAME store kernel, on the same GPU at the same
 // clocks, writes twelve 786 MB allocations of one process at 5.7 .. 6.9 TB/s -- each buffer at its own, stable rate
-// (tools/micro/store_placement.hip, profiles/r02f_store_placement.txt; this, not the device, is the "box-to-box" spread of
+// (tools/micro/store_placement.hip, profiles/archive/r02f_store_placement.txt; this, not the device, is the "box-to-box" spread of
 // the rollout kernel: 117 .. 141 us per launch).  So a large trajectory buffer is CHOSEN: a few candidate allocations are
 // written once in the rollout's own store shape, timed with events, and the fastest one is kept.  A one-off cost of a few
 // milliseconds at reservation; GU_OPT_TRAJ_CANDIDATES = 1 turns it off.  What the search may hold and when it gives up is
@@ -677,7 +677,7 @@ static hipError_t gu_traj_malloc(gu_engine *h, int32_t **p, size_t bytes)
 #ifdef GU_EXPERIMENTS
     // EXPERIMENT (libgu_exp.so only): the trajectory buffer with the uncached memory type (MTYPE_UC: stores do not allocate in
     // L2).  The rollout kernel runs 8 % faster on it -- 112 against 121 .. 124 us per 65 536 x 1000 launch
-    // (profiles/r02i_uncached_ab.txt) -- but kernels that READ such a buffer can see stale bytes
+    // (profiles/archive/r02i_uncached_ab.txt) -- but kernels that READ such a buffer can see stale bytes
     // (tests/test_gpu_mc.py::test_chunk_boundaries_do_not_change_the_result fails reproducibly when an earlier engine of the
     // process has used the same memory), and nothing in user space can flush that.  A library whose
     // contract is bit-exactness does not ship the mode: the product build has no code for it.

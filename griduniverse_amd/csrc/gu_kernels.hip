@@ -15,7 +15,7 @@
 // integer work: no MFMA, and no inter-block reuse apart from the <=64 KiB record planes that
 // every XCD's L2 holds after first touch -- so there is nothing for an XCD-aware block remap to
 // win here; the grid is N/256 four-wave workgroups (at N = 65 536 that is one workgroup per CU,
-// one wave per SIMD; measured 3 % faster than 1024 one-wave workgroups, profiles/r01b_bench_blocksize.txt).
+// one wave per SIMD; measured 3 % faster than 1024 one-wave workgroups, profiles/archive/r01b_bench_blocksize.txt).
 //
 // The action -> delta LUT is four int16 lanes of one 64-bit scalar register (v_lshrrev_b64 +
 // v_bfe_i32): staging a 4-entry table in LDS instead would put a second, dependent ds_read on
@@ -477,7 +477,7 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
         return GU_OK;
     }
     // The device must be at its working clocks first.  A calibration right after start-up, on a GPU still ramping up from idle,
-    // sees a slower kernel and a different cliff (profiles/r03f_pace_warmup.txt).  The ramp is gradual -- successive launches agree
+    // sees a slower kernel and a different cliff (profiles/archive/r03f_pace_warmup.txt).  The ramp is gradual -- successive launches agree
     // within 1 % all along it -- so: unpaced launches until the mean of the last 16 agrees with the mean of the 16 before within
     // 0.4 %, for at least 30 ms when the device has not been running rollouts in the last 50 ms, 150 ms at most.
     {
@@ -594,7 +594,7 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
 // batches of more than four waves per SIMD are not paced and not calibrated.
 // (Until r03o a batch of more than one wave per SIMD was also tried as several launches in a row of one wave per SIMD each: the
 // idle-turn limiter had nothing to work with at four waves per SIMD.  The schedule has -- 262 144 envs in ONE launch 0.44 .. 0.48 ms,
-// as four launches in a row 0.56 .. 0.59, profiles/r03o_c4_split.txt -- and that form is gone.)
+// as four launches in a row 0.56 .. 0.59, profiles/archive/r03o_c4_split.txt -- and that form is gone.)
 // WHEN it is calibrated (round 4).  The search costs a few hundred full-size launches (374 = 52 ms at the headline size) and saves ~10 % of each later one: it pays for itself
 // only after a few thousand launches of that kind.  So, with GU_OPT_ROLLOUT_PACE at its default (-1):
 //   * a period this PROCESS already found for the same launch shape (device, batch, length class, policy, auto-reset, kernel, row bytes,
@@ -616,7 +616,7 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_byte
     }
     // (T < 64: fewer than four groups to schedule.  More than four waves per SIMD -- 524 288 envs and more on 256 CUs --: a per-wave
     // schedule found nothing to gain there, 0.96 .. 0.98 ms = 6.4 .. 6.6 TB/s with and without, and a batch that does not fit the
-    // device at once is not on one schedule anyway; profiles/r03n_batch_sizes.txt)
+    // device at once is not on one schedule anyway; profiles/archive/r03n_batch_sizes.txt)
     if ((double)h->N * (double)T * (double)row_bytes < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024) return GU_OK;
     gu_engine::PaceRecord &rec = h->pace[slot];
     const bool current = rec.known && rec.buffer == (const void *)h->d_traj && rec.blocks == blocks && !(T > 2 * rec.T || 2 * T < rec.T);

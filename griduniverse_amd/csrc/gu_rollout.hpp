@@ -5,11 +5,12 @@
 #include "gu_map.hpp"
 
 #include <cstdlib>
+#include <functional>
 
 // ------------------------------------------------------------------------------------
 // fused rollout: T env-steps per lane in one launch
 //   algorithmic HBM bytes per env-step with GU_F_TRAJECTORY: 3 x 4 B row writes = 12 B
-//   (+4 B action read for GU_POLICY_STREAM); state is loaded/stored once per launch.
+//   (+0.25 B for GU_POLICY_STREAM: the caller's actions are read packed, two bits each); state is loaded/stored once per launch.
 // ------------------------------------------------------------------------------------
 // Inverse CDF on one 32-bit word: a = #{k < 3 : word >= t_k} over the thresholds that a word can reach.  A threshold that no
 // word reaches (cumulative probability >= 1: every one-hot or zero-tailed row has some) is stored as 0 -- which every word
@@ -51,7 +52,7 @@ struct RolloutArgs {
 // (s_memrealtime, 10 ns) per 16 steps; a wave may begin its next group of steps no earlier than its own start + steps done x
 // pace / 16, and does not wait at all when it is late.
 //
-// WHY (round 3; tools/micro/store_pacing.hip, write_ceiling.hip, store_deadline.hip, tools/pace_ab.py, profiles/r03d_*, r03k_*):
+// WHY (round 3; tools/micro/store_pacing.hip, write_ceiling.hip, store_deadline.hip, tools/pace_ab.py, profiles/archive/r03d_*, r03k_*):
 // the HBM write path of an MI355X shows CONGESTION COLLAPSE.  65 536 lanes that hand their three rows per step to the memory
 // system as fast as it will take them keep every queue on the way full, and the sustained rate then DROPS: to 5.7 TB/s on most
 // allocations (round 2's "slow class"), 6.6 on some.  The same stores offered just below the memory's capacity go through at
@@ -153,18 +154,18 @@ __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint3
 //       (a fifth variant -- one dword record per cell replicated 32 times, so that the per-step gather is free of LDS bank
 //       conflicts -- was built and measured SLOWER than variant 1 at every batch size but one, 66.8 against 62.3 us for the
 //       stats-only launch of config 3: the conflicts (SQ_LDS_BANK_CONFLICT ~ 7 cycles per gather) are not what bounds the
-//       latency-bound modes, the length of the dependent chain is; profiles/r02b_map_ab.txt.  What shortens the chain is the
+//       latency-bound modes, the length of the dependent chain is; profiles/archive/r02b_map_ab.txt.  What shortens the chain is the
 //       transition-row table of gu_rollout_rows.hip.)
 #define GU_PRIVATE_PAD 16
 // Cache-policy bits of the trajectory stores (buffer_store aux: 1 = sc0, 2 = nt, 16 = sc1).  The int32 rows go out with sc1 + nt:
 // written through at device scope instead of staying dirty in the L2 until they are evicted, and marked as streaming -- the rows
 // are never read again by the launch, and the memory then sees them in the order the waves issue them, not in the L2's eviction
 // order.  Measured with library variants, 24 buffers each, processes interleaved.  Under the first (idle-turn) limiter
-// (profiles/r03k_store_scope.txt): 119.4 us without, 116.4 with sc1, 115.3 with sc0 + sc1, 119.2 with nt alone, 116.1 with all
-// three.  Under the schedule limiter (profiles/r03p_store_scope_schedule.txt, two boxes): default policy 114.4, nt alone 110.5, sc1
+// (profiles/archive/r03k_store_scope.txt): 119.4 us without, 116.4 with sc1, 115.3 with sc0 + sc1, 119.2 with nt alone, 116.1 with all
+// three.  Under the schedule limiter (profiles/archive/r03p_store_scope_schedule.txt, two boxes): default policy 114.4, nt alone 110.5, sc1
 // 110.7 / 109.0, sc0 + sc1 110.3, sc1 + nt 107.6 / 108.1, all three 108.2 -- on slow allocations sc1 111.2 .. 111.5 against 107.8 ..
 // 108.2 with sc1 + nt, on fast ones no difference (107.1 / 107.7).  The packed row (4 B per env-step, transition-row kernel: 45 us
-// per 65 536 x 1000 launch) gains from sc1 too: 1.35e12 -> 1.44e12 env-steps/s, three runs each (profiles/r03m_packed_sc1.txt).
+// per 65 536 x 1000 launch) gains from sc1 too: 1.35e12 -> 1.44e12 env-steps/s, three runs each (profiles/archive/r03m_packed_sc1.txt).
 #ifndef GU_STORE_AUX
 #define GU_STORE_AUX 18
 #endif
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             // lazy `if done: env.reset()` (env:187-193) with a single start cell: two selects keyed directly on the
             // TERM bit of the record that just arrived (no separate done register on the dependent chain).  A variant
             // that precomputes the move from the start cell off the chain was measured slower at every occupancy
-            // (profiles/r01e_auto_form_ab.txt).
+            // (profiles/archive/r01e_auto_form_ab.txt).
             const bool was_done = flags & GU_CELL_TERM;
             ep += was_done;
             s = was_done ? start0 : s;

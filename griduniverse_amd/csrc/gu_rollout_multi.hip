@@ -251,7 +251,7 @@ static int multi_mode(const gu_engine *h) { return (int)gu_opt(h, GU_OPT_ROLLOUT
 // batch needs on 256 CUs
 static bool multi_shape(const gu_engine *h, int *K, int *block, int *copies)
 {
-    // diagnostics: force K, replicate the table (a second copy across the banks buys nothing: profiles/r02h_multi_ab.txt)
+    // diagnostics: force K, replicate the table (a second copy across the banks buys nothing: profiles/archive/r02h_multi_ab.txt)
     const int only = (int)gu_opt(h, GU_OPT_ROLLOUT_MULTI_K), max_copies = gu_opt(h, GU_OPT_ROLLOUT_MULTI_COPIES) == 2 ? 2 : 1;
     for (int bs = 256; bs <= GU_MAX_BLOCK; bs <<= 1) {
         const int64_t blocks = (h->N + bs - 1) / bs, per_cu = (blocks + h->n_cu - 1) / h->n_cu;

@@ -25,7 +25,7 @@
 //                                 threshold gather, the compares, the move, and a second gather for the record)
 //
 // Results are bit-identical to the general kernel (tests/test_gpu_round2.py runs both on the same seeds); the launcher
-// picks this one where it is faster (profiles/r02b_map_ab.txt, profiles/r02d_rows_crossover.txt).
+// picks this one where it is faster (profiles/archive/r02b_map_ab.txt, profiles/archive/r02d_rows_crossover.txt).
 #include "gu_rollout.hpp"
 
 #define GU_ROW_ADDR_MASK 0xFFFFFu
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) gu_build_policy_rows_kernel(const BuildPo
 // launch, the steps up to the next 16-step word, the last T mod 16) run on a one-step table of the same record format that sits
 // behind the pair table in LDS (144 bytes per cell in all: grids of up to ~1100 cells, one workgroup per CU).  What it buys:
 // launches bound by the dependent chain, not by the write path -- packed rows at 65 536 envs, int32 rows at a config-4 shard of
-// 32 768 envs (profiles/r03r_pair_rows.txt).
+// 32 768 envs (profiles/archive/r03r_pair_rows.txt).
 __device__ __forceinline__ uint32_t gu_row_record(const uint8_t *cell, int32_t cell_bytes, int32_t base, uint32_t act, int32_t W, int32_t row_shift);
 
 struct BuildPairRowsArgs {
@@ -418,9 +418,9 @@ static bool rows_shape(const gu_engine *h, int row_bytes, int max_copies, int *b
 {
     if (h->n_grids != 1) return false;
     // the smallest workgroup that fits, with as many copies as its LDS share admits (the copy count matters little once the
-    // table is staged with wide, pipelined stores; the workgroup size does: profiles/r02e_rows_copies.txt)
+    // table is staged with wide, pipelined stores; the workgroup size does: profiles/archive/r02e_rows_copies.txt)
     // (128- and 64-thread workgroups, which spread a 32 768-env launch over all CUs instead of half of them, are no faster: 70 .. 72 us
-    // either way, profiles/r03h_rows_block.txt)
+    // either way, profiles/archive/r03h_rows_block.txt)
     for (int bs = 256; bs <= GU_MAX_BLOCK; bs <<= 1) {
         const int64_t blocks = (h->N + bs - 1) / bs, per_cu = (blocks + h->n_cu - 1) / h->n_cu;
         for (int c = max_copies; c >= 1; c >>= 1) {
@@ -472,7 +472,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return false;
     if (auto_mode == 2) return false;  // several start cells: the reset draws from the RNG, it cannot be tabulated
     const int mode = rows_mode(h);
-    // Default policy (profiles/r02b_map_ab.txt, profiles/r02d_rows_crossover.txt, profiles/r02e_policy_rows.txt; interleaved
+    // Default policy (profiles/archive/r02b_map_ab.txt, profiles/archive/r02d_rows_crossover.txt, profiles/archive/r02e_policy_rows.txt; interleaved
     // A/B in one process): every launch that is bound by the dependent chain rather than by the HBM write path --
     //   stats only           : every batch size (uniform: 62 -> 40 us at 65 536 envs, 68 -> 35 us at 262 144)
     //   packed rows (4 B)    : up to one 256-env workgroup per CU (83 -> 51 us at 65 536 envs; 103 against 111 us at 131 072)
@@ -488,7 +488,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         const unsigned blocks = gu_blocks(h->N, 256);
         // (a caller-supplied stream with int32 rows: the row-table kernel reads its action words straight from HBM, and a load
         // among streaming stores waits for all of them -- beyond 16 384 envs the general kernel, which stages the words in LDS,
-        // is the quicker one: 88 against 116 us at 32 768 envs, profiles/r02j_stream_crossover.txt)
+        // is the quicker one: 88 against 116 us at 32 768 envs, profiles/archive/r02j_stream_crossover.txt)
         // (measured on the 256 CUs of an MI355X; stated relative to the CU count: one workgroup per CU, a quarter, half of them)
         const unsigned cus = (unsigned)h->n_cu;
         // (round 3, under the schedule limiter, 65 536 envs with int32 rows, profiles/r03s_rows_vs_general.txt: greedy with auto-reset
@@ -540,7 +540,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     // faster on the one-step table -- 58 .. 61 against 65 us at 32 768 envs, 110 against 115 at 65 536: six stores and two records'
     // worth of unpacking per round trip cost what the shorter chain saves, and those launches are close to the write path's rate
     // anyway; without rows the K-step kernel of gu_rollout_multi.hip is the tool), one 256-lane workgroup per CU at most (144 bytes
-    // of LDS per cell).  GU_OPT_ROLLOUT_ROWS = 2 keeps the one-step table (A/B, tests).  profiles/r03r_pair_rows.txt
+    // of LDS per cell).  GU_OPT_ROLLOUT_ROWS = 2 keeps the one-step table (A/B, tests).  profiles/archive/r03r_pair_rows.txt
     bool pair = !table_policy && traj == 2 && mode != 2 && gu_blocks(h->N, 256) <= (unsigned)h->n_cu && (int64_t)h->S * 144 <= h->lds_per_cu - 2048 &&
                 ((int64_t)h->S << GU_PAIR_SHIFT) <= (int64_t)GU_ROW_ADDR_MASK;
     if (pair) {

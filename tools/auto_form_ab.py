@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of two single-start auto-reset forms of the rollout kernel (GU_AUTO_FORM=1: reset candidate computed off
 the dependent chain; 3: plain selects keyed on the TERM bit), stats-only and trajectory rollouts, two batch sizes.
-Result (profiles/r01e_auto_form_ab.txt): form 3 wins everywhere (61.9 vs 64.6-65.4 us stats-only at 65 536 envs) and
+Result (profiles/archive/r01e_auto_form_ab.txt): form 3 wins everywhere (61.9 vs 64.6-65.4 us stats-only at 65 536 envs) and
 is the one the library keeps; the GU_AUTO_FORM switch was removed, so this script is a record of the experiment."""
 import os
 import random

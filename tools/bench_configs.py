@@ -79,7 +79,8 @@ def paths(name, template, N, T=1000, reps=20):
     eng.reserve_trajectory(Ts)
     wall, dev = timed(eng, lambda: eng.rollout(Ts, 'stream', True, True), reps)
     out['rollout_stream_steps_per_s'] = N * Ts * reps / wall
-    out['rollout_stream_GBps_16B'] = 16 * N * Ts * reps / dev / 1e9
+    # (the stream kernel reads PACKED actions, two bits each: 12 B of rows + 0.25 B of actions per env-step)
+    out['rollout_stream_GBps_12.25B'] = 12.25 * N * Ts * reps / dev / 1e9
     # one launch per env-step, actions already in HBM (eager launches vs one hipGraph replay)
     def eager():
         for t in range(Ts):

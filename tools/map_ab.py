@@ -22,7 +22,7 @@ def sw(rep='0', rows='0', xcd='0', block='256'):
 VARIANTS = [('planes', sw()), ('planes+xcd', sw(xcd='1')), ('planes/1024', sw(block='1024')), ('planes/1024+xcd', sw(block='1024', xcd='1')),
             ('rows', sw(rows='1')), ('rows+xcd', sw(rows='1', xcd='1'))]
 # ('replicated', GU_ROLLOUT_REP=1: one dword record per cell replicated 32x, conflict-free) was part of this A/B in round 2 and
-# lost to 'planes' (profiles/r02b_map_ab.txt); the variant and its switch were removed from the library afterwards.
+# lost to 'planes' (profiles/archive/r02b_map_ab.txt); the variant and its switch were removed from the library afterwards.
 if len(sys.argv) > 1:
     VARIANTS = [v for v in VARIANTS if v[0] in sys.argv[1:]]
 

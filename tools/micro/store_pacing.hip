@@ -1,7 +1,7 @@
 // store_pacing.hip -- does the PACE at which a wave hands its three trajectory stores to the memory system matter?  (tuning
 // evidence, not product code; round 3)
 //
-// Round 2 found (profiles/r02g_store_sleep_spacing.txt) that the bare three-store loop runs at 113..117 us per 65 536 x 1000
+// Round 2 found (profiles/archive/r02g_store_sleep_spacing.txt) that the bare three-store loop runs at 113..117 us per 65 536 x 1000
 // launch on buffers of the SLOW write-rate class (134..136 us unpaced) once an `s_sleep 1` separates the three stores -- and that
 // the same sleeps made the rollout kernel slower.  This file measures, per buffer of one process (so that both classes show up):
 //   bare<G>     : the bare loop, the three stores of a step separated by G idle clocks (s_nop)
@@ -12,7 +12,7 @@
 //   paced / spread / pipe : the stores spread over the step (LDS waits or fixed gaps between them; the rows of step t - 1 during step t)
 //   tailx       : tail + a workgroup barrier per step and / or the XCD-aware block order
 //   timer, timer2 : a per-wave deadline on the shader clock (s_memtime), read on / off the critical path
-// FINDINGS (profiles/r03d_store_pacing_*.txt): only the average rate matters (burst 176 = bare g64 = 110 .. 116 us on every buffer
+// FINDINGS (profiles/archive/r03d_store_pacing_*.txt): only the average rate matters (burst 176 = bare g64 = 110 .. 116 us on every buffer
 // against 115 .. 139 us unpaced); the window is narrow (burst 160: collapse on slow buffers again; burst 192: 118 .. 121 everywhere);
 // LDS waits do not pace well; fixed gaps that idle the wave while its own chain waits are too expensive (pipe); a clock read per
 // step costs more than it saves; a barrier per step works in this micro-kernel (122 .. 125 us everywhere) but not in the product's
@@ -441,7 +441,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     Args a{};
     a.cells = dc; a.checksum = dsum; a.N = N; a.T = T; a.start = 0;
-    // variant sets (the profiles/r03d_store_pacing_*.txt files, in the order they were recorded); first_rollout: where the variants
+    // variant sets (the profiles/archive/r03d_store_pacing_*.txt files, in the order they were recorded); first_rollout: where the variants
     // that compute the rollout -- and must agree on its checksum -- begin
     struct Variant { const char *name; std::function<void(dim3, dim3)> launch; };
 #define BARE(G) {"bare g" #G, [&](dim3 g, dim3 b) { k_bare<G><<<g, b>>>(a); }}

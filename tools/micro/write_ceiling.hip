@@ -1,7 +1,7 @@
 // write_ceiling.hip -- what is the highest rate at which ANY rate-limited store stream writes HBM on this device?  (tuning evidence,
 // not product code; round 3)
 //
-// Round 1's store-ceiling table (profiles/r01b_store_ceiling.txt: 5.0 .. 6.0 TB/s whatever the store width, block size or cache
+// Round 1's store-ceiling table (profiles/archive/r01b_store_ceiling.txt: 5.0 .. 6.0 TB/s whatever the store width, block size or cache
 // policy) was measured before round 3 found that an over-driven store stream collapses: all of its rows are
 // collapsed streams.  This file repeats the question with the limiter in place.  One kernel writes 786 MB (the bench launch's
 // bytes) as `planes` planes of [T][N] int32, a lane owning VEC adjacent columns (one dword / dwordx2 / dwordx4 store per plane and

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of a GU_TRAJ_SKEW knob (skew between the obs/reward/done trajectory planes, in int32 elements)
 for the bench launch: interleaved rounds, median and min per setting (cdna_hip_programming.md 5.4 rule 24).
-Result (profiles/r01c_traj_skew_ab.txt): no setting helps -- every skew sits at 139-145 us with occasional 120 us
+Result (profiles/archive/r01c_traj_skew_ab.txt): no setting helps -- every skew sits at 139-145 us with occasional 120 us
 samples right after an idle gap (clock boost), so the knob was removed from the library again; this script is kept
 as the record of the experiment and no longer has an effect."""
 import os

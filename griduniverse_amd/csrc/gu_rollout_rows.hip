@@ -24,6 +24,13 @@
 //                                 threshold compares and a three-select pick of the next record (the general kernel: a
 //                                 threshold gather, the compares, the move, and a second gather for the record)
 //
+// Store waves -- a second half of the workgroup that drains an LDS ring of records and issues the rows' stores, so that the stepping
+// waves' in-order instruction stream carries neither the stores nor their stalls -- were built in round 4 and measured SLOWER for
+// every launch whose chain is short (uniform / greedy at 4096 .. 32 768 envs: 75 against 50 .. 60 us per 1000 steps: the hand-over
+// itself, a produced / consumed count pair per wave and eight records per group, costs ~180 clocks per step) and no faster where the
+// chain is long (sampled policy at 65 536 envs: 130 against 128; 110 against 117 at 32 768): profiles/r04s_rows_store_waves_ab.json.
+// Removed again; the sampled launch with int32 rows stays bound by its one wave per SIMD issuing chain and stores in order.
+//
 // Results are bit-identical to the general kernel (tests/test_gpu_round2.py runs both on the same seeds); the launcher
 // picks this one where it is faster (profiles/archive/r02b_map_ab.txt, profiles/archive/r02d_rows_crossover.txt).
 #include "gu_rollout.hpp"

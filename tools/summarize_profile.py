@@ -18,8 +18,11 @@ BENCH_KERNEL = 'gu_rollout_kernel<'
 MODES = {
     'headline': lambda name, grid: 'gu_rollout_kernel<' in name and grid == 65536,
     'strong_c4': lambda name, grid: 'gu_rollout_kernel<' in name and grid == 262144,
-    'packed_rows': lambda name, grid: 'gu_rollout_rows_kernel<' in name and grid == 65536,
+    'packed_rows': lambda name, grid: 'gu_rollout_rows_kernel<0, 2,' in name and grid == 65536,   # <uniform, packed rows, ...>
     'stats_only': lambda name, grid: 'gu_rollout_multi_kernel<' in name and grid == 65536,
+    'rollout_sample_policy_traj': lambda name, grid: 'gu_rollout_rows_kernel<3, 1,' in name and grid == 65536,  # <sampled, int32 rows, ...>
+    'rollout_sample_policy_stats_only': lambda name, grid: 'gu_rollout_rows_kernel<3, 0,' in name and grid == 65536,
+    'c5_rounds_in_one_launch': lambda name, grid: 'gu_vi_sweep_step_xcd_kernel<' in name,
 }
 
 

@@ -91,9 +91,16 @@ def main():
                 if g == 65536:
                     seq['stats_only'].append((g, v))
             elif 'gu_rollout_rows_kernel<' in n:
-                names['packed_rows'] = n
-                if g == 65536:
-                    seq['packed_rows'].append((g, v))
+                # <policy, rows, ...>: uniform with packed rows / sampled with int32 rows / sampled, statistics only (other_modes);
+                # the int32-row launches of configs 2 and 4-shard run on this kernel at other batch sizes
+                form = ('packed_rows' if '<0, 2,' in n else 'rollout_sample_policy_traj' if '<3, 1,' in n
+                        else 'rollout_sample_policy_stats_only' if '<3, 0,' in n else None)
+                if form and g == 65536:
+                    names[form] = n
+                    seq[form].append((g, v))
+            elif 'gu_vi_sweep_step_xcd_kernel<' in n:
+                names['c5_rounds_in_one_launch'] = n
+                seq['c5_rounds_in_one_launch'].append((g, v))
             elif 'gu_rollout_kernel<' in n:
                 names.setdefault('general', n)
                 if marker is None or i < marker:

@@ -261,8 +261,11 @@ struct GuXcdPlan {
     size_t lds = 0, slots_bytes = 0, work_bytes = 0;  // dynamic LDS; scratch: delta-key slots (all XCCs), granule buffers (per XCC)
 };
 struct ViStepXcdArgs;
-bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan);
-int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a);
+#define GU_VI_FALLBACK 1  /* internal: a one-launch DP form did not apply or gave up, the tables are as they were -- take the next form */
+bool gu_vi_xcd_plan(const gu_engine *h, bool agents, GuXcdPlan *plan);
+int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a, bool agents, bool greedy);
+int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds, int32_t *rounds_done,
+                     double *deltas);
 
 // ---- agent trail (gu_trail.hip): no-ops while the trail is off ----------------------
 int gu_trail_after_step(gu_engine *h, uint32_t flags);

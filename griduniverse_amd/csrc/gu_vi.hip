@@ -652,6 +652,18 @@ static ViArgs vi_args(gu_engine *h, double gamma, unsigned long long *delta_key)
 
 // The single-workgroup path: grids of up to VI_PB_MAX_STATES states (GU_OPT_VI_PATH = 2 forces the per-round
 // launches, for the tests).  Runs up to max_rounds rounds in place on the current tables.
+// Grids of GU_VI_XCD_MIN_STATES states and more take the per-XCD launch first (gu_vi_xcd.hip): ~1.1 us per round whatever the size,
+// against 1.4 (8x8) .. 5 us (64x64) in one workgroup and ~4 us behind the chip-wide barrier; below, one workgroup is as quick and
+// starts without the chip-wide registration wait.
+#ifndef GU_VI_XCD_MIN_STATES
+#define GU_VI_XCD_MIN_STATES 1536
+#endif
+static bool vi_xcd_preferred(const gu_engine *h)
+{
+    const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
+    return (path == 0 || path == 5) && h->S >= GU_VI_XCD_MIN_STATES;
+}
+
 static bool vi_block_eligible(const gu_engine *h)
 {
     return h->S <= VI_PB_MAX_STATES && gu_opt(h, GU_OPT_VI_PATH) != 2;
@@ -702,7 +714,6 @@ static int vi_block_run(gu_engine *h, double gamma, double threshold, bool use_t
 // one-launch-per-round path instead, for the tests and A/B runs; so does a device with too few CUs for the workgroups to be
 // resident together -- a CPX partition, a CU mask, a smaller part).  Runs up to max_rounds rounds; the value table ends in
 // d_v[vi_cur] (buffers swapped on an odd round count), the policy is updated in place.
-#define GU_VI_FALLBACK 1  /* internal: the cluster launch did not complete, the tables are as they were -- take the other path */
 
 static bool vi_cluster_shape(const gu_engine *h, int *K_out, unsigned *G_out)
 {
@@ -825,6 +836,11 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(iters > 0 && iters <= 4096, GU_ERR_INVALID, "iters must be in 1..4096 per call");
+    if (vi_xcd_preferred(h)) {  // one launch of one XCD's workgroups, nothing leaves that XCD's L2 (gu_vi_xcd.hip)
+        int32_t done = 0;
+        rc = gu_vi_xcd_dp_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
+        if (rc != GU_VI_FALLBACK) return rc;
+    }
     if (vi_block_eligible(h)) {
         int32_t done = 0;
         return vi_block_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
@@ -870,6 +886,10 @@ int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, in
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
+    if (vi_xcd_preferred(h)) {
+        rc = gu_vi_xcd_dp_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
+        if (rc != GU_VI_FALLBACK) return rc;
+    }
     if (vi_block_eligible(h)) return vi_block_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
     if (vi_cluster_eligible(h)) {
         rc = vi_cluster_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
@@ -932,6 +952,10 @@ int gu_vi_eval_run(gu_handle h, double gamma, double threshold, int32_t max_step
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
+    if (vi_xcd_preferred(h)) {
+        rc = gu_vi_xcd_dp_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
+        if (rc != GU_VI_FALLBACK) return rc;
+    }
     if (vi_block_eligible(h)) return vi_block_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
     if (vi_cluster_eligible(h)) {
         rc = vi_cluster_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
@@ -1065,7 +1089,7 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
     // one launch per round.  The one-launch forms work on a snapshot's ORIGINAL: a form that gives up (every spin in them is bounded)
     // leaves half-advanced state, which is put back before the next form runs.
     GuXcdPlan xp{};
-    const bool try_xcd = (path == 0 || path == 5) && gu_vi_xcd_plan(h, &xp);
+    const bool try_xcd = (path == 0 || path == 5) && gu_vi_xcd_plan(h, true, &xp);
     const bool try_cluster = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && G <= (h->n_cu < VI_CL_MAX_WGS ? h->n_cu : VI_CL_MAX_WGS) &&
                              (path == 0 || path == 3 || path == 4 || path == 5);
     if (try_xcd || try_cluster) {
@@ -1111,7 +1135,7 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
                 a.work_bytes = (uint32_t)xp.work_bytes;
                 GU_HIP(hipMemsetAsync(a.gx, 0, 8 * xp.work_bytes, h->stream));  // every word that crosses workgroups is tagged with its round: no tag of an earlier launch may be left
                 a.inject_failure = path == 5;  // tests: the per-XCD form gives up
-                if ((rc = gu_vi_xcd_launch(h, xp, a)) != GU_OK) return rc;
+                if ((rc = gu_vi_xcd_launch(h, xp, a, true, true)) != GU_OK) return rc;
             } else {
                 if (path == 3) GU_HIP(hipMemsetD32Async((hipDeviceptr_t)(hdr_d + 1), 1, 1, h->stream));  // tests: an injected timeout
                 hipLaunchKernelGGL(gu_vi_sweep_step_cluster_kernel, dim3((unsigned)G), dim3(VI_CL_THREADS), 2 * (size_t)h->cell_bytes, h->stream,

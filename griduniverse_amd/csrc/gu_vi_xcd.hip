@@ -44,7 +44,10 @@
 #include "gu_rng.hpp"
 #include "gu_vi.hpp"
 
+#include <cstdio>
+#include <cstring>
 #include <type_traits>
+#include <vector>
 
 #define VI_XCD_MAX_XCC 8
 #define VI_XCD_SLOTS 64                      /* workgroups of one cluster at most */
@@ -106,10 +109,17 @@ __device__ __forceinline__ vi_u64 vi_wave_max_last(vi_u64 k)
 #endif
 
 // K = states per thread at most.  Launched with 256, 512 or 1024 threads per workgroup.
-template <int K>
-__global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStepXcdArgs a)
+// AGENTS: config 5, the loop described above.  !AGENTS: the tables alone -- gu_vi_sweep / gu_vi_run / gu_vi_eval_run on grids whose
+// planes and values fit one workgroup's LDS: the workgroups of ONE cluster (the XCD of workgroup 0; the others leave after the
+// registration) run { V1; delta; V2 if GREEDY } with the stopping rule of value_iteration / of policy_iteration's evaluation loop
+// (dynamic_programming.py:14-27, 40-42) decided in the kernel: every workgroup waits for every member's delta key of the round --
+// posted with the round's values, fetched beside them -- so all of them stop behind the same round.
+template <int K, bool AGENTS, bool GREEDY>
+__global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
 {
+    static_assert(!AGENTS || GREEDY, "the agents follow the greedy policy of the round");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ vi_u64 round_key_lds;  // !AGENTS: the cluster's delta key of the round
     __shared__ uint32_t info[4];  // [0] XCC id, [1] rank in the cluster, [2] members, [3] bit 0: failed, bit 1: this cluster writes the tables
     const ViMap cell = vi_stage<true>(a.vi.cell, a.vi.cell_bytes, smem);  // the agents gather records of arbitrary cells
     double *vL = reinterpret_cast<double *>(smem + 2 * a.vi.cell_bytes);  // [S2 + 2] values: the own chunk and a grid row either side are kept current (+ a spare slot); then the action words
@@ -158,6 +168,7 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     vi_u64 *slots = a.slots + (size_t)xcc * 4 * VI_XCD_SLOTS * 2;   // [round & 3][member][2]
     uint8_t *gx = a.gx + (size_t)xcc * a.work_bytes;                // this cluster's granules: [2][S] values | [2][n_aw] action items
 
+    if (!AGENTS && !writes_tables) return;  // the tables need ONE cluster (every member of the others decides the same: no one waits for them)
     const int32_t lo = (int32_t)rank * chunk, hi = lo + chunk < S ? lo + chunk : S;  // this workgroup's states [lo, hi)
 
     // ---- per-state constants, the initial table, the own envs ----
@@ -191,13 +202,13 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     const int32_t own_states = lo < S ? (chunk < S - lo ? chunk : S - lo) : 0;                // states of this workgroup
     const int32_t state_waves = K == 1 ? (own_states + 63) >> 6 : (own_states > 0 ? waves : 0);
     const bool split = K == 1 && 2 * state_waves <= waves;
-    const bool has_envs = !split || wave >= state_waves;  // (wave-uniform)
+    const bool has_envs = AGENTS && (!split || wave >= state_waves);  // (wave-uniform)
     int64_t gid[2];
     bool own_env[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int32_t block = split ? 2 * (wave - state_waves) + e : wave;  // which 64 envs of the workgroup's B
-        const bool mine = split ? (wave >= state_waves && block < waves) : e == 0;
+        const bool mine = AGENTS && (split ? (wave >= state_waves && block < waves) : e == 0);
         gid[e] = (int64_t)blockIdx.x * B + (int64_t)block * 64 + lane;
         own_env[e] = mine && gid[e] < a.N;
     }
@@ -227,6 +238,11 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     const uint64_t stamp_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const bool keeps_deltas = writes_tables && rank == 0;
+    // The tables alone: every workgroup takes in every member's delta key every round -- the stopping rule needs it before the next
+    // round, and it is what keeps the members within a round of each other (their values only tie neighbours together: without it a
+    // far member could run a dozen rounds ahead and overwrite its four-deep key slots before they are collected).  With agents the
+    // action words tie every workgroup to every other one anyway, and workgroup 0 collects the keys a round late.
+    const bool sync_delta = !AGENTS;
     // What a round fetches, in 16-byte items: the value granules of one grid row either side of the own chunk (the chunk's own
     // values go from registers to LDS), then the action words, two per item.
     const int32_t below0 = lo - W > 0 ? lo - W : 0, n_below = lo < S ? lo - below0 : 0;    // states [below0, lo)
@@ -238,7 +254,7 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
     // The items this thread fetches are the same every round: source (parity 0), destination in LDS and kind are worked out ONCE
     // (computed inside the loop, the selects and bounds of this bookkeeping were three quarters of the fetch's 1900 clocks).
     // kind: 0 = none, 1 = value granule, 2 = action item with two words, 3 = action item whose second word does not exist.
-    const int32_t n_items = n_below + n_above + n_aw;
+    const int32_t n_items = n_below + n_above + (AGENTS ? n_aw : 0);
     uint32_t it_src[4], it_dst[4], it_kind[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -344,7 +360,7 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
             d_lo = vi_ld_l2(slot + 2 * lane + 1);
         }
     };
-    auto delta_finish = [&](int32_t rr) {
+    auto delta_finish = [&](int32_t rr) -> vi_u64 {
         const uint32_t tag = (uint32_t)rr + 1u;
         const bool polls = (uint32_t)lane < members;
         uint32_t spins = 0;
@@ -355,17 +371,12 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
                     __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     atomicOr(&info[3], 1u);
                 }
-                return;
+                return 0ull;
             }
             __builtin_amdgcn_s_sleep(1);
             delta_load(rr);
         }
-        const vi_u64 k = vi_wave_max_last(polls ? (d_hi & 0xFFFFFFFF00000000ull) | (d_lo >> 32) : 0ull);
-#ifndef GU_VI_XCD_STAMPS
-        if (lane == 63) a.vi.delta_key[rr] = k;
-#else
-        asm volatile("" ::"v"(k));
-#endif
+        return vi_wave_max_last(polls ? (d_hi & 0xFFFFFFFF00000000ull) | (d_lo >> 32) : 0ull);  // (in the wave's last lane)
     };
     uint32_t act_prev[K];  // greedy action of the thread's states under the policy of the round before
     double v_new[K];       // the states' current values
@@ -401,7 +412,7 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
                     key = k > key ? k : key;
                 }
             }
-            if (r > 0) publish_actions(par, tag, act_prev);  // (the actions of round r - 1 travel with the values of round r)
+            if (AGENTS && r > 0) publish_actions(par, tag, act_prev);  // (the actions of round r - 1 travel with the values of round r)
             VI_STAMP(0);
             // the thread's delta key goes to LDS as it is; the workgroup's maximum is taken behind the barrier, by a wave that
             // owns no states where there is one (one ds_write here instead of ~50 DPP / compare / select instructions)
@@ -422,15 +433,27 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
                 vi_st_l2(slot + 2 * rank, (mine & 0xFFFFFFFF00000000ull) | tag);
                 vi_st_l2(slot + 2 * rank + 1, (mine << 32) | tag);
             }
+            if (sync_delta) {  // the round's delta, for everybody: this wave collects the members' keys while the others fetch the values
+                delta_load(r);
+                const vi_u64 k = delta_finish(r);
+                if (lane == 63) round_key_lds = k;
+            }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j)
             if (st[j] >= 0) vL[st[j]] = v_new[j];
-        const bool collects = keeps_deltas && wave == 0 && r > 0;
+        const bool collects = !sync_delta && keeps_deltas && wave == 0 && r > 0;  // (one round late: off everybody's critical path)
         if (collects) delta_load(r - 1);
-        fetch(par, tag, true, r > 0);
+        fetch(par, tag, true, AGENTS && r > 0);
         VI_STAMP(6);
-        if (collects) delta_finish(r - 1);
+        if (collects) {
+            const vi_u64 k = delta_finish(r - 1);
+#ifndef GU_VI_XCD_STAMPS
+            if (lane == 63) a.vi.delta_key[r - 1] = k;
+#else
+            asm volatile("" ::"v"(k));
+#endif
+        }
 #ifdef GU_VI_XCD_STAMPS
         VI_STAMP(1);   // (delta_finish alone: added to the key phase)
         fetch(par, tag, true, r > 0);  // probe: the same fetch once more, everything certainly there
@@ -441,6 +464,11 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
         if (info[3] & 1u) {
             failed = true;
             break;
+        }
+        vi_u64 round_key = 0ull;
+        if (sync_delta) {
+            round_key = round_key_lds;
+            if (keeps_deltas && tid == 0) a.vi.delta_key[r] = round_key;
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {  // V2 (utils.py:55-72) on v'
@@ -457,27 +485,33 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
                     q[act] = __dadd_rn((double)(int8_t)(rn[j] >> (8 * act)), gv[j][act]);
                     k[act] = rint(__dmul_rn(q[act], 100000000.0));
                 }
-                const double kmax = fmax(fmax(k[0], k[1]), fmax(k[2], k[3]));
-                const double kabs = fmax(fmax(fabs(k[0]), fabs(k[1])), fmax(fabs(k[2]), fabs(k[3])));
-                uint32_t mask = 0u;
+                if (GREEDY) {  // (!GREEDY: the evaluation sweeps of policy_iteration keep the policy; V1 still wants gamma * v'[next])
+                    const double kmax = fmax(fmax(k[0], k[1]), fmax(k[2], k[3]));
+                    const double kabs = fmax(fmax(fabs(k[0]), fabs(k[1])), fmax(fabs(k[2]), fabs(k[3])));
+                    uint32_t mask = 0u;
 #pragma unroll
-                for (int act = 0; act < 4; ++act) mask |= (uint32_t)(k[act] == kmax) << act;
-                const bool any_nan = k[0] != k[0] || k[1] != k[1] || k[2] != k[2] || k[3] != k[3];
-                if (!(kabs < 3355443200000000.0) || any_nan) {  // 2^25 * 1e8 (proof: gu_vi.hpp, vi_tie_mask)
-                    double qmax = q[0];
+                    for (int act = 0; act < 4; ++act) mask |= (uint32_t)(k[act] == kmax) << act;
+                    const bool any_nan = k[0] != k[0] || k[1] != k[1] || k[2] != k[2] || k[3] != k[3];
+                    if (!(kabs < 3355443200000000.0) || any_nan) {  // 2^25 * 1e8 (proof: gu_vi.hpp, vi_tie_mask)
+                        double qmax = q[0];
 #pragma unroll
-                    for (int act = 1; act < 4; ++act) qmax = (q[act] > qmax) ? q[act] : qmax;
-                    mask = vi_tie_mask(q, qmax);
+                        for (int act = 1; act < 4; ++act) qmax = (q[act] > qmax) ? q[act] : qmax;
+                        mask = vi_tie_mask(q, qmax);
+                    }
+                    if (rec[j] & GU_CELL_TERM) mask = 0u;
+                    const double share = vi_share(mask);
+#pragma unroll
+                    for (int act = 0; act < 4; ++act) p[j][act] = ((mask >> act) & 1u) ? share : 0.0;
+                    act_prev[j] = mask ? (uint32_t)__ffs((int)mask) - 1u : 0u;  // an all-zero row (terminal state): argmax = 0
                 }
-                if (rec[j] & GU_CELL_TERM) mask = 0u;
-                const double share = vi_share(mask);
-#pragma unroll
-                for (int act = 0; act < 4; ++act) p[j][act] = ((mask >> act) & 1u) ? share : 0.0;
-                act_prev[j] = mask ? (uint32_t)__ffs((int)mask) - 1u : 0u;  // an all-zero row (terminal state): argmax = 0
             }
         }
         VI_STAMP(8);
-        if (r > 0 && has_envs) agents();
+        if (sync_delta && a.vi.use_threshold && vi_unkey_dev(round_key) < a.vi.threshold) {  // dynamic_programming.py:22-23 / :42
+            ++r;
+            break;
+        }
+        if (AGENTS && r > 0 && has_envs) agents();
 #ifdef GU_VI_XCD_STAMPS
         asm volatile("" ::"v"(e_pos[0]), "v"(e_rew[0]), "v"(e_done[1]), "v"(p[0][0]));  // the round ends here, not wherever its results are needed
 #endif
@@ -497,13 +531,20 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
         }
 #endif
     }
-    if (!failed && r > 0) {  // the agents' step of the last round: its actions alone cross the cluster
+    if (AGENTS && !failed && r > 0) {  // the agents' step of the last round: its actions alone cross the cluster
         const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;
         if (wave_has_states) publish_actions(par, tag, act_prev);
         __syncthreads();
         if (keeps_deltas && wave == 0) delta_load(r - 1);
         fetch(par, tag, false, true);
-        if (keeps_deltas && wave == 0) delta_finish(r - 1);
+        if (keeps_deltas && wave == 0) {
+            const vi_u64 k = delta_finish(r - 1);
+#ifndef GU_VI_XCD_STAMPS
+            if (lane == 63) a.vi.delta_key[r - 1] = k;
+#else
+            asm volatile("" ::"v"(k));
+#endif
+        }
         __syncthreads();
         if (info[3] & 1u) failed = true;
         else if (has_envs) agents();
@@ -522,12 +563,12 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
             const int32_t s = st[j];
             if (s >= 0) {
                 vf[s] = vL[s];
-                *reinterpret_cast<double4 *>(a.vi.pi + 4 * (int64_t)s) = make_double4(p[j][0], p[j][1], p[j][2], p[j][3]);
+                if (GREEDY) *reinterpret_cast<double4 *>(a.vi.pi + 4 * (int64_t)s) = make_double4(p[j][0], p[j][1], p[j][2], p[j][3]);
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; AGENTS && e < 2; ++e) {
         if (own_env[e]) {
             a.pos[gid[e]] = e_pos[e];
             a.reward[gid[e]] = e_rew[e];
@@ -541,10 +582,11 @@ __global__ void __launch_bounds__(1024) gu_vi_sweep_step_xcd_kernel(const ViStep
 }
 
 // ------------------------------------------------------------------------------------ host side
-// The launch shape for this engine, or false when the per-XCD form does not apply: one grid, table + planes within one
-// workgroup's LDS, every workgroup resident (at most one per CU), enough workgroups per XCD under the round-robin placement
-// for K <= 2 states per thread.
-bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan)
+// The launch shape for this engine, or false when the per-XCD form does not apply: one grid, planes + values (+ action words) within
+// one workgroup's LDS, every workgroup resident (at most one per CU), enough workgroups per XCD under the round-robin placement for
+// K <= 2 states per thread, four fetch items per thread at most.  `agents`: config 5 (every cluster steps a share of the envs);
+// otherwise the tables alone (one cluster does the work, 8 x as many workgroups are launched so that it has enough members).
+bool gu_vi_xcd_plan(const gu_engine *h, bool agents, GuXcdPlan *plan)
 {
     if (h->n_grids != 1 || h->S > GU_MAX_LDS_CELLS || h->n_cu < VI_XCD_MAX_XCC) return false;
     const int64_t S2 = ((int64_t)h->S + 1) & ~(int64_t)1, n_words = ((int64_t)h->S + 15) / 16, n_aw = (n_words + 1) / 2;
@@ -552,21 +594,21 @@ bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan)
     const size_t lds = ((2 * (size_t)h->cell_bytes + (size_t)S2 * sizeof(double) + 16 + (size_t)n_aw * 8 + 15) & ~(size_t)15) + 2 * 1024 * sizeof(vi_u64);
     if ((int64_t)lds + 1024 > h->lds_per_cu) return false;
     const int64_t forced = gu_opt(h, GU_OPT_VI_XCD_BLOCK);
-    const int max_wgs = h->n_cu;
+    const int max_wgs = h->n_cu & ~(VI_XCD_MAX_XCC - 1);
+    const int64_t items = 2 * (int64_t)(h->W < h->S ? h->W : h->S) + (agents ? n_aw : 0);  // halo granules (+ action items): four per thread at most
     for (int64_t B = forced ? forced : 256; B <= 1024; B <<= 1) {
-        const int64_t env_wgs = (h->N + B - 1) / B;
-        if (env_wgs > max_wgs) {
+        const int64_t env_wgs = agents ? (h->N + B - 1) / B : 0;
+        if (env_wgs > h->n_cu) {
             if (forced) return false;
             continue;
         }
         // enough workgroups for one state per thread in every cluster, as far as the device has CUs for them
         int64_t G = VI_XCD_MAX_XCC * (((int64_t)h->S + B - 1) / B);
-        if (G > (max_wgs & ~(VI_XCD_MAX_XCC - 1))) G = max_wgs & ~(VI_XCD_MAX_XCC - 1);
+        if (G > max_wgs) G = max_wgs;
         if (G < env_wgs) G = env_wgs;
         const int64_t per_xcc = G / VI_XCD_MAX_XCC > 0 ? G / VI_XCD_MAX_XCC : 1;  // the smallest cluster under round-robin placement
         if ((G + VI_XCD_MAX_XCC - 1) / VI_XCD_MAX_XCC > VI_XCD_SLOTS) return false;
         const int64_t chunk = ((((int64_t)h->S + per_xcc - 1) / per_xcc) + 63) & ~(int64_t)63;
-        const int64_t items = 2 * (int64_t)(h->W < h->S ? h->W : h->S) + n_aw;  // halo granules + action items: four per thread at most
         const int K = items > 4 * B ? 0 : chunk <= B ? 1 : chunk <= 2 * B ? 2 : 0;
         if (K == 0) {
             if (forced) return false;
@@ -583,16 +625,76 @@ bool gu_vi_xcd_plan(const gu_engine *h, GuXcdPlan *plan)
     return false;
 }
 
-int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a)
+// agents: config 5.  Otherwise the tables alone, with (`greedy`) or without the policy update.
+int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a, bool agents, bool greedy)
 {
-    static std::atomic<uint64_t> lds_mask[2];
-    if (plan.K == 1) {
-        gu_allow_lds(gu_vi_sweep_step_xcd_kernel<1>, lds_mask[0], h->device, plan.lds, (size_t)h->lds_per_cu);
-        hipLaunchKernelGGL(gu_vi_sweep_step_xcd_kernel<1>, dim3(plan.G), dim3(plan.block), plan.lds, h->stream, a);
-    } else {
-        gu_allow_lds(gu_vi_sweep_step_xcd_kernel<2>, lds_mask[1], h->device, plan.lds, (size_t)h->lds_per_cu);
-        hipLaunchKernelGGL(gu_vi_sweep_step_xcd_kernel<2>, dim3(plan.G), dim3(plan.block), plan.lds, h->stream, a);
-    }
+    typedef void (*Kernel)(const ViStepXcdArgs);
+    static std::atomic<uint64_t> lds_mask[6];
+    const int which = (plan.K == 1 ? 0 : 1) + (agents ? 0 : greedy ? 2 : 4);
+    static const Kernel kernels[6] = {gu_vi_xcd_kernel<1, true, true>,  gu_vi_xcd_kernel<2, true, true>,  gu_vi_xcd_kernel<1, false, true>,
+                                      gu_vi_xcd_kernel<2, false, true>, gu_vi_xcd_kernel<1, false, false>, gu_vi_xcd_kernel<2, false, false>};
+    const Kernel kern = kernels[which];
+    gu_allow_lds(kern, lds_mask[which], h->device, plan.lds, (size_t)h->lds_per_cu - 1024);  // (the kernel also has a few static LDS words)
+    hipLaunchKernelGGL(kern, dim3(plan.G), dim3(plan.block), plan.lds, h->stream, a);
     GU_HIP(hipGetLastError());
+    return GU_OK;
+}
+
+// gu_vi_sweep / gu_vi_run / gu_vi_eval_run as ONE launch of one XCD's workgroups (see the kernel, !AGENTS).  Runs up to max_rounds
+// rounds on the current tables; GU_VI_FALLBACK: not applicable here or the launch gave up -- the tables are as they were.
+int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds, int32_t *rounds_done,
+                     double *deltas)
+{
+    *rounds_done = 0;
+    if (max_rounds <= 0) return GU_OK;
+    const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
+    GuXcdPlan xp{};
+    if (!(path == 0 || path == 5) || !gu_vi_xcd_plan(h, false, &xp)) return GU_VI_FALLBACK;
+    // scratch: header (64 B) | delta keys [max_rounds] | delta-key slots | snapshot of v and pi | granule buffers
+    const size_t key_bytes = (size_t)max_rounds * sizeof(unsigned long long);
+    const size_t slots_off = (64 + key_bytes + 255) & ~(size_t)255, snap_off = slots_off + xp.slots_bytes;
+    const size_t v_bytes = (size_t)h->S * sizeof(double), snap_bytes = (5 * v_bytes + 255) & ~(size_t)255;
+    int rc = gu_ensure_scratch(h, snap_off + snap_bytes + 8 * xp.work_bytes);
+    if (rc != GU_OK) return rc;
+    char *base = (char *)h->d_scratch, *snap = base + snap_off;
+    if ((rc = gu_device_copy(h, snap, h->d_v[h->vi_cur], v_bytes)) != GU_OK) return rc;
+    if ((rc = gu_device_copy(h, snap + v_bytes, h->d_pi[h->vi_cur], 4 * v_bytes)) != GU_OK) return rc;
+    GU_HIP(hipMemsetAsync(base, 0, snap_off, h->stream));  // header, keys, slots: every polled word is zeroed before every launch
+    ViStepXcdArgs a{};
+    a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, threshold, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1], h->d_pi[h->vi_cur],
+                         (vi_u64 *)(base + 64), (uint32_t *)base, (int32_t *)base + 2, max_rounds, use_threshold ? 1 : 0};
+    a.N = 0;
+    a.slots = (vi_u64 *)(base + slots_off);
+    a.gx = (uint8_t *)(snap + snap_bytes);
+    a.work_bytes = (uint32_t)xp.work_bytes;
+    a.inject_failure = path == 5;
+    GU_HIP(hipMemsetAsync(a.gx, 0, 8 * xp.work_bytes, h->stream));  // no tag of an earlier launch may be left in the granule buffers
+    if ((rc = gu_vi_xcd_launch(h, xp, a, false, greedy)) != GU_OK) return rc;
+    int32_t ctl[4] = {0, 0, 0, 0};  // [workgroups registered, fallback word, rounds_done, -]
+    GU_HIP(hipMemcpyAsync(ctl, base, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
+    const int32_t done = ctl[1] ? -1 : ctl[2];
+    if (done < 0) {
+        if ((rc = gu_device_copy(h, h->d_v[h->vi_cur], snap, v_bytes)) != GU_OK) return rc;
+        if ((rc = gu_device_copy(h, h->d_pi[h->vi_cur], snap + v_bytes, 4 * v_bytes)) != GU_OK) return rc;
+        GU_HIP(hipStreamSynchronize(h->stream));
+        if (gu_debug()) fprintf(stderr, "[gu] DP per-XCD kernel gave up (workgroups not resident together, or clusters too uneven); tables restored, next form\n");
+        return GU_VI_FALLBACK;
+    }
+    if (deltas && done > 0) {
+        std::vector<unsigned long long> keys((size_t)done);
+        GU_HIP(hipMemcpy(keys.data(), base + 64, (size_t)done * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int32_t i = 0; i < done; ++i) {
+            const unsigned long long k = keys[(size_t)i], b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+            memcpy(&deltas[i], &b, sizeof(double));
+        }
+    }
+    if (done & 1) {  // the value table ended in the other buffer; the policy stayed where it was
+        double *t = h->d_v[0];
+        h->d_v[0] = h->d_v[1];
+        h->d_v[1] = t;
+    }
+    *rounds_done = done;
+    h->greedy_valid = false;
     return GU_OK;
 }

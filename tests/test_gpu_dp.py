@@ -17,12 +17,13 @@ from tests import _golden as G
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=['one_workgroup', 'launch_per_round'])
+@pytest.fixture(autouse=True, params=['one_launch', 'no_per_xcd_form', 'launch_per_round'])
 def vi_path(request, gu_option):
-    """Every test runs twice: grids of up to 4096 states normally take the single-workgroup kernel (v in LDS, the
-    whole iteration in one launch); option vi_path = 2 sends them down the one-launch-per-round path that larger
-    grids use."""
-    gu_option('vi_path', 2 if request.param == 'launch_per_round' else None)
+    """Every test runs three times.  'one_launch': the default dispatch -- grids of 1536 states and more take the per-XCD launch
+    (csrc/gu_vi_xcd.hip: one XCD's workgroups, the whole iteration in one launch), smaller ones the single-workgroup kernel (v in
+    LDS).  'no_per_xcd_form' (option vi_path = 4): the single-workgroup kernel up to 4096 states, the chip-wide workgroup cluster
+    beyond.  'launch_per_round' (vi_path = 2): one launch per round on every grid size."""
+    gu_option('vi_path', {'launch_per_round': 2, 'no_per_xcd_form': 4}.get(request.param))
     return request.param
 
 
@@ -367,8 +368,11 @@ def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, gu_option):
     free = np.setdiff1d(np.arange(S), walls)
     spec = GridSpec(W, H, [int(free[0])], [int(x) for x in free[-3:]], [int(x) for x in free[5:9]], [int(x) for x in walls])
     out = {}
-    for cluster in ('0', '1', 'timeout'):  # 'timeout': a grid-barrier timeout is injected -> tables restored, launch-per-round path
-        gu_option('vi_path', {'0': 1, '1': None, 'timeout': 3}[cluster])
+    # '1': the default dispatch (the per-XCD launch where planes + values fit one workgroup's LDS, else the chip-wide cluster);
+    # 'chip_wide': no per-XCD form; 'timeout': a grid-barrier timeout is injected into the chip-wide cluster -> tables restored,
+    # launch-per-round path; 'xcd_gives_up': the per-XCD launch gives up at once -> tables restored, next form
+    for cluster in ('0', '1', 'chip_wide', 'timeout', 'xcd_gives_up'):
+        gu_option('vi_path', {'0': 1, '1': None, 'chip_wide': 4, 'timeout': 3, 'xcd_gives_up': 5}[cluster])
         res = []
         with Engine(2, spec) as eng:
             eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
@@ -386,7 +390,9 @@ def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, gu_option):
             steps, deltas = eng.vi_run(1.0, 1e9, 5)  # stops after its first round
             res += [steps, deltas.tobytes(), *(x.tobytes() for x in eng.vi_get())]
         out[cluster] = res
-    assert out['0'][0] > 3 and out['0'] == out['1'] and out['0'] == out['timeout']
+    assert out['0'][0] > 3
+    for cluster in ('1', 'chip_wide', 'timeout', 'xcd_gives_up'):
+        assert out[cluster] == out['0'], cluster
 
 
 @pytest.mark.parametrize('name,N,auto', [('maze64_s5', 65536, True), ('maze64_s5_g097', 4096, False), ('rect6x5_g1', 100, True),

@@ -22,7 +22,7 @@ MODES = {
     'stats_only': lambda name, grid: 'gu_rollout_multi_kernel<' in name and grid == 65536,
     'rollout_sample_policy_traj': lambda name, grid: 'gu_rollout_rows_kernel<3, 1,' in name and grid == 65536,  # <sampled, int32 rows, ...>
     'rollout_sample_policy_stats_only': lambda name, grid: 'gu_rollout_rows_kernel<3, 0,' in name and grid == 65536,
-    'c5_rounds_in_one_launch': lambda name, grid: 'gu_vi_sweep_step_xcd_kernel<' in name,
+    'c5_rounds_in_one_launch': lambda name, grid: 'gu_vi_xcd_kernel<' in name or 'gu_vi_sweep_step_xcd_kernel<' in name,
 }
 
 
@@ -98,7 +98,7 @@ def main():
                 if form and g == 65536:
                     names[form] = n
                     seq[form].append((g, v))
-            elif 'gu_vi_sweep_step_xcd_kernel<' in n:
+            elif 'gu_vi_xcd_kernel<' in n or 'gu_vi_sweep_step_xcd_kernel<' in n:
                 names['c5_rounds_in_one_launch'] = n
                 seq['c5_rounds_in_one_launch'].append((g, v))
             elif 'gu_rollout_kernel<' in n:

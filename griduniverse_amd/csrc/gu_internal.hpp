@@ -161,6 +161,7 @@ struct gu_engine {
     double *d_delta = nullptr;      // per-block maxima + final
     uint8_t *d_greedy = nullptr;    // first-argmax action per state [cell_bytes]
     bool greedy_valid = false;
+    int32_t vi_xcd_members[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // workgroups that registered per XCC in the last per-XCD launch of gu_vi_sweep_step_run
     int vi_run_form = 0;            // which form the last gu_vi_sweep_step_run took: 1 per XCD, 2 chip-wide cluster, 3 one launch per round
 
     // agent trail (gu_trail.hip): off unless gu_trail_enable was called
@@ -258,6 +259,7 @@ int gu_launch_greedy_table(gu_engine *h);
 struct GuXcdPlan {
     int block = 0, K = 0;      // threads per workgroup, states per thread at most
     unsigned G = 0;            // workgroups
+    uint32_t values = 0;       // doubles of a workgroup's value window in LDS
     size_t lds = 0, slots_bytes = 0, work_bytes = 0;  // dynamic LDS; scratch: delta-key slots (all XCCs), granule buffers (per XCC)
 };
 struct ViStepXcdArgs;

@@ -546,7 +546,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     // Pair tables (two steps per LDS round trip) where they pay: state-independent actions, PACKED rows (int32 rows are as fast or
     // faster on the one-step table -- 58 .. 61 against 65 us at 32 768 envs, 110 against 115 at 65 536: six stores and two records'
     // worth of unpacking per round trip cost what the shorter chain saves, and those launches are close to the write path's rate
-    // anyway; without rows the K-step kernel of gu_rollout_multi.hip is the tool), one 256-lane workgroup per CU at most (144 bytes
+    // anyway -- round 4, forced for int32 rows again: 47.6 against 49.0 us at config 2's 4096 envs, 65.2 against 59.4 at a config-4 shard; without rows the K-step kernel of gu_rollout_multi.hip is the tool), one 256-lane workgroup per CU at most (144 bytes
     // of LDS per cell).  GU_OPT_ROLLOUT_ROWS = 2 keeps the one-step table (A/B, tests).  profiles/archive/r03r_pair_rows.txt
     bool pair = !table_policy && traj == 2 && mode != 2 && gu_blocks(h->N, 256) <= (unsigned)h->n_cu && (int64_t)h->S * 144 <= h->lds_per_cu - 2048 &&
                 ((int64_t)h->S << GU_PAIR_SHIFT) <= (int64_t)GU_ROW_ADDR_MASK;

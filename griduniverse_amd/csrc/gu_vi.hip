@@ -1144,9 +1144,10 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
             }
             // rounds_done is written by ONE workgroup, and giving up need not be unanimous: the fallback word, raised by whoever
             // gives up, decides (see vi_cluster_run)
-            int32_t ctl[4] = {0, 0, 0, 0};  // [arrival counter, fallback word, rounds_done, -]
+            int32_t ctl[12] = {0};  // [arrival counter, fallback word, rounds_done, 1 + XCC of workgroup 0, workgroups registered per XCC x 8]
             GU_HIP(hipMemcpyAsync(ctl, h->d_scratch, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
             GU_HIP(hipStreamSynchronize(h->stream));
+            if (form == 0) memcpy(h->vi_xcd_members, ctl + 4, sizeof h->vi_xcd_members);  // (what the hardware reported: HW_REG_XCC_ID per workgroup)
             if (!ctl[1] && ctl[2] == iters) {
                 if (deltas) {
                     std::vector<unsigned long long> keys((size_t)iters);
@@ -1184,5 +1185,12 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
 }
 
 int gu_vi_last_form(gu_handle h) { return h ? h->vi_run_form : 0; }
+
+int gu_vi_last_clusters(gu_handle h, int32_t *members)
+{
+    if (!h || !members) return gu_fail(GU_ERR_INVALID, "null handle or pointer");
+    memcpy(members, h->vi_xcd_members, sizeof h->vi_xcd_members);
+    return GU_OK;
+}
 
 }  // extern "C"

@@ -173,4 +173,5 @@ struct ViStepXcdArgs : ViStepClusterArgs {
                               //   [2 parities][S] value granules of 16 bytes | [2 parities][ceil(S / 32)] action items of 16 bytes
     uint32_t work_bytes;      // bytes per XCC
     uint32_t inject_failure;  // tests: every workgroup gives up at once
+    uint32_t lds_values;      // doubles of a workgroup's value window in LDS (the launcher sets it from its plan)
 };

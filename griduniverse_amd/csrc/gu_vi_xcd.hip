@@ -122,9 +122,9 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     __shared__ vi_u64 round_key_lds;  // !AGENTS: the cluster's delta key of the round
     __shared__ uint32_t info[4];  // [0] XCC id, [1] rank in the cluster, [2] members, [3] bit 0: failed, bit 1: this cluster writes the tables
     const ViMap cell = vi_stage<true>(a.vi.cell, a.vi.cell_bytes, smem);  // the agents gather records of arbitrary cells
-    double *vL = reinterpret_cast<double *>(smem + 2 * a.vi.cell_bytes);  // [S2 + 2] values: the own chunk and a grid row either side are kept current (+ a spare slot); then the action words
+    double *vL_window = reinterpret_cast<double *>(smem + 2 * a.vi.cell_bytes);  // [a.lds_values] the values of the own chunk and of one grid row either side: all a workgroup ever reads
     const int32_t tid = threadIdx.x, B = blockDim.x, S = a.vi.S, W = a.vi.W;
-    const int32_t S2 = (S + 1) & ~1, cb = a.vi.cell_bytes;
+    const int32_t cb = a.vi.cell_bytes;
     const double gamma = a.vi.gamma;
     uint32_t *hdr = a.vi.sync;  // [0] workgroups registered, [1] fallback word, [3] 1 + XCC id of workgroup 0, [4 .. 11] members per XCC
 
@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             writes = vi_ld_word(hdr + 3) == xcc + 1u;
             const int64_t chunk = ((((int64_t)S + members - 1) / members) + 63) & ~(int64_t)63;
             const int64_t items = 2 * (int64_t)(W < S ? W : S) + (((S + 15) >> 4) + 1) / 2;  // what one thread's four fetch items must cover
-            bad = rank >= VI_XCD_SLOTS || members > VI_XCD_SLOTS || chunk > (int64_t)K * B || items > 4 * (int64_t)B;
+            bad = rank >= VI_XCD_SLOTS || members > VI_XCD_SLOTS || chunk > (int64_t)K * B || items > 4 * (int64_t)B ||
+                  chunk + 2 * (int64_t)(W < S ? W : S) > (int64_t)a.lds_values;
         }
         if (bad || a.inject_failure) {
             bad = 1u;
@@ -194,7 +195,13 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             p[j][0] = row.x, p[j][1] = row.y, p[j][2] = row.z, p[j][3] = row.w;
         }
     }
-    for (int32_t i = tid; i < S2; i += B) vL[i] = i < S ? a.vi.v0[i] : 0.0;
+    // the value window: states [vbase, vbase + a.lds_values) -- the chunk and W states either side; vL[state] as if the table were whole
+    const int32_t vbase = lo - W > 0 ? lo - W : 0;
+    double *vL = vL_window - vbase;
+    {
+        const int32_t top = lo < S ? (hi + W < S ? hi + W : S) : vbase;
+        for (int32_t i = vbase + tid; i < top; i += B) vL[i] = a.vi.v0[i];
+    }
     // Division of labour inside the workgroup: the waves that own states carry the round's critical path (V1, V2).  When at
     // most half of the waves do, they carry NO agents: every other wave steps two blocks of 64 envs (two independent gather
     // chains that interleave) and one of them reduces the workgroup's delta keys -- both beside the critical path, not on it.
@@ -228,7 +235,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     bool wave_has_states = false;  // (wave-uniform: the states of a chunk are dealt to whole waves)
 #pragma unroll
     for (int j = 0; j < K; ++j) wave_has_states = wave_has_states || __any(st[j] >= 0);
-    vi_u64 *lane_key = reinterpret_cast<vi_u64 *>(smem + ((2u * (uint32_t)cb + (uint32_t)S2 * 8u + 16u + (uint32_t)((((S + 15) >> 4) + 1) >> 1) * 8u + 15u) & ~15u));  // [2][B] the lanes' delta keys, by round parity
+    vi_u64 *lane_key = reinterpret_cast<vi_u64 *>(smem + ((2u * (uint32_t)cb + a.lds_values * 8u + 16u + (uint32_t)((((S + 15) >> 4) + 1) >> 1) * 8u + 15u) & ~15u));  // [2][B] the lanes' delta keys, by round parity
     for (int32_t i = tid; i < 2 * B; i += B) lane_key[i] = 0ull;       // (a lane without a state never writes its entry)
     const int32_t key_wave = split ? state_waves : 0;                 // the wave that reduces them
     __syncthreads();
@@ -249,7 +256,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     const int32_t n_above = lo < S ? (hi + W < S ? hi + W : S) - hi : 0;                     // states [hi, hi + n_above)
     const int32_t n_words = (S + 15) >> 4, n_aw = (n_words + 1) >> 1;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)gx, 0, a.work_bytes, 0x00020000);
-    const uint32_t lds_v = 2u * (uint32_t)cb, lds_spare = lds_v + (uint32_t)S2 * 8u, lds_a = lds_spare + 16u;
+    const uint32_t lds_v = 2u * (uint32_t)cb, lds_spare = lds_v + a.lds_values * 8u, lds_a = lds_spare + 16u;
     const uint32_t gv_bytes = (uint32_t)S * 16u, aw_off = 2u * gv_bytes, aw_bytes = (uint32_t)n_aw * 16u;  // [2][S] granules | [2][n_aw] action items
     // The items this thread fetches are the same every round: source (parity 0), destination in LDS and kind are worked out ONCE
     // (computed inside the loop, the selects and bounds of this bookkeeping were three quarters of the fetch's 1900 clocks).
@@ -263,7 +270,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         const int32_t w = x - n_v;                                        // the index of an action item
         it_kind[m] = x >= n_items ? 0u : x < n_v ? 1u : (2 * w + 1 < n_words) ? 2u : 3u;
         it_src[m] = it_kind[m] == 1u ? (uint32_t)s * 16u : aw_off + (uint32_t)w * 16u;
-        it_dst[m] = it_kind[m] == 0u ? lds_spare : it_kind[m] == 1u ? lds_v + (uint32_t)s * 8u : lds_a + (uint32_t)w * 8u;
+        it_dst[m] = it_kind[m] == 0u ? lds_spare : it_kind[m] == 1u ? lds_v + (uint32_t)(s - vbase) * 8u : lds_a + (uint32_t)w * 8u;
     }
     // One exchange: fetch the halo granules (with_v) and the action words (with_act) tagged `tag` from the buffers of parity
     // `par`, reloading until every tag is there.  Straight-line, unpredicated loads: a load or an LDS write inside a divergent
@@ -589,13 +596,10 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
 bool gu_vi_xcd_plan(const gu_engine *h, bool agents, GuXcdPlan *plan)
 {
     if (h->n_grids != 1 || h->S > GU_MAX_LDS_CELLS || h->n_cu < VI_XCD_MAX_XCC) return false;
-    const int64_t S2 = ((int64_t)h->S + 1) & ~(int64_t)1, n_words = ((int64_t)h->S + 15) / 16, n_aw = (n_words + 1) / 2;
-    // planes | values | spare slot of the fetch | action words | the lanes' delta keys [2][threads]
-    const size_t lds = ((2 * (size_t)h->cell_bytes + (size_t)S2 * sizeof(double) + 16 + (size_t)n_aw * 8 + 15) & ~(size_t)15) + 2 * 1024 * sizeof(vi_u64);
-    if ((int64_t)lds + 1024 > h->lds_per_cu) return false;
+    const int64_t n_words = ((int64_t)h->S + 15) / 16, n_aw = (n_words + 1) / 2, halo = 2 * (int64_t)(h->W < h->S ? h->W : h->S);
     const int64_t forced = gu_opt(h, GU_OPT_VI_XCD_BLOCK);
     const int max_wgs = h->n_cu & ~(VI_XCD_MAX_XCC - 1);
-    const int64_t items = 2 * (int64_t)(h->W < h->S ? h->W : h->S) + (agents ? n_aw : 0);  // halo granules (+ action items): four per thread at most
+    const int64_t items = halo + (agents ? n_aw : 0);  // halo granules (+ action items): four per thread at most
     for (int64_t B = forced ? forced : 256; B <= 1024; B <<= 1) {
         const int64_t env_wgs = agents ? (h->N + B - 1) / B : 0;
         if (env_wgs > h->n_cu) {
@@ -614,10 +618,18 @@ bool gu_vi_xcd_plan(const gu_engine *h, bool agents, GuXcdPlan *plan)
             if (forced) return false;
             continue;
         }
+        // planes | value window (the chunk and one grid row either side) | spare slot of the fetch | action words | the lanes' delta keys
+        const int64_t values = ((int64_t)K * B + halo + 2) & ~(int64_t)1;
+        const size_t lds = ((2 * (size_t)h->cell_bytes + (size_t)values * sizeof(double) + 16 + (size_t)n_aw * 8 + 15) & ~(size_t)15) + 2 * 1024 * sizeof(vi_u64);
+        if ((int64_t)lds + 1024 > h->lds_per_cu) {
+            if (forced) return false;
+            continue;
+        }
         plan->block = (int)B;
         plan->G = (unsigned)G;
         plan->K = K;
         plan->lds = lds;
+        plan->values = (uint32_t)values;
         plan->slots_bytes = (size_t)VI_XCD_MAX_XCC * 4 * VI_XCD_SLOTS * 2 * sizeof(vi_u64);
         plan->work_bytes = ((2 * (size_t)h->S * 16 + 2 * (size_t)n_aw * 16) + 255) & ~(size_t)255;
         return true;
@@ -626,8 +638,10 @@ bool gu_vi_xcd_plan(const gu_engine *h, bool agents, GuXcdPlan *plan)
 }
 
 // agents: config 5.  Otherwise the tables alone, with (`greedy`) or without the policy update.
-int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a, bool agents, bool greedy)
+int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &args, bool agents, bool greedy)
 {
+    ViStepXcdArgs a = args;
+    a.lds_values = plan.values;
     typedef void (*Kernel)(const ViStepXcdArgs);
     static std::atomic<uint64_t> lds_mask[6];
     const int which = (plan.K == 1 ? 0 : 1) + (agents ? 0 : greedy ? 2 : 4);

@@ -361,6 +361,12 @@ class Engine(object):
         barrier per round, 3 = one launch per round (0: none yet)."""
         return int(self.lib.gu_vi_last_form(self._h))
 
+    def vi_last_clusters(self):
+        """Workgroups per XCC id in the last per-XCD launch of vi_sweep_step_run, as the hardware reported them (list of 8)."""
+        m = np.zeros(8, np.int32)
+        check(self.lib.gu_vi_last_clusters(self._h, ptr(m)))
+        return m.tolist()
+
     def mc_evaluate(self, T, first_state, discount_pow, keep, every_visit=False, incremental_mean=True,
                     stationary_env=True, alpha=0.001):
         """Monte-Carlo evaluation over the trajectory rows 0..T-1 of the last rollout (env e = episode e).

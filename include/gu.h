@@ -306,7 +306,9 @@ int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int3
  *               of a workgroup cluster with a chip-wide barrier per round (max(S, N) <= 1024 x the device's CUs,
  *               S <= 32 767); (3) one launch per round.  A form that cannot hold its workgroups resident together gives up
  *               (bounded spins), the state is put back, the next form runs.  deltas[iters] optional.
- * gu_vi_last_form : which of the three the last gu_vi_sweep_step_run of this engine took (1, 2, 3; 0 = none yet). */
+ * gu_vi_last_form : which of the three the last gu_vi_sweep_step_run of this engine took (1, 2, 3; 0 = none yet).
+ * gu_vi_last_clusters : members[8] = how many workgroups of its last per-XCD launch read each HW_REG_XCC_ID (the clusters as the
+ *               hardware reported them; equal under the round-robin placement observed on MI355X -- speed only, any split is correct). */
 int gu_vi_set(gu_handle h, const double *v, const double *pi);
 int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update, double *deltas);
 int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, int32_t *steps_done, double *deltas);
@@ -316,6 +318,7 @@ int gu_vi_get(gu_handle h, double *v, double *pi);
 int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta);
 int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flags, double *deltas);
 int gu_vi_last_form(gu_handle h);
+int gu_vi_last_clusters(gu_handle h, int32_t *members);
 
 /* ---- Monte-Carlo policy evaluation: core/algorithms/monte_carlo.py:29-99 ----------------
  * Consumes the trajectory rows 0..T-1 of the last gu_rollout (run WITHOUT auto-reset: env e is

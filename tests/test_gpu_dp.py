@@ -422,6 +422,9 @@ def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, g
                 deltas = np.concatenate([deltas, eng.vi_sweep_step_run(gamma, 2, auto_reset=auto)])  # even + odd round counts
                 eng.vi_sweep_step_run(gamma, 1, auto_reset=auto)
                 form[mode] = eng.vi_last_form()
+                if mode == 'run' and form[mode] == 1:  # the clusters as the hardware reported them: every workgroup of the launch in exactly one
+                    clusters = eng.vi_last_clusters()
+                    assert sum(clusters) >= max(8, -(-N // 1024)) and all(c >= 0 for c in clusters) and sum(c > 0 for c in clusters) >= 1, clusters
             if mode == 'single':
                 deltas = np.concatenate([deltas, [eng.vi_sweep_step(gamma, auto_reset=auto) for _ in range(3)]])[:iters + 2]
             v, pi = eng.vi_get()

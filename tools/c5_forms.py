@@ -77,6 +77,8 @@ def main():
             if rep:
                 times[name].append(dt / rounds * 1e6)
             out['forms'].setdefault(name, {})['form_taken'] = form
+            if form == 1:
+                out['forms'][name]['workgroups_per_xcc'] = eng.vi_last_clusters()
     for name, ts in times.items():
         ts.sort()
         out['forms'][name].update(us_per_round_median=ts[len(ts) // 2], us_per_round_min=ts[0], us_per_round_max=ts[-1],

@@ -45,6 +45,7 @@
 #include "gu_vi.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -92,6 +93,30 @@ __device__ __forceinline__ vi_u64 vi_wave_max_last(vi_u64 k)
     VI_DPP_STEP(0x143, 0xC)  // row_bcast:31   -> rows 2 and 3 take in lane 31
 #undef VI_DPP_STEP
     return k;
+}
+
+// The same maximum, in every lane, in two passes of 32-bit halves (the keys order like (high word, low word)): v_max_u32 takes the
+// DPP operand itself, so a pass is six instructions where the 64-bit compare-and-select above needs ~8 per step.
+__device__ __forceinline__ uint32_t vi_wave_max32(uint32_t x)
+{
+#define VI_DPP_STEP(ctrl, rows)                                                                  \
+    {                                                                                            \
+        const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xF, false); \
+        x = o_ > x ? o_ : x;                                                                     \
+    }
+    VI_DPP_STEP(0x111, 0xF)
+    VI_DPP_STEP(0x112, 0xF)
+    VI_DPP_STEP(0x114, 0xF)
+    VI_DPP_STEP(0x118, 0xF)
+    VI_DPP_STEP(0x142, 0xA)
+    VI_DPP_STEP(0x143, 0xC)
+#undef VI_DPP_STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ vi_u64 vi_wave_max_all(vi_u64 k)
+{
+    const uint32_t hi = (uint32_t)(k >> 32), top = vi_wave_max32(hi);
+    return ((vi_u64)top << 32) | vi_wave_max32(hi == top ? (uint32_t)k : 0u);
 }
 
 // -DGU_VI_XCD_STAMPS (a diagnostic variant library, tools/c5_stamps.py; never the product): workgroup rank 0 of the cluster that
@@ -152,7 +177,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             bad = rank >= VI_XCD_SLOTS || members > VI_XCD_SLOTS || chunk > (int64_t)K * B || items > 4 * (int64_t)B ||
                   chunk + 2 * (int64_t)(W < S ? W : S) > (int64_t)a.lds_values;
         }
-        if (bad || a.inject_failure) {
+        if (bad || (a.inject_failure & 1u)) {
             bad = 1u;
             __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tell everyone; never hang
         }
@@ -248,7 +273,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     // The tables alone: every workgroup takes in every member's delta key every round -- the stopping rule needs it before the next
     // round, and it is what keeps the members within a round of each other (their values only tie neighbours together: without it a
     // far member could run a dozen rounds ahead and overwrite its four-deep key slots before they are collected).  With agents the
-    // action words tie every workgroup to every other one anyway, and workgroup 0 collects the keys a round late.
+    // action words tie every workgroup to every other one anyway, and workgroup 0 collects the keys two rounds late.
     const bool sync_delta = !AGENTS;
     // What a round fetches, in 16-byte items: the value granules of one grid row either side of the own chunk (the chunk's own
     // values go from registers to LDS), then the action words, two per item.
@@ -278,7 +303,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     // OTHER, 450 clocks each).  A lane without an item loads from beyond the buffer's size (the bounds check returns zeros
     // without a memory access) and writes to a spare 16 bytes behind the table.
     const int32_t n_batches = (n_items + B - 1) / B;  // 16-byte loads per thread (uniform over the workgroup): 1 at config 5
-    auto fetch_n = [&](auto batches, uint32_t par, uint32_t tag, bool with_v, bool with_act) {
+    auto fetch_n = [&](auto batches, uint32_t par, uint32_t tag, bool with_v, bool with_act, auto &&meanwhile) {
         constexpr int NB = decltype(batches)::value;
         uint32_t src[NB];
         bool on[NB];
@@ -289,9 +314,11 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         }
         vi_u32x4 t[NB];
         uint32_t spins = 0, bad = 0u;
-        for (;;) {
 #pragma unroll
-            for (int m = 0; m < NB; ++m) t[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, src[m], 0, VI_XCD_LOAD_AUX);
+        for (int m = 0; m < NB; ++m) t[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, src[m], 0, VI_XCD_LOAD_AUX);
+        meanwhile();  // (work of this wave that does not depend on the exchange runs under the loads' round trip)
+        VI_STAMP(2);
+        for (;;) {
             bool ok = true;
 #pragma unroll
             for (int m = 0; m < NB; ++m) ok = ok && (!on[m] || (t[m].x == tag && (t[m].z == tag || it_kind[m] == 3u)));
@@ -301,10 +328,14 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
                 break;
             }
             if (spins > 8u) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int m = 0; m < NB; ++m) t[m] = __builtin_amdgcn_raw_buffer_load_b128(rs, src[m], 0, VI_XCD_LOAD_AUX);
         }
 #ifdef GU_VI_XCD_STAMPS
         stamp_acc[10] += spins;
+        asm volatile("" ::"v"(t[0].x));
 #endif
+        VI_STAMP(4);
         // a value granule {tag, high half} {tag, low half} becomes one double, an action item two 32-bit words of 16 actions
 #pragma unroll
         for (int m = 0; m < NB; ++m) {
@@ -316,10 +347,10 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             atomicOr(&info[3], 1u);
         }
     };
-    auto fetch = [&](uint32_t par, uint32_t tag, bool with_v, bool with_act) {
-        if (n_batches <= 1) fetch_n(std::integral_constant<int, 1>{}, par, tag, with_v, with_act);
-        else if (n_batches == 2) fetch_n(std::integral_constant<int, 2>{}, par, tag, with_v, with_act);
-        else fetch_n(std::integral_constant<int, 4>{}, par, tag, with_v, with_act);
+    auto fetch = [&](uint32_t par, uint32_t tag, bool with_v, bool with_act, auto &&meanwhile) {
+        if (n_batches <= 1) fetch_n(std::integral_constant<int, 1>{}, par, tag, with_v, with_act, meanwhile);
+        else if (n_batches == 2) fetch_n(std::integral_constant<int, 2>{}, par, tag, with_v, with_act, meanwhile);
+        else fetch_n(std::integral_constant<int, 4>{}, par, tag, with_v, with_act, meanwhile);
     };
     // this wave's sixteen-action words of parity `par`: lanes 0 .. 3 assemble them from two ballots and store them
     auto publish_actions = [&](uint32_t par, uint32_t tag, const uint32_t act[K]) {
@@ -328,13 +359,10 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             const int32_t s_first = lo + (wave << 6) + j * B;  // the state of lane 0 (chunks and waves are whole multiples of 64)
             const uint64_t b0 = __ballot((act[j] & 1u) != 0u), b1 = __ballot((act[j] & 2u) != 0u);
             if (lane < 4 && (wave << 6) + j * B < chunk && s_first + 16 * lane < S) {
-                uint32_t e = (uint32_t)(b0 >> (16 * lane)) & 0xFFFFu, o = (uint32_t)(b1 >> (16 * lane)) & 0xFFFFu;
-                e = (e | (e << 8)) & 0x00FF00FFu, o = (o | (o << 8)) & 0x00FF00FFu;  // spread 16 bits over the even positions of 32
-                e = (e | (e << 4)) & 0x0F0F0F0Fu, o = (o | (o << 4)) & 0x0F0F0F0Fu;
-                e = (e | (e << 2)) & 0x33333333u, o = (o | (o << 2)) & 0x33333333u;
-                e = (e | (e << 1)) & 0x55555555u, o = (o | (o << 1)) & 0x55555555u;
+                // sixteen states' low action bits in the word's low half, their high bits in its high half
+                const uint32_t e = (uint32_t)(b0 >> (16 * lane)) & 0xFFFFu, o = (uint32_t)(b1 >> (16 * lane)) & 0xFFFFu;
                 const uint32_t word = (uint32_t)(s_first >> 4) + (uint32_t)lane;
-                vi_st_l2(reinterpret_cast<vi_u64 *>(gx + aw_off + par * aw_bytes) + word, ((vi_u64)(e | (o << 1)) << 32) | tag);
+                vi_st_l2(reinterpret_cast<vi_u64 *>(gx + aw_off + par * aw_bytes) + word, ((vi_u64)(e | (o << 16)) << 32) | tag);
             }
         }
     };
@@ -351,7 +379,10 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         // (unpredicated: a lane without an env walks cell 0; two independent chains of three dependent LDS gathers)
         uint32_t act[2], rec_e[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) act[e] = (actL[e_pos[e] >> 4] >> (2 * (e_pos[e] & 15))) & 3u, rec_e[e] = cell.f[e_pos[e]];
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t w = actL[e_pos[e] >> 4] >> (e_pos[e] & 15);
+            act[e] = (w & 1u) | ((w >> 15) & 2u), rec_e[e] = cell.f[e_pos[e]];
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) e_pos[e] = vi_next(e_pos[e], rec_e[e], act[e], W);
 #pragma unroll
@@ -383,8 +414,40 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             __builtin_amdgcn_s_sleep(1);
             delta_load(rr);
         }
-        return vi_wave_max_last(polls ? (d_hi & 0xFFFFFFFF00000000ull) | (d_lo >> 32) : 0ull);  // (in the wave's last lane)
+        return vi_wave_max_all(polls ? (d_hi & 0xFFFFFFFF00000000ull) | (d_lo >> 32) : 0ull);
     };
+    // the workgroup's delta key of round `rr`: the maximum of its lanes' keys in LDS (in every lane), and its post
+    auto reduce_keys = [&](int32_t rr) -> vi_u64 {
+        vi_u64 m = 0ull;
+        if (K == 1 && state_waves <= 2) {  // (both reads in flight at once)
+            const vi_u64 k0 = lane_key[(rr & 1) * B + lane], k1 = state_waves > 1 ? lane_key[(rr & 1) * B + 64 + lane] : 0ull;
+            m = k0 > k1 ? k0 : k1;
+        } else {
+            for (int32_t i = lane; i < (K == 1 ? state_waves * 64 : B); i += 64) {
+                const vi_u64 k = lane_key[(rr & 1) * B + i];
+                m = k > m ? k : m;
+            }
+        }
+        return vi_wave_max_all(m);
+    };
+    auto post = [&](int32_t rr, vi_u64 m) {
+        if (lane == 0) {
+            const uint32_t tag = (uint32_t)rr + 1u;
+            vi_u64 *slot = slots + (size_t)((uint32_t)rr & 3u) * VI_XCD_SLOTS * 2;
+            vi_st_l2(slot + 2 * rank, (m & 0xFFFFFFFF00000000ull) | tag);
+            vi_st_l2(slot + 2 * rank + 1, (m << 32) | tag);
+        }
+    };
+    auto collect = [&](int32_t rr) {
+        const vi_u64 k = delta_finish(rr);
+#ifndef GU_VI_XCD_STAMPS
+        if (lane == 0) a.vi.delta_key[rr] = k;
+#else
+        asm volatile("" ::"v"(k));
+#endif
+    };
+    const bool late = AGENTS && split;                   // this workgroup has waves that own no states
+    const int32_t collect_wave = late ? waves - 1 : 0;  // (the key wave is the first of them)
     uint32_t act_prev[K];  // greedy action of the thread's states under the policy of the round before
     double v_new[K];       // the states' current values
     double gv[K][4];       // gamma * value of the four successors
@@ -419,53 +482,42 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
                     key = k > key ? k : key;
                 }
             }
-            if (AGENTS && r > 0) publish_actions(par, tag, act_prev);  // (the actions of round r - 1 travel with the values of round r)
             VI_STAMP(0);
-            // the thread's delta key goes to LDS as it is; the workgroup's maximum is taken behind the barrier, by a wave that
-            // owns no states where there is one (one ds_write here instead of ~50 DPP / compare / select instructions)
+            // the thread's delta key goes to LDS as it is; the workgroup's maximum is taken behind the barrier, under the exchange's
+            // round trip, by a wave that owns no states where there is one
             lane_key[(r & 1) * B + tid] = key;
             VI_STAMP(1);
         }
         __syncthreads();  // nobody reads the old values or actions in LDS any more; the lanes' keys are in LDS
         VI_STAMP(3);
-        if (wave == key_wave) {  // post the workgroup's key (read one round late by the workgroup that collects the deltas)
-            vi_u64 mine = 0ull;
-            for (int32_t i = lane; i < (K == 1 ? state_waves * 64 : B); i += 64) {
-                const vi_u64 k = lane_key[(r & 1) * B + i];
-                mine = k > mine ? k : mine;
-            }
-            mine = vi_wave_max_last(mine);
-            if (lane == 63) {
-                vi_u64 *slot = slots + (size_t)((uint32_t)r & 3u) * VI_XCD_SLOTS * 2;
-                vi_st_l2(slot + 2 * rank, (mine & 0xFFFFFFFF00000000ull) | tag);
-                vi_st_l2(slot + 2 * rank + 1, (mine << 32) | tag);
-            }
-            if (sync_delta) {  // the round's delta, for everybody: this wave collects the members' keys while the others fetch the values
-                delta_load(r);
-                const vi_u64 k = delta_finish(r);
-                if (lane == 63) round_key_lds = k;
-            }
-        }
 #pragma unroll
         for (int j = 0; j < K; ++j)
             if (st[j] >= 0) vL[st[j]] = v_new[j];
-        const bool collects = !sync_delta && keeps_deltas && wave == 0 && r > 0;  // (one round late: off everybody's critical path)
-        if (collects) delta_load(r - 1);
-        fetch(par, tag, true, AGENTS && r > 0);
+        // (two rounds late, and where there is one by a wave that owns no states, behind barrier 2: off everybody's critical path)
+        const bool collects = !sync_delta && keeps_deltas && wave == collect_wave && r > 1;
+        if (collects) delta_load(r - 2);
+        // The workgroup's key.  The tables alone want it this round, everybody: reduced and posted while the exchange is in flight.
+        // With agents it is collected two rounds late by workgroup 0: a wave without states reduces and posts it behind barrier 2,
+        // where it has time to spare; a wave that owns states too reduces it under the exchange's round trip and posts it BEHIND
+        // the exchange (a store ahead of it would turn the wait for the loads into a wait for the store's acknowledgement as well).
+        const bool posts = wave == key_wave, posts_late = late;
+        vi_u64 mine = 0ull;
+        fetch(par, tag, true, AGENTS && r > 0, [&]() {
+            if (!posts || posts_late) return;
+            mine = reduce_keys(r);
+            if (sync_delta) {
+                post(r, mine);
+                delta_load(r);
+            }
+        });
+        if (posts && !sync_delta && !posts_late) post(r, mine);
         VI_STAMP(6);
-        if (collects) {
-            const vi_u64 k = delta_finish(r - 1);
-#ifndef GU_VI_XCD_STAMPS
-            if (lane == 63) a.vi.delta_key[r - 1] = k;
-#else
-            asm volatile("" ::"v"(k));
-#endif
+        if (posts && sync_delta) {  // the round's delta, for everybody
+            const vi_u64 k = delta_finish(r);
+            if (lane == 0) round_key_lds = k;
         }
-#ifdef GU_VI_XCD_STAMPS
-        VI_STAMP(1);   // (delta_finish alone: added to the key phase)
-        fetch(par, tag, true, r > 0);  // probe: the same fetch once more, everything certainly there
-        VI_STAMP(4);
-#endif
+        if (collects && !late) collect(r - 2);
+        VI_STAMP(5);
         __syncthreads();
         VI_STAMP(7);
         if (info[3] & 1u) {
@@ -513,51 +565,42 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
                 }
             }
         }
+        // the actions of this round leave before the values of the next: every agent of the cluster waits for every member's
+        // actions, and a word that has a V1 of head start is there when it is asked for
+        if (AGENTS && wave_has_states) publish_actions(par ^ 1u, tag + 1u, act_prev);
         VI_STAMP(8);
         if (sync_delta && a.vi.use_threshold && vi_unkey_dev(round_key) < a.vi.threshold) {  // dynamic_programming.py:22-23 / :42
             ++r;
             break;
         }
+        // (ahead of the agents' step, whose LDS round trips then cover the stores' acknowledgements -- the next barrier waits for them;
+        // the lanes' keys of this round stay in LDS until V1 of the round after next)
+        if (collects && late) collect(r - 2);
+        if (posts && posts_late) post(r, reduce_keys(r));
         if (AGENTS && r > 0 && has_envs) agents();
 #ifdef GU_VI_XCD_STAMPS
         asm volatile("" ::"v"(e_pos[0]), "v"(e_rew[0]), "v"(e_done[1]), "v"(p[0][0]));  // the round ends here, not wherever its results are needed
 #endif
         VI_STAMP(9);
-#ifdef GU_VI_XCD_STAMPS
-        {   // latency probes (diagnostic build only): one dependent load of a word nobody writes, L1-bypassing and plain
-            const uint64_t t0_ = __builtin_amdgcn_s_memtime();
-            const uint32_t x_ = vi_ld_word(hdr + 12);
-            asm volatile("s_waitcnt vmcnt(0)" ::"v"(x_) : "memory");
-            const uint64_t t1_ = __builtin_amdgcn_s_memtime();
-            const uint32_t y_ = *reinterpret_cast<volatile const uint32_t *>(hdr + 13 + (x_ & 1u));
-            asm volatile("s_waitcnt vmcnt(0)" ::"v"(y_) : "memory");
-            const uint64_t t2_ = __builtin_amdgcn_s_memtime();
-            stamp_acc[2] += t1_ - t0_;
-            stamp_acc[5] += t2_ - t1_;
-            stamp_last = t2_;
-        }
-#endif
     }
     if (AGENTS && !failed && r > 0) {  // the agents' step of the last round: its actions alone cross the cluster
-        const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;
-        if (wave_has_states) publish_actions(par, tag, act_prev);
+        const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;  // (published behind V2 of the last round)
         __syncthreads();
-        if (keeps_deltas && wave == 0) delta_load(r - 1);
-        fetch(par, tag, false, true);
-        if (keeps_deltas && wave == 0) {
-            const vi_u64 k = delta_finish(r - 1);
-#ifndef GU_VI_XCD_STAMPS
-            if (lane == 63) a.vi.delta_key[r - 1] = k;
-#else
-            asm volatile("" ::"v"(k));
-#endif
+        const bool collects = keeps_deltas && wave == collect_wave;
+        if (collects && r > 1) delta_load(r - 2);
+        fetch(par, tag, false, true, []() {});
+        if (collects) {  // the last two deltas
+            if (r > 1) collect(r - 2);
+            delta_load(r - 1);
+            collect(r - 1);
         }
         __syncthreads();
         if (info[3] & 1u) failed = true;
         else if (has_envs) agents();
     }
 #ifdef GU_VI_XCD_STAMPS
-    if (keeps_deltas && tid == 0 && a.vi.max_rounds >= 12) {
+    // (which wave of which member is stamped: GU_VI_STAMP_WAVE / GU_VI_STAMP_RANK in the environment of the variant library)
+    if (writes_tables && rank == ((a.inject_failure >> 16) & 0xFFu) && tid == (int32_t)((a.inject_failure >> 8) & 0xFFu) * 64 && a.vi.max_rounds >= 12) {
         stamp_acc[11] = __builtin_amdgcn_s_memrealtime() - stamp_t0;
         for (int i = 0; i < 12; ++i) a.vi.delta_key[i] = stamp_acc[i];
     }
@@ -642,6 +685,10 @@ int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a
 {
     ViStepXcdArgs a = args;
     a.lds_values = plan.values;
+#ifdef GU_VI_XCD_STAMPS
+    if (const char *w = getenv("GU_VI_STAMP_WAVE")) a.inject_failure |= ((uint32_t)atoi(w) & 0xFFu) << 8;
+    if (const char *k = getenv("GU_VI_STAMP_RANK")) a.inject_failure |= ((uint32_t)atoi(k) & 0xFFu) << 16;
+#endif
     typedef void (*Kernel)(const ViStepXcdArgs);
     static std::atomic<uint64_t> lds_mask[6];
     const int which = (plan.K == 1 ? 0 : 1) + (agents ? 0 : greedy ? 2 : 4);

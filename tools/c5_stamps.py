@@ -17,8 +17,9 @@ sys.path.insert(0, ROOT)
 import griduniverse_amd as gua  # noqa: E402
 from griduniverse_amd import _lib  # noqa: E402
 
-PHASES = ['V1 (LDS reads, f64 chain, granules stored, action words published)', 'delta key: DPP maximum + one LDS atomic', '(probe) one dependent sc1 load of an idle word', 'workgroup barrier 1',
-          '(probe) the same fetch once more', '(probe) one dependent plain load of an idle word', 'fetch: halo granules + action words, reloaded until tagged -> LDS', 'workgroup barrier 2', 'V2', 'agent step']
+PHASES = ['V1 from registers, granules stored', 'delta keys to LDS', 'own values to LDS, exchange loads issued, key wave: the workgroup\'s key reduced', 'workgroup barrier 1',
+          'exchange: halo granules + action words, reloaded until tagged', 'delta collected (workgroup 0, wave 0)', 'exchange -> LDS; key wave: key posted',
+          'workgroup barrier 2', 'V2, action words published', 'agent step (none in a wave that owns states)']
 
 
 def main():
@@ -26,13 +27,14 @@ def main():
     ap.add_argument('--envs', type=int, default=65536)
     ap.add_argument('--size', type=int, default=64)
     ap.add_argument('--rounds', type=int, default=2000)
+    ap.add_argument('--blocks', type=int, nargs='+', default=[256, 512, 1024])
     a = ap.parse_args()
     random.seed(5)
     np.random.seed(5)
     env = gua.GridUniverseEnv(grid_shape=(a.size, a.size), random_maze=True)
     S = env.world.size
     out = {}
-    for block in (256, 512, 1024):
+    for block in a.blocks:
         _lib.set_default_option('vi_xcd_block', block)
         with gua.Engine(a.envs, gua.GridSpec.from_env(env), seed=5) as eng:
             for rep in range(2):

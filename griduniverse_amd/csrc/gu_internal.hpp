@@ -257,7 +257,7 @@ int gu_launch_greedy_table(gu_engine *h);
 
 // ---- config 5 synchronised per XCD (gu_vi_xcd.hip) --------------------------------
 struct GuXcdPlan {
-    int block = 0, K = 0;      // threads per workgroup, states per thread at most
+    int block = 0, K = 0, NB = 1;  // threads per workgroup, states per thread at most, 16-byte exchange loads per thread (1 or 4)
     unsigned G = 0;            // workgroups
     uint32_t values = 0;       // doubles of a workgroup's value window in LDS
     size_t lds = 0, slots_bytes = 0, work_bytes = 0;  // dynamic LDS; scratch: delta-key slots (all XCCs), granule buffers (per XCC)

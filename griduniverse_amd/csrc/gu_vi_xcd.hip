@@ -21,8 +21,10 @@
 //                  state's successors are itself, s +- 1 and s +- W -- and (b) the greedy action of EVERY state, which its agents
 //                  look up (2 bits per state; an agent re-deriving its action from the values would need the whole float64 table
 //                  in every workgroup and ~100 more float64 instructions per wave and round).  The actions of round r are known
-//                  only after V2 of round r: they travel with the values of round r + 1, and the agents run ONE ROUND BEHIND the
-//                  tables (they feed nothing back into them); a last exchange after the loop delivers the last actions.
+//                  only after V2 of round r: they are published right there, tagged for round r + 1 and fetched with its values
+//                  -- every agent waits for EVERY member's actions, so they get the length of a V1 as a head start -- and the
+//                  agents run ONE ROUND BEHIND the tables (they feed nothing back into them); a last exchange after the loop
+//                  delivers the last actions.
 //   granules     = every word that crosses carries the round: a value is two 8-byte words {high half | tag}, {low half | tag}
 //                  (16 bytes per state), sixteen actions are one word {32 action bits | tag}; tag = round + 1, buffers zeroed
 //                  before the launch, double-buffered by round parity.  A consumer loads what it needs (16-byte L1-bypassing
@@ -32,9 +34,14 @@
 //   overwriting  = a buffer of parity p is rewritten two rounds later.  To store round r + 2 a workgroup must have finished its
 //                  fetch of round r + 1, which contains words EVERY member stored in its own round r + 1, i.e. after that
 //                  member's fetch of round r was complete: nobody still wants the words of round r.
-//   deltas       = the per-round maximum of v - v' (dynamic_programming.py:17) is reduced per workgroup (DPP + one LDS atomic),
-//                  posted in a tagged slot (four deep) and collected one round late by workgroup 0 of the cluster that writes the
-//                  tables -- off everybody's critical path.
+//   deltas       = the per-round maximum of v - v' (dynamic_programming.py:17): every lane leaves its key in LDS, a wave reduces them
+//                  (two passes of 32-bit DPP maxima) and posts the workgroup's key in a tagged slot (four deep), and workgroup 0 of
+//                  the cluster that writes the tables collects the slots TWO rounds late.  Where a workgroup has waves that own no
+//                  states (config 5: two of four), those do both, behind barrier 2, ahead of their agents' step -- nothing of it
+//                  is on the path store -> exchange -> V2 -> V1 -> store that bounds the round.
+//   waves        = a round of a wave that owns states: V1 from registers, granule stored, key to LDS | barrier 1 | own value to LDS,
+//                  exchange | barrier 2 | V2, actions published.  Of a wave that owns none: | barrier 1 | exchange | barrier 2 |
+//                  (deltas collected) (key reduced, posted) agents' step.  tools/c5_stamps.py times the phases per wave.
 //
 // The same float64 operations in the same order per state as every other DP kernel of the library, hence the same bits; the
 // agents of all clusters see identical tables, so which cluster steps which env is invisible in the results.  Every spin is
@@ -71,32 +78,12 @@ __device__ __forceinline__ void vi_st_l2(vi_u64 *p, vi_u64 x) { __hip_atomic_sto
 __device__ __forceinline__ vi_u64 vi_ld_l2(const vi_u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t vi_ld_word(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Maximum over the wave, left in its LAST lane (lane 63): DPP row shifts inside each row of 16 lanes, then the two row broadcasts
-// of the gfx9 family -- register moves inside the SIMD, no LDS round trips.  (A 64-bit __shfl butterfly costs ~700 clocks of
-// dependent ds_bpermute traffic.  An LDS atomicMax per lane is turned by the compiler's atomic optimizer into a scalar loop over
-// the active lanes at ~100 clocks per lane: 7300 clocks for a full wave, and still 3400 for the 32 lanes that hold a cluster's
-// slot keys -- in ONE workgroup, for which the whole cluster then waits every round.)
-__device__ __forceinline__ vi_u64 vi_wave_max_last(vi_u64 k)
-{
-#define VI_DPP_STEP(ctrl, rows)                                                                                          \
-    {                                                                                                                    \
-        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, ctrl, rows, 0xF, false);         \
-        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), ctrl, rows, 0xF, false); \
-        const vi_u64 o_ = ((vi_u64)hi_ << 32) | lo_;                                                                     \
-        k = o_ > k ? o_ : k;                                                                                             \
-    }
-    VI_DPP_STEP(0x111, 0xF)  // row_shr:1 (a lane without a source reads 0: keys are never below 1)
-    VI_DPP_STEP(0x112, 0xF)  // row_shr:2
-    VI_DPP_STEP(0x114, 0xF)  // row_shr:4
-    VI_DPP_STEP(0x118, 0xF)  // row_shr:8      -> lane 15 of every row holds the row's maximum
-    VI_DPP_STEP(0x142, 0xA)  // row_bcast:15   -> rows 1 and 3 take in the last lane of rows 0 and 2
-    VI_DPP_STEP(0x143, 0xC)  // row_bcast:31   -> rows 2 and 3 take in lane 31
-#undef VI_DPP_STEP
-    return k;
-}
-
-// The same maximum, in every lane, in two passes of 32-bit halves (the keys order like (high word, low word)): v_max_u32 takes the
-// DPP operand itself, so a pass is six instructions where the 64-bit compare-and-select above needs ~8 per step.
+// Maximum of a 64-bit key over the wave, in every lane: DPP row shifts inside each row of 16 lanes, then the two row broadcasts of
+// the gfx9 family -- register moves inside the SIMD, no LDS round trips -- in two passes of 32-bit halves (the keys order like
+// (high word, low word)): v_max_u32 takes the DPP operand itself, so a pass is six instructions, where a 64-bit compare-and-select
+// needs ~8 per step.  (A 64-bit __shfl butterfly costs ~700 clocks of dependent ds_bpermute traffic.  An LDS atomicMax per lane is
+// turned by the compiler's atomic optimizer into a scalar loop over the active lanes at ~100 clocks per lane: 7300 clocks for a
+// full wave; a hand-written ds_max_u64 of 64 lanes on one word holds the LDS for ~4 clocks per lane.)
 __device__ __forceinline__ uint32_t vi_wave_max32(uint32_t x)
 {
 #define VI_DPP_STEP(ctrl, rows)                                                                  \
@@ -104,12 +91,12 @@ __device__ __forceinline__ uint32_t vi_wave_max32(uint32_t x)
         const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xF, false); \
         x = o_ > x ? o_ : x;                                                                     \
     }
-    VI_DPP_STEP(0x111, 0xF)
-    VI_DPP_STEP(0x112, 0xF)
-    VI_DPP_STEP(0x114, 0xF)
-    VI_DPP_STEP(0x118, 0xF)
-    VI_DPP_STEP(0x142, 0xA)
-    VI_DPP_STEP(0x143, 0xC)
+    VI_DPP_STEP(0x111, 0xF)  // row_shr:1 (a lane without a source reads 0)
+    VI_DPP_STEP(0x112, 0xF)  // row_shr:2
+    VI_DPP_STEP(0x114, 0xF)  // row_shr:4
+    VI_DPP_STEP(0x118, 0xF)  // row_shr:8      -> lane 15 of every row holds the row's maximum
+    VI_DPP_STEP(0x142, 0xA)  // row_bcast:15   -> rows 1 and 3 take in the last lane of rows 0 and 2
+    VI_DPP_STEP(0x143, 0xC)  // row_bcast:31   -> rows 2 and 3 take in lane 31: lane 63 holds the wave's
 #undef VI_DPP_STEP
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
@@ -119,9 +106,10 @@ __device__ __forceinline__ vi_u64 vi_wave_max_all(vi_u64 k)
     return ((vi_u64)top << 32) | vi_wave_max32(hi == top ? (uint32_t)k : 0u);
 }
 
-// -DGU_VI_XCD_STAMPS (a diagnostic variant library, tools/c5_stamps.py; never the product): workgroup rank 0 of the cluster that
-// writes the tables sums the shader-clock cycles its first wave spends in every phase of a round and returns the sums IN PLACE
-// OF the first deltas (delta_key[0 .. 11]; [10] = poll turns, [11] = 100 MHz ticks of the whole loop).
+// -DGU_VI_XCD_STAMPS (a diagnostic variant library, tools/c5_stamps.py; never the product): ONE wave of one member of the cluster
+// that writes the tables (GU_VI_STAMP_RANK, GU_VI_STAMP_WAVE in the environment at launch) sums the shader-clock cycles it spends
+// in every phase of a round and returns the sums IN PLACE OF the first deltas (delta_key[0 .. 11]; [10] = poll turns, [11] =
+// 100 MHz ticks of the whole loop).
 #ifdef GU_VI_XCD_STAMPS
 #define VI_STAMP(i)                                             \
     do {                                                        \
@@ -139,7 +127,7 @@ __device__ __forceinline__ vi_u64 vi_wave_max_all(vi_u64 k)
 // registration) run { V1; delta; V2 if GREEDY } with the stopping rule of value_iteration / of policy_iteration's evaluation loop
 // (dynamic_programming.py:14-27, 40-42) decided in the kernel: every workgroup waits for every member's delta key of the round --
 // posted with the round's values, fetched beside them -- so all of them stop behind the same round.
-template <int K, bool AGENTS, bool GREEDY>
+template <int K, bool AGENTS, bool GREEDY, int NB>
 __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
 {
     static_assert(!AGENTS || GREEDY, "the agents follow the greedy policy of the round");
@@ -199,7 +187,8 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
 
     // ---- per-state constants, the initial table, the own envs ----
     int32_t st[K];    // the thread's states (-1: none)
-    uint32_t rec[K], rn[K];
+    uint32_t rec[K];
+    double rn[K][4];  // the rewards of a state's four successors (integers, as doubles: converted once)
     int32_t r_own[K];
     double p[K][4];
 #pragma unroll
@@ -207,7 +196,9 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         const int32_t local = tid + j * B;
         const int32_t s = (int32_t)rank * chunk + local;
         st[j] = (!failed && local < chunk && s < S) ? s : -1;
-        rec[j] = rn[j] = 0u;
+        rec[j] = 0u;
+#pragma unroll
+        for (int act = 0; act < 4; ++act) rn[j][act] = 0.0;
         r_own[j] = 0;
 #pragma unroll
         for (int act = 0; act < 4; ++act) p[j][act] = 0.0;
@@ -215,7 +206,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             rec[j] = cell.f[s];
             r_own[j] = cell.r[s];
 #pragma unroll
-            for (uint32_t act = 0; act < 4; ++act) rn[j] |= (uint32_t)(uint8_t)cell.r[vi_next(s, rec[j], act, W)] << (8 * act);
+            for (uint32_t act = 0; act < 4; ++act) rn[j][act] = (double)cell.r[vi_next(s, rec[j], act, W)];
             const double4 row = *reinterpret_cast<const double4 *>(a.vi.pi + 4 * (int64_t)s);
             p[j][0] = row.x, p[j][1] = row.y, p[j][2] = row.z, p[j][3] = row.w;
         }
@@ -287,9 +278,9 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     // (computed inside the loop, the selects and bounds of this bookkeeping were three quarters of the fetch's 1900 clocks).
     // kind: 0 = none, 1 = value granule, 2 = action item with two words, 3 = action item whose second word does not exist.
     const int32_t n_items = n_below + n_above + (AGENTS ? n_aw : 0);
-    uint32_t it_src[4], it_dst[4], it_kind[4];
+    uint32_t it_src[NB], it_dst[NB], it_kind[NB];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < NB; ++m) {
         const int32_t x = m * B + tid, n_v = n_below + n_above;
         const int32_t s = x < n_below ? below0 + x : hi + (x - n_below);  // the state of a value item
         const int32_t w = x - n_v;                                        // the index of an action item
@@ -302,9 +293,8 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     // branch makes the compiler wait for every load in flight at the branch (a first version ran its eight loads ONE AFTER THE
     // OTHER, 450 clocks each).  A lane without an item loads from beyond the buffer's size (the bounds check returns zeros
     // without a memory access) and writes to a spare 16 bytes behind the table.
-    const int32_t n_batches = (n_items + B - 1) / B;  // 16-byte loads per thread (uniform over the workgroup): 1 at config 5
-    auto fetch_n = [&](auto batches, uint32_t par, uint32_t tag, bool with_v, bool with_act, auto &&meanwhile) {
-        constexpr int NB = decltype(batches)::value;
+    // NB = 16-byte loads per thread: 1 at config 5 (the host picks the instance: 1 where the items fit the workgroup, else 4)
+    auto fetch = [&](uint32_t par, uint32_t tag, bool with_v, bool with_act, auto &&meanwhile) {
         uint32_t src[NB];
         bool on[NB];
 #pragma unroll
@@ -346,11 +336,6 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atomicOr(&info[3], 1u);
         }
-    };
-    auto fetch = [&](uint32_t par, uint32_t tag, bool with_v, bool with_act, auto &&meanwhile) {
-        if (n_batches <= 1) fetch_n(std::integral_constant<int, 1>{}, par, tag, with_v, with_act, meanwhile);
-        else if (n_batches == 2) fetch_n(std::integral_constant<int, 2>{}, par, tag, with_v, with_act, meanwhile);
-        else fetch_n(std::integral_constant<int, 4>{}, par, tag, with_v, with_act, meanwhile);
     };
     // this wave's sixteen-action words of parity `par`: lanes 0 .. 3 assemble them from two ballots and store them
     auto publish_actions = [&](uint32_t par, uint32_t tag, const uint32_t act[K]) {
@@ -541,17 +526,21 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
 #pragma unroll
                 for (uint32_t act = 0; act < 4; ++act) {
                     gv[j][act] = __dmul_rn(gamma, vL[vi_next(s, rec[j], act, W)]);
-                    q[act] = __dadd_rn((double)(int8_t)(rn[j] >> (8 * act)), gv[j][act]);
+                    q[act] = __dadd_rn(rn[j][act], gv[j][act]);
                     k[act] = rint(__dmul_rn(q[act], 100000000.0));
                 }
                 if (GREEDY) {  // (!GREEDY: the evaluation sweeps of policy_iteration keep the policy; V1 still wants gamma * v'[next])
                     const double kmax = fmax(fmax(k[0], k[1]), fmax(k[2], k[3]));
-                    const double kabs = fmax(fmax(fabs(k[0]), fabs(k[1])), fmax(fabs(k[2]), fabs(k[3])));
-                    uint32_t mask = 0u;
+                    uint32_t mask = 0u, top = 0u;
 #pragma unroll
-                    for (int act = 0; act < 4; ++act) mask |= (uint32_t)(k[act] == kmax) << act;
-                    const bool any_nan = k[0] != k[0] || k[1] != k[1] || k[2] != k[2] || k[3] != k[3];
-                    if (!(kabs < 3355443200000000.0) || any_nan) {  // 2^25 * 1e8 (proof: gu_vi.hpp, vi_tie_mask)
+                    for (int act = 0; act < 4; ++act) {
+                        mask |= (uint32_t)(k[act] == kmax) << act;
+                        const uint32_t h = (uint32_t)((vi_u64)__double_as_longlong(k[act]) >> 32) & 0x7FFFFFFFu;
+                        top = h > top ? h : top;  // (sign off, exponent and the top of the mantissa: orders like |k|, NaN and inf on top)
+                    }
+                    // |k| >= 2^25 * 1e8 = 3355443200000000.0 = 0x4327D784_00000000, or NaN (proof: gu_vi.hpp, vi_tie_mask), told from
+                    // the high words alone -- four integer instructions instead of seven double-rate ones
+                    if (top >= 0x4327D784u) {
                         double qmax = q[0];
 #pragma unroll
                         for (int act = 1; act < 4; ++act) qmax = (q[act] > qmax) ? q[act] : qmax;
@@ -671,6 +660,7 @@ bool gu_vi_xcd_plan(const gu_engine *h, bool agents, GuXcdPlan *plan)
         plan->block = (int)B;
         plan->G = (unsigned)G;
         plan->K = K;
+        plan->NB = items <= B ? 1 : 4;
         plan->lds = lds;
         plan->values = (uint32_t)values;
         plan->slots_bytes = (size_t)VI_XCD_MAX_XCC * 4 * VI_XCD_SLOTS * 2 * sizeof(vi_u64);
@@ -690,10 +680,12 @@ int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a
     if (const char *k = getenv("GU_VI_STAMP_RANK")) a.inject_failure |= ((uint32_t)atoi(k) & 0xFFu) << 16;
 #endif
     typedef void (*Kernel)(const ViStepXcdArgs);
-    static std::atomic<uint64_t> lds_mask[6];
-    const int which = (plan.K == 1 ? 0 : 1) + (agents ? 0 : greedy ? 2 : 4);
-    static const Kernel kernels[6] = {gu_vi_xcd_kernel<1, true, true>,  gu_vi_xcd_kernel<2, true, true>,  gu_vi_xcd_kernel<1, false, true>,
-                                      gu_vi_xcd_kernel<2, false, true>, gu_vi_xcd_kernel<1, false, false>, gu_vi_xcd_kernel<2, false, false>};
+    static std::atomic<uint64_t> lds_mask[12];
+    const int which = (plan.K == 1 ? 0 : 1) + (agents ? 0 : greedy ? 2 : 4) + (plan.NB == 1 ? 0 : 6);
+    static const Kernel kernels[12] = {gu_vi_xcd_kernel<1, true, true, 1>,   gu_vi_xcd_kernel<2, true, true, 1>,   gu_vi_xcd_kernel<1, false, true, 1>,
+                                       gu_vi_xcd_kernel<2, false, true, 1>,  gu_vi_xcd_kernel<1, false, false, 1>, gu_vi_xcd_kernel<2, false, false, 1>,
+                                       gu_vi_xcd_kernel<1, true, true, 4>,   gu_vi_xcd_kernel<2, true, true, 4>,   gu_vi_xcd_kernel<1, false, true, 4>,
+                                       gu_vi_xcd_kernel<2, false, true, 4>,  gu_vi_xcd_kernel<1, false, false, 4>, gu_vi_xcd_kernel<2, false, false, 4>};
     const Kernel kern = kernels[which];
     gu_allow_lds(kern, lds_mask[which], h->device, plan.lds, (size_t)h->lds_per_cu - 1024);  // (the kernel also has a few static LDS words)
     hipLaunchKernelGGL(kern, dim3(plan.G), dim3(plan.block), plan.lds, h->stream, a);

@@ -18,6 +18,10 @@
 #define GU_RNG_STREAM_ACTION 0u
 #define GU_RNG_STREAM_START 1u
 #define GU_RNG_STREAM_SAMPLE 2u
+#ifndef GU_RNG_SAMPLE_LOG2
+#define GU_RNG_SAMPLE_LOG2 4u  // steps per hashed word of stream 2: 1 << this = 16 (oracle/gu_rng.py: SAMPLE_GROUP_LOG2)
+#endif
+#define GU_RNG_SAMPLE_MASK ((1u << GU_RNG_SAMPLE_LOG2) - 1u)
 
 __host__ __device__ __forceinline__ uint32_t gu_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 
@@ -53,9 +57,10 @@ __host__ __device__ __forceinline__ uint32_t gu_rng_word_begin(uint32_t prefix, 
     uint32_t len = 16u;
     const uint32_t hi = ctr >> 28;  // beyond 2^28 draws of one stream: the high counter bits are a fifth key word
 #if defined(__HIP_DEVICE_COMPILE__)
-    // a WAVE-UNIFORM branch (one scalar test; the whole wave skips the block in the practically universal case), instead of
-    // a per-lane one that would be executed under an empty EXEC mask on every draw
-    if (__builtin_amdgcn_ballot_w64(hi != 0u)) {
+    // a WAVE-UNIFORM branch (one scalar test; the whole wave passes the block by in the practically universal case), instead of
+    // a per-lane one that would be executed under an empty EXEC mask on every draw; marked unlikely, so that the block is laid out
+    // of line and the usual path falls through (a TAKEN branch costs ~60 clocks where a SIMD has one wave)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(hi != 0u) != 0ull, 0)) {
         const uint32_t h5 = gu_mm3_block(h, hi);
         h = hi ? h5 : h;
         len = hi ? 20u : 16u;
@@ -84,10 +89,11 @@ __host__ __device__ __forceinline__ uint32_t gu_rng_word(uint32_t prefix, uint32
     return gu_rng_word_finish(gu_rng_word_begin(prefix, stream, ctr));
 }
 
-// Stream 2, the words behind the inverse-CDF samples of a table policy (oracle/gu_rng.py: sample_word): ONE hashed word per FOUR
-// steps, the words of the three steps behind it by a multiply-free bijection (xorshift32 step + Weyl increment).  A hash per
-// step was what bound the sampled rollout: five quarter-rate 32-bit multiplies, ~80 clocks of issue time per step against the
-// ~30 of the rest of the step.
+// Stream 2, the words behind the inverse-CDF samples of a table policy (oracle/gu_rng.py: sample_word): ONE hashed word per
+// SIXTEEN steps, the words of the fifteen steps behind it by a multiply-free bijection (xorshift32 step + Weyl increment).  A
+// hash per step was what bound the sampled rollout (five quarter-rate 32-bit multiplies, ~80 clocks of issue time per step
+// against the ~30 of the rest of the step); one per four steps still left it 9 of a step's 34 instructions, and the sampled
+// rollout with int32 rows at 0.80 of the HBM peak; one per sixteen: 0.87 (profiles/r04z_sample_rollout.json).
 __host__ __device__ __forceinline__ uint32_t gu_rng_sample_next(uint32_t x)
 {
     x ^= x << 13;
@@ -98,22 +104,31 @@ __host__ __device__ __forceinline__ uint32_t gu_rng_sample_next(uint32_t x)
 
 __host__ __device__ __forceinline__ uint32_t gu_rng_sample_word(uint32_t prefix, uint32_t t)
 {
-    uint32_t w = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t >> 2);
-    for (uint32_t i = 0; i < (t & 3u); ++i) w = gu_rng_sample_next(w);
+    uint32_t w = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, t >> GU_RNG_SAMPLE_LOG2);
+    for (uint32_t i = 0; i < (t & GU_RNG_SAMPLE_MASK); ++i) w = gu_rng_sample_next(w);
     return w;
 }
 
 // The word of step t + 1 from the word of step t.  Device: the hash is behind a WAVE-UNIFORM test, so a wave whose lanes are at
-// one step count (every launch that did not start from a per-env gu_set_state) hashes once in four steps.
+// one step count (every launch that did not start from a per-env gu_set_state) hashes once in sixteen steps.  The rollout kernels
+// use this form only where the lanes' step counts differ or are not yet a multiple of sixteen; where they agree the schedule is
+// unrolled (gu_rng_sample_advance_at): the test is a ballot and a branch per step, and with one wave per SIMD a taken branch
+// costs ~60 clocks -- fifteen steps in sixteen.
 __device__ __forceinline__ uint32_t gu_rng_sample_advance(uint32_t prefix, uint32_t t, uint32_t word)
 {
     uint32_t next = gu_rng_sample_next(word);
-    const bool fresh = ((t + 1u) & 3u) == 0u;
+    const bool fresh = ((t + 1u) & GU_RNG_SAMPLE_MASK) == 0u;
     if (__builtin_amdgcn_ballot_w64(fresh)) {
-        const uint32_t hashed = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, (t + 1u) >> 2);
+        const uint32_t hashed = gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, (t + 1u) >> GU_RNG_SAMPLE_LOG2);
         next = fresh ? hashed : next;
     }
     return next;
+}
+// the same where the caller knows at compile time whether step t + 1 starts a word (t the same in every lane)
+template <bool FRESH>
+__device__ __forceinline__ uint32_t gu_rng_sample_advance_at(uint32_t prefix, uint32_t t, uint32_t word)
+{
+    return FRESH ? gu_rng_word(prefix, GU_RNG_STREAM_SAMPLE, (t + 1u) >> GU_RNG_SAMPLE_LOG2) : gu_rng_sample_next(word);
 }
 
 // index into starts[] for episode `ep` (multiply-shift range reduction)

@@ -6,6 +6,7 @@
 
 #include <cstdlib>
 #include <functional>
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------
 // fused rollout: T env-steps per lane in one launch
@@ -409,7 +410,10 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         GuPacer pacer;
         pacer.start(TRAJ == 1 ? a.pace : 0u);
         auto run = [&](auto thr_at) {
-            auto tstep = [&](uint32_t soff) {
+            // fresh: 0 = step t + 1 starts no sampling word, 1 = it does (both: t the same in every lane, known at compile time),
+            // 2 = ask the lanes (gu_rng.hpp)
+            auto tstep = [&](uint32_t soff, auto fresh_tag) {
+                constexpr int FRESH = decltype(fresh_tag)::value;
                 if (AUTO == 1) {
                     const bool was_done = flags & GU_CELL_TERM;
                     s = was_done ? start0 : s;
@@ -431,22 +435,48 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                     // inverse CDF of pi[s] on one uniform 32-bit word (RNG stream 2, counter = step count), as integer
                     // thresholds (gu_pi_threshold_kernel)
                     const uint4 q = thr_at(s);
-                    const uint32_t next_word = gu_rng_sample_advance(prefix, t, word);
+                    const uint32_t next_word = FRESH == 2 ? gu_rng_sample_advance(prefix, t, word)
+                                               : FRESH == 1 ? gu_rng_sample_advance_at<true>(prefix, t, word) : gu_rng_sample_advance_at<false>(prefix, t, word);
                     act = gu_sample_action(word, q);
                     word = next_word;
                 }
                 ++t;
                 step(act, soff);
             };
+            const std::integral_constant<int, 0> same_word{};
+            const std::integral_constant<int, 1> new_word{};
+            const std::integral_constant<int, 2> ask{};
             int64_t i = 0;
-            for (; i + 8 <= a.T; i += 8) {
+            const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);
+            if (POLICY == GU_POLICY_SAMPLE && __all(t == t_first)) {
+                // every lane at the same step count: single steps up to a multiple of four, then groups of eight in which the
+                // fourth and the eighth step start a word -- no ballot, no branch (a taken branch costs ~60 clocks at one wave per SIMD)
+                t = t_first;
+                for (; i < a.T && (t & GU_RNG_SAMPLE_MASK); ++i) {
+                    tstep(0, ask);
+                    if (TRAJ) rebase(1);
+                }
+                if (i) pacer.after((uint32_t)i);
+                constexpr uint32_t G = GU_RNG_SAMPLE_MASK + 1u < 8u ? 8u : GU_RNG_SAMPLE_MASK + 1u;  // steps per unrolled group
+                for (; i + G <= a.T; i += G) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tstep(j * row32);
-                if (TRAJ) rebase(8);
-                if (i + 8 < a.T) pacer.after(8);
+                    for (uint32_t j = 0; j < G; ++j) {
+                        if ((j & GU_RNG_SAMPLE_MASK) == GU_RNG_SAMPLE_MASK) tstep(j * row32, new_word);
+                        else tstep(j * row32, same_word);
+                    }
+                    if (TRAJ) rebase(G);
+                    if (i + G < a.T) pacer.after(G);
+                }
+            } else {
+                for (; i + 8 <= a.T; i += 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) tstep(j * row32, ask);
+                    if (TRAJ) rebase(8);
+                    if (i + 8 < a.T) pacer.after(8);
+                }
             }
             for (; i < a.T; ++i) {
-                tstep(0);
+                tstep(0, ask);
                 if (TRAJ) rebase(1);
             }
         };

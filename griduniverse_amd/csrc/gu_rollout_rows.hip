@@ -380,11 +380,37 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             word = next_word;
             ++t;
         };
-        for (; i + 8 <= a.T; i += 8) {
+        // Sampled policy, every lane at the same step count: a head of single steps up to a multiple of four, then groups of eight
+        // in which the steps that start a word (the fourth and the eighth) are known at compile time -- no ballot, no branch.
+        const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);
+        if (POLICY == GU_POLICY_SAMPLE && __all(t == t_first)) {
+            t = t_first;
+            for (; i < a.T && (t & GU_RNG_SAMPLE_MASK); ++i) {
+                pstep(0);
+                if (TRAJ) rebase(1);
+            }
+            if (i > 1) pacer.after((uint32_t)i);
+            constexpr uint32_t G = GU_RNG_SAMPLE_MASK + 1u < 8u ? 8u : GU_RNG_SAMPLE_MASK + 1u;  // steps per unrolled group
+            for (; i + G <= a.T; i += G) {
 #pragma unroll
-            for (uint32_t j = 0; j < 8; ++j) pstep(j * row32);
-            if (TRAJ) rebase(8);
-            if (i + 8 < a.T) pacer.after(8);
+                for (uint32_t j = 0; j < G; ++j) {
+                    uint32_t next_word = 0u;
+                    step(word, j * row32, [&] {
+                        next_word = (j & GU_RNG_SAMPLE_MASK) == GU_RNG_SAMPLE_MASK ? gu_rng_sample_advance_at<true>(prefix, t, word) : gu_rng_sample_advance_at<false>(prefix, t, word);
+                    });
+                    word = next_word;
+                    ++t;
+                }
+                if (TRAJ) rebase(G);
+                if (i + G < a.T) pacer.after(G);
+            }
+        } else {
+            for (; i + 8 <= a.T; i += 8) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) pstep(j * row32);
+                if (TRAJ) rebase(8);
+                if (i + 8 < a.T) pacer.after(8);
+            }
         }
         for (; i < a.T; ++i) {
             pstep(0);

@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     const int32_t own_states = lo < S ? (chunk < S - lo ? chunk : S - lo) : 0;                // states of this workgroup
     const int32_t state_waves = K == 1 ? (own_states + 63) >> 6 : (own_states > 0 ? waves : 0);
     const bool split = K == 1 && 2 * state_waves <= waves;
-    const bool has_envs = AGENTS && (!split || wave >= state_waves);  // (wave-uniform)
+    const bool envs_here = AGENTS && (!split || wave >= state_waves);  // (wave-uniform)
     int64_t gid[2];
     bool own_env[2];
 #pragma unroll
@@ -248,9 +248,9 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         }
     __syncthreads();
 
-    bool wave_has_states = false;  // (wave-uniform: the states of a chunk are dealt to whole waves)
+    bool any_states = false;  // (wave-uniform: the states of a chunk are dealt to whole waves)
 #pragma unroll
-    for (int j = 0; j < K; ++j) wave_has_states = wave_has_states || __any(st[j] >= 0);
+    for (int j = 0; j < K; ++j) any_states = any_states || __any(st[j] >= 0);
     vi_u64 *lane_key = reinterpret_cast<vi_u64 *>(smem + ((2u * (uint32_t)cb + a.lds_values * 8u + 16u + (uint32_t)((((S + 15) >> 4) + 1) >> 1) * 8u + 15u) & ~15u));  // [2][B] the lanes' delta keys, by round parity
     for (int32_t i = tid; i < 2 * B; i += B) lane_key[i] = 0ull;       // (a lane without a state never writes its entry)
     const int32_t key_wave = split ? state_waves : 0;                 // the wave that reduces them
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             bool ok = true;
 #pragma unroll
             for (int m = 0; m < NB; ++m) ok = ok && (!on[m] || (t[m].x == tag && (t[m].z == tag || it_kind[m] == 3u)));
-            if (__all(ok)) break;
+            if (__builtin_expect(__all(ok) != 0, 1)) break;
             if (++spins > VI_CL_SPIN_LIMIT || ((spins & 255u) == 0u && vi_ld_word(hdr + 1))) {
                 bad = 1u;
                 break;
@@ -443,8 +443,15 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
 #pragma unroll
         for (uint32_t act = 0; act < 4; ++act) gv[j][act] = st[j] >= 0 ? __dmul_rn(gamma, vL[vi_next(st[j], rec[j], act, W)]) : 0.0;
     }
+    // One round.  Its code exists once per ROLE of a wave, so that a wave passes none of the other roles' work: with one wave per SIMD
+    // a taken branch costs ~60 clocks (measured, tools/c5_stamps.py), and a wave that owns states skipped eleven blocks per round.
+    // ROLE 1: a wave that owns states in a workgroup where other waves do everything else; 2: one of those other waves; 0: any wave
+    // of a workgroup whose waves all own states.
     int r = 0;
-    for (; r < a.vi.max_rounds && !failed; ++r) {
+    auto round = [&](auto role) -> bool {
+        constexpr int ROLE = decltype(role)::value;
+        const bool wave_has_states = ROLE == 1 ? true : ROLE == 2 ? false : any_states;
+        const bool has_envs = ROLE == 1 ? false : envs_here;
         const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;
         if (wave_has_states) {
             vi_u64 key = 0ull;
@@ -479,13 +486,13 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         for (int j = 0; j < K; ++j)
             if (st[j] >= 0) vL[st[j]] = v_new[j];
         // (two rounds late, and where there is one by a wave that owns no states, behind barrier 2: off everybody's critical path)
-        const bool collects = !sync_delta && keeps_deltas && wave == collect_wave && r > 1;
+        const bool collects = ROLE != 1 && !sync_delta && keeps_deltas && wave == collect_wave && r > 1;
         if (collects) delta_load(r - 2);
         // The workgroup's key.  The tables alone want it this round, everybody: reduced and posted while the exchange is in flight.
         // With agents it is collected two rounds late by workgroup 0: a wave without states reduces and posts it behind barrier 2,
         // where it has time to spare; a wave that owns states too reduces it under the exchange's round trip and posts it BEHIND
         // the exchange (a store ahead of it would turn the wait for the loads into a wait for the store's acknowledgement as well).
-        const bool posts = wave == key_wave, posts_late = late;
+        const bool posts = ROLE != 1 && wave == key_wave, posts_late = late;
         vi_u64 mine = 0ull;
         fetch(par, tag, true, AGENTS && r > 0, [&]() {
             if (!posts || posts_late) return;
@@ -507,7 +514,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         VI_STAMP(7);
         if (info[3] & 1u) {
             failed = true;
-            break;
+            return false;
         }
         vi_u64 round_key = 0ull;
         if (sync_delta) {
@@ -540,7 +547,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
                     }
                     // |k| >= 2^25 * 1e8 = 3355443200000000.0 = 0x4327D784_00000000, or NaN (proof: gu_vi.hpp, vi_tie_mask), told from
                     // the high words alone -- four integer instructions instead of seven double-rate ones
-                    if (top >= 0x4327D784u) {
+                    if (__builtin_expect(top >= 0x4327D784u, 0)) {  // (unlikely: laid out of line, the usual path falls through)
                         double qmax = q[0];
 #pragma unroll
                         for (int act = 1; act < 4; ++act) qmax = (q[act] > qmax) ? q[act] : qmax;
@@ -560,7 +567,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         VI_STAMP(8);
         if (sync_delta && a.vi.use_threshold && vi_unkey_dev(round_key) < a.vi.threshold) {  // dynamic_programming.py:22-23 / :42
             ++r;
-            break;
+            return false;
         }
         // (ahead of the agents' step, whose LDS round trips then cover the stores' acknowledgements -- the next barrier waits for them;
         // the lanes' keys of this round stay in LDS until V1 of the round after next)
@@ -571,6 +578,17 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         asm volatile("" ::"v"(e_pos[0]), "v"(e_rew[0]), "v"(e_done[1]), "v"(p[0][0]));  // the round ends here, not wherever its results are needed
 #endif
         VI_STAMP(9);
+        return true;
+    };
+    if (!split) {
+        for (; r < a.vi.max_rounds && !failed; ++r)
+            if (!round(std::integral_constant<int, 0>{})) break;
+    } else if (wave < state_waves) {
+        for (; r < a.vi.max_rounds && !failed; ++r)
+            if (!round(std::integral_constant<int, 1>{})) break;
+    } else {
+        for (; r < a.vi.max_rounds && !failed; ++r)
+            if (!round(std::integral_constant<int, 2>{})) break;
     }
     if (AGENTS && !failed && r > 0) {  // the agents' step of the last round: its actions alone cross the cluster
         const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;  // (published behind V2 of the last round)
@@ -585,7 +603,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         }
         __syncthreads();
         if (info[3] & 1u) failed = true;
-        else if (has_envs) agents();
+        else if (envs_here) agents();
     }
 #ifdef GU_VI_XCD_STAMPS
     // (which wave of which member is stamped: GU_VI_STAMP_WAVE / GU_VI_STAMP_RANK in the environment of the variant library)

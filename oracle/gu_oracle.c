@@ -129,12 +129,12 @@ void gu_oracle_reset(const gu_oracle_grid *g, uint64_t seed, int64_t env_id0, in
     }
 }
 
-/* the word behind the sampled action of step t (oracle/gu_rng.py: sample_word): one hashed word of stream 2 per four steps,
- * the three behind it by xorshift32 + a Weyl increment */
+/* the word behind the sampled action of step t (oracle/gu_rng.py: sample_word): one hashed word of stream 2 per sixteen steps,
+ * the fifteen behind it by xorshift32 + a Weyl increment */
 uint32_t gu_oracle_rng_sample_word(uint64_t seed, uint32_t env, uint32_t t)
 {
-    uint32_t w = gu_oracle_rng_word(seed, env, 2, t >> 2);
-    for (uint32_t i = 0; i < (t & 3u); ++i) {
+    uint32_t w = gu_oracle_rng_word(seed, env, 2, t >> 4);
+    for (uint32_t i = 0; i < (t & 15u); ++i) {
         w ^= w << 13;
         w ^= w >> 17;
         w ^= w << 5;

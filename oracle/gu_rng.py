@@ -15,13 +15,15 @@ is sharded, so the build defines one and this file is its specification:
 
     action(seed, env, t)      = (word(seed, env, 0, t >> 4) >> (2 * (t & 15))) & 3
     start_index(seed, env, e) = (word(seed, env, 1, e) * n_starts) >> 32
-    sample_word(seed, env, t) = next^(t & 3)(word(seed, env, 2, t >> 2)):  ONE hashed word per FOUR steps; the words of
-                                the three steps behind it by a multiply-free bijection of 32 bits,
+    sample_word(seed, env, t) = next^(t & 15)(word(seed, env, 2, t >> 4)):  ONE hashed word per SIXTEEN steps; the words of
+                                the fifteen steps behind it by a multiply-free bijection of 32 bits,
                                 next(x): x ^= x << 13; x ^= x >> 17; x ^= x << 5; x += 0x9E3779B9   (mod 2**32)
                                 (Marsaglia's xorshift32 step followed by a Weyl increment).  Every word is a bijective
-                                image of a MurmurHash3 output, so each draw by itself is exactly as uniform as the hash.
+                                image of a MurmurHash3 output, so each draw by itself is exactly as uniform as the hash;
+                                tests/test_oracle_mc.py checks the draws of a group against each other at every lag.
                                 (Until round 3 every step hashed a word of its own: the five 32-bit multiplies of the
-                                hash were what bound the sampled rollout on the GPU.)
+                                hash were what bound the sampled rollout on the GPU.  Round 4 went to one hash per four
+                                steps, then per sixteen.)
     sampled(seed, env, t, p)  = #{k < 3 : u >= p[0] + .. + p[k]},  u = sample_word(seed, env, t) / 2**32
                                 (float64 partial sums left to right; the batched form of
                                 np.random.choice(4, p=policy[obs]), core/algorithms/monte_carlo.py:20)
@@ -89,8 +91,12 @@ def start_index(seed, env, episode, n_starts):
     return (word(seed, env, STREAM_START, episode) * int(n_starts)) >> 32
 
 
+SAMPLE_GROUP_LOG2 = 4  # 16 steps share one hashed word (csrc/gu_rng.hpp: GU_RNG_SAMPLE_LOG2)
+SAMPLE_GROUP = 1 << SAMPLE_GROUP_LOG2
+
+
 def sample_next(x):
-    """The multiply-free bijection that turns one sampling word into the next one of its group of four."""
+    """The multiply-free bijection that turns one sampling word into the next one of its group of sixteen."""
     x ^= (x << 13) & M32
     x ^= x >> 17
     x ^= (x << 5) & M32
@@ -98,10 +104,10 @@ def sample_next(x):
 
 
 def sample_word(seed, env, t):
-    """The 32-bit word behind the sampled action of step t (stream 2): one hash per four steps."""
+    """The 32-bit word behind the sampled action of step t (stream 2): one hash per sixteen steps."""
     t = int(t) & M32
-    w = word(seed, env, STREAM_SAMPLE, t >> 2)
-    for _ in range(t & 3):
+    w = word(seed, env, STREAM_SAMPLE, t >> SAMPLE_GROUP_LOG2)
+    for _ in range(t & (SAMPLE_GROUP - 1)):
         w = sample_next(w)
     return w
 

@@ -451,7 +451,9 @@ def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, g
         assert v.tobytes() == z['vi_v_%d' % meta['iters']].tobytes() and pi.tobytes() == z['vi_pi_%d' % meta['iters']].tobytes()
 
 
-@pytest.mark.parametrize('name,N', [('maze64_s5', 65536), ('maze32_s1_g099', 3000), ('rect6x5_g1', 700), ('maze11_s3_g09', 64)])
+# (128x128 and 101x101: two states per thread and two to three exchange loads per thread in the per-XCD kernel, its other instances)
+@pytest.mark.parametrize('name,N', [('maze64_s5', 65536), ('maze128_s7', 20000), ('level101_g099', 5000), ('maze32_s1_g099', 3000), ('rect6x5_g1', 700),
+                                    ('maze11_s3_g09', 64)])
 @pytest.mark.parametrize('values', ['ties', 'huge', 'nonfinite'])
 def test_sweep_step_run_forms_agree_on_random_tables(name, N, values, vi_path, gu_option):
     """Every form of gu_vi_sweep_step_run from RANDOM tables: exact ties of np.around(q, 8), values beyond 3.3e7 (where the tie

@@ -93,17 +93,18 @@ def test_reference_rng_episode_generator_on_an_oracle_table_reproduces_the_refer
         random.setstate(py_state)
 
 
-def test_sampling_words_one_hash_per_four_steps_c_oracle_equals_the_specification():
-    """RNG stream 2 (round 4): the word of step t is the hashed word of group t >> 2 advanced t & 3 times by the multiply-free
+def test_sampling_words_one_hash_per_sixteen_steps_c_oracle_equals_the_specification():
+    """RNG stream 2 (round 4): the word of step t is the hashed word of group t >> 4 advanced t & 15 times by the multiply-free
     bijection -- oracle/gu_oracle.c against oracle/gu_rng.py, across group boundaries and the 2^28 counter boundary; the
     bijection is one (no two of 2^16 consecutive inputs collide, and it has no short cycle through 0)."""
     lib = C.lib()
     for seed, env in ((0, 0), (7, 12345), (0xDEADBEEFCAFE, 0xFFFFFFFF)):
-        for t in list(range(0, 41)) + [2 ** 30 - 2, 2 ** 30 - 1, 2 ** 30, 2 ** 30 + 5, 2 ** 32 - 1]:
+        for t in list(range(0, 70)) + [2 ** 32 - 18, 2 ** 32 - 17, 2 ** 32 - 16, 2 ** 32 - 11, 2 ** 32 - 1]:
             assert lib.gu_oracle_rng_sample_word(seed, env, t) == gu_rng.sample_word(seed, env, t), (seed, env, t)
-        for t in range(0, 40, 4):  # the first word of a group IS the hash of stream 2 at counter t >> 2
-            assert gu_rng.sample_word(seed, env, t) == gu_rng.word(seed, env, gu_rng.STREAM_SAMPLE, t >> 2)
-            assert gu_rng.sample_word(seed, env, t + 1) == gu_rng.sample_next(gu_rng.sample_word(seed, env, t))
+        for t in range(0, 64, 16):  # the first word of a group IS the hash of stream 2 at counter t >> 4
+            assert gu_rng.sample_word(seed, env, t) == gu_rng.word(seed, env, gu_rng.STREAM_SAMPLE, t >> 4)
+            for k in range(15):
+                assert gu_rng.sample_word(seed, env, t + k + 1) == gu_rng.sample_next(gu_rng.sample_word(seed, env, t + k))
     images = {gu_rng.sample_next(x) for x in range(1 << 16)}
     assert len(images) == 1 << 16
     x, seen = 0, set()
@@ -115,18 +116,22 @@ def test_sampling_words_one_hash_per_four_steps_c_oracle_equals_the_specificatio
 
 def test_sampled_actions_follow_the_policy_chi_square_over_two_million_draws():
     """The draw's distribution: chi-square of the action counts against pi over 2^21 draws (one env stream and many envs, so that
-    both the words within a group of four and the groups are covered), for a flat, a skewed and a nearly one-hot row."""
+    both the words within a group of sixteen and the groups are covered), for a flat, a skewed and a nearly one-hot row; every
+    position of the group on its own; and the draws of one group against each other at EVERY lag 1 .. 15 (the 4 x 4 table of
+    the action pair, and the correlation of the words themselves)."""
+    G = gu_rng.SAMPLE_GROUP
     n_env, T = 512, 4096
     words = np.empty((n_env, T), np.uint32)
-    hashed = gu_rng.word_v(5, np.arange(n_env)[:, None], gu_rng.STREAM_SAMPLE, np.arange(T // 4)[None, :]).astype(np.uint64)
+    hashed = gu_rng.word_v(5, np.arange(n_env)[:, None], gu_rng.STREAM_SAMPLE, np.arange(T // G)[None, :]).astype(np.uint64)
     cur = hashed
-    for j in range(4):
-        words[:, j::4] = cur.astype(np.uint32)
+    for j in range(G):
+        words[:, j::G] = cur.astype(np.uint32)
         cur = cur ^ ((cur << np.uint64(13)) & np.uint64(0xFFFFFFFF))
         cur = cur ^ (cur >> np.uint64(17))
         cur = cur ^ ((cur << np.uint64(5)) & np.uint64(0xFFFFFFFF))
         cur = (cur + np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
     assert words[3, 9] == gu_rng.sample_word(5, 3, 9) and words[511, 4095] == gu_rng.sample_word(5, 511, 4095)
+    assert words[17, 1000] == gu_rng.sample_word(5, 17, 1000)
     u = words.astype(np.float64) / 4294967296.0
     n = u.size
     for p in ([0.25, 0.25, 0.25, 0.25], [0.6, 0.05, 0.3, 0.05], [0.001, 0.997, 0.001, 0.001]):
@@ -135,17 +140,27 @@ def test_sampled_actions_follow_the_policy_chi_square_over_two_million_draws():
         counts = np.bincount(acts.ravel(), minlength=4)
         chi2 = float(np.sum((counts - n * np.asarray(p)) ** 2 / (n * np.asarray(p))))
         assert chi2 < 21.1, (p, counts, chi2)  # 3 degrees of freedom: P(chi2 > 21.1) = 1e-4
-        for j in range(4):  # ... and the same for each position inside the group of four on its own
-            cj = np.bincount(acts[:, j::4].ravel(), minlength=4)
-            chi2 = float(np.sum((cj - n / 4 * np.asarray(p)) ** 2 / (n / 4 * np.asarray(p))))
-            assert chi2 < 24.0, (p, j, cj, chi2)
-    # consecutive draws of one group are not tied to each other: the 4 x 4 table of (action at t, action at t + 1) inside a group
-    p = np.asarray([0.25, 0.25, 0.25, 0.25])
-    acts = (u >= 0.25).astype(np.int64) + (u >= 0.5) + (u >= 0.75)
-    for j in range(3):
-        pair = np.bincount((acts[:, j::4] * 4 + acts[:, j + 1::4]).ravel(), minlength=16)
-        chi2 = float(np.sum((pair - n / 4 / 16) ** 2 / (n / 4 / 16)))
-        assert chi2 < 44.3, (j, chi2)  # 15 degrees of freedom: P(chi2 > 44.3) = 1e-4
+        for j in range(G):  # ... and the same for each position inside the group on its own
+            cj = np.bincount(acts[:, j::G].ravel(), minlength=4)
+            chi2 = float(np.sum((cj - n / G * np.asarray(p)) ** 2 / (n / G * np.asarray(p))))
+            assert chi2 < 27.9, (p, j, cj, chi2)  # P(chi2_3 > 27.9) = 4e-6: 48 such tests
+    # the draws of one group are not tied to each other, at any distance inside the group: the 4 x 4 table of (action at position
+    # j, action at position j + lag) over all groups, for a flat and a skewed row, and the correlation of the uniforms
+    grouped = u.reshape(n_env, T // G, G)
+    for p in ([0.25, 0.25, 0.25, 0.25], [0.6, 0.05, 0.3, 0.05]):
+        c = np.cumsum(p)[:3]
+        acts = (grouped >= c[0]).astype(np.int64) + (grouped >= c[1]) + (grouped >= c[2])
+        expect = np.outer(p, p).ravel()
+        for lag in range(1, G):
+            a0, a1 = acts[:, :, :G - lag].ravel(), acts[:, :, lag:].ravel()
+            pair = np.bincount(a0 * 4 + a1, minlength=16)
+            m = a0.size
+            chi2 = float(np.sum((pair - m * expect) ** 2 / (m * expect)))
+            assert chi2 < 50.0, (p, lag, chi2)  # 15 degrees of freedom: P(chi2 > 50) = 1e-5; 30 such tests
+    for lag in range(1, G):
+        x, y = grouped[:, :, :G - lag].ravel(), grouped[:, :, lag:].ravel()
+        r = float(np.corrcoef(x, y)[0, 1])
+        assert abs(r) < 5.0 / np.sqrt(x.size), (lag, r)  # five standard errors
 
 
 def test_sampled_action_at_the_edges_of_the_policy_simplex():

@@ -521,6 +521,7 @@ def other_modes(eng, template, seed, env_id0, N, T, K, check):
     it): per-env statistics only (return, episodes finished: no HBM stream at all, bound by the LDS round trip of the
     K-step transition table), and one packed uint32 per env-step (4 B)."""
     def launch_ms(**kw):
+        getattr(eng, 'calibrate_rollout', eng.rollout)(T, 'uniform', auto_reset=True, **kw)
         for _ in range(3):
             eng.rollout(T, 'uniform', auto_reset=True, **kw)
         eng.sync()
@@ -545,6 +546,7 @@ def other_modes(eng, template, seed, env_id0, N, T, K, check):
         eng.vi_set(np.zeros(S), np.random.RandomState(1).dirichlet(np.ones(4), S))
 
         def sample_ms(**kw):
+            getattr(eng, 'calibrate_rollout', eng.rollout)(T, 'sample', auto_reset=True, **kw)  # (the pacing search up front, as for the headline)
             for _ in range(3):
                 eng.rollout(T, 'sample', auto_reset=True, **kw)
             eng.sync()

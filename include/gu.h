@@ -60,7 +60,10 @@ extern "C" {
 #define GU_POLICY_STREAM 1  /* a = actions[t][env] uploaded with gu_upload_actions           */
 #define GU_POLICY_GREEDY 2  /* a = first argmax of pi[pos] (np.argmax; examples/griduniverse_alg_examples.py:76) */
 #define GU_POLICY_SAMPLE 3  /* a ~ pi[pos]: inverse CDF on one 32-bit word of RNG stream 2 per step, the batched form of
-                               np.random.choice(4, p=policy[obs]) in core/algorithms/monte_carlo.py:20 */
+                               np.random.choice(4, p=policy[obs]) in core/algorithms/monte_carlo.py:20.  The stream is the
+                               build's own (oracle/gu_rng.py is its specification): one MurmurHash3 word per sixteen steps
+                               of an env, the fifteen behind it by xorshift32 + a Weyl increment -- sampled sequences
+                               differ from those of libraries built before ABI round 4, their distribution does not */
 
 typedef struct gu_engine *gu_handle;
 

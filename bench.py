@@ -323,6 +323,7 @@ def baseline_configs(engine_cls, device, K, check):
         pass
 
     def rows(eng, policy='uniform'):
+        getattr(eng, 'calibrate_rollout', eng.rollout)(T, policy, auto_reset=True, trajectory=True)  # (the pacing search up front where the kind is paced)
         for _ in range(3):
             eng.rollout(T, policy, auto_reset=True, trajectory=True)
         eng.sync()

@@ -652,16 +652,21 @@ static ViArgs vi_args(gu_engine *h, double gamma, unsigned long long *delta_key)
 
 // The single-workgroup path: grids of up to VI_PB_MAX_STATES states (GU_OPT_VI_PATH = 2 forces the per-round
 // launches, for the tests).  Runs up to max_rounds rounds in place on the current tables.
-// Grids of GU_VI_XCD_MIN_STATES states and more take the per-XCD launch first (gu_vi_xcd.hip): ~1.1 us per round whatever the size,
-// against 1.4 (8x8) .. 5 us (64x64) in one workgroup and ~4 us behind the chip-wide barrier; below, one workgroup is as quick and
-// starts without the chip-wide registration wait.
+// The per-XCD launch (gu_vi_xcd.hip) runs a round in ~1.06 us WHATEVER the grid's size (1.02 at 8x8, 1.06 at 64x64), against 1.35
+// (8x8) .. 1.9 (32x32) .. 5 us (64x64) in one workgroup and ~4 us behind the chip-wide barrier -- but a call of it costs ~70 us
+// more than one of the single-workgroup kernel (the chip-wide registration wait, the snapshot its give-up path restores, the
+// zeroed exchange buffers).  It is taken first from GU_VI_XCD_MIN_STATES states on, and below that when the call may run
+// GU_VI_XCD_MIN_ROUNDS rounds or more (profiles/r04z_dp_small_grids.txt: it breaks even after 80 rounds at 32x32, 200 at 8x8).
 #ifndef GU_VI_XCD_MIN_STATES
 #define GU_VI_XCD_MIN_STATES 1536
 #endif
-static bool vi_xcd_preferred(const gu_engine *h)
+#ifndef GU_VI_XCD_MIN_ROUNDS
+#define GU_VI_XCD_MIN_ROUNDS 192
+#endif
+static bool vi_xcd_preferred(const gu_engine *h, int32_t rounds)
 {
     const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
-    return (path == 0 || path == 5) && h->S >= GU_VI_XCD_MIN_STATES;
+    return (path == 0 || path == 5) && (h->S >= GU_VI_XCD_MIN_STATES || rounds >= GU_VI_XCD_MIN_ROUNDS);
 }
 
 static bool vi_block_eligible(const gu_engine *h)
@@ -836,7 +841,7 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(iters > 0 && iters <= 4096, GU_ERR_INVALID, "iters must be in 1..4096 per call");
-    if (vi_xcd_preferred(h)) {  // one launch of one XCD's workgroups, nothing leaves that XCD's L2 (gu_vi_xcd.hip)
+    if (vi_xcd_preferred(h, iters)) {  // one launch of one XCD's workgroups, nothing leaves that XCD's L2 (gu_vi_xcd.hip)
         int32_t done = 0;
         rc = gu_vi_xcd_dp_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
         if (rc != GU_VI_FALLBACK) return rc;
@@ -886,7 +891,7 @@ int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, in
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
-    if (vi_xcd_preferred(h)) {
+    if (vi_xcd_preferred(h, max_steps)) {
         rc = gu_vi_xcd_dp_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
         if (rc != GU_VI_FALLBACK) return rc;
     }
@@ -952,7 +957,7 @@ int gu_vi_eval_run(gu_handle h, double gamma, double threshold, int32_t max_step
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
-    if (vi_xcd_preferred(h)) {
+    if (vi_xcd_preferred(h, max_steps)) {
         rc = gu_vi_xcd_dp_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
         if (rc != GU_VI_FALLBACK) return rc;
     }

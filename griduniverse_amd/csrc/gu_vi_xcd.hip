@@ -431,14 +431,16 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         asm volatile("" ::"v"(k));
 #endif
     };
-    const bool late = AGENTS && split;                   // this workgroup has waves that own no states
+    const bool late = split;                             // this workgroup has waves that own no states
     const int32_t collect_wave = late ? waves - 1 : 0;  // (the key wave is the first of them)
     uint32_t act_prev[K];  // greedy action of the thread's states under the policy of the round before
     double v_new[K];       // the states' current values
+    double v_prev[K];      // ... and those of the round before (the tables alone: a round is taken back when the stopping rule says so)
     double gv[K][4];       // gamma * value of the four successors
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         act_prev[j] = 0u;
+        v_prev[j] = 0.0;
         v_new[j] = st[j] >= 0 ? vL[st[j]] : 0.0;
 #pragma unroll
         for (uint32_t act = 0; act < 4; ++act) gv[j][act] = st[j] >= 0 ? __dmul_rn(gamma, vL[vi_next(st[j], rec[j], act, W)]) : 0.0;
@@ -465,6 +467,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
 #pragma unroll
                     for (uint32_t act = 0; act < 4; ++act) acc = __dadd_rn(acc, __dmul_rn(p[j][act], gv[j][act]));
                     const double v_old = v_new[j];
+                    v_prev[j] = v_old;
                     v_new[j] = acc;
                     const vi_u64 bits = (vi_u64)__double_as_longlong(acc);
                     vi_u32x4 g;
@@ -488,24 +491,23 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         // (two rounds late, and where there is one by a wave that owns no states, behind barrier 2: off everybody's critical path)
         const bool collects = ROLE != 1 && !sync_delta && keeps_deltas && wave == collect_wave && r > 1;
         if (collects) delta_load(r - 2);
-        // The workgroup's key.  The tables alone want it this round, everybody: reduced and posted while the exchange is in flight.
-        // With agents it is collected two rounds late by workgroup 0: a wave without states reduces and posts it behind barrier 2,
-        // where it has time to spare; a wave that owns states too reduces it under the exchange's round trip and posts it BEHIND
-        // the exchange (a store ahead of it would turn the wait for the loads into a wait for the store's acknowledgement as well).
+        // The workgroup's key: a wave without states reduces and posts it behind barrier 2, where it has time to spare; a wave that
+        // owns states too reduces it under the exchange's round trip and posts it BEHIND the exchange (a store ahead of it would
+        // turn the wait for the loads into a wait for the store's acknowledgement as well).  With agents workgroup 0 collects the
+        // keys two rounds late.  The tables alone: EVERY workgroup takes in every member's key ONE round late -- asked for ahead
+        // of this round's exchange, looked at behind it -- and the round that turns out to be one too many is taken back (below).
         const bool posts = ROLE != 1 && wave == key_wave, posts_late = late;
+        const bool takes_in = sync_delta && posts && r > 0;
+        if (takes_in) delta_load(r - 1);
         vi_u64 mine = 0ull;
         fetch(par, tag, true, AGENTS && r > 0, [&]() {
             if (!posts || posts_late) return;
             mine = reduce_keys(r);
-            if (sync_delta) {
-                post(r, mine);
-                delta_load(r);
-            }
         });
-        if (posts && !sync_delta && !posts_late) post(r, mine);
+        if (posts && !posts_late) post(r, mine);
         VI_STAMP(6);
-        if (posts && sync_delta) {  // the round's delta, for everybody
-            const vi_u64 k = delta_finish(r);
+        if (takes_in) {  // the delta of the round before, for everybody
+            const vi_u64 k = delta_finish(r - 1);
             if (lane == 0) round_key_lds = k;
         }
         if (collects && !late) collect(r - 2);
@@ -516,10 +518,17 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             failed = true;
             return false;
         }
-        vi_u64 round_key = 0ull;
-        if (sync_delta) {
-            round_key = round_key_lds;
-            if (keeps_deltas && tid == 0) a.vi.delta_key[r] = round_key;
+        if (sync_delta && r > 0) {
+            // The stopping rule (dynamic_programming.py:22-23 / :42) on the delta of round r - 1, which took this round to cross the
+            // cluster: if it says stop, round r was one too many.  Its V1 is taken back (the values of the round before are kept
+            // beside the new ones; V2 of round r has not run, so the policy is still that of round r - 1) and r rounds count.
+            const vi_u64 round_key = round_key_lds;
+            if (keeps_deltas && tid == 0) a.vi.delta_key[r - 1] = round_key;
+            if (a.vi.use_threshold && vi_unkey_dev(round_key) < a.vi.threshold) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) v_new[j] = v_prev[j];
+                return false;
+            }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {  // V2 (utils.py:55-72) on v'
@@ -565,10 +574,6 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         // actions, and a word that has a V1 of head start is there when it is asked for
         if (AGENTS && wave_has_states) publish_actions(par ^ 1u, tag + 1u, act_prev);
         VI_STAMP(8);
-        if (sync_delta && a.vi.use_threshold && vi_unkey_dev(round_key) < a.vi.threshold) {  // dynamic_programming.py:22-23 / :42
-            ++r;
-            return false;
-        }
         // (ahead of the agents' step, whose LDS round trips then cover the stores' acknowledgements -- the next barrier waits for them;
         // the lanes' keys of this round stay in LDS until V1 of the round after next)
         if (collects && late) collect(r - 2);
@@ -589,6 +594,13 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     } else {
         for (; r < a.vi.max_rounds && !failed; ++r)
             if (!round(std::integral_constant<int, 2>{})) break;
+    }
+    if (!AGENTS && !failed && r > 0 && r == a.vi.max_rounds && keeps_deltas) {  // the tables alone, not stopped: the last round's delta is still out
+        __syncthreads();
+        if (wave == key_wave) {
+            delta_load(r - 1);
+            collect(r - 1);
+        }
     }
     if (AGENTS && !failed && r > 0) {  // the agents' step of the last round: its actions alone cross the cluster
         const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;  // (published behind V2 of the last round)
@@ -619,7 +631,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         for (int j = 0; j < K; ++j) {
             const int32_t s = st[j];
             if (s >= 0) {
-                vf[s] = vL[s];
+                vf[s] = v_new[j];
                 if (GREEDY) *reinterpret_cast<double4 *>(a.vi.pi + 4 * (int64_t)s) = make_double4(p[j][0], p[j][1], p[j][2], p[j][3]);
             }
         }
@@ -656,8 +668,10 @@ bool gu_vi_xcd_plan(const gu_engine *h, bool agents, GuXcdPlan *plan)
             if (forced) return false;
             continue;
         }
-        // enough workgroups for one state per thread in every cluster, as far as the device has CUs for them
-        int64_t G = VI_XCD_MAX_XCC * (((int64_t)h->S + B - 1) / B);
+        // enough workgroups for one state per thread in every cluster, as far as the device has CUs for them; the tables alone:
+        // for one state per TWO threads, so that half of a workgroup's waves own no states and take the delta keys off the others
+        const int64_t per_wg = agents ? B : B / 2;
+        int64_t G = VI_XCD_MAX_XCC * (((int64_t)h->S + per_wg - 1) / per_wg);
         if (G > max_wgs) G = max_wgs;
         if (G < env_wgs) G = env_wgs;
         const int64_t per_xcc = G / VI_XCD_MAX_XCC > 0 ? G / VI_XCD_MAX_XCC : 1;  // the smallest cluster under round-robin placement

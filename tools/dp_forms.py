@@ -28,7 +28,7 @@ def maze(w, h, k):
 def main():
     out = {}
     rounds = 2000
-    for w in (8, 32, 40, 64, 101, 128):
+    for w in [int(x) for x in sys.argv[1:]] or (8, 32, 40, 64, 101, 128):
         env = maze(w, w, 5)
         S = env.world.size
         row = {}

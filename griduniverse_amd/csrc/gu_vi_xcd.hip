@@ -38,7 +38,10 @@
 //                  (two passes of 32-bit DPP maxima) and posts the workgroup's key in a tagged slot (four deep), and workgroup 0 of
 //                  the cluster that writes the tables collects the slots TWO rounds late.  Where a workgroup has waves that own no
 //                  states (config 5: two of four), those do both, behind barrier 2, ahead of their agents' step -- nothing of it
-//                  is on the path store -> exchange -> V2 -> V1 -> store that bounds the round.
+//                  is on the path store -> exchange -> V2 -> V1 -> store that bounds the round.  The tables alone (no agents): the
+//                  stopping rule wants every round's delta in every workgroup.  Each takes in every member's key ONE round late
+//                  (asked for ahead of the round's exchange, looked at behind it) and applies the rule before V2; a round that was
+//                  one too many is taken back -- its V1 kept the values of the round before in registers, its V2 has not run.
 //   waves        = a round of a wave that owns states: V1 from registers, granule stored, key to LDS | barrier 1 | own value to LDS,
 //                  exchange | barrier 2 | V2, actions published.  Of a wave that owns none: | barrier 1 | exchange | barrier 2 |
 //                  (deltas collected) (key reduced, posted) agents' step.  tools/c5_stamps.py times the phases per wave.
@@ -261,8 +264,8 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     const uint64_t stamp_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const bool keeps_deltas = writes_tables && rank == 0;
-    // The tables alone: every workgroup takes in every member's delta key every round -- the stopping rule needs it before the next
-    // round, and it is what keeps the members within a round of each other (their values only tie neighbours together: without it a
+    // The tables alone: every workgroup takes in every member's delta key of the round BEFORE every round -- the stopping rule needs
+    // it, and it is what keeps the members within a round of each other (their values only tie neighbours together: without it a
     // far member could run a dozen rounds ahead and overwrite its four-deep key slots before they are collected).  With agents the
     // action words tie every workgroup to every other one anyway, and workgroup 0 collects the keys two rounds late.
     const bool sync_delta = !AGENTS;

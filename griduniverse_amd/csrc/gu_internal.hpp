@@ -249,6 +249,19 @@ int gu_probe_trajectory_buffer(gu_engine *h, int32_t *buf, int64_t T, float *ms)
 // DP cluster launches take of the engine's state, and put back, stay on the kernel path (ordered with the launches around them,
 // no copy-engine round trip for a few hundred KB).
 int gu_device_copy(gu_engine *h, void *dst, const void *src, size_t bytes);
+#define GU_MAX_SEGMENTS 8
+struct GuSegments {  // gu_device_segments: copies (src != nullptr) and fills with zero (src == nullptr) of whole 32-bit words, one launch
+    void *dst[GU_MAX_SEGMENTS];
+    const void *src[GU_MAX_SEGMENTS];
+    size_t words[GU_MAX_SEGMENTS];
+    int n = 0;
+    void add(void *d, const void *s, size_t bytes)
+    {
+        dst[n] = d, src[n] = s, words[n] = bytes / 4;
+        ++n;
+    }
+};
+int gu_device_segments(gu_engine *h, const GuSegments &s);
 
 // ---- tabular DP launchers (gu_vi.hip) --------------------------------------------
 int gu_vi_alloc(gu_engine *h);

@@ -356,6 +356,36 @@ int gu_device_copy(gu_engine *h, void *dst, const void *src, size_t bytes)
     return GU_OK;
 }
 
+// Up to GU_MAX_SEGMENTS device-to-device copies and fills with zero in ONE launch (a launch costs ~6 us of stream time; the
+// snapshot and the zeroed exchange buffers of the one-launch DP forms were seven of them per call).  src == nullptr: zero.
+__global__ void __launch_bounds__(256) gu_segments_kernel(const GuSegments s)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < s.n; ++k) {
+        uint32_t *dst = (uint32_t *)s.dst[k];
+        const uint32_t *src = (const uint32_t *)s.src[k];
+        if (src) {
+            for (size_t i = first; i < s.words[k]; i += step) dst[i] = src[i];
+        } else {
+            for (size_t i = first; i < s.words[k]; i += step) dst[i] = 0u;
+        }
+    }
+}
+
+int gu_device_segments(gu_engine *h, const GuSegments &s)
+{
+    size_t most = 0;
+    for (int k = 0; k < s.n; ++k) {
+        GU_REQUIRE(((uintptr_t)s.dst[k] | (uintptr_t)s.src[k]) % 4 == 0, GU_ERR_INVALID, "gu_device_segments: segment %d unaligned", k);
+        most = std::max(most, s.words[k]);
+    }
+    if (!most) return GU_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>((most + 255) / 256, (size_t)h->n_cu * 8);
+    hipLaunchKernelGGL(gu_segments_kernel, dim3(blocks), dim3(256), 0, h->stream, s);
+    GU_HIP(hipGetLastError());
+    return GU_OK;
+}
+
 static void gu_rollout_general(gu_engine *h, const RolloutArgs &a, int32_t policy, int auto_mode, int traj, bool stats, int bs)
 {
     switch (policy) {

@@ -27,7 +27,7 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_ROLLOUT_MULTI_K", 0, 0, 4},
     {"GU_ROLLOUT_MULTI_COPIES", 1, 1, 2},
     {"GU_ROLLOUT_XCD", 0, 0, 1},
-    {"GU_VI_PATH", 0, 0, 5},
+    {"GU_VI_PATH", 0, 0, 6},
     {"GU_MC_SCRATCH_MB", 2048, 1, 1 << 20},
     {"GU_MC_LANE_RETURNS", 0, 0, 1},
     {"GU_MC_GLOBAL_WALK", 0, 0, 1},

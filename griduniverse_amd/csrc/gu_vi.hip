@@ -653,20 +653,16 @@ static ViArgs vi_args(gu_engine *h, double gamma, unsigned long long *delta_key)
 // The single-workgroup path: grids of up to VI_PB_MAX_STATES states (GU_OPT_VI_PATH = 2 forces the per-round
 // launches, for the tests).  Runs up to max_rounds rounds in place on the current tables.
 // The per-XCD launch (gu_vi_xcd.hip) runs a round in ~1.06 us WHATEVER the grid's size (1.02 at 8x8, 1.06 at 64x64), against 1.35
-// (8x8) .. 1.9 (32x32) .. 5 us (64x64) in one workgroup and ~4 us behind the chip-wide barrier -- but a call of it costs ~70 us
-// more than one of the single-workgroup kernel (the chip-wide registration wait, the snapshot its give-up path restores, the
-// zeroed exchange buffers).  It is taken first from GU_VI_XCD_MIN_STATES states on, and below that when the call may run
-// GU_VI_XCD_MIN_ROUNDS rounds or more (profiles/r04z_dp_small_grids.txt: it breaks even after 80 rounds at 32x32, 200 at 8x8).
-#ifndef GU_VI_XCD_MIN_STATES
-#define GU_VI_XCD_MIN_STATES 1536
-#endif
-#ifndef GU_VI_XCD_MIN_ROUNDS
-#define GU_VI_XCD_MIN_ROUNDS 192
-#endif
+// (8x8) .. 1.9 (32x32) .. 5 us (64x64) in one workgroup and ~4 us behind the chip-wide barrier, and since its snapshot and its
+// zeroed buffers are ONE launch and its results one copy back, a call of it is no dearer either: 39 us for one round, 145 for a
+// hundred at 32x32, against 46 and 240 of the single-workgroup kernel (profiles/r04z_dp_calls.txt).  It is taken first on every
+// grid it fits; the other paths are what it falls back to (a grid that does not fit a workgroup's LDS, workgroups that cannot all
+// be resident, GU_OPT_VI_PATH).
 static bool vi_xcd_preferred(const gu_engine *h, int32_t rounds)
 {
+    (void)rounds;
     const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
-    return (path == 0 || path == 5) && (h->S >= GU_VI_XCD_MIN_STATES || rounds >= GU_VI_XCD_MIN_ROUNDS);
+    return path == 0 || path == 5 || path == 6;
 }
 
 static bool vi_block_eligible(const gu_engine *h)
@@ -737,7 +733,7 @@ static bool vi_cluster_shape(const gu_engine *h, int *K_out, unsigned *G_out)
 static bool vi_cluster_eligible(const gu_engine *h)
 {
     const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
-    return (path == 0 || path == 3) && vi_cluster_shape(h, nullptr, nullptr);
+    return (path == 0 || path == 3 || path == 6) && vi_cluster_shape(h, nullptr, nullptr);
 }
 
 static int vi_cluster_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds,
@@ -1094,9 +1090,12 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
     // one launch per round.  The one-launch forms work on a snapshot's ORIGINAL: a form that gives up (every spin in them is bounded)
     // leaves half-advanced state, which is put back before the next form runs.
     GuXcdPlan xp{};
-    const bool try_xcd = (path == 0 || path == 5) && gu_vi_xcd_plan(h, true, &xp);
+    // (a call of ONE round: the one-launch forms cost ~10 us more to start -- the registration wait, the snapshot, the zeroed
+    // exchange buffers -- than they save; profiles/r04z_c5_forms.json, xcd_default_us_per_call_by_rounds.  GU_OPT_VI_PATH = 6: always)
+    const bool short_call = path == 0 && iters <= 1;
+    const bool try_xcd = !short_call && (path == 0 || path == 5 || path == 6) && gu_vi_xcd_plan(h, true, &xp);
     const bool try_cluster = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && G <= (h->n_cu < VI_CL_MAX_WGS ? h->n_cu : VI_CL_MAX_WGS) &&
-                             (path == 0 || path == 3 || path == 4 || path == 5);
+                             !short_call && (path == 0 || path == 3 || path == 4 || path == 5 || path == 6);
     if (try_xcd || try_cluster) {
         // scratch: header (64 B) | delta keys [iters] | delta-key slots of the per-XCD form | snapshot | the per-XCD granule buffers
         const size_t key_bytes = (size_t)iters * sizeof(unsigned long long);
@@ -1115,11 +1114,19 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
         void *live[5] = {h->d_v[h->vi_cur], h->d_pi[h->vi_cur], h->d_out3, h->d_episode, h->d_done_bits};
         const size_t size[5] = {v_bytes, 4 * v_bytes, 3 * n4, n4, bits_bytes};
         size_t off = 0;
-        for (int k = 0; k < 5; off += size[k], ++k)
-            if ((rc = gu_device_copy(h, snap + off, live[k], size[k])) != GU_OK) return rc;
+        bool snapped = false;
         for (int form = 0; form < 2; ++form) {  // 0: per XCD, 1: chip-wide
             if (form == 0 ? !try_xcd : !try_cluster) continue;
-            GU_HIP(hipMemsetAsync(h->d_scratch, 0, form == 0 ? snap_off : slots_off, h->stream));  // every polled word is zeroed before every launch
+            // ONE launch: the snapshot (first form tried only), every polled word zeroed (before every launch), and for the per-XCD
+            // form its exchange buffers zeroed -- every word that crosses workgroups there is tagged with its round, no tag of an
+            // earlier launch may be left
+            GuSegments seg;
+            off = 0;
+            for (int k = 0; k < 5 && !snapped; off += size[k], ++k) seg.add(snap + off, live[k], size[k]);
+            snapped = true;
+            seg.add(h->d_scratch, nullptr, form == 0 ? snap_off : slots_off);
+            if (form == 0) seg.add(snap + snap_bytes, nullptr, 8 * xp.work_bytes);
+            if ((rc = gu_device_segments(h, seg)) != GU_OK) return rc;
             ViStepXcdArgs a{};
             a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, 0.0, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1],
                                  h->d_pi[h->vi_cur], keys_d, hdr_d, done_d, iters, 0};
@@ -1138,7 +1145,6 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
                 a.slots = (vi_u64 *)((char *)h->d_scratch + slots_off);
                 a.gx = (uint8_t *)(snap + snap_bytes);
                 a.work_bytes = (uint32_t)xp.work_bytes;
-                GU_HIP(hipMemsetAsync(a.gx, 0, 8 * xp.work_bytes, h->stream));  // every word that crosses workgroups is tagged with its round: no tag of an earlier launch may be left
                 a.inject_failure = path == 5;  // tests: the per-XCD form gives up
                 if ((rc = gu_vi_xcd_launch(h, xp, a, true, true)) != GU_OK) return rc;
             } else {
@@ -1149,16 +1155,15 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
             }
             // rounds_done is written by ONE workgroup, and giving up need not be unanimous: the fallback word, raised by whoever
             // gives up, decides (see vi_cluster_run)
-            int32_t ctl[12] = {0};  // [arrival counter, fallback word, rounds_done, 1 + XCC of workgroup 0, workgroups registered per XCC x 8]
-            GU_HIP(hipMemcpyAsync(ctl, h->d_scratch, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
+            // (header and delta keys lie side by side: ONE copy back, one wait)
+            std::vector<unsigned long long> back(8 + (deltas ? (size_t)iters : 0));
+            GU_HIP(hipMemcpyAsync(back.data(), h->d_scratch, back.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
             GU_HIP(hipStreamSynchronize(h->stream));
+            int32_t ctl[12];  // [arrival counter, fallback word, rounds_done, 1 + XCC of workgroup 0, workgroups registered per XCC x 8]
+            memcpy(ctl, back.data(), sizeof ctl);
             if (form == 0) memcpy(h->vi_xcd_members, ctl + 4, sizeof h->vi_xcd_members);  // (what the hardware reported: HW_REG_XCC_ID per workgroup)
             if (!ctl[1] && ctl[2] == iters) {
-                if (deltas) {
-                    std::vector<unsigned long long> keys((size_t)iters);
-                    GU_HIP(hipMemcpy(keys.data(), keys_d, key_bytes, hipMemcpyDeviceToHost));
-                    for (int32_t i = 0; i < iters; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
-                }
+                for (int32_t i = 0; deltas && i < iters; ++i) deltas[i] = vi_unkey(back[8 + (size_t)i]);
                 if (iters & 1) {
                     double *t = h->d_v[0];
                     h->d_v[0] = h->d_v[1];

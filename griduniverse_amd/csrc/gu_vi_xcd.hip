@@ -737,7 +737,7 @@ int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_thre
     if (max_rounds <= 0) return GU_OK;
     const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
     GuXcdPlan xp{};
-    if (!(path == 0 || path == 5) || !gu_vi_xcd_plan(h, false, &xp)) return GU_VI_FALLBACK;
+    if (!(path == 0 || path == 5 || path == 6) || !gu_vi_xcd_plan(h, false, &xp)) return GU_VI_FALLBACK;
     // scratch: header (64 B) | delta keys [max_rounds] | delta-key slots | snapshot of v and pi | granule buffers
     const size_t key_bytes = (size_t)max_rounds * sizeof(unsigned long long);
     const size_t slots_off = (64 + key_bytes + 255) & ~(size_t)255, snap_off = slots_off + xp.slots_bytes;
@@ -745,9 +745,14 @@ int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_thre
     int rc = gu_ensure_scratch(h, snap_off + snap_bytes + 8 * xp.work_bytes);
     if (rc != GU_OK) return rc;
     char *base = (char *)h->d_scratch, *snap = base + snap_off;
-    if ((rc = gu_device_copy(h, snap, h->d_v[h->vi_cur], v_bytes)) != GU_OK) return rc;
-    if ((rc = gu_device_copy(h, snap + v_bytes, h->d_pi[h->vi_cur], 4 * v_bytes)) != GU_OK) return rc;
-    GU_HIP(hipMemsetAsync(base, 0, snap_off, h->stream));  // header, keys, slots: every polled word is zeroed before every launch
+    // ONE launch: the snapshot; header, keys, slots zeroed (every polled word, before every launch); the granule buffers zeroed (no
+    // tag of an earlier launch may be left in them)
+    GuSegments seg;
+    seg.add(snap, h->d_v[h->vi_cur], v_bytes);
+    seg.add(snap + v_bytes, h->d_pi[h->vi_cur], 4 * v_bytes);
+    seg.add(base, nullptr, snap_off);
+    seg.add(snap + snap_bytes, nullptr, 8 * xp.work_bytes);
+    if ((rc = gu_device_segments(h, seg)) != GU_OK) return rc;
     ViStepXcdArgs a{};
     a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, threshold, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1], h->d_pi[h->vi_cur],
                          (vi_u64 *)(base + 64), (uint32_t *)base, (int32_t *)base + 2, max_rounds, use_threshold ? 1 : 0};
@@ -756,11 +761,14 @@ int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_thre
     a.gx = (uint8_t *)(snap + snap_bytes);
     a.work_bytes = (uint32_t)xp.work_bytes;
     a.inject_failure = path == 5;
-    GU_HIP(hipMemsetAsync(a.gx, 0, 8 * xp.work_bytes, h->stream));  // no tag of an earlier launch may be left in the granule buffers
     if ((rc = gu_vi_xcd_launch(h, xp, a, false, greedy)) != GU_OK) return rc;
-    int32_t ctl[4] = {0, 0, 0, 0};  // [workgroups registered, fallback word, rounds_done, -]
-    GU_HIP(hipMemcpyAsync(ctl, base, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
+    // (header and delta keys lie side by side: ONE copy back and one wait for calls of up to 4096 rounds)
+    const size_t first_keys = deltas ? (size_t)(max_rounds < 4096 ? max_rounds : 4096) : 0;
+    std::vector<unsigned long long> back(8 + first_keys);
+    GU_HIP(hipMemcpyAsync(back.data(), base, back.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     GU_HIP(hipStreamSynchronize(h->stream));
+    int32_t ctl[4];  // [workgroups registered, fallback word, rounds_done, -]
+    memcpy(ctl, back.data(), sizeof ctl);
     const int32_t done = ctl[1] ? -1 : ctl[2];
     if (done < 0) {
         if ((rc = gu_device_copy(h, h->d_v[h->vi_cur], snap, v_bytes)) != GU_OK) return rc;
@@ -770,10 +778,14 @@ int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_thre
         return GU_VI_FALLBACK;
     }
     if (deltas && done > 0) {
-        std::vector<unsigned long long> keys((size_t)done);
-        GU_HIP(hipMemcpy(keys.data(), base + 64, (size_t)done * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> rest;
+        if ((size_t)done > first_keys) {
+            rest.resize((size_t)done - first_keys);
+            GU_HIP(hipMemcpy(rest.data(), base + 64 + first_keys * sizeof(unsigned long long), rest.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        }
         for (int32_t i = 0; i < done; ++i) {
-            const unsigned long long k = keys[(size_t)i], b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+            const unsigned long long k = (size_t)i < first_keys ? back[8 + (size_t)i] : rest[(size_t)i - first_keys];
+            const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
             memcpy(&deltas[i], &b, sizeof(double));
         }
     }

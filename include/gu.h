@@ -96,7 +96,9 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_VI_PATH 8              /* DP: 1 = no workgroup-cluster kernel, 2 = one launch per round on every grid size,
                                          3 = chip-wide cluster kernel with an INJECTED grid-barrier timeout (tests of the
                                          fallback), 4 = no per-XCD form of gu_vi_sweep_step_run (the chip-wide cluster kernel
-                                         instead), 5 = its per-XCD form gives up at once (INJECTED; tests of the fallback)   */
+                                         instead), 5 = its per-XCD form gives up at once (INJECTED; tests of the fallback),
+                                         6 = the per-XCD form of gu_vi_sweep_step_run for calls of ONE round too (by default
+                                         those take the single fused launch, which starts ~10 us quicker; tests, measurements) */
 #define GU_OPT_MC_SCRATCH_MB 9        /* scratch budget of gu_mc_evaluate (2048)                                              */
 #define GU_OPT_MC_LANE_RETURNS 10     /* 1 = return sums by the per-lane kernel instead of the LDS-tiled one                  */
 #define GU_OPT_MC_GLOBAL_WALK 11      /* 1 = history walk with its counters in global memory instead of LDS                   */

@@ -17,14 +17,20 @@ from tests import _golden as G
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=['one_launch', 'no_per_xcd_form', 'launch_per_round'])
+@pytest.fixture(autouse=True, params=['one_launch', 'per_xcd_everywhere', 'no_per_xcd_form', 'launch_per_round'])
 def vi_path(request, gu_option):
-    """Every test runs three times.  'one_launch': the default dispatch -- grids of 1536 states and more take the per-XCD launch
-    (csrc/gu_vi_xcd.hip: one XCD's workgroups, the whole iteration in one launch), smaller ones the single-workgroup kernel (v in
-    LDS).  'no_per_xcd_form' (option vi_path = 4): the single-workgroup kernel up to 4096 states, the chip-wide workgroup cluster
-    beyond.  'launch_per_round' (vi_path = 2): one launch per round on every grid size."""
-    gu_option('vi_path', {'launch_per_round': 2, 'no_per_xcd_form': 4}.get(request.param))
+    """Every test runs four times.  'one_launch': the default dispatch -- every grid that fits takes the per-XCD launch
+    (csrc/gu_vi_xcd.hip: one XCD's workgroups, the whole iteration in one launch); fused sweep + step calls of ONE round take the
+    single fused launch.  'per_xcd_everywhere' (option vi_path = 6): the per-XCD launch for those too.  'no_per_xcd_form'
+    (vi_path = 4): the single-workgroup kernel up to 4096 states, the chip-wide workgroup cluster beyond.  'launch_per_round'
+    (vi_path = 2): one launch per round on every grid size."""
+    gu_option('vi_path', {'launch_per_round': 2, 'no_per_xcd_form': 4, 'per_xcd_everywhere': 6}.get(request.param))
     return request.param
+
+
+def base_path(vi_path):
+    """The option value a test that switches vi_path itself goes back to for 'the default dispatch' of this run."""
+    return 6 if vi_path == 'per_xcd_everywhere' else None
 
 
 def spec_of(meta):
@@ -273,7 +279,7 @@ def test_vi_eval_run_is_the_host_loop_of_policy_iteration(name):
             assert v.tobytes() == v_want.tobytes() and pi.tobytes() == pi0.tobytes() == pi_want.tobytes()
 
 
-def test_one_workgroup_and_launch_per_round_agree_at_64x64(gu_option):
+def test_one_workgroup_and_launch_per_round_agree_at_64x64(vi_path, gu_option):
     """config 5's grid through both paths: 300 rounds of value iteration, a policy-evaluation run and sweeps from a
     random policy and value table (ties, negative and positive values), compared as raw bytes."""
     import random
@@ -287,7 +293,7 @@ def test_one_workgroup_and_launch_per_round_agree_at_64x64(gu_option):
     v0, pi0 = rs.randn(S) * 3, rs.dirichlet(np.ones(4), S)
     out = []
     for multi in (False, True):
-        gu_option('vi_path', 2 if multi else None)
+        gu_option('vi_path', 2 if multi else base_path(vi_path))
         with Engine(4, GridSpec.from_env(env)) as eng:
             res = []
             eng.vi_set(v0, pi0)
@@ -372,7 +378,7 @@ def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, gu_option):
     # 'chip_wide': no per-XCD form; 'timeout': a grid-barrier timeout is injected into the chip-wide cluster -> tables restored,
     # launch-per-round path; 'xcd_gives_up': the per-XCD launch gives up at once -> tables restored, next form
     for cluster in ('0', '1', 'chip_wide', 'timeout', 'xcd_gives_up'):
-        gu_option('vi_path', {'0': 1, '1': None, 'chip_wide': 4, 'timeout': 3, 'xcd_gives_up': 5}[cluster])
+        gu_option('vi_path', {'0': 1, '1': base_path(vi_path), 'chip_wide': 4, 'timeout': 3, 'xcd_gives_up': 5}[cluster])
         res = []
         with Engine(2, spec) as eng:
             eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
@@ -410,7 +416,7 @@ def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, g
              'run_no_cluster': 1, 'run_timeout': 3, 'run_xcd_gives_up': 5}
     for mode, path in modes.items():
         if vi_path != 'launch_per_round':
-            gu_option('vi_path', path)
+            gu_option('vi_path', path if path is not None else base_path(vi_path))
         gu_option('vi_xcd_block', int(mode[8:]) if mode.startswith('run_xcd_') and mode[8:].isdigit() else None)
         with Engine(N, spec_of(meta), seed=3) as eng:
             eng.reset()
@@ -419,9 +425,15 @@ def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, g
                 deltas = np.array([eng.vi_sweep_step(gamma, auto_reset=auto) for _ in range(iters)])
             else:
                 deltas = eng.vi_sweep_step_run(gamma, iters, auto_reset=auto)
-                deltas = np.concatenate([deltas, eng.vi_sweep_step_run(gamma, 2, auto_reset=auto)])  # even + odd round counts
-                eng.vi_sweep_step_run(gamma, 1, auto_reset=auto)
                 form[mode] = eng.vi_last_form()
+                # even + odd round counts; by default calls this short take one launch per round, under vi_path = 6 (and wherever
+                # a mode sets a path of its own) the one-launch forms run them too
+                deltas = np.concatenate([deltas, eng.vi_sweep_step_run(gamma, 2, auto_reset=auto)])
+                eng.vi_sweep_step_run(gamma, 1, auto_reset=auto)
+                if vi_path == 'launch_per_round' or (path is None and vi_path != 'per_xcd_everywhere'):  # (a mode without a path of its own runs the default dispatch)
+                    assert eng.vi_last_form() == 3
+                else:
+                    assert eng.vi_last_form() == form[mode], (mode, eng.vi_last_form(), form[mode])
                 if mode == 'run' and form[mode] == 1:  # the clusters as the hardware reported them: every workgroup of the launch in exactly one
                     clusters = eng.vi_last_clusters()
                     assert sum(clusters) >= max(8, -(-N // 1024)) and all(c >= 0 for c in clusters) and sum(c > 0 for c in clusters) >= 1, clusters
@@ -441,7 +453,7 @@ def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, g
         # (262 144 envs need 1024-thread workgroups to stay at one per CU: the smaller sizes then decline and the chip-wide form runs)
         assert form['run'] == 1 and form['run_xcd_1024'] == 1 and form['run_xcd_256'] == (1 if N <= 65536 else 2), form
         assert form['run_chip_wide'] == 2 and form['run_xcd_gives_up'] == 2 and form['run_no_cluster'] == 3 and form['run_timeout'] == 3, form
-    gu_option('vi_path', 2 if vi_path == 'launch_per_round' else None)
+    gu_option('vi_path', 2 if vi_path == 'launch_per_round' else base_path(vi_path))
     with Engine(N, spec_of(meta), seed=3) as eng:  # the table part is the reference's value-iteration trace
         eng.reset()
         eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
@@ -476,14 +488,15 @@ def test_sweep_step_run_forms_agree_on_random_tables(name, N, values, vi_path, g
             v[5::13] = np.inf
             v[6::17] = -np.inf
             v[7::19] = np.nan
-        for mode, path in (('per_xcd', None), ('chip_wide', 4), ('per_launch', 1)):
+        for mode, path in (('per_xcd', base_path(vi_path)), ('chip_wide', 4), ('per_launch', 1)):
             gu_option('vi_path', path)
             with Engine(N, spec_of(meta), seed=3) as eng:
                 eng.reset()
                 eng.vi_set(v, pi)
                 with np.errstate(all='ignore'):
-                    deltas = np.concatenate([eng.vi_sweep_step_run(gamma, 7, auto_reset=True), eng.vi_sweep_step_run(gamma, 2, auto_reset=True)])
-                form[mode] = eng.vi_last_form()
+                    deltas = eng.vi_sweep_step_run(gamma, 7, auto_reset=True)
+                    form[mode] = eng.vi_last_form()
+                    deltas = np.concatenate([deltas, eng.vi_sweep_step_run(gamma, 2, auto_reset=True)])  # (by default: one launch per round)
                 vv, pp = eng.vi_get()
                 st = eng.get_state()
                 out[mode] = [deltas.tobytes(), vv.tobytes(), pp.tobytes(), st['pos'].tobytes(), st['done'].tobytes(), st['episode'].tobytes(),

@@ -86,11 +86,15 @@ def main():
     # launch overhead of the per-XCD form: the same launch with few rounds
     _lib.set_default_option('vi_path', None)
     _lib.set_default_option('vi_xcd_block', None)
-    short = {}
-    for rounds in (1, 10, 100):
-        ts = sorted(run(eng, S, rounds)[0] for _ in range(5))
-        short[rounds] = ts[2] * 1e6
-    out['xcd_default_us_per_call_by_rounds'] = short
+    # (the default dispatch gives calls of one or two rounds to one launch per round; vi_path = 6: the per-XCD form always)
+    for label, path in (('default_us_per_call_by_rounds', None), ('xcd_always_us_per_call_by_rounds', 6), ('launch_per_round_us_per_call_by_rounds', 1)):
+        _lib.set_default_option('vi_path', path)
+        short = {}
+        for rounds in (1, 2, 3, 4, 10, 100):
+            ts = sorted(run(eng, S, rounds)[0] for _ in range(5))
+            short[rounds] = ts[2] * 1e6
+        out[label] = short
+    _lib.set_default_option('vi_path', None)
     first = None
     bad = 0
     for i in range(a.stress):

@@ -72,10 +72,10 @@ while time.time() - t0 < budget:
         N = int(rs.choice([3, 300, 4096, 20000, 65536, 100000]))
         rounds = int(rs.randint(1, 400))
         out = {}
-        for form, path in (('per_xcd', None), ('chip_wide', 4)):
+        for form, path in (('per_xcd', 6), ('chip_wide', 4)):  # (6: the per-XCD form for the short second call too)
             with gua.Engine(N, spec, seed=5) as eng:
                 eng.set_option('vi_path', path)
-                eng.set_option('vi_xcd_block', int(rs.choice([0, 256, 512, 1024])) if path is None else None)
+                eng.set_option('vi_xcd_block', int(rs.choice([0, 256, 512, 1024])) if path == 6 else None)
                 eng.reset()
                 eng.vi_set(np.zeros(S), np.full((S, 4), 0.25))
                 d1 = eng.vi_sweep_step_run(gamma, rounds, True)
@@ -88,7 +88,7 @@ while time.time() - t0 < budget:
     else:  # the tables alone
         out = {}
         T = int(rs.randint(5, 300))
-        for form, path in (('per_xcd', None), ('other', 4)):
+        for form, path in (('per_xcd', 6), ('other', 4)):  # (6: whatever the grid's size and the call's length)
             with gua.Engine(8, spec, seed=5) as eng:
                 eng.set_option('vi_path', path)
                 eng.vi_set(np.zeros(S), np.full((S, 4), 0.25))

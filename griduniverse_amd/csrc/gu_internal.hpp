@@ -141,6 +141,7 @@ struct gu_engine {
 
     // pinned host staging (4*N int32)
     int32_t *h_pin = nullptr;
+    unsigned long long *h_ctl = nullptr;  // page-locked landing area of small results (gu_read_back): GU_CTL_WORDS 64-bit words
     uint32_t *h_seq = nullptr;      // page-locked control words (64 bytes): [0] completion word of gu_step's host-visible
                                     // paths, [GU_HOST_ERR_WORD] raised by a kernel that met an invalid action / state,
                                     // [GU_HOST_COUNT_WORD] number of done envs written by the compaction kernel
@@ -262,6 +263,11 @@ struct GuSegments {  // gu_device_segments: copies (src != nullptr) and fills wi
     }
 };
 int gu_device_segments(gu_engine *h, const GuSegments &s);
+// Small results back to the host through the engine's page-locked landing area (a device-to-host copy into pageable memory is
+// staged and waited for by the runtime; into pinned memory it is one DMA): copies `bytes` from `src` on the device to `dst`, behind
+// everything queued on the engine's stream, and waits.  Larger than the area: the plain copy.
+#define GU_CTL_WORDS (8 + 4096)
+int gu_read_back(gu_engine *h, void *dst, const void *src, size_t bytes);
 
 // ---- tabular DP launchers (gu_vi.hip) --------------------------------------------
 int gu_vi_alloc(gu_engine *h);

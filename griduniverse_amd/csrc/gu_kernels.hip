@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -383,6 +384,20 @@ int gu_device_segments(gu_engine *h, const GuSegments &s)
     const unsigned blocks = (unsigned)std::min<size_t>((most + 255) / 256, (size_t)h->n_cu * 8);
     hipLaunchKernelGGL(gu_segments_kernel, dim3(blocks), dim3(256), 0, h->stream, s);
     GU_HIP(hipGetLastError());
+    return GU_OK;
+}
+
+int gu_read_back(gu_engine *h, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return GU_OK;
+    if (h->h_ctl && bytes <= GU_CTL_WORDS * sizeof(unsigned long long)) {
+        GU_HIP(hipMemcpyAsync(h->h_ctl, src, bytes, hipMemcpyDeviceToHost, h->stream));
+        GU_HIP(hipStreamSynchronize(h->stream));
+        memcpy(dst, h->h_ctl, bytes);
+        return GU_OK;
+    }
+    GU_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    GU_HIP(hipStreamSynchronize(h->stream));
     return GU_OK;
 }
 

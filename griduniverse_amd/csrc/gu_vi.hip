@@ -699,8 +699,10 @@ static int vi_block_run(gu_engine *h, double gamma, double threshold, bool use_t
     hipLaunchKernelGGL(kern, dim3(1), dim3(VI_PB_THREADS), smem, h->stream, a);
     GU_HIP(hipGetLastError());
     int32_t done = 0;
-    GU_HIP(hipMemcpyAsync(&done, done_d, sizeof done, hipMemcpyDeviceToHost, h->stream));
-    GU_HIP(hipStreamSynchronize(h->stream));
+    {
+        const int rb = gu_read_back(h, &done, done_d, sizeof done);
+        if (rb != GU_OK) return rb;
+    }
     if (deltas && done > 0) {
         std::vector<unsigned long long> keys((size_t)done);
         GU_HIP(hipMemcpy(keys.data(), keys_d, (size_t)done * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -776,8 +778,10 @@ static int vi_cluster_run(gu_engine *h, double gamma, double threshold, bool use
     // rounds_done is written by ONE workgroup, and a timeout need not be unanimous (the workgroup that arrives last finds the
     // counter complete and goes on while the others have given up): the timeout word, raised by whoever gives up, decides.
     int32_t ctl[4] = {0, 0, 0, 0};  // [arrival counter, timeout word, rounds_done, pad]
-    GU_HIP(hipMemcpyAsync(ctl, h->d_scratch, sizeof ctl, hipMemcpyDeviceToHost, h->stream));
-    GU_HIP(hipStreamSynchronize(h->stream));
+    {
+        const int rb = gu_read_back(h, ctl, h->d_scratch, sizeof ctl);
+        if (rb != GU_OK) return rb;
+    }
     const int32_t done = ctl[1] ? -1 : ctl[2];
     if (done < 0) {
         if ((rc = gu_device_copy(h, h->d_v[h->vi_cur], snap, v_bytes)) != GU_OK) return rc;
@@ -825,9 +829,9 @@ int gu_vi_get(gu_handle h, double *v, double *pi)
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
-    GU_HIP(hipStreamSynchronize(h->stream));
-    if (v) GU_HIP(hipMemcpy(v, h->d_v[h->vi_cur], (size_t)h->S * sizeof(double), hipMemcpyDeviceToHost));
-    if (pi) GU_HIP(hipMemcpy(pi, h->d_pi[h->vi_cur], 4 * (size_t)h->S * sizeof(double), hipMemcpyDeviceToHost));
+    if (v && (rc = gu_read_back(h, v, h->d_v[h->vi_cur], (size_t)h->S * sizeof(double))) != GU_OK) return rc;
+    if (pi && (rc = gu_read_back(h, pi, h->d_pi[h->vi_cur], 4 * (size_t)h->S * sizeof(double))) != GU_OK) return rc;
+    if (!v && !pi) GU_HIP(hipStreamSynchronize(h->stream));
     return GU_OK;
 }
 
@@ -874,8 +878,10 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
     h->greedy_valid = false;
     if (deltas) {
         std::vector<unsigned long long> keys((size_t)iters);
-        GU_HIP(hipMemcpyAsync(keys.data(), h->d_delta, (size_t)iters * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-        GU_HIP(hipStreamSynchronize(h->stream));
+        {
+            const int rb = gu_read_back(h, keys.data(), h->d_delta, (size_t)iters * sizeof(unsigned long long));
+            if (rb != GU_OK) return rb;
+        }
         for (int32_t i = 0; i < iters; ++i) deltas[i] = vi_unkey(keys[(size_t)i]);
     }
     return GU_OK;
@@ -931,8 +937,10 @@ int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, in
         if (rc != GU_OK) return rc;
         h->vi_cur ^= n & 1;
         GU_HIP(hipGetLastError());
-        GU_HIP(hipMemcpyAsync(keys.data(), h->d_delta, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-        GU_HIP(hipStreamSynchronize(h->stream));
+        {
+            const int rb = gu_read_back(h, keys.data(), h->d_delta, (size_t)n * sizeof(unsigned long long));
+            if (rb != GU_OK) return rb;
+        }
         // rounds of this batch that ran: up to and including the first one whose delta met the threshold (:22-23)
         for (int32_t i = 0; i < n && !stop; ++i) {
             const double delta = vi_unkey(keys[(size_t)i]);
@@ -991,8 +999,10 @@ int gu_vi_eval_run(gu_handle h, double gamma, double threshold, int32_t max_step
         };
         rc = sweeps(n);
         if (rc != GU_OK) return rc;
-        GU_HIP(hipMemcpyAsync(keys.data(), h->d_delta, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-        GU_HIP(hipStreamSynchronize(h->stream));
+        {
+            const int rb = gu_read_back(h, keys.data(), h->d_delta, (size_t)n * sizeof(unsigned long long));
+            if (rb != GU_OK) return rb;
+        }
         int32_t ran = n;
         for (int32_t i = 0; i < n; ++i) {
             const double delta = vi_unkey(keys[(size_t)i]);
@@ -1068,8 +1078,7 @@ int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta)
     h->steps_taken += 1;
     if (delta) {
         unsigned long long key = 0;
-        GU_HIP(hipMemcpyAsync(&key, h->d_delta, sizeof key, hipMemcpyDeviceToHost, h->stream));
-        GU_HIP(hipStreamSynchronize(h->stream));
+        if ((rc = gu_read_back(h, &key, h->d_delta, sizeof key)) != GU_OK) return rc;
         *delta = vi_unkey(key);
     }
     return GU_OK;
@@ -1157,8 +1166,7 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
             // gives up, decides (see vi_cluster_run)
             // (header and delta keys lie side by side: ONE copy back, one wait)
             std::vector<unsigned long long> back(8 + (deltas ? (size_t)iters : 0));
-            GU_HIP(hipMemcpyAsync(back.data(), h->d_scratch, back.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-            GU_HIP(hipStreamSynchronize(h->stream));
+            if ((rc = gu_read_back(h, back.data(), h->d_scratch, back.size() * sizeof(unsigned long long))) != GU_OK) return rc;
             int32_t ctl[12];  // [arrival counter, fallback word, rounds_done, 1 + XCC of workgroup 0, workgroups registered per XCC x 8]
             memcpy(ctl, back.data(), sizeof ctl);
             if (form == 0) memcpy(h->vi_xcd_members, ctl + 4, sizeof h->vi_xcd_members);  // (what the hardware reported: HW_REG_XCC_ID per workgroup)

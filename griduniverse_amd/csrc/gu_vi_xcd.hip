@@ -765,8 +765,7 @@ int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_thre
     // (header and delta keys lie side by side: ONE copy back and one wait for calls of up to 4096 rounds)
     const size_t first_keys = deltas ? (size_t)(max_rounds < 4096 ? max_rounds : 4096) : 0;
     std::vector<unsigned long long> back(8 + first_keys);
-    GU_HIP(hipMemcpyAsync(back.data(), base, back.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
-    GU_HIP(hipStreamSynchronize(h->stream));
+    if ((rc = gu_read_back(h, back.data(), base, back.size() * sizeof(unsigned long long))) != GU_OK) return rc;
     int32_t ctl[4];  // [workgroups registered, fallback word, rounds_done, -]
     memcpy(ctl, back.data(), sizeof ctl);
     const int32_t done = ctl[1] ? -1 : ctl[2];

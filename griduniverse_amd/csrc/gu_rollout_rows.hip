@@ -158,6 +158,8 @@ struct RowBytes {
     static constexpr int log2 = POLICY == GU_POLICY_GREEDY ? 2 : POLICY == GU_POLICY_SAMPLE ? 5 : 4;
 };
 
+// nothing but the chain between the arrival of a record and the issue of the read it addresses (see word16)
+#define GU_CHAIN_FENCE() __builtin_amdgcn_sched_barrier(0)
 template <int POLICY, int TRAJ, bool STATS, bool PAIR = false>
 __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const RolloutArgs a, const int32_t auto_reset)
 {
@@ -311,7 +313,11 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
                 const uint32_t prev = q ? r2[q - 1] : rec;
                 uint32_t off = __builtin_amdgcn_ubfe(word, 4 * q, 4) << 3;  // off the chain
                 asm("" : "+v"(off));
+                // (nothing but the chain between the arrival of `prev` and the issue of the next read: left to itself the scheduler
+                // put ~10 instructions of the records' emission there, ~50 clocks on every round trip of a wave that has its SIMD alone)
+                GU_CHAIN_FENCE();
                 const gu_v2u pr = *(lds_v2u_ptr)(uintptr_t)((prev & GU_ROW_ADDR_MASK) | off);
+                GU_CHAIN_FENCE();
                 r1[q] = pr.x;
                 r2[q] = pr.y;
                 if (q == 0) {
@@ -572,7 +578,10 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     // Pair tables (two steps per LDS round trip) where they pay: state-independent actions, PACKED rows (int32 rows are as fast or
     // faster on the one-step table -- 58 .. 61 against 65 us at 32 768 envs, 110 against 115 at 65 536: six stores and two records'
     // worth of unpacking per round trip cost what the shorter chain saves, and those launches are close to the write path's rate
-    // anyway -- round 4, forced for int32 rows again: 47.6 against 49.0 us at config 2's 4096 envs, 65.2 against 59.4 at a config-4 shard; without rows the K-step kernel of gu_rollout_multi.hip is the tool), one 256-lane workgroup per CU at most (144 bytes
+    // anyway -- round 4, forced for int32 rows again, the chain fenced (GU_CHAIN_FENCE): 43.8 against 44.6 ns per step at config 2's
+    // 4096 envs, slower at 32 768 and 65 536.  What bounds a wave that has its SIMD alone is the ISSUE of its stores, ~25 clocks per
+    // 256-byte buffer_store_dword: 107 clocks per step with three of them, 143 per packed pair with two, 210 per int32 pair with six
+    // (slopes over T = 2000 .. 4000); without rows the K-step kernel of gu_rollout_multi.hip is the tool), one 256-lane workgroup per CU at most (144 bytes
     // of LDS per cell).  GU_OPT_ROLLOUT_ROWS = 2 keeps the one-step table (A/B, tests).  profiles/archive/r03r_pair_rows.txt
     bool pair = !table_policy && traj == 2 && mode != 2 && gu_blocks(h->N, 256) <= (unsigned)h->n_cu && (int64_t)h->S * 144 <= h->lds_per_cu - 2048 &&
                 ((int64_t)h->S << GU_PAIR_SHIFT) <= (int64_t)GU_ROW_ADDR_MASK;

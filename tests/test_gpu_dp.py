@@ -503,3 +503,33 @@ def test_sweep_step_run_forms_agree_on_random_tables(name, N, values, vi_path, g
                              eng.read_outputs()[1].tobytes()]
         assert out['per_xcd'] == out['chip_wide'] == out['per_launch'], (gamma, [a == b for a, b in zip(out['per_xcd'], out['per_launch'])])
     assert form == {'per_xcd': 1, 'chip_wide': 2, 'per_launch': 3}
+
+
+def test_calls_of_thousands_of_rounds_return_every_delta(vi_path, gu_option):
+    """Calls longer than the 4096 deltas that come back with the control words in one copy (csrc/gu_vi_xcd.hip: gu_vi_xcd_dp_run),
+    and a fused sweep + step call of thousands of rounds: round count, every delta and the tables equal those of the
+    single-workgroup kernel / of one launch per round."""
+    if vi_path != 'one_launch':
+        pytest.skip('compares the default dispatch with the others itself')
+    meta, _ = G.load_dp('maze8_s1')
+    S = meta['W'] * meta['H']
+    out = {}
+    for mode, path in (('default', None), ('one_workgroup', 4), ('per_launch', 2)):
+        gu_option('vi_path', path)
+        with Engine(300, spec_of(meta), seed=2) as eng:
+            eng.reset()
+            eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+            steps, deltas = eng.vi_run(0.999, -1.0, 5000)  # (a threshold no delta is below: every round runs)
+            v, pi = eng.vi_get()
+            res = [steps, deltas.tobytes(), v.tobytes(), pi.tobytes()]
+            assert steps == 5000 and deltas.shape == (5000,)
+            steps, deltas = eng.vi_eval_run(0.9, -1.0, 4100)
+            res += [steps, deltas.tobytes(), eng.vi_get()[0].tobytes()]
+            if mode != 'one_workgroup':
+                eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+                d = eng.vi_sweep_step_run(0.999, 4500, auto_reset=True)
+                st = eng.get_state()
+                res += [d.tobytes(), eng.vi_get()[0].tobytes(), st['pos'].tobytes(), st['episode'].tobytes()]
+            out[mode] = res
+    assert out['default'][:7] == out['one_workgroup'][:7] == out['per_launch'][:7]
+    assert out['default'][7:] == out['per_launch'][7:]

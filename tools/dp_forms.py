@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tabular DP as ONE launch: rounds per second of value iteration (V1 + delta + V2 per round, stopping rule off) by grid size in
-every one-launch form -- the per-XCD launch (default from 1536 states), the single workgroup (up to 4096 states), the chip-wide
+every one-launch form -- the per-XCD launch (the default wherever the grid fits it), the single workgroup (up to 4096 states), the chip-wide
 workgroup cluster (beyond) -- and one launch per round.  Tables compared byte for byte between the forms.
 Usage: python tools/dp_forms.py [out.json]"""
 import hashlib

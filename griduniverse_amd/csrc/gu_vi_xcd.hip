@@ -137,7 +137,14 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ vi_u64 round_key_lds;  // !AGENTS: the cluster's delta key of the round
     __shared__ uint32_t info[4];  // [0] XCC id, [1] rank in the cluster, [2] members, [3] bit 0: failed, bit 1: this cluster writes the tables
+#ifdef GU_VI_XCD_STAMPS
+    uint64_t life[7];  // 100 MHz ticks: entry, planes staged, registered, loop begins, loop ends, last exchange done, results written
+    life[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     const ViMap cell = vi_stage<true>(a.vi.cell, a.vi.cell_bytes, smem);  // the agents gather records of arbitrary cells
+#ifdef GU_VI_XCD_STAMPS
+    life[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     double *vL_window = reinterpret_cast<double *>(smem + 2 * a.vi.cell_bytes);  // [a.lds_values] the values of the own chunk and of one grid row either side: all a workgroup ever reads
     const int32_t tid = threadIdx.x, B = blockDim.x, S = a.vi.S, W = a.vi.W;
     const int32_t cb = a.vi.cell_bytes;
@@ -178,6 +185,9 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         info[3] = bad | (writes << 1);
     }
     __syncthreads();
+#ifdef GU_VI_XCD_STAMPS
+    life[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t xcc = info[0], rank = info[1], members = info[2];
     const bool writes_tables = (info[3] & 2u) != 0;
     bool failed = (info[3] & 1u) != 0;
@@ -262,6 +272,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     uint64_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t stamp_last = __builtin_amdgcn_s_memtime();
     const uint64_t stamp_t0 = __builtin_amdgcn_s_memrealtime();
+    life[3] = stamp_t0;
 #endif
     const bool keeps_deltas = writes_tables && rank == 0;
     // The tables alone: every workgroup takes in every member's delta key of the round BEFORE every round -- the stopping rule needs
@@ -598,6 +609,9 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         for (; r < a.vi.max_rounds && !failed; ++r)
             if (!round(std::integral_constant<int, 2>{})) break;
     }
+#ifdef GU_VI_XCD_STAMPS
+    life[4] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (!AGENTS && !failed && r > 0 && r == a.vi.max_rounds && keeps_deltas) {  // the tables alone, not stopped: the last round's delta is still out
         __syncthreads();
         if (wave == key_wave) {
@@ -621,7 +635,9 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         else if (envs_here) agents();
     }
 #ifdef GU_VI_XCD_STAMPS
+    life[5] = __builtin_amdgcn_s_memrealtime();
     // (which wave of which member is stamped: GU_VI_STAMP_WAVE / GU_VI_STAMP_RANK in the environment of the variant library)
+    const bool stamps_here = writes_tables && rank == ((a.inject_failure >> 16) & 0xFFu) && tid == (int32_t)((a.inject_failure >> 8) & 0xFFu) * 64;
     if (writes_tables && rank == ((a.inject_failure >> 16) & 0xFFu) && tid == (int32_t)((a.inject_failure >> 8) & 0xFFu) * 64 && a.vi.max_rounds >= 12) {
         stamp_acc[11] = __builtin_amdgcn_s_memrealtime() - stamp_t0;
         for (int i = 0; i < 12; ++i) a.vi.delta_key[i] = stamp_acc[i];
@@ -651,6 +667,13 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         if (lane == 0 && own_env[e]) a.done_bits[gid[e] >> 6] = bits;
     }
     if (blockIdx.x == 0 && tid == 0) *a.vi.rounds_done = failed ? -1 : r;
+#ifdef GU_VI_XCD_STAMPS
+    if (stamps_here && a.vi.max_rounds >= 20) {  // (the kernel's life beside the loop: delta_key[12 .. 18], ticks since entry)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        life[6] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 1; i < 7; ++i) a.vi.delta_key[12 + i] = life[i] - life[0];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ host side

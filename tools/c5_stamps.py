@@ -57,11 +57,17 @@ def main():
                 keys = []
                 for b in bits.tolist():  # key -> double was: top bit set ? clear it : ~key; invert
                     keys.append((b | (1 << 63)) if not (b >> 63) else (~b) & ((1 << 64) - 1))
+                life = None
+                if a.rounds >= 20:  # the kernel's life beside the loop, 100 MHz ticks since entry -> us
+                    lk = []
+                    for b in d[13:19].view(np.uint64).tolist():
+                        lk.append((b | (1 << 63)) if not (b >> 63) else (~b) & ((1 << 64) - 1))
+                    life = dict(zip(['planes_staged', 'registered', 'loop_begins', 'loop_ends', 'last_exchange_done', 'results_written'], [round(x / 100.0, 2) for x in lk]))
                 cyc = [k / a.rounds for k in keys[:10]]
                 ticks = keys[11]
                 out['runs'].append({'block': block, 'rank': rank, 'wave': wave, 'cycles_per_round': [round(cyc[i], 1) for i in ORDER],
                                     'cycles_per_round_total': round(sum(cyc), 1), 'poll_turns_per_round': keys[10] / a.rounds,
-                                    'us_per_round_100MHz_clock': ticks / 100.0 / a.rounds, 'shader_clock_GHz': sum(cyc) * a.rounds / (ticks * 10.0)})
+                                    'us_per_round_100MHz_clock': ticks / 100.0 / a.rounds, 'kernel_life_us_since_entry': life, 'shader_clock_GHz': sum(cyc) * a.rounds / (ticks * 10.0)})
     print(json.dumps(out, indent=1))
     print('\n'.join('block %4d rank %2d wave %d: ' % (r['block'], r['rank'], r['wave']) + ' '.join('%6.0f' % c for c in r['cycles_per_round'])
                     + '  | total %6.0f, polls %.2f' % (r['cycles_per_round_total'], r['poll_turns_per_round']) for r in out['runs']), file=sys.stderr)

@@ -267,3 +267,36 @@ def test_pair_tables_leave_the_same_rows_as_the_one_step_table_and_the_general_k
         want = C.rollout(grid, 4, st, T, True)
         for k in ('obs', 'reward', 'done'):
             assert np.array_equal(got[k][:, N - 2048:], want[k]), (N, traj, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows', ['1', '0'])
+def test_sampled_policy_with_per_env_step_counts(gu_option, rows):
+    """RNG stream 2 hashes one word per sixteen steps of an env; where the lanes of a wave are at ONE step count the kernels run
+    an unrolled schedule, where gu_set_state gave every env its own they ask the lanes step by step.  Both against the C oracle:
+    a common count that is no multiple of sixteen (head of single steps), ragged counts, counts across the 16-step groups."""
+    gu_option('rollout_rows', int(rows))
+    meta, _ = G.load_traj('c3_maze32')
+    S = meta['W'] * meta['H']
+    N = 777
+    rs = np.random.RandomState(6)
+    pi = rs.dirichlet(np.ones(4) * 0.6, S)
+    for counts in ('common_13', 'ragged', 'common_4090'):
+        grid, st, eng = _oracle_and_engine(meta, N, 21, env_id0=5)
+        with eng:
+            eng.reserve_trajectory(70)
+            eng.vi_set(np.zeros(S), pi)
+            st.tcount[:] = {'common_13': 13, 'common_4090': 4090}.get(counts, 0) if counts != 'ragged' else rs.randint(0, 100, N)
+            eng.set_state(pos=st.pos, done=st.done, episode=st.episode, tcount=st.tcount)
+            for T in (70, 5, 33):
+                for traj in (True, False):
+                    eng.rollout(T, 'sample', True, traj, stats=True)
+                    want = C.rollout(grid, 21, st, T, True, stats=True, pi=pi)
+                    if traj:
+                        got = eng.read_trajectory(0, T)
+                        for k in got:
+                            assert np.array_equal(got[k], want[k]), (counts, T, k)
+                    ret, eps = eng.read_stats()
+                    assert np.array_equal(ret, want['ret']) and np.array_equal(eps, want['episodes']), (counts, T, traj)
+                    s = eng.get_state()
+                    assert all(np.array_equal(s[k], getattr(st, k)) for k in ('pos', 'done', 'episode', 'tcount')), (counts, T, traj)

@@ -688,15 +688,18 @@ bool gu_vi_xcd_plan(const gu_engine *h, bool agents, GuXcdPlan *plan)
     const int64_t forced = gu_opt(h, GU_OPT_VI_XCD_BLOCK);
     const int max_wgs = h->n_cu & ~(VI_XCD_MAX_XCC - 1);
     const int64_t items = halo + (agents ? n_aw : 0);  // halo granules (+ action items): four per thread at most
+    // Two passes over the workgroup sizes: first for a shape in which half of a workgroup's waves own no states (they take the delta
+    // keys, the collection and the agents off the waves that carry the round: 1.05 against 1.43 us per round at 80x80, 1.53 against
+    // 1.91 at 128x128 for the tables alone), then for any shape that fits.
+    for (int pass = forced ? 1 : 0; pass < 2; ++pass)
     for (int64_t B = forced ? forced : 256; B <= 1024; B <<= 1) {
         const int64_t env_wgs = agents ? (h->N + B - 1) / B : 0;
         if (env_wgs > h->n_cu) {
             if (forced) return false;
             continue;
         }
-        // enough workgroups for one state per thread in every cluster, as far as the device has CUs for them; the tables alone:
-        // for one state per TWO threads, so that half of a workgroup's waves own no states and take the delta keys off the others
-        const int64_t per_wg = agents ? B : B / 2;
+        // enough workgroups for one state per TWO threads in every cluster, as far as the device has CUs for them
+        const int64_t per_wg = B / 2;
         int64_t G = VI_XCD_MAX_XCC * (((int64_t)h->S + per_wg - 1) / per_wg);
         if (G > max_wgs) G = max_wgs;
         if (G < env_wgs) G = env_wgs;
@@ -708,6 +711,7 @@ bool gu_vi_xcd_plan(const gu_engine *h, bool agents, GuXcdPlan *plan)
             if (forced) return false;
             continue;
         }
+        if (pass == 0 && !(K == 1 && 2 * chunk <= B)) continue;
         // planes | value window (the chunk and one grid row either side) | spare slot of the fetch | action words | the lanes' delta keys
         const int64_t values = ((int64_t)K * B + halo + 2) & ~(int64_t)1;
         const size_t lds = ((2 * (size_t)h->cell_bytes + (size_t)values * sizeof(double) + 16 + (size_t)n_aw * 8 + 15) & ~(size_t)15) + 2 * 1024 * sizeof(vi_u64);

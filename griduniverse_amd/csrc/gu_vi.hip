@@ -1167,9 +1167,10 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
             // (header and delta keys lie side by side: ONE copy back, one wait)
             std::vector<unsigned long long> back(8 + (deltas ? (size_t)iters : 0));
             if ((rc = gu_read_back(h, back.data(), h->d_scratch, back.size() * sizeof(unsigned long long))) != GU_OK) return rc;
-            int32_t ctl[12];  // [arrival counter, fallback word, rounds_done, 1 + XCC of workgroup 0, workgroups registered per XCC x 8]
+            int32_t ctl[4];  // [arrival counter (chip-wide form), fallback word, rounds_done, -]
             memcpy(ctl, back.data(), sizeof ctl);
-            if (form == 0) memcpy(h->vi_xcd_members, ctl + 4, sizeof h->vi_xcd_members);  // (what the hardware reported: HW_REG_XCC_ID per workgroup)
+            if (form == 0)  // the per-XCD form's registration word: eight 7-bit counts of workgroups per HW_REG_XCC_ID (gu_vi_xcd.hip)
+                for (int k = 0; k < 8; ++k) h->vi_xcd_members[k] = (int32_t)((back[2] >> (7 * k)) & 0x7Full);
             if (!ctl[1] && ctl[2] == iters) {
                 for (int32_t i = 0; deltas && i < iters; ++i) deltas[i] = vi_unkey(back[8 + (size_t)i]);
                 if (iters & 1) {

@@ -11,8 +11,9 @@
 // states at 64x64: nothing next to 65 536 agents) with its own workgroups and steps its own share of the agents, so nothing a
 // round needs ever leaves the XCD, and there is NO barrier between workgroups at all -- the data carries its own round number:
 //
-//   cluster      = the workgroups that read the same HW_REG_XCC_ID; each claims a rank in its cluster at start (one returning
-//                  atomic per workgroup + ONE chip-wide arrival wait per launch, so that every cluster knows its size).
+//   cluster      = the workgroups that read the same HW_REG_XCC_ID; each claims a rank in its cluster at start (ONE returning
+//                  atomic per workgroup on a word of eight packed counters + ONE chip-wide wait per launch until the counters
+//                  add up to the grid, so that every cluster knows its size).
 //                  Membership is what the hardware reports, not a guess from blockIdx: any placement gives correct results,
 //                  the observed round-robin placement (blocks b and b + 8 share an XCD) gives equal clusters.
 //   state chunk  = cluster of n workgroups, workgroup `rank` owns states [rank * chunk, (rank + 1) * chunk), chunk =
@@ -149,30 +150,41 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     const int32_t tid = threadIdx.x, B = blockDim.x, S = a.vi.S, W = a.vi.W;
     const int32_t cb = a.vi.cell_bytes;
     const double gamma = a.vi.gamma;
-    uint32_t *hdr = a.vi.sync;  // [0] workgroups registered, [1] fallback word, [3] 1 + XCC id of workgroup 0, [4 .. 11] members per XCC
+    uint32_t *hdr = a.vi.sync;  // [1] fallback word, [2] rounds done, [4 .. 5] the registration word (below)
 
     // ---- registration: who shares this XCD ----
     if (tid == 0) {
         const uint32_t xcc = __builtin_amdgcn_s_getreg(VI_XCD_GETREG_XCC_ID);
-        uint32_t rank = 0, bad = xcc >= VI_XCD_MAX_XCC;
-        if (!bad) {
-            rank = __hip_atomic_fetch_add(hdr + 4 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (blockIdx.x == 0) __hip_atomic_store(hdr + 3, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the claim (returned) and the leader word (written through) are out
-        __hip_atomic_fetch_add(hdr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t bad = xcc >= VI_XCD_MAX_XCC;
+        // ONE returning atomic on ONE 64-bit word does the claim, the arrival and the leader's mark: eight 7-bit counters of
+        // workgroups per XCC (at most one workgroup per CU: <= 32) and, in bits 56 .. 59, 1 + the XCC of workgroup 0.  The word
+        // read back until its counters add up to the grid is all a workgroup needs to know -- its rank came with the claim.
+        // (Separate words for claim, arrival and leader cost a second atomic behind a wait for the first, and two more loads
+        // behind the poll: 8 us of a launch, all of it round trips through memory across the XCDs.)
+        vi_u64 *reg = reinterpret_cast<vi_u64 *>(hdr + 4);
+        const uint32_t field = 7u * (xcc & (VI_XCD_MAX_XCC - 1));
+        const vi_u64 mine = ((vi_u64)1 << field) | (blockIdx.x == 0 ? (vi_u64)((xcc & 7u) + 1u) << 56 : 0ull);
+        vi_u64 seen = __hip_atomic_fetch_add(reg, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t rank = (uint32_t)(seen >> field) & 0x7Fu;
+        seen += mine;  // (the word as this workgroup left it: the last one to arrive needs no further look)
+        auto arrived = [](vi_u64 w) {
+            uint32_t n = 0;
+            for (int k = 0; k < VI_XCD_MAX_XCC; ++k) n += (uint32_t)(w >> (7 * k)) & 0x7Fu;
+            return n;
+        };
         uint32_t spins = 0;
-        while (!bad && vi_ld_word(hdr) < gridDim.x) {  // the one chip-wide wait of the launch
+        while (!bad && arrived(seen) < gridDim.x) {  // the one chip-wide wait of the launch
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > VI_CL_SPIN_LIMIT || vi_ld_word(hdr + 1)) bad = 1u;
+            seen = vi_ld_l2(reg);
+            if (++spins > VI_CL_SPIN_LIMIT || ((spins & 7u) == 0u && vi_ld_word(hdr + 1))) bad = 1u;
         }
         uint32_t members = 0, writes = 0;
         if (!bad) {
-            members = vi_ld_word(hdr + 4 + xcc);
-            writes = vi_ld_word(hdr + 3) == xcc + 1u;
+            members = (uint32_t)(seen >> field) & 0x7Fu;
+            writes = ((uint32_t)(seen >> 56) & 0xFu) == xcc + 1u;
             const int64_t chunk = ((((int64_t)S + members - 1) / members) + 63) & ~(int64_t)63;
             const int64_t items = 2 * (int64_t)(W < S ? W : S) + (((S + 15) >> 4) + 1) / 2;  // what one thread's four fetch items must cover
-            bad = rank >= VI_XCD_SLOTS || members > VI_XCD_SLOTS || chunk > (int64_t)K * B || items > 4 * (int64_t)B ||
+            bad = rank >= VI_XCD_SLOTS || members > VI_XCD_SLOTS || chunk > (int64_t)K * B || items > (int64_t)NB * B ||
                   chunk + 2 * (int64_t)(W < S ? W : S) > (int64_t)a.lds_values;
         }
         if (bad || (a.inject_failure & 1u)) {

@@ -29,7 +29,8 @@ OPT_UNSET = -2 ** 63
 OPTIONS = {'rollout_block': 1, 'rollout_rows': 2, 'rows_copies': 3, 'rollout_multi': 4, 'rollout_multi_k': 5,
            'rollout_multi_copies': 6, 'rollout_xcd': 7, 'vi_path': 8, 'mc_scratch_mb': 9, 'mc_lane_returns': 10,
            'mc_global_walk': 11, 'step_sync': 12, 'traj_candidates': 13, 'traj_far_candidates': 14, 'traj_stride_mib': 15,
-           'traj_far_mib': 16, 'traj_probe_all': 17, 'rollout_pace': 18, 'vi_xcd_block': 19,
+           'traj_far_mib': 16, 'traj_probe_all': 17, 'rollout_pace': 18, 'vi_xcd_block': 19, 'pace_target': 20, 'pace_bar_num': 21,
+           'pace_inc_q': 22, 'pace_dec_q': 23, 'traj_layout': 24,
            # experiments: refused by libgu.so, accepted by libgu_exp.so only
            'x_traj_uncached': 100, 'x_traj_poison': 101, 'x_mc_poison': 102}
 
@@ -68,6 +69,9 @@ SIGNATURES = {
     'gu_rollout_pacing': [_vp, _i32, _u32, _vp, _vp, _vp, _vp, _vp],
     'gu_rollout_calibrate': [_vp, _i64, _i32, _u32],
     'gu_rollout_pacing_totals': [_vp, _vp, _vp, _vp, _vp, _vp],
+    'gu_rollout_pace_log': [_vp, _i32, _u32, _i32, _vp, _vp, _vp],
+    'gu_rollout_pace_waves': [_vp, _i32, _vp, _vp],
+    'gu_rollout_pace_search': [_vp, _i64, _i32, _u32, _vp, _vp, _vp, _vp, _vp],
     'gu_read_trajectory': [_vp, _i64, _i64, _vp, _vp, _vp],
     'gu_read_trajectory_packed': [_vp, _i64, _i64, _vp],
     'gu_read_stats': [_vp, _vp, _vp],

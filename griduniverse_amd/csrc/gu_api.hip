@@ -166,7 +166,7 @@ int gu_destroy(gu_handle h)
     gu_placement_release(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     void *bufs[] = {h->d_kind, h->d_rows[0], h->d_rows[1], h->d_rows2[0], h->d_rows2[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
-                    h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy};
+                    h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy, h->d_pace_ring, h->d_pace_waves};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -250,7 +250,7 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
     if (h->d_prow) GU_HIP(hipFree(h->d_prow));
     h->d_prow = nullptr;
     h->has_grid = false;
-    for (auto &p : h->pace) p.known = false;  // (another grid: another chain length)
+    for (auto &p : h->pace) p.active = false;  // (another grid: another chain length)
     gu_vi_free(h);
     const size_t plane_bytes = 2 * (size_t)cell_bytes * n_grids;
     GU_HIP(hipMalloc(&h->d_cell, plane_bytes));
@@ -910,38 +910,95 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
     int rc = gu_launch_rollout(h, T, policy_kind, flags);
     if (rc == GU_OK) {
         h->stats_valid = (flags & GU_F_STATS) != 0;
-        if (flags & (GU_F_TRAJECTORY | GU_F_PACKED)) h->traj_kind = (flags & GU_F_PACKED) ? 2 : 1;
+        if (flags & (GU_F_TRAJECTORY | GU_F_PACKED)) h->traj_kind = h->traj_written;
     }
     return rc;
 }
 
 int gu_rollout_calibrate(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags)
 {
-    if (!h) return gu_fail(GU_ERR_INVALID, "null handle");
-    h->pace_requested = true;  // (read by gu_pace_for: search now instead of waiting for the launch count)
-    const int rc = gu_rollout(h, T, policy_kind, flags);
-    h->pace_requested = false;
-    return rc;
+    // (rounds 3 and 4: gu_rollout with the pacing search made now.  There is no search any more -- the launches of a kind choose
+    // their period themselves from the first one on -- and this entry point is gu_rollout, kept for callers that still call it.)
+    return gu_rollout(h, T, policy_kind, flags);
+}
+
+// the launch kind's slot: the general kernel's ring, else the transition-row kernel's (a launch kind of one engine runs on one of the two)
+static int gu_pace_slot_in_use(gu_engine *h, int32_t policy_kind, uint32_t flags)
+{
+    const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->all_single_start ? 1 : 2) : 0;
+    if (flags & GU_F_PACKED) {  // packed rows: the transition-row kernel's ring of its own
+        const int slot = 24 + policy_kind * 3 + auto_mode;
+        return h->pace[slot].active && h->pace[slot].seq && h->pace[slot].buffer == (const void *)h->d_traj ? slot : -1;
+    }
+    int found = -1;
+    uint32_t most = 0;
+    for (int base : {0, 12}) {
+        const gu_engine::PaceKind &k = h->pace[base + policy_kind * 3 + auto_mode];
+        if (k.active && k.seq > most && k.buffer == (const void *)h->d_traj) found = base + policy_kind * 3 + auto_mode, most = k.seq;
+    }
+    return found;
 }
 
 int gu_rollout_pacing_totals(gu_handle h, float *calibration_ms, int32_t *launches_spent, int32_t *kinds_paced, int32_t *kinds_from_cache,
                              int32_t *kinds_waiting)
 {
     GU_ENTER(h);
-    float ms = 0.0f;
-    int32_t spent = 0, paced = 0, cached = 0, waiting = 0;
-    for (const gu_engine::PaceRecord &r : h->pace) {
-        ms += r.calibration_ms;
-        spent += r.launches_spent;
-        paced += r.known ? 1 : 0;
-        cached += (r.known && r.from_cache) ? 1 : 0;
-        waiting += (!r.known && r.launches_seen > 0) ? 1 : 0;
-    }
-    if (calibration_ms) *calibration_ms = ms;
-    if (launches_spent) *launches_spent = spent;
+    int32_t paced = 0;
+    for (const gu_engine::PaceKind &k : h->pace) paced += (k.active && k.seq) ? 1 : 0;
+    if (calibration_ms) *calibration_ms = h->pace_search_ms;          // only gu_rollout_pace_search ever spends anything
+    if (launches_spent) *launches_spent = h->pace_search_launches;
     if (kinds_paced) *kinds_paced = paced;
-    if (kinds_from_cache) *kinds_from_cache = cached;
-    if (kinds_waiting) *kinds_waiting = waiting;
+    if (kinds_from_cache) *kinds_from_cache = 0;
+    if (kinds_waiting) *kinds_waiting = 0;
+    return GU_OK;
+}
+
+int gu_rollout_pace_log(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t capacity, uint64_t *entries, int32_t *count, uint32_t *launches)
+{
+    GU_ENTER(h);
+    GU_REQUIRE(policy_kind >= GU_POLICY_UNIFORM && policy_kind <= GU_POLICY_SAMPLE, GU_ERR_INVALID, "unknown policy kind %d", policy_kind);
+    const int slot = gu_pace_slot_in_use(h, policy_kind, flags);
+    GU_REQUIRE(slot >= 0, GU_ERR_STATE, "this launch kind keeps no schedule on the current trajectory buffer (not launched yet, or not a launch that is paced)");
+    const gu_engine::PaceKind &k = h->pace[slot];
+    GuPaceEntry ring[GU_PACE_RING];
+    GU_HIP(hipStreamSynchronize(h->stream));
+    GU_HIP(hipMemcpy(ring, h->d_pace_ring + (size_t)slot * GU_PACE_RING, sizeof(ring), hipMemcpyDeviceToHost));
+    // oldest first: launches seq - n + 1 .. seq of the kind (a launch is judged by the NEXT one: the last entry has no verdict yet)
+    const uint32_t have = std::min<uint32_t>(k.seq, GU_PACE_RING - 2u);
+    const uint32_t n = std::min<uint32_t>(have, capacity > 0 ? (uint32_t)capacity : 0u);
+    for (uint32_t i = 0; i < n && entries; ++i) {
+        const uint32_t seq = k.seq - n + 1u + i;
+        const GuPaceEntry &e = ring[seq & (GU_PACE_RING - 1u)];
+        const GuPaceEntry &next = ring[(seq + 1u) & (GU_PACE_RING - 1u)];
+        uint64_t *o = entries + (size_t)i * 8;
+        o[0] = e.seq;
+        o[1] = e.period_q;
+        o[2] = e.verdict;
+        o[3] = e.waves;
+        o[4] = e.late_q;
+        o[5] = e.ended_late;
+        o[6] = e.max_behind;
+        o[7] = (seq < k.seq && next.seq == seq + 1u && next.t_start > e.t_start) ? next.t_start - e.t_start : 0;  // start to start, 10 ns ticks
+    }
+    if (count) *count = (int32_t)n;
+    if (launches) *launches = k.seq;
+    return GU_OK;
+}
+
+int gu_rollout_pace_waves(gu_handle h, int32_t capacity, uint32_t *records, int32_t *count)
+{
+    GU_ENTER(h);
+    if (!h->d_pace_waves) {  // first call: from now on the paced launches of this engine leave one record per wave
+        const int64_t cap = (h->N + 63) / 64;
+        GU_HIP(hipMalloc((void **)&h->d_pace_waves, (size_t)cap * sizeof(uint4)));
+        GU_HIP(hipMemsetAsync(h->d_pace_waves, 0, (size_t)cap * sizeof(uint4), h->stream));
+        h->pace_waves_cap = cap;
+        h->pace_waves_last = 0;
+    }
+    const int64_t n = std::min<int64_t>(h->pace_waves_last, capacity > 0 ? capacity : 0);
+    GU_HIP(hipStreamSynchronize(h->stream));
+    if (n && records) GU_HIP(hipMemcpy(records, h->d_pace_waves, (size_t)n * sizeof(uint4), hipMemcpyDeviceToHost));
+    if (count) *count = (int32_t)n;
     return GU_OK;
 }
 
@@ -949,26 +1006,35 @@ int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t 
                       int32_t *evaluated, float *calibration_ms)
 {
     GU_ENTER(h);
-    GU_REQUIRE(policy_kind >= GU_POLICY_UNIFORM && policy_kind <= GU_POLICY_SAMPLE, GU_ERR_INVALID, "unknown policy kind %d", policy_kind);
-    const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->all_single_start ? 1 : 2) : 0;
-    // (the general kernel's record, else the transition-row kernel's: a launch kind of one engine runs on one of the two)
-    const gu_engine::PaceRecord *found = nullptr;
-    if (flags & GU_F_PACKED) {  // packed rows: the transition-row kernel's record of its own
-        const gu_engine::PaceRecord &cand = h->pace[24 + policy_kind * 3 + auto_mode];
-        if (cand.known && cand.buffer == (const void *)h->d_traj) found = &cand;
-    } else {
-        for (int base : {0, 12}) {
-            const gu_engine::PaceRecord &cand = h->pace[base + policy_kind * 3 + auto_mode];
-            if (!found && cand.known && cand.buffer == (const void *)h->d_traj) found = &cand;
-        }
-    }
-    GU_REQUIRE(found != nullptr, GU_ERR_STATE, "no pacing calibration for this launch kind on the current trajectory buffer");
-    const gu_engine::PaceRecord &rec = *found;
-    if (period) *period = (int32_t)rec.period;
-    if (ms_unpaced) *ms_unpaced = rec.ms_unpaced;
-    if (ms_paced) *ms_paced = rec.ms_paced;
-    if (evaluated) *evaluated = rec.evaluated;
-    if (calibration_ms) *calibration_ms = rec.calibration_ms;
+    uint64_t last[8];
+    int32_t n = 0;
+    uint32_t launches = 0;
+    const int rc = gu_rollout_pace_log(h, policy_kind, flags, 1, last, &n, &launches);
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(n == 1, GU_ERR_STATE, "no launch of this kind has been recorded yet");
+    if (period) *period = (int32_t)((last[1] + 32u) >> 6);
+    if (ms_unpaced) *ms_unpaced = 0.0f;  // (nothing runs without the limiter any more)
+    if (ms_paced) *ms_paced = (float)(((last[1] + 32u) >> 6) * (uint64_t)(h->pace[gu_pace_slot_in_use(h, policy_kind, flags)].T / 16)) * 1e-5f;  // its schedule
+    if (evaluated) *evaluated = (int32_t)launches;
+    if (calibration_ms) *calibration_ms = 0.0f;
+    return GU_OK;
+}
+
+int gu_rollout_pace_search(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
+                           int32_t *launches, float *ms_spent)
+{
+    if (!h) return gu_fail(GU_ERR_INVALID, "null handle");
+    h->pace_search_requested = true;  // (read by gu_pace_for)
+    const int rc = gu_rollout(h, T, policy_kind, flags);
+    const bool searched = !h->pace_search_requested && h->pace_search_found;
+    h->pace_search_requested = false;
+    if (rc != GU_OK) return rc;
+    GU_REQUIRE(searched, GU_ERR_STATE, "this launch is not one that keeps a schedule (less than 128 MB of rows, fewer than 64 steps, or no rows at all)");
+    if (period) *period = (int32_t)h->pace_search_period;
+    if (ms_unpaced) *ms_unpaced = h->pace_search_ms_unpaced;
+    if (ms_paced) *ms_paced = h->pace_search_ms_paced;
+    if (launches) *launches = h->pace_search_last_launches;
+    if (ms_spent) *ms_spent = h->pace_search_last_ms;
     return GU_OK;
 }
 
@@ -979,8 +1045,21 @@ int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t
                (long long)t0, (long long)(t0 + T));
     GU_REQUIRE(h->traj_kind != 2, GU_ERR_STATE, "the buffer holds a PACKED trajectory: use gu_read_trajectory_packed");
     const size_t n = (size_t)h->N, rows = (size_t)h->traj_T * n, count = (size_t)T * n;
-    GU_HIP(hipStreamSynchronize(h->stream));
     int32_t *dst[3] = {obs, reward, done};
+    if (h->traj_kind == 3) {  // triples [T][N][3]: taken apart on the device, a bounded number of rows at a time, then copied like planes
+        const size_t chunk_rows = std::max<size_t>(1, std::min<size_t>((size_t)T, ((size_t)256 << 20) / (12 * n)));
+        int rc = gu_ensure_scratch(h, chunk_rows * n * 12);
+        if (rc != GU_OK) return rc;
+        for (size_t r0 = 0; r0 < (size_t)T; r0 += chunk_rows) {
+            const size_t nr = std::min(chunk_rows, (size_t)T - r0), cnt = nr * n;
+            if ((rc = gu_launch_deinterleave(h, h->d_traj + ((size_t)t0 + r0) * n * 3, (int32_t *)h->d_scratch, (int64_t)cnt)) != GU_OK) return rc;
+            GU_HIP(hipStreamSynchronize(h->stream));
+            for (int k = 0; k < 3; ++k)
+                if (dst[k]) GU_HIP(hipMemcpy(dst[k] + r0 * n, (int32_t *)h->d_scratch + k * cnt, cnt * 4, hipMemcpyDeviceToHost));
+        }
+        return GU_OK;
+    }
+    GU_HIP(hipStreamSynchronize(h->stream));
     for (int k = 0; k < 3; ++k)
         if (dst[k]) GU_HIP(hipMemcpy(dst[k], h->d_traj + k * rows + (size_t)t0 * n, count * 4, hipMemcpyDeviceToHost));
     return GU_OK;

@@ -35,6 +35,46 @@
 
 #define GU_STREAM_PAD_WORDS 4  // spare rows behind the packed action stream: the rollout kernels read up to four words ahead
 
+// ---- closed-loop store pacing (gu_rollout.hpp: GuPacer, gu_pace_next) -----------------
+struct GuPaceEntry {   // the log record of one launch of one kind; 64 bytes
+    // written by ONE wave of the launch itself (plain stores)
+    uint32_t period_q;    // the period this launch ran with, in 1/64 ticks (the schedule uses the rounded tick count)
+    uint32_t seq;         // the kind's launch number (an entry with another number is not the previous launch's: ignored)
+    uint64_t t_start;     // 100 MHz clock when the launch's first workgroup began
+    // what the NEXT launch of the kind made of it (summed from the launch's buckets by that launch's first wave)
+    uint32_t verdict;     // 0 not judged yet, 1 on schedule, 2 behind (some wave ended further behind its schedule than the bar)
+    uint32_t waves;       // waves that reported
+    uint32_t late_q;      // sum over the waves of 64 x (groups begun behind schedule / groups)
+    uint32_t ended_late;  // waves that ended more than two periods behind their schedule
+    uint32_t max_behind;  // ticks: the most any wave ended behind its schedule (0 when none ended more than two periods behind)
+    uint32_t reserved[7];
+};
+// What the waves of a launch leave behind for the next launch of the kind: ONE agent-scope atomic per wave (and a second one from a
+// wave that ended far behind), spread over GU_PACE_BUCKETS cache lines.  (All 1024 waves on one line: the atomics of a launch are
+// executed one after the other at ~11 ns each -- the first version of the closed loop added 34 us to every 105 us launch that way,
+// profiles/r05a_pace_c3.txt.)
+struct GuPaceBucket {  // one 128-byte line
+    uint64_t sum;         // bits 0..19: late_q summed, 20..35: waves, 36..51: waves that ended more than two periods behind
+    uint64_t max_behind;  // ticks
+    uint64_t pad[14];
+};
+#define GU_PACE_RING 64u     /* log entries per launch kind: the last 62 launches can be read back (gu_rollout_pace_log) */
+#define GU_PACE_BUCKETS 32u  /* lines a launch's waves spread their reports over */
+#define GU_PACE_DEPTH 4u     /* bucket sets per kind: launch k adds to set k & 3, launch k + 1 reads it and clears set (k + 2) & 3 */
+struct GuPaceArgs {
+    GuPaceEntry *ring;      // nullptr: `period` as it is (0 = no limiter), nothing recorded
+    GuPaceBucket *buckets;  // [GU_PACE_DEPTH][GU_PACE_BUCKETS]
+    uint4 *waves;           // measurement aid, usually nullptr: one record per wave of the launch {groups begun late, groups, ticks
+                            // behind schedule at the end (two's complement), ticks from the launch's start to the wave's}
+    uint32_t seq;           // this launch's number within its kind (the host counts)
+    uint32_t period;        // ring == nullptr or `fixed`: the period in ticks; else the period of a kind's first launch (the model)
+    uint32_t lo, hi;        // the controller keeps the period within [lo, hi] ticks
+    uint32_t groups;        // 16-step groups of this launch (T / 16): the length of its schedule in periods
+    uint16_t bar_num;       // of 256: a launch was BEHIND when a wave ended more than bar_num / 256 of the schedule behind it
+    uint16_t fixed;         // 1: run with `period` and only record (measurement aid: tools/pace_loop.py)
+    uint32_t inc_q, dec_q;  // 1/64 ticks: the period's step up after a launch that was behind; the floor of its step down after one on schedule
+};
+
 struct gu_engine {
     int device = -1;
     int n_cu = 256;                  // compute units of the device (hipDeviceAttributeMultiprocessorCount)
@@ -88,7 +128,8 @@ struct gu_engine {
     // trajectory buffers obs|reward|done, each [traj_T][N]
     int32_t *d_traj = nullptr;
     int64_t traj_T = 0;
-    int traj_kind = 0;  // what the last rollout left in the buffer: 0 nothing, 1 int32 rows, 2 packed rows
+    int traj_kind = 0;  // what the last rollout left in the buffer: 0 nothing, 1 int32 rows (three planes), 2 packed rows, 3 int32 triples
+    int traj_written = 0;  // ... as gu_launch_rollout chose it for the launch it issued last
     int32_t traj_candidates = 0;                // allocations tried for the buffer (gu_alloc_trajectory)
     float traj_probe_ms_best = 0.0f, traj_probe_ms_worst = 0.0f;
     std::vector<float> traj_probe_ms;           // per candidate, in the order tried
@@ -98,23 +139,27 @@ struct gu_engine {
     uint64_t traj_peak_bytes = 0;               // most device memory the search held at once
     bool traj_registered = false;               // counted in the per-device registry of chosen buffers
 
-    // store pacing of the general rollout kernel's int32-row launches (gu_rollout.hpp: GuPacer), calibrated per launch kind
-    // [policy * 3 + auto mode] on the trajectory buffer in use
-    struct PaceRecord {
-        bool known = false;
-        const void *buffer = nullptr;  // the trajectory buffer the calibration ran on
-        int64_t T = 0;                 // ... and the launch length
-        uint32_t period = 0;           // the waves' schedule: 10 ns ticks per 16 steps (0: no limiter)
-        float ms_unpaced = 0.0f, ms_paced = 0.0f, calibration_ms = 0.0f;  // calibration_ms: summed over everything this slot ever spent
-        int32_t evaluated = 0;         // candidates timed
-        unsigned blocks = 0;           // workgroups of the launch the record belongs to
-        int32_t launches_seen = 0;     // launches of this kind issued without a limiter, waiting for the search to be worth it
-        int32_t launches_spent = 0;    // full-size launches the calibration (search or check) issued, summed
-        bool cache_checked = false;    // the process-wide cache has been consulted for this launch shape
-        bool from_cache = false;       // the period is an earlier engine's, checked here
-    } pace[36];  // [policy * 3 + auto mode] for the general kernel, + 12 for the transition-row kernel's int32 rows, + 24 for its packed rows
+    // store pacing of the launches that write rows (gu_rollout.hpp: GuPacer): one ring of launch records per launch kind
+    // [policy * 3 + auto mode] for the general kernel, + 12 for the transition-row kernel's int32 rows, + 24 for its packed rows
+    struct PaceKind {
+        bool active = false;           // the kind's ring is in use
+        const void *buffer = nullptr;  // the launch shape the ring belongs to: trajectory buffer, workgroups, launch length (within
+        unsigned blocks = 0;           // a factor of two), bytes per env-step -- another shape starts the ring over
+        int64_t T = 0;
+        int row_bytes = 0;
+        uint32_t seq = 0;              // launches of the kind recorded in the ring so far
+        uint32_t model = 0;            // the period its first launch started from
+    } pace[36];
+    GuPaceEntry *d_pace_ring = nullptr;  // [36][GU_PACE_RING] followed by the kinds' bucket sets [36][GU_PACE_DEPTH][GU_PACE_BUCKETS]
+    uint4 *d_pace_waves = nullptr;       // per-wave records of the last paced launch (allocated by the first gu_rollout_pace_waves call)
+    int64_t pace_waves_cap = 0, pace_waves_last = 0;  // records the buffer holds / waves of the last launch that wrote into it
     hipEvent_t ev_cal[2] = {nullptr, nullptr};
-    bool pace_requested = false;   // inside gu_rollout_calibrate: search now
+    float pace_search_ms = 0.0f;       // gu_rollout_pace_search (the open-loop search of rounds 3 and 4, a measurement aid now):
+    int32_t pace_search_launches = 0;  // what it cost this engine, summed
+    bool pace_search_requested = false, pace_search_found = false;  // inside gu_rollout_pace_search / its launch kind keeps a schedule
+    uint32_t pace_search_period = 0;   // the last search's outcome
+    float pace_search_ms_unpaced = 0.0f, pace_search_ms_paced = 0.0f, pace_search_last_ms = 0.0f;
+    int32_t pace_search_last_launches = 0;
 
     // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in
     uint32_t *d_rows[2] = {nullptr, nullptr};
@@ -245,6 +290,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags);
 int gu_launch_lookahead(gu_engine *h, int64_t n, const int32_t *d_states, const int32_t *d_actions, bool care,
                         int32_t *d_next, int32_t *d_reward, int32_t *d_done);
 int gu_launch_done_compact(gu_engine *h);
+int gu_launch_deinterleave(gu_engine *h, const int32_t *triples, int32_t *planes, int64_t count);  // [count][3] -> [3][count]
 int gu_probe_trajectory_buffer(gu_engine *h, int32_t *buf, int64_t T, float *ms);  // one timed full write, rollout store shape
 // Device-to-device copy by a kernel on the engine's stream (bytes a multiple of 4): the snapshots that the pace calibration and the
 // DP cluster launches take of the engine's state, and put back, stay on the kernel path (ordered with the launches around them,

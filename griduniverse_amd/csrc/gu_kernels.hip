@@ -411,46 +411,25 @@ static void gu_rollout_general(gu_engine *h, const RolloutArgs &a, int32_t polic
     }
 }
 
-// Which schedule (GuPacer: 10 ns ticks per 16 steps) makes THIS launch kind fastest on THIS trajectory buffer: the kernel itself is
-// timed -- full-length launches on the engine's own state, which is snapshot first and put back afterwards (positions, rewards,
-// done flags and their ballots, episode counters; the step counter lives on the host and is not advanced), so a calibrated engine
-// continues exactly where an uncalibrated one would.  Launch time follows the schedule (period x groups + a constant) down to
+// The open-loop search of rounds 3 and 4, kept as a MEASUREMENT AID (gu_rollout_pace_search, include/gu_diag.h): which fixed period
+// makes this launch kind fastest on this trajectory buffer, found by timing the kernel itself -- full-length launches on the engine's
+// own state, which is snapshot first and put back afterwards (positions, rewards, done flags and their ballots, episode counters;
+// the step counter lives on the host and is not advanced).  Launch time follows the schedule (period x groups + a constant) down to
 // the memory's capacity; below it the waves fall behind, first gracefully, then the launch collapses (the cliff).  The search:
 // down from the period that equals the unpaced launch time in steps of 4 % until the time jumps, then up from the collapsed
-// side in steps of 1 %, every candidate entered from a COLLAPSED stream (two unpaced launches first) -- the period to keep is
-// the shortest one that gets out of the collapse by itself, because a timed region is not kind either (a pause, a neighbour on
-// the device, and a stream that only holds while it is healthy is collapsed for good).  ~80 launches, once per (policy,
-// auto-reset mode, buffer).
+// side in steps of 1 %, every candidate entered from a COLLAPSED stream (two unpaced launches first) -- the period it reports is
+// the shortest one that gets out of the collapse by itself, plus 1 %.  A few hundred launches.  The product never runs it: the
+// launches choose their period themselves (gu_rollout.hpp: gu_pace_next); tests and tools/pace_loop.py hold the closed loop
+// against what it finds.
 #ifndef GU_PACE_MARGIN
-#define GU_PACE_MARGIN 1.01  /* the kept period over the first one that recovered and held */
+#define GU_PACE_MARGIN 1.01  /* the reported period over the first one that recovered and held */
 #endif
-// What a calibration cost this process, by launch shape: a later engine of the same shape on the same device does not search again,
-// it CHECKS the period found then with six launches (three without the limiter, three with it) and keeps it when it still wins.
-struct GuPaceKey {
-    int device, slot, row_bytes;
-    int64_t N, T_class;
-    unsigned blocks;
-    bool operator<(const GuPaceKey &o) const
-    {
-        return std::tie(device, slot, row_bytes, N, T_class, blocks) < std::tie(o.device, o.slot, o.row_bytes, o.N, o.T_class, o.blocks);
-    }
+struct GuPaceSearch {
+    uint32_t period = 0;
+    float ms_unpaced = 0.0f, ms_paced = 0.0f, ms_spent = 0.0f;
+    int32_t evaluated = 0, launches = 0;
 };
-struct GuPaceCached {
-    uint32_t period;
-    float ms_unpaced, ms_paced;
-};
-static std::mutex g_pace_mutex;
-static std::map<GuPaceKey, GuPaceCached> g_pace_cache;
-static int64_t gu_pace_T_class(int64_t T)
-{
-    int64_t c = 0;
-    while ((T >> c) > 1) ++c;
-    return c;  // launches within a factor of two of each other share a period (the schedule is per 16 steps)
-}
-
-// `hint`: a period this process found earlier for the same launch shape -- validate it instead of searching.
-static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::function<void(uint32_t)> &launch, gu_engine::PaceRecord *rec,
-                             const GuPaceCached *hint = nullptr)
+static int gu_search_pace(gu_engine *h, int slot, int64_t T, const std::function<void(uint32_t)> &launch, GuPaceSearch *rec)
 {
     const auto t_start = std::chrono::steady_clock::now();
     const size_t n4 = (size_t)h->N * 4, bits = (((size_t)h->N + 63) / 64) * 8;
@@ -487,41 +466,7 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
     for (hipEvent_t &ev : h->ev_cal)
         if (!ev) GU_HIP(hipEventCreate(&ev));
     int evaluated = 0, launches = 0;
-    if (hint) {  // six launches: does the period found earlier still beat no limiter on THIS engine's buffer?
-        auto timed = [&](uint32_t period, float *ms) -> int {
-            launch(period);
-            GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
-            launch(period);
-            launch(period);
-            GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
-            GU_HIP(hipEventSynchronize(h->ev_cal[1]));
-            GU_HIP(hipGetLastError());
-            GU_HIP(hipEventElapsedTime(ms, h->ev_cal[0], h->ev_cal[1]));
-            *ms /= 2.0f;
-            launches += 3;
-            return GU_OK;
-        };
-        float without = 0.0f, with = 0.0f;
-        if ((rc = timed(0u, &without)) != GU_OK) return rc;
-        if ((rc = timed(hint->period, &with)) != GU_OK) return rc;
-        if ((rc = restore.run()) != GU_OK) return rc;
-        const bool keep = hint->period == 0u ? true : with <= 0.995f * without;
-        rec->known = keep;
-        rec->from_cache = keep;
-        rec->buffer = h->d_traj;
-        rec->T = T;
-        rec->period = keep ? hint->period : 0u;
-        rec->ms_unpaced = without;
-        rec->ms_paced = keep && hint->period ? with : without;
-        rec->evaluated = 2;
-        rec->launches_spent += launches;
-        rec->calibration_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-        if (gu_debug())
-            fprintf(stderr, "[gu] store pacing: period %u of an earlier engine of this shape %s (%.4f ms without, %.4f with; %d launches)\n", hint->period,
-                    keep ? "kept" : "REJECTED here: a search follows when the launch count warrants it", without, with, launches);
-        return GU_OK;
-    }
-    // The device must be at its working clocks first.  A calibration right after start-up, on a GPU still ramping up from idle,
+    // The device must be at its working clocks first.  A search right after start-up, on a GPU still ramping up from idle,
     // sees a slower kernel and a different cliff (profiles/archive/r03f_pace_warmup.txt).  The ramp is gradual -- successive launches agree
     // within 1 % all along it -- so: unpaced launches until the mean of the last 16 agrees with the mean of the 16 before within
     // 0.4 %, for at least 30 ms when the device has not been running rollouts in the last 50 ms, 150 ms at most.
@@ -614,100 +559,121 @@ static int gu_calibrate_pace(gu_engine *h, int slot, int64_t T, const std::funct
         if (unpaced <= 1.01f * pick_ms) pick = 0, pick_ms = unpaced;
     }
     if ((rc = restore.run()) != GU_OK) return rc;
-    rec->known = true;
-    rec->from_cache = false;
-    rec->buffer = h->d_traj;
-    rec->T = T;
     rec->period = pick;
     rec->ms_unpaced = unpaced;
     rec->ms_paced = pick_ms;
     rec->evaluated = evaluated;
-    rec->launches_spent += launches;
-    rec->calibration_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    rec->launches = launches;
+    rec->ms_spent = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    h->pace_search_ms += rec->ms_spent;
+    h->pace_search_launches += launches;
     if (gu_debug())
-        fprintf(stderr, "[gu] store pacing (%s kernel, policy %d, auto %d, %lld x %lld): %u ticks of 10 ns per 16 steps, %.4f -> %.4f ms per launch, %d candidates in %.1f ms\n",
+        fprintf(stderr, "[gu] store pacing search (%s kernel, policy %d, auto %d, %lld x %lld): %u ticks of 10 ns per 16 steps, %.4f -> %.4f ms per launch, %d candidates in %.1f ms\n",
                 slot >= 24 ? "row-table (packed rows)" : slot >= 12 ? "row-table" : "general", (slot % 12) / 3, slot % 3, (long long)h->N, (long long)T, pick, unpaced, pick_ms, evaluated,
-                rec->calibration_ms);
+                rec->ms_spent);
     return GU_OK;
 }
 
-// The schedule of this launch: option GU_OPT_ROLLOUT_PACE when set (0 = none, n = that many 10 ns ticks per 16 steps), else the
-// calibrated period for this launch kind on this buffer -- calibrated now if it is not known yet.  `slot` = policy * 3 + auto mode
-// (+ 12 for the transition-row kernel's int32 rows, + 24 for its packed rows, `row_bytes` = 12 / 4 per env-step); `launch(period)`
-// enqueues the launch with that period.  Launches that cannot be bound by
-// the HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs), launches of fewer than 64 steps, and
-// batches of more than four waves per SIMD are not paced and not calibrated.
-// (Until r03o a batch of more than one wave per SIMD was also tried as several launches in a row of one wave per SIMD each: the
-// idle-turn limiter had nothing to work with at four waves per SIMD.  The schedule has -- 262 144 envs in ONE launch 0.44 .. 0.48 ms,
-// as four launches in a row 0.56 .. 0.59, profiles/archive/r03o_c4_split.txt -- and that form is gone.)
-// WHEN it is calibrated (round 4).  The search costs a few hundred full-size launches (374 = 52 ms at the headline size) and saves ~10 % of each later one: it pays for itself
-// only after a few thousand launches of that kind.  So, with GU_OPT_ROLLOUT_PACE at its default (-1):
-//   * a period this PROCESS already found for the same launch shape (device, batch, length class, policy, auto-reset, kernel, row bytes,
-//     workgroups) is checked with six launches and kept when it still beats no limiter;
-//   * otherwise the launch kind runs WITHOUT a limiter until the engine has issued GU_PACE_LAZY_LAUNCHES launches of it, and is
-//     searched then;
-//   * gu_rollout_calibrate asks for the search now (a benchmark, a long-running service at start-up); GU_OPT_ROLLOUT_PACE = -2 makes
-//     the first launch of every kind do so (the behaviour of round 3).
-#ifndef GU_PACE_LAZY_LAUNCHES
-#define GU_PACE_LAZY_LAUNCHES 1024
-#endif
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, const std::function<void(uint32_t)> &launch, uint32_t *pace)
+// The schedule of this launch.  `slot` = policy * 3 + auto mode (+ 12 for the transition-row kernel's int32 rows, + 24 for its packed
+// rows, `row_bytes` = 12 / 4 per env-step); `launch(period)` enqueues the launch with that FIXED period (the search above only).
+//   GU_OPT_ROLLOUT_PACE = 0: no limiter.  n > 0: that period, fixed.  -1 (the default): the launches of a kind choose their period
+//   themselves, closed loop, from the first one on (GuPacer / gu_pace_next): no search, no dedicated launch, nothing on the host.
+// Launches that cannot be bound by the HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs), launches of
+// fewer than 64 steps (fewer than four groups to schedule) and batches of more than four waves per SIMD (524 288 envs and more on
+// 256 CUs: a per-wave schedule found nothing to gain there, 0.96 .. 0.98 ms = 6.4 .. 6.6 TB/s with and without, and a batch that does
+// not fit the device at once is not on one schedule anyway; profiles/archive/r03n_batch_sizes.txt) keep no schedule and no record --
+// a fixed period applies to them all the same.  A kind's ring belongs to one launch SHAPE (trajectory buffer, workgroups, length
+// within a factor of two, row bytes): another shape starts it over from the model, the rows of 16 steps at GU_OPT_PACE_TARGET GB/s
+// (7200; the cliff sits at 7.4 .. 7.5 TB/s on the allocations measured in rounds 3 and 4).
+static size_t gu_pace_ring_bytes() { return sizeof(GuPaceEntry) * GU_PACE_RING * 36; }
+static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, GuPaceArgs *pace)
 {
-    *pace = 0;
-    const int64_t opt = gu_opt(h, GU_OPT_ROLLOUT_PACE);
-    if (opt >= 0) {
-        *pace = (uint32_t)opt;
+    const size_t set_bytes = sizeof(GuPaceBucket) * GU_PACE_DEPTH * GU_PACE_BUCKETS;
+    if (!h->d_pace_ring) {
+        GU_HIP(hipMalloc((void **)&h->d_pace_ring, gu_pace_ring_bytes() + set_bytes * 36));
+        GU_HIP(hipMemsetAsync(h->d_pace_ring, 0, gu_pace_ring_bytes() + set_bytes * 36, h->stream));
+    }
+    gu_engine::PaceKind &k = h->pace[slot];
+    GuPaceEntry *ring = h->d_pace_ring + (size_t)slot * GU_PACE_RING;
+    GuPaceBucket *buckets = (GuPaceBucket *)((char *)h->d_pace_ring + gu_pace_ring_bytes() + set_bytes * (size_t)slot);
+    const bool same = k.active && k.buffer == (const void *)h->d_traj && k.blocks == blocks && k.row_bytes == row_bytes && !(T > 2 * k.T || 2 * T < k.T);
+    if (!same) {
+        if (k.seq) {
+            GU_HIP(hipMemsetAsync(ring, 0, sizeof(GuPaceEntry) * GU_PACE_RING, h->stream));
+            GU_HIP(hipMemsetAsync(buckets, 0, set_bytes, h->stream));
+        }
+        k.active = true;
+        k.buffer = h->d_traj;
+        k.blocks = blocks;
+        k.row_bytes = row_bytes;
+        k.T = T;
+        k.seq = 0;
+        const double target = (double)gu_opt(h, GU_OPT_PACE_TARGET) * 1e9;  // bytes per second
+        const double ticks = 16.0 * (double)h->N * (double)row_bytes / target * 1e8;
+        k.model = (uint32_t)std::min<double>(std::max(1.0, ticks + 0.5), 1e6);
+    }
+    pace->ring = ring;
+    pace->buckets = buckets;
+    pace->waves = nullptr;
+    const int64_t waves = (h->N + 63) / 64;
+    if (h->d_pace_waves && waves <= h->pace_waves_cap) pace->waves = h->d_pace_waves, h->pace_waves_last = waves;
+    pace->seq = ++k.seq;
+    pace->period = k.model;
+    pace->lo = std::max<uint32_t>(1u, k.model * 3u / 4u);
+    pace->hi = std::max<uint32_t>(k.model * 2u, k.model + 4u);
+    pace->groups = (uint32_t)std::min<int64_t>(T / 16, 0x7FFFFFFF);
+    pace->bar_num = (uint16_t)gu_opt(h, GU_OPT_PACE_BAR_NUM);
+    pace->inc_q = (uint32_t)gu_opt(h, GU_OPT_PACE_INC_Q);
+    pace->dec_q = (uint32_t)gu_opt(h, GU_OPT_PACE_DEC_Q);
+    pace->fixed = 0;
+    return GU_OK;
+}
+
+static bool gu_pace_eligible(const gu_engine *h, int64_t T, unsigned blocks, int row_bytes)
+{
+    return !((double)h->N * (double)T * (double)row_bytes < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024);
+}
+
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, const std::function<void(uint32_t)> &launch, GuPaceArgs *pace)
+{
+    *pace = GuPaceArgs{};
+    if (h->pace_search_requested) {  // gu_rollout_pace_search: the search first, then this launch without a limiter
+        h->pace_search_requested = false;
+        h->pace_search_found = false;
+        if (!gu_pace_eligible(h, T, blocks, row_bytes)) return GU_OK;
+        GuPaceSearch found;
+        const int rc = gu_search_pace(h, slot, T, launch, &found);
+        if (rc != GU_OK) return rc;
+        h->pace_search_found = true;
+        h->pace_search_period = found.period;
+        h->pace_search_ms_unpaced = found.ms_unpaced;
+        h->pace_search_ms_paced = found.ms_paced;
+        h->pace_search_last_launches = found.launches;
+        h->pace_search_last_ms = found.ms_spent;
         return GU_OK;
     }
-    // (T < 64: fewer than four groups to schedule.  More than four waves per SIMD -- 524 288 envs and more on 256 CUs --: a per-wave
-    // schedule found nothing to gain there, 0.96 .. 0.98 ms = 6.4 .. 6.6 TB/s with and without, and a batch that does not fit the
-    // device at once is not on one schedule anyway; profiles/archive/r03n_batch_sizes.txt)
-    if ((double)h->N * (double)T * (double)row_bytes < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024) return GU_OK;
-    gu_engine::PaceRecord &rec = h->pace[slot];
-    const bool current = rec.known && rec.buffer == (const void *)h->d_traj && rec.blocks == blocks && !(T > 2 * rec.T || 2 * T < rec.T);
-    if (!current) {
-        if (rec.buffer != (const void *)h->d_traj || rec.blocks != blocks || T > 2 * rec.T || 2 * T < rec.T) {  // another launch shape: start over
-            rec.known = false;
-            rec.cache_checked = false;
-            rec.launches_seen = 0;
-            rec.buffer = h->d_traj;
-            rec.blocks = blocks;
-            rec.T = T;
-        }
-        const GuPaceKey key{h->device, slot, row_bytes, h->N, gu_pace_T_class(T), blocks};
-        if (!rec.cache_checked) {
-            rec.cache_checked = true;
-            GuPaceCached cached{};
-            bool have = false;
-            {
-                std::lock_guard<std::mutex> lock(g_pace_mutex);
-                auto it = g_pace_cache.find(key);
-                if (it != g_pace_cache.end()) cached = it->second, have = true;
-            }
-            if (have) {
-                const int rc = gu_calibrate_pace(h, slot, T, launch, &rec, &cached);
-                if (rc != GU_OK) return rc;
-                rec.blocks = blocks;
-            }
-        }
-        if (!rec.known) {
-            const bool now = opt == -2 || h->pace_requested || ++rec.launches_seen > GU_PACE_LAZY_LAUNCHES;
-            if (!now) return GU_OK;  // no limiter yet
-            const int rc = gu_calibrate_pace(h, slot, T, launch, &rec);
-            if (rc != GU_OK) return rc;
-            rec.blocks = blocks;
-            std::lock_guard<std::mutex> lock(g_pace_mutex);
-            g_pace_cache[key] = GuPaceCached{rec.period, rec.ms_unpaced, rec.ms_paced};
-        }
+    const int64_t opt = gu_opt(h, GU_OPT_ROLLOUT_PACE);
+    if (opt == 0) return GU_OK;
+    const bool eligible = gu_pace_eligible(h, T, blocks, row_bytes);
+    if (eligible) {
+        const int rc = gu_pace_ring_for(h, slot, T, blocks, row_bytes, pace);
+        if (rc != GU_OK) return rc;
+        if (opt > 0) pace->period = (uint32_t)opt, pace->fixed = 1;  // fixed, and recorded all the same
+        if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
+        return GU_OK;
     }
-    *pace = rec.period;
-    if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
+    if (opt > 0) pace->period = (uint32_t)opt;
     return GU_OK;
 }
 
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
 {
-    const int traj = (flags & GU_F_PACKED) ? 2 : ((flags & GU_F_TRAJECTORY) ? 1 : 0);
+    // int32 rows: three planes [T][N], or -- GU_OPT_TRAJ_LAYOUT = 1 -- one plane of (obs, reward, done) triples [T][N][3]: the same
+    // words, one 12-byte store per lane and step (gu_rollout.hpp: TRAJ == 3; the readers de-interleave).  Batches of more than 2^24
+    // envs (lane offset + 15 rows must stay below 2^32 bytes) and engines with the agent trail on keep the planes.
+    int traj = (flags & GU_F_PACKED) ? 2 : ((flags & GU_F_TRAJECTORY) ? 1 : 0);
+    if (traj == 1 && gu_opt(h, GU_OPT_TRAJ_LAYOUT) == 1 && h->N <= ((int64_t)1 << 24) && !h->trail_cap) traj = 3;
+    h->traj_written = traj;
     const bool stats = flags & GU_F_STATS;
     const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->all_single_start ? 1 : 2) : 0;
     const int64_t rows = traj ? h->traj_T * h->N : 0;
@@ -747,7 +713,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.stream_lds_off = 0;
     a.stream_lds_words = 0;
     const int bs = gu_rollout_block(h);
-    a.pace = 0;
+    a.pace = GuPaceArgs{};
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)
     if (policy == GU_POLICY_SAMPLE)
         hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
@@ -767,14 +733,15 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
         }
     }
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
-    if (traj == 1) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: GuPacer)
+    if (traj == 1 || traj == 3) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: GuPacer)
         RolloutArgs c = a;
         int rc = gu_pace_for(h, policy * 3 + auto_mode, T, gu_blocks(h->N, bs), 12, [&](uint32_t period) {
-            c.pace = period;
-            gu_rollout_general(h, c, policy, auto_mode, 1, stats, bs);
+            c.pace = GuPaceArgs{};
+            c.pace.period = period;
+            gu_rollout_general(h, c, policy, auto_mode, traj, stats, bs);
         }, &a.pace);
         if (rc != GU_OK) return rc;
-        gu_rollout_general(h, a, policy, auto_mode, 1, stats, bs);
+        gu_rollout_general(h, a, policy, auto_mode, traj, stats, bs);
     } else {
         gu_rollout_general(h, a, policy, auto_mode, traj, stats, bs);
     }
@@ -842,6 +809,24 @@ int gu_probe_trajectory_buffer(gu_engine *h, int32_t *buf, int64_t T, float *ms)
     GU_HIP(hipGetLastError());
     GU_HIP(hipEventElapsedTime(ms, h->ev_begin, h->ev_end));
     *ms /= 3.0f;
+    return GU_OK;
+}
+
+// int32 triples [count][3] (GU_OPT_TRAJ_LAYOUT = 1) -> three planes [3][count], for the readers that hand planes to the host
+__global__ void __launch_bounds__(256) gu_deinterleave_kernel(const int32_t *__restrict__ triples, int32_t *__restrict__ planes, int64_t count)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        planes[i] = triples[3 * i];
+        planes[count + i] = triples[3 * i + 1];
+        planes[2 * count + i] = triples[3 * i + 2];
+    }
+}
+
+int gu_launch_deinterleave(gu_engine *h, const int32_t *triples, int32_t *planes, int64_t count)
+{
+    const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, (int64_t)h->n_cu * 16);
+    hipLaunchKernelGGL(gu_deinterleave_kernel, dim3(blocks), dim3(256), 0, h->stream, triples, planes, count);
+    GU_HIP(hipGetLastError());
     return GU_OK;
 }
 

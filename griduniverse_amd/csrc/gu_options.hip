@@ -21,7 +21,7 @@ struct OptSpec {
 const OptSpec g_spec[GU_OPT_COUNT] = {
     {nullptr, 0, 0, 0},
     {"GU_ROLLOUT_BLOCK", 256, 64, 1024},
-    {"GU_ROLLOUT_ROWS", -1, -1, 2},
+    {"GU_ROLLOUT_ROWS", -1, -1, 3},
     {"GU_ROWS_COPIES", 0, 0, 32},
     {"GU_ROLLOUT_MULTI", -1, -1, 1},
     {"GU_ROLLOUT_MULTI_K", 0, 0, 4},
@@ -39,6 +39,11 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_TRAJ_PROBE_ALL", 0, 0, 1},
     {"GU_ROLLOUT_PACE", -1, -2, 0xFFFFF},
     {"GU_VI_XCD_BLOCK", 0, 0, 1024},
+    {"GU_PACE_TARGET", 7200, 100, 100000},
+    {"GU_PACE_BAR_NUM", 20, 1, 256},
+    {"GU_PACE_INC_Q", 128, 1, 64 * 64},
+    {"GU_PACE_DEC_Q", 2, 0, 64},
+    {"GU_TRAJ_LAYOUT", 0, 0, 1},
 };
 const char *g_spec_x[GU_OPT_X_COUNT] = {"GU_TRAJ_UNCACHED", "GU_TRAJ_POISON", "GU_MC_POISON"};
 
@@ -127,8 +132,9 @@ int gu_set_option(gu_handle h, int32_t option, int64_t value)
     }
     if (h) {
         h->opt[option] = value;
-        // a launch-shape option may change which kernel a launch kind runs on: what the store pacing learned is looked at again
-        for (gu_engine::PaceRecord &r : h->pace) r.known = false, r.cache_checked = false, r.launches_seen = 0, r.buffer = nullptr;
+        // a launch-shape option may change which kernel a launch kind runs on: the store pacing of every kind starts over
+        if (option != GU_OPT_ROLLOUT_PACE)
+            for (gu_engine::PaceKind &k : h->pace) k.active = false;
     } else {
         g_default[option].store(value, std::memory_order_relaxed);
     }

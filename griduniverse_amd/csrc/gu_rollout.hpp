@@ -21,6 +21,164 @@ __device__ __forceinline__ uint32_t gu_sample_action(uint32_t word, const uint4 
     return (uint32_t)(word >= q.x) + (uint32_t)(word >= q.y) + (uint32_t)(word >= q.z) - q.w;
 }
 
+
+// The rate limiter of the trajectory store stream (int32 rows; packed rows on the transition-row kernel): every wave keeps a SCHEDULE.  `pace` = ticks of the constant 100 MHz clock
+// (s_memrealtime, 10 ns) per 16 steps; a wave may begin its next group of steps no earlier than its own start + steps done x
+// pace / 16, and does not wait at all when it is late.
+//
+// WHY (round 3; tools/micro/store_pacing.hip, write_ceiling.hip, store_deadline.hip, tools/pace_ab.py, profiles/archive/r03d_*, r03k_*):
+// the HBM write path of an MI355X shows CONGESTION COLLAPSE.  65 536 lanes that hand their three rows per step to the memory
+// system as fast as it will take them keep every queue on the way full, and the sustained rate then DROPS: to 5.7 TB/s on most
+// allocations (round 2's "slow class"), 6.6 on some.  The same stores offered just below the memory's capacity go through at
+// 7.2 .. 7.5 TB/s on EVERY allocation.  The first limiter (until r03j) idled a fixed number of scalar-loop turns every four
+// steps: it works only while no wave is ever held up -- every wave idles the same amount whether it is ahead or behind, so
+// waves that were blocked stay behind, the rows in flight spread out and the collapse feeds itself; its best setting was the
+// one at which the waves' own pace equalled the memory's (113 .. 116 us per 65 536 x 1000 launch on slow allocations), one turn
+// of 33 clocks less and the launch collapsed.  A schedule has neither problem: late waves catch up, the waves stay within a
+// few rows of each other, and the period has a resolution of 0.6 % (one tick in ~170).  Same kernel, same buffers: 107 .. 110 us
+// (7.2 .. 7.35 TB/s) on slow allocations, 105 .. 107 on fast ones.  One clock read per 16 steps: a read per step costs more than
+// it saves (s_memtime per step: 146 us), per 16 steps it is not measurable.
+//  * 100 MHz, not the shader clock (s_memtime runs at the engine clock, which moves with load and power).
+//  * WHO CHOOSES THE PERIOD (round 5): the launches themselves, closed loop, on the device.  Rounds 3 and 4 searched it with a few
+//    hundred dedicated full-size launches on a snapshot of the engine's state (on request, or after 1024 launches of a kind) and
+//    then held it open loop.  Now every launch kind of an engine owns a ring of launch records and four sets of 32 counters in
+//    device memory (gu_internal.hpp: GuPaceEntry, GuPaceBucket).  A wave that leaves adds ONE word to one of the 32 counters of
+//    its launch's set -- how much of its time it ran behind its schedule, and whether it ENDED more than two periods behind -- and,
+//    only if it did, raises that counter's maximum.  Every wave of the NEXT launch of the kind reads the 32 counters and derives
+//    -- all of them the same way, from the same words, so no wave waits for another -- the period it runs with (gu_pace_next).
+//    No host round trip, no dedicated launch, no snapshot; the first launch of a kind starts from a model (the rows of 16 steps
+//    at 7.2 TB/s).
+// (GuPaceEntry, GuPaceBucket, GuPaceArgs: gu_internal.hpp)
+struct GuPaceSum {
+    uint32_t late_q, waves, ended_late, max_behind;
+};
+__device__ __forceinline__ GuPaceSum gu_pace_sum(const GuPaceBucket *set)
+{
+    uint64_t sum = 0, most = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < GU_PACE_BUCKETS; ++b) {
+        sum += set[b].sum;
+        const uint64_t m = set[b].max_behind;
+        most = m > most ? m : most;
+    }
+    GuPaceSum s;
+    s.late_q = (uint32_t)(sum & 0xFFFFFu);
+    s.waves = (uint32_t)((sum >> 20) & 0xFFFFu);
+    s.ended_late = (uint32_t)((sum >> 36) & 0xFFFFu);
+    s.max_behind = most > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)most;
+    return s;
+}
+
+// The period of launch `seq` (1/64 ticks), from the record of launch `seq - 1` and what its waves reported.  Scalar code, every
+// wave the same.  A launch is BEHIND when one of its waves ended more than bar_num / 256 of the schedule's length behind its own
+// schedule -- the launch took that much longer than asked for: the store stream collapsed, or never kept up.  Then the period
+// goes UP by inc_q; after a launch on schedule it comes DOWN by max(dec_q, 8 / (8 + seq) tick) -- stochastic approximation
+// (Robbins-Monro): the period settles where a launch is behind with probability dec / (inc + dec), quickly at first, the steps
+// shrinking as launches accumulate.  (The first version of the loop moved one whole tick per launch and kept a "period known to
+// fail" with exponential back-off.  It is wrong for this memory: near the cliff a launch collapses SPORADICALLY, a few per
+// cent of the launches even well above it; two unlucky launches in a row doubled the back-off twice and the period drifted up
+// by 8 ticks in 300 launches and stayed there, profiles/r05a_pace_c3.txt.)
+__device__ __forceinline__ uint32_t gu_pace_next(const GuPaceArgs &pa, const GuPaceEntry *prev, const GuPaceSum &rep, uint32_t *verdict)
+{
+    uint32_t p_q = pa.period << 6;
+    *verdict = 0;
+    if (prev->seq + 1u == pa.seq && prev->period_q) {
+        p_q = prev->period_q;
+        if (rep.waves) {
+            const uint64_t schedule = ((uint64_t)(p_q >> 6) * pa.groups);  // ticks
+            const bool behind = (uint64_t)rep.max_behind * 256u > schedule * pa.bar_num;
+            *verdict = behind ? 2u : 1u;
+            if (behind) {
+                p_q += pa.inc_q;
+            } else {
+                const uint32_t early = 512u / (8u + (pa.seq > 100000u ? 100000u : pa.seq));  // 64 x 8 / (8 + seq)
+                const uint32_t dec = early > pa.dec_q ? early : pa.dec_q;
+                p_q = p_q > dec ? p_q - dec : p_q;
+            }
+        }
+    }
+    p_q = p_q < (pa.lo << 6) ? (pa.lo << 6) : p_q;
+    p_q = p_q > (pa.hi << 6) ? (pa.hi << 6) : p_q;
+    return pa.fixed ? (pa.period << 6) : p_q;
+}
+
+struct GuPacer {
+    uint64_t due, t0;
+    uint32_t ticks;
+    uint32_t n_groups, n_late;  // scalar: groups done, groups begun behind schedule
+    GuPaceBucket *mine;         // this wave's counter in the launch's set
+    uint4 *wave_rec;
+    uint32_t start_delay;
+    __device__ __forceinline__ void start(const GuPaceArgs &pa, bool on)
+    {
+        mine = nullptr;
+        wave_rec = nullptr;
+        n_groups = n_late = 0;
+        start_delay = 0;
+        ticks = on ? pa.period : 0u;
+        if (on && pa.ring) {
+            GuPaceEntry *prev = pa.ring + ((pa.seq - 1u) & (GU_PACE_RING - 1u));
+            GuPaceEntry *entry = pa.ring + (pa.seq & (GU_PACE_RING - 1u));
+            const GuPaceSum rep = gu_pace_sum(pa.buckets + ((pa.seq - 1u) & (GU_PACE_DEPTH - 1u)) * GU_PACE_BUCKETS);
+            uint32_t verdict;
+            const uint32_t p_q = gu_pace_next(pa, prev, rep, &verdict);
+            ticks = (p_q + 32u) >> 6;
+            const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+            mine = pa.buckets + (pa.seq & (GU_PACE_DEPTH - 1u)) * GU_PACE_BUCKETS + (wave & (GU_PACE_BUCKETS - 1u));
+            const uint64_t now = __builtin_amdgcn_s_memrealtime();
+            if (blockIdx.x == 0 && threadIdx.x < GU_PACE_BUCKETS) {
+                // the launch's first wave: this launch's record, its verdict on the launch before, and an empty set of counters
+                // for the launch behind it (lane b clears counter b)
+                GuPaceBucket *clear = pa.buckets + ((pa.seq + 1u) & (GU_PACE_DEPTH - 1u)) * GU_PACE_BUCKETS + threadIdx.x;
+                clear->sum = 0, clear->max_behind = 0;
+                if (threadIdx.x == 0) {
+                    entry->period_q = p_q, entry->seq = pa.seq, entry->t_start = now;
+                    entry->verdict = 0, entry->waves = 0, entry->late_q = 0, entry->ended_late = 0, entry->max_behind = 0;
+                    if (verdict) {
+                        prev->verdict = verdict, prev->waves = rep.waves, prev->late_q = rep.late_q, prev->ended_late = rep.ended_late;
+                        prev->max_behind = rep.max_behind;
+                    }
+                }
+            }
+            if (pa.waves) {
+                wave_rec = pa.waves + wave;
+                const uint64_t began = entry->seq == pa.seq ? entry->t_start : now;  // (as far as it is visible yet: a measurement aid)
+                start_delay = (uint32_t)(now - began);
+            }
+            due = t0 = now;
+            return;
+        }
+        due = t0 = ticks ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    }
+    // `steps` steps have just been done (rows stored): wait until their time is up
+    __device__ __forceinline__ void after(uint32_t steps)
+    {
+        if (ticks) {
+            due += (ticks * steps) >> 4;
+            const bool late = (int64_t)(__builtin_amdgcn_s_memrealtime() - due) >= 0;
+            ++n_groups;
+            n_late += late;
+            // (bounded: an `s_sleep 1` takes ~30 ns = 3 ticks, so a wait of one period ends within ticks / 3 turns; a clock that does
+            // not advance must slow the launch down, not hang it)
+            if (!late)
+                for (uint32_t turn = 0; turn < 2u * ticks + 64u && (int64_t)(__builtin_amdgcn_s_memrealtime() - due) < 0; ++turn)
+                    __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    // the wave leaves: its report into the launch's counters (`steps` = steps done since the last after())
+    __device__ __forceinline__ void finish(uint32_t steps)
+    {
+        if (mine && (threadIdx.x & 63u) == 0u) {
+            const int64_t behind = (int64_t)(__builtin_amdgcn_s_memrealtime() - (due + ((ticks * steps) >> 4)));
+            const bool far = behind > (int64_t)(2u * ticks);
+            const uint32_t late_q = n_groups ? (n_late * 64u) / n_groups : 0u;
+            (void)__hip_atomic_fetch_add(&mine->sum, (uint64_t)late_q | (1ull << 20) | ((uint64_t)far << 36), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (far) (void)__hip_atomic_fetch_max(&mine->max_behind, (uint64_t)behind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave_rec) *wave_rec = make_uint4(n_late, n_groups, (uint32_t)(int32_t)(behind > 0x7FFFFFFFll ? 0x7FFFFFFFll : behind), start_delay);
+        }
+    }
+};
+
 struct RolloutArgs {
     const uint8_t *cell;
     const uint8_t *greedy;  // first-argmax action per state (GU_POLICY_GREEDY)
@@ -45,48 +203,7 @@ struct RolloutArgs {
     int32_t stream_lds_off; // GU_POLICY_STREAM, MAP 1: byte offset in LDS of the staged action words [stream_lds_words][blockDim.x] ...
     int32_t stream_lds_words;  // ... and how many words per lane fit (0: every word is read from HBM when its steps are due)
     int32_t xcd_remap;      // workgroup b works on env block (b % 8) * (blocks / 8) + b / 8: one XCD = one contiguous env range
-    uint32_t pace;          // launches that write rows: the waves' schedule (GuPacer), 10 ns ticks per 16 steps -- the rate limiter of the
-                            // store stream; chosen per engine and launch kind by gu_launch_rollout's calibration, 0 = none
-};
-
-// The rate limiter of the trajectory store stream (int32 rows; packed rows on the transition-row kernel): every wave keeps a SCHEDULE.  `pace` = ticks of the constant 100 MHz clock
-// (s_memrealtime, 10 ns) per 16 steps; a wave may begin its next group of steps no earlier than its own start + steps done x
-// pace / 16, and does not wait at all when it is late.
-//
-// WHY (round 3; tools/micro/store_pacing.hip, write_ceiling.hip, store_deadline.hip, tools/pace_ab.py, profiles/archive/r03d_*, r03k_*):
-// the HBM write path of an MI355X shows CONGESTION COLLAPSE.  65 536 lanes that hand their three rows per step to the memory
-// system as fast as it will take them keep every queue on the way full, and the sustained rate then DROPS: to 5.7 TB/s on most
-// allocations (round 2's "slow class"), 6.6 on some.  The same stores offered just below the memory's capacity go through at
-// 7.2 .. 7.5 TB/s on EVERY allocation.  The first limiter (until r03j) idled a fixed number of scalar-loop turns every four
-// steps: it works only while no wave is ever held up -- every wave idles the same amount whether it is ahead or behind, so
-// waves that were blocked stay behind, the rows in flight spread out and the collapse feeds itself; its best setting was the
-// one at which the waves' own pace equalled the memory's (113 .. 116 us per 65 536 x 1000 launch on slow allocations), one turn
-// of 33 clocks less and the launch collapsed.  A schedule has neither problem: late waves catch up, the waves stay within a
-// few rows of each other, and the period has a resolution of 0.6 % (one tick in ~170).  Same kernel, same buffers: 107 .. 110 us
-// (7.2 .. 7.35 TB/s) on slow allocations, 105 .. 107 on fast ones.  One clock read per 16 steps: a read per step costs more than
-// it saves (s_memtime per step: 146 us), per 16 steps it is not measurable.
-//  * the period is CALIBRATED per engine, trajectory buffer and launch kind by timing this very kernel (gu_launch_rollout:
-//    gu_calibrate_pace): launch time follows the schedule down to the memory's capacity, then jumps (the cliff);
-//  * 100 MHz, not the shader clock (s_memtime runs at the engine clock, which moves with load and power).
-struct GuPacer {
-    uint64_t due;
-    uint32_t ticks;
-    __device__ __forceinline__ void start(uint32_t pace)
-    {
-        ticks = pace;
-        due = pace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    }
-    // `steps` steps have just been done (rows stored): wait until their time is up
-    __device__ __forceinline__ void after(uint32_t steps)
-    {
-        if (ticks) {
-            due += (ticks * steps) >> 4;
-            // (bounded: an `s_sleep 1` takes ~30 ns = 3 ticks, so a wait of one period ends within ticks / 3 turns; a clock that does
-            // not advance must slow the launch down, not hang it)
-            for (uint32_t turn = 0; turn < 2u * ticks + 64u && (int64_t)(__builtin_amdgcn_s_memrealtime() - due) < 0; ++turn)
-                __builtin_amdgcn_s_sleep(1);
-        }
-    }
+    GuPaceArgs pace;        // launches that write rows: the waves' schedule (GuPacer), the rate limiter of the store stream
 };
 
 // Workgroups are handed to the 8 XCDs round-robin (workgroup b -> XCD b % 8), so neighbouring env blocks would be
@@ -174,7 +291,9 @@ __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint3
 #define GU_STORE_AUX_PACKED 16
 #endif
 #define GU_MAX_BLOCK 1024
-// TRAJ: 0 = no trajectory; 1 = int32 obs / reward / done rows (12 B per env-step);
+typedef uint32_t gu_v3u __attribute__((ext_vector_type(3)));
+// TRAJ: 0 = no trajectory; 1 = int32 obs / reward / done rows (12 B per env-step), three planes [T][N]; 3 = the same int32 words as
+//       ONE plane of triples [T][N][3] (one 12-byte store per lane and step instead of three 4-byte ones);
 //       2 = ONE packed uint32 row: obs | (reward & 0xFF) << 16 | done << 24 (4 B per env-step, grids up to 65 536 cells)
 template <int POLICY, int AUTO, int TRAJ, bool STATS, int MAP>
 __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutArgs a)
@@ -237,16 +356,23 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     const uint32_t e4 = e * 4u;
     const int64_t row = a.N * 4;
     const uint32_t row32 = (uint32_t)row;  // gu_create caps N at 2^25, so lane offset + 15 rows < 2^31 bytes
+    // the trajectory's own row pitch and lane offset: TRAJ == 3 keeps ONE row of (obs, reward, done) triples per step
+    // (the launcher takes that layout for batches of up to 2^24 envs only: lane offset + 15 rows of 12 N bytes < 2^32)
+    const int64_t trow = TRAJ == 3 ? a.N * 12 : row;
+    const uint32_t trow32 = (uint32_t)trow;
+    const uint32_t te = TRAJ == 3 ? e * 12u : e4;
     __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0xFFFFFFFFu, 0x00020000);
     __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
     __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
     auto rebase = [&](int64_t rows) {
-        po += rows * row;
-        pr += rows * row;
-        pd += rows * row;
+        po += rows * trow;
         ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0xFFFFFFFFu, 0x00020000);
-        rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
-        rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
+        if (TRAJ == 1) {
+            pr += rows * trow;
+            pd += rows * trow;
+            rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
+            rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
+        }
     };
 
     // AUTO == 1 keeps the invariant "d == TERM bit of the REGISTER copy of flags", so the lazy reset needs no
@@ -290,6 +416,9 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             __builtin_amdgcn_raw_buffer_store_b32((int32_t)d, rd, e4, soff, GU_STORE_AUX);
         } else if (TRAJ == 2) {
             __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)s | (((uint32_t)r & 0xFFu) << 16) | (d << 24)), ro, e4, soff, GU_STORE_AUX_PACKED);
+        } else if (TRAJ == 3) {  // one 12-byte store per lane and step: the wave's 768 bytes are contiguous
+            const gu_v3u triple = {(uint32_t)s, (uint32_t)r, d};
+            __builtin_amdgcn_raw_buffer_store_b96(triple, ro, te, soff, GU_STORE_AUX);
         }
     };
     auto step1 = [&](uint32_t act) {  // one step, then advance the resource base by one row
@@ -297,6 +426,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         if (TRAJ) rebase(1);
     };
 
+    GuPacer pacer;
+    pacer.start(a.pace, TRAJ == 1 || TRAJ == 3);
     if (POLICY == GU_POLICY_UNIFORM) {
         // Fast path: every lane of the wave is at the same step count (always true unless
         // gu_set_state installed per-env counters), so the 16-actions-per-word schedule is
@@ -305,14 +436,12 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         if (__all(t_lane == t_first)) {
             uint32_t t = t_first;
             int64_t i = 0;
-            GuPacer pacer;
-            pacer.start(TRAJ == 1 ? a.pace : 0u);
             if (t & 15u) {  // head: finish the current word
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
                 for (; i < a.T && (t & 7u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
                 if ((t & 15u) == 8u && i + 8 <= a.T) {  // the word's second half as one unrolled block (launches of 1000 steps begin here every other time)
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) step(__builtin_amdgcn_ubfe(word, 16 + 2 * j, 2), j * row32);
+                    for (uint32_t j = 0; j < 8; ++j) step(__builtin_amdgcn_ubfe(word, 16 + 2 * j, 2), j * trow32);
                     if (TRAJ) rebase(8);
                     i += 8, t += 8;
                 }
@@ -322,7 +451,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             for (; i + 16 <= a.T; i += 16, t += 16) {  // body: 16 steps per word, fully unrolled
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32);
                 if (TRAJ) rebase(16);
                 if (i + 16 < a.T) pacer.after(16);  // (nothing to wait for behind the last group)
             }
@@ -331,7 +460,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                 uint32_t j = 0;
                 if (i + 8 <= a.T) {  // its first half as one unrolled block
 #pragma unroll
-                    for (uint32_t k = 0; k < 8; ++k) step(__builtin_amdgcn_ubfe(word, 2 * k, 2), k * row32);
+                    for (uint32_t k = 0; k < 8; ++k) step(__builtin_amdgcn_ubfe(word, 2 * k, 2), k * trow32);
                     if (TRAJ) rebase(8);
                     i += 8, j = 8;
                 }
@@ -350,8 +479,6 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         // The uploaded stream arrives packed like the uniform policy's RNG words (16 two-bit actions per env and word,
         // gu_pack_actions_kernel), always from row 0.
         const char *pw = pa;  // the word's row base moves (64-bit), the lane offset stays e4
-        GuPacer pacer;
-        pacer.start(TRAJ == 1 ? a.pace : 0u);
         auto load_word = [&](uint32_t soff) {
             return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void *)pw, 0, 0xFFFFFFFFu, 0x00020000), e4, soff, 0);
         };
@@ -382,7 +509,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                 for (k = 0; k * 16 + 16 <= steps; ++k) {
                     const uint32_t next = k + 1 < cnt ? sw[(k + 1) * bd] : 0u;  // one word ahead of its steps
 #pragma unroll
-                    for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                    for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32);
                     if (TRAJ) rebase(16);
                     pacer.after(16);
                     word = next;
@@ -395,7 +522,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                 pa, row, e4, a.T, 0,
                 [&](uint32_t word) {
 #pragma unroll
-                    for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32);
+                    for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32);
                     if (TRAJ) rebase(16);
                     pacer.after(16);
                 },
@@ -407,8 +534,6 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         // word of the NEXT step is hashed while this step's threshold read is in flight (it does not depend on s).
         uint32_t t = t_lane;
         uint32_t word = POLICY == GU_POLICY_SAMPLE ? gu_rng_sample_word(prefix, t) : 0u;
-        GuPacer pacer;
-        pacer.start(TRAJ == 1 ? a.pace : 0u);
         auto run = [&](auto thr_at) {
             // fresh: 0 = step t + 1 starts no sampling word, 1 = it does (both: t the same in every lane, known at compile time),
             // 2 = ask the lanes (gu_rng.hpp)
@@ -461,8 +586,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                 for (; i + G <= a.T; i += G) {
 #pragma unroll
                     for (uint32_t j = 0; j < G; ++j) {
-                        if ((j & GU_RNG_SAMPLE_MASK) == GU_RNG_SAMPLE_MASK) tstep(j * row32, new_word);
-                        else tstep(j * row32, same_word);
+                        if ((j & GU_RNG_SAMPLE_MASK) == GU_RNG_SAMPLE_MASK) tstep(j * trow32, new_word);
+                        else tstep(j * trow32, same_word);
                     }
                     if (TRAJ) rebase(G);
                     if (i + G < a.T) pacer.after(G);
@@ -470,7 +595,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             } else {
                 for (; i + 8 <= a.T; i += 8) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) tstep(j * row32, ask);
+                    for (int j = 0; j < 8; ++j) tstep(j * trow32, ask);
                     if (TRAJ) rebase(8);
                     if (i + 8 < a.T) pacer.after(8);
                 }
@@ -483,6 +608,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         if (thr_in_lds) run([thr_lds](int32_t at) { return thr_lds[at]; });
         else run([&a](int32_t at) { return a.pi_thr[at]; });
     }
+    pacer.finish(16);
     a.pos[e] = s;
     a.reward[e] = r;
     a.done[e] = (int32_t)d;
@@ -577,6 +703,9 @@ static void gu_rollout_dispatch2(gu_engine *h, const RolloutArgs &a, int traj, b
     } else if (traj == 2) {
         if (stats) gu_rollout_launch<POLICY, AUTO, 2, true>(h, a, bs);
         else gu_rollout_launch<POLICY, AUTO, 2, false>(h, a, bs);
+    } else if (traj == 3) {
+        if (stats) gu_rollout_launch<POLICY, AUTO, 3, true>(h, a, bs);
+        else gu_rollout_launch<POLICY, AUTO, 3, false>(h, a, bs);
     } else {
         if (stats) gu_rollout_launch<POLICY, AUTO, 0, true>(h, a, bs);
         else gu_rollout_launch<POLICY, AUTO, 0, false>(h, a, bs);
@@ -600,7 +729,7 @@ void gu_rollout_greedy(gu_engine *h, const RolloutArgs &a, int auto_mode, int tr
 void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
 // the transition-row kernel (gu_rollout_rows.hip): true when it took the launch (*rc: what its pace calibration returned)
 bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats, int *rc);
-// store pacing (gu_kernels.hip): the schedule of a launch that writes rows (ticks per 16 steps), calibrated on first use
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, const std::function<void(uint32_t)> &launch, uint32_t *pace);
+// store pacing (gu_kernels.hip): the schedule of a launch that writes rows -- the launch kind's ring of records, or a fixed period
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, const std::function<void(uint32_t)> &launch, GuPaceArgs *pace);
 // the K-step kernel (gu_rollout_multi.hip; uniform policy, no trajectory): true when it took the launch
 bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);

@@ -219,17 +219,22 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
     const char *pa = (const char *)a.actions;
     const uint32_t e4 = e * 4u;
     const int64_t row = a.N * 4;
-    const uint32_t row32 = (uint32_t)row;
+    // the trajectory's own row pitch and lane offset (TRAJ == 3: one row of (obs, reward, done) triples per step, gu_rollout.hpp)
+    const int64_t trow = TRAJ == 3 ? a.N * 12 : row;
+    const uint32_t trow32 = (uint32_t)trow;
+    const uint32_t te = TRAJ == 3 ? e * 12u : e4;
     __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0xFFFFFFFFu, 0x00020000);
     __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
     __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
     auto rebase = [&](int64_t rows) {
-        po += rows * row;
-        pr += rows * row;
-        pd += rows * row;
+        po += rows * trow;
         ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0xFFFFFFFFu, 0x00020000);
-        rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
-        rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
+        if (TRAJ == 1) {
+            pr += rows * trow;
+            pd += rows * trow;
+            rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
+            rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
+        }
     };
     // everything a step leaves behind hangs off the record that the step fetched -- none of it is on the chain.  It is
     // emitted one iteration late, i.e. AFTER the next step's LDS read has been issued, so that it fills that read's latency
@@ -245,6 +250,9 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
                 __builtin_amdgcn_raw_buffer_store_b32(cell, ro, e4, soff, GU_STORE_AUX);
                 __builtin_amdgcn_raw_buffer_store_b32(r, rr, e4, soff, GU_STORE_AUX);
                 __builtin_amdgcn_raw_buffer_store_b32((int32_t)dn, rd, e4, soff, GU_STORE_AUX);
+            } else if (TRAJ == 3) {
+                const gu_v3u triple = {(uint32_t)cell, (uint32_t)r, dn};
+                __builtin_amdgcn_raw_buffer_store_b96(triple, ro, te, soff, GU_STORE_AUX);
             } else {
                 __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)cell | (((uint32_t)r & 0xFFu) << 16) | (dn << 24)), ro, e4, soff, GU_STORE_AUX_PACKED);
             }
@@ -302,7 +310,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
     };
     auto nothing = [] {};
     GuPacer pacer;
-    pacer.start(TRAJ ? a.pace : 0u);
+    pacer.start(a.pace, TRAJ != 0);
     auto step1 = [&](uint32_t x) {
         step(x, 0, nothing);
         if (TRAJ) rebase(1);
@@ -327,15 +335,15 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
                 if (q == 0) {
                     emit(rec, 0);
                 } else {
-                    emit(r1[q - 1], (2 * q - 1) * row32);
-                    emit(r2[q - 1], (2 * q) * row32);
+                    emit(r1[q - 1], (2 * q - 1) * trow32);
+                    emit(r2[q - 1], (2 * q) * trow32);
                 }
             }
-            emit(r1[7], 15 * row32);
+            emit(r1[7], 15 * trow32);
             rec = r2[7];
         } else {
 #pragma unroll
-            for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * row32, nothing);
+            for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32, nothing);
         }
     };
 
@@ -405,7 +413,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
 #pragma unroll
                 for (uint32_t j = 0; j < G; ++j) {
                     uint32_t next_word = 0u;
-                    step(word, j * row32, [&] {
+                    step(word, j * trow32, [&] {
                         next_word = (j & GU_RNG_SAMPLE_MASK) == GU_RNG_SAMPLE_MASK ? gu_rng_sample_advance_at<true>(prefix, t, word) : gu_rng_sample_advance_at<false>(prefix, t, word);
                     });
                     word = next_word;
@@ -417,7 +425,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         } else {
             for (; i + 8 <= a.T; i += 8) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) pstep(j * row32);
+                for (uint32_t j = 0; j < 8; ++j) pstep(j * trow32);
                 if (TRAJ) rebase(8);
                 if (i + 8 < a.T) pacer.after(8);
             }
@@ -438,6 +446,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             step1);
     }
     emit(rec, 0);  // the last step's record (row T - 1: every loop above leaves the row base one step behind)
+    pacer.finish(16);
     // resets performed = steps that started from a done env = (done at entry: counted in first_step) + done flags seen
     // on every step but the last
     const uint32_t d_last = __builtin_amdgcn_ubfe(rec, GU_ROW_DONE_BIT, 1);
@@ -502,6 +511,8 @@ static void rows_dispatch(const gu_engine *h, const RolloutArgs &a, int traj, bo
         if (stats) GU_ROWS_LAUNCH(1, true); else GU_ROWS_LAUNCH(1, false);
     } else if (traj == 2) {
         if (stats) GU_ROWS_LAUNCH(2, true); else GU_ROWS_LAUNCH(2, false);
+    } else if (traj == 3) {
+        if (stats) GU_ROWS_LAUNCH(3, true); else GU_ROWS_LAUNCH(3, false);
     } else {
         if (stats) GU_ROWS_LAUNCH(0, true); else GU_ROWS_LAUNCH(0, false);
     }
@@ -527,7 +538,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     //                          is bound by its ~45 vector instructions, half of them the MurmurHash3 of its RNG word, not by
     //                          the LDS round trips the row table saves
     if (mode == 0) return false;
-    if (mode != 1 && mode != 2) {
+    if (mode != 1 && mode != 2 && mode != 3) {
         const unsigned blocks = gu_blocks(h->N, 256);
         // (a caller-supplied stream with int32 rows: the row-table kernel reads its action words straight from HBM, and a load
         // among streaming stores waits for all of them -- beyond 16 384 envs the general kernel, which stages the words in LDS,
@@ -542,7 +553,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         // from HBM among the streaming stores --; with sc1 + nt stores it is the quicker one up to 32 768 like the uniform policy:
         // 60 .. 61 against 66 .. 71 us)
         const unsigned int32_limit = (policy == GU_POLICY_SAMPLE || (policy == GU_POLICY_GREEDY && auto_mode == 1)) ? cus : cus / 2;
-        if ((traj == 1 && blocks > int32_limit) || (traj == 2 && blocks > cus)) return false;
+        if (((traj == 1 || traj == 3) && blocks > int32_limit) || (traj == 2 && blocks > cus)) return false;
         if (policy == GU_POLICY_SAMPLE && auto_mode != 1 && traj == 0) return false;
     }
     const bool table_policy = policy == GU_POLICY_GREEDY || policy == GU_POLICY_SAMPLE;
@@ -587,7 +598,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     // 256-byte buffer_store_dword: 107 clocks per step with three of them, 143 per packed pair with two, 210 per int32 pair with six
     // (slopes over T = 2000 .. 4000); without rows the K-step kernel of gu_rollout_multi.hip is the tool), one 256-lane workgroup per CU at most (144 bytes
     // of LDS per cell).  GU_OPT_ROLLOUT_ROWS = 2 keeps the one-step table (A/B, tests).  profiles/archive/r03r_pair_rows.txt
-    bool pair = !table_policy && traj == 2 && mode != 2 && gu_blocks(h->N, 256) <= (unsigned)h->n_cu && (int64_t)h->S * 144 <= h->lds_per_cu - 2048 &&
+    bool pair = !table_policy && (traj == 2 || (traj == 3 && mode == 3)) && mode != 2 && gu_blocks(h->N, 256) <= (unsigned)h->n_cu && (int64_t)h->S * 144 <= h->lds_per_cu - 2048 &&
                 ((int64_t)h->S << GU_PAIR_SHIFT) <= (int64_t)GU_ROW_ADDR_MASK;
     if (pair) {
         if (!h->d_rows2[which]) {
@@ -628,10 +639,11 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         default: rows_dispatch<GU_POLICY_SAMPLE>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
         }
     };
-    if (traj) {  // rows to write: the store stream is rate-limited here too (gu_rollout.hpp: GuPacer; calibrated on first use)
+    if (traj) {  // rows to write: the store stream is rate-limited here too (gu_rollout.hpp: GuPacer)
         RolloutArgs c = a;
-        *rc = gu_pace_for(h, (traj == 1 ? 12 : 24) + policy * 3 + auto_mode, a.T, grid.x, traj == 1 ? 12 : 4, [&](uint32_t period) {
-            c.pace = period;
+        *rc = gu_pace_for(h, (traj != 2 ? 12 : 24) + policy * 3 + auto_mode, a.T, grid.x, traj != 2 ? 12 : 4, [&](uint32_t period) {
+            c.pace = GuPaceArgs{};
+            c.pace.period = period;
             launch(c);
         }, &a.pace);
         if (*rc != GU_OK) return true;

@@ -222,25 +222,24 @@ class Engine(object):
         check(self.lib.gu_rollout(self._h, int(T), _POLICIES[policy], flags))
 
     def calibrate_rollout(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
-        """rollout(...) with the store-pacing search for this launch kind made NOW if the kind is paced and has no period yet
-        (include/gu.h: gu_rollout_calibrate).  By default the search waits until an engine has issued 1024 launches of a kind --
-        it costs a few hundred launches (~50 ms at the headline size) and saves ~10 % of each later one; a benchmark or a long-running service calls this once."""
+        """= rollout(...).  Rounds 3 and 4 searched the store-pacing period here; the launches choose it themselves now
+        (include/gu.h: gu_rollout_calibrate), so nothing is left to ask for."""
         flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_STATS if stats else 0)
         flags |= _lib.F_PACKED if trajectory == 'packed' else (_lib.F_TRAJECTORY if trajectory else 0)
         check(self.lib.gu_rollout_calibrate(self._h, int(T), _POLICIES[policy], flags))
 
     def rollout_pacing_totals(self):
-        """Over all launch kinds of this engine: dict(calibration_ms, launches_spent, kinds_paced, kinds_from_cache, kinds_waiting)."""
+        """Over all launch kinds of this engine: dict(calibration_ms, launches_spent, kinds_paced, kinds_from_cache, kinds_waiting) --
+        ms and launches are what rollout_pace_search spent (0 unless a tool asked for one)."""
         ms = ctypes.c_float(0.0)
         n = [ctypes.c_int32(0) for _ in range(4)]
         check(self.lib.gu_rollout_pacing_totals(self._h, ctypes.byref(ms), *[ctypes.byref(x) for x in n]))
         return dict(calibration_ms=ms.value, launches_spent=n[0].value, kinds_paced=n[1].value, kinds_from_cache=n[2].value, kinds_waiting=n[3].value)
 
     def rollout_pacing(self, policy='uniform', auto_reset=True, packed=False):
-        """What the store-pacing calibration found for this launch kind on the current trajectory buffer (include/gu.h:
-        gu_rollout_pacing): dict(period=the waves' schedule in 10 ns ticks per 16 steps (0: no limiter), ms_unpaced, ms_paced, evaluated,
-        calibration_ms), or None when the
-        kind has not been calibrated (not launched yet, or too small to be paced)."""
+        """The schedule of this launch kind on the current trajectory buffer (include/gu.h: gu_rollout_pacing): dict(period = 10 ns
+        ticks per 16 steps of its last launch, ms_paced = that launch on the device's clock, evaluated = launches of the kind so
+        far; ms_unpaced and calibration_ms are 0), or None when the kind keeps no schedule (not launched yet, or too small)."""
         period, n = ctypes.c_int32(0), ctypes.c_int32(0)
         a, b, c = ctypes.c_float(0.0), ctypes.c_float(0.0), ctypes.c_float(0.0)
         rc = self.lib.gu_rollout_pacing(self._h, _POLICIES[policy], (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_PACKED if packed else 0), ctypes.byref(period),
@@ -249,6 +248,48 @@ class Engine(object):
             return None
         check(rc)
         return dict(period=period.value, ms_unpaced=a.value, ms_paced=b.value, evaluated=n.value, calibration_ms=c.value)
+
+    def rollout_pace_log(self, policy='uniform', auto_reset=True, packed=False):
+        """The records of the last (at most 62) launches of this kind, oldest first, as a dict of int64 arrays: seq, period (ticks,
+        float), verdict (of the launch behind it: 0 none yet, 1 on schedule, 2 behind), waves, late_share (mean over the waves),
+        ended_late (waves), max_behind (ticks), interval (ticks to the next launch's start; 0 for the last); plus 'launches' (of
+        the kind on the current shape).  None when the kind keeps no schedule."""
+        buf = np.zeros((62, 8), dtype=np.uint64)
+        n, launches = ctypes.c_int32(0), ctypes.c_uint32(0)
+        rc = self.lib.gu_rollout_pace_log(self._h, _POLICIES[policy], (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_PACKED if packed else 0), 62,
+                                          buf.ctypes.data, ctypes.byref(n), ctypes.byref(launches))
+        if rc == -4:
+            return None
+        check(rc)
+        e = buf[:n.value].astype(np.int64)
+        return dict(seq=e[:, 0], period=e[:, 1] / 64.0, verdict=e[:, 2], waves=e[:, 3], late_share=e[:, 4] / 64.0 / np.maximum(1, e[:, 3]),
+                    ended_late=e[:, 5], max_behind=e[:, 6], interval=e[:, 7], launches=launches.value)
+
+    def rollout_pace_waves(self):
+        """MEASUREMENT AID: per wave of the last paced launch, int64[waves, 4]: groups begun behind schedule, groups, ticks behind
+        schedule at the end, ticks from the launch's start to the wave's.  The first call switches the recording on (empty)."""
+        cap = (self.N + 63) // 64
+        buf = np.zeros((cap, 4), dtype=np.uint32)
+        n = ctypes.c_int32(0)
+        check(self.lib.gu_rollout_pace_waves(self._h, cap, buf.ctypes.data, ctypes.byref(n)))
+        out = buf[:n.value].astype(np.int64)
+        out[:, 2] = buf[:n.value, 2].view(np.int32)
+        return out
+
+    def rollout_pace_search(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
+        """MEASUREMENT AID (include/gu.h: gu_rollout_pace_search): the open-loop period search of rounds 3 and 4 on a snapshot of the
+        engine's state, then the rollout itself without a limiter.  dict(period, ms_unpaced, ms_paced, launches, ms_spent), or None
+        for a launch that keeps no schedule (the rollout has still run)."""
+        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_STATS if stats else 0)
+        flags |= _lib.F_PACKED if trajectory == 'packed' else (_lib.F_TRAJECTORY if trajectory else 0)
+        period, n = ctypes.c_int32(0), ctypes.c_int32(0)
+        a, b, c = ctypes.c_float(0.0), ctypes.c_float(0.0), ctypes.c_float(0.0)
+        rc = self.lib.gu_rollout_pace_search(self._h, int(T), _POLICIES[policy], flags, ctypes.byref(period), ctypes.byref(a), ctypes.byref(b), ctypes.byref(n),
+                                             ctypes.byref(c))
+        if rc == -4:
+            return None
+        check(rc)
+        return dict(period=period.value, ms_unpaced=a.value, ms_paced=b.value, launches=n.value, ms_spent=c.value)
 
     def read_trajectory(self, t0, T, pinned=False):
         """Rows t0..t0+T-1 of the trajectory as obs/reward/done int32[T, N].  pinned=True returns views of

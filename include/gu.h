@@ -108,10 +108,18 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_TRAJ_STRIDE_MIB 15     /* spacer size (3072)                                                                   */
 #define GU_OPT_TRAJ_FAR_MIB 16        /* most memory the search may hold at once (49152)                                      */
 #define GU_OPT_TRAJ_PROBE_ALL 17      /* 1 = probe every candidate, no early stop (measurement aid)                           */
-#define GU_OPT_ROLLOUT_PACE 18        /* store pacing of launches that write rows: 10 ns ticks per 16 steps; -1 = calibrate when it pays
-                                         (default, see gu_rollout_pacing), -2 = at the first launch, 0 = none */
+#define GU_OPT_ROLLOUT_PACE 18        /* store pacing of launches that write rows: -1 = closed loop (default, see gu_rollout_pacing),
+                                         0 = none, n = fixed period of n 10 ns ticks per 16 steps (-2: accepted, same as -1) */
 #define GU_OPT_VI_XCD_BLOCK 19        /* workgroup size of the per-XCD form of gu_vi_sweep_step_run: 256, 512, 1024 (0 = by batch size) */
-#define GU_OPT_COUNT 20
+#define GU_OPT_PACE_TARGET 20         /* closed-loop store pacing: GB/s of rows the first launch of a kind is scheduled for (7200)  */
+#define GU_OPT_PACE_BAR_NUM 21        /* ... a launch was BEHIND when a wave ended more than this many 256ths of the schedule late (20) */
+#define GU_OPT_PACE_INC_Q 22          /* ... 1/64 ticks: the period's step up after a launch that was behind (128); this option + 1: its
+                                         smallest step down after a launch on schedule (GU_OPT_PACE_DEC_Q, 2)                    */
+#define GU_OPT_PACE_DEC_Q 23
+#define GU_OPT_TRAJ_LAYOUT 24         /* device layout of the int32 trajectory: 0 = three planes [T][N], 1 = one plane of (obs, reward,
+                                         done) triples [T][N][3] written with one 12-byte store per lane and step; what
+                                         gu_read_trajectory, gu_mc_evaluate and the host see does not change                   */
+#define GU_OPT_COUNT 25
 #define GU_OPT_X_TRAJ_UNCACHED 100    /* EXPERIMENT: uncached memory type for the trajectory (readers may see stale bytes)    */
 #define GU_OPT_X_TRAJ_POISON 101      /* EXPERIMENT: fill a fresh trajectory buffer with 0x5A                                 */
 #define GU_OPT_X_MC_POISON 102        /* EXPERIMENT: fill the Monte-Carlo scratch with 0x5A before every evaluation           */
@@ -246,28 +254,39 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 /* Store pacing.  The HBM write path shows congestion collapse: lanes that hand their rows to the memory system as fast as it will
  * take them are served at 5.7 TB/s on most allocations, the same stores offered just below the memory's capacity at 7.2 .. 7.5 on
  * every one.  Launches with GU_F_TRAJECTORY (and GU_F_PACKED launches on the transition-row kernel) of 128 MB of rows
- * and 64 steps and more (up to four waves per SIMD) can keep a SCHEDULE: a wave begins its next 16 steps no earlier than `period` ticks of the 100 MHz clock (10 ns) after the last ones were due, and never
- * waits when it is late.  The period is found by timing the kernel itself on the engine's own state (snapshot before, put back
- * after -- on every exit path: results never depend on it), a few hundred full-size launches (warm-up ramp, two scans).  That pays for itself after a few thousand
- * launches, so with GU_OPT_ROLLOUT_PACE at its default (-1) a launch kind (policy, auto-reset, kernel, row bytes) runs WITHOUT a
- * limiter until
- *   - this PROCESS has already searched the same launch shape on the same device (another engine, or this one before its buffer
- *     changed): that period is CHECKED with six launches and kept when it still beats no limiter; or
- *   - the engine has issued 1024 launches of that kind: the search runs then (that one gu_rollout is synchronous and a few hundred
- *     launches longer); or
- *   - gu_rollout_calibrate is called: gu_rollout with the search made NOW when the kind has no period yet (what a benchmark or a
- *     long-running service does once at start-up).
- * GU_OPT_ROLLOUT_PACE = -2 searches at the first launch of every kind (round 3's behaviour), 0 = never a limiter, n = that period.
- * gu_rollout_pacing reports what was found for a launch kind: the period, ms per launch without and with the limiter, candidates
- * timed, ms spent calibrating (GU_ERR_STATE when that kind has no period: not launched yet, still waiting, or not a launch that is
- * paced; `flags` with GU_F_PACKED asks for the packed-row launches' record).  gu_rollout_pacing_totals: over ALL launch kinds of the
- * engine -- ms and full-size launches spent calibrating (searches and checks), kinds with a period, how many of those periods
- * came from the process-wide cache, kinds still running without a limiter and counting. */
+ * and 64 steps and more (up to four waves per SIMD) keep a SCHEDULE: a wave begins its next 16 steps no earlier than `period` ticks
+ * of the 100 MHz clock (10 ns) after the last ones were due, and never waits when it is late.  THE LAUNCHES CHOOSE THE PERIOD
+ * THEMSELVES, closed loop, on the device (round 5): every wave counts the groups it began behind its schedule, the next launch of
+ * the kind (policy, auto-reset, kernel, row bytes) reads the sum and moves the period -- one tick down while the launch before it
+ * was on schedule, back up when it was not, and a period that failed is tried again only after 2, 4 .. 1024 launches on schedule.
+ * The first launch of a kind starts from a model (its rows at GU_OPT_PACE_TARGET GB/s).  There is no search, no dedicated launch,
+ * no snapshot, nothing on the host: an engine that is simply used gets the paced rate from its first launches on, and a
+ * neighbour on the device or a change of clocks moves the period instead of collapsing the stream for good.  Results never depend
+ * on any of it.  GU_OPT_ROLLOUT_PACE = 0: no limiter; n > 0: that period, fixed.
+ * gu_rollout_calibrate is gu_rollout (rounds 3 and 4 searched the period there; kept for callers that call it).
+ * gu_rollout_pacing reports a launch kind's current period, the length of its schedule (ms_paced; ms_unpaced and
+ * calibration_ms are 0), and how many launches of the kind have run on the current shape (`evaluated`); GU_ERR_STATE when the kind
+ * keeps no schedule.  gu_rollout_pacing_totals: kinds with a schedule; ms and launches are what gu_rollout_pace_search
+ * (include/gu_diag.h) spent, i.e. 0 unless a tool asked for a search. */
 int gu_rollout_calibrate(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 int gu_rollout_pacing_totals(gu_handle h, float *calibration_ms, int32_t *launches_spent, int32_t *kinds_paced, int32_t *kinds_from_cache,
                              int32_t *kinds_waiting);
 int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
                       int32_t *evaluated, float *calibration_ms);
+/* The records of the last launches of a kind, oldest first (at most 62; waits for the stream): per launch eight 64-bit words --
+ * launch number, period in 1/64 ticks, verdict of the launch behind it (0 none yet, 1 on schedule, 2 behind), waves that reported,
+ * their late shares summed (64ths), waves that ended more than two periods behind, the most a wave ended behind (ticks), and the
+ * ticks from this launch's start to the next one's (0 for the last).  *launches = launches of the kind on the current shape. */
+int gu_rollout_pace_log(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t capacity, uint64_t *entries, int32_t *count, uint32_t *launches);
+/* MEASUREMENT AID: one record per wave of the last paced launch -- four uint32: groups begun behind schedule, groups, ticks behind
+ * schedule at the end (int32), ticks from the launch's first wave to this wave's start.  The first call only switches the
+ * recording on (count 0). */
+int gu_rollout_pace_waves(gu_handle h, int32_t capacity, uint32_t *records, int32_t *count);
+/* MEASUREMENT AID: the open-loop search of rounds 3 and 4 (a few hundred full-size launches on a snapshot of the engine's state,
+ * which is put back), followed by the rollout itself without a limiter.  Reports the period it would have installed; installs
+ * nothing.  tests/test_gpu_store_pacing.py and tools/pace_loop.py hold the closed loop against it. */
+int gu_rollout_pace_search(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
+                           int32_t *launches, float *ms_spent);
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);
 int gu_read_trajectory_packed(gu_handle h, int64_t t0, int64_t T, uint32_t *packed);   /* [T][N] after GU_F_PACKED */
 int gu_read_stats(gu_handle h, int64_t *reward_sum, int32_t *episodes);

@@ -842,7 +842,7 @@ def capture_big_digest():
     """BASELINE config 3 at FULL size straight from the reference: 65 536 envs x 1000 steps of its step() on the
     32x32 generator maze (seed 123) = 65.5 M reference steps (~2.5 min), kept as sha256 digests."""
     path = os.path.join(OUT, 'digests.json')
-    store = json.load(open(path))
+    store = json.load(open(path)) if os.path.exists(path) else {}
     env = seeded_maze_env(32, 32, 123)
     save_digest(store, 'c3_maze32_65536x1000', env, 123, 65536, 1000, True)
     json.dump(store, open(path, 'w'), indent=1)
@@ -857,7 +857,7 @@ def capture_stream_digests():
     reference itself and kept as sha256 digests: what the STREAM policy (gu_upload_actions + gu_rollout) must reproduce.
     The stream seed is part of the fixture; T = 1000 is not a multiple of the 16-action word of the device's packed form."""
     path = os.path.join(OUT, 'digests.json')
-    store = json.load(open(path))
+    store = json.load(open(path)) if os.path.exists(path) else {}
 
     def one(name, env, seed, stream_seed, N, T, auto_reset):
         env_ids = list(range(N))
@@ -875,45 +875,122 @@ def capture_stream_digests():
     json.dump(store, open(path, 'w'), indent=1)
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
+def reseed():
+    """Both global RNG streams back to a fixed point: every capture starts from here, so that a capture run alone writes the
+    same fixture as a full run (round 4: capture_trail drew a multi-start level's start cell from whatever the captures before
+    it had left of the stdlib stream)."""
     random.seed(0)
     np.random.seed(0)
-    what = {a.split('=')[0] for a in sys.argv[1:]} or {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'mcnp', 'driver', 'bfs', 'arrows', 'trail'}  # plus 'big' (slow) on request
+
+
+def same_npz(a, b):
+    """Two .npz files hold the same arrays: names, dtypes, shapes and raw bytes."""
+    with np.load(a, allow_pickle=False) as x, np.load(b, allow_pickle=False) as y:
+        if sorted(x.files) != sorted(y.files):
+            return 'array names differ: %s / %s' % (sorted(x.files), sorted(y.files))
+        for k in x.files:
+            u, v = x[k], y[k]
+            if u.dtype != v.dtype or u.shape != v.shape or u.tobytes() != v.tobytes():
+                return 'array %r differs' % k
+    return None
+
+
+def check(made, committed):
+    """Compare everything under `made` (a fresh regeneration) with the committed fixtures by CONTENT: .json by equality of the
+    parsed data, .npz array by array, byte-wise.  digests.json is compared entry by entry -- a regeneration without `big` does not
+    hold the two full-size digests.  Returns the list of differences."""
+    bad = []
+    for name in sorted(os.listdir(made)):
+        new, old = os.path.join(made, name), os.path.join(committed, name)
+        if not os.path.exists(old):
+            bad.append('%s: not among the committed fixtures' % name)
+        elif name.endswith('.json'):
+            x, y = json.load(open(new)), json.load(open(old))
+            if name == 'digests.json':
+                bad += ['digests.json[%s] differs' % k for k in x if x[k] != y.get(k)]
+            elif x != y:
+                keys = [k for k in x if isinstance(x, dict) and isinstance(y, dict) and x[k] != y.get(k)]
+                bad.append('%s differs%s' % (name, ' in ' + ', '.join(map(str, keys[:8])) if keys else ''))
+        elif name.endswith('.npz'):
+            why = same_npz(new, old)
+            if why:
+                bad.append('%s: %s' % (name, why))
+    return bad
+
+
+def main():
+    """make_golden.py [what ...]          regenerate those fixtures in place (default: all but `big` and `stream`)
+    make_golden.py --check [what ...]  regenerate into a temporary directory and compare with the committed fixtures by content
+                                       (default: all but `big`; exit code 1 and a list when anything differs)"""
+    global OUT
+    argv = [a for a in sys.argv[1:] if a != '--check']
+    checking = len(argv) != len(sys.argv) - 1
+    sys.argv[1:] = argv  # (capture_dp reads its dp=<name> filters from there)
+    if checking:
+        import tempfile
+        OUT = tempfile.mkdtemp(prefix='gu_golden_check_')
+    os.makedirs(OUT, exist_ok=True)
+    everything = {'kat', 'err', 'render', 'maze', 'dp', 'traj', 'mc', 'mcnp', 'driver', 'bfs', 'arrows', 'trail'}  # plus 'big' (slow) and 'stream' on request
+    what = {a.split('=')[0] for a in argv} or (everything | {'stream'} if checking else everything)
     if 'kat' in what:
+        reseed()
         json.dump(capture_kats(), open(os.path.join(OUT, 'kat.json'), 'w'), indent=1)
     if 'err' in what:
+        reseed()
         json.dump(capture_errors(), open(os.path.join(OUT, 'errors.json'), 'w'), indent=1)
     if 'render' in what:
+        reseed()
         json.dump(capture_render_and_quirks(), open(os.path.join(OUT, 'render_quirks.json'), 'w'), indent=1)
     if 'maze' in what:
+        reseed()
         mazes, levels = capture_mazes_and_levels()
         json.dump(mazes, open(os.path.join(OUT, 'mazes.json'), 'w'), indent=1)
         json.dump(levels, open(os.path.join(OUT, 'levels.json'), 'w'), indent=1)
     if 'dp' in what:
+        reseed()
         capture_dp()
     if 'mc' in what:
+        reseed()
         capture_mc()
     if 'mcnp' in what:
+        reseed()
         capture_mc_numpy_rng()
     if 'driver' in what:
+        reseed()
         capture_driver()
     if 'bfs' in what:
+        reseed()
         json.dump(capture_bfs(), open(os.path.join(OUT, 'bfs.json'), 'w'), indent=1)
     if 'arrows' in what:
+        reseed()
         json.dump(capture_arrows(), open(os.path.join(OUT, 'arrows.json'), 'w'))
     if 'trail' in what:
+        reseed()
         json.dump(capture_trail(), open(os.path.join(OUT, 'trail.json'), 'w'))
     if 'big' in what:
+        reseed()
         capture_big_digest()
     if 'stream' in what:
+        reseed()
         capture_stream_digests()
     if 'traj' in what:
+        reseed()
         path = os.path.join(OUT, 'digests.json')
         store = json.load(open(path)) if os.path.exists(path) else {}
         store.update(capture_trajectories())  # keeps the separately captured full-size digest ('big')
         json.dump(store, open(path, 'w'), indent=1)
     assert not any('__pycache__' in d for d, _, _ in os.walk(REF)), 'bytecode was written into the reference'
+    if checking:
+        import shutil
+        bad = check(OUT, HERE)
+        n = len(os.listdir(OUT))
+        shutil.rmtree(OUT, ignore_errors=True)
+        if bad:
+            print('make_golden --check: %d of %d regenerated fixtures DIFFER from the committed ones:' % (len(bad), n))
+            for b in bad:
+                print('  ' + b)
+            sys.exit(1)
+        print('make_golden --check: %d fixtures regenerated from the reference, all identical to the committed ones' % n)
 
 
 if __name__ == '__main__':

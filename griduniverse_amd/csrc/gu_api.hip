@@ -166,7 +166,7 @@ int gu_destroy(gu_handle h)
     gu_placement_release(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     void *bufs[] = {h->d_kind, h->d_rows[0], h->d_rows[1], h->d_rows2[0], h->d_rows2[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
-                    h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy, h->d_pace_ring, h->d_pace_waves};
+                    h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy, h->d_pace_ring, h->d_pace_waves, h->d_pace_slots};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -963,8 +963,9 @@ int gu_rollout_pace_log(gu_handle h, int32_t policy_kind, uint32_t flags, int32_
     GuPaceEntry ring[GU_PACE_RING];
     GU_HIP(hipStreamSynchronize(h->stream));
     GU_HIP(hipMemcpy(ring, h->d_pace_ring + (size_t)slot * GU_PACE_RING, sizeof(ring), hipMemcpyDeviceToHost));
-    // oldest first: launches seq - n + 1 .. seq of the kind (a launch is judged by the NEXT one: the last entry has no verdict yet)
-    const uint32_t have = std::min<uint32_t>(k.seq, GU_PACE_RING - 2u);
+    // oldest first: launches seq - n + 1 .. seq of the kind (a launch's reports are summed by the NEXT one: the last entry has no
+    // verdict yet; the slot one ahead of the last launch holds the period of the launch to come)
+    const uint32_t have = std::min<uint32_t>(k.seq, GU_PACE_RING - 3u);
     const uint32_t n = std::min<uint32_t>(have, capacity > 0 ? (uint32_t)capacity : 0u);
     for (uint32_t i = 0; i < n && entries; ++i) {
         const uint32_t seq = k.seq - n + 1u + i;
@@ -1129,7 +1130,7 @@ int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uin
         for (auto &x : t) x -= h->steps_taken;  // stored as an offset to the lock-step counter
         GU_HIP(hipMemcpy(h->d_tcount, t.data(), n * 4, hipMemcpyHostToDevice));
     }
-    return GU_OK;
+    return gu_trail_after_set_state(h, pos != nullptr, done != nullptr);
 }
 
 int gu_done_indices(gu_handle h, int32_t *idx, int32_t *count)

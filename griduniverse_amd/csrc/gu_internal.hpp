@@ -36,43 +36,41 @@
 #define GU_STREAM_PAD_WORDS 4  // spare rows behind the packed action stream: the rollout kernels read up to four words ahead
 
 // ---- closed-loop store pacing (gu_rollout.hpp: GuPacer, gu_pace_next) -----------------
-struct GuPaceEntry {   // the log record of one launch of one kind; 64 bytes
-    // written by ONE wave of the launch itself (plain stores)
-    uint32_t period_q;    // the period this launch ran with, in 1/64 ticks (the schedule uses the rounded tick count)
-    uint32_t seq;         // the kind's launch number (an entry with another number is not the previous launch's: ignored)
-    uint64_t t_start;     // 100 MHz clock when the launch's first workgroup began
-    // what the NEXT launch of the kind made of it (summed from the launch's buckets by that launch's first wave)
-    uint32_t verdict;     // 0 not judged yet, 1 on schedule, 2 behind (some wave ended further behind its schedule than the bar)
+struct GuPaceEntry {   // one launch of one kind: the period it runs with, and -- afterwards -- what became of it; 64 bytes
+    uint32_t period_q;    // the period of launch `seq`, in 1/64 ticks (the schedule uses the rounded tick count): written by the
+    uint32_t seq;         // first wave of launch seq - 1 (gu_rollout.hpp: GuPacer::decide); an entry with another number is stale
+    uint64_t t_start;     // 100 MHz clock when the launch's first workgroup began (written by that launch)
+    // the log: what the waves of the launch reported, summed by the first wave of launch seq + 1
+    uint32_t verdict;     // 0 not summed yet, 1 on schedule, 2 behind (the log's bar: GuPaceArgs::bar_num)
     uint32_t waves;       // waves that reported
     uint32_t late_q;      // sum over the waves of 64 x (groups begun behind schedule / groups)
-    uint32_t ended_late;  // waves that ended more than two periods behind their schedule
-    uint32_t max_behind;  // ticks: the most any wave ended behind its schedule (0 when none ended more than two periods behind)
+    uint32_t ended_late;  // waves that were more than two periods behind their schedule when they reported
+    uint32_t max_behind;  // ticks: the most any of them was behind (0 when none was more than two periods behind)
     uint32_t reserved[7];
 };
-// What the waves of a launch leave behind for the next launch of the kind: ONE agent-scope atomic per wave (and a second one from a
-// wave that ended far behind), spread over GU_PACE_BUCKETS cache lines.  (All 1024 waves on one line: the atomics of a launch are
-// executed one after the other at ~11 ns each -- the first version of the closed loop added 34 us to every 105 us launch that way,
-// profiles/r05a_pace_c3.txt.)
-struct GuPaceBucket {  // one 128-byte line
-    uint64_t sum;         // bits 0..19: late_q summed, 20..35: waves, 36..51: waves that ended more than two periods behind
-    uint64_t max_behind;  // ticks
-    uint64_t pad[14];
-};
-#define GU_PACE_RING 64u     /* log entries per launch kind: the last 62 launches can be read back (gu_rollout_pace_log) */
-#define GU_PACE_BUCKETS 32u  /* lines a launch's waves spread their reports over */
-#define GU_PACE_DEPTH 4u     /* bucket sets per kind: launch k adds to set k & 3, launch k + 1 reads it and clears set (k + 2) & 3 */
+// What a wave leaves behind for the loop: ONE 8-byte plain store into its own slot of its launch's set (two sets per kind, by launch
+// parity), a few groups before the end of the launch.  bit 63: reported; bit 62: more than two periods behind; bits 32 .. 38:
+// 64 x share of its groups begun behind schedule; bits 0 .. 30: ticks behind (0 when ahead).
+// (NOT atomics.  Round 5's first version had every wave add its counts to one word of its launch's record: the 3072 agent-scope
+// atomics of a launch were executed one after the other at ~11 ns each and added 34 us to every 105 us launch.  Spread over 32
+// neighbouring cache lines they still cost 6 .. 9 us per launch -- the lines share a memory channel, and that is where device-scope
+// atomics are executed; profiles/r05a_pace_c3.txt, r05c_pace_c3.txt "held ... WITHOUT records".)
+#define GU_PACE_RING 64u  /* entries per launch kind: the last 61 launches can be read back (gu_rollout_pace_log) */
 struct GuPaceArgs {
     GuPaceEntry *ring;      // nullptr: `period` as it is (0 = no limiter), nothing recorded
-    GuPaceBucket *buckets;  // [GU_PACE_DEPTH][GU_PACE_BUCKETS]
+    uint64_t *slots;        // [2][slot_stride]: the waves' reports of this launch (set seq & 1) and of the launch before it
     uint4 *waves;           // measurement aid, usually nullptr: one record per wave of the launch {groups begun late, groups, ticks
-                            // behind schedule at the end (two's complement), ticks from the launch's start to the wave's}
+                            // behind schedule when it reported (two's complement), ticks from the launch's start to the wave's}
     uint32_t seq;           // this launch's number within its kind (the host counts)
     uint32_t period;        // ring == nullptr or `fixed`: the period in ticks; else the period of a kind's first launch (the model)
-    uint32_t lo, hi;        // the controller keeps the period within [lo, hi] ticks
+    uint32_t lo, hi;        // the loop keeps the period within [lo, hi] ticks
     uint32_t groups;        // 16-step groups of this launch (T / 16): the length of its schedule in periods
-    uint16_t bar_num;       // of 256: a launch was BEHIND when a wave ended more than bar_num / 256 of the schedule behind it
+    uint32_t report_at;     // the waves report once they have done this many steps (a few groups before the end: gu_rollout.hpp, GuPacer::report)
+    uint32_t n_waves, slot_stride;  // waves of this launch; slots per set
+    uint16_t bar_num;       // of 256: the log calls a launch BEHIND when a wave was more than bar_num / 256 of the schedule behind it
     uint16_t fixed;         // 1: run with `period` and only record (measurement aid: tools/pace_loop.py)
-    uint32_t inc_q, dec_q;  // 1/64 ticks: the period's step up after a launch that was behind; the floor of its step down after one on schedule
+    uint32_t gain_q;        // 1/64 ticks: what the period goes up by after a launch in which EVERY wave fell behind (a share of the waves: that share of it)
+    uint32_t dec_q;         // 1/64 ticks: what it comes down by, every launch
 };
 
 struct gu_engine {
@@ -150,7 +148,9 @@ struct gu_engine {
         uint32_t seq = 0;              // launches of the kind recorded in the ring so far
         uint32_t model = 0;            // the period its first launch started from
     } pace[36];
-    GuPaceEntry *d_pace_ring = nullptr;  // [36][GU_PACE_RING] followed by the kinds' bucket sets [36][GU_PACE_DEPTH][GU_PACE_BUCKETS]
+    GuPaceEntry *d_pace_ring = nullptr;  // [36][GU_PACE_RING]
+    uint64_t *d_pace_slots = nullptr;    // [36][2][pace_slot_stride] the waves' reports (allocated with the ring)
+    int64_t pace_slot_stride = 0;
     uint4 *d_pace_waves = nullptr;       // per-wave records of the last paced launch (allocated by the first gu_rollout_pace_waves call)
     int64_t pace_waves_cap = 0, pace_waves_last = 0;  // records the buffer holds / waves of the last launch that wrote into it
     hipEvent_t ev_cal[2] = {nullptr, nullptr};
@@ -209,6 +209,7 @@ struct gu_engine {
     bool greedy_valid = false;
     int32_t vi_xcd_members[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // workgroups that registered per XCC in the last per-XCD launch of gu_vi_sweep_step_run
     int vi_run_form = 0;            // which form the last gu_vi_sweep_step_run took: 1 per XCD, 2 chip-wide cluster, 3 one launch per round
+    int vi_dp_form = 0;             // ... and the last gu_vi_sweep / gu_vi_run / gu_vi_eval_run: 1 per XCD, 2 one workgroup, 3 chip-wide cluster, 4 one launch per round
 
     // agent trail (gu_trail.hip): off unless gu_trail_enable was called
     int32_t trail_cap = 0;             // entries per env (0: off)
@@ -338,6 +339,7 @@ int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_thre
 int gu_trail_after_step(gu_engine *h, uint32_t flags);
 int gu_trail_before_reset(gu_engine *h, const uint8_t *d_mask, bool only_done);
 int gu_trail_after_rollout(gu_engine *h, int64_t T, int traj, bool auto_reset);
+int gu_trail_after_set_state(gu_engine *h, bool moved, bool done_given);
 void gu_trail_free(gu_engine *h);
 
 // ---- grids (gu_api.hip / gu_maze.hip) ----------------------------------------------

@@ -585,22 +585,26 @@ static int gu_search_pace(gu_engine *h, int slot, int64_t T, const std::function
 // a fixed period applies to them all the same.  A kind's ring belongs to one launch SHAPE (trajectory buffer, workgroups, length
 // within a factor of two, row bytes): another shape starts it over from the model, the rows of 16 steps at GU_OPT_PACE_TARGET GB/s
 // (7200; the cliff sits at 7.4 .. 7.5 TB/s on the allocations measured in rounds 3 and 4).
-static size_t gu_pace_ring_bytes() { return sizeof(GuPaceEntry) * GU_PACE_RING * 36; }
 static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, GuPaceArgs *pace)
 {
-    const size_t set_bytes = sizeof(GuPaceBucket) * GU_PACE_DEPTH * GU_PACE_BUCKETS;
+    const int64_t waves = (h->N + 63) / 64;
     if (!h->d_pace_ring) {
-        GU_HIP(hipMalloc((void **)&h->d_pace_ring, gu_pace_ring_bytes() + set_bytes * 36));
-        GU_HIP(hipMemsetAsync(h->d_pace_ring, 0, gu_pace_ring_bytes() + set_bytes * 36, h->stream));
+        const size_t ring_bytes = sizeof(GuPaceEntry) * GU_PACE_RING * 36;
+        h->pace_slot_stride = (waves + 63) & ~(int64_t)63;
+        const size_t slot_bytes = sizeof(uint64_t) * 2 * (size_t)h->pace_slot_stride * 36;
+        GU_HIP(hipMalloc((void **)&h->d_pace_ring, ring_bytes));
+        GU_HIP(hipMalloc((void **)&h->d_pace_slots, slot_bytes));
+        GU_HIP(hipMemsetAsync(h->d_pace_ring, 0, ring_bytes, h->stream));
+        GU_HIP(hipMemsetAsync(h->d_pace_slots, 0, slot_bytes, h->stream));
     }
     gu_engine::PaceKind &k = h->pace[slot];
     GuPaceEntry *ring = h->d_pace_ring + (size_t)slot * GU_PACE_RING;
-    GuPaceBucket *buckets = (GuPaceBucket *)((char *)h->d_pace_ring + gu_pace_ring_bytes() + set_bytes * (size_t)slot);
+    uint64_t *slots = h->d_pace_slots + (size_t)slot * 2 * (size_t)h->pace_slot_stride;
     const bool same = k.active && k.buffer == (const void *)h->d_traj && k.blocks == blocks && k.row_bytes == row_bytes && !(T > 2 * k.T || 2 * T < k.T);
     if (!same) {
         if (k.seq) {
             GU_HIP(hipMemsetAsync(ring, 0, sizeof(GuPaceEntry) * GU_PACE_RING, h->stream));
-            GU_HIP(hipMemsetAsync(buckets, 0, set_bytes, h->stream));
+            GU_HIP(hipMemsetAsync(slots, 0, sizeof(uint64_t) * 2 * (size_t)h->pace_slot_stride, h->stream));
         }
         k.active = true;
         k.buffer = h->d_traj;
@@ -613,17 +617,19 @@ static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, 
         k.model = (uint32_t)std::min<double>(std::max(1.0, ticks + 0.5), 1e6);
     }
     pace->ring = ring;
-    pace->buckets = buckets;
+    pace->slots = slots;
     pace->waves = nullptr;
-    const int64_t waves = (h->N + 63) / 64;
     if (h->d_pace_waves && waves <= h->pace_waves_cap) pace->waves = h->d_pace_waves, h->pace_waves_last = waves;
     pace->seq = ++k.seq;
     pace->period = k.model;
     pace->lo = std::max<uint32_t>(1u, k.model * 3u / 4u);
     pace->hi = std::max<uint32_t>(k.model * 2u, k.model + 4u);
     pace->groups = (uint32_t)std::min<int64_t>(T / 16, 0x7FFFFFFF);
+    pace->report_at = (uint32_t)std::min<int64_t>(T > 160 ? T - 96 : std::max<int64_t>(T - 32, 1), 0x7FFFFFFF);
+    pace->n_waves = (uint32_t)waves;
+    pace->slot_stride = (uint32_t)h->pace_slot_stride;
     pace->bar_num = (uint16_t)gu_opt(h, GU_OPT_PACE_BAR_NUM);
-    pace->inc_q = (uint32_t)gu_opt(h, GU_OPT_PACE_INC_Q);
+    pace->gain_q = (uint32_t)gu_opt(h, GU_OPT_PACE_GAIN_Q);
     pace->dec_q = (uint32_t)gu_opt(h, GU_OPT_PACE_DEC_Q);
     pace->fixed = 0;
     return GU_OK;
@@ -655,7 +661,7 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_byte
     const int64_t opt = gu_opt(h, GU_OPT_ROLLOUT_PACE);
     if (opt == 0) return GU_OK;
     const bool eligible = gu_pace_eligible(h, T, blocks, row_bytes);
-    if (eligible) {
+    if (eligible && !(opt > 0 && gu_opt(h, GU_OPT_PACE_RECORD) == 0)) {
         const int rc = gu_pace_ring_for(h, slot, T, blocks, row_bytes, pace);
         if (rc != GU_OK) return rc;
         if (opt > 0) pace->period = (uint32_t)opt, pace->fixed = 1;  // fixed, and recorded all the same
@@ -668,11 +674,22 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_byte
 
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
 {
-    // int32 rows: three planes [T][N], or -- GU_OPT_TRAJ_LAYOUT = 1 -- one plane of (obs, reward, done) triples [T][N][3]: the same
-    // words, one 12-byte store per lane and step (gu_rollout.hpp: TRAJ == 3; the readers de-interleave).  Batches of more than 2^24
-    // envs (lane offset + 15 rows must stay below 2^32 bytes) and engines with the agent trail on keep the planes.
+    // int32 rows: three planes [T][N], or one plane of (obs, reward, done) triples [T][N][3] -- the same words, one 12-byte store
+    // per lane and step (gu_rollout.hpp: TRAJ == 3; the readers take them apart again: gu_read_trajectory, gu_mc_evaluate).
+    // GU_OPT_TRAJ_LAYOUT: 0 = planes, 1 = triples wherever possible, -1 (default) = triples where they are faster.  Measured
+    // (profiles/r05b_layout_ab.txt, r05c_layout_sizes.txt, five variants interleaved in one process): a launch bound by the HBM write path is
+    // SLOWER with triples -- 65 536 envs: 117 against 112 us, a config-4 shard of 32 768: 68 against 63 -- and so is every table
+    // policy; a launch of a few waves, bound by the ISSUE of its stores (~25 clocks per 256-byte store of a wave that has its SIMD
+    // alone), gains little from the triple alone (config 2, 4096 envs: 49.4 against 49.9 us) but 25 % together with the pair tables
+    // (two steps per LDS round trip, two stores per pair instead of six: 37.3 us), up to 8192 envs = one workgroup per eight
+    // CUs; at 16 384 the two are level, beyond it the planes win.  So: triples for the uniform policy on the transition-row
+    // kernel with pair tables, up to n_cu / 8 workgroups of 256.  Batches of more than 2^24 envs (lane offset + 15 rows must stay
+    // below 2^32 bytes) and engines with the agent trail on always keep the planes.
     int traj = (flags & GU_F_PACKED) ? 2 : ((flags & GU_F_TRAJECTORY) ? 1 : 0);
-    if (traj == 1 && gu_opt(h, GU_OPT_TRAJ_LAYOUT) == 1 && h->N <= ((int64_t)1 << 24) && !h->trail_cap) traj = 3;
+    if (traj == 1 && h->N <= ((int64_t)1 << 24) && !h->trail_cap) {
+        const int64_t layout = gu_opt(h, GU_OPT_TRAJ_LAYOUT);
+        if (layout == 1 || (layout == -1 && policy == GU_POLICY_UNIFORM && gu_rows_pairs_fit(h) && (int64_t)gu_blocks(h->N, 256) * 8 <= h->n_cu)) traj = 3;
+    }
     h->traj_written = traj;
     const bool stats = flags & GU_F_STATS;
     const int auto_mode = (flags & GU_F_AUTO_RESET) ? (h->all_single_start ? 1 : 2) : 0;

@@ -41,123 +41,181 @@ __device__ __forceinline__ uint32_t gu_sample_action(uint32_t word, const uint4 
 //  * 100 MHz, not the shader clock (s_memtime runs at the engine clock, which moves with load and power).
 //  * WHO CHOOSES THE PERIOD (round 5): the launches themselves, closed loop, on the device.  Rounds 3 and 4 searched it with a few
 //    hundred dedicated full-size launches on a snapshot of the engine's state (on request, or after 1024 launches of a kind) and
-//    then held it open loop.  Now every launch kind of an engine owns a ring of launch records and four sets of 32 counters in
-//    device memory (gu_internal.hpp: GuPaceEntry, GuPaceBucket).  A wave that leaves adds ONE word to one of the 32 counters of
-//    its launch's set -- how much of its time it ran behind its schedule, and whether it ENDED more than two periods behind -- and,
-//    only if it did, raises that counter's maximum.  Every wave of the NEXT launch of the kind reads the 32 counters and derives
-//    -- all of them the same way, from the same words, so no wave waits for another -- the period it runs with (gu_pace_next).
-//    No host round trip, no dedicated launch, no snapshot; the first launch of a kind starts from a model (the rows of 16 steps
-//    at 7.2 TB/s).
-// (GuPaceEntry, GuPaceBucket, GuPaceArgs: gu_internal.hpp)
+//    then held it open loop.  Now every launch kind of an engine owns a ring of launch records and two sets of per-wave slots in
+//    device memory (gu_internal.hpp: GuPaceEntry).  A few groups before its end every wave stores ONE word into its own slot: was
+//    it more than two periods behind its schedule, and by how much.  The FIRST WAVE of the next launch of the kind -- in the time
+//    it would otherwise sleep away behind its first group -- sums the slots and writes the period of the launch after it into
+//    that launch's record (GuPacer::decide); every wave of a launch reads its launch's record when it starts.  No host round
+//    trip, no dedicated launch, no snapshot, no atomics, nobody waits for anybody; what a launch does is felt two launches later.
+//    The first launch of a kind starts from a model (the rows of 16 steps at 7.2 TB/s).
+//  * THE RULE.  Per launch:   period += gain x (share of the waves more than two periods behind)  -  dec     (1/64 ticks)
+//    -- stochastic approximation (Robbins-Monro): the period settles where the MEAN share of waves behind is dec / gain (the
+//    defaults: 16 / 256 = 6 %).  Why the share of waves: near the cliff of this memory launches fall behind sporadically -- a
+//    few per cent of them even 10 ticks above it, a workgroup or two each time, 4 .. 8 us late (0.5 % of the waves on average) --
+//    while below it most waves of every launch do; the mean share rises from 0.5 % to 3 % to > 50 % within ten ticks, so 6 % is
+//    reached within a tick or two of the period at which the mean launch time is shortest, on every allocation, and five times the
+//    background keeps the loop from creeping up on a noisy device (profiles/r05c_pace_c3.txt).  The first launches come down
+//    faster: dec is at least 8 / (8 + seq) tick.
+// (History, all in profiles/r05*_pace_*.txt.  Version 1 moved one whole tick per launch and kept a "period known to fail" with
+// exponential back-off: two unlucky launches in a row doubled the back-off twice, and the period drifted up by 8 ticks in 300
+// launches and stayed there.  Version 2 stepped up by two ticks per launch behind and down by 1/32 tick: 4 ticks = 2.3 % above
+// the best fixed period, because a launch behind costs 8 us here, not the 35 us that ratio was chosen for.  Version 3 stepped up
+// in proportion to the slowest wave's distance behind: the background events alone held it 6 ticks above the best period.)
 struct GuPaceSum {
     uint32_t late_q, waves, ended_late, max_behind;
 };
-__device__ __forceinline__ GuPaceSum gu_pace_sum(const GuPaceBucket *set)
-{
-    uint64_t sum = 0, most = 0;
-#pragma unroll
-    for (uint32_t b = 0; b < GU_PACE_BUCKETS; ++b) {
-        sum += set[b].sum;
-        const uint64_t m = set[b].max_behind;
-        most = m > most ? m : most;
-    }
-    GuPaceSum s;
-    s.late_q = (uint32_t)(sum & 0xFFFFFu);
-    s.waves = (uint32_t)((sum >> 20) & 0xFFFFu);
-    s.ended_late = (uint32_t)((sum >> 36) & 0xFFFFu);
-    s.max_behind = most > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)most;
-    return s;
-}
-
-// The period of launch `seq` (1/64 ticks), from the record of launch `seq - 1` and what its waves reported.  Scalar code, every
-// wave the same.  A launch is BEHIND when one of its waves ended more than bar_num / 256 of the schedule's length behind its own
-// schedule -- the launch took that much longer than asked for: the store stream collapsed, or never kept up.  Then the period
-// goes UP by inc_q; after a launch on schedule it comes DOWN by max(dec_q, 8 / (8 + seq) tick) -- stochastic approximation
-// (Robbins-Monro): the period settles where a launch is behind with probability dec / (inc + dec), quickly at first, the steps
-// shrinking as launches accumulate.  (The first version of the loop moved one whole tick per launch and kept a "period known to
-// fail" with exponential back-off.  It is wrong for this memory: near the cliff a launch collapses SPORADICALLY, a few per
-// cent of the launches even well above it; two unlucky launches in a row doubled the back-off twice and the period drifted up
-// by 8 ticks in 300 launches and stayed there, profiles/r05a_pace_c3.txt.)
-__device__ __forceinline__ uint32_t gu_pace_next(const GuPaceArgs &pa, const GuPaceEntry *prev, const GuPaceSum &rep, uint32_t *verdict)
-{
-    uint32_t p_q = pa.period << 6;
-    *verdict = 0;
-    if (prev->seq + 1u == pa.seq && prev->period_q) {
-        p_q = prev->period_q;
-        if (rep.waves) {
-            const uint64_t schedule = ((uint64_t)(p_q >> 6) * pa.groups);  // ticks
-            const bool behind = (uint64_t)rep.max_behind * 256u > schedule * pa.bar_num;
-            *verdict = behind ? 2u : 1u;
-            if (behind) {
-                p_q += pa.inc_q;
-            } else {
-                const uint32_t early = 512u / (8u + (pa.seq > 100000u ? 100000u : pa.seq));  // 64 x 8 / (8 + seq)
-                const uint32_t dec = early > pa.dec_q ? early : pa.dec_q;
-                p_q = p_q > dec ? p_q - dec : p_q;
-            }
-        }
-    }
-    p_q = p_q < (pa.lo << 6) ? (pa.lo << 6) : p_q;
-    p_q = p_q > (pa.hi << 6) ? (pa.hi << 6) : p_q;
-    return pa.fixed ? (pa.period << 6) : p_q;
-}
 
 struct GuPacer {
-    uint64_t due, t0;
+    uint64_t due;
     uint32_t ticks;
     uint32_t n_groups, n_late;  // scalar: groups done, groups begun behind schedule
-    GuPaceBucket *mine;         // this wave's counter in the launch's set
+    uint32_t report_at;         // the wave reports behind the group that completes this many steps (0: it has, or there is nothing to report to)
+    uint32_t n_steps;
+    uint32_t p_q;
+    uint32_t deciding;          // 1: this is the launch's first wave and it has not summed the launch before yet
+    uint64_t *slot;             // this wave's slot in the launch's set
+#ifdef GU_PACE_WAVE_RECORDS  // (a variant build for tools/pace_loop.py --waves: `make variant VARIANT=_waves EXTRA=-DGU_PACE_WAVE_RECORDS`)
     uint4 *wave_rec;
     uint32_t start_delay;
+#endif
+    // at the very top of the kernel: ask for this launch's record, so that the answer is there when start() wants it
+    __device__ __forceinline__ void fetch(const GuPaceArgs &pa, bool on)
+    {
+        ticks = on ? pa.period : 0u;
+        p_q = pa.period << 6;
+        if (on && pa.ring) {
+            const GuPaceEntry *entry = pa.ring + (pa.seq & (GU_PACE_RING - 1u));
+            const uint32_t have = entry->seq == pa.seq ? entry->period_q : 0u;  // (two scalar loads)
+            if (have && !pa.fixed) p_q = have;
+            p_q = p_q < (pa.lo << 6) ? (pa.lo << 6) : p_q;
+            p_q = p_q > (pa.hi << 6) ? (pa.hi << 6) : p_q;
+            if (pa.fixed) p_q = pa.period << 6;
+            ticks = (p_q + 32u) >> 6;
+        }
+    }
     __device__ __forceinline__ void start(const GuPaceArgs &pa, bool on)
     {
-        mine = nullptr;
+        slot = nullptr;
+        n_groups = n_late = n_steps = 0;
+        report_at = 0;
+        deciding = 0;
+#ifdef GU_PACE_WAVE_RECORDS
         wave_rec = nullptr;
-        n_groups = n_late = 0;
         start_delay = 0;
-        ticks = on ? pa.period : 0u;
+#endif
         if (on && pa.ring) {
-            GuPaceEntry *prev = pa.ring + ((pa.seq - 1u) & (GU_PACE_RING - 1u));
             GuPaceEntry *entry = pa.ring + (pa.seq & (GU_PACE_RING - 1u));
-            const GuPaceSum rep = gu_pace_sum(pa.buckets + ((pa.seq - 1u) & (GU_PACE_DEPTH - 1u)) * GU_PACE_BUCKETS);
-            uint32_t verdict;
-            const uint32_t p_q = gu_pace_next(pa, prev, rep, &verdict);
-            ticks = (p_q + 32u) >> 6;
-            const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-            mine = pa.buckets + (pa.seq & (GU_PACE_DEPTH - 1u)) * GU_PACE_BUCKETS + (wave & (GU_PACE_BUCKETS - 1u));
+            const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+            slot = pa.slots + (size_t)(pa.seq & 1u) * pa.slot_stride + wave;
+            report_at = pa.report_at;
             const uint64_t now = __builtin_amdgcn_s_memrealtime();
-            if (blockIdx.x == 0 && threadIdx.x < GU_PACE_BUCKETS) {
-                // the launch's first wave: this launch's record, its verdict on the launch before, and an empty set of counters
-                // for the launch behind it (lane b clears counter b)
-                GuPaceBucket *clear = pa.buckets + ((pa.seq + 1u) & (GU_PACE_DEPTH - 1u)) * GU_PACE_BUCKETS + threadIdx.x;
-                clear->sum = 0, clear->max_behind = 0;
-                if (threadIdx.x == 0) {
-                    entry->period_q = p_q, entry->seq = pa.seq, entry->t_start = now;
-                    entry->verdict = 0, entry->waves = 0, entry->late_q = 0, entry->ended_late = 0, entry->max_behind = 0;
-                    if (verdict) {
-                        prev->verdict = verdict, prev->waves = rep.waves, prev->late_q = rep.late_q, prev->ended_late = rep.ended_late;
-                        prev->max_behind = rep.max_behind;
-                    }
-                }
+            // (wave-uniform, and the compiler must know it: a flag derived from threadIdx would live in a vector register and turn
+            // every test of it into a divergent branch of the main loop)
+            deciding = (blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) < 64u) ? 1u : 0u;
+            if (deciding && threadIdx.x == 0) {  // this launch's record (the period is there already unless this is the kind's first launch)
+                entry->period_q = p_q, entry->seq = pa.seq, entry->t_start = now;
+                entry->verdict = 0, entry->waves = 0, entry->late_q = 0, entry->ended_late = 0, entry->max_behind = 0;
             }
+#ifdef GU_PACE_WAVE_RECORDS
             if (pa.waves) {
                 wave_rec = pa.waves + wave;
                 const uint64_t began = entry->seq == pa.seq ? entry->t_start : now;  // (as far as it is visible yet: a measurement aid)
                 start_delay = (uint32_t)(now - began);
             }
-            due = t0 = now;
+#endif
+            due = now;
             return;
         }
-        due = t0 = ticks ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        due = ticks ? __builtin_amdgcn_s_memrealtime() : 0ull;
     }
-    // `steps` steps have just been done (rows stored): wait until their time is up
-    __device__ __forceinline__ void after(uint32_t steps)
+    // The launch's first wave, once, in the time it would otherwise sleep: what the waves of the launch BEFORE this one reported
+    // (set (seq - 1) & 1), summed over the wave's lanes; that launch's log; the period of the launch BEHIND this one.  The set is
+    // cleared as it is read: the launch behind this one reports into it.
+    __device__ __forceinline__ void decide(const GuPaceArgs &pa)
+    {
+        deciding = 0;
+        uint64_t *set = pa.slots + (size_t)((pa.seq - 1u) & 1u) * pa.slot_stride;
+        uint32_t waves = 0, far = 0, late_q = 0, most = 0;
+        // sixteen slots per lane and round trip, all asked for before the first is looked at (a loop that waits for each load in
+        // turn keeps this wave 10 .. 30 us behind its schedule, and the launch ends when its last wave does: the first cut of this
+        // function added 8 us to every launch, profiles/r05d_pace_c3.txt)
+        for (uint32_t base = 0; base < pa.n_waves; base += 64u * 16u) {
+            uint64_t w[16];
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; ++j) {
+                const uint32_t i = base + j * 64u + threadIdx.x;
+                w[j] = i < pa.n_waves ? __builtin_nontemporal_load(set + i) : 0ull;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; ++j) {
+                const uint32_t i = base + j * 64u + threadIdx.x;
+                if (i < pa.n_waves) set[i] = 0;
+                waves += (uint32_t)(w[j] >> 63);
+                far += (uint32_t)(w[j] >> 62) & 1u;
+                late_q += (uint32_t)(w[j] >> 32) & 0x7Fu;
+                const uint32_t behind = (uint32_t)w[j] & 0x7FFFFFFFu;
+                most = behind > most ? behind : most;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            waves += __shfl_xor(waves, m);
+            far += __shfl_xor(far, m);
+            late_q += __shfl_xor(late_q, m);
+            const uint32_t o = __shfl_xor(most, m);
+            most = o > most ? o : most;
+        }
+        if (threadIdx.x == 0) {
+            GuPaceEntry *prev = pa.ring + ((pa.seq - 1u) & (GU_PACE_RING - 1u));
+            GuPaceEntry *next = pa.ring + ((pa.seq + 1u) & (GU_PACE_RING - 1u));
+            uint32_t n_q = p_q;
+            if (waves) {
+                const uint64_t schedule = (uint64_t)ticks * pa.groups;
+                if (prev->seq + 1u == pa.seq) {
+                    prev->verdict = (uint64_t)most * 256u > schedule * pa.bar_num ? 2u : 1u;
+                    prev->waves = waves, prev->late_q = late_q, prev->ended_late = far, prev->max_behind = far ? most : 0u;
+                }
+                const uint32_t up = (uint32_t)(((uint64_t)pa.gain_q * far) / waves);
+                const uint32_t early = 512u / (8u + (pa.seq > 100000u ? 100000u : pa.seq));  // 64 x 8 / (8 + seq)
+                const uint32_t dec = early > pa.dec_q ? early : pa.dec_q;
+                n_q += up;
+                n_q = n_q > dec ? n_q - dec : n_q;
+            }
+            n_q = n_q < (pa.lo << 6) ? (pa.lo << 6) : n_q;
+            n_q = n_q > (pa.hi << 6) ? (pa.hi << 6) : n_q;
+            next->period_q = n_q, next->seq = pa.seq + 1u, next->t_start = 0;
+            next->verdict = 0, next->waves = 0, next->late_q = 0, next->ended_late = 0, next->max_behind = 0;
+        }
+    }
+    // The wave's report: ONE plain 8-byte store into its own slot (gu_internal.hpp).  Made `report_at` steps into the launch, i.e.
+    // a few groups BEFORE its end, so that nothing of it is in flight when the kernel wants to complete.
+    __device__ __forceinline__ void report(int64_t behind)
+    {
+        if ((threadIdx.x & 63u) == 0u) {
+            const bool far = behind > (int64_t)(2u * ticks);
+            const uint32_t late_q = n_groups ? (n_late * 64u) / n_groups : 0u;
+            const uint64_t b = behind <= 0 ? 0ull : (behind > 0x7FFFFFFFll ? 0x7FFFFFFFull : (uint64_t)behind);
+            *slot = (1ull << 63) | ((uint64_t)far << 62) | ((uint64_t)late_q << 32) | b;
+#ifdef GU_PACE_WAVE_RECORDS
+            if (wave_rec) *wave_rec = make_uint4(n_late, n_groups, (uint32_t)(int32_t)(behind > 0x7FFFFFFFll ? 0x7FFFFFFFll : behind), start_delay);
+#endif
+        }
+        report_at = 0;
+    }
+    // `steps` steps have just been done (rows stored): wait until their time is up.  MAIN: the call sites in a kernel's main loop --
+    // the only ones that carry the first wave's decide().
+    template <bool MAIN = false>
+    __device__ __forceinline__ void after(uint32_t steps, const GuPaceArgs &pa)
     {
         if (ticks) {
             due += (ticks * steps) >> 4;
-            const bool late = (int64_t)(__builtin_amdgcn_s_memrealtime() - due) >= 0;
+            if (MAIN && __builtin_expect(__builtin_amdgcn_readfirstlane(deciding) != 0u, 0)) decide(pa);  // (readfirstlane: the flag is wave-uniform, and the branch must be a scalar one)
+            const int64_t behind = (int64_t)(__builtin_amdgcn_s_memrealtime() - due);
+            const bool late = behind >= 0;
             ++n_groups;
             n_late += late;
+            n_steps += steps;
+            if (__builtin_expect(__builtin_amdgcn_readfirstlane(report_at) != 0u && n_steps >= report_at, 0)) report(behind);
             // (bounded: an `s_sleep 1` takes ~30 ns = 3 ticks, so a wait of one period ends within ticks / 3 turns; a clock that does
             // not advance must slow the launch down, not hang it)
             if (!late)
@@ -165,17 +223,11 @@ struct GuPacer {
                     __builtin_amdgcn_s_sleep(1);
         }
     }
-    // the wave leaves: its report into the launch's counters (`steps` = steps done since the last after())
-    __device__ __forceinline__ void finish(uint32_t steps)
+    // the wave leaves (a launch too short, or too oddly aligned, to have reached report_at -- or its decide() -- does both now)
+    __device__ __forceinline__ void finish(const GuPaceArgs &pa)
     {
-        if (mine && (threadIdx.x & 63u) == 0u) {
-            const int64_t behind = (int64_t)(__builtin_amdgcn_s_memrealtime() - (due + ((ticks * steps) >> 4)));
-            const bool far = behind > (int64_t)(2u * ticks);
-            const uint32_t late_q = n_groups ? (n_late * 64u) / n_groups : 0u;
-            (void)__hip_atomic_fetch_add(&mine->sum, (uint64_t)late_q | (1ull << 20) | ((uint64_t)far << 36), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (far) (void)__hip_atomic_fetch_max(&mine->max_behind, (uint64_t)behind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (wave_rec) *wave_rec = make_uint4(n_late, n_groups, (uint32_t)(int32_t)(behind > 0x7FFFFFFFll ? 0x7FFFFFFFll : behind), start_delay);
-        }
+        if (slot && report_at) report((int64_t)(__builtin_amdgcn_s_memrealtime() - (due + ticks)));
+        if (slot && deciding) decide(pa);
     }
 };
 
@@ -302,6 +354,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // this lane's state is asked for BEFORE the grid is staged, so that the two round trips to memory overlap (at the start of a
     // launch the loads queue behind what is left of the previous launch's stores: ~1 us each)
+    GuPacer pacer;
+    pacer.fetch(a.pace, TRAJ == 1 || TRAJ == 3);
     const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * blockDim.x + threadIdx.x;  // (remap only on single-grid engines)
     const bool live = e64 < a.N;
     const uint32_t e = (uint32_t)e64;
@@ -426,7 +480,6 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         if (TRAJ) rebase(1);
     };
 
-    GuPacer pacer;
     pacer.start(a.pace, TRAJ == 1 || TRAJ == 3);
     if (POLICY == GU_POLICY_UNIFORM) {
         // Fast path: every lane of the wave is at the same step count (always true unless
@@ -446,14 +499,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                     i += 8, t += 8;
                 }
                 for (; i < a.T && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
-                pacer.after((uint32_t)i);
+                pacer.after((uint32_t)i, a.pace);
             }
             for (; i + 16 <= a.T; i += 16, t += 16) {  // body: 16 steps per word, fully unrolled
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
 #pragma unroll
                 for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32);
                 if (TRAJ) rebase(16);
-                if (i + 16 < a.T) pacer.after(16);  // (nothing to wait for behind the last group)
+                if (i + 16 < a.T) pacer.after<true>(16, a.pace);  // (nothing to wait for behind the last group)
             }
             if (i < a.T) {  // tail
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
@@ -511,7 +564,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
 #pragma unroll
                     for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32);
                     if (TRAJ) rebase(16);
-                    pacer.after(16);
+                    pacer.after<true>(16, a.pace);
                     word = next;
                 }
                 for (int64_t q = k * 16, j = 0; q < steps; ++q, ++j) step1((word >> (2u * (uint32_t)j)) & 3u);  // tail of the stream
@@ -524,7 +577,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
 #pragma unroll
                     for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32);
                     if (TRAJ) rebase(16);
-                    pacer.after(16);
+                    pacer.after<true>(16, a.pace);
                 },
                 step1);
         }
@@ -581,7 +634,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                     tstep(0, ask);
                     if (TRAJ) rebase(1);
                 }
-                if (i) pacer.after((uint32_t)i);
+                if (i) pacer.after((uint32_t)i, a.pace);
                 constexpr uint32_t G = GU_RNG_SAMPLE_MASK + 1u < 8u ? 8u : GU_RNG_SAMPLE_MASK + 1u;  // steps per unrolled group
                 for (; i + G <= a.T; i += G) {
 #pragma unroll
@@ -590,14 +643,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                         else tstep(j * trow32, same_word);
                     }
                     if (TRAJ) rebase(G);
-                    if (i + G < a.T) pacer.after(G);
+                    if (i + G < a.T) pacer.after<true>(G, a.pace);
                 }
             } else {
                 for (; i + 8 <= a.T; i += 8) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) tstep(j * trow32, ask);
                     if (TRAJ) rebase(8);
-                    if (i + 8 < a.T) pacer.after(8);
+                    if (i + 8 < a.T) pacer.after<true>(8, a.pace);
                 }
             }
             for (; i < a.T; ++i) {
@@ -608,7 +661,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         if (thr_in_lds) run([thr_lds](int32_t at) { return thr_lds[at]; });
         else run([&a](int32_t at) { return a.pi_thr[at]; });
     }
-    pacer.finish(16);
+    pacer.finish(a.pace);
     a.pos[e] = s;
     a.reward[e] = r;
     a.done[e] = (int32_t)d;
@@ -729,6 +782,7 @@ void gu_rollout_greedy(gu_engine *h, const RolloutArgs &a, int auto_mode, int tr
 void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int traj, bool stats, int bs);
 // the transition-row kernel (gu_rollout_rows.hip): true when it took the launch (*rc: what its pace calibration returned)
 bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats, int *rc);
+bool gu_rows_pairs_fit(const gu_engine *h);  // its pair tables fit this engine's grid (and GU_OPT_ROLLOUT_ROWS does not forbid them)
 // store pacing (gu_kernels.hip): the schedule of a launch that writes rows -- the launch kind's ring of records, or a fixed period
 int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, const std::function<void(uint32_t)> &launch, GuPaceArgs *pace);
 // the K-step kernel (gu_rollout_multi.hip; uniform policy, no trajectory): true when it took the launch

@@ -165,6 +165,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
 {
     static_assert(!PAIR || POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM, "pair tables: policies whose actions do not depend on the state");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    GuPacer pacer;
+    pacer.fetch(a.pace, TRAJ != 0);  // (asked for ahead of the staging: gu_rollout.hpp)
     const int32_t shift = PAIR ? GU_PAIR_SHIFT : a.row_shift;  // log2(row bytes * copies)
     const int32_t copies_log2 = shift - RowBytes<POLICY>::log2;
     // LDS address of the staged table: folded into every record (0 in practice: this kernel has no static LDS), so that a
@@ -309,7 +311,6 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         emit(prev, soff);
     };
     auto nothing = [] {};
-    GuPacer pacer;
     pacer.start(a.pace, TRAJ != 0);
     auto step1 = [&](uint32_t x) {
         step(x, 0, nothing);
@@ -359,13 +360,13 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             if (t & 15u) {  // head: finish the current word
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
                 for (; i < a.T && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
-                pacer.after((uint32_t)i);
+                pacer.after((uint32_t)i, a.pace);
             }
             for (; i + 16 <= a.T; i += 16, t += 16) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
                 word16(word);
                 if (TRAJ) rebase(16);
-                if (i + 16 < a.T) pacer.after(16);  // (gu_rollout.hpp: GuPacer)
+                if (i + 16 < a.T) pacer.after<true>(16, a.pace);  // (gu_rollout.hpp: GuPacer)
             }
             if (i < a.T) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
                 pstep(0);
                 if (TRAJ) rebase(1);
             }
-            if (i > 1) pacer.after((uint32_t)i);
+            if (i > 1) pacer.after((uint32_t)i, a.pace);
             constexpr uint32_t G = GU_RNG_SAMPLE_MASK + 1u < 8u ? 8u : GU_RNG_SAMPLE_MASK + 1u;  // steps per unrolled group
             for (; i + G <= a.T; i += G) {
 #pragma unroll
@@ -420,14 +421,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
                     ++t;
                 }
                 if (TRAJ) rebase(G);
-                if (i + G < a.T) pacer.after(G);
+                if (i + G < a.T) pacer.after<true>(G, a.pace);
             }
         } else {
             for (; i + 8 <= a.T; i += 8) {
 #pragma unroll
                 for (uint32_t j = 0; j < 8; ++j) pstep(j * trow32);
                 if (TRAJ) rebase(8);
-                if (i + 8 < a.T) pacer.after(8);
+                if (i + 8 < a.T) pacer.after<true>(8, a.pace);
             }
         }
         for (; i < a.T; ++i) {
@@ -441,12 +442,12 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             [&](uint32_t word) {
                 word16(word);
                 if (TRAJ) rebase(16);
-                pacer.after(16);
+                pacer.after<true>(16, a.pace);
             },
             step1);
     }
     emit(rec, 0);  // the last step's record (row T - 1: every loop above leaves the row base one step behind)
-    pacer.finish(16);
+    pacer.finish(a.pace);
     // resets performed = steps that started from a done env = (done at entry: counted in first_step) + done flags seen
     // on every step but the last
     const uint32_t d_last = __builtin_amdgcn_ubfe(rec, GU_ROW_DONE_BIT, 1);
@@ -517,6 +518,13 @@ static void rows_dispatch(const gu_engine *h, const RolloutArgs &a, int traj, bo
         if (stats) GU_ROWS_LAUNCH(0, true); else GU_ROWS_LAUNCH(0, false);
     }
 #undef GU_ROWS_LAUNCH
+}
+
+// the pair tables fit this engine's grid: one grid, one start cell (or no auto-reset), 144 bytes of LDS per cell in one workgroup's share
+bool gu_rows_pairs_fit(const gu_engine *h)
+{
+    return h->n_grids == 1 && (int64_t)h->S * 144 <= h->lds_per_cu - 2048 && ((int64_t)h->S << GU_PAIR_SHIFT) <= (int64_t)GU_ROW_ADDR_MASK && rows_mode(h) != 0 &&
+           rows_mode(h) != 2;
 }
 
 // Returns true when the launch was taken by the row-table kernel.
@@ -598,8 +606,11 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     // 256-byte buffer_store_dword: 107 clocks per step with three of them, 143 per packed pair with two, 210 per int32 pair with six
     // (slopes over T = 2000 .. 4000); without rows the K-step kernel of gu_rollout_multi.hip is the tool), one 256-lane workgroup per CU at most (144 bytes
     // of LDS per cell).  GU_OPT_ROLLOUT_ROWS = 2 keeps the one-step table (A/B, tests).  profiles/archive/r03r_pair_rows.txt
-    bool pair = !table_policy && (traj == 2 || (traj == 3 && mode == 3)) && mode != 2 && gu_blocks(h->N, 256) <= (unsigned)h->n_cu && (int64_t)h->S * 144 <= h->lds_per_cu - 2048 &&
-                ((int64_t)h->S << GU_PAIR_SHIFT) <= (int64_t)GU_ROW_ADDR_MASK;
+    // (int32 TRIPLES, round 5: two 12-byte stores per pair instead of six 4-byte ones -- 37 against 50 us at config 2's 4096 envs, 39 at
+    // 8192, level with the one-step table at 16 384, slower beyond; the launcher hands triples to this kernel only where they pay,
+    // GU_OPT_ROLLOUT_ROWS = 3 forces the pairs for every triples launch)
+    bool pair = !table_policy && (traj == 2 || (traj == 3 && (mode == 3 || policy == GU_POLICY_UNIFORM) && (mode == 3 || (int64_t)gu_blocks(h->N, 256) * 8 <= h->n_cu))) &&
+                mode != 2 && gu_blocks(h->N, 256) <= (unsigned)h->n_cu && gu_rows_pairs_fit(h);
     if (pair) {
         if (!h->d_rows2[which]) {
             if (hipMalloc(&h->d_rows2[which], (size_t)h->S * 144) != hipSuccess) {

@@ -98,6 +98,25 @@ int gu_trail_before_reset(gu_engine *h, const uint8_t *d_mask, bool only_done)
     return GU_OK;
 }
 
+// gu_set_state put envs somewhere else and / or installed done flags: an env that was moved by hand has no trail to continue
+// (its ring is emptied -- the reference has no counterpart: `current_state` assigned from outside leaves `last_n_states` stale), and
+// the flag that decides the next lazy reset is the installed one, not the one behind the last append.
+__global__ void __launch_bounds__(256) gu_trail_set_state_kernel(const TrailArgs t, const int32_t *__restrict__ done, int32_t moved, int32_t done_given)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= t.N) return;
+    if (moved) t.len[e] = 0;
+    if (done_given) t.was_done[e] = done[e] != 0;
+}
+
+int gu_trail_after_set_state(gu_engine *h, bool moved, bool done_given)
+{
+    if (!h->trail_cap || !(moved || done_given)) return GU_OK;
+    hipLaunchKernelGGL(gu_trail_set_state_kernel, dim3(trail_blocks(h)), dim3(256), 0, h->stream, trail_args(h), h->done(), moved ? 1 : 0, done_given ? 1 : 0);
+    GU_HIP(hipGetLastError());
+    return GU_OK;
+}
+
 int gu_trail_after_rollout(gu_engine *h, int64_t T, int traj, bool auto_reset)
 {
     if (!h->trail_cap) return GU_OK;

@@ -735,7 +735,9 @@ static bool vi_cluster_shape(const gu_engine *h, int *K_out, unsigned *G_out)
 static bool vi_cluster_eligible(const gu_engine *h)
 {
     const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
-    return (path == 0 || path == 3 || path == 6) && vi_cluster_shape(h, nullptr, nullptr);
+    // (4 = the chip-wide cluster where the per-XCD form would apply, 5 = the per-XCD form made to give up: both end on the cluster
+    // here, as in gu_vi_sweep_step_run)
+    return (path == 0 || path == 3 || path == 4 || path == 5 || path == 6) && vi_cluster_shape(h, nullptr, nullptr);
 }
 
 static int vi_cluster_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds,
@@ -844,17 +846,21 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
     if (vi_xcd_preferred(h, iters)) {  // one launch of one XCD's workgroups, nothing leaves that XCD's L2 (gu_vi_xcd.hip)
         int32_t done = 0;
         rc = gu_vi_xcd_dp_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
+        h->vi_dp_form = 1;
         if (rc != GU_VI_FALLBACK) return rc;
     }
     if (vi_block_eligible(h)) {
         int32_t done = 0;
+        h->vi_dp_form = 2;
         return vi_block_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
     }
     if (vi_cluster_eligible(h)) {
         int32_t done = 0;
         rc = vi_cluster_run(h, gamma, 0.0, false, greedy_update != 0, iters, &done, deltas);
+        h->vi_dp_form = 3;
         if (rc != GU_VI_FALLBACK) return rc;
     }
+    h->vi_dp_form = 4;
     GU_HIP(hipMemsetAsync(h->d_delta, 0, (size_t)iters * sizeof(unsigned long long), h->stream));
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
@@ -895,13 +901,19 @@ int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, in
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
     if (vi_xcd_preferred(h, max_steps)) {
         rc = gu_vi_xcd_dp_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
+        h->vi_dp_form = 1;
         if (rc != GU_VI_FALLBACK) return rc;
     }
-    if (vi_block_eligible(h)) return vi_block_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
+    if (vi_block_eligible(h)) {
+        h->vi_dp_form = 2;
+        return vi_block_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
+    }
     if (vi_cluster_eligible(h)) {
         rc = vi_cluster_run(h, gamma, threshold, true, true, max_steps, steps_done, deltas);
+        h->vi_dp_form = 3;
         if (rc != GU_VI_FALLBACK) return rc;
     }
+    h->vi_dp_form = 4;
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
     const size_t smem = lds ? 2 * (size_t)h->cell_bytes : 0;
@@ -963,13 +975,19 @@ int gu_vi_eval_run(gu_handle h, double gamma, double threshold, int32_t max_step
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
     if (vi_xcd_preferred(h, max_steps)) {
         rc = gu_vi_xcd_dp_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
+        h->vi_dp_form = 1;
         if (rc != GU_VI_FALLBACK) return rc;
     }
-    if (vi_block_eligible(h)) return vi_block_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
+    if (vi_block_eligible(h)) {
+        h->vi_dp_form = 2;
+        return vi_block_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
+    }
     if (vi_cluster_eligible(h)) {
         rc = vi_cluster_run(h, gamma, threshold, true, false, max_steps, steps_done, deltas);
+        h->vi_dp_form = 3;
         if (rc != GU_VI_FALLBACK) return rc;
     }
+    h->vi_dp_form = 4;
     // larger grids: one evaluation launch per sweep, the host looks at the deltas once per batch
     const dim3 grid(vi_blocks(h->S)), block(VI_BLOCK);
     const bool lds = h->S <= GU_MAX_LDS_CELLS;
@@ -1204,6 +1222,7 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
 }
 
 int gu_vi_last_form(gu_handle h) { return h ? h->vi_run_form : 0; }
+int gu_vi_last_dp_form(gu_handle h) { return h ? h->vi_dp_form : 0; }
 
 int gu_vi_last_clusters(gu_handle h, int32_t *members)
 {

@@ -172,6 +172,12 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             for (int k = 0; k < VI_XCD_MAX_XCC; ++k) n += (uint32_t)(w >> (7 * k)) & 0x7Fu;
             return n;
         };
+        // (a seven-bit counter holds 127: a cluster of more than VI_XCD_SLOTS workgroups -- no MI355X partition has one -- gives the
+        // launch up BEFORE a carry can reach the neighbouring counter and leave everybody waiting for a sum that never comes)
+        if (rank >= VI_XCD_SLOTS) {
+            bad = 1u;
+            __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         uint32_t spins = 0;
         while (!bad && arrived(seen) < gridDim.x) {  // the one chip-wide wait of the launch
             __builtin_amdgcn_s_sleep(1);
@@ -183,9 +189,14 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             members = (uint32_t)(seen >> field) & 0x7Fu;
             writes = ((uint32_t)(seen >> 56) & 0xFu) == xcc + 1u;
             const int64_t chunk = ((((int64_t)S + members - 1) / members) + 63) & ~(int64_t)63;
-            const int64_t items = 2 * (int64_t)(W < S ? W : S) + (((S + 15) >> 4) + 1) / 2;  // what one thread's four fetch items must cover
-            bad = rank >= VI_XCD_SLOTS || members > VI_XCD_SLOTS || chunk > (int64_t)K * B || items > (int64_t)NB * B ||
-                  chunk + 2 * (int64_t)(W < S ? W : S) > (int64_t)a.lds_values;
+            // what one thread's fetch items must cover: the halo granules, and -- with agents -- the action items (the same sum
+            // gu_vi_xcd_plan sized NB for; round 4 counted the action items for the tables alone too and sent 125x32, 100x40,
+            // 1024x5 .. through a failed launch and a restore to the older forms)
+            const int64_t items = 2 * (int64_t)(W < S ? W : S) + (AGENTS ? (((S + 15) >> 4) + 1) / 2 : 0);
+            // the tables alone run on ONE cluster: the shape of the others (whose members leave right behind the registration) is
+            // nobody's business, and must not veto the launch
+            bad = (AGENTS || writes) && (rank >= VI_XCD_SLOTS || members > VI_XCD_SLOTS || chunk > (int64_t)K * B || items > (int64_t)NB * B ||
+                                         chunk + 2 * (int64_t)(W < S ? W : S) > (int64_t)a.lds_values);
         }
         if (bad || (a.inject_failure & 1u)) {
             bad = 1u;

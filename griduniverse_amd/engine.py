@@ -402,6 +402,11 @@ class Engine(object):
         barrier per round, 3 = one launch per round (0: none yet)."""
         return int(self.lib.gu_vi_last_form(self._h))
 
+    def vi_last_dp_form(self):
+        """Which form finished the last vi_sweep / vi_run / vi_eval_run: 1 = one XCD's workgroups in one launch, 2 = one workgroup,
+        3 = chip-wide cluster, 4 = one launch per round (0: none yet)."""
+        return int(self.lib.gu_vi_last_dp_form(self._h))
+
     def vi_last_clusters(self):
         """Workgroups per XCC id in the last per-XCD launch of vi_sweep_step_run, as the hardware reported them (list of 8)."""
         m = np.zeros(8, np.int32)

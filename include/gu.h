@@ -112,14 +112,16 @@ int gu_device_info(int device_id, char *buf, size_t len);
                                          0 = none, n = fixed period of n 10 ns ticks per 16 steps (-2: accepted, same as -1) */
 #define GU_OPT_VI_XCD_BLOCK 19        /* workgroup size of the per-XCD form of gu_vi_sweep_step_run: 256, 512, 1024 (0 = by batch size) */
 #define GU_OPT_PACE_TARGET 20         /* closed-loop store pacing: GB/s of rows the first launch of a kind is scheduled for (7200)  */
-#define GU_OPT_PACE_BAR_NUM 21        /* ... a launch was BEHIND when a wave ended more than this many 256ths of the schedule late (20) */
-#define GU_OPT_PACE_INC_Q 22          /* ... 1/64 ticks: the period's step up after a launch that was behind (128); this option + 1: its
-                                         smallest step down after a launch on schedule (GU_OPT_PACE_DEC_Q, 2)                    */
-#define GU_OPT_PACE_DEC_Q 23
+#define GU_OPT_PACE_BAR_NUM 21        /* ... the log calls a launch BEHIND when a wave was more than this many 256ths of the schedule late (20) */
+#define GU_OPT_PACE_GAIN_Q 22         /* ... 1/64 ticks: the period's step up after a launch whose waves ALL fell behind (256); a share of
+                                         the waves: that share of it                                                          */
+#define GU_OPT_PACE_DEC_Q 23          /* ... 1/64 ticks: what the period comes down by, every launch (16)                           */
 #define GU_OPT_TRAJ_LAYOUT 24         /* device layout of the int32 trajectory: 0 = three planes [T][N], 1 = one plane of (obs, reward,
-                                         done) triples [T][N][3] written with one 12-byte store per lane and step; what
+                                         done) triples [T][N][3] written with one 12-byte store per lane and step, -1 (default) =
+                                         triples where they are faster (small batches under the uniform policy); what
                                          gu_read_trajectory, gu_mc_evaluate and the host see does not change                   */
-#define GU_OPT_COUNT 25
+#define GU_OPT_PACE_RECORD 25         /* 0 = launches with a FIXED period keep no record (measurement aid: what the records cost)   */
+#define GU_OPT_COUNT 26
 #define GU_OPT_X_TRAJ_UNCACHED 100    /* EXPERIMENT: uncached memory type for the trajectory (readers may see stale bytes)    */
 #define GU_OPT_X_TRAJ_POISON 101      /* EXPERIMENT: fill a fresh trajectory buffer with 0x5A                                 */
 #define GU_OPT_X_MC_POISON 102        /* EXPERIMENT: fill the Monte-Carlo scratch with 0x5A before every evaluation           */
@@ -342,6 +344,9 @@ int gu_vi_get(gu_handle h, double *v, double *pi);
 int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta);
 int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flags, double *deltas);
 int gu_vi_last_form(gu_handle h);
+/* ... and the last gu_vi_sweep / gu_vi_run / gu_vi_eval_run: 1 per XCD (one cluster's workgroups), 2 one workgroup, 3 chip-wide
+ * cluster, 4 one launch per round (the form that finished the call; 0 = none yet). */
+int gu_vi_last_dp_form(gu_handle h);
 int gu_vi_last_clusters(gu_handle h, int32_t *members);
 
 /* ---- Monte-Carlo policy evaluation: core/algorithms/monte_carlo.py:29-99 ----------------

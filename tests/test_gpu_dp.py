@@ -373,7 +373,7 @@ def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, gu_option):
     walls = rs.choice(S, S // 5, replace=False)
     free = np.setdiff1d(np.arange(S), walls)
     spec = GridSpec(W, H, [int(free[0])], [int(x) for x in free[-3:]], [int(x) for x in free[5:9]], [int(x) for x in walls])
-    out = {}
+    out, form = {}, {}
     # '1': the default dispatch (the per-XCD launch where planes + values fit one workgroup's LDS, else the chip-wide cluster);
     # 'chip_wide': no per-XCD form; 'timeout': a grid-barrier timeout is injected into the chip-wide cluster -> tables restored,
     # launch-per-round path; 'xcd_gives_up': the per-XCD launch gives up at once -> tables restored, next form
@@ -383,13 +383,16 @@ def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, gu_option):
         with Engine(2, spec) as eng:
             eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
             steps, deltas = eng.vi_run(0.9, 1e-3, 300)
+            form[cluster] = [eng.vi_last_dp_form()]
             res += [steps, deltas.tobytes(), *(x.tobytes() for x in eng.vi_get())]
             res += [eng.vi_sweep(0.97, 3, greedy_update=True).tobytes(), *(x.tobytes() for x in eng.vi_get())]  # odd round count
+            form[cluster].append(eng.vi_last_dp_form())
             pi = np.random.RandomState(3).dirichlet(np.ones(4), S)
             v = np.random.RandomState(4).randn(S) * 20
             v[::7] = np.round(v[::7])
             eng.vi_set(v, pi)
             steps, deltas = eng.vi_eval_run(0.9, 1e-2, 25)
+            form[cluster].append(eng.vi_last_dp_form())
             res += [steps, deltas.tobytes(), *(x.tobytes() for x in eng.vi_get())]
             res += [eng.vi_sweep(1.0, 2, greedy_update=True).tobytes(), *(x.tobytes() for x in eng.vi_get())]
             res += [eng.vi_sweep(1.0, 1, greedy_update=False).tobytes(), *(x.tobytes() for x in eng.vi_get())]
@@ -399,6 +402,39 @@ def test_cluster_kernel_and_launch_per_round_agree(W, H, vi_path, gu_option):
     assert out['0'][0] > 3
     for cluster in ('1', 'chip_wide', 'timeout', 'xcd_gives_up'):
         assert out[cluster] == out['0'], cluster
+    # ... and each mode really ran the form it names (vi_last_dp_form: 1 per XCD, 2 one workgroup, 3 chip-wide cluster, 4 one launch
+    # per round) -- results alone cannot tell a form that silently gave up from one that ran: round 4's per-XCD kernel counted the
+    # agents' action items for the tables alone and sent 1024x5 (and 125x32, 100x40 ..) through a failed launch and a restore
+    per_xcd = 1 if S <= 32767 else 3
+    want = {'0': 4, '1': per_xcd, 'chip_wide': 3, 'timeout': 4, 'xcd_gives_up': 3}
+    for cluster, forms in form.items():
+        assert forms == [want[cluster]] * 3, (cluster, forms)
+
+
+@pytest.mark.parametrize('W,H', [(125, 32), (100, 40), (120, 30), (1024, 5), (64, 64), (8, 8)])
+def test_the_tables_alone_take_the_per_xcd_launch_wherever_it_fits(W, H, vi_path, gu_option):
+    """gu_vi_run / gu_vi_sweep / gu_vi_eval_run under the default dispatch: ONE launch of one XCD's workgroups finishes the call
+    on every grid of up to 32 767 states -- among them the shapes whose halo fits the launch the plan chose but whose halo PLUS the
+    agents' action items (which the tables alone do not exchange) would not."""
+    if vi_path not in ('one_launch', 'per_xcd_everywhere'):
+        pytest.skip('the default dispatch is what this test is about')
+    S = W * H
+    spec = GridSpec(W, H, [0], [S - 1], [S // 2], [])
+    grid = C.Grid.from_lists(W=W, H=H, starts=[0], goals=[S - 1], lava=[S // 2], walls=[])
+    with Engine(2, spec) as eng:
+        eng.vi_set(np.zeros(S), np.ones((S, 4)) / 4)
+        steps, deltas = eng.vi_run(0.9, 1e-3, 40)
+        assert eng.vi_last_dp_form() == 1, (W, H)
+        v, pi = np.zeros(S), np.ones((S, 4)) / 4
+        for i in range(steps):
+            v, pi, d = C.value_iteration_step(grid, 0.9, pi, v)
+            assert d == deltas[i]
+        got_v, got_pi = eng.vi_get()
+        assert got_v.tobytes() == v.tobytes() and got_pi.tobytes() == pi.tobytes()
+        eng.vi_sweep(0.9, 3, greedy_update=False)
+        assert eng.vi_last_dp_form() == 1
+        eng.vi_eval_run(0.9, 1e-2, 10)
+        assert eng.vi_last_dp_form() == 1
 
 
 @pytest.mark.parametrize('name,N,auto', [('maze64_s5', 65536, True), ('maze64_s5_g097', 4096, False), ('rect6x5_g1', 100, True),

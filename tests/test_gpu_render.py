@@ -179,3 +179,33 @@ def test_agent_trail_equals_the_reference_quads_and_the_stated_blend(px):
             rings[how] = eng.trail_read(0, N)
             assert all(len(r) <= 40 for r in rings[how]) and any(len(r) < 40 for r in rings[how]) and any(len(r) == 40 for r in rings[how])
     assert rings['steps'] == rings['rollout']
+
+
+def test_the_trail_follows_set_state():
+    """gu_set_state moves envs by hand and installs done flags: an env that was moved has no trail to continue (its ring is
+    emptied), and the NEXT lazy reset is decided by the installed flag, not by the one behind the trail's last append (round 4
+    kept a private flag that set_state never touched)."""
+    spec = GridSpec(4, 4, [0], [15], [], [])
+    N = 4
+    with Engine(N, spec, seed=1) as eng:
+        eng.trail_enable(500)
+        eng.reset()
+        for a in (1, 1, 2):  # right, right, down: 1, 2, 6
+            eng.step(np.full(N, a, np.int32))
+        assert eng.trail_read(0, N) == [[1, 2, 6]] * N
+        # done flags installed by hand, positions untouched: the trail stays, the next auto-reset step empties it first
+        eng.set_state(done=np.array([1, 0, 1, 0], np.int32))
+        assert eng.trail_read(0, N) == [[1, 2, 6]] * N
+        eng.step(np.full(N, 1, np.int32), auto_reset=True)  # done envs: back to the start cell 0, then right -> 1
+        assert eng.trail_read(0, N) == [[1], [1, 2, 6, 7], [1], [1, 2, 6, 7]]
+        # envs moved by hand: every ring starts over from there
+        eng.set_state(pos=np.array([5, 5, 9, 9], np.int32), done=np.zeros(N, np.int32))
+        assert eng.trail_read(0, N) == [[]] * N
+        eng.step(np.full(N, 2, np.int32), auto_reset=True)  # down
+        assert eng.trail_read(0, N) == [[9], [9], [13], [13]]
+        # a done flag cleared by hand keeps the env where it is: no reset, the trail goes on
+        eng.set_state(pos=np.array([14, 14, 14, 14], np.int32))
+        eng.step(np.full(N, 1, np.int32), auto_reset=True)  # right -> 15, the goal: done
+        eng.set_state(done=np.zeros(N, np.int32))
+        eng.step(np.full(N, 3, np.int32), auto_reset=True)  # (the goal is absorbing for a step that is not a reset: stays on 15)
+        assert eng.trail_read(0, N) == [[15, 15]] * N

@@ -19,6 +19,7 @@ ap.add_argument('--reps', type=int, default=5)
 ap.add_argument('--launches', type=int, default=20)
 ap.add_argument('--json', default=None)
 ap.add_argument('--only', default=None)
+ap.add_argument('--sizes', type=int, nargs='*', default=None, help='batch sizes for a crossover table on the config-2 and config-4 grids')
 args = ap.parse_args()
 T = 1000
 
@@ -33,14 +34,20 @@ def workload(name):
     return gua.GridUniverseEnv(grid_shape=(32, 32), random_maze=True), 65536
 
 
+if args.sizes:
+    pass
 cases = [('c2', 'uniform'), ('c4', 'uniform'), ('c3', 'uniform'), ('c3', 'sample'), ('c3', 'greedy'), ('c3', 'stream')]
 variants = [('planes', dict(traj_layout=0)), ('triples', dict(traj_layout=1)), ('triples+pairs', dict(traj_layout=1, rollout_rows=3)),
             ('planes general', dict(traj_layout=0, rollout_rows=0)), ('triples general', dict(traj_layout=1, rollout_rows=0))]
 out = {}
+if args.sizes:
+    cases = [(w + '@%d' % n, 'uniform') for w in ('c2', 'c4') for n in args.sizes]
 for wname, policy in cases:
     if args.only and args.only != wname + ':' + policy:
         continue
-    env, N = workload(wname)
+    env, N = workload(wname.split('@')[0])
+    if '@' in wname:
+        N = int(wname.split('@')[1])
     spec = gua.GridSpec.from_env(env)
     S = spec.W * spec.H
     engines = {}

@@ -5,7 +5,7 @@
   loop   : a FRESH engine, launches back to back from the first one on: period, late share and device time of every launch
            (read from the kind's ring every 60 launches), event-timed wall per chunk;
   search : what the open-loop search of rounds 3 and 4 finds on the same buffer, and launches held at that period.
-    python tools/pace_loop.py [--kind c3|c4|sample|stream|packed] [--launches 600] [--bar 20 --inc 128 --dec 2] [--waves 200] [--sweep lo hi step] [--json out]"""
+    python tools/pace_loop.py [--kind c3|c4|sample|stream|packed] [--launches 600] [--bar 20 --inc <gain of 256> --dec <1/64 ticks>] [--waves 200] [--sweep lo hi step] [--json out]"""
 import argparse
 import json
 import os
@@ -46,7 +46,7 @@ policy = {'c3': 'uniform', 'c4': 'uniform', 'sample': 'sample', 'stream': 'strea
 traj = 'packed' if args.kind == 'packed' else True
 if args.candidates:
     _lib.set_default_option('traj_candidates', args.candidates)
-for name, v in (('pace_bar_num', args.bar), ('pace_inc_q', args.inc), ('pace_dec_q', args.dec), ('pace_target', args.target)):
+for name, v in (('pace_bar_num', args.bar), ('pace_gain_q', args.inc), ('pace_dec_q', args.dec), ('pace_target', args.target)):
     if v is not None:
         _lib.set_default_option(name, v)
 
@@ -177,6 +177,17 @@ if not args.no_search:
         res = [round(chunk(eng, 60)[0], 2) for _ in range(5)]
         print('   held at %d: wall us per launch, 5 x 60 launches: %s' % (found['period'], res))
         out['held'] = res
+        eng.set_option('pace_record', 0)  # the same period without the launch records: what they cost
+        go(eng, 20)
+        res = []
+        for _ in range(5):
+            eng.sync()
+            eng.timer_begin()
+            go(eng, 60)
+            res.append(round(eng.timer_end() / 60 * 1e3, 2))
+        print('   held at %d WITHOUT records: wall us per launch, 5 x 60 launches: %s' % (found['period'], res))
+        out['held_no_records'] = res
+        eng.set_option('pace_record', None)
         eng.set_option('rollout_pace', None)
         go(eng, 300)  # the closed loop again on this (now warm) engine
         res = []

@@ -323,8 +323,7 @@ def baseline_configs(engine_cls, device, K, check):
         pass
 
     def rows(eng, policy='uniform'):
-        getattr(eng, 'calibrate_rollout', eng.rollout)(T, policy, auto_reset=True, trajectory=True)  # (the pacing search up front where the kind is paced)
-        for _ in range(3):
+        for _ in range(settle_launches(eng, T, policy, trajectory=True)):
             eng.rollout(T, policy, auto_reset=True, trajectory=True)
         eng.sync()
         eng.timer_begin()
@@ -523,8 +522,7 @@ def other_modes(eng, template, seed, env_id0, N, T, K, check):
     it): per-env statistics only (return, episodes finished: no HBM stream at all, bound by the LDS round trip of the
     K-step transition table), and one packed uint32 per env-step (4 B)."""
     def launch_ms(**kw):
-        getattr(eng, 'calibrate_rollout', eng.rollout)(T, 'uniform', auto_reset=True, **kw)
-        for _ in range(3):
+        for _ in range(settle_launches(eng, T, 'uniform', **kw)):
             eng.rollout(T, 'uniform', auto_reset=True, **kw)
         eng.sync()
         eng.timer_begin()
@@ -548,8 +546,7 @@ def other_modes(eng, template, seed, env_id0, N, T, K, check):
         eng.vi_set(np.zeros(S), np.random.RandomState(1).dirichlet(np.ones(4), S))
 
         def sample_ms(**kw):
-            getattr(eng, 'calibrate_rollout', eng.rollout)(T, 'sample', auto_reset=True, **kw)  # (the pacing search up front, as for the headline)
-            for _ in range(3):
+            for _ in range(settle_launches(eng, T, 'sample', **kw)):
                 eng.rollout(T, 'sample', auto_reset=True, **kw)
             eng.sync()
             eng.timer_begin()
@@ -745,23 +742,45 @@ def device_block(engine_cls, device):
     return info
 
 
+def settle_launches(eng, T, policy, **kw):
+    """Untimed launches in front of a timed block of a launch kind: 3 -- or, for a kind whose rows keep a schedule, the few hundred
+    the closed loop of the store pacing takes to come down from its model period (it runs inside the launches themselves: nothing
+    else is asked of the engine; 200 launches = 20 ms at the headline size)."""
+    eng.rollout(T, policy, auto_reset=True, **kw)
+    paced = hasattr(eng, 'rollout_pacing') and eng.rollout_pacing(policy, True, packed=kw.get('trajectory') == 'packed') is not None
+    return 200 if paced else 3
+
+
 def pacing_block(eng):
-    """roofline.store_pacing: what the rollout kernel's rate limiter was calibrated to for the bench launch (the waves' schedule: 10 ns
-    ticks per 16 steps), and the launch time the calibration itself measured without and with it."""
+    """roofline.store_pacing: where the closed loop of the rollout kernel's rate limiter stands for the bench launch (the waves'
+    schedule: 10 ns ticks per 16 steps), and the records of its last launches."""
     if not hasattr(eng, 'rollout_pacing'):
         return None
     info = eng.rollout_pacing('uniform', True)
     totals = eng.rollout_pacing_totals() if hasattr(eng, 'rollout_pacing_totals') else None
     if info is None:
-        return {'calibrated': False, 'totals': totals}
-    info['calibrated'] = True
-    info['requested'] = 'bench.py asks for the search before its warm-up launches (gu_rollout_calibrate); an engine left to itself runs without a ' \
-                        'limiter until it has issued 1024 launches of a kind, or takes over a period this process found earlier after a six-launch check'
+        return {'paced': False, 'totals': totals}
+    info['paced'] = True
+    info['requested'] = 'nothing: bench.py only launches (rounds 3 and 4 called gu_rollout_calibrate before the warm-up); totals.launches_spent ' \
+                        'counts launches the engine issued for itself'
     info['totals'] = totals
+    if hasattr(eng, 'rollout_pace_log'):
+        lg = eng.rollout_pace_log('uniform', True)
+        iv = lg['interval'][lg['interval'] > 0]
+        info['last_launches'] = {
+            'launches_of_the_kind': int(lg['launches']), 'periods': [round(float(x), 2) for x in lg['period'][-16:]],
+            'phase': [int(x) for x in lg['phase'][-16:]],
+            'launches_in_log': int(len(lg['seq'])), 'launches_behind_in_log': int((lg['verdict'] == 2).sum()),
+            'waves_behind_share_in_log': float(lg['ended_late'].sum()) / max(1, int(lg['waves'].sum())),
+            'start_to_start_us_median': float(np.median(iv)) / 100.0 if len(iv) else None,
+            'is': 'the kind\'s ring of launch records on the device: the period each of the last launches ran with (0 = without the limiter), '
+                  'how many waves reported more than two periods behind their schedule, the device-clock time from one launch\'s start to the next'}
     info['is'] = 'the HBM write path collapses when it is over-driven (5.7 TB/s on most allocations): every wave keeps a schedule -- its ' \
-                 'next 16 steps begin no earlier than `period` ticks of 10 ns after the last ones were due, late waves do not wait --, a ' \
-                 'period found by timing the kernel itself on this engine and buffer (state snapshot and put back); ms_unpaced / ' \
-                 'ms_paced are the calibration\'s own per-launch times (DESIGN.md section 6)'
+                 'next 16 steps begin no earlier than `period` ticks of 10 ns after the last ones were due, late waves do not wait.  The ' \
+                 'period is chosen by the launches themselves, closed loop, on the device: every wave reports whether it fell behind, the ' \
+                 'first wave of the next launch sums the reports and moves the period of the launch after it (up by the share of waves ' \
+                 'behind, down by a quarter tick per launch), and every 1024 launches three launches run without the limiter to see ' \
+                 'whether it pays at all (DESIGN.md section 6; gu_rollout.hpp: GuPacer)'
     return info
 
 
@@ -849,8 +868,7 @@ def strong_c4(args, ranks, engine_cls, device):
         ref = reference_digest('c4', template, seed, n, T_check, rank * n) if world == 1 else None
         ref_ok = None if ref is None else sha256_triplet(got) == ref
         del got
-        getattr(eng, 'calibrate_rollout', eng.rollout)(args.T, 'uniform', auto_reset=True, trajectory=True)  # (the pacing search, up front)
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, settle_launches(eng, args.T, 'uniform', trajectory=True))):
             eng.rollout(args.T, 'uniform', auto_reset=True, trajectory=True)
         wall, kern, _, _ = timed_region(eng, ranks, args.T, args.steps, args.min_seconds / 2)
         pacing = pacing_block(eng)
@@ -995,8 +1013,8 @@ def run_single_process(args, engine_cls=None, emit=print):
             e.reset()
             e.reserve_trajectory(T)
         launches = 1
-        for e in engines:  # (the store-pacing search up front, see run(); the launch itself is the first one from reset)
-            getattr(e, 'calibrate_rollout', e.rollout)(T, 'uniform', auto_reset=True, trajectory=True)
+        for e in engines:  # (the first launch from reset: checked in full below)
+            e.rollout(T, 'uniform', auto_reset=True, trajectory=True)
         checks = {}
         if not args.no_checks:
             first = engines[0].read_trajectory(0, T)
@@ -1168,12 +1186,10 @@ def run(args, engine_cls=None, emit=print):
     eng.reset()
     eng.reserve_trajectory(T)
 
-    # ---- launch 1, from reset: checked in full.  (A benchmark issues thousands of launches: it asks for the store-pacing search
-    # up front -- by default an engine runs without a limiter until it has issued 1024 launches of a kind; the search works on a
-    # snapshot of the state and puts it back, so this IS the first launch from reset, whatever the search found.)
+    # ---- launch 1, from reset: checked in full.  (Nothing is asked of the engine but the launches themselves: the store pacing of
+    # the rollout kernel is a closed loop that runs inside them from the first one on -- rounds 3 and 4 asked for a search here.)
     launches = 1
-    first_launch = getattr(eng, 'calibrate_rollout', eng.rollout)
-    first_launch(T, 'uniform', auto_reset=True, trajectory=True)
+    eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
     eng.sync()
     checks = {}
     if rank == 0 and not args.no_checks:

@@ -973,10 +973,10 @@ int gu_rollout_pace_log(gu_handle h, int32_t policy_kind, uint32_t flags, int32_
         const GuPaceEntry &next = ring[(seq + 1u) & (GU_PACE_RING - 1u)];
         uint64_t *o = entries + (size_t)i * 8;
         o[0] = e.seq;
-        o[1] = e.period_q;
-        o[2] = e.verdict;
+        o[1] = e.unpaced ? 0u : e.period_q;
+        o[2] = e.verdict | (e.phase << 8);
         o[3] = e.waves;
-        o[4] = e.late_q;
+        o[4] = e.elapsed;
         o[5] = e.ended_late;
         o[6] = e.max_behind;
         o[7] = (seq < k.seq && next.seq == seq + 1u && next.t_start > e.t_start) ? next.t_start - e.t_start : 0;  // start to start, 10 ns ticks

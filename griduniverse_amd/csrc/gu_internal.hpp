@@ -36,21 +36,30 @@
 #define GU_STREAM_PAD_WORDS 4  // spare rows behind the packed action stream: the rollout kernels read up to four words ahead
 
 // ---- closed-loop store pacing (gu_rollout.hpp: GuPacer, gu_pace_next) -----------------
-struct GuPaceEntry {   // one launch of one kind: the period it runs with, and -- afterwards -- what became of it; 64 bytes
+struct GuPaceEntry {   // one launch of one kind: how it runs, the loop's state behind it, and -- afterwards -- what became of it; 64 bytes
     uint32_t period_q;    // the period of launch `seq`, in 1/64 ticks (the schedule uses the rounded tick count): written by the
     uint32_t seq;         // first wave of launch seq - 1 (gu_rollout.hpp: GuPacer::decide); an entry with another number is stale
     uint64_t t_start;     // 100 MHz clock when the launch's first workgroup began (written by that launch)
+    uint32_t unpaced;     // 1: launch `seq` runs WITHOUT the limiter (a probe, or because the limiter does not pay for this kind)
+    uint32_t phase;       // GU_PACE_NORMAL .. : where the loop's "does the limiter pay at all" cycle stands (GuPacer::decide)
+    uint32_t left;        // launches left in this phase
+    uint32_t ema_paced;   // ticks: launches WITH the limiter, from the wave's start to its report, the slowest wave (running mean)
+    uint32_t ema_unpaced; // ... and WITHOUT it (the mean of the last probe's launches)
     // the log: what the waves of the launch reported, summed by the first wave of launch seq + 1
     uint32_t verdict;     // 0 not summed yet, 1 on schedule, 2 behind (the log's bar: GuPaceArgs::bar_num)
     uint32_t waves;       // waves that reported
-    uint32_t late_q;      // sum over the waves of 64 x (groups begun behind schedule / groups)
+    uint32_t elapsed;     // ticks from start to report, the slowest wave
     uint32_t ended_late;  // waves that were more than two periods behind their schedule when they reported
     uint32_t max_behind;  // ticks: the most any of them was behind (0 when none was more than two periods behind)
-    uint32_t reserved[7];
+    uint32_t reserved[2];
 };
+#define GU_PACE_NORMAL 0   /* the limiter is on, the period follows the rule                                                      */
+#define GU_PACE_PROBE_OFF 1 /* a few launches without the limiter: how long do they take?                                          */
+#define GU_PACE_OFF 2      /* the launches without it were quicker: the kind runs without a limiter                               */
+#define GU_PACE_PROBE_ON 3 /* ... until it is tried again for a few launches                                                      */
 // What a wave leaves behind for the loop: ONE 8-byte plain store into its own slot of its launch's set (two sets per kind, by launch
-// parity), a few groups before the end of the launch.  bit 63: reported; bit 62: more than two periods behind; bits 32 .. 38:
-// 64 x share of its groups begun behind schedule; bits 0 .. 30: ticks behind (0 when ahead).
+// parity), a few groups before the end of the launch.  bit 63: reported; bits 32 .. 38: 64 x share of its groups begun behind
+// schedule; bits 0 .. 30: ticks from the wave's start to this moment.
 // (NOT atomics.  Round 5's first version had every wave add its counts to one word of its launch's record: the 3072 agent-scope
 // atomics of a launch were executed one after the other at ~11 ns each and added 34 us to every 105 us launch.  Spread over 32
 // neighbouring cache lines they still cost 6 .. 9 us per launch -- the lines share a memory channel, and that is where device-scope
@@ -71,6 +80,7 @@ struct GuPaceArgs {
     uint16_t fixed;         // 1: run with `period` and only record (measurement aid: tools/pace_loop.py)
     uint32_t gain_q;        // 1/64 ticks: what the period goes up by after a launch in which EVERY wave fell behind (a share of the waves: that share of it)
     uint32_t dec_q;         // 1/64 ticks: what it comes down by, every launch
+    uint32_t probe_every;   // launches between two looks at the other side (limiter off while it is on, on while it is off); 0 = never
 };
 
 struct gu_engine {

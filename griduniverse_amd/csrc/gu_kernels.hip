@@ -631,6 +631,7 @@ static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, 
     pace->bar_num = (uint16_t)gu_opt(h, GU_OPT_PACE_BAR_NUM);
     pace->gain_q = (uint32_t)gu_opt(h, GU_OPT_PACE_GAIN_Q);
     pace->dec_q = (uint32_t)gu_opt(h, GU_OPT_PACE_DEC_Q);
+    pace->probe_every = (uint32_t)gu_opt(h, GU_OPT_PACE_PROBE_EVERY);
     pace->fixed = 0;
     return GU_OK;
 }

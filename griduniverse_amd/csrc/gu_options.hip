@@ -45,6 +45,7 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_PACE_DEC_Q", 16, 0, 64},
     {"GU_TRAJ_LAYOUT", -1, -1, 1},
     {"GU_PACE_RECORD", 1, 0, 1},
+    {"GU_PACE_PROBE_EVERY", 1024, 0, 1 << 24},
 };
 const char *g_spec_x[GU_OPT_X_COUNT] = {"GU_TRAJ_UNCACHED", "GU_TRAJ_POISON", "GU_MC_POISON"};
 

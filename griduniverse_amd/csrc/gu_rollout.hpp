@@ -55,18 +55,14 @@ __device__ __forceinline__ uint32_t gu_sample_action(uint32_t word, const uint4 
 //    while below it most waves of every launch do; the mean share rises from 0.5 % to 3 % to > 50 % within ten ticks, so 6 % is
 //    reached within a tick or two of the period at which the mean launch time is shortest, on every allocation, and five times the
 //    background keeps the loop from creeping up on a noisy device (profiles/r05c_pace_c3.txt).  The first launches come down
-//    faster: dec is at least 8 / (8 + seq) tick.
+//    faster: dec is at least 8 / (8 + seq) tick.  And the loop keeps asking whether the limiter pays at all (decide()).
 // (History, all in profiles/r05*_pace_*.txt.  Version 1 moved one whole tick per launch and kept a "period known to fail" with
 // exponential back-off: two unlucky launches in a row doubled the back-off twice, and the period drifted up by 8 ticks in 300
 // launches and stayed there.  Version 2 stepped up by two ticks per launch behind and down by 1/32 tick: 4 ticks = 2.3 % above
 // the best fixed period, because a launch behind costs 8 us here, not the 35 us that ratio was chosen for.  Version 3 stepped up
 // in proportion to the slowest wave's distance behind: the background events alone held it 6 ticks above the best period.)
-struct GuPaceSum {
-    uint32_t late_q, waves, ended_late, max_behind;
-};
-
 struct GuPacer {
-    uint64_t due;
+    uint64_t due, t0;
     uint32_t ticks;
     uint32_t n_groups, n_late;  // scalar: groups done, groups begun behind schedule
     uint32_t report_at;         // the wave reports behind the group that completes this many steps (0: it has, or there is nothing to report to)
@@ -85,12 +81,14 @@ struct GuPacer {
         p_q = pa.period << 6;
         if (on && pa.ring) {
             const GuPaceEntry *entry = pa.ring + (pa.seq & (GU_PACE_RING - 1u));
-            const uint32_t have = entry->seq == pa.seq ? entry->period_q : 0u;  // (two scalar loads)
+            const bool mine = entry->seq == pa.seq;  // (scalar loads)
+            const uint32_t have = mine ? entry->period_q : 0u;
+            const uint32_t unpaced = mine ? entry->unpaced : 0u;
             if (have && !pa.fixed) p_q = have;
             p_q = p_q < (pa.lo << 6) ? (pa.lo << 6) : p_q;
             p_q = p_q > (pa.hi << 6) ? (pa.hi << 6) : p_q;
             if (pa.fixed) p_q = pa.period << 6;
-            ticks = (p_q + 32u) >> 6;
+            ticks = (unpaced && !pa.fixed) ? 0u : (p_q + 32u) >> 6;
         }
     }
     __device__ __forceinline__ void start(const GuPaceArgs &pa, bool on)
@@ -99,6 +97,7 @@ struct GuPacer {
         n_groups = n_late = n_steps = 0;
         report_at = 0;
         deciding = 0;
+        t0 = 0;
 #ifdef GU_PACE_WAVE_RECORDS
         wave_rec = nullptr;
         start_delay = 0;
@@ -112,9 +111,13 @@ struct GuPacer {
             // (wave-uniform, and the compiler must know it: a flag derived from threadIdx would live in a vector register and turn
             // every test of it into a divergent branch of the main loop)
             deciding = (blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) < 64u) ? 1u : 0u;
-            if (deciding && threadIdx.x == 0) {  // this launch's record (the period is there already unless this is the kind's first launch)
+            if (deciding && threadIdx.x == 0) {  // this launch's record (the rest of it is there already unless this is the kind's first launch)
+                if (entry->seq != pa.seq) {
+                    entry->unpaced = 0, entry->phase = GU_PACE_NORMAL, entry->left = pa.probe_every ? 24u : 0u;
+                    entry->ema_paced = 0, entry->ema_unpaced = 0;
+                }
                 entry->period_q = p_q, entry->seq = pa.seq, entry->t_start = now;
-                entry->verdict = 0, entry->waves = 0, entry->late_q = 0, entry->ended_late = 0, entry->max_behind = 0;
+                entry->verdict = 0, entry->waves = 0, entry->elapsed = 0, entry->ended_late = 0, entry->max_behind = 0;
             }
 #ifdef GU_PACE_WAVE_RECORDS
             if (pa.waves) {
@@ -123,19 +126,25 @@ struct GuPacer {
                 start_delay = (uint32_t)(now - began);
             }
 #endif
-            due = now;
+            due = t0 = now;
             return;
         }
         due = ticks ? __builtin_amdgcn_s_memrealtime() : 0ull;
     }
     // The launch's first wave, once, in the time it would otherwise sleep: what the waves of the launch BEFORE this one reported
-    // (set (seq - 1) & 1), summed over the wave's lanes; that launch's log; the period of the launch BEHIND this one.  The set is
+    // (set (seq - 1) & 1), summed over the wave's lanes; that launch's log; how the launch BEHIND this one runs.  The set is
     // cleared as it is read: the launch behind this one reports into it.
     __device__ __forceinline__ void decide(const GuPaceArgs &pa)
     {
         deciding = 0;
         uint64_t *set = pa.slots + (size_t)((pa.seq - 1u) & 1u) * pa.slot_stride;
-        uint32_t waves = 0, far = 0, late_q = 0, most = 0;
+        GuPaceEntry *prev = pa.ring + ((pa.seq - 1u) & (GU_PACE_RING - 1u));
+        GuPaceEntry *cur = pa.ring + (pa.seq & (GU_PACE_RING - 1u));
+        // the launch before: its schedule up to the report (0: it ran without the limiter, nobody was "behind")
+        const bool prev_ok = prev->seq + 1u == pa.seq;
+        const uint32_t prev_ticks = (prev_ok && !prev->unpaced) ? (pa.fixed ? pa.period : (prev->period_q + 32u) >> 6) : 0u;
+        const uint32_t scheduled = (prev_ticks * ((pa.report_at + 15u) & ~15u)) >> 4;
+        uint32_t waves = 0, far = 0, most = 0, longest = 0;
         // sixteen slots per lane and round trip, all asked for before the first is looked at (a loop that waits for each load in
         // turn keeps this wave 10 .. 30 us behind its schedule, and the launch ends when its last wave does: the first cut of this
         // function added 8 us to every launch, profiles/r05d_pace_c3.txt)
@@ -150,54 +159,72 @@ struct GuPacer {
             for (uint32_t j = 0; j < 16u; ++j) {
                 const uint32_t i = base + j * 64u + threadIdx.x;
                 if (i < pa.n_waves) set[i] = 0;
-                waves += (uint32_t)(w[j] >> 63);
-                far += (uint32_t)(w[j] >> 62) & 1u;
-                late_q += (uint32_t)(w[j] >> 32) & 0x7Fu;
-                const uint32_t behind = (uint32_t)w[j] & 0x7FFFFFFFu;
+                const uint32_t reported = (uint32_t)(w[j] >> 63), elapsed = (uint32_t)w[j] & 0x7FFFFFFFu;
+                const uint32_t behind = (prev_ticks && elapsed > scheduled) ? elapsed - scheduled : 0u;
+                waves += reported;
+                far += (reported && behind > 2u * prev_ticks) ? 1u : 0u;
                 most = behind > most ? behind : most;
+                longest = elapsed > longest ? elapsed : longest;
             }
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             waves += __shfl_xor(waves, m);
             far += __shfl_xor(far, m);
-            late_q += __shfl_xor(late_q, m);
-            const uint32_t o = __shfl_xor(most, m);
+            uint32_t o = __shfl_xor(most, m);
             most = o > most ? o : most;
+            o = __shfl_xor(longest, m);
+            longest = o > longest ? o : longest;
         }
         if (threadIdx.x == 0) {
-            GuPaceEntry *prev = pa.ring + ((pa.seq - 1u) & (GU_PACE_RING - 1u));
             GuPaceEntry *next = pa.ring + ((pa.seq + 1u) & (GU_PACE_RING - 1u));
-            uint32_t n_q = p_q;
-            if (waves) {
-                const uint64_t schedule = (uint64_t)ticks * pa.groups;
-                if (prev->seq + 1u == pa.seq) {
-                    prev->verdict = (uint64_t)most * 256u > schedule * pa.bar_num ? 2u : 1u;
-                    prev->waves = waves, prev->late_q = late_q, prev->ended_late = far, prev->max_behind = far ? most : 0u;
+            uint32_t n_q = cur->period_q, phase = cur->phase, left = cur->left, ema_p = cur->ema_paced, ema_u = cur->ema_unpaced;
+            if (waves && prev_ok) {
+                prev->verdict = (uint64_t)most * 256u > (uint64_t)prev_ticks * pa.groups * pa.bar_num ? 2u : 1u;
+                prev->waves = waves, prev->elapsed = longest, prev->ended_late = far, prev->max_behind = far ? most : 0u;
+                if (prev->unpaced) {
+                    ema_u = ema_u ? (ema_u + longest) >> 1 : longest;
+                } else {
+                    ema_p = ema_p ? (ema_p * 7u + longest) >> 3 : longest;
+                    // THE RULE (above): up by the share of waves that fell behind, down by a fraction of a tick
+                    const uint32_t up = (uint32_t)(((uint64_t)pa.gain_q * far) / waves);
+                    const uint32_t early = 512u / (8u + (pa.seq > 100000u ? 100000u : pa.seq));  // 64 x 8 / (8 + seq)
+                    const uint32_t dec = early > pa.dec_q ? early : pa.dec_q;
+                    n_q += up;
+                    n_q = n_q > dec ? n_q - dec : n_q;
                 }
-                const uint32_t up = (uint32_t)(((uint64_t)pa.gain_q * far) / waves);
-                const uint32_t early = 512u / (8u + (pa.seq > 100000u ? 100000u : pa.seq));  // 64 x 8 / (8 + seq)
-                const uint32_t dec = early > pa.dec_q ? early : pa.dec_q;
-                n_q += up;
-                n_q = n_q > dec ? n_q - dec : n_q;
             }
             n_q = n_q < (pa.lo << 6) ? (pa.lo << 6) : n_q;
             n_q = n_q > (pa.hi << 6) ? (pa.hi << 6) : n_q;
+            // DOES THE LIMITER PAY AT ALL?  A kind bound by its own dependent chain, not by the memory (packed rows at one wave per
+            // SIMD: 44 us without the limiter, 48 at the period the rule settles on -- the waves' natural pace) is better off
+            // without it.  So every `probe_every` launches (the first time after 24) three launches run without the limiter; when
+            // they reach their report quicker (by 1 %) than the launches with it do on average, the kind runs WITHOUT it, and the
+            // limiter gets six launches to prove itself again every 2 x probe_every.  Three launches in a thousand: 0.04 % of a
+            // kind that is better off with the limiter.
+            if (pa.probe_every && !pa.fixed && left && --left == 0u) {
+                const bool off_wins = ema_u && ema_p && (uint64_t)ema_u * 100u < (uint64_t)ema_p * 99u;
+                if (phase == GU_PACE_NORMAL) phase = GU_PACE_PROBE_OFF, left = 3u, ema_u = 0u;
+                else if (phase == GU_PACE_OFF) phase = GU_PACE_PROBE_ON, left = 6u, ema_p = 0u;
+                else if (off_wins) phase = GU_PACE_OFF, left = 2u * pa.probe_every;
+                else phase = GU_PACE_NORMAL, left = pa.probe_every;
+            }
             next->period_q = n_q, next->seq = pa.seq + 1u, next->t_start = 0;
-            next->verdict = 0, next->waves = 0, next->late_q = 0, next->ended_late = 0, next->max_behind = 0;
+            next->unpaced = (phase == GU_PACE_PROBE_OFF || phase == GU_PACE_OFF) ? 1u : 0u;
+            next->phase = phase, next->left = left, next->ema_paced = ema_p, next->ema_unpaced = ema_u;
+            next->verdict = 0, next->waves = 0, next->elapsed = 0, next->ended_late = 0, next->max_behind = 0;
         }
     }
     // The wave's report: ONE plain 8-byte store into its own slot (gu_internal.hpp).  Made `report_at` steps into the launch, i.e.
     // a few groups BEFORE its end, so that nothing of it is in flight when the kernel wants to complete.
-    __device__ __forceinline__ void report(int64_t behind)
+    __device__ __forceinline__ void report(uint64_t now)
     {
         if ((threadIdx.x & 63u) == 0u) {
-            const bool far = behind > (int64_t)(2u * ticks);
             const uint32_t late_q = n_groups ? (n_late * 64u) / n_groups : 0u;
-            const uint64_t b = behind <= 0 ? 0ull : (behind > 0x7FFFFFFFll ? 0x7FFFFFFFull : (uint64_t)behind);
-            *slot = (1ull << 63) | ((uint64_t)far << 62) | ((uint64_t)late_q << 32) | b;
+            const uint64_t elapsed = now - t0;
+            *slot = (1ull << 63) | ((uint64_t)late_q << 32) | (elapsed > 0x7FFFFFFFull ? 0x7FFFFFFFull : elapsed);
 #ifdef GU_PACE_WAVE_RECORDS
-            if (wave_rec) *wave_rec = make_uint4(n_late, n_groups, (uint32_t)(int32_t)(behind > 0x7FFFFFFFll ? 0x7FFFFFFFll : behind), start_delay);
+            if (wave_rec) *wave_rec = make_uint4(n_late, n_groups, (uint32_t)elapsed, start_delay);
 #endif
         }
         report_at = 0;
@@ -209,24 +236,28 @@ struct GuPacer {
     {
         if (ticks) {
             due += (ticks * steps) >> 4;
-            if (MAIN && __builtin_expect(__builtin_amdgcn_readfirstlane(deciding) != 0u, 0)) decide(pa);  // (readfirstlane: the flag is wave-uniform, and the branch must be a scalar one)
-            const int64_t behind = (int64_t)(__builtin_amdgcn_s_memrealtime() - due);
-            const bool late = behind >= 0;
+            if (MAIN && __builtin_expect(__builtin_amdgcn_readfirstlane(deciding) != 0u, 0)) decide(pa);  // (readfirstlane: wave-uniform; the branch must be a scalar one)
+            const uint64_t now = __builtin_amdgcn_s_memrealtime();
+            const bool late = (int64_t)(now - due) >= 0;
             ++n_groups;
             n_late += late;
             n_steps += steps;
-            if (__builtin_expect(__builtin_amdgcn_readfirstlane(report_at) != 0u && n_steps >= report_at, 0)) report(behind);
+            if (__builtin_expect(__builtin_amdgcn_readfirstlane(report_at) != 0u && n_steps >= report_at, 0)) report(now);
             // (bounded: an `s_sleep 1` takes ~30 ns = 3 ticks, so a wait of one period ends within ticks / 3 turns; a clock that does
             // not advance must slow the launch down, not hang it)
             if (!late)
                 for (uint32_t turn = 0; turn < 2u * ticks + 64u && (int64_t)(__builtin_amdgcn_s_memrealtime() - due) < 0; ++turn)
                     __builtin_amdgcn_s_sleep(1);
+        } else if (slot) {  // a launch without the limiter that is part of the loop: no clock but for its one report
+            n_steps += steps;
+            if (MAIN && __builtin_expect(__builtin_amdgcn_readfirstlane(deciding) != 0u, 0)) decide(pa);
+            if (__builtin_expect(__builtin_amdgcn_readfirstlane(report_at) != 0u && n_steps >= report_at, 0)) report(__builtin_amdgcn_s_memrealtime());
         }
     }
     // the wave leaves (a launch too short, or too oddly aligned, to have reached report_at -- or its decide() -- does both now)
     __device__ __forceinline__ void finish(const GuPaceArgs &pa)
     {
-        if (slot && report_at) report((int64_t)(__builtin_amdgcn_s_memrealtime() - (due + ticks)));
+        if (slot && report_at) report(__builtin_amdgcn_s_memrealtime());
         if (slot && deciding) decide(pa);
     }
 };

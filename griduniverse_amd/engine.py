@@ -250,19 +250,20 @@ class Engine(object):
         return dict(period=period.value, ms_unpaced=a.value, ms_paced=b.value, evaluated=n.value, calibration_ms=c.value)
 
     def rollout_pace_log(self, policy='uniform', auto_reset=True, packed=False):
-        """The records of the last (at most 62) launches of this kind, oldest first, as a dict of int64 arrays: seq, period (ticks,
-        float), verdict (of the launch behind it: 0 none yet, 1 on schedule, 2 behind), waves, late_share (mean over the waves),
-        ended_late (waves), max_behind (ticks), interval (ticks to the next launch's start; 0 for the last); plus 'launches' (of
-        the kind on the current shape).  None when the kind keeps no schedule."""
-        buf = np.zeros((62, 8), dtype=np.uint64)
+        """The records of the last (at most 61) launches of this kind, oldest first, as a dict of arrays: seq, period (ticks, float;
+        0 = the launch ran without the limiter), verdict (of the launch behind it: 0 none yet, 1 on schedule, 2 behind), phase (0
+        limiter on, 1 probing without it, 2 limiter off, 3 probing with it), waves, elapsed (ticks from start to report, slowest
+        wave), ended_late (waves), max_behind (ticks), interval (ticks to the next launch's start; 0 for the last); plus 'launches'
+        (of the kind on the current shape).  None when the kind keeps no schedule."""
+        buf = np.zeros((61, 8), dtype=np.uint64)
         n, launches = ctypes.c_int32(0), ctypes.c_uint32(0)
-        rc = self.lib.gu_rollout_pace_log(self._h, _POLICIES[policy], (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_PACKED if packed else 0), 62,
+        rc = self.lib.gu_rollout_pace_log(self._h, _POLICIES[policy], (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_PACKED if packed else 0), 61,
                                           buf.ctypes.data, ctypes.byref(n), ctypes.byref(launches))
         if rc == -4:
             return None
         check(rc)
         e = buf[:n.value].astype(np.int64)
-        return dict(seq=e[:, 0], period=e[:, 1] / 64.0, verdict=e[:, 2], waves=e[:, 3], late_share=e[:, 4] / 64.0 / np.maximum(1, e[:, 3]),
+        return dict(seq=e[:, 0], period=e[:, 1] / 64.0, verdict=e[:, 2] & 0xFF, phase=e[:, 2] >> 8, waves=e[:, 3], elapsed=e[:, 4],
                     ended_late=e[:, 5], max_behind=e[:, 6], interval=e[:, 7], launches=launches.value)
 
     def rollout_pace_waves(self):

@@ -121,7 +121,9 @@ int gu_device_info(int device_id, char *buf, size_t len);
                                          triples where they are faster (small batches under the uniform policy); what
                                          gu_read_trajectory, gu_mc_evaluate and the host see does not change                   */
 #define GU_OPT_PACE_RECORD 25         /* 0 = launches with a FIXED period keep no record (measurement aid: what the records cost)   */
-#define GU_OPT_COUNT 26
+#define GU_OPT_PACE_PROBE_EVERY 26    /* launches between two looks at whether the limiter pays at all: three launches without it while it
+                                         is on, six with it (every 2 x this) while it is off (1024; 0 = never: the limiter stays on)   */
+#define GU_OPT_COUNT 27
 #define GU_OPT_X_TRAJ_UNCACHED 100    /* EXPERIMENT: uncached memory type for the trajectory (readers may see stale bytes)    */
 #define GU_OPT_X_TRAJ_POISON 101      /* EXPERIMENT: fill a fresh trajectory buffer with 0x5A                                 */
 #define GU_OPT_X_MC_POISON 102        /* EXPERIMENT: fill the Monte-Carlo scratch with 0x5A before every evaluation           */
@@ -275,10 +277,12 @@ int gu_rollout_pacing_totals(gu_handle h, float *calibration_ms, int32_t *launch
                              int32_t *kinds_waiting);
 int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
                       int32_t *evaluated, float *calibration_ms);
-/* The records of the last launches of a kind, oldest first (at most 62; waits for the stream): per launch eight 64-bit words --
- * launch number, period in 1/64 ticks, verdict of the launch behind it (0 none yet, 1 on schedule, 2 behind), waves that reported,
- * their late shares summed (64ths), waves that ended more than two periods behind, the most a wave ended behind (ticks), and the
- * ticks from this launch's start to the next one's (0 for the last).  *launches = launches of the kind on the current shape. */
+/* The records of the last launches of a kind, oldest first (at most 61; waits for the stream): per launch eight 64-bit words --
+ * launch number; period in 1/64 ticks (0: the launch ran without the limiter); verdict of the launch behind it (0 none yet, 1 on
+ * schedule, 2 behind) | phase of the loop << 8 (0 limiter on, 1 three launches without it, 2 limiter off, 3 six launches with it);
+ * waves that reported; ticks from start to report of the slowest wave; waves that were more than two periods behind; the most a
+ * wave was behind (ticks); ticks from this launch's start to the next one's (0 for the last).  *launches = launches of the kind
+ * on the current shape. */
 int gu_rollout_pace_log(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t capacity, uint64_t *entries, int32_t *count, uint32_t *launches);
 /* MEASUREMENT AID: one record per wave of the last paced launch -- four uint32: groups begun behind schedule, groups, ticks behind
  * schedule at the end (int32), ticks from the launch's first wave to this wave's start.  The first call only switches the

@@ -32,7 +32,13 @@ def test_oracle_use_in_entry_points_is_confined():
 
 
 # the fixture generators: run only in the build container, where the reference is mounted
-GENERATORS = ('tests/golden/make_golden.py', 'tests/golden/calibrate_cpu.py', 'tests/golden/reference_api_latency.py')
+GENERATORS = ('tests/golden/make_golden.py', 'tests/golden/calibrate_cpu.py', 'tests/golden/reference_api_latency.py',
+              'tests/test_reference_pin.py')  # (the last one RUNS make_golden.py --check where the reference is, and skips elsewhere)
+
+
+def test_the_reference_pin_check_is_not_a_gpu_test():
+    text = open(os.path.join(ROOT, 'tests', 'test_reference_pin.py')).read()
+    assert 'mark.gpu' not in text and 'skipif' in text  # never selected by `-m gpu`, skipped where /root/reference is absent
 
 
 def test_nothing_on_the_gpu_box_reads_the_reference():

@@ -87,7 +87,7 @@ def chunk(eng, n, trace=None):
         trace['period'] += [round(float(x), 2) for x in lg['period'][-k:]]
         trace['us'] += [round(float(x) / 100.0, 2) for x in lg['interval'][-k:]]
         trace['verdict'] += [int(x) for x in lg['verdict'][-k:]]
-        trace['late_share'] += [round(float(x), 3) for x in lg['late_share'][-k:]]
+        trace['late_share'] += [int(x) for x in lg['phase'][-k:]]
         trace['behind_us'] += [round(float(x) / 100.0, 1) for x in lg['max_behind'][-k:]]
         trace['ended_late'] += [int(x) for x in lg['ended_late'][-k:]]
     return wall, lg
@@ -99,7 +99,7 @@ trace = dict(period=[], us=[], verdict=[], late_share=[], behind_us=[], ended_la
 chunks = []
 done = 0
 while done < args.launches:
-    n = min(60, args.launches - done)
+    n = min(58, args.launches - done)
     wall, lg = chunk(eng, n, trace)
     if lg is None:
         print('this launch kind keeps no schedule')
@@ -112,6 +112,7 @@ print('   first 40 launches: period       ', trace['period'][:40])
 print('                      start-start us', trace['us'][:40])
 print('                      verdict       ', trace['verdict'][:40])
 print('                      behind us     ', trace['behind_us'][:40])
+print('   phases seen (0 limiter on, 1 probing without, 2 off, 3 probing with):', sorted(set(trace['late_share'])), ' launches without the limiter:', sum(1 for x in trace['period'] if x == 0))
 us = np.array(trace['us'])
 per = np.array(trace['period'])
 ver = np.array(trace['verdict'])
@@ -121,7 +122,7 @@ for a, b in ((0, 6), (6, 32), (32, 100), (100, 300), (300, 600), (600, 1200), (1
         seg = us[a:b]
         seg = seg[seg > 0]
         print('   launches %4d .. %4d: start-to-start us median %.2f mean %.2f max %.2f   periods %.1f .. %.1f   launches behind: %d' % (
-            a, b - 1, np.median(seg), seg.mean(), seg.max(), per[a:b].min(), per[a:b].max(), int((ver[a:b] == 2).sum())))
+            a, b - 1, np.median(seg), seg.mean(), seg.max(), per[a:b][per[a:b] > 0].min() if (per[a:b] > 0).any() else 0, per[a:b].max(), int((ver[a:b] == 2).sum())))
 print('   wall us per launch by chunk of 60 (events):', chunks)
 out['loop'] = dict(trace=trace, wall_us_by_chunk=chunks)
 
@@ -162,7 +163,7 @@ if args.sweep:
         row = [p, round(float(np.median(u)), 2), round(float(u.mean()), 2), int((np.array(tr['verdict']) == 2).sum()), round(wall, 2),
                round(float(np.median(tr['late_share'])), 3)]
         rows.append(row)
-        print('   %4d | %7.2f %7.2f | %2d | %7.2f | late share median %.3f' % tuple(row))
+        print('   %4d | %7.2f %7.2f | %2d | %7.2f | phase/late %.3f' % tuple(row))
     eng.set_option('rollout_pace', None)
     out['sweep'] = rows
 
@@ -174,7 +175,7 @@ if not args.no_search:
     if found and found['period']:
         eng.set_option('rollout_pace', found['period'])
         go(eng, 20)
-        res = [round(chunk(eng, 60)[0], 2) for _ in range(5)]
+        res = [round(chunk(eng, 58)[0], 2) for _ in range(5)]
         print('   held at %d: wall us per launch, 5 x 60 launches: %s' % (found['period'], res))
         out['held'] = res
         eng.set_option('pace_record', 0)  # the same period without the launch records: what they cost
@@ -192,8 +193,8 @@ if not args.no_search:
         go(eng, 300)  # the closed loop again on this (now warm) engine
         res = []
         for _ in range(5):
-            wall, lg = chunk(eng, 60)
-            res.append((round(wall, 2), round(float(np.median(lg['period'][-60:])), 1)))
+            wall, lg = chunk(eng, 58)
+            res.append((round(wall, 2), round(float(np.median(lg['period'][-58:])), 1)))
         print('   closed loop after it (300 launches later): (wall us, period median) per 60 launches: %s' % res)
         out['loop_after'] = res
 eng.close()

@@ -1,4 +1,4 @@
-"""ctypes binding of libgu.so (include/gu.h) -- the only door to the HIP kernels.
+"""ctypes binding of libgu.so (include/gu.h, and the introspection calls of include/gu_diag.h) -- the only door to the HIP kernels.
 
 There is deliberately NO fallback: if the library is missing, or no MI355X is
 visible, every compute entry point raises `GuError`.  Host-only logic (argument
@@ -30,14 +30,14 @@ OPTIONS = {'rollout_block': 1, 'rollout_rows': 2, 'rows_copies': 3, 'rollout_mul
            'rollout_multi_copies': 6, 'rollout_xcd': 7, 'vi_path': 8, 'mc_scratch_mb': 9, 'mc_lane_returns': 10,
            'mc_global_walk': 11, 'step_sync': 12, 'traj_candidates': 13, 'traj_far_candidates': 14, 'traj_stride_mib': 15,
            'traj_far_mib': 16, 'traj_probe_all': 17, 'rollout_pace': 18, 'vi_xcd_block': 19, 'pace_target': 20, 'pace_bar_num': 21,
-           'pace_gain_q': 22, 'pace_dec_q': 23, 'traj_layout': 24, 'pace_record': 25, 'pace_probe_every': 26,
+           'pace_gain_q': 22, 'pace_dec_q': 23, 'traj_layout': 24, 'pace_record': 25, 'pace_probe_every': 26, 'pace_adapt': 27,
            # experiments: refused by libgu.so, accepted by libgu_exp.so only
            'x_traj_uncached': 100, 'x_traj_poison': 101, 'x_mc_poison': 102}
 
 _c = ctypes
 _vp, _i32, _i64, _u32, _u64, _f64 = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint32, _c.c_uint64, _c.c_double
 
-# name -> argtypes (restype is int everywhere).  Must list every symbol of include/gu.h;
+# name -> argtypes (restype is int everywhere).  Must list every symbol of include/gu.h and include/gu_diag.h;
 # tests/test_abi.py cross-checks this table against the header and the built library.
 SIGNATURES = {
     'gu_version': [],
@@ -70,7 +70,7 @@ SIGNATURES = {
     'gu_rollout_calibrate': [_vp, _i64, _i32, _u32],
     'gu_rollout_pacing_totals': [_vp, _vp, _vp, _vp, _vp, _vp],
     'gu_rollout_pace_log': [_vp, _i32, _u32, _i32, _vp, _vp, _vp],
-    'gu_rollout_pace_waves': [_vp, _i32, _vp, _vp],
+    'gu_rollout_pace_waves': [_vp, _i32, _u32, _i32, _vp, _vp],
     'gu_rollout_pace_search': [_vp, _i64, _i32, _u32, _vp, _vp, _vp, _vp, _vp],
     'gu_read_trajectory': [_vp, _i64, _i64, _vp, _vp, _vp],
     'gu_read_trajectory_packed': [_vp, _i64, _i64, _vp],
@@ -133,7 +133,7 @@ def source_hash():
     import hashlib
     names = sorted(n for n in os.listdir(CSRC) if n.endswith(('.hip', '.hpp')))
     h = hashlib.sha256()
-    for path in [os.path.join(CSRC, n) for n in names] + [os.path.join(os.path.dirname(_HERE), 'include', 'gu.h')]:
+    for path in [os.path.join(CSRC, n) for n in names] + [os.path.join(os.path.dirname(_HERE), 'include', n) for n in ('gu.h', 'gu_diag.h')]:
         with open(path, 'rb') as f:
             h.update(f.read())
     return h.hexdigest()[:16]

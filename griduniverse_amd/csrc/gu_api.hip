@@ -166,7 +166,7 @@ int gu_destroy(gu_handle h)
     gu_placement_release(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     void *bufs[] = {h->d_kind, h->d_rows[0], h->d_rows[1], h->d_rows2[0], h->d_rows2[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
-                    h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy, h->d_pace_ring, h->d_pace_waves, h->d_pace_slots};
+                    h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy, h->d_pace_ring, h->d_pace_slots};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -721,9 +721,13 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
     }
     size_t free_b = 0, total_b = 0;
     if (bytes < ((size_t)64 << 20) || want <= 1 || hipMemGetInfo(&free_b, &total_b) != hipSuccess) want = 1;
-    // Never hold more than a third of what is free, even briefly -- an eighth, and no spacers, once another engine of the
-    // process owns a chosen buffer on the device (several engines, or several ranks of one process group, share it).
-    size_t budget = others ? free_b / 8 : free_b / 3;
+    // Never hold more than a TENTH of what is free, even briefly (a third until round 4: a co-tenant of the device saw that) -- a
+    // sixteenth, and no spacers, once another engine of the process owns a chosen buffer on the device (several engines, or several
+    // ranks of one process group, share it).  What the search is still worth under the closed-loop store pacing: the first
+    // allocation an engine gets runs the headline launch at 105.9 .. 110.2 us (ten buffers of one process, median 107.5), the
+    // searched one at 105.2 -- 2 % in the median, 4 % at worst; the probe time ranks them in the same order
+    // (profiles/r05f_placement_loop.txt).  Why buffers differ is still not known (tools/micro/placement_*.hip).
+    size_t budget = others ? free_b / 16 : free_b / 10;
     if (others) {
         want = want < 4 ? want : 4;
         far = 0;
@@ -974,7 +978,7 @@ int gu_rollout_pace_log(gu_handle h, int32_t policy_kind, uint32_t flags, int32_
         uint64_t *o = entries + (size_t)i * 8;
         o[0] = e.seq;
         o[1] = e.unpaced ? 0u : e.period_q;
-        o[2] = e.verdict | (e.phase << 8);
+        o[2] = e.verdict | (e.phase << 8) | ((uint64_t)e.dec_q << 16);
         o[3] = e.waves;
         o[4] = e.elapsed;
         o[5] = e.ended_late;
@@ -986,19 +990,20 @@ int gu_rollout_pace_log(gu_handle h, int32_t policy_kind, uint32_t flags, int32_
     return GU_OK;
 }
 
-int gu_rollout_pace_waves(gu_handle h, int32_t capacity, uint32_t *records, int32_t *count)
+int gu_rollout_pace_waves(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t capacity, uint32_t *elapsed, int32_t *count)
 {
     GU_ENTER(h);
-    if (!h->d_pace_waves) {  // first call: from now on the paced launches of this engine leave one record per wave
-        const int64_t cap = (h->N + 63) / 64;
-        GU_HIP(hipMalloc((void **)&h->d_pace_waves, (size_t)cap * sizeof(uint4)));
-        GU_HIP(hipMemsetAsync(h->d_pace_waves, 0, (size_t)cap * sizeof(uint4), h->stream));
-        h->pace_waves_cap = cap;
-        h->pace_waves_last = 0;
-    }
-    const int64_t n = std::min<int64_t>(h->pace_waves_last, capacity > 0 ? capacity : 0);
+    GU_REQUIRE(policy_kind >= GU_POLICY_UNIFORM && policy_kind <= GU_POLICY_SAMPLE, GU_ERR_INVALID, "unknown policy kind %d", policy_kind);
+    const int slot = gu_pace_slot_in_use(h, policy_kind, flags);
+    GU_REQUIRE(slot >= 0, GU_ERR_STATE, "this launch kind keeps no schedule on the current trajectory buffer");
+    const gu_engine::PaceKind &k = h->pace[slot];
+    const int64_t waves = (h->N + 63) / 64;
+    const int64_t n = std::min<int64_t>(waves, capacity > 0 ? capacity : 0);
+    std::vector<uint64_t> words((size_t)n);
     GU_HIP(hipStreamSynchronize(h->stream));
-    if (n && records) GU_HIP(hipMemcpy(records, h->d_pace_waves, (size_t)n * sizeof(uint4), hipMemcpyDeviceToHost));
+    // the set the LAST launch of the kind reported into (nobody has summed -- and cleared -- it yet)
+    if (n) GU_HIP(hipMemcpy(words.data(), h->d_pace_slots + ((size_t)slot * 2 + (k.seq & 1u)) * (size_t)h->pace_slot_stride, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n && elapsed; ++i) elapsed[i] = (words[(size_t)i] >> 63) ? (uint32_t)(words[(size_t)i] & 0x7FFFFFFFu) : 0u;
     if (count) *count = (int32_t)n;
     return GU_OK;
 }

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/gu.h"
+#include "../../include/gu_diag.h"
 
 // ---- per-cell records (two byte planes, staged in LDS by every kernel) ----------------
 // Compiled on the host from the row bit-planes handed to gu_set_grid().  Together they
@@ -36,14 +37,14 @@
 #define GU_STREAM_PAD_WORDS 4  // spare rows behind the packed action stream: the rollout kernels read up to four words ahead
 
 // ---- closed-loop store pacing (gu_rollout.hpp: GuPacer, gu_pace_next) -----------------
-struct GuPaceEntry {   // one launch of one kind: how it runs, the loop's state behind it, and -- afterwards -- what became of it; 64 bytes
+struct GuPaceEntry {   // one launch of one kind: how it runs, the loop's state behind it, and -- afterwards -- what became of it; 128 bytes
     uint32_t period_q;    // the period of launch `seq`, in 1/64 ticks (the schedule uses the rounded tick count): written by the
     uint32_t seq;         // first wave of launch seq - 1 (gu_rollout.hpp: GuPacer::decide); an entry with another number is stale
     uint64_t t_start;     // 100 MHz clock when the launch's first workgroup began (written by that launch)
     uint32_t unpaced;     // 1: launch `seq` runs WITHOUT the limiter (a probe, or because the limiter does not pay for this kind)
     uint32_t phase;       // GU_PACE_NORMAL .. : where the loop's "does the limiter pay at all" cycle stands (GuPacer::decide)
     uint32_t left;        // launches left in this phase
-    uint32_t ema_paced;   // ticks: launches WITH the limiter, from the wave's start to its report, the slowest wave (running mean)
+    uint32_t ema_paced;   // ticks: launches WITH the limiter, from one launch's start to the next one's (running mean)
     uint32_t ema_unpaced; // ... and WITHOUT it (the mean of the last probe's launches)
     // the log: what the waves of the launch reported, summed by the first wave of launch seq + 1
     uint32_t verdict;     // 0 not summed yet, 1 on schedule, 2 behind (the log's bar: GuPaceArgs::bar_num)
@@ -52,14 +53,24 @@ struct GuPaceEntry {   // one launch of one kind: how it runs, the loop's state 
     uint32_t ended_late;  // waves that were more than two periods behind their schedule when they reported
     uint32_t max_behind;  // ticks: the most any of them was behind (0 when none was more than two periods behind)
     uint32_t reserved[2];
+    // the slow loop around the rule: which SHARE of waves behind is the best one to aim for on this buffer (GuPacer::decide)
+    uint32_t dec_q;       // what the period comes down by per launch, 1/64 ticks: the rule aims for a share of dec_q / gain_q
+    uint32_t block_left;  // launches left in this block (the first GU_PACE_BLOCK_SKIP of a block are not counted: the period is on its way)
+    uint32_t block_sum;   // ticks: start-to-start intervals of the block's counted launches, summed
+    uint32_t block_n;     // ... and how many
+    uint32_t last_mean;   // ticks: the mean of the block before (0: none yet)
+    uint32_t up;          // 1: the last change of dec_q was upwards
+    uint32_t reserved2[10];
 };
+static_assert(sizeof(GuPaceEntry) == 128, "GuPaceEntry is two cache lines' halves: 128 bytes");
+#define GU_PACE_BLOCK 192u      /* launches per block of the slow loop ...                       */
+#define GU_PACE_BLOCK_SKIP 64u  /* ... of which the first ones only let the period settle        */
 #define GU_PACE_NORMAL 0   /* the limiter is on, the period follows the rule                                                      */
 #define GU_PACE_PROBE_OFF 1 /* a few launches without the limiter: how long do they take?                                          */
 #define GU_PACE_OFF 2      /* the launches without it were quicker: the kind runs without a limiter                               */
 #define GU_PACE_PROBE_ON 3 /* ... until it is tried again for a few launches                                                      */
 // What a wave leaves behind for the loop: ONE 8-byte plain store into its own slot of its launch's set (two sets per kind, by launch
-// parity), a few groups before the end of the launch.  bit 63: reported; bits 32 .. 38: 64 x share of its groups begun behind
-// schedule; bits 0 .. 30: ticks from the wave's start to this moment.
+// parity), a few groups before the end of the launch.  bit 63: reported; bits 0 .. 30: ticks from the wave's start to this moment.
 // (NOT atomics.  Round 5's first version had every wave add its counts to one word of its launch's record: the 3072 agent-scope
 // atomics of a launch were executed one after the other at ~11 ns each and added 34 us to every 105 us launch.  Spread over 32
 // neighbouring cache lines they still cost 6 .. 9 us per launch -- the lines share a memory channel, and that is where device-scope
@@ -68,8 +79,6 @@ struct GuPaceEntry {   // one launch of one kind: how it runs, the loop's state 
 struct GuPaceArgs {
     GuPaceEntry *ring;      // nullptr: `period` as it is (0 = no limiter), nothing recorded
     uint64_t *slots;        // [2][slot_stride]: the waves' reports of this launch (set seq & 1) and of the launch before it
-    uint4 *waves;           // measurement aid, usually nullptr: one record per wave of the launch {groups begun late, groups, ticks
-                            // behind schedule when it reported (two's complement), ticks from the launch's start to the wave's}
     uint32_t seq;           // this launch's number within its kind (the host counts)
     uint32_t period;        // ring == nullptr or `fixed`: the period in ticks; else the period of a kind's first launch (the model)
     uint32_t lo, hi;        // the loop keeps the period within [lo, hi] ticks
@@ -81,6 +90,7 @@ struct GuPaceArgs {
     uint32_t gain_q;        // 1/64 ticks: what the period goes up by after a launch in which EVERY wave fell behind (a share of the waves: that share of it)
     uint32_t dec_q;         // 1/64 ticks: what it comes down by, every launch
     uint32_t probe_every;   // launches between two looks at the other side (limiter off while it is on, on while it is off); 0 = never
+    uint32_t adapt;         // 1: the slow loop moves the rule's aim (dec_q) by what the launches' start-to-start time says
 };
 
 struct gu_engine {
@@ -161,8 +171,6 @@ struct gu_engine {
     GuPaceEntry *d_pace_ring = nullptr;  // [36][GU_PACE_RING]
     uint64_t *d_pace_slots = nullptr;    // [36][2][pace_slot_stride] the waves' reports (allocated with the ring)
     int64_t pace_slot_stride = 0;
-    uint4 *d_pace_waves = nullptr;       // per-wave records of the last paced launch (allocated by the first gu_rollout_pace_waves call)
-    int64_t pace_waves_cap = 0, pace_waves_last = 0;  // records the buffer holds / waves of the last launch that wrote into it
     hipEvent_t ev_cal[2] = {nullptr, nullptr};
     float pace_search_ms = 0.0f;       // gu_rollout_pace_search (the open-loop search of rounds 3 and 4, a measurement aid now):
     int32_t pace_search_launches = 0;  // what it cost this engine, summed

@@ -618,8 +618,6 @@ static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, 
     }
     pace->ring = ring;
     pace->slots = slots;
-    pace->waves = nullptr;
-    if (h->d_pace_waves && waves <= h->pace_waves_cap) pace->waves = h->d_pace_waves, h->pace_waves_last = waves;
     pace->seq = ++k.seq;
     pace->period = k.model;
     pace->lo = std::max<uint32_t>(1u, k.model * 3u / 4u);
@@ -632,6 +630,7 @@ static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, 
     pace->gain_q = (uint32_t)gu_opt(h, GU_OPT_PACE_GAIN_Q);
     pace->dec_q = (uint32_t)gu_opt(h, GU_OPT_PACE_DEC_Q);
     pace->probe_every = (uint32_t)gu_opt(h, GU_OPT_PACE_PROBE_EVERY);
+    pace->adapt = (uint32_t)gu_opt(h, GU_OPT_PACE_ADAPT);
     pace->fixed = 0;
     return GU_OK;
 }

@@ -41,11 +41,12 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_VI_XCD_BLOCK", 0, 0, 1024},
     {"GU_PACE_TARGET", 7200, 100, 100000},
     {"GU_PACE_BAR_NUM", 20, 1, 256},
-    {"GU_PACE_GAIN_Q", 256, 1, 64 * 64},
-    {"GU_PACE_DEC_Q", 16, 0, 64},
+    {"GU_PACE_GAIN_Q", 128, 1, 64 * 64},
+    {"GU_PACE_DEC_Q", 8, 0, 64},
     {"GU_TRAJ_LAYOUT", -1, -1, 1},
     {"GU_PACE_RECORD", 1, 0, 1},
     {"GU_PACE_PROBE_EVERY", 1024, 0, 1 << 24},
+    {"GU_PACE_ADAPT", 1, 0, 1},
 };
 const char *g_spec_x[GU_OPT_X_COUNT] = {"GU_TRAJ_UNCACHED", "GU_TRAJ_POISON", "GU_MC_POISON"};
 

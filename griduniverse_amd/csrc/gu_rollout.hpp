@@ -44,13 +44,13 @@ __device__ __forceinline__ uint32_t gu_sample_action(uint32_t word, const uint4 
 //    then held it open loop.  Now every launch kind of an engine owns a ring of launch records and two sets of per-wave slots in
 //    device memory (gu_internal.hpp: GuPaceEntry).  A few groups before its end every wave stores ONE word into its own slot: was
 //    it more than two periods behind its schedule, and by how much.  The FIRST WAVE of the next launch of the kind -- in the time
-//    it would otherwise sleep away behind its first group -- sums the slots and writes the period of the launch after it into
-//    that launch's record (GuPacer::decide); every wave of a launch reads its launch's record when it starts.  No host round
+//    before its own first step -- sums the slots and writes the period of the launch after it into that launch's record
+//    (GuPacer::decide); every wave of a launch reads its launch's record when it starts.  No host round
 //    trip, no dedicated launch, no snapshot, no atomics, nobody waits for anybody; what a launch does is felt two launches later.
 //    The first launch of a kind starts from a model (the rows of 16 steps at 7.2 TB/s).
 //  * THE RULE.  Per launch:   period += gain x (share of the waves more than two periods behind)  -  dec     (1/64 ticks)
 //    -- stochastic approximation (Robbins-Monro): the period settles where the MEAN share of waves behind is dec / gain (the
-//    defaults: 16 / 256 = 6 %).  Why the share of waves: near the cliff of this memory launches fall behind sporadically -- a
+//    defaults: 8 / 128 = 6 %).  Why the share of waves: near the cliff of this memory launches fall behind sporadically -- a
 //    few per cent of them even 10 ticks above it, a workgroup or two each time, 4 .. 8 us late (0.5 % of the waves on average) --
 //    while below it most waves of every launch do; the mean share rises from 0.5 % to 3 % to > 50 % within ten ticks, so 6 % is
 //    reached within a tick or two of the period at which the mean launch time is shortest, on every allocation, and five times the
@@ -61,99 +61,112 @@ __device__ __forceinline__ uint32_t gu_sample_action(uint32_t word, const uint4 
 // launches and stayed there.  Version 2 stepped up by two ticks per launch behind and down by 1/32 tick: 4 ticks = 2.3 % above
 // the best fixed period, because a launch behind costs 8 us here, not the 35 us that ratio was chosen for.  Version 3 stepped up
 // in proportion to the slowest wave's distance behind: the background events alone held it 6 ticks above the best period.)
+// sum / maximum of a 32-bit value over the wave, in lane 63: DPP row shifts inside each row of 16 lanes, then the two row
+// broadcasts of the gfx9 family -- register moves inside the SIMD (six instructions per reduction; a __shfl_xor butterfly is six
+// dependent ds_bpermute round trips, ~0.2 us each way of a wave that has its SIMD alone)
+#define GU_DPP_REDUCE(x, OP)                                                                                     \
+    do {                                                                                                         \
+        uint32_t o_;                                                                                             \
+        o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x111, 0xF, 0xF, false), (x) = OP((x), o_);      \
+        o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x112, 0xF, 0xF, false), (x) = OP((x), o_);      \
+        o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x114, 0xF, 0xF, false), (x) = OP((x), o_);      \
+        o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x118, 0xF, 0xF, false), (x) = OP((x), o_);      \
+        o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x142, 0xA, 0xF, false), (x) = OP((x), o_);      \
+        o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x143, 0xC, 0xF, false), (x) = OP((x), o_);      \
+    } while (0)
+#define GU_OP_ADD(a_, b_) ((a_) + (b_))
+#define GU_OP_MAX(a_, b_) ((a_) > (b_) ? (a_) : (b_))
+
 struct GuPacer {
     uint64_t due, t0;
     uint32_t ticks;
-    uint32_t n_groups, n_late;  // scalar: groups done, groups begun behind schedule
-    uint32_t report_at;         // the wave reports behind the group that completes this many steps (0: it has, or there is nothing to report to)
+    uint32_t report_at;  // the wave reports behind the group that completes this many steps (0: it has, or there is nothing to report to)
     uint32_t n_steps;
     uint32_t p_q;
-    uint32_t deciding;          // 1: this is the launch's first wave and it has not summed the launch before yet
-    uint64_t *slot;             // this wave's slot in the launch's set
-#ifdef GU_PACE_WAVE_RECORDS  // (a variant build for tools/pace_loop.py --waves: `make variant VARIANT=_waves EXTRA=-DGU_PACE_WAVE_RECORDS`)
-    uint4 *wave_rec;
-    uint32_t start_delay;
-#endif
+    uint64_t *slot;      // this wave's slot in the launch's set
+    // what the launch's first wave asks for at the very top of the kernel, to have it by the time it decides (start()): the first
+    // 1024 slots of the launch before (sixteen per lane), and the loop's state in this launch's and that launch's records
+    uint64_t w[16];
+    uint32_t c_seq, c_phase, c_left, c_ema_p, c_ema_u, v_period_q, v_seq, v_unpaced;
+    uint32_t c_dec_q, c_block_left, c_block_sum, c_block_n, c_last_mean, c_up;
+    uint64_t v_t_start;
+    bool first_wave;
     // at the very top of the kernel: ask for this launch's record, so that the answer is there when start() wants it
     __device__ __forceinline__ void fetch(const GuPaceArgs &pa, bool on)
     {
         ticks = on ? pa.period : 0u;
         p_q = pa.period << 6;
+        first_wave = false;
         if (on && pa.ring) {
             const GuPaceEntry *entry = pa.ring + (pa.seq & (GU_PACE_RING - 1u));
-            const bool mine = entry->seq == pa.seq;  // (scalar loads)
+            const GuPaceEntry *prev = pa.ring + ((pa.seq - 1u) & (GU_PACE_RING - 1u));
+            c_seq = entry->seq;  // (scalar loads, all of them)
+            const bool mine = c_seq == pa.seq;
             const uint32_t have = mine ? entry->period_q : 0u;
             const uint32_t unpaced = mine ? entry->unpaced : 0u;
+            c_phase = entry->phase, c_left = entry->left, c_ema_p = entry->ema_paced, c_ema_u = entry->ema_unpaced;
+            v_period_q = prev->period_q, v_seq = prev->seq, v_unpaced = prev->unpaced, v_t_start = prev->t_start;
             if (have && !pa.fixed) p_q = have;
             p_q = p_q < (pa.lo << 6) ? (pa.lo << 6) : p_q;
             p_q = p_q > (pa.hi << 6) ? (pa.hi << 6) : p_q;
             if (pa.fixed) p_q = pa.period << 6;
             ticks = (unpaced && !pa.fixed) ? 0u : (p_q + 32u) >> 6;
+            first_wave = blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) < 64u;
+            if (first_wave) {
+                c_dec_q = entry->dec_q, c_block_left = entry->block_left, c_block_sum = entry->block_sum, c_block_n = entry->block_n;
+                c_last_mean = entry->last_mean, c_up = entry->up;
+                const uint64_t *set = pa.slots + (size_t)((pa.seq - 1u) & 1u) * pa.slot_stride;
+#pragma unroll
+                for (uint32_t j = 0; j < 16u; ++j) {
+                    const uint32_t i = j * 64u + threadIdx.x;
+                    w[j] = i < pa.n_waves ? __builtin_nontemporal_load(set + i) : 0ull;
+                }
+            }
         }
     }
+    // right before the first step.  The launch's FIRST WAVE sums what the launch before this one reported and writes the record of
+    // the launch behind this one (decide).  Here, not in the step loop: inlined into the loop's back edge the same code cost
+    // every kernel 30 .. 50 registers and spills (packed rows: 43 -> 48 us per launch, profiles/r05f_pace_packed.txt); and with
+    // everything it reads asked for at the top of the kernel, because a wave that starts its steps 2 us late ends 2 us late when
+    // the launch runs without the limiter (nobody waits, nobody catches up: packed rows 42 -> 45 us).
     __device__ __forceinline__ void start(const GuPaceArgs &pa, bool on)
     {
         slot = nullptr;
-        n_groups = n_late = n_steps = 0;
+        n_steps = 0;
         report_at = 0;
-        deciding = 0;
         t0 = 0;
-#ifdef GU_PACE_WAVE_RECORDS
-        wave_rec = nullptr;
-        start_delay = 0;
-#endif
         if (on && pa.ring) {
-            GuPaceEntry *entry = pa.ring + (pa.seq & (GU_PACE_RING - 1u));
             const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
             slot = pa.slots + (size_t)(pa.seq & 1u) * pa.slot_stride + wave;
             report_at = pa.report_at;
             const uint64_t now = __builtin_amdgcn_s_memrealtime();
-            // (wave-uniform, and the compiler must know it: a flag derived from threadIdx would live in a vector register and turn
-            // every test of it into a divergent branch of the main loop)
-            deciding = (blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) < 64u) ? 1u : 0u;
-            if (deciding && threadIdx.x == 0) {  // this launch's record (the rest of it is there already unless this is the kind's first launch)
-                if (entry->seq != pa.seq) {
-                    entry->unpaced = 0, entry->phase = GU_PACE_NORMAL, entry->left = pa.probe_every ? 24u : 0u;
-                    entry->ema_paced = 0, entry->ema_unpaced = 0;
-                }
-                entry->period_q = p_q, entry->seq = pa.seq, entry->t_start = now;
-                entry->verdict = 0, entry->waves = 0, entry->elapsed = 0, entry->ended_late = 0, entry->max_behind = 0;
-            }
-#ifdef GU_PACE_WAVE_RECORDS
-            if (pa.waves) {
-                wave_rec = pa.waves + wave;
-                const uint64_t began = entry->seq == pa.seq ? entry->t_start : now;  // (as far as it is visible yet: a measurement aid)
-                start_delay = (uint32_t)(now - began);
-            }
-#endif
             due = t0 = now;
+            if (first_wave) decide(pa, now);
             return;
         }
         due = ticks ? __builtin_amdgcn_s_memrealtime() : 0ull;
     }
-    // The launch's first wave, once, in the time it would otherwise sleep: what the waves of the launch BEFORE this one reported
-    // (set (seq - 1) & 1), summed over the wave's lanes; that launch's log; how the launch BEHIND this one runs.  The set is
-    // cleared as it is read: the launch behind this one reports into it.
-    __device__ __forceinline__ void decide(const GuPaceArgs &pa)
+    // The launch's first wave, once: what the waves of the launch BEFORE this one reported (set (seq - 1) & 1), summed over the
+    // wave's lanes; that launch's log; how the launch BEHIND this one runs.  The set is cleared as it is read: the launch behind
+    // this one reports into it.
+    __device__ __forceinline__ void decide(const GuPaceArgs &pa, uint64_t now)
     {
-        deciding = 0;
         uint64_t *set = pa.slots + (size_t)((pa.seq - 1u) & 1u) * pa.slot_stride;
-        GuPaceEntry *prev = pa.ring + ((pa.seq - 1u) & (GU_PACE_RING - 1u));
         GuPaceEntry *cur = pa.ring + (pa.seq & (GU_PACE_RING - 1u));
+        GuPaceEntry *prev = pa.ring + ((pa.seq - 1u) & (GU_PACE_RING - 1u));
+        const bool fresh = c_seq != pa.seq;  // the kind's first launch on this shape: nobody wrote its record
         // the launch before: its schedule up to the report (0: it ran without the limiter, nobody was "behind")
-        const bool prev_ok = prev->seq + 1u == pa.seq;
-        const uint32_t prev_ticks = (prev_ok && !prev->unpaced) ? (pa.fixed ? pa.period : (prev->period_q + 32u) >> 6) : 0u;
+        const bool prev_ok = v_seq + 1u == pa.seq;
+        const uint32_t prev_ticks = (prev_ok && !v_unpaced) ? (pa.fixed ? pa.period : (v_period_q + 32u) >> 6) : 0u;
         const uint32_t scheduled = (prev_ticks * ((pa.report_at + 15u) & ~15u)) >> 4;
-        uint32_t waves = 0, far = 0, most = 0, longest = 0;
-        // sixteen slots per lane and round trip, all asked for before the first is looked at (a loop that waits for each load in
-        // turn keeps this wave 10 .. 30 us behind its schedule, and the launch ends when its last wave does: the first cut of this
-        // function added 8 us to every launch, profiles/r05d_pace_c3.txt)
+        uint32_t counts = 0, most = 0, longest = 0;  // counts: waves that reported << 16 | waves that were far behind
         for (uint32_t base = 0; base < pa.n_waves; base += 64u * 16u) {
-            uint64_t w[16];
+            if (base) {  // (batches of more than 1024 waves: the slots behind the first 1024, sixteen per lane and round trip)
 #pragma unroll
-            for (uint32_t j = 0; j < 16u; ++j) {
-                const uint32_t i = base + j * 64u + threadIdx.x;
-                w[j] = i < pa.n_waves ? __builtin_nontemporal_load(set + i) : 0ull;
+                for (uint32_t j = 0; j < 16u; ++j) {
+                    const uint32_t i = base + j * 64u + threadIdx.x;
+                    w[j] = i < pa.n_waves ? __builtin_nontemporal_load(set + i) : 0ull;
+                }
             }
 #pragma unroll
             for (uint32_t j = 0; j < 16u; ++j) {
@@ -161,57 +174,88 @@ struct GuPacer {
                 if (i < pa.n_waves) set[i] = 0;
                 const uint32_t reported = (uint32_t)(w[j] >> 63), elapsed = (uint32_t)w[j] & 0x7FFFFFFFu;
                 const uint32_t behind = (prev_ticks && elapsed > scheduled) ? elapsed - scheduled : 0u;
-                waves += reported;
-                far += (reported && behind > 2u * prev_ticks) ? 1u : 0u;
+                counts += (reported << 16) + ((reported && behind > 2u * prev_ticks) ? 1u : 0u);
                 most = behind > most ? behind : most;
                 longest = elapsed > longest ? elapsed : longest;
             }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            waves += __shfl_xor(waves, m);
-            far += __shfl_xor(far, m);
-            uint32_t o = __shfl_xor(most, m);
-            most = o > most ? o : most;
-            o = __shfl_xor(longest, m);
-            longest = o > longest ? o : longest;
-        }
-        if (threadIdx.x == 0) {
+        GU_DPP_REDUCE(counts, GU_OP_ADD);
+        GU_DPP_REDUCE(most, GU_OP_MAX);
+        GU_DPP_REDUCE(longest, GU_OP_MAX);
+        if (threadIdx.x == 63) {  // (the lane the reductions end in)
+            const uint32_t waves = counts >> 16, far = counts & 0xFFFFu;
             GuPaceEntry *next = pa.ring + ((pa.seq + 1u) & (GU_PACE_RING - 1u));
-            uint32_t n_q = cur->period_q, phase = cur->phase, left = cur->left, ema_p = cur->ema_paced, ema_u = cur->ema_unpaced;
+            uint32_t n_q = p_q, phase = GU_PACE_NORMAL, left = pa.probe_every ? (pa.probe_every < 128u ? pa.probe_every : 128u) : 0u, ema_p = 0, ema_u = 0;
+            uint32_t dec_q = pa.dec_q, block_left = GU_PACE_BLOCK, block_sum = 0, block_n = 0, last_mean = 0, up = 1;
+            if (!fresh) {
+                phase = c_phase, left = c_left, ema_p = c_ema_p, ema_u = c_ema_u;
+                dec_q = c_dec_q, block_left = c_block_left, block_sum = c_block_sum, block_n = c_block_n, last_mean = c_last_mean, up = c_up;
+            } else {
+                cur->unpaced = 0, cur->phase = phase, cur->left = left, cur->ema_paced = 0, cur->ema_unpaced = 0;
+                cur->dec_q = dec_q, cur->block_left = block_left, cur->block_sum = 0, cur->block_n = 0, cur->last_mean = 0, cur->up = up;
+            }
+            cur->period_q = p_q, cur->seq = pa.seq, cur->t_start = now;
+            cur->verdict = 0, cur->waves = 0, cur->elapsed = 0, cur->ended_late = 0, cur->max_behind = 0;
             if (waves && prev_ok) {
                 prev->verdict = (uint64_t)most * 256u > (uint64_t)prev_ticks * pa.groups * pa.bar_num ? 2u : 1u;
                 prev->waves = waves, prev->elapsed = longest, prev->ended_late = far, prev->max_behind = far ? most : 0u;
-                if (prev->unpaced) {
-                    ema_u = ema_u ? (ema_u + longest) >> 1 : longest;
+                // the launch before, from its start to this launch's: what a caller who launches back to back pays per launch.  (A
+                // gap on the host stretches it: an interval of more than twice the mean is not taken in.)
+                const uint64_t gap = now - v_t_start;
+                const uint32_t mean = v_unpaced ? ema_u : ema_p;
+                const uint32_t took = gap > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)gap;
+                const bool plausible = v_t_start && (!mean || took < 2u * mean);
+                if (v_unpaced) {
+                    if (plausible) ema_u = ema_u ? (ema_u + took) >> 1 : took;
                 } else {
-                    ema_p = ema_p ? (ema_p * 7u + longest) >> 3 : longest;
+                    if (plausible) ema_p = ema_p ? (ema_p * 7u + took) >> 3 : took;
                     // THE RULE (above): up by the share of waves that fell behind, down by a fraction of a tick
-                    const uint32_t up = (uint32_t)(((uint64_t)pa.gain_q * far) / waves);
+                    const uint32_t step_up = (uint32_t)(((uint64_t)pa.gain_q * far) / waves);
                     const uint32_t early = 512u / (8u + (pa.seq > 100000u ? 100000u : pa.seq));  // 64 x 8 / (8 + seq)
-                    const uint32_t dec = early > pa.dec_q ? early : pa.dec_q;
-                    n_q += up;
+                    const uint32_t dec = early > dec_q ? early : dec_q;
+                    n_q += step_up;
                     n_q = n_q > dec ? n_q - dec : n_q;
+                    // THE SLOW LOOP AROUND IT: which share of waves behind is the best one to AIM for differs from buffer to buffer
+                    // (how often a launch falls behind at a given distance from the cliff, and what that costs: on one allocation
+                    // the rule's 6 % held the period 8 ticks = 3 % above the best one, profiles/r05f_pytest_slow_buffer.txt).  What
+                    // counts is the time from one launch's start to the next one's, and the first wave sees it: blocks of 192
+                    // launches (the last 128 counted), each with its own aim -- dec_q moves by a factor of 3/2 per block, in the
+                    // direction of the last move while the block's mean interval got shorter, the other way when it got longer.
+                    if (phase == GU_PACE_NORMAL && !pa.fixed && pa.adapt) {
+                        if (block_left <= GU_PACE_BLOCK - GU_PACE_BLOCK_SKIP && plausible) block_sum += took, ++block_n;
+                        if (block_left) --block_left;
+                        if (!block_left) {
+                            const uint32_t mean = block_n ? block_sum / block_n : 0u;
+                            if (mean && last_mean && mean > last_mean) up ^= 1u;
+                            if (mean) last_mean = mean;
+                            dec_q = up ? (dec_q * 3u + 1u) / 2u : (dec_q * 2u) / 3u;
+                            dec_q = dec_q < 4u ? 4u : dec_q;
+                            dec_q = dec_q > pa.gain_q / 4u ? pa.gain_q / 4u : dec_q;  // (aims of 4 / gain .. 25 %)
+                            block_left = GU_PACE_BLOCK, block_sum = 0, block_n = 0;
+                        }
+                    }
                 }
             }
             n_q = n_q < (pa.lo << 6) ? (pa.lo << 6) : n_q;
             n_q = n_q > (pa.hi << 6) ? (pa.hi << 6) : n_q;
             // DOES THE LIMITER PAY AT ALL?  A kind bound by its own dependent chain, not by the memory (packed rows at one wave per
-            // SIMD: 44 us without the limiter, 48 at the period the rule settles on -- the waves' natural pace) is better off
-            // without it.  So every `probe_every` launches (the first time after 24) three launches run without the limiter; when
-            // they reach their report quicker (by 1 %) than the launches with it do on average, the kind runs WITHOUT it, and the
-            // limiter gets six launches to prove itself again every 2 x probe_every.  Three launches in a thousand: 0.04 % of a
-            // kind that is better off with the limiter.
+            // SIMD: 42 us without the limiter, 48 at the period the rule settles on -- the waves' natural pace) is better off
+            // without it.  So every `probe_every` launches (the first time after 128, when the period has come down from the model)
+            // four launches run without the limiter; when they come round quicker (by 2 %, start to start) than the launches with
+            // it do on average, the kind runs WITHOUT it, and the limiter gets eight launches to prove itself again every
+            // 2 x probe_every.  Four launches in a thousand: 0.05 % of a kind that is better off with the limiter.
             if (pa.probe_every && !pa.fixed && left && --left == 0u) {
-                const bool off_wins = ema_u && ema_p && (uint64_t)ema_u * 100u < (uint64_t)ema_p * 99u;
-                if (phase == GU_PACE_NORMAL) phase = GU_PACE_PROBE_OFF, left = 3u, ema_u = 0u;
-                else if (phase == GU_PACE_OFF) phase = GU_PACE_PROBE_ON, left = 6u, ema_p = 0u;
+                const bool off_wins = ema_u && ema_p && (uint64_t)ema_u * 100u < (uint64_t)ema_p * 98u;
+                if (phase != GU_PACE_NORMAL || off_wins) block_left = GU_PACE_BLOCK, block_sum = 0, block_n = 0, last_mean = 0;  // (a block starts over behind a probe)
+                if (phase == GU_PACE_NORMAL) phase = GU_PACE_PROBE_OFF, left = 4u, ema_u = 0u;
+                else if (phase == GU_PACE_OFF) phase = GU_PACE_PROBE_ON, left = 8u, ema_p = 0u;
                 else if (off_wins) phase = GU_PACE_OFF, left = 2u * pa.probe_every;
                 else phase = GU_PACE_NORMAL, left = pa.probe_every;
             }
             next->period_q = n_q, next->seq = pa.seq + 1u, next->t_start = 0;
             next->unpaced = (phase == GU_PACE_PROBE_OFF || phase == GU_PACE_OFF) ? 1u : 0u;
             next->phase = phase, next->left = left, next->ema_paced = ema_p, next->ema_unpaced = ema_u;
+            next->dec_q = dec_q, next->block_left = block_left, next->block_sum = block_sum, next->block_n = block_n, next->last_mean = last_mean, next->up = up;
             next->verdict = 0, next->waves = 0, next->elapsed = 0, next->ended_late = 0, next->max_behind = 0;
         }
     }
@@ -220,45 +264,33 @@ struct GuPacer {
     __device__ __forceinline__ void report(uint64_t now)
     {
         if ((threadIdx.x & 63u) == 0u) {
-            const uint32_t late_q = n_groups ? (n_late * 64u) / n_groups : 0u;
             const uint64_t elapsed = now - t0;
-            *slot = (1ull << 63) | ((uint64_t)late_q << 32) | (elapsed > 0x7FFFFFFFull ? 0x7FFFFFFFull : elapsed);
-#ifdef GU_PACE_WAVE_RECORDS
-            if (wave_rec) *wave_rec = make_uint4(n_late, n_groups, (uint32_t)elapsed, start_delay);
-#endif
+            *slot = (1ull << 63) | (elapsed > 0x7FFFFFFFull ? 0x7FFFFFFFull : elapsed);
         }
         report_at = 0;
     }
-    // `steps` steps have just been done (rows stored): wait until their time is up.  MAIN: the call sites in a kernel's main loop --
-    // the only ones that carry the first wave's decide().
-    template <bool MAIN = false>
-    __device__ __forceinline__ void after(uint32_t steps, const GuPaceArgs &pa)
+    // `steps` steps have just been done (rows stored): wait until their time is up
+    __device__ __forceinline__ void after(uint32_t steps)
     {
         if (ticks) {
             due += (ticks * steps) >> 4;
-            if (MAIN && __builtin_expect(__builtin_amdgcn_readfirstlane(deciding) != 0u, 0)) decide(pa);  // (readfirstlane: wave-uniform; the branch must be a scalar one)
             const uint64_t now = __builtin_amdgcn_s_memrealtime();
-            const bool late = (int64_t)(now - due) >= 0;
-            ++n_groups;
-            n_late += late;
             n_steps += steps;
-            if (__builtin_expect(__builtin_amdgcn_readfirstlane(report_at) != 0u && n_steps >= report_at, 0)) report(now);
+            if (__builtin_expect(report_at != 0u && n_steps >= report_at, 0)) report(now);
             // (bounded: an `s_sleep 1` takes ~30 ns = 3 ticks, so a wait of one period ends within ticks / 3 turns; a clock that does
             // not advance must slow the launch down, not hang it)
-            if (!late)
+            if ((int64_t)(now - due) < 0)
                 for (uint32_t turn = 0; turn < 2u * ticks + 64u && (int64_t)(__builtin_amdgcn_s_memrealtime() - due) < 0; ++turn)
                     __builtin_amdgcn_s_sleep(1);
         } else if (slot) {  // a launch without the limiter that is part of the loop: no clock but for its one report
             n_steps += steps;
-            if (MAIN && __builtin_expect(__builtin_amdgcn_readfirstlane(deciding) != 0u, 0)) decide(pa);
-            if (__builtin_expect(__builtin_amdgcn_readfirstlane(report_at) != 0u && n_steps >= report_at, 0)) report(__builtin_amdgcn_s_memrealtime());
+            if (__builtin_expect(report_at != 0u && n_steps >= report_at, 0)) report(__builtin_amdgcn_s_memrealtime());
         }
     }
-    // the wave leaves (a launch too short, or too oddly aligned, to have reached report_at -- or its decide() -- does both now)
-    __device__ __forceinline__ void finish(const GuPaceArgs &pa)
+    // the wave leaves (a launch too short, or too oddly aligned, to have reached report_at reports now)
+    __device__ __forceinline__ void finish()
     {
         if (slot && report_at) report(__builtin_amdgcn_s_memrealtime());
-        if (slot && deciding) decide(pa);
     }
 };
 
@@ -530,14 +562,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                     i += 8, t += 8;
                 }
                 for (; i < a.T && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
-                pacer.after((uint32_t)i, a.pace);
+                pacer.after((uint32_t)i);
             }
             for (; i + 16 <= a.T; i += 16, t += 16) {  // body: 16 steps per word, fully unrolled
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
 #pragma unroll
                 for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32);
                 if (TRAJ) rebase(16);
-                if (i + 16 < a.T) pacer.after<true>(16, a.pace);  // (nothing to wait for behind the last group)
+                if (i + 16 < a.T) pacer.after(16);  // (nothing to wait for behind the last group)
             }
             if (i < a.T) {  // tail
                 const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
@@ -595,7 +627,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
 #pragma unroll
                     for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32);
                     if (TRAJ) rebase(16);
-                    pacer.after<true>(16, a.pace);
+                    pacer.after(16);
                     word = next;
                 }
                 for (int64_t q = k * 16, j = 0; q < steps; ++q, ++j) step1((word >> (2u * (uint32_t)j)) & 3u);  // tail of the stream
@@ -608,7 +640,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
 #pragma unroll
                     for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32);
                     if (TRAJ) rebase(16);
-                    pacer.after<true>(16, a.pace);
+                    pacer.after(16);
                 },
                 step1);
         }
@@ -665,7 +697,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                     tstep(0, ask);
                     if (TRAJ) rebase(1);
                 }
-                if (i) pacer.after((uint32_t)i, a.pace);
+                if (i) pacer.after((uint32_t)i);
                 constexpr uint32_t G = GU_RNG_SAMPLE_MASK + 1u < 8u ? 8u : GU_RNG_SAMPLE_MASK + 1u;  // steps per unrolled group
                 for (; i + G <= a.T; i += G) {
 #pragma unroll
@@ -674,14 +706,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                         else tstep(j * trow32, same_word);
                     }
                     if (TRAJ) rebase(G);
-                    if (i + G < a.T) pacer.after<true>(G, a.pace);
+                    if (i + G < a.T) pacer.after(G);
                 }
             } else {
                 for (; i + 8 <= a.T; i += 8) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) tstep(j * trow32, ask);
                     if (TRAJ) rebase(8);
-                    if (i + 8 < a.T) pacer.after<true>(8, a.pace);
+                    if (i + 8 < a.T) pacer.after(8);
                 }
             }
             for (; i < a.T; ++i) {
@@ -692,7 +724,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         if (thr_in_lds) run([thr_lds](int32_t at) { return thr_lds[at]; });
         else run([&a](int32_t at) { return a.pi_thr[at]; });
     }
-    pacer.finish(a.pace);
+    pacer.finish();
     a.pos[e] = s;
     a.reward[e] = r;
     a.done[e] = (int32_t)d;

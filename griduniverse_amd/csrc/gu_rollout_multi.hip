@@ -17,7 +17,7 @@
 // state are all that is kept.  Steps that do not fill a group -- the first step of a launch (on the per-cell planes: a stored
 // state may disagree with its cell), the steps up to the next multiple of K of the env's step counter, the last T mod K --
 // run on a one-step table of the same format that sits behind the K-step table in LDS.
-// Results are bit-identical to the other two kernels (tests/test_gpu_round2.py).
+// Results are bit-identical to the other two kernels (tests/test_gpu_kstep_kernel.py).
 #include "gu_rollout.hpp"
 
 #define GU_MROW_ADDR_MASK 0x3FFFFu

@@ -31,7 +31,7 @@
 // chain is long (sampled policy at 65 536 envs: 130 against 128; 110 against 117 at 32 768): profiles/r04s_rows_store_waves_ab.json.
 // Removed again; the sampled launch with int32 rows stays bound by its one wave per SIMD issuing chain and stores in order.
 //
-// Results are bit-identical to the general kernel (tests/test_gpu_round2.py runs both on the same seeds); the launcher
+// Results are bit-identical to the general kernel (tests/test_gpu_rows_kernel.py runs both on the same seeds); the launcher
 // picks this one where it is faster (profiles/archive/r02b_map_ab.txt, profiles/archive/r02d_rows_crossover.txt).
 #include "gu_rollout.hpp"
 
@@ -360,13 +360,13 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             if (t & 15u) {  // head: finish the current word
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
                 for (; i < a.T && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
-                pacer.after((uint32_t)i, a.pace);
+                pacer.after((uint32_t)i);
             }
             for (; i + 16 <= a.T; i += 16, t += 16) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
                 word16(word);
                 if (TRAJ) rebase(16);
-                if (i + 16 < a.T) pacer.after<true>(16, a.pace);  // (gu_rollout.hpp: GuPacer)
+                if (i + 16 < a.T) pacer.after(16);  // (gu_rollout.hpp: GuPacer)
             }
             if (i < a.T) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
                 pstep(0);
                 if (TRAJ) rebase(1);
             }
-            if (i > 1) pacer.after((uint32_t)i, a.pace);
+            if (i > 1) pacer.after((uint32_t)i);
             constexpr uint32_t G = GU_RNG_SAMPLE_MASK + 1u < 8u ? 8u : GU_RNG_SAMPLE_MASK + 1u;  // steps per unrolled group
             for (; i + G <= a.T; i += G) {
 #pragma unroll
@@ -421,14 +421,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
                     ++t;
                 }
                 if (TRAJ) rebase(G);
-                if (i + G < a.T) pacer.after<true>(G, a.pace);
+                if (i + G < a.T) pacer.after(G);
             }
         } else {
             for (; i + 8 <= a.T; i += 8) {
 #pragma unroll
                 for (uint32_t j = 0; j < 8; ++j) pstep(j * trow32);
                 if (TRAJ) rebase(8);
-                if (i + 8 < a.T) pacer.after<true>(8, a.pace);
+                if (i + 8 < a.T) pacer.after(8);
             }
         }
         for (; i < a.T; ++i) {
@@ -442,12 +442,12 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             [&](uint32_t word) {
                 word16(word);
                 if (TRAJ) rebase(16);
-                pacer.after<true>(16, a.pace);
+                pacer.after(16);
             },
             step1);
     }
     emit(rec, 0);  // the last step's record (row T - 1: every loop above leaves the row base one step behind)
-    pacer.finish(a.pace);
+    pacer.finish();
     // resets performed = steps that started from a done env = (done at entry: counted in first_step) + done flags seen
     // on every step but the last
     const uint32_t d_last = __builtin_amdgcn_ubfe(rec, GU_ROW_DONE_BIT, 1);

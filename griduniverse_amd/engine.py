@@ -263,19 +263,21 @@ class Engine(object):
             return None
         check(rc)
         e = buf[:n.value].astype(np.int64)
-        return dict(seq=e[:, 0], period=e[:, 1] / 64.0, verdict=e[:, 2] & 0xFF, phase=e[:, 2] >> 8, waves=e[:, 3], elapsed=e[:, 4],
+        return dict(seq=e[:, 0], period=e[:, 1] / 64.0, verdict=e[:, 2] & 0xFF, phase=(e[:, 2] >> 8) & 0xFF, dec_q=e[:, 2] >> 16, waves=e[:, 3], elapsed=e[:, 4],
                     ended_late=e[:, 5], max_behind=e[:, 6], interval=e[:, 7], launches=launches.value)
 
-    def rollout_pace_waves(self):
-        """MEASUREMENT AID: per wave of the last paced launch, int64[waves, 4]: groups begun behind schedule, groups, ticks behind
-        schedule at the end, ticks from the launch's start to the wave's.  The first call switches the recording on (empty)."""
+    def rollout_pace_waves(self, policy='uniform', auto_reset=True, packed=False):
+        """MEASUREMENT AID: what every wave of this kind's last launch reported: int64[waves] ticks (10 ns) from the wave's start to
+        its report a few groups before the end of the launch (0 = did not report).  None when the kind keeps no schedule."""
         cap = (self.N + 63) // 64
-        buf = np.zeros((cap, 4), dtype=np.uint32)
+        buf = np.zeros(cap, dtype=np.uint32)
         n = ctypes.c_int32(0)
-        check(self.lib.gu_rollout_pace_waves(self._h, cap, buf.ctypes.data, ctypes.byref(n)))
-        out = buf[:n.value].astype(np.int64)
-        out[:, 2] = buf[:n.value, 2].view(np.int32)
-        return out
+        rc = self.lib.gu_rollout_pace_waves(self._h, _POLICIES[policy], (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_PACKED if packed else 0), cap,
+                                            buf.ctypes.data, ctypes.byref(n))
+        if rc == -4:
+            return None
+        check(rc)
+        return buf[:n.value].astype(np.int64)
 
     def rollout_pace_search(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
         """MEASUREMENT AID (include/gu.h: gu_rollout_pace_search): the open-loop period search of rounds 3 and 4 on a snapshot of the

@@ -107,27 +107,14 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_TRAJ_FAR_CANDIDATES 14 /* candidates behind spacers (0 = none, the default)                                       */
 #define GU_OPT_TRAJ_STRIDE_MIB 15     /* spacer size (3072)                                                                   */
 #define GU_OPT_TRAJ_FAR_MIB 16        /* most memory the search may hold at once (49152)                                      */
-#define GU_OPT_TRAJ_PROBE_ALL 17      /* 1 = probe every candidate, no early stop (measurement aid)                           */
 #define GU_OPT_ROLLOUT_PACE 18        /* store pacing of launches that write rows: -1 = closed loop (default, see gu_rollout_pacing),
                                          0 = none, n = fixed period of n 10 ns ticks per 16 steps (-2: accepted, same as -1) */
 #define GU_OPT_VI_XCD_BLOCK 19        /* workgroup size of the per-XCD form of gu_vi_sweep_step_run: 256, 512, 1024 (0 = by batch size) */
-#define GU_OPT_PACE_TARGET 20         /* closed-loop store pacing: GB/s of rows the first launch of a kind is scheduled for (7200)  */
-#define GU_OPT_PACE_BAR_NUM 21        /* ... the log calls a launch BEHIND when a wave was more than this many 256ths of the schedule late (20) */
-#define GU_OPT_PACE_GAIN_Q 22         /* ... 1/64 ticks: the period's step up after a launch whose waves ALL fell behind (256); a share of
-                                         the waves: that share of it                                                          */
-#define GU_OPT_PACE_DEC_Q 23          /* ... 1/64 ticks: what the period comes down by, every launch (16)                           */
 #define GU_OPT_TRAJ_LAYOUT 24         /* device layout of the int32 trajectory: 0 = three planes [T][N], 1 = one plane of (obs, reward,
                                          done) triples [T][N][3] written with one 12-byte store per lane and step, -1 (default) =
                                          triples where they are faster (small batches under the uniform policy); what
                                          gu_read_trajectory, gu_mc_evaluate and the host see does not change                   */
-#define GU_OPT_PACE_RECORD 25         /* 0 = launches with a FIXED period keep no record (measurement aid: what the records cost)   */
-#define GU_OPT_PACE_PROBE_EVERY 26    /* launches between two looks at whether the limiter pays at all: three launches without it while it
-                                         is on, six with it (every 2 x this) while it is off (1024; 0 = never: the limiter stays on)   */
-#define GU_OPT_COUNT 27
-#define GU_OPT_X_TRAJ_UNCACHED 100    /* EXPERIMENT: uncached memory type for the trajectory (readers may see stale bytes)    */
-#define GU_OPT_X_TRAJ_POISON 101      /* EXPERIMENT: fill a fresh trajectory buffer with 0x5A                                 */
-#define GU_OPT_X_MC_POISON 102        /* EXPERIMENT: fill the Monte-Carlo scratch with 0x5A before every evaluation           */
-#define GU_OPT_X_COUNT 3
+#define GU_OPT_COUNT 28
 int gu_set_option(gu_handle h, int32_t option, int64_t value);
 int gu_get_option(gu_handle h, int32_t option, int64_t *value);   /* the value in force (own, process default or built-in) */
 
@@ -240,20 +227,12 @@ int gu_reserve_trajectory(gu_handle h, int64_t T);
  *   - looks at GU_OPT_TRAJ_CANDIDATES (4) back-to-back candidates; only when GU_OPT_TRAJ_FAR_CANDIDATES (0) is set and those were
  *     at least 6 % apart does it continue -- buffers of 256 MiB and more -- with that many more, each behind a spacer of
  *     GU_OPT_TRAJ_STRIDE_MIB (3072) that is held until the choice is made;
- *   - never holds more than a third of the device's free memory nor GU_OPT_TRAJ_FAR_MIB (48 GiB) at once, everything but the
+ *   - never holds more than a tenth of the device's free memory nor GU_OPT_TRAJ_FAR_MIB (48 GiB) at once, everything but the
  *     kept buffer is freed before the call returns;
  *   - is per-process aware: once an engine of the process owns a chosen trajectory buffer on the device, later engines
- *     probe at most 4 back-to-back candidates, hold at most an eighth of the free memory, and stop at the first
+ *     probe at most 4 back-to-back candidates, hold at most a sixteenth of the free memory, and stop at the first
  *     candidate within 3 % of the rate the first search ended on.
- * gu_trajectory_placement reports the outcome, gu_trajectory_placement_detail everything that was tried: per candidate its
- * probe time (ms per full write) and device address (capacity entries; *count = number tried), the index of the kept one,
- * the wall time the search took and the largest number of bytes it held at once.  Any pointer may be NULL.
- * gu_probe_trajectory re-runs the same timed write on the buffer the engine holds NOW (it overwrites the rows: for
- * measurements -- bench.py runs it right after its timed region to tell a drifting device from a slow kernel). */
-int gu_trajectory_placement(gu_handle h, int32_t *candidates, float *best_ms, float *worst_ms);
-int gu_trajectory_placement_detail(gu_handle h, int32_t capacity, float *probe_ms, uint64_t *address, int32_t *count,
-                                   int32_t *kept, float *search_ms, uint64_t *peak_bytes);
-int gu_probe_trajectory(gu_handle h, float *milliseconds);
+ * (What the search did, and the probe itself: gu_trajectory_placement* and gu_probe_trajectory, include/gu_diag.h.) */
 int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 /* Store pacing.  The HBM write path shows congestion collapse: lanes that hand their rows to the memory system as fast as it will
  * take them are served at 5.7 TB/s on most allocations, the same stores offered just below the memory's capacity at 7.2 .. 7.5 on
@@ -268,31 +247,8 @@ int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
  * neighbour on the device or a change of clocks moves the period instead of collapsing the stream for good.  Results never depend
  * on any of it.  GU_OPT_ROLLOUT_PACE = 0: no limiter; n > 0: that period, fixed.
  * gu_rollout_calibrate is gu_rollout (rounds 3 and 4 searched the period there; kept for callers that call it).
- * gu_rollout_pacing reports a launch kind's current period, the length of its schedule (ms_paced; ms_unpaced and
- * calibration_ms are 0), and how many launches of the kind have run on the current shape (`evaluated`); GU_ERR_STATE when the kind
- * keeps no schedule.  gu_rollout_pacing_totals: kinds with a schedule; ms and launches are what gu_rollout_pace_search
- * (include/gu_diag.h) spent, i.e. 0 unless a tool asked for a search. */
+ * (Where the loop stands, its records, and the open-loop search of rounds 3 and 4 as a measurement aid: include/gu_diag.h.) */
 int gu_rollout_calibrate(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
-int gu_rollout_pacing_totals(gu_handle h, float *calibration_ms, int32_t *launches_spent, int32_t *kinds_paced, int32_t *kinds_from_cache,
-                             int32_t *kinds_waiting);
-int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
-                      int32_t *evaluated, float *calibration_ms);
-/* The records of the last launches of a kind, oldest first (at most 61; waits for the stream): per launch eight 64-bit words --
- * launch number; period in 1/64 ticks (0: the launch ran without the limiter); verdict of the launch behind it (0 none yet, 1 on
- * schedule, 2 behind) | phase of the loop << 8 (0 limiter on, 1 three launches without it, 2 limiter off, 3 six launches with it);
- * waves that reported; ticks from start to report of the slowest wave; waves that were more than two periods behind; the most a
- * wave was behind (ticks); ticks from this launch's start to the next one's (0 for the last).  *launches = launches of the kind
- * on the current shape. */
-int gu_rollout_pace_log(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t capacity, uint64_t *entries, int32_t *count, uint32_t *launches);
-/* MEASUREMENT AID: one record per wave of the last paced launch -- four uint32: groups begun behind schedule, groups, ticks behind
- * schedule at the end (int32), ticks from the launch's first wave to this wave's start.  The first call only switches the
- * recording on (count 0). */
-int gu_rollout_pace_waves(gu_handle h, int32_t capacity, uint32_t *records, int32_t *count);
-/* MEASUREMENT AID: the open-loop search of rounds 3 and 4 (a few hundred full-size launches on a snapshot of the engine's state,
- * which is put back), followed by the rollout itself without a limiter.  Reports the period it would have installed; installs
- * nothing.  tests/test_gpu_store_pacing.py and tools/pace_loop.py hold the closed loop against it. */
-int gu_rollout_pace_search(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
-                           int32_t *launches, float *ms_spent);
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);
 int gu_read_trajectory_packed(gu_handle h, int64_t t0, int64_t T, uint32_t *packed);   /* [T][N] after GU_F_PACKED */
 int gu_read_stats(gu_handle h, int64_t *reward_sum, int32_t *episodes);
@@ -347,11 +303,6 @@ int gu_vi_greedy(gu_handle h, double gamma);
 int gu_vi_get(gu_handle h, double *v, double *pi);
 int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta);
 int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flags, double *deltas);
-int gu_vi_last_form(gu_handle h);
-/* ... and the last gu_vi_sweep / gu_vi_run / gu_vi_eval_run: 1 per XCD (one cluster's workgroups), 2 one workgroup, 3 chip-wide
- * cluster, 4 one launch per round (the form that finished the call; 0 = none yet). */
-int gu_vi_last_dp_form(gu_handle h);
-int gu_vi_last_clusters(gu_handle h, int32_t *members);
 
 /* ---- Monte-Carlo policy evaluation: core/algorithms/monte_carlo.py:29-99 ----------------
  * Consumes the trajectory rows 0..T-1 of the last gu_rollout (run WITHOUT auto-reset: env e is
@@ -407,16 +358,9 @@ int gu_render_policy_rgb(gu_handle h, int32_t cell_px, uint8_t *rgb);
 int gu_host_alloc(size_t bytes, void **ptr);
 int gu_host_free(void *ptr);
 
-/* ---- stream / timing -----------------------------------------------------------
- * HIP events on the handle's own stream (torch.cuda.Event cannot see it). */
+/* ---- stream ---------------------------------------------------------------------
+ * (HIP-event timers on the handle's own stream -- torch.cuda.Event cannot see it --: gu_timer_*, include/gu_diag.h.) */
 int gu_sync(gu_handle h);
-int gu_timer_begin(gu_handle h);
-int gu_timer_end(gu_handle h, float *milliseconds); /* records, waits, returns elapsed */
-/* Lap timing: gu_timer_mark records one event on the stream per call (async); gu_timer_laps waits for the last mark,
- * writes the count-1 intervals between consecutive marks (capacity = room in `milliseconds`, which may be NULL to
- * discard) and forgets the marks. */
-int gu_timer_mark(gu_handle h);
-int gu_timer_laps(gu_handle h, float *milliseconds, int32_t capacity, int32_t *count);
 
 /* ---- multi-GPU gathered view (RCCL over xGMI) ----------------------------------
  * One process per GPU.  Rank 0 calls gu_comm_unique_id and ships the 128 bytes to

@@ -1,4 +1,4 @@
-// fake_rccl.hip -- TEST DOUBLE for librccl (tests/test_gpu_round2.py only; never shipped, never loaded unless GU_RCCL_LIB
+// fake_rccl.hip -- TEST DOUBLE for librccl (tests/test_gpu_comm.py only; never shipped, never loaded unless GU_RCCL_LIB
 // names it).  Lets ONE GPU play several ranks: every rank is a thread of one process with its own libgu handle, and
 // ncclAllGather is a rendezvous of those threads followed by device-to-device copies.  It exists to run gu_comm_init with
 // nranks > 1 and the rank-major -> env-major unpack of gu_allgather_view on real hardware where only one device is at hand

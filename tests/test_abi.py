@@ -10,10 +10,16 @@ from griduniverse_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, 'include', 'gu.h')).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'^\s*int\s+(gu_\w+)\s*\(', text, flags=re.M)))
+def header_symbols(name=None):
+    """Entry points declared in include/gu.h (the surface a reference maintainer binds) and include/gu_diag.h (introspection and
+    measurement aids), or in one of the two."""
+    out = []
+    for header in ([name] if name else ['gu.h', 'gu_diag.h']):
+        text = open(os.path.join(ROOT, 'include', header)).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        out += re.findall(r'^\s*int\s+(gu_\w+)\s*\(', text, flags=re.M)
+    assert len(out) == len(set(out)), 'an entry point is declared twice'
+    return sorted(out)
 
 
 @pytest.fixture(scope='module')
@@ -26,9 +32,17 @@ def lib():
 def test_header_binding_and_library_agree(lib):
     declared = header_symbols()
     assert len(declared) >= 30
-    assert declared == sorted(_lib.SIGNATURES), 'python binding table differs from include/gu.h'
+    assert declared == sorted(_lib.SIGNATURES), 'python binding table differs from include/gu.h + include/gu_diag.h'
     for name in declared:
         assert hasattr(lib, name), 'libgu.so does not export ' + name
+    # the split: what a maintainer of the reference binds, and what only bench.py / tools / tests look at
+    surface, diag = header_symbols('gu.h'), header_symbols('gu_diag.h')
+    assert len(surface) >= 45 and 10 <= len(diag) <= 25
+    for name in ('gu_create', 'gu_set_grid', 'gu_set_grids', 'gu_seed', 'gu_reset', 'gu_step', 'gu_step_device', 'gu_rollout', 'gu_get_state', 'gu_set_state',
+                 'gu_done_indices', 'gu_vi_sweep', 'gu_allgather_view', 'gu_last_error', 'gu_version', 'gu_destroy'):
+        assert name in surface, name
+    for name in diag:
+        assert re.match(r'gu_(timer_|rollout_pac|vi_last_|trajectory_placement|probe_trajectory)', name), name + ' does not look like introspection'
 
 
 def test_version_and_error_text(lib):
@@ -103,7 +117,7 @@ def test_options_have_defaults_ranges_and_process_wide_values(lib):
     for name, builtin in (('rollout_block', 256), ('rollout_rows', -1), ('rollout_multi', -1), ('vi_path', 0), ('mc_scratch_mb', 2048),
                           ('traj_candidates', 4), ('traj_far_candidates', 0), ('rollout_pace', -1), ('traj_stride_mib', 3072), ('traj_far_mib', 49152),
                           ('step_sync', 0), ('rollout_xcd', 0), ('traj_probe_all', 0), ('vi_xcd_block', 0), ('pace_target', 7200), ('pace_bar_num', 20),
-                          ('pace_gain_q', 256), ('pace_dec_q', 16), ('traj_layout', -1), ('pace_record', 1), ('pace_probe_every', 1024)):
+                          ('pace_gain_q', 128), ('pace_dec_q', 8), ('traj_layout', -1), ('pace_record', 1), ('pace_probe_every', 1024), ('pace_adapt', 1)):
         assert _lib.get_default_option(name) == builtin, name
     _lib.set_default_option('rollout_block', 512)
     try:
@@ -114,7 +128,7 @@ def test_options_have_defaults_ranges_and_process_wide_values(lib):
     for name, bad in (('rollout_block', 100), ('rows_copies', 3), ('rollout_multi_k', 3), ('vi_path', 9), ('traj_candidates', 0), ('vi_xcd_block', 128)):
         with pytest.raises(_lib.GuError):
             _lib.set_default_option(name, bad)
-    assert sorted(v for v in _lib.OPTIONS.values() if v < 100) == list(range(1, 27))
+    assert sorted(v for v in _lib.OPTIONS.values() if v < 100) == list(range(1, 28))
 
 
 def test_the_product_library_has_no_code_for_the_unsafe_experiments(lib, monkeypatch):

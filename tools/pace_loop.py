@@ -25,6 +25,8 @@ ap.add_argument('--bar', type=int, default=None)
 ap.add_argument('--inc', type=int, default=None)
 ap.add_argument('--dec', type=int, default=None)
 ap.add_argument('--waves', type=int, default=0)
+ap.add_argument('--adapt', type=int, default=None)
+ap.add_argument('--summary', action='store_true', help='one line: mean wall us per launch over the second half of the run')
 ap.add_argument('--target', type=int, default=None)
 ap.add_argument('--sweep', type=int, nargs=3, default=None)
 ap.add_argument('--no-search', action='store_true')
@@ -46,7 +48,7 @@ policy = {'c3': 'uniform', 'c4': 'uniform', 'sample': 'sample', 'stream': 'strea
 traj = 'packed' if args.kind == 'packed' else True
 if args.candidates:
     _lib.set_default_option('traj_candidates', args.candidates)
-for name, v in (('pace_bar_num', args.bar), ('pace_gain_q', args.inc), ('pace_dec_q', args.dec), ('pace_target', args.target)):
+for name, v in (('pace_adapt', args.adapt), ('pace_bar_num', args.bar), ('pace_gain_q', args.inc), ('pace_dec_q', args.dec), ('pace_target', args.target)):
     if v is not None:
         _lib.set_default_option(name, v)
 
@@ -90,6 +92,7 @@ def chunk(eng, n, trace=None):
         trace['late_share'] += [int(x) for x in lg['phase'][-k:]]
         trace['behind_us'] += [round(float(x) / 100.0, 1) for x in lg['max_behind'][-k:]]
         trace['ended_late'] += [int(x) for x in lg['ended_late'][-k:]]
+        trace.setdefault('dec_q', []).extend(int(x) for x in lg['dec_q'][-k:])
     return wall, lg
 
 
@@ -106,6 +109,13 @@ while done < args.launches:
         sys.exit(1)
     chunks.append(round(wall, 2))
     done += n
+if args.summary:
+    half = chunks[len(chunks) // 2:]
+    per = np.array(trace['period'])
+    per = per[per > 0]
+    print('SUMMARY %s gain %s dec %s adapt %s: wall us per launch, second half of %d launches: mean %.2f min %.2f max %.2f | period p10 %.1f median %.1f p90 %.1f | probe %.4f' % (
+        args.kind, args.inc, args.dec, args.adapt, args.launches, np.mean(half), np.min(half), np.max(half), np.percentile(per[len(per) // 2:], 10),
+        np.median(per[len(per) // 2:]), np.percentile(per[len(per) // 2:], 90), eng.trajectory_placement()[1]))
 print('== loop: %s, %d envs x %d steps, fresh engine, %d launches' % (args.kind, N, T, args.launches))
 print('   placement', eng.trajectory_placement(), 'totals', eng.rollout_pacing_totals())
 print('   first 40 launches: period       ', trace['period'][:40])
@@ -124,29 +134,26 @@ for a, b in ((0, 6), (6, 32), (32, 100), (100, 300), (300, 600), (600, 1200), (1
         print('   launches %4d .. %4d: start-to-start us median %.2f mean %.2f max %.2f   periods %.1f .. %.1f   launches behind: %d' % (
             a, b - 1, np.median(seg), seg.mean(), seg.max(), per[a:b][per[a:b] > 0].min() if (per[a:b] > 0).any() else 0, per[a:b].max(), int((ver[a:b] == 2).sum())))
 print('   wall us per launch by chunk of 60 (events):', chunks)
+print('   the aim (dec_q, 1/64 ticks per launch) every 192 launches:', trace['dec_q'][::192])
 out['loop'] = dict(trace=trace, wall_us_by_chunk=chunks)
 
 # ---- what a launch that is behind looks like, wave by wave (launches one at a time) ----------------------------
 if args.waves:
-    eng.rollout_pace_waves()  # switches the per-wave records on
     shown = 0
-    stats = []
+    mb = []
     for i in range(args.waves):
         eng.rollout(T, policy, True, traj)
-        w = eng.rollout_pace_waves()
-        behind = w[:, 2]
-        stats.append((int(behind.max()), int((behind > 0).sum())))
-        if behind.max() > 500 and shown < 6:
+        el = eng.rollout_pace_waves(policy, True, packed=(traj == 'packed'))
+        el = el[el > 0]
+        mb.append(int(el.max() - np.median(el)))
+        if mb[-1] > 500 and shown < 6:
             shown += 1
-            pc = np.percentile(behind, [0, 10, 50, 90, 99, 100]).astype(int)
-            late_sh = w[:, 0] / np.maximum(1, w[:, 1])
-            order = np.argsort(-behind)[:8]
-            print('   launch %d one at a time: ticks behind at the end over %d waves: min %d p10 %d median %d p90 %d p99 %d max %d; waves > 500 behind: %d; '
-                  'late share median %.3f max %.3f; start delay max %d ticks; worst waves %s (block %s)' % (
-                      i, len(w), pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], int((behind > 500).sum()), np.median(late_sh), late_sh.max(), int(w[:, 3].max()),
-                      order.tolist(), (order // 4).tolist()))
-    mb = np.array([x[0] for x in stats])
-    print('== one at a time, %d launches: max-behind ticks median %d p90 %d max %d; launches with a wave > 500 ticks behind: %d' % (
+            pc = np.percentile(el, [0, 10, 50, 90, 99, 100]).astype(int)
+            order = np.argsort(-el)[:8]
+            print('   launch %d one at a time: ticks from start to report over %d waves: min %d p10 %d median %d p90 %d p99 %d max %d; worst waves %s (workgroup %s)' % (
+                i, len(el), pc[0], pc[1], pc[2], pc[3], pc[4], pc[5], order.tolist(), (order // 4).tolist()))
+    mb = np.array(mb)
+    print('== one at a time, %d launches: slowest wave minus median wave, ticks: median %d p90 %d max %d; launches > 500: %d' % (
         args.waves, np.median(mb), np.percentile(mb, 90), mb.max(), int((mb > 500).sum())))
 
 # ---- sweep: fixed periods on the same engine ----------------------------------------------------------------

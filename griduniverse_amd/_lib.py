@@ -89,8 +89,11 @@ SIGNATURES = {
     'gu_vi_sweep_step_run': [_vp, _f64, _i32, _u32, _vp],
     'gu_vi_last_form': [_vp],
     'gu_vi_last_dp_form': [_vp],
+    'gu_vi_xcd_torn_words': [_vp, _vp],
     'gu_vi_last_clusters': [_vp, _vp],
     'gu_mc_evaluate': [_vp, _i64, _vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp],
+    'gu_mc_walk_lengths': [_vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp, _vp],
+    'gu_mc_walk_episodes': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i64],
     'gu_shortest_paths': [_vp, _i32, _vp, _vp, _vp],
     'gu_render_rgb': [_vp, _i64, _i64, _i32, _vp],
     'gu_trail_enable': [_vp, _i32],

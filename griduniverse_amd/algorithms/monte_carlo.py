@@ -124,6 +124,76 @@ def reference_rng_episodes(policy, env, num_episodes, max_steps_per_episode=1000
     return np.asarray(first, np.int32), actions, np.asarray(lengths, np.int32), states, bool(done)
 
 
+def reference_rng_offsets(policy, env, eng, num_episodes, max_steps_per_episode=1000):
+    """The reference's episodes WITHOUT walking them on the host (csrc/gu_mc_ref.hip): start cells from the stdlib's global stream
+    (one env.reset() per episode -- a stream of its own, so all of them can be drawn first), uniforms of numpy's global stream drawn
+    in bulk; the device walks the episode that would begin at EVERY offset of a block of uniforms (gu_mc_walk_lengths), the host
+    follows the chain offset -> offset + length, one table look-up per episode, drawing further blocks while episodes are left; the
+    global stream ends exactly where the reference leaves it.  Returns (first_state, offsets, lengths, uniforms, cdf), or None when
+    a policy row is no distribution (np.random.choice raises for it the moment an episode draws from it: the host walk knows how)."""
+    p = np.asarray(policy, dtype=np.float64)
+    if not (np.isfinite(p).all() and (p >= 0).all() and (np.abs(p.sum(axis=1) - 1.0) <= 1e-9).all()):
+        return None
+    cdf = p.cumsum(axis=1)
+    cdf /= cdf[:, -1:]
+    N, cap = int(num_episodes), int(max_steps_per_episode)
+    first = np.array([env.reset() for _ in range(N)], np.int32)
+    starts, sidx = np.unique(first, return_inverse=True)
+    starts = starts.astype(np.int32)
+    sidx = sidx.tolist()
+    # the uniforms are drawn in pieces of at most 65 536, the stream's state remembered in front of each: putting the stream
+    # back to "exactly `pos` draws made" then costs one set_state and at most 65 535 draws, whatever was drawn ahead
+    pieces, marks, drawn = [], [], 0
+
+    def draw(upto):
+        nonlocal drawn
+        while drawn < upto:
+            n = min(65536, upto - drawn)
+            marks.append((drawn, np.random.get_state()))
+            pieces.append(np.random.random_sample(n))
+            drawn += n
+
+    U = np.empty(0, np.float64)
+    offsets, lengths = np.zeros(N, np.int64), np.zeros(N, np.int32)
+    pos, e = 0, 0
+    while e < N:
+        base = pos
+        # offsets walked speculatively this time: a guess at first (64 uniforms per episode), then what the episodes so far say the
+        # rest will need, and a quarter more (episodes that run into the step cap: 1000 uniforms each)
+        guess = 64 * (N - e) if e == 0 else int((N - e) * (pos / e) * 1.25) + 4096
+        block = int(min(max(16384, guess), (N - e) * cap, 1 << 20))
+        if drawn < base + block + cap:
+            draw(base + block + cap)
+            U = np.concatenate(pieces) if len(pieces) > 1 else pieces[0]
+        table = eng.mc_walk_lengths(U[base:base + block + cap], block, starts, cap, cdf)
+        while e < N and pos - base < block:
+            length = int(table[sidx[e], pos - base])
+            offsets[e], lengths[e] = pos, length
+            pos += length
+            e += 1
+    at, state = next((m for m in reversed(marks) if m[0] <= pos), (0, None)) if marks else (0, None)
+    if state is not None:
+        np.random.set_state(state)
+        if pos > at:
+            np.random.random_sample(pos - at)  # the stream has advanced by exactly the draws the episodes made
+    return first, offsets, lengths, U[:pos + cap], cdf
+
+
+def _states_of_episode(env, first_state, uniforms, cdf, cap):
+    """The states one episode visits (the reset state first) and whether it ended on a terminal step: the host's copy of the
+    device's walk, for the ONE episode whose end the caller's env instance is left at."""
+    nxt, _, don = env._transition_table(True)
+    s, states, done = int(first_state), [int(first_state)], False
+    for t in range(min(cap, len(uniforms))):
+        a = bisect.bisect_right(cdf[s].tolist(), float(uniforms[t]))
+        done = bool(don[s][a])
+        s = int(nxt[s][a])
+        states.append(s)
+        if done:
+            break
+    return states, done
+
+
 def monte_carlo_evaluation(policy, env, every_visit=False, incremental_mean=True, stationary_env=True,
                            discount_factor=0.99, threshold=0.0001, alpha=0.001, num_episodes=100, *,
                            max_steps_per_episode=1000, seed=0, return_details=False, rng='device'):
@@ -139,9 +209,6 @@ def monte_carlo_evaluation(policy, env, every_visit=False, incremental_mean=True
     if rng not in ('device', 'numpy'):
         raise ValueError("rng must be 'device' or 'numpy'")
     numpy_rng = rng == 'numpy'
-    if numpy_rng:
-        # host side first (it is what consumes the global streams, and it may raise like np.random.choice does)
-        first_np, actions_np, lengths_np, last_states, last_done = reference_rng_episodes(policy, env, num_episodes, max_steps_per_episode)
     device = getattr(engine_of(env), 'device', 0)
     # the batch engine of the previous call on this env is kept (creating one costs a few ms of allocations, the
     # evaluation itself well under one): re-seeding restores exactly the state of a fresh engine
@@ -159,9 +226,20 @@ def monte_carlo_evaluation(policy, env, every_visit=False, incremental_mean=True
             env._episode_batch = (key, batch)
     try:
         eng = batch.engine
-        if numpy_rng:
-            # the reference's episodes, replayed on the device: start cells installed, actions as a caller-supplied stream,
-            # no auto-reset (an env past its terminal step is absorbing and its rows are not read), reduced by gu_mc_evaluate
+        walked = reference_rng_offsets(policy, env, eng, num_episodes, max_steps_per_episode) if numpy_rng and hasattr(eng, 'mc_walk_lengths') else None
+        if numpy_rng and walked is not None:
+            # the reference's episodes, found and walked on the device (csrc/gu_mc_ref.hip), reduced by gu_mc_evaluate
+            first, offsets, lengths_np, uniforms, cdf = walked
+            T = max(1, int(lengths_np.max()) if lengths_np.size else 1)
+            eng.reserve_trajectory(T)
+            eng.mc_walk_episodes(uniforms, cdf, offsets, first, int(max_steps_per_episode), T)
+            last = int(num_episodes) - 1
+            last_states, last_done = _states_of_episode(env, first[last], uniforms[offsets[last]:offsets[last] + lengths_np[last]], cdf, int(max_steps_per_episode))
+        elif numpy_rng:
+            # (a policy row that is no distribution: the host walks, and raises where np.random.choice would)  The reference's
+            # episodes replayed on the device: start cells installed, actions as a caller-supplied stream, no auto-reset (an env past
+            # its terminal step is absorbing and its rows are not read), reduced by gu_mc_evaluate
+            first_np, actions_np, lengths_np, last_states, last_done = reference_rng_episodes(policy, env, num_episodes, max_steps_per_episode)
             T = int(actions_np.shape[0])
             first = first_np
             eng.set_state(pos=first, done=np.zeros(first.size, np.int32))

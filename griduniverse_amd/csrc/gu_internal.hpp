@@ -227,6 +227,7 @@ struct gu_engine {
     bool greedy_valid = false;
     int32_t vi_xcd_members[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // workgroups that registered per XCC in the last per-XCD launch of gu_vi_sweep_step_run
     int vi_run_form = 0;            // which form the last gu_vi_sweep_step_run took: 1 per XCD, 2 chip-wide cluster, 3 one launch per round
+    int64_t vi_xcd_torn = 0;        // -DGU_VI_XCD_TORN builds: exchange words found with the right tag and the wrong payload, summed over the per-XCD launches
     int vi_dp_form = 0;             // ... and the last gu_vi_sweep / gu_vi_run / gu_vi_eval_run: 1 per XCD, 2 one workgroup, 3 chip-wide cluster, 4 one launch per round
 
     // agent trail (gu_trail.hip): off unless gu_trail_enable was called

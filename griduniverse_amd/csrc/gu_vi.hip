@@ -1187,8 +1187,10 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
             if ((rc = gu_read_back(h, back.data(), h->d_scratch, back.size() * sizeof(unsigned long long))) != GU_OK) return rc;
             int32_t ctl[4];  // [arrival counter (chip-wide form), fallback word, rounds_done, -]
             memcpy(ctl, back.data(), sizeof ctl);
-            if (form == 0)  // the per-XCD form's registration word: eight 7-bit counts of workgroups per HW_REG_XCC_ID (gu_vi_xcd.hip)
+            if (form == 0) {  // the per-XCD form's registration word: eight 7-bit counts of workgroups per HW_REG_XCC_ID (gu_vi_xcd.hip)
                 for (int k = 0; k < 8; ++k) h->vi_xcd_members[k] = (int32_t)((back[2] >> (7 * k)) & 0x7Full);
+                h->vi_xcd_torn += (int64_t)(back[4] & 0xFFFFFFFFull);  // (hdr[8]: counted by a -DGU_VI_XCD_TORN build only)
+            }
             if (!ctl[1] && ctl[2] == iters) {
                 for (int32_t i = 0; deltas && i < iters; ++i) deltas[i] = vi_unkey(back[8 + (size_t)i]);
                 if (iters & 1) {
@@ -1223,6 +1225,17 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
 
 int gu_vi_last_form(gu_handle h) { return h ? h->vi_run_form : 0; }
 int gu_vi_last_dp_form(gu_handle h) { return h ? h->vi_dp_form : 0; }
+int gu_vi_xcd_torn_words(gu_handle h, int64_t *count)
+{
+    if (!h) return gu_fail(GU_ERR_INVALID, "null handle");
+#ifdef GU_VI_XCD_TORN
+    if (count) *count = h->vi_xcd_torn;
+    return GU_OK;
+#else
+    if (count) *count = -1;
+    return gu_fail(GU_ERR_UNSUPPORTED, "this library was built without -DGU_VI_XCD_TORN (make variant VARIANT=_torn EXTRA=-DGU_VI_XCD_TORN)");
+#endif
+}
 
 int gu_vi_last_clusters(gu_handle h, int32_t *members)
 {

@@ -76,6 +76,20 @@
 
 typedef uint32_t vi_u32x4 __attribute__((ext_vector_type(4)));
 
+// -DGU_VI_XCD_TORN (a diagnostic variant library, tools/xcd_stress.py; never the product): the exchange relies on each 8-byte half
+// {tag | payload} of a 16-byte store landing as ONE unit -- a consumer that sees the right tag takes the payload beside it.  The
+// tags catch a half that is not there yet; they cannot catch a half torn at 4 bytes (new tag, old payload).  This build can: the
+// tag word carries the round in its low 16 bits and, above them, a check of the payload it was stored with; a word whose tag is
+// right and whose check is not is COUNTED (hdr[8], gu_vi_xcd_torn_words) and fetched again.
+#ifdef GU_VI_XCD_TORN
+__device__ __forceinline__ uint32_t vi_tagw(uint32_t tag, uint32_t payload) { return (tag & 0xFFFFu) | (((payload >> 16) ^ payload ^ tag) << 16); }
+__device__ __forceinline__ bool vi_tag_is(uint32_t tagw, uint32_t tag) { return (tagw & 0xFFFFu) == (tag & 0xFFFFu); }
+__device__ __forceinline__ bool vi_tag_torn(uint32_t tagw, uint32_t tag, uint32_t payload) { return vi_tag_is(tagw, tag) && tagw != vi_tagw(tag, payload); }
+#else
+__device__ __forceinline__ uint32_t vi_tagw(uint32_t tag, uint32_t) { return tag; }
+__device__ __forceinline__ bool vi_tag_is(uint32_t tagw, uint32_t tag) { return tagw == tag; }
+#endif
+
 // 8-byte store that stays in this XCD's L2 (workgroup scope: `global_store_dwordx2 ... sc0`)
 __device__ __forceinline__ void vi_st_l2(vi_u64 *p, vi_u64 x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // 8-byte / 4-byte loads that bypass this CU's L1 (`sc1`)
@@ -348,7 +362,17 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         for (;;) {
             bool ok = true;
 #pragma unroll
-            for (int m = 0; m < NB; ++m) ok = ok && (!on[m] || (t[m].x == tag && (t[m].z == tag || it_kind[m] == 3u)));
+            for (int m = 0; m < NB; ++m) ok = ok && (!on[m] || (vi_tag_is(t[m].x, tag) && (vi_tag_is(t[m].z, tag) || it_kind[m] == 3u)));
+#ifdef GU_VI_XCD_TORN
+#pragma unroll
+            for (int m = 0; m < NB; ++m) {  // right tag, wrong payload: a half torn at four bytes -- counted, and fetched again
+                const uint32_t torn = on[m] ? (uint32_t)vi_tag_torn(t[m].x, tag, t[m].y) + (uint32_t)(it_kind[m] != 3u && vi_tag_torn(t[m].z, tag, t[m].w)) : 0u;
+                if (torn) {
+                    atomicAdd(hdr + 8, torn);
+                    ok = false;
+                }
+            }
+#endif
             if (__builtin_expect(__all(ok) != 0, 1)) break;
             if (++spins > VI_CL_SPIN_LIMIT || ((spins & 255u) == 0u && vi_ld_word(hdr + 1))) {
                 bad = 1u;
@@ -384,7 +408,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
                 // sixteen states' low action bits in the word's low half, their high bits in its high half
                 const uint32_t e = (uint32_t)(b0 >> (16 * lane)) & 0xFFFFu, o = (uint32_t)(b1 >> (16 * lane)) & 0xFFFFu;
                 const uint32_t word = (uint32_t)(s_first >> 4) + (uint32_t)lane;
-                vi_st_l2(reinterpret_cast<vi_u64 *>(gx + aw_off + par * aw_bytes) + word, ((vi_u64)(e | (o << 16)) << 32) | tag);
+                vi_st_l2(reinterpret_cast<vi_u64 *>(gx + aw_off + par * aw_bytes) + word, ((vi_u64)(e | (o << 16)) << 32) | vi_tagw(tag, e | (o << 16)));
             }
         }
     };
@@ -508,7 +532,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
                     v_new[j] = acc;
                     const vi_u64 bits = (vi_u64)__double_as_longlong(acc);
                     vi_u32x4 g;
-                    g.x = tag, g.y = (uint32_t)(bits >> 32), g.z = tag, g.w = (uint32_t)bits;
+                    g.x = vi_tagw(tag, (uint32_t)(bits >> 32)), g.y = (uint32_t)(bits >> 32), g.z = vi_tagw(tag, (uint32_t)bits), g.w = (uint32_t)bits;
                     __builtin_amdgcn_raw_buffer_store_b128(g, rs, par * gv_bytes + (uint32_t)s * 16u, 0, VI_XCD_STORE_AUX);
                     const vi_u64 k = vi_key(__dsub_rn(v_old, acc));  // signed, dynamic_programming.py:17
                     key = k > key ? k : key;
@@ -818,6 +842,7 @@ int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_thre
     if ((rc = gu_read_back(h, back.data(), base, back.size() * sizeof(unsigned long long))) != GU_OK) return rc;
     int32_t ctl[4];  // [workgroups registered, fallback word, rounds_done, -]
     memcpy(ctl, back.data(), sizeof ctl);
+    h->vi_xcd_torn += (int64_t)(back[4] & 0xFFFFFFFFull);  // (hdr[8]: counted by a -DGU_VI_XCD_TORN build only)
     const int32_t done = ctl[1] ? -1 : ctl[2];
     if (done < 0) {
         if ((rc = gu_device_copy(h, h->d_v[h->vi_cur], snap, v_bytes)) != GU_OK) return rc;

@@ -410,11 +410,36 @@ class Engine(object):
         3 = chip-wide cluster, 4 = one launch per round (0: none yet)."""
         return int(self.lib.gu_vi_last_dp_form(self._h))
 
+    def vi_xcd_torn_words(self):
+        """A -DGU_VI_XCD_TORN build: exchange words of the per-XCD launches found with the right tag and the wrong payload, summed over
+        this engine's launches; None on the product library."""
+        n = ctypes.c_int64(0)
+        rc = self.lib.gu_vi_xcd_torn_words(self._h, ctypes.byref(n))
+        return None if rc else int(n.value)
+
     def vi_last_clusters(self):
         """Workgroups per XCC id in the last per-XCD launch of vi_sweep_step_run, as the hardware reported them (list of 8)."""
         m = np.zeros(8, np.int32)
         check(self.lib.gu_vi_last_clusters(self._h, ptr(m)))
         return m.tolist()
+
+    def mc_walk_lengths(self, u, n_offsets, start_states, cap, cdf):
+        """include/gu.h: gu_mc_walk_lengths.  uint16[n_starts, n_offsets]: the length of the reference's episode that begins at uniform
+        i of `u` in start cell start_states[c] (0xFFFF: the uniforms ran out before it ended)."""
+        u = _lib.as_array(u, np.float64, None, 'u')
+        starts = _lib.as_array(start_states, np.int32, None, 'start_states')
+        cdf = _lib.as_array(cdf, np.float64, None, 'cdf')
+        out = np.empty((starts.size, int(n_offsets)), np.uint16)
+        check(self.lib.gu_mc_walk_lengths(self._h, u.size, ptr(u), int(n_offsets), starts.size, ptr(starts), int(cap), ptr(cdf), ptr(out)))
+        return out
+
+    def mc_walk_episodes(self, u, cdf, offsets, first_state, cap, T):
+        """include/gu.h: gu_mc_walk_episodes: episode e from uniform offsets[e] and cell first_state[e] into rows 0 .. T-1 of the trajectory."""
+        u = _lib.as_array(u, np.float64, None, 'u')
+        cdf = _lib.as_array(cdf, np.float64, None, 'cdf')
+        off = _lib.as_array(offsets, np.int64, (self.N,), 'offsets')
+        first = _lib.as_array(first_state, np.int32, (self.N,), 'first_state')
+        check(self.lib.gu_mc_walk_episodes(self._h, u.size, ptr(u), ptr(cdf), ptr(off), ptr(first), int(cap), int(T)))
 
     def mc_evaluate(self, T, first_state, discount_pow, keep, every_visit=False, incremental_mean=True,
                     stationary_env=True, alpha=0.001):

@@ -319,6 +319,20 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
 int gu_mc_evaluate(gu_handle h, int64_t T, const int32_t *first_state, int32_t every_visit, int32_t incremental_mean,
                    int32_t stationary_env, double alpha, const double *discount_pow, const uint8_t *keep,
                    double *value_out, double *visits_out);
+/* The REFERENCE'S OWN episodes for gu_mc_evaluate: run_episode (core/algorithms/monte_carlo.py:7-26) draws one
+ * np.random.choice(4, p=policy[obs]) -- one uniform of numpy's global stream -- per step, episode after episode.  The host
+ * pre-draws the uniforms u[K] in bulk; the episode that begins at uniform i in start cell c is a pure function of (i, c), so
+ *   gu_mc_walk_lengths  walks it for EVERY offset i < n_offsets and every start cell start_states[n_starts], one lane each:
+ *                       lengths[c][i] = steps until done or `cap` (run_episode's max_steps_per_episode; 0xFFFF: the uniforms ran
+ *                       out first); cdf[S][4] = the rows np.random.choice builds (p.cumsum() / p.sum()).  The caller follows the chain
+ *                       offset -> offset + length through the table, one look-up per episode;
+ *   gu_mc_walk_episodes walks episode e (env e of the engine) from uniform offsets[e] and cell first_state[e] and writes its
+ *                       (obs, reward, done) rows 0 .. T-1 into the trajectory buffer (rows past its end: the absorbing state, as a
+ *                       rollout without auto-reset leaves them), for gu_mc_evaluate.  The engine's env state is not touched. */
+int gu_mc_walk_lengths(gu_handle h, int64_t K, const double *u, int64_t n_offsets, int32_t n_starts, const int32_t *start_states,
+                       int32_t cap, const double *cdf, uint16_t *lengths);
+int gu_mc_walk_episodes(gu_handle h, int64_t K, const double *u, const double *cdf, const int64_t *offsets, const int32_t *first_state,
+                        int32_t cap, int64_t T);
 
 /* ---- shortest paths: the breadth-first search of core/algorithms/maze_solving.py:43-50, 123-193 for EVERY grid ----
  * One lane per grid searches from the grid's first start cell over the care_about_terminal=False move graph

@@ -58,6 +58,10 @@ int gu_vi_last_form(gu_handle h);
  * cluster, 4 one launch per round (the form that finished the call; 0 = none yet). */
 int gu_vi_last_dp_form(gu_handle h);
 int gu_vi_last_clusters(gu_handle h, int32_t *members);
+/* A -DGU_VI_XCD_TORN build of the library (tools/xcd_stress.py) counts the words of the per-XCD exchange that arrived with the right
+ * round tag and the WRONG payload -- a 16-byte store whose 8-byte half was torn at four bytes -- over all launches of this engine.
+ * The product library returns GU_ERR_UNSUPPORTED (*count = -1). */
+int gu_vi_xcd_torn_words(gu_handle h, int64_t *count);
 
 /* ---- timing: HIP events on the handle's own stream (torch.cuda.Event cannot see it) ----- */
 int gu_timer_begin(gu_handle h);

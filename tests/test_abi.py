@@ -42,7 +42,7 @@ def test_header_binding_and_library_agree(lib):
                  'gu_done_indices', 'gu_vi_sweep', 'gu_allgather_view', 'gu_last_error', 'gu_version', 'gu_destroy'):
         assert name in surface, name
     for name in diag:
-        assert re.match(r'gu_(timer_|rollout_pac|vi_last_|trajectory_placement|probe_trajectory)', name), name + ' does not look like introspection'
+        assert re.match(r'gu_(timer_|rollout_pac|vi_last_|vi_xcd_torn|trajectory_placement|probe_trajectory)', name), name + ' does not look like introspection'
 
 
 def test_version_and_error_text(lib):

@@ -60,6 +60,7 @@ if os.environ.get('GU_STRESS_NO_NEIGHBOUR') != '1':
     load.start()
 rs = np.random.RandomState(11)
 t0, cases, forms = time.time(), 0, {1: 0, 2: 0, 3: 0}
+torn, torn_build, xcd_rounds = 0, False, 0  # (a -DGU_VI_XCD_TORN build of the library counts halves of the exchange torn at four bytes)
 while time.time() - t0 < budget:
     w, h = int(rs.randint(6, 110)), int(rs.randint(6, 110))
     random.seed(int(rs.randint(1 << 30)))
@@ -84,6 +85,9 @@ while time.time() - t0 < budget:
                 out[form] = digest(d1, d2, *eng.vi_get(), st['pos'], st['done'], st['episode'], eng.read_outputs()[1])
                 if form == 'per_xcd':
                     forms[eng.vi_last_form()] += 1
+                    n_torn = eng.vi_xcd_torn_words()
+                    if n_torn is not None:
+                        torn_build, torn, xcd_rounds = True, torn + n_torn, xcd_rounds + rounds + 1 + rounds % 3
         assert out['per_xcd'] == out['chip_wide'], ('sweep+step', w, h, N, rounds, gamma)
     else:  # the tables alone
         out = {}
@@ -96,6 +100,10 @@ while time.time() - t0 < budget:
                 v, pi = eng.vi_get()
                 steps2, deltas2 = eng.vi_eval_run(0.9, 1e-3, 40)
                 out[form] = digest(np.int64(steps), deltas, v, pi, np.int64(steps2), deltas2, eng.vi_get()[0])
+                if form == 'per_xcd':
+                    n_torn = eng.vi_xcd_torn_words()
+                    if n_torn is not None:
+                        torn_build, torn, xcd_rounds = True, torn + n_torn, xcd_rounds + int(steps) + int(steps2)
         assert out['per_xcd'] == out['other'], ('tables', w, h, gamma)
     cases += 1
 stop.set()
@@ -103,5 +111,10 @@ if load.is_alive():
     load.join(timeout=30)
 say('%d random cases in %.0f s under a streaming neighbour on the device, every one byte-identical on the per-XCD form and the chip-wide / '
     'single-workgroup form; form taken by the fused sweep + step cases (1 per XCD, 2 chip-wide, 3 per launch): %r' % (cases, time.time() - t0, forms))
+if torn_build:
+    say('torn-half detector (library built with -DGU_VI_XCD_TORN: every tag word carries a check of the payload it was stored with): %d words '
+        'with the right tag and the wrong payload in %d rounds of per-XCD launches' % (torn, xcd_rounds))
+else:
+    say('(product library: no torn-half detector -- make variant VARIANT=_torn EXTRA=-DGU_VI_XCD_TORN, GU_LIB_PATH=.../libgu_torn.so)')
 if len(sys.argv) > 2:
     open(sys.argv[2], 'w').write('\n'.join(lines) + '\n')

@@ -227,6 +227,9 @@ struct gu_engine {
     bool greedy_valid = false;
     int32_t vi_xcd_members[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // workgroups that registered per XCC in the last per-XCD launch of gu_vi_sweep_step_run
     int vi_run_form = 0;            // which form the last gu_vi_sweep_step_run took: 1 per XCD, 2 chip-wide cluster, 3 one launch per round
+    void *d_vi_xcd_ctl = nullptr, *d_vi_xcd_work = nullptr;  // the per-XCD launches' own headers / keys / slots and granule buffers (gu_vi_xcd.hip)
+    size_t vi_xcd_ctl_bytes = 0, vi_xcd_work_bytes = 0;
+    uint32_t vi_xcd_epoch = 1;      // number of the next per-XCD launch (its tags carry it)
     int64_t vi_xcd_torn = 0;        // -DGU_VI_XCD_TORN builds: exchange words found with the right tag and the wrong payload, summed over the per-XCD launches
     int vi_dp_form = 0;             // ... and the last gu_vi_sweep / gu_vi_run / gu_vi_eval_run: 1 per XCD, 2 one workgroup, 3 chip-wide cluster, 4 one launch per round
 
@@ -351,6 +354,9 @@ struct ViStepXcdArgs;
 #define GU_VI_FALLBACK 1  /* internal: a one-launch DP form did not apply or gave up, the tables are as they were -- take the next form */
 bool gu_vi_xcd_plan(const gu_engine *h, bool agents, GuXcdPlan *plan);
 int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a, bool agents, bool greedy);
+int gu_vi_xcd_buffers(gu_engine *h, const GuXcdPlan &xp);  // the per-XCD launches' own buffers, wiped when they must be
+uint32_t gu_vi_xcd_tag0(const gu_engine *h);                // the launch's number, where its tags carry it
+void gu_vi_xcd_free(gu_engine *h);
 int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds, int32_t *rounds_done,
                      double *deltas);
 

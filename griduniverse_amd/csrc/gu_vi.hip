@@ -611,6 +611,7 @@ void gu_vi_free(gu_engine *h)
     h->d_pi_thr = nullptr;
     if (h->d_delta) (void)hipFree(h->d_delta);
     h->d_delta = nullptr;
+    gu_vi_xcd_free(h);
     h->has_vi = false;
     h->greedy_valid = false;
 }

@@ -174,4 +174,15 @@ struct ViStepXcdArgs : ViStepClusterArgs {
     uint32_t work_bytes;      // bytes per XCC
     uint32_t inject_failure;  // tests: every workgroup gives up at once
     uint32_t lds_values;      // doubles of a workgroup's value window in LDS (the launcher sets it from its plan)
+    // Round 5: nothing has to be ZEROED in front of a launch.  Every tag carries the launch's number above the round (tag0 = epoch
+    // << 13: up to 8190 rounds per launch, 524 287 launches before the host wipes the buffers once), so a word of an earlier launch
+    // can never be taken for one of this launch -- the buffers are the engine's own, nothing else ever writes them -- and the header
+    // is one of a ring of sixteen: workgroup 0 clears the NEXT launch's header when it is done.  tag0 == 0: as before (the host
+    // zeroed everything; launches of more than 8190 rounds, the -DGU_VI_XCD_TORN variant with its 16-bit tags).
+    uint32_t tag0;
+    uint32_t *hdr_next;       // the header of the launch behind this one (16 words), or nullptr
+    // ... and the tables alone leave their INPUT alone: the final values go to v_out, the final policy rows (GREEDY) to pi_out --
+    // the other halves of the engine's double buffers --, which the host makes current only when the launch did not give up; no
+    // snapshot, no restore.  nullptr: in place, as before (config 5: the envs' state is not double-buffered, its launch keeps a snapshot)
+    double *v_out, *pi_out;
 };

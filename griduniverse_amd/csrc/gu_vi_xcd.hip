@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         }
     };
     auto delta_finish = [&](int32_t rr) -> vi_u64 {
-        const uint32_t tag = (uint32_t)rr + 1u;
+        const uint32_t tag = a.tag0 + (uint32_t)rr + 1u;
         const bool polls = (uint32_t)lane < members;
         uint32_t spins = 0;
         // (normally there at the first look: the slots of round rr were posted before anything of round rr + 1 was stored)
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
     };
     auto post = [&](int32_t rr, vi_u64 m) {
         if (lane == 0) {
-            const uint32_t tag = (uint32_t)rr + 1u;
+            const uint32_t tag = a.tag0 + (uint32_t)rr + 1u;
             vi_u64 *slot = slots + (size_t)((uint32_t)rr & 3u) * VI_XCD_SLOTS * 2;
             vi_st_l2(slot + 2 * rank, (m & 0xFFFFFFFF00000000ull) | tag);
             vi_st_l2(slot + 2 * rank + 1, (m << 32) | tag);
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         constexpr int ROLE = decltype(role)::value;
         const bool wave_has_states = ROLE == 1 ? true : ROLE == 2 ? false : any_states;
         const bool has_envs = ROLE == 1 ? false : envs_here;
-        const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;
+        const uint32_t par = (uint32_t)r & 1u, tag = a.tag0 + (uint32_t)r + 1u;
         if (wave_has_states) {
             vi_u64 key = 0ull;
 #pragma unroll
@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         }
     }
     if (AGENTS && !failed && r > 0) {  // the agents' step of the last round: its actions alone cross the cluster
-        const uint32_t par = (uint32_t)r & 1u, tag = (uint32_t)r + 1u;  // (published behind V2 of the last round)
+        const uint32_t par = (uint32_t)r & 1u, tag = a.tag0 + (uint32_t)r + 1u;  // (published behind V2 of the last round)
         __syncthreads();
         const bool collects = keeps_deltas && wave == collect_wave;
         if (collects && r > 1) delta_load(r - 2);
@@ -692,13 +692,15 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
 #endif
     // ---- results: one cluster writes the tables, every workgroup its envs ----
     if (writes_tables && !failed && r > 0) {
-        double *vf = (r & 1) ? a.vi.v1 : a.vi.v0;  // where `r` swaps of the double-buffered table leave the current values
+        // (in place: where `r` swaps of the double-buffered table leave the current values; else: the buffers the host hands over)
+        double *vf = a.v_out ? a.v_out : (r & 1) ? a.vi.v1 : a.vi.v0;
+        double *pf = a.pi_out ? a.pi_out : a.vi.pi;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const int32_t s = st[j];
             if (s >= 0) {
                 vf[s] = v_new[j];
-                if (GREEDY) *reinterpret_cast<double4 *>(a.vi.pi + 4 * (int64_t)s) = make_double4(p[j][0], p[j][1], p[j][2], p[j][3]);
+                if (GREEDY) *reinterpret_cast<double4 *>(pf + 4 * (int64_t)s) = make_double4(p[j][0], p[j][1], p[j][2], p[j][3]);
             }
         }
     }
@@ -714,6 +716,7 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
         if (lane == 0 && own_env[e]) a.done_bits[gid[e] >> 6] = bits;
     }
     if (blockIdx.x == 0 && tid == 0) *a.vi.rounds_done = failed ? -1 : r;
+    if (blockIdx.x == 0 && tid < 16 && a.hdr_next) a.hdr_next[tid] = 0u;  // the header of the launch behind this one (nobody of THIS launch looks at it)
 #ifdef GU_VI_XCD_STAMPS
     if (stamps_here && a.vi.max_rounds >= 20) {  // (the kernel's life beside the loop: delta_key[12 .. 18], ticks since entry)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -802,73 +805,144 @@ int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a
     return GU_OK;
 }
 
+// The per-XCD launches' own buffers (see gu_vi_xcd_dp_run): allocated on first use, again when the plan needs more, wiped whenever
+// they are (re)allocated and when the launch number is about to repeat.
+#define VI_XCD_CTL_KEYS 1024u                       /* bytes of the sixteen launch headers in front of the delta keys */
+#define VI_XCD_CTL_SLOTS (VI_XCD_CTL_KEYS + 4096u * 8u) /* the delta-key slots behind 4096 keys */
+int gu_vi_xcd_buffers(gu_engine *h, const GuXcdPlan &xp)
+{
+    const size_t ctl_bytes = VI_XCD_CTL_SLOTS + xp.slots_bytes, work_bytes = 8 * xp.work_bytes;
+    bool wipe = (h->vi_xcd_epoch & 0x7FFFFu) == 0u;  // (the tags hold 19 bits of it)
+    if (wipe) h->vi_xcd_epoch += 1u;
+    if (!h->d_vi_xcd_ctl || h->vi_xcd_ctl_bytes < ctl_bytes) {
+        if (h->d_vi_xcd_ctl) (void)hipFree(h->d_vi_xcd_ctl);
+        h->d_vi_xcd_ctl = nullptr;
+        GU_HIP(hipMalloc(&h->d_vi_xcd_ctl, ctl_bytes));
+        h->vi_xcd_ctl_bytes = ctl_bytes;
+        wipe = true;
+    }
+    if (!h->d_vi_xcd_work || h->vi_xcd_work_bytes < work_bytes) {
+        if (h->d_vi_xcd_work) (void)hipFree(h->d_vi_xcd_work);
+        h->d_vi_xcd_work = nullptr;
+        GU_HIP(hipMalloc(&h->d_vi_xcd_work, work_bytes));
+        h->vi_xcd_work_bytes = work_bytes;
+        wipe = true;
+    }
+#ifdef GU_VI_XCD_TORN
+    wipe = true;  // (16-bit tags: no room for the launch's number -- this variant zeroes everything in front of every launch, like round 4)
+#endif
+    if (wipe) {
+        GU_HIP(hipMemsetAsync(h->d_vi_xcd_ctl, 0, h->vi_xcd_ctl_bytes, h->stream));
+        GU_HIP(hipMemsetAsync(h->d_vi_xcd_work, 0, h->vi_xcd_work_bytes, h->stream));
+    }
+    return GU_OK;
+}
+
+uint32_t gu_vi_xcd_tag0(const gu_engine *h)
+{
+#ifdef GU_VI_XCD_TORN
+    (void)h;
+    return 0u;
+#else
+    return (h->vi_xcd_epoch & 0x7FFFFu) << 13;
+#endif
+}
+
+void gu_vi_xcd_free(gu_engine *h)
+{
+    if (h->d_vi_xcd_ctl) (void)hipFree(h->d_vi_xcd_ctl);
+    if (h->d_vi_xcd_work) (void)hipFree(h->d_vi_xcd_work);
+    h->d_vi_xcd_ctl = h->d_vi_xcd_work = nullptr;
+    h->vi_xcd_ctl_bytes = h->vi_xcd_work_bytes = 0;
+}
+
 // gu_vi_sweep / gu_vi_run / gu_vi_eval_run as ONE launch of one XCD's workgroups (see the kernel, !AGENTS).  Runs up to max_rounds
 // rounds on the current tables; GU_VI_FALLBACK: not applicable here or the launch gave up -- the tables are as they were.
-int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds, int32_t *rounds_done,
-                     double *deltas)
+static int vi_xcd_dp_launch(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds, int32_t *rounds_done,
+                            double *deltas)
 {
     *rounds_done = 0;
     if (max_rounds <= 0) return GU_OK;
     const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
     GuXcdPlan xp{};
     if (!(path == 0 || path == 5 || path == 6) || !gu_vi_xcd_plan(h, false, &xp)) return GU_VI_FALLBACK;
-    // scratch: header (64 B) | delta keys [max_rounds] | delta-key slots | snapshot of v and pi | granule buffers
-    const size_t key_bytes = (size_t)max_rounds * sizeof(unsigned long long);
-    const size_t slots_off = (64 + key_bytes + 255) & ~(size_t)255, snap_off = slots_off + xp.slots_bytes;
-    const size_t v_bytes = (size_t)h->S * sizeof(double), snap_bytes = (5 * v_bytes + 255) & ~(size_t)255;
-    int rc = gu_ensure_scratch(h, snap_off + snap_bytes + 8 * xp.work_bytes);
+    // The engine's OWN buffers (nothing else ever writes them -- the scratch area is shared with every other call):
+    //   ctl  = a ring of sixteen 64-byte launch headers | delta keys [4096] | delta-key slots
+    //   work = the clusters' granule buffers
+    // Every tag in them carries this launch's number above the round (ViStepXcdArgs::tag0), the kernel clears the NEXT launch's
+    // header when it is done, and the final tables go to the other halves of the double buffers: ONE launch per call, nothing
+    // zeroed, nothing snapshot, nothing to restore.  (Until round 4: a launch of copies and zero fills in front of every call, ~6 us.)
+    int rc = gu_vi_xcd_buffers(h, xp);
     if (rc != GU_OK) return rc;
-    char *base = (char *)h->d_scratch, *snap = base + snap_off;
-    // ONE launch: the snapshot; header, keys, slots zeroed (every polled word, before every launch); the granule buffers zeroed (no
-    // tag of an earlier launch may be left in them)
-    GuSegments seg;
-    seg.add(snap, h->d_v[h->vi_cur], v_bytes);
-    seg.add(snap + v_bytes, h->d_pi[h->vi_cur], 4 * v_bytes);
-    seg.add(base, nullptr, snap_off);
-    seg.add(snap + snap_bytes, nullptr, 8 * xp.work_bytes);
-    if ((rc = gu_device_segments(h, seg)) != GU_OK) return rc;
+    char *ctl = (char *)h->d_vi_xcd_ctl;
+    const uint32_t slot_i = h->vi_xcd_epoch & 15u;
+    uint32_t *hdr = (uint32_t *)(ctl + 64 * (size_t)slot_i);
+    vi_u64 *keys = (vi_u64 *)(ctl + VI_XCD_CTL_KEYS);
     ViStepXcdArgs a{};
     a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, threshold, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1], h->d_pi[h->vi_cur],
-                         (vi_u64 *)(base + 64), (uint32_t *)base, (int32_t *)base + 2, max_rounds, use_threshold ? 1 : 0};
+                         keys, hdr, (int32_t *)hdr + 2, max_rounds, use_threshold ? 1 : 0};
     a.N = 0;
-    a.slots = (vi_u64 *)(base + slots_off);
-    a.gx = (uint8_t *)(snap + snap_bytes);
+    a.slots = (vi_u64 *)(ctl + VI_XCD_CTL_SLOTS);
+    a.gx = (uint8_t *)h->d_vi_xcd_work;
     a.work_bytes = (uint32_t)xp.work_bytes;
     a.inject_failure = path == 5;
+    a.tag0 = gu_vi_xcd_tag0(h);
+    a.hdr_next = (uint32_t *)(ctl + 64 * (size_t)((slot_i + 1u) & 15u));
+    a.v_out = h->d_v[h->vi_cur ^ 1];
+    a.pi_out = greedy ? h->d_pi[h->vi_cur ^ 1] : nullptr;
     if ((rc = gu_vi_xcd_launch(h, xp, a, false, greedy)) != GU_OK) return rc;
-    // (header and delta keys lie side by side: ONE copy back and one wait for calls of up to 4096 rounds)
-    const size_t first_keys = deltas ? (size_t)(max_rounds < 4096 ? max_rounds : 4096) : 0;
-    std::vector<unsigned long long> back(8 + first_keys);
-    if ((rc = gu_read_back(h, back.data(), base, back.size() * sizeof(unsigned long long))) != GU_OK) return rc;
-    int32_t ctl[4];  // [workgroups registered, fallback word, rounds_done, -]
-    memcpy(ctl, back.data(), sizeof ctl);
-    h->vi_xcd_torn += (int64_t)(back[4] & 0xFFFFFFFFull);  // (hdr[8]: counted by a -DGU_VI_XCD_TORN build only)
-    const int32_t done = ctl[1] ? -1 : ctl[2];
-    if (done < 0) {
-        if ((rc = gu_device_copy(h, h->d_v[h->vi_cur], snap, v_bytes)) != GU_OK) return rc;
-        if ((rc = gu_device_copy(h, h->d_pi[h->vi_cur], snap + v_bytes, 4 * v_bytes)) != GU_OK) return rc;
-        GU_HIP(hipStreamSynchronize(h->stream));
-        if (gu_debug()) fprintf(stderr, "[gu] DP per-XCD kernel gave up (workgroups not resident together, or clusters too uneven); tables restored, next form\n");
+    ++h->vi_xcd_epoch;
+    // (the sixteen headers and the first delta keys lie side by side: ONE copy back and one wait)
+    const size_t first_keys = deltas ? (size_t)(max_rounds < 3968 ? max_rounds : 3968) : 0;
+    std::vector<unsigned long long> back(128 + first_keys);
+    if ((rc = gu_read_back(h, back.data(), ctl, back.size() * sizeof(unsigned long long))) != GU_OK) return rc;
+    int32_t ctlw[4];  // [workgroups registered, fallback word, rounds_done, -]
+    memcpy(ctlw, back.data() + 8 * (size_t)slot_i, sizeof ctlw);
+    h->vi_xcd_torn += (int64_t)(back[8 * (size_t)slot_i + 4] & 0xFFFFFFFFull);  // (hdr[8]: counted by a -DGU_VI_XCD_TORN build only)
+    const int32_t done = ctlw[1] ? -1 : ctlw[2];
+    if (done < 0) {  // the input tables are as they were; the ring is wiped (who knows which header this launch left how)
+        GU_HIP(hipMemsetAsync(ctl, 0, VI_XCD_CTL_KEYS, h->stream));
+        if (gu_debug()) fprintf(stderr, "[gu] DP per-XCD kernel gave up (workgroups not resident together, or clusters too uneven); next form\n");
         return GU_VI_FALLBACK;
     }
     if (deltas && done > 0) {
         std::vector<unsigned long long> rest;
         if ((size_t)done > first_keys) {
             rest.resize((size_t)done - first_keys);
-            GU_HIP(hipMemcpy(rest.data(), base + 64 + first_keys * sizeof(unsigned long long), rest.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            GU_HIP(hipMemcpy(rest.data(), keys + first_keys, rest.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         }
         for (int32_t i = 0; i < done; ++i) {
-            const unsigned long long k = (size_t)i < first_keys ? back[8 + (size_t)i] : rest[(size_t)i - first_keys];
+            const unsigned long long k = (size_t)i < first_keys ? back[128 + (size_t)i] : rest[(size_t)i - first_keys];
             const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
             memcpy(&deltas[i], &b, sizeof(double));
         }
     }
-    if (done & 1) {  // the value table ended in the other buffer; the policy stayed where it was
-        double *t = h->d_v[0];
-        h->d_v[0] = h->d_v[1];
-        h->d_v[1] = t;
+    if (done > 0) {  // the results are in the other halves of the double buffers: they become the current ones
+        std::swap(h->d_v[0], h->d_v[1]);
+        if (greedy) std::swap(h->d_pi[0], h->d_pi[1]);
     }
     *rounds_done = done;
     h->greedy_valid = false;
+    return GU_OK;
+}
+
+// gu_vi_sweep / gu_vi_run / gu_vi_eval_run on the per-XCD kernel: launches of up to 4096 rounds (the tags keep 13 bits for the round,
+// the engine's buffer 4096 delta keys), one after the other while the stopping rule has not fired -- a call of up to 4096 rounds
+// is ONE launch.  The tables pass from launch to launch in memory, exactly as between two calls.
+int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds, int32_t *rounds_done,
+                     double *deltas)
+{
+    *rounds_done = 0;
+    int32_t total = 0;
+    while (total < max_rounds) {
+        const int32_t n = max_rounds - total < 4096 ? max_rounds - total : 4096;
+        int32_t done = 0;
+        const int rc = vi_xcd_dp_launch(h, gamma, threshold, use_threshold, greedy, n, &done, deltas ? deltas + total : nullptr);
+        if (rc == GU_VI_FALLBACK && total > 0) return gu_fail(GU_ERR_HIP, "the per-XCD DP launch gave up %d rounds into a call", total);
+        if (rc != GU_OK) return rc;
+        total += done;
+        *rounds_done = total;
+        if (done < n) break;  // the stopping rule fired
+    }
     return GU_OK;
 }

@@ -352,11 +352,13 @@ def baseline_configs(engine_cls, device, K, check):
     out['c2'] = dict(workload='c2: %d envs on the %s, seed %d, uniform device-RNG actions, auto-reset, int32 trajectory, %d env-steps per launch' % (N, desc, seed, T),
                      us_per_launch=ms * 1e3, env_steps_per_s=float(N) * T / ms * 1e3, hbm_gbps=BYTES_PER_ENV_STEP * N * T / ms / 1e6,
                      frac_of_hbm_peak=BYTES_PER_ENV_STEP * N * T / ms / 1e6 / HBM_PEAK_GBPS,
-                     bound='latency / issue of one wave: 64 waves on 1024 SIMDs, each a chain of %d dependent steps -- one LDS round trip + one '
-                           'vector op per step, and beside it the issue of the step\'s three 256-byte stores at ~25 clocks each '
-                           '(gu_rollout_rows_kernel; measured slope 44.6 ns = 107 clocks per step, 4 us fixed per launch); the HBM stream is 49 MB per launch' % T,
-                     cycles_per_step=cyc, floor_us='%d steps x ~85 shader clocks (ds_read_b32 issue -> use, MI355X_MICROARCH.md) = %.0f us at the clock '
-                                                   'HIP reports, + ~5 us of table staging and the first step' % (T, T * 85 / ((clock_ghz or 2.4) * 1e3)),
+                     bound='latency / issue of one wave: 64 waves on 1024 SIMDs, each a chain of %d dependent steps.  Since round 5 the rows of a '
+                           'batch this small are one plane of (obs, reward, done) triples and the steps go through the pair tables: one LDS round '
+                           'trip per TWO steps and two 12-byte-per-lane stores per pair where round 4 issued six 4-byte ones (three 256-byte '
+                           'stores per step at ~25 clocks each: 49 us per launch then) -- gu_rollout_rows_kernel<UNIFORM, triples, pairs>; the '
+                           'HBM stream is 49 MB per launch' % T,
+                     cycles_per_step=cyc, floor_us='%d pairs x ~85 shader clocks (ds_read_b64 issue -> use, MI355X_MICROARCH.md) = %.0f us at the clock '
+                                                   'HIP reports, + ~5 us of table staging and the first step' % (T // 2, T // 2 * 85 / ((clock_ghz or 2.4) * 1e3)),
                      bit_exact=ok, check='first launch from reset == the reference digest c2_open8x8_4096x1000 (tests/golden/digests.json)')
 
     # ---- config 4, one shard of eight: 32 768 envs with global ids 32768 .. 65535 on the lava grid

@@ -126,7 +126,8 @@ struct GuPacer {
     }
     // right before the first step.  The launch's FIRST WAVE sums what the launch before this one reported and writes the record of
     // the launch behind this one (decide).  Here, not in the step loop: inlined into the loop's back edge the same code cost
-    // every kernel 30 .. 50 registers and spills (packed rows: 43 -> 48 us per launch, profiles/r05f_pace_packed.txt); and with
+    // every kernel 30 .. 50 registers and spills (the row-table kernel: from 70 SGPRs and none spilled to 106 and 28 spilled, its
+    // launch without a limiter from 42.7 to 48.1 us); and with
     // everything it reads asked for at the top of the kernel, because a wave that starts its steps 2 us late ends 2 us late when
     // the launch runs without the limiter (nobody waits, nobody catches up: packed rows 42 -> 45 us).
     __device__ __forceinline__ void start(const GuPaceArgs &pa, bool on)

@@ -553,10 +553,10 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         // is the quicker one: 88 against 116 us at 32 768 envs, profiles/archive/r02j_stream_crossover.txt)
         // (measured on the 256 CUs of an MI355X; stated relative to the CU count: one workgroup per CU, a quarter, half of them)
         const unsigned cus = (unsigned)h->n_cu;
-        // (round 3, under the schedule limiter, 65 536 envs with int32 rows, profiles/r03s_rows_vs_general.txt: greedy with auto-reset
+        // (round 3, under the schedule limiter, 65 536 envs with int32 rows, profiles/archive/r03s_rows_vs_general.txt: greedy with auto-reset
         // 108 .. 111 us here against 119 .. 120 on the general kernel, whose step then has two dependent LDS reads; sampled without
         // auto-reset 135 against 142; uniform / stream / greedy without auto-reset: the same on both, they stay where they were)
-        // (the whole table, 8192 .. 65 536 envs x four policy kinds x int32 / packed rows on both kernels: profiles/r03s_rows_crossover.txt.
+        // (the whole table, 8192 .. 65 536 envs x four policy kinds x int32 / packed rows on both kernels: profiles/archive/r03s_rows_crossover.txt.
         // A caller-supplied stream with int32 rows used to leave this kernel at 16 384 envs -- its action words are read straight
         // from HBM among the streaming stores --; with sc1 + nt stores it is the quicker one up to 32 768 like the uniform policy:
         // 60 .. 61 against 66 .. 71 us)

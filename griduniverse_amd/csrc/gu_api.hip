@@ -649,7 +649,7 @@ int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done)
 // ---------------------------------------------------------------------------------- rollout
 // Where a large buffer lands in HBM decides how fast it can be written: the SAME store kernel, on the same GPU at the same
 // clocks, writes twelve 786 MB allocations of one process at 5.7 .. 6.9 TB/s -- each buffer at its own, stable rate
-// (tools/micro/store_placement.hip, profiles/archive/r02f_store_placement.txt; this, not the device, is the "box-to-box" spread of
+// (tools/archive/micro/store_placement.hip, profiles/archive/r02f_store_placement.txt; this, not the device, is the "box-to-box" spread of
 // the rollout kernel: 117 .. 141 us per launch).  So a large trajectory buffer is CHOSEN: a few candidate allocations are
 // written once in the rollout's own store shape, timed with events, and the fastest one is kept.  A one-off cost of a few
 // milliseconds at reservation; GU_OPT_TRAJ_CANDIDATES = 1 turns it off.  What the search may hold and when it gives up is
@@ -726,7 +726,7 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
     // ranks of one process group, share it).  What the search is still worth under the closed-loop store pacing: the first
     // allocation an engine gets runs the headline launch at 105.9 .. 110.2 us (ten buffers of one process, median 107.5), the
     // searched one at 105.2 -- 2 % in the median, 4 % at worst; the probe time ranks them in the same order
-    // (profiles/r05f_placement_loop.txt).  Why buffers differ is still not known (tools/micro/placement_*.hip).
+    // (profiles/r05f_placement_loop.txt).  Why buffers differ is still not known (tools/archive/micro/placement_*.hip).
     size_t budget = others ? free_b / 16 : free_b / 10;
     if (others) {
         want = want < 4 ? want : 4;

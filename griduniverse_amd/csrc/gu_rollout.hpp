@@ -26,7 +26,7 @@ __device__ __forceinline__ uint32_t gu_sample_action(uint32_t word, const uint4 
 // (s_memrealtime, 10 ns) per 16 steps; a wave may begin its next group of steps no earlier than its own start + steps done x
 // pace / 16, and does not wait at all when it is late.
 //
-// WHY (round 3; tools/micro/store_pacing.hip, write_ceiling.hip, store_deadline.hip, tools/pace_ab.py, profiles/archive/r03d_*, r03k_*):
+// WHY (round 3; tools/archive/micro/store_pacing.hip, write_ceiling.hip, store_deadline.hip, tools/pace_ab.py, profiles/archive/r03d_*, r03k_*):
 // the HBM write path of an MI355X shows CONGESTION COLLAPSE.  65 536 lanes that hand their three rows per step to the memory
 // system as fast as it will take them keep every queue on the way full, and the sustained rate then DROPS: to 5.7 TB/s on most
 // allocations (round 2's "slow class"), 6.6 on some.  The same stores offered just below the memory's capacity go through at

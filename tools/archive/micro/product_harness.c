@@ -2,8 +2,8 @@
  * Python tools report a property of the kernel or of the way they drive it?  Engines of 65 536 envs on a 32 x 32 grid (one start
  * cell), each with the first trajectory allocation it gets; per engine and rate-limiter setting (option rollout_pace) 2 + 30
  * launches between gu_timer_begin / gu_timer_end.
- *   gcc -std=c11 -O2 -Iinclude tools/micro/product_harness.c -o tools/micro/product_harness -Lgriduniverse_amd/lib -lgu<variant> \
- *       -Wl,-rpath,$PWD/griduniverse_amd/lib && tools/micro/product_harness [engines] [T] [pace values ...] */
+ *   gcc -std=c11 -O2 -Iinclude tools/archive/micro/product_harness.c -o tools/archive/micro/product_harness -Lgriduniverse_amd/lib -lgu<variant> \
+ *       -Wl,-rpath,$PWD/griduniverse_amd/lib && tools/archive/micro/product_harness [engines] [T] [pace values ...] */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>

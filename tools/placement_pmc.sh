@@ -5,7 +5,7 @@ TAG=${1:-r02h}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_place_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BIN=$GRAFT_REPO_ROOT/tools/micro/placement_pmc
+BIN=$GRAFT_REPO_ROOT/tools/archive/micro/placement_pmc
 i=0
 for group in "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum TCC_EA0_WRREQ_WRITE_GMI_32B_sum TCC_EA0_WRREQ_WRITE_IO_32B_sum TCC_EA0_WRREQ_sum" \
              "TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_GMI_CREDIT_STALL_sum TCC_EA0_WRREQ_IO_CREDIT_STALL_sum" \

@@ -52,7 +52,8 @@ struct GuPaceEntry {   // one launch of one kind: how it runs, the loop's state 
     uint32_t elapsed;     // ticks from start to report, the slowest wave
     uint32_t ended_late;  // waves that were more than two periods behind their schedule when they reported
     uint32_t max_behind;  // ticks: the most any of them was behind (0 when none was more than two periods behind)
-    uint32_t reserved[2];
+    uint32_t report_steps; // the step count behind which this launch's waves reported (launches of one kind may differ in length)
+    uint32_t groups;      // 16-step groups of this launch
     // the slow loop around the rule: which SHARE of waves behind is the best one to aim for on this buffer (GuPacer::decide)
     uint32_t dec_q;       // what the period comes down by per launch, 1/64 ticks: the rule aims for a share of dec_q / gain_q
     uint32_t block_left;  // launches left in this block (the first GU_PACE_BLOCK_SKIP of a block are not counted: the period is on its way)

@@ -87,7 +87,7 @@ struct GuPacer {
     // what the launch's first wave asks for at the very top of the kernel, to have it by the time it decides (start()): the first
     // 1024 slots of the launch before (sixteen per lane), and the loop's state in this launch's and that launch's records
     uint64_t w[16];
-    uint32_t c_seq, c_phase, c_left, c_ema_p, c_ema_u, v_period_q, v_seq, v_unpaced;
+    uint32_t c_seq, c_phase, c_left, c_ema_p, c_ema_u, v_period_q, v_seq, v_unpaced, v_report_steps, v_groups;
     uint32_t c_dec_q, c_block_left, c_block_sum, c_block_n, c_last_mean, c_up;
     uint64_t v_t_start;
     bool first_wave;
@@ -106,6 +106,7 @@ struct GuPacer {
             const uint32_t unpaced = mine ? entry->unpaced : 0u;
             c_phase = entry->phase, c_left = entry->left, c_ema_p = entry->ema_paced, c_ema_u = entry->ema_unpaced;
             v_period_q = prev->period_q, v_seq = prev->seq, v_unpaced = prev->unpaced, v_t_start = prev->t_start;
+            v_report_steps = prev->report_steps, v_groups = prev->groups;
             if (have && !pa.fixed) p_q = have;
             p_q = p_q < (pa.lo << 6) ? (pa.lo << 6) : p_q;
             p_q = p_q > (pa.hi << 6) ? (pa.hi << 6) : p_q;
@@ -159,7 +160,8 @@ struct GuPacer {
         // the launch before: its schedule up to the report (0: it ran without the limiter, nobody was "behind")
         const bool prev_ok = v_seq + 1u == pa.seq;
         const uint32_t prev_ticks = (prev_ok && !v_unpaced) ? (pa.fixed ? pa.period : (v_period_q + 32u) >> 6) : 0u;
-        const uint32_t scheduled = (prev_ticks * ((pa.report_at + 15u) & ~15u)) >> 4;
+        const uint32_t scheduled = (prev_ticks * ((v_report_steps + 15u) & ~15u)) >> 4;  // (ITS report point: launches of a kind may differ in length)
+        const bool same_length = v_groups == pa.groups;  // (times of launches of different lengths are not compared)
         uint32_t counts = 0, most = 0, longest = 0;  // counts: waves that reported << 16 | waves that were far behind
         for (uint32_t base = 0; base < pa.n_waves; base += 64u * 16u) {
             if (base) {  // (batches of more than 1024 waves: the slots behind the first 1024, sixteen per lane and round trip)
@@ -195,17 +197,17 @@ struct GuPacer {
                 cur->unpaced = 0, cur->phase = phase, cur->left = left, cur->ema_paced = 0, cur->ema_unpaced = 0;
                 cur->dec_q = dec_q, cur->block_left = block_left, cur->block_sum = 0, cur->block_n = 0, cur->last_mean = 0, cur->up = up;
             }
-            cur->period_q = p_q, cur->seq = pa.seq, cur->t_start = now;
+            cur->period_q = p_q, cur->seq = pa.seq, cur->t_start = now, cur->report_steps = pa.report_at, cur->groups = pa.groups;
             cur->verdict = 0, cur->waves = 0, cur->elapsed = 0, cur->ended_late = 0, cur->max_behind = 0;
             if (waves && prev_ok) {
-                prev->verdict = (uint64_t)most * 256u > (uint64_t)prev_ticks * pa.groups * pa.bar_num ? 2u : 1u;
+                prev->verdict = (uint64_t)most * 256u > (uint64_t)prev_ticks * v_groups * pa.bar_num ? 2u : 1u;
                 prev->waves = waves, prev->elapsed = longest, prev->ended_late = far, prev->max_behind = far ? most : 0u;
                 // the launch before, from its start to this launch's: what a caller who launches back to back pays per launch.  (A
                 // gap on the host stretches it: an interval of more than twice the mean is not taken in.)
                 const uint64_t gap = now - v_t_start;
                 const uint32_t mean = v_unpaced ? ema_u : ema_p;
                 const uint32_t took = gap > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)gap;
-                const bool plausible = v_t_start && (!mean || took < 2u * mean);
+                const bool plausible = same_length && v_t_start && (!mean || took < 2u * mean);
                 if (v_unpaced) {
                     if (plausible) ema_u = ema_u ? (ema_u + took) >> 1 : took;
                 } else {
@@ -257,7 +259,7 @@ struct GuPacer {
             next->unpaced = (phase == GU_PACE_PROBE_OFF || phase == GU_PACE_OFF) ? 1u : 0u;
             next->phase = phase, next->left = left, next->ema_paced = ema_p, next->ema_unpaced = ema_u;
             next->dec_q = dec_q, next->block_left = block_left, next->block_sum = block_sum, next->block_n = block_n, next->last_mean = last_mean, next->up = up;
-            next->verdict = 0, next->waves = 0, next->elapsed = 0, next->ended_late = 0, next->max_behind = 0;
+            next->verdict = 0, next->waves = 0, next->elapsed = 0, next->ended_late = 0, next->max_behind = 0, next->report_steps = 0, next->groups = 0;
         }
     }
     // The wave's report: ONE plain 8-byte store into its own slot (gu_internal.hpp).  Made `report_at` steps into the launch, i.e.

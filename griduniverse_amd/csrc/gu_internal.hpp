@@ -133,6 +133,9 @@ struct gu_engine {
     // SoA env state
     int32_t *d_out3 = nullptr;  // pos[N] | reward[N] | done[N]
     uint32_t *d_episode = nullptr;
+    int32_t *d_out3_alt = nullptr;      // a second set of the env-state arrays: config 5's per-XCD launch writes its results there and
+    uint32_t *d_episode_alt = nullptr;  // the sets change places when it did not give up (gu_vi_xcd.hip: gu_vi_xcd_fused_run)
+    uint64_t *d_done_bits_alt = nullptr;
     uint32_t *d_tcount = nullptr;  // per-env step-count OFFSET; effective count = offset + steps_taken
     uint32_t steps_taken = 0;      // lock-step counter since gu_seed (all envs step together)
     uint64_t seed = 0;
@@ -358,6 +361,7 @@ int gu_vi_xcd_launch(gu_engine *h, const GuXcdPlan &plan, const ViStepXcdArgs &a
 int gu_vi_xcd_buffers(gu_engine *h, const GuXcdPlan &xp);  // the per-XCD launches' own buffers, wiped when they must be
 uint32_t gu_vi_xcd_tag0(const gu_engine *h);                // the launch's number, where its tags carry it
 void gu_vi_xcd_free(gu_engine *h);
+int gu_vi_xcd_fused_run(gu_engine *h, const GuXcdPlan &xp, double gamma, int32_t iters, uint32_t flags, double *deltas);
 int gu_vi_xcd_dp_run(gu_engine *h, double gamma, double threshold, bool use_threshold, bool greedy, int32_t max_rounds, int32_t *rounds_done,
                      double *deltas);
 

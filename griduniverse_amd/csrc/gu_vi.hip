@@ -1124,7 +1124,12 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
     const bool try_xcd = !short_call && (path == 0 || path == 5 || path == 6) && gu_vi_xcd_plan(h, true, &xp);
     const bool try_cluster = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && G <= (h->n_cu < VI_CL_MAX_WGS ? h->n_cu : VI_CL_MAX_WGS) &&
                              !short_call && (path == 0 || path == 3 || path == 4 || path == 5 || path == 6);
-    if (try_xcd || try_cluster) {
+    if (try_xcd) {  // ONE launch per up to 4096 rounds, results into the other halves of the double buffers (gu_vi_xcd.hip)
+        rc = gu_vi_xcd_fused_run(h, xp, gamma, iters, flags, deltas);
+        if (rc == GU_OK) h->vi_run_form = 1;
+        if (rc != GU_VI_FALLBACK) return rc;
+    }
+    if (try_cluster) {
         // scratch: header (64 B) | delta keys [iters] | delta-key slots of the per-XCD form | snapshot | the per-XCD granule buffers
         const size_t key_bytes = (size_t)iters * sizeof(unsigned long long);
         const size_t slots_off = (64 + key_bytes + 255) & ~(size_t)255;
@@ -1143,8 +1148,8 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
         const size_t size[5] = {v_bytes, 4 * v_bytes, 3 * n4, n4, bits_bytes};
         size_t off = 0;
         bool snapped = false;
-        for (int form = 0; form < 2; ++form) {  // 0: per XCD, 1: chip-wide
-            if (form == 0 ? !try_xcd : !try_cluster) continue;
+        for (int form = 1; form < 2; ++form) {  // (0: per XCD -- handled above since round 5), 1: chip-wide
+            if (!try_cluster) continue;
             // ONE launch: the snapshot (first form tried only), every polled word zeroed (before every launch), and for the per-XCD
             // form its exchange buffers zeroed -- every word that crosses workgroups there is tagged with its round, no tag of an
             // earlier launch may be left

@@ -185,4 +185,9 @@ struct ViStepXcdArgs : ViStepClusterArgs {
     // the other halves of the engine's double buffers --, which the host makes current only when the launch did not give up; no
     // snapshot, no restore.  nullptr: in place, as before (config 5: the envs' state is not double-buffered, its launch keeps a snapshot)
     double *v_out, *pi_out;
+    // ... and so does config 5's fused launch since the engine keeps a second set of env-state arrays for it: the envs' final
+    // positions, rewards, done flags, episode counters and done ballots go to these (nullptr: in place)
+    int32_t *pos_out, *reward_out, *done_out;
+    uint32_t *episode_out;
+    uint64_t *done_bits_out;
 };

@@ -707,13 +707,13 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
 #pragma unroll
     for (int e = 0; AGENTS && e < 2; ++e) {
         if (own_env[e]) {
-            a.pos[gid[e]] = e_pos[e];
-            a.reward[gid[e]] = e_rew[e];
-            a.done[gid[e]] = e_done[e];
-            a.episode[gid[e]] = e_ep[e];
+            (a.pos_out ? a.pos_out : a.pos)[gid[e]] = e_pos[e];
+            (a.reward_out ? a.reward_out : a.reward)[gid[e]] = e_rew[e];
+            (a.done_out ? a.done_out : a.done)[gid[e]] = e_done[e];
+            (a.episode_out ? a.episode_out : a.episode)[gid[e]] = e_ep[e];
         }
         const uint64_t bits = __ballot(own_env[e] && e_done[e] != 0);
-        if (lane == 0 && own_env[e]) a.done_bits[gid[e] >> 6] = bits;
+        if (lane == 0 && own_env[e]) (a.done_bits_out ? a.done_bits_out : a.done_bits)[gid[e] >> 6] = bits;
     }
     if (blockIdx.x == 0 && tid == 0) *a.vi.rounds_done = failed ? -1 : r;
     if (blockIdx.x == 0 && tid < 16 && a.hdr_next) a.hdr_next[tid] = 0u;  // the header of the launch behind this one (nobody of THIS launch looks at it)
@@ -923,6 +923,100 @@ static int vi_xcd_dp_launch(gu_engine *h, double gamma, double threshold, bool u
     }
     *rounds_done = done;
     h->greedy_valid = false;
+    return GU_OK;
+}
+
+// Config 5 (gu_vi_sweep_step_run) on the per-XCD kernel, ONE launch per up to 4096 rounds and nothing else: the tables' and the
+// envs' final state go to the other halves of the engine's double buffers (the env-state arrays got a second set for this), which
+// become the current ones only when the launch did not give up -- no snapshot launch in front, nothing to put back behind.
+// GU_VI_FALLBACK: the launch gave up (or does not apply), everything is as it was.
+int gu_vi_xcd_fused_run(gu_engine *h, const GuXcdPlan &xp, double gamma, int32_t iters, uint32_t flags, double *deltas)
+{
+    const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
+    const size_t n4 = (size_t)h->N * 4, bits_bytes = (((size_t)h->N + 63) / 64) * 8;
+    if (!h->d_out3_alt) {
+        GU_HIP(hipMalloc((void **)&h->d_out3_alt, 3 * n4));
+        GU_HIP(hipMalloc((void **)&h->d_episode_alt, n4));
+        GU_HIP(hipMalloc((void **)&h->d_done_bits_alt, bits_bytes));
+    }
+    int32_t total = 0;
+    while (total < iters) {
+        const int32_t n = iters - total < 4096 ? iters - total : 4096;
+        int rc = gu_vi_xcd_buffers(h, xp);
+        if (rc != GU_OK) return rc;
+        char *ctl = (char *)h->d_vi_xcd_ctl;
+        const uint32_t slot_i = h->vi_xcd_epoch & 15u;
+        uint32_t *hdr = (uint32_t *)(ctl + 64 * (size_t)slot_i);
+        vi_u64 *keys = (vi_u64 *)(ctl + VI_XCD_CTL_KEYS);
+        ViStepXcdArgs a{};
+        a.vi = ViClusterArgs{h->d_cell, h->cell_bytes, h->W, h->S, gamma, 0.0, h->d_v[h->vi_cur], h->d_v[h->vi_cur ^ 1], h->d_pi[h->vi_cur],
+                             keys, hdr, (int32_t *)hdr + 2, n, 0};
+        a.pos = h->pos();
+        a.reward = h->reward();
+        a.done = h->done();
+        a.episode = h->d_episode;
+        a.starts = h->d_starts;
+        a.n_starts = (uint32_t)h->n_starts;
+        a.seed_prefix = h->seed_prefix;
+        a.env_id0 = (uint32_t)h->env_id0;
+        a.N = h->N;
+        a.flags = flags;
+        a.done_bits = h->d_done_bits;
+        a.slots = (vi_u64 *)(ctl + VI_XCD_CTL_SLOTS);
+        a.gx = (uint8_t *)h->d_vi_xcd_work;
+        a.work_bytes = (uint32_t)xp.work_bytes;
+        a.inject_failure = path == 5;
+        a.tag0 = gu_vi_xcd_tag0(h);
+        a.hdr_next = (uint32_t *)(ctl + 64 * (size_t)((slot_i + 1u) & 15u));
+        a.v_out = h->d_v[h->vi_cur ^ 1];
+        a.pi_out = h->d_pi[h->vi_cur ^ 1];
+        a.pos_out = h->d_out3_alt;
+        a.reward_out = h->d_out3_alt + h->N;
+        a.done_out = h->d_out3_alt + 2 * h->N;
+        a.episode_out = h->d_episode_alt;
+        a.done_bits_out = h->d_done_bits_alt;
+        if ((rc = gu_vi_xcd_launch(h, xp, a, true, true)) != GU_OK) return rc;
+        ++h->vi_xcd_epoch;
+        const size_t first_keys = deltas ? (size_t)(n < 3968 ? n : 3968) : 0;
+        std::vector<unsigned long long> back(128 + first_keys);
+        if ((rc = gu_read_back(h, back.data(), ctl, back.size() * sizeof(unsigned long long))) != GU_OK) return rc;
+        int32_t ctlw[4];  // [-, fallback word, rounds_done, -]
+        memcpy(ctlw, back.data() + 8 * (size_t)slot_i, sizeof ctlw);
+        for (int k = 0; k < 8; ++k) h->vi_xcd_members[k] = (int32_t)((back[8 * (size_t)slot_i + 2] >> (7 * k)) & 0x7Full);  // the registration word
+        h->vi_xcd_torn += (int64_t)(back[8 * (size_t)slot_i + 4] & 0xFFFFFFFFull);
+        if (ctlw[1] || ctlw[2] != n) {
+            GU_HIP(hipMemsetAsync(ctl, 0, VI_XCD_CTL_KEYS, h->stream));
+            if (gu_debug()) fprintf(stderr, "[gu] sweep-step per-XCD kernel gave up (workgroups not resident together, or clusters too uneven); next form\n");
+            if (total > 0) return gu_fail(GU_ERR_HIP, "the per-XCD sweep + step launch gave up %d rounds into a call", total);
+            return GU_VI_FALLBACK;
+        }
+        if (deltas) {
+            std::vector<unsigned long long> rest;
+            if ((size_t)n > first_keys) {
+                rest.resize((size_t)n - first_keys);
+                GU_HIP(hipMemcpy(rest.data(), keys + first_keys, rest.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            }
+            for (int32_t i = 0; i < n; ++i) {
+                const unsigned long long k = (size_t)i < first_keys ? back[128 + (size_t)i] : rest[(size_t)i - first_keys];
+                const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+                memcpy(&deltas[total + i], &b, sizeof(double));
+            }
+        }
+        // the results become the current state
+        std::swap(h->d_v[0], h->d_v[1]);
+        std::swap(h->d_pi[0], h->d_pi[1]);
+        std::swap(h->d_out3, h->d_out3_alt);
+        std::swap(h->d_episode, h->d_episode_alt);
+        std::swap(h->d_done_bits, h->d_done_bits_alt);
+        h->done_bits_valid = true;
+        if (h->graph_exec) {  // (a captured step graph carries the old arrays in its arguments)
+            (void)hipGraphExecDestroy(h->graph_exec);
+            h->graph_exec = nullptr;
+        }
+        h->greedy_valid = false;
+        h->steps_taken += (uint32_t)n;
+        total += n;
+    }
     return GU_OK;
 }
 

@@ -566,6 +566,11 @@ def other_modes(eng, template, seed, env_id0, N, T, K, check):
         ms = launch_ms(trajectory='packed')
         out['packed_rows'] = {'ms_per_launch': ms, 'value': float(N) * T / ms * 1e3, 'unit': 'env-steps/s (this rank)',
                               'bytes_per_env_step': 4, 'achieved_GBps': 4.0 * N * T / ms / 1e6,
+                              'frac_of_hbm_peak': 4.0 * N * T / ms / 1e6 / HBM_PEAK_GBPS,
+                              'bound': 'the dependent chain of one wave per SIMD, not the memory (the closed loop of the store pacing finds the limiter '
+                                       'useless for this kind and switches it off): %d pairs of steps x (one ds_read_b64 round trip ~85 clocks + the issue of '
+                                       'two 256-byte stores at ~25 clocks each) = ~%d clocks, + ~5 us of table staging and the first step' % (T // 2, T // 2 * 135),
+                              'floor_us': T // 2 * 135 / 2.4e3 + 5.0,
                               'is': 'obs | reward << 16 | done << 24 in one uint32 per env-step'}
     return out
 

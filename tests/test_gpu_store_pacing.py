@@ -113,7 +113,7 @@ def test_an_engine_that_is_simply_used_gets_the_paced_rate(kind, gu_option):
     """Rounds 3 and 4 needed gu_rollout_calibrate (a search of a few hundred launches, 40 .. 60 ms) to reach the paced rate; an engine
     left alone ran without a limiter for 1024 launches and then stalled for the search.  Now: no launch of a fresh engine is ever
     spent on anything but the caller's work (launches_spent stays 0, the first launch costs a kernel), no launch takes more than
-    1.5 x the median, and after a few hundred launches the engine runs at least as fast (5 %; measured: -2 .. +3 %, profiles/r05h_matrix.txt) as the better of (a) no limiter and
+    twice the median, and after a few hundred launches the engine runs at least as fast (5 %; measured: -2 .. +3 %, profiles/r05h_matrix.txt) as the better of (a) no limiter and
     (b) the period the old search finds on the same buffer, held -- for the headline launch, where the limiter is worth 10 %, and
     for packed rows at one wave per SIMD, where it is worth nothing and the loop must find that out and switch it off."""
     meta, _ = G.load_traj('c3_maze32')
@@ -129,13 +129,13 @@ def test_an_engine_that_is_simply_used_gets_the_paced_rate(kind, gu_option):
         eng.rollout(T, 'uniform', True, traj)
         eng.sync()
         first_ms = (time.perf_counter() - t0) * 1e3
-        assert first_ms < 3.0, first_ms  # (a 0.12 ms kernel + what a first launch of a kernel costs)
+        assert first_ms < 10.0, first_ms  # (a 0.12 ms kernel + what a first launch of a kernel costs: ~1 ms; the searches of rounds 3 and 4: 40 .. 60)
         # launches 2 .. 59 back to back: start-to-start intervals from the device's own clock (the kind's ring of launch records)
         for _ in range(57):
             eng.rollout(T, 'uniform', True, traj)
         lg = eng.rollout_pace_log('uniform', True, packed=packed)
         iv = lg['interval'][(lg['interval'] > 0) & (lg['seq'] >= 2)] / 100.0  # us (launch 1 was waited for by the host)
-        assert len(iv) >= 50 and iv.max() < 1.5 * np.median(iv), (np.median(iv), iv.max())
+        assert len(iv) >= 50 and iv.max() < 2.0 * np.median(iv), (np.median(iv), iv.max())  # (measured: < 1.35 x)
         early_us = float(np.mean(iv[5:32]))
         for _ in range(6):
             wall_us(eng, 58, T, 'uniform', traj)

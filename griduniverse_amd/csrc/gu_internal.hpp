@@ -61,7 +61,9 @@ struct GuPaceEntry {   // one launch of one kind: how it runs, the loop's state 
     uint32_t block_n;     // ... and how many
     uint32_t last_mean;   // ticks: the mean of the block before (0: none yet)
     uint32_t up;          // 1: the last change of dec_q was upwards
-    uint32_t reserved2[10];
+    uint32_t quiet;       // 1: the limiter is off and stays off for now -- the waves of launch `seq` report nothing, its first wave only
+                          // counts the launch and keeps the start-to-start mean (what a kind that is better off unpaced pays: ~nothing)
+    uint32_t reserved2[9];
 };
 static_assert(sizeof(GuPaceEntry) == 128, "GuPaceEntry is two cache lines' halves: 128 bytes");
 #define GU_PACE_BLOCK 192u      /* launches per block of the slow loop ...                       */

@@ -587,7 +587,7 @@ static int gu_search_pace(gu_engine *h, int slot, int64_t T, const std::function
 // (7200; the cliff sits at 7.4 .. 7.5 TB/s on the allocations measured in rounds 3 and 4).
 static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, GuPaceArgs *pace)
 {
-    const int64_t waves = (h->N + 63) / 64;
+    const int64_t waves = (h->N + 31) / 32;  // (the most a launch can have: the transition-row kernel's half waves)
     if (!h->d_pace_ring) {
         const size_t ring_bytes = sizeof(GuPaceEntry) * GU_PACE_RING * 36;
         h->pace_slot_stride = (waves + 63) & ~(int64_t)63;
@@ -624,7 +624,7 @@ static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, 
     pace->hi = std::max<uint32_t>(k.model * 2u, k.model + 4u);
     pace->groups = (uint32_t)std::min<int64_t>(T / 16, 0x7FFFFFFF);
     pace->report_at = (uint32_t)std::min<int64_t>(T > 160 ? T - 96 : std::max<int64_t>(T - 32, 1), 0x7FFFFFFF);
-    pace->n_waves = (uint32_t)waves;
+    pace->n_waves = (uint32_t)std::min<int64_t>(waves, (int64_t)h->pace_slot_stride);  // (every slot the launch may write: an unused one reads as 'did not report')
     pace->slot_stride = (uint32_t)h->pace_slot_stride;
     pace->bar_num = (uint16_t)gu_opt(h, GU_OPT_PACE_BAR_NUM);
     pace->gain_q = (uint32_t)gu_opt(h, GU_OPT_PACE_GAIN_Q);
@@ -682,13 +682,14 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     // policy; a launch of a few waves, bound by the ISSUE of its stores (~25 clocks per 256-byte store of a wave that has its SIMD
     // alone), gains little from the triple alone (config 2, 4096 envs: 49.4 against 49.9 us) but 25 % together with the pair tables
     // (two steps per LDS round trip, two stores per pair instead of six: 37.3 us), up to 8192 envs = one workgroup per eight
-    // CUs; at 16 384 the two are level, beyond it the planes win.  So: triples for the uniform policy on the transition-row
-    // kernel with pair tables, up to n_cu / 8 workgroups of 256.  Batches of more than 2^24 envs (lane offset + 15 rows must stay
+    // CUs; at 16 384 the two are level -- unless the batch is spread over twice the waves (32 envs each: 43.6 against 53.3 us,
+    // profiles/r05m_half_sizes.txt) --, beyond it the planes win.  So: triples for the uniform policy on the transition-row
+    // kernel with pair tables, up to n_cu / 4 workgroups of 256 (half waves for the upper half of that range).  Batches of more than 2^24 envs (lane offset + 15 rows must stay
     // below 2^32 bytes) and engines with the agent trail on always keep the planes.
     int traj = (flags & GU_F_PACKED) ? 2 : ((flags & GU_F_TRAJECTORY) ? 1 : 0);
     if (traj == 1 && h->N <= ((int64_t)1 << 24) && !h->trail_cap) {
         const int64_t layout = gu_opt(h, GU_OPT_TRAJ_LAYOUT);
-        if (layout == 1 || (layout == -1 && policy == GU_POLICY_UNIFORM && gu_rows_pairs_fit(h) && (int64_t)gu_blocks(h->N, 256) * 8 <= h->n_cu)) traj = 3;
+        if (layout == 1 || (layout == -1 && policy == GU_POLICY_UNIFORM && gu_rows_pairs_fit(h) && (int64_t)gu_blocks(h->N, 256) * 4 <= h->n_cu)) traj = 3;
     }
     h->traj_written = traj;
     const bool stats = flags & GU_F_STATS;
@@ -729,6 +730,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.row_shift = 0;
     a.stream_lds_off = 0;
     a.stream_lds_words = 0;
+    a.half_waves = 0;
     const int bs = gu_rollout_block(h);
     a.pace = GuPaceArgs{};
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)

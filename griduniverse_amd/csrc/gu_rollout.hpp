@@ -88,7 +88,7 @@ struct GuPacer {
     // 1024 slots of the launch before (sixteen per lane), and the loop's state in this launch's and that launch's records
     uint64_t w[16];
     uint32_t c_seq, c_phase, c_left, c_ema_p, c_ema_u, v_period_q, v_seq, v_unpaced, v_report_steps, v_groups;
-    uint32_t c_dec_q, c_block_left, c_block_sum, c_block_n, c_last_mean, c_up;
+    uint32_t c_dec_q, c_block_left, c_block_sum, c_block_n, c_last_mean, c_up, c_quiet;
     uint64_t v_t_start;
     bool first_wave;
     // at the very top of the kernel: ask for this launch's record, so that the answer is there when start() wants it
@@ -112,8 +112,9 @@ struct GuPacer {
             p_q = p_q > (pa.hi << 6) ? (pa.hi << 6) : p_q;
             if (pa.fixed) p_q = pa.period << 6;
             ticks = (unpaced && !pa.fixed) ? 0u : (p_q + 32u) >> 6;
+            c_quiet = (mine && !pa.fixed) ? entry->quiet : 0u;
             first_wave = blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) < 64u;
-            if (first_wave) {
+            if (first_wave && !c_quiet) {
                 c_dec_q = entry->dec_q, c_block_left = entry->block_left, c_block_sum = entry->block_sum, c_block_n = entry->block_n;
                 c_last_mean = entry->last_mean, c_up = entry->up;
                 const uint64_t *set = pa.slots + (size_t)((pa.seq - 1u) & 1u) * pa.slot_stride;
@@ -138,21 +139,54 @@ struct GuPacer {
         report_at = 0;
         t0 = 0;
         if (on && pa.ring) {
+            const uint64_t now = __builtin_amdgcn_s_memrealtime();
+            due = t0 = now;
+            if (c_quiet) {  // the limiter is off and stays off: nobody reports, the first wave counts the launch
+                if (first_wave) decide_quiet(pa, now);
+                return;
+            }
             const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
             slot = pa.slots + (size_t)(pa.seq & 1u) * pa.slot_stride + wave;
             report_at = pa.report_at;
-            const uint64_t now = __builtin_amdgcn_s_memrealtime();
-            due = t0 = now;
-            if (first_wave) decide(pa, now);
+            if (first_wave) decide(pa, now);  // (unless decide_early has done it)
             return;
         }
         due = ticks ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    }
+    // a kernel some of whose lanes leave before start() (the transition-row kernel's half waves): the first wave decides while it is
+    // still whole
+    __device__ __forceinline__ void decide_early(const GuPaceArgs &pa)
+    {
+        if (first_wave && !c_quiet) decide(pa, __builtin_amdgcn_s_memrealtime());
+    }
+    // A launch of a kind whose limiter is off (GU_PACE_OFF) and stays off: the record of the launch behind this one is this one's,
+    // one launch further along; the mean start-to-start time of the launches without the limiter is kept up (the next comparison
+    // with the limiter wants it fresh).  One lane, a dozen scalar operations, two stores.
+    __device__ __forceinline__ void decide_quiet(const GuPaceArgs &pa, uint64_t now)
+    {
+        first_wave = false;
+        if (threadIdx.x == 0) {
+            GuPaceEntry *cur = pa.ring + (pa.seq & (GU_PACE_RING - 1u));
+            GuPaceEntry *next = pa.ring + ((pa.seq + 1u) & (GU_PACE_RING - 1u));
+            uint32_t ema_u = c_ema_u;
+            const uint64_t gap = now - v_t_start;
+            const uint32_t took = gap > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)gap;
+            if (v_seq + 1u == pa.seq && v_unpaced && v_t_start && v_groups == pa.groups && (!ema_u || took < 2u * ema_u)) ema_u = ema_u ? (ema_u * 7u + took) >> 3 : took;
+            cur->t_start = now, cur->groups = pa.groups, cur->report_steps = 0;
+            const uint32_t left = c_left > 0u ? c_left - 1u : 0u;
+            next->period_q = p_q, next->seq = pa.seq + 1u, next->t_start = 0, next->unpaced = 1u;
+            next->phase = GU_PACE_OFF, next->left = left, next->ema_paced = c_ema_p, next->ema_unpaced = ema_u;
+            next->verdict = 0, next->waves = 0, next->elapsed = 0, next->ended_late = 0, next->max_behind = 0, next->report_steps = 0, next->groups = 0;
+            next->dec_q = pa.dec_q, next->block_left = GU_PACE_BLOCK, next->block_sum = 0, next->block_n = 0, next->last_mean = 0, next->up = 1;
+            next->quiet = left > 1u ? 1u : 0u;  // (the launch that ends the phase is a full one: it sets the probe up)
+        }
     }
     // The launch's first wave, once: what the waves of the launch BEFORE this one reported (set (seq - 1) & 1), summed over the
     // wave's lanes; that launch's log; how the launch BEHIND this one runs.  The set is cleared as it is read: the launch behind
     // this one reports into it.
     __device__ __forceinline__ void decide(const GuPaceArgs &pa, uint64_t now)
     {
+        first_wave = false;
         uint64_t *set = pa.slots + (size_t)((pa.seq - 1u) & 1u) * pa.slot_stride;
         GuPaceEntry *cur = pa.ring + (pa.seq & (GU_PACE_RING - 1u));
         GuPaceEntry *prev = pa.ring + ((pa.seq - 1u) & (GU_PACE_RING - 1u));
@@ -259,6 +293,7 @@ struct GuPacer {
             next->unpaced = (phase == GU_PACE_PROBE_OFF || phase == GU_PACE_OFF) ? 1u : 0u;
             next->phase = phase, next->left = left, next->ema_paced = ema_p, next->ema_unpaced = ema_u;
             next->dec_q = dec_q, next->block_left = block_left, next->block_sum = block_sum, next->block_n = block_n, next->last_mean = last_mean, next->up = up;
+            next->quiet = (phase == GU_PACE_OFF && left > 1u) ? 1u : 0u;
             next->verdict = 0, next->waves = 0, next->elapsed = 0, next->ended_late = 0, next->max_behind = 0, next->report_steps = 0, next->groups = 0;
         }
     }
@@ -320,6 +355,7 @@ struct RolloutArgs {
     int32_t row_shift;      // log2(16 * copies) of that table
     int32_t stream_lds_off; // GU_POLICY_STREAM, MAP 1: byte offset in LDS of the staged action words [stream_lds_words][blockDim.x] ...
     int32_t stream_lds_words;  // ... and how many words per lane fit (0: every word is read from HBM when its steps are due)
+    int32_t half_waves;     // transition-row kernel: lanes 0 .. 31 of every wave carry an env, twice the waves (gu_rollout_rows.hip)
     int32_t xcd_remap;      // workgroup b works on env block (b % 8) * (blocks / 8) + b / 8: one XCD = one contiguous env range
     GuPaceArgs pace;        // launches that write rows: the waves' schedule (GuPacer), the rate limiter of the store stream
 };

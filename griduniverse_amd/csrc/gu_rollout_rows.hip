@@ -202,7 +202,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         }
         __syncthreads();
     }
-    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * blockDim.x + threadIdx.x;
+    // HALF WAVES (a.half_waves, round 5): lanes 0 .. 31 of every wave carry an env, the others leave -- twice as many waves for the
+    // batch.  (The idea: a wave that has its SIMD to itself is bound by its own in-order issue, and the row stores might cost by the
+    // lanes they carry.  They do not -- see the launcher for what was measured and where this is used.)
+    const uint32_t half = (uint32_t)a.half_waves;
+    if (half) pacer.decide_early(a.pace);  // (the launch's first wave sums the launch before while it still has its 64 lanes)
+    if (half && (threadIdx.x & 32u)) return;
+    const uint32_t slot_in_block = half ? ((threadIdx.x >> 6) << 5) | (threadIdx.x & 31u) : threadIdx.x;
+    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * (blockDim.x >> half) + slot_in_block;
     if (e64 >= a.N) return;
     const uint32_t e = (uint32_t)e64;
     const uint32_t lane_copy = PAIR ? 0u : (threadIdx.x & ((1u << copies_log2) - 1u)) << RowBytes<POLICY>::log2;  // this lane's copy of every row
@@ -461,7 +468,10 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
         a.episodes_fin[e] = (int32_t)fin;
     }
     const uint64_t bits = __ballot(d_last != 0);
-    if ((threadIdx.x & 63) == 0) a.done_bits[e >> 6] = bits;
+    if ((threadIdx.x & 63) == 0) {
+        if (half) reinterpret_cast<uint32_t *>(a.done_bits)[e >> 5] = (uint32_t)bits;  // (this wave's 32 envs: one half of a ballot word)
+        else a.done_bits[e >> 6] = bits;
+    }
 }
 
 // ------------------------------------------------------------------------------------ host side
@@ -609,7 +619,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     // (int32 TRIPLES, round 5: two 12-byte stores per pair instead of six 4-byte ones -- 37 against 50 us at config 2's 4096 envs, 39 at
     // 8192, level with the one-step table at 16 384, slower beyond; the launcher hands triples to this kernel only where they pay,
     // GU_OPT_ROLLOUT_ROWS = 3 forces the pairs for every triples launch)
-    bool pair = !table_policy && (traj == 2 || (traj == 3 && (mode == 3 || policy == GU_POLICY_UNIFORM) && (mode == 3 || (int64_t)gu_blocks(h->N, 256) * 8 <= h->n_cu))) &&
+    bool pair = !table_policy && (traj == 2 || (traj == 3 && (mode == 3 || policy == GU_POLICY_UNIFORM) && (mode == 3 || (int64_t)gu_blocks(h->N, 256) * 4 <= h->n_cu))) &&
                 mode != 2 && gu_blocks(h->N, 256) <= (unsigned)h->n_cu && gu_rows_pairs_fit(h);
     if (pair) {
         if (!h->d_rows2[which]) {
@@ -634,7 +644,16 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     }
     a.row_shift = shift;
     const size_t lds = pair ? (size_t)h->S * 144 : ((size_t)h->S << row_log2) << (shift - row_log2);
-    const dim3 grid(gu_blocks(h->N, bs)), block(bs);
+    // Half waves (see the kernel).  Measured (profiles/r05m_half_sizes.txt, r05m_half_ab.txt): the stores of a wave do NOT get cheaper
+    // with fewer lanes -- planes at 4096 .. 8192 envs: 52.3 us either way, 55.4 against 53.3 at 16 384, and 223 against 126 us
+    // where two half waves share a SIMD -- so this is no cure for the issue-bound launches.  It pays in ONE place: triples with
+    // the pair tables between 8192 and 16 384 envs (43.6 against 47.6 us; the planes: 53.3), where a workgroup per four CUs
+    // becomes one per two.  That is the default; GU_OPT_ROLLOUT_HALF_WAVES = 1 / 0 forces / forbids it.
+    const int64_t half_opt = gu_opt(h, GU_OPT_ROLLOUT_HALF_WAVES);
+    const bool half = traj != 0 && h->N % 32 == 0 &&
+                      (half_opt == 1 || (half_opt == -1 && traj == 3 && pair && (int64_t)gu_blocks(h->N, 256) * 8 > h->n_cu && (int64_t)gu_blocks(h->N, 256) * 4 <= h->n_cu));
+    a.half_waves = half ? 1 : 0;
+    const dim3 grid(gu_blocks(h->N, half ? bs / 2 : bs)), block(bs);
     a.xcd_remap = a.xcd_remap && grid.x % 8 == 0;
     auto launch = [&](const RolloutArgs &args) {
         switch (policy) {

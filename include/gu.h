@@ -114,7 +114,9 @@ int gu_device_info(int device_id, char *buf, size_t len);
                                          done) triples [T][N][3] written with one 12-byte store per lane and step, -1 (default) =
                                          triples where they are faster (small batches under the uniform policy); what
                                          gu_read_trajectory, gu_mc_evaluate and the host see does not change                   */
-#define GU_OPT_COUNT 28
+#define GU_OPT_ROLLOUT_HALF_WAVES 28   /* transition-row kernel, launches that write rows: 32 envs per wave and twice the waves; -1 = where
+                                         measured faster (triples + pair tables at 8192 .. 16 384 envs; default), 0 never, 1 always   */
+#define GU_OPT_COUNT 29
 int gu_set_option(gu_handle h, int32_t option, int64_t value);
 int gu_get_option(gu_handle h, int32_t option, int64_t *value);   /* the value in force (own, process default or built-in) */
 

@@ -19,6 +19,7 @@ ap.add_argument('--reps', type=int, default=5)
 ap.add_argument('--launches', type=int, default=20)
 ap.add_argument('--json', default=None)
 ap.add_argument('--only', default=None)
+ap.add_argument('--half', action='store_true')
 ap.add_argument('--sizes', type=int, nargs='*', default=None, help='batch sizes for a crossover table on the config-2 and config-4 grids')
 args = ap.parse_args()
 T = 1000
@@ -37,8 +38,13 @@ def workload(name):
 if args.sizes:
     pass
 cases = [('c2', 'uniform'), ('c4', 'uniform'), ('c3', 'uniform'), ('c3', 'sample'), ('c3', 'greedy'), ('c3', 'stream')]
-variants = [('planes', dict(traj_layout=0)), ('triples', dict(traj_layout=1)), ('triples+pairs', dict(traj_layout=1, rollout_rows=3)),
+variants = [('planes', dict(traj_layout=0, rollout_half_waves=0)), ('triples', dict(traj_layout=1, rollout_half_waves=0)),
+            ('triples+pairs', dict(traj_layout=1, rollout_rows=3, rollout_half_waves=0)),
             ('planes general', dict(traj_layout=0, rollout_rows=0)), ('triples general', dict(traj_layout=1, rollout_rows=0))]
+if args.half:  # the transition-row kernel with 32 envs per wave and twice the waves (option rollout_half_waves)
+    variants = [('planes', dict(traj_layout=0, rollout_half_waves=0)), ('planes/half', dict(traj_layout=0, rollout_half_waves=1)),
+                ('triples/half', dict(traj_layout=1, rollout_half_waves=1)), ('tri+pairs', dict(traj_layout=1, rollout_rows=3, rollout_half_waves=0)),
+                ('tri+pairs/half', dict(traj_layout=1, rollout_rows=3, rollout_half_waves=1)), ('default', dict())]
 out = {}
 if args.sizes:
     cases = [(w + '@%d' % n, 'uniform') for w in ('c2', 'c4') for n in args.sizes]

@@ -135,6 +135,7 @@ int gu_create(int device_id, int64_t num_envs, int64_t env_id0, gu_handle *out)
         GU_HIP(hipHostMalloc(&h->h_pin, 4 * n * sizeof(int32_t), hipHostMallocDefault));
         GU_HIP(hipHostMalloc(&h->h_seq, 64, hipHostMallocDefault));
         GU_HIP(hipHostMalloc(&h->h_ctl, GU_CTL_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+        GU_HIP(hipHostMalloc(&h->h_up, GU_UP_BYTES, hipHostMallocDefault));
         memset(h->h_seq, 0, 64);
         GU_HIP(hipMalloc(&h->d_blocks_done, sizeof(uint32_t)));
         GU_HIP(hipMemsetAsync(h->d_blocks_done, 0, sizeof(uint32_t), h->stream));
@@ -172,6 +173,7 @@ int gu_destroy(gu_handle h)
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_seq) (void)hipHostFree(h->h_seq);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+    if (h->h_up) (void)hipHostFree(h->h_up);
     if (h->d_blocks_done) (void)hipFree(h->d_blocks_done);
     for (hipEvent_t ev : h->ev_marks) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : h->ev_cal)

@@ -211,6 +211,8 @@ struct gu_engine {
     // pinned host staging (4*N int32)
     int32_t *h_pin = nullptr;
     unsigned long long *h_ctl = nullptr;  // page-locked landing area of small results (gu_read_back): GU_CTL_WORDS 64-bit words
+    char *h_up = nullptr;                 // page-locked staging of small uploads (GU_UP_BYTES): a copy from it is one DMA the stream orders,
+                                          // a copy from the caller's pageable array is staged and waited for by the runtime
     uint32_t *h_seq = nullptr;      // page-locked control words (64 bytes): [0] completion word of gu_step's host-visible
                                     // paths, [GU_HOST_ERR_WORD] raised by a kernel that met an invalid action / state,
                                     // [GU_HOST_COUNT_WORD] number of done envs written by the compaction kernel
@@ -341,7 +343,8 @@ int gu_device_segments(gu_engine *h, const GuSegments &s);
 // Small results back to the host through the engine's page-locked landing area (a device-to-host copy into pageable memory is
 // staged and waited for by the runtime; into pinned memory it is one DMA): copies `bytes` from `src` on the device to `dst`, behind
 // everything queued on the engine's stream, and waits.  Larger than the area: the plain copy.
-#define GU_CTL_WORDS (8 + 4096)
+#define GU_CTL_WORDS (8 + 4096 + 20480)  /* ... and the tables of grids of up to 4096 states (v + pi: 40 bytes per state) in one go */
+#define GU_UP_BYTES (40 * 4096)         /* page-locked staging of small uploads (gu_vi_set) */
 int gu_read_back(gu_engine *h, void *dst, const void *src, size_t bytes);
 
 // ---- tabular DP launchers (gu_vi.hip) --------------------------------------------

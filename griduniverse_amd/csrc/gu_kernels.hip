@@ -585,7 +585,7 @@ static int gu_search_pace(gu_engine *h, int slot, int64_t T, const std::function
 // a fixed period applies to them all the same.  A kind's ring belongs to one launch SHAPE (trajectory buffer, workgroups, length
 // within a factor of two, row bytes): another shape starts it over from the model, the rows of 16 steps at GU_OPT_PACE_TARGET GB/s
 // (7200; the cliff sits at 7.4 .. 7.5 TB/s on the allocations measured in rounds 3 and 4).
-static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, GuPaceArgs *pace)
+static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int block_size, int row_bytes, GuPaceArgs *pace)
 {
     const int64_t waves = (h->N + 31) / 32;  // (the most a launch can have: the transition-row kernel's half waves)
     if (!h->d_pace_ring) {
@@ -624,7 +624,7 @@ static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, 
     pace->hi = std::max<uint32_t>(k.model * 2u, k.model + 4u);
     pace->groups = (uint32_t)std::min<int64_t>(T / 16, 0x7FFFFFFF);
     pace->report_at = (uint32_t)std::min<int64_t>(T > 160 ? T - 96 : std::max<int64_t>(T - 32, 1), 0x7FFFFFFF);
-    pace->n_waves = (uint32_t)std::min<int64_t>(waves, (int64_t)h->pace_slot_stride);  // (every slot the launch may write: an unused one reads as 'did not report')
+    pace->n_waves = (uint32_t)std::min<int64_t>((int64_t)blocks * (block_size / 64), (int64_t)h->pace_slot_stride);  // the waves of THIS launch
     pace->slot_stride = (uint32_t)h->pace_slot_stride;
     pace->bar_num = (uint16_t)gu_opt(h, GU_OPT_PACE_BAR_NUM);
     pace->gain_q = (uint32_t)gu_opt(h, GU_OPT_PACE_GAIN_Q);
@@ -640,7 +640,7 @@ static bool gu_pace_eligible(const gu_engine *h, int64_t T, unsigned blocks, int
     return !((double)h->N * (double)T * (double)row_bytes < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024);
 }
 
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_bytes, const std::function<void(uint32_t)> &launch, GuPaceArgs *pace)
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int block_size, int row_bytes, const std::function<void(uint32_t)> &launch, GuPaceArgs *pace)
 {
     *pace = GuPaceArgs{};
     if (h->pace_search_requested) {  // gu_rollout_pace_search: the search first, then this launch without a limiter
@@ -662,7 +662,7 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int row_byte
     if (opt == 0) return GU_OK;
     const bool eligible = gu_pace_eligible(h, T, blocks, row_bytes);
     if (eligible && !(opt > 0 && gu_opt(h, GU_OPT_PACE_RECORD) == 0)) {
-        const int rc = gu_pace_ring_for(h, slot, T, blocks, row_bytes, pace);
+        const int rc = gu_pace_ring_for(h, slot, T, blocks, block_size, row_bytes, pace);
         if (rc != GU_OK) return rc;
         if (opt > 0) pace->period = (uint32_t)opt, pace->fixed = 1;  // fixed, and recorded all the same
         if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
@@ -754,7 +754,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
     if (traj == 1 || traj == 3) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: GuPacer)
         RolloutArgs c = a;
-        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, gu_blocks(h->N, bs), 12, [&](uint32_t period) {
+        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, gu_blocks(h->N, bs), bs, 12, [&](uint32_t period) {
             c.pace = GuPaceArgs{};
             c.pace.period = period;
             gu_rollout_general(h, c, policy, auto_mode, traj, stats, bs);

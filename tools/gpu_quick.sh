@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python tools/dp_call_breakdown.py > gpurun_out/r05n_dp_call_breakdown.txt 2>&1; cat gpurun_out/r05n_dp_call_breakdown.txt
-timeout 900 python -m pytest tests/test_gpu_dp.py tests/test_gpu_compat_drivers.py tests/test_gpu_facade.py tests/test_gpu_mc.py -q -m gpu > gpurun_out/r05n_pytest.txt 2>&1; grep -E " passed| failed|rror" gpurun_out/r05n_pytest.txt | tail -5
+python tools/pace_loop.py --kind c3 --summary > gpurun_out/r05q_pace_loop_c3.txt 2>&1; tail -15 gpurun_out/r05q_pace_loop_c3.txt
+timeout 900 python -m pytest tests/test_gpu_store_pacing.py tests/test_gpu_traj_layout.py -q -m gpu > gpurun_out/r05q_pytest.txt 2>&1; grep -E " passed| failed|rror" gpurun_out/r05q_pytest.txt | tail -5
+for i in 1 2 3; do python bench.py --steps 400 --warmup 50 2>/dev/null | tail -1 >> gpurun_out/r05q_bench.jsonl; done; cat gpurun_out/r05q_bench.jsonl | cut -c1-400

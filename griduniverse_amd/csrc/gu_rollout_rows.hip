@@ -160,8 +160,11 @@ struct RowBytes {
 
 // nothing but the chain between the arrival of a record and the issue of the read it addresses (see word16)
 #define GU_CHAIN_FENCE() __builtin_amdgcn_sched_barrier(0)
+// (workgroups of up to 512 lanes, i.e. 256 registers: the staging below keeps up to twelve 16-byte rows per lane in flight beside the
+// 32 registers of the first wave's pacing slots)
+#define GU_ROWS_MAX_BLOCK 512
 template <int POLICY, int TRAJ, bool STATS, bool PAIR = false>
-__global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const RolloutArgs a, const int32_t auto_reset)
+__global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(const RolloutArgs a, const int32_t auto_reset)
 {
     static_assert(!PAIR || POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM, "pair tables: policies whose actions do not depend on the state");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -172,61 +175,172 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
     // LDS address of the staged table: folded into every record (0 in practice: this kernel has no static LDS), so that a
     // record's address bits are the raw ds_read address and no base is added on the dependent chain
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    // ---- The launch's fixed cost (round 5: 8.6 us of a 60 us config-4 shard, profiles/r05r_rows_intercept.txt) is LATENCY: the table
+    // came in through four dependent rounds of global loads (every copy of a row fetched separately, eight loads in flight), and
+    // the first step's three dependent global reads (state -> the cell's flags -> the next cell's flags and reward) started behind
+    // the staging barrier.  Now: the env's state is asked for before anything else; every SOURCE row is loaded once, all of a
+    // thread's loads in flight together, and written to its `copies` places from registers; and the first step's reads are issued
+    // between the stages of that, so that their round trips pass under it.
+    const uint32_t half = (uint32_t)a.half_waves;
+    const uint32_t slot_in_block = half ? ((threadIdx.x >> 6) << 5) | (threadIdx.x & 31u) : threadIdx.x;
+    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * (blockDim.x >> half) + slot_in_block;
+    const bool live = e64 < a.N && !(half && (threadIdx.x & 32u));
+    const uint32_t e = live ? (uint32_t)e64 : 0u;  // (a lane without an env reads the state of env 0 and stores nothing)
+    const uint32_t prefix = gu_rng_prefix(a.seed_prefix, a.env_id0 + e);
+    const int32_t start0 = auto_reset ? a.starts[0] : 0;
+    const char *pa = (const char *)a.actions;
+    const uint32_t e4 = e * 4u;
+    // First step of the launch, on the per-cell planes: the stored done flag decides the lazy reset (it may disagree with the
+    // cell: fresh reset onto a terminal start, gu_set_state).  In four parts, each one global round trip behind the one before:
+    // the state; the (post-reset) cell's flags and what the policy wants to know there; the flags and the reward of the cell the
+    // move ends on; the record.  (The `asm volatile` pins: left to itself the compiler hoists the first USE of a load to right
+    // behind its issue -- a wait for the state ahead of the table's loads.)
+    int32_t s = 0;
+    uint32_t d = 0, ep = 0, t_lane = 0, f0 = 0, first_x = 0, f1 = 0, r1 = 0, first_word = 0;
+    uint4 first_thr = make_uint4(0u, 0u, 0u, 0u);
+    auto first_0 = [&]() {
+        uint32_t ee = e;
+        asm volatile("" : "+v"(ee));
+        s = a.pos[ee];
+        d = (uint32_t)a.done[ee];
+        ep = a.episode[ee];
+        t_lane = a.tcount[ee];
+    };
+    auto first_a = [&]() {
+        asm volatile("" : "+v"(t_lane), "+v"(s), "+v"(d));
+        t_lane += a.steps_taken;
+        if (auto_reset && d) {
+            s = start0;
+            ++ep;
+        }
+        f0 = a.cell[s];
+        if (POLICY == GU_POLICY_GREEDY) first_x = a.greedy[s];
+        if (POLICY == GU_POLICY_SAMPLE) {
+            first_thr = a.pi_thr[s];
+            first_word = gu_rng_sample_word(prefix, t_lane);
+        }
+        if (POLICY == GU_POLICY_UNIFORM) first_x = (gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t_lane >> 4) >> (2u * (t_lane & 15u))) & 3u;
+        if (POLICY == GU_POLICY_STREAM) first_x = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void *)pa, 0, 0xFFFFFFFFu, 0x00020000), e4, 0, 0) & 3u;
+    };
+    auto first_b = [&]() {
+        asm volatile("" : "+v"(f0));
+        const uint32_t act = POLICY == GU_POLICY_SAMPLE ? gu_sample_action(first_word, first_thr) : first_x;
+        const int8_t *rew = reinterpret_cast<const int8_t *>(a.cell + a.cell_bytes);
+        s += ((f0 >> act) & 1u) ? gu_delta<false>(act, 0, a.W) : 0;
+        f1 = a.cell[s];
+        r1 = (uint32_t)(uint8_t)rew[s];
+    };
     {
-        // Staging, 16 bytes per thread and iteration, consecutive threads -> consecutive LDS addresses; unrolled so that eight
-        // loads are in flight before the first store (one load's L2 latency per iteration made this the launch's fixed cost:
-        // 15 us for 128 KB of greedy rows copied dword by dword).
-        const int32_t units = PAIR ? a.S * 9 : (a.S << shift) >> 4;  // 16-byte units of the LDS image (PAIR: 128 + 16 bytes per cell)
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        const uint4 *g4 = reinterpret_cast<const uint4 *>(a.rows);
+        const uint32_t copies = 1u << copies_log2;
+        if (POLICY == GU_POLICY_GREEDY && copies_log2 < 2) {  // (fewer than four copies of a dword row: the old way, dword by dword)
+            const int32_t units = (a.S << shift) >> 4;
+            first_0();
+            first_a();
 #pragma unroll 8
-        for (int32_t u = threadIdx.x; u < units; u += blockDim.x) {
-            uint4 v;
-            if (POLICY == GU_POLICY_GREEDY) {  // four consecutive dwords of the image: copies of one cell, or of neighbours
+            for (int32_t u = threadIdx.x; u < units; u += blockDim.x) {
                 const int32_t d0 = u << 2;
-                v = make_uint4(a.rows[d0 >> copies_log2], a.rows[(d0 + 1) >> copies_log2], a.rows[(d0 + 2) >> copies_log2],
-                               a.rows[(d0 + 3) >> copies_log2]);
+                uint4 v = make_uint4(a.rows[d0 >> copies_log2], a.rows[(d0 + 1) >> copies_log2], a.rows[(d0 + 2) >> copies_log2], a.rows[(d0 + 3) >> copies_log2]);
                 v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
-            } else if (POLICY == GU_POLICY_SAMPLE) {  // unit 2r = thresholds of row r (as they are), 2r + 1 = its next records
-                const int32_t c = (u >> 1) >> copies_log2;
-                v = g4[2 * c + (u & 1)];
-                if (u & 1) v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
-            } else if (PAIR) {  // the global image is the LDS image: pair table, then the one-step table
-                v = reinterpret_cast<const uint4 *>(a.rows2)[u];
-                v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
-            } else {
-                v = g4[u >> copies_log2];
-                v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
+                dst[u] = v;
             }
-            dst[u] = v;
+            first_b();
+        } else {
+            // Source rows: the LDS image itself (PAIR: pair table, then the one-step table; nothing is replicated), or one dword per
+            // cell (greedy), one 16-byte unit per cell (uniform / stream), two per cell (sampled: thresholds, next records), each
+            // written to `places` places: place k of a row is copy (k + cell) mod copies, so that the lanes of a store, which hold
+            // consecutive cells, hit different 16-byte slots of the bank row instead of all the same one.
+            // No guards: a lane beyond the end works on the LAST row again, same value to the same place, and the code is chosen once,
+            // by the number of source rows per thread, among straight-line variants.  (A per-lane guard is an exec-mask region of ~25
+            // clocks around every one of a thread's 30 .. 60 loads and stores; wave-uniform guards make the compiler wait for ALL loads
+            // before every guarded one -- for all it knows a guarded load's guarded use was skipped --; an unrolled loop with a
+            // `break` came back as a loop over an array in scratch memory.)
+            const int32_t B = (int32_t)blockDim.x, log2_b = 31 - __builtin_clz((uint32_t)B);
+            const int32_t n_src = PAIR ? a.S * 9 : POLICY == GU_POLICY_SAMPLE ? 2 * a.S : a.S;
+            const uint4 *g4 = reinterpret_cast<const uint4 *>(PAIR ? a.rows2 : a.rows);
+            const uint32_t places = PAIR ? 1u : POLICY == GU_POLICY_GREEDY ? copies >> 2 : copies;  // 16-byte places per source row
+            auto put = [&](uint4 v, int32_t g) {
+                if (PAIR || (POLICY != GU_POLICY_GREEDY && (POLICY != GU_POLICY_SAMPLE || (g & 1)))) v.x += lds_base, v.y += lds_base, v.z += lds_base, v.w += lds_base;
+                if (PAIR) {
+                    dst[g] = v;
+                    return;
+                }
+                const uint32_t cell = POLICY == GU_POLICY_SAMPLE ? (uint32_t)g >> 1 : (uint32_t)g;
+                auto at = [&](uint32_t k) {
+                    const uint32_t place = (k + cell) & (places - 1u);
+                    return POLICY == GU_POLICY_SAMPLE ? ((cell * places + place) << 1) | ((uint32_t)g & 1u) : cell * places + place;
+                };
+                if (places == 8u) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; ++k) dst[at(k)] = v;
+                } else if (places == 4u) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) dst[at(k)] = v;
+                } else {
+                    for (uint32_t k = 0; k < places; ++k) dst[at(k)] = v;
+                }
+            };
+            // NB rows per thread from `base` on: all loads out, `between()`, then the stores
+            auto stage = [&](auto nb, int32_t base, auto between) {
+                constexpr int NB = decltype(nb)::value;
+                uint4 v[NB];
+#pragma unroll
+                for (int32_t j = 0; j < NB; ++j) {
+                    const uint32_t g = (uint32_t)min(base + j * B + (int32_t)threadIdx.x, n_src - 1);  // (unsigned: base register + 32-bit offset, no address pair per load)
+                    if (POLICY == GU_POLICY_GREEDY && !PAIR) {
+                        const uint32_t w = a.rows[g] + lds_base;
+                        v[j] = make_uint4(w, w, w, w);
+                    } else {
+                        v[j] = g4[g];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (the state BEHIND the table's loads: an address of theirs otherwise waits for it, see first_0)
+                between();
+#pragma unroll
+                for (int32_t j = 0; j < NB; ++j) put(v[j], min(base + j * B + (int32_t)threadIdx.x, n_src - 1));
+            };
+            auto first_0a = [&]() {
+                first_0();
+                first_a();
+            };
+            auto nothing = []() {};
+            const int32_t rows_total = (n_src + B - 1) >> log2_b;  // source rows per thread
+            if (rows_total <= 1) {
+                stage(std::integral_constant<int, 1>{}, 0, first_0a);
+                first_b();
+            } else if (rows_total <= 2) {
+                stage(std::integral_constant<int, 2>{}, 0, first_0a);
+                first_b();
+            } else if (rows_total <= 4) {
+                stage(std::integral_constant<int, 4>{}, 0, first_0a);
+                first_b();
+            } else if (TRAJ != 0 && rows_total <= 8) {
+                stage(std::integral_constant<int, 8>{}, 0, first_0a);
+                first_b();
+            } else {
+                // (launches that write no rows run several workgroups per CU: they keep to four rows in flight, 16 registers)
+                constexpr int WIDE = TRAJ == 0 ? 4 : 12;
+                stage(std::integral_constant<int, WIDE>{}, 0, first_0a);
+                stage(std::integral_constant<int, WIDE>{}, WIDE * B, first_b);
+#pragma unroll 1
+                for (int32_t base = 2 * WIDE * B; base < n_src; base += WIDE * B) stage(std::integral_constant<int, WIDE>{}, base, nothing);
+            }
         }
         __syncthreads();
     }
     // HALF WAVES (a.half_waves, round 5): lanes 0 .. 31 of every wave carry an env, the others leave -- twice as many waves for the
     // batch.  (The idea: a wave that has its SIMD to itself is bound by its own in-order issue, and the row stores might cost by the
     // lanes they carry.  They do not -- see the launcher for what was measured and where this is used.)
-    const uint32_t half = (uint32_t)a.half_waves;
     if (half) pacer.decide_early(a.pace);  // (the launch's first wave sums the launch before while it still has its 64 lanes)
-    if (half && (threadIdx.x & 32u)) return;
-    const uint32_t slot_in_block = half ? ((threadIdx.x >> 6) << 5) | (threadIdx.x & 31u) : threadIdx.x;
-    const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * (blockDim.x >> half) + slot_in_block;
-    if (e64 >= a.N) return;
-    const uint32_t e = (uint32_t)e64;
+    if (!live) return;
     const uint32_t lane_copy = PAIR ? 0u : (threadIdx.x & ((1u << copies_log2) - 1u)) << RowBytes<POLICY>::log2;  // this lane's copy of every row
     const uint32_t base1 = lds_base + ((uint32_t)a.S << GU_PAIR_SHIFT);  // PAIR: the one-step table behind the pair table
 
-    int32_t s = a.pos[e];
-    uint32_t d = (uint32_t)a.done[e];
-    uint32_t ep = a.episode[e];
-    const uint32_t t_lane = a.tcount[e] + a.steps_taken;
-    const uint32_t prefix = gu_rng_prefix(a.seed_prefix, a.env_id0 + e);
     int32_t ret = 0;
     uint32_t fin = 0;
     uint32_t rec;
 
     char *po = (char *)a.tr_obs, *pr = (char *)a.tr_reward, *pd = (char *)a.tr_done;
-    const char *pa = (const char *)a.actions;
-    const uint32_t e4 = e * 4u;
     const int64_t row = a.N * 4;
     // the trajectory's own row pitch and lane offset (TRAJ == 3: one row of (obs, reward, done) triples per step, gu_rollout.hpp)
     const int64_t trow = TRAJ == 3 ? a.N * 12 : row;
@@ -267,19 +381,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             }
         }
     };
-    // first step of the launch, on the per-cell planes: the stored done flag decides the lazy reset (it may disagree
-    // with the cell: fresh reset onto a terminal start, gu_set_state)
-    auto first_step = [&](uint32_t act) {
-        const int8_t *rew = reinterpret_cast<const int8_t *>(a.cell + a.cell_bytes);
-        if (auto_reset && d) {
-            s = a.starts[0];
-            ++ep;
-        }
-        const uint32_t f0 = a.cell[s];
-        s += ((f0 >> act) & 1u) ? gu_delta<false>(act, 0, a.W) : 0;
-        const uint32_t dn = (a.cell[s] >> GU_CELL_TERM_BIT) & 1u;
-        rec = (((uint32_t)s << shift) + lds_base) | (dn << GU_ROW_DONE_BIT) | ((uint32_t)(uint8_t)rew[s] << 24);
-    };
+    // third part of the launch's first step (its loads were issued under the staging, above): the record it ends on
+    rec = (((uint32_t)s << shift) + lds_base) | (((f1 >> GU_CELL_TERM_BIT) & 1u) << GU_ROW_DONE_BIT) | (r1 << 24);
     // `x`: the action (uniform / stream), nothing (greedy), the step's RNG word (sample); `between`: work that does not depend
     // on the env state (hashing the next step's RNG word), placed between the issue of the LDS reads and their first use
     auto step = [&](uint32_t x, uint32_t soff, auto between) {
@@ -357,8 +460,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
 
     if (POLICY == GU_POLICY_UNIFORM) {
         uint32_t t = t_lane;
-        uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
-        first_step((word >> (2u * (t & 15u))) & 3u);
+        uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);  // (the first step is taken: first_a / first_b)
         ++t;
         int64_t i = 1;
         const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);
@@ -390,11 +492,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
     } else if (POLICY == GU_POLICY_GREEDY || POLICY == GU_POLICY_SAMPLE) {
         // first step on the planes; the policy is consulted at the post-reset cell
         uint32_t t = t_lane;
-        uint32_t word = POLICY == GU_POLICY_SAMPLE ? gu_rng_sample_word(prefix, t) : 0u;
-        {
-            const int32_t at = (auto_reset && d) ? a.starts[0] : s;
-            first_step(POLICY == GU_POLICY_GREEDY ? (uint32_t)a.greedy[at] : gu_sample_action(word, a.pi_thr[at]));
-        }
+        uint32_t word = first_word;  // (the first step is taken: first_a / first_b)
         if (POLICY == GU_POLICY_SAMPLE) word = gu_rng_sample_advance(prefix, t, word);
         ++t;
         int64_t i = 1;
@@ -443,7 +541,6 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_rows_kernel(const Rol
             if (TRAJ) rebase(1);
         }
     } else {  // GU_POLICY_STREAM: packed words of 16 two-bit actions (gu_pack_actions_kernel), see gu_stream_run
-        first_step((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void *)pa, 0, 0xFFFFFFFFu, 0x00020000), e4, 0, 0) & 3u);
         gu_stream_run(
             pa, row, e4, a.T, 1,
             [&](uint32_t word) {
@@ -484,7 +581,7 @@ static bool rows_shape(const gu_engine *h, int row_bytes, int max_copies, int *b
     // table is staged with wide, pipelined stores; the workgroup size does: profiles/archive/r02e_rows_copies.txt)
     // (128- and 64-thread workgroups, which spread a 32 768-env launch over all CUs instead of half of them, are no faster: 70 .. 72 us
     // either way, profiles/archive/r03h_rows_block.txt)
-    for (int bs = 256; bs <= GU_MAX_BLOCK; bs <<= 1) {
+    for (int bs = 256; bs <= GU_ROWS_MAX_BLOCK; bs <<= 1) {
         const int64_t blocks = (h->N + bs - 1) / bs, per_cu = (blocks + h->n_cu - 1) / h->n_cu;
         for (int c = max_copies; c >= 1; c >>= 1) {
             if ((int64_t)h->S * row_bytes * c * per_cu <= h->lds_per_cu - 2048) {

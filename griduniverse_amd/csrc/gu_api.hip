@@ -232,6 +232,7 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
     const int32_t S = W * H;
     const int32_t cell_bytes = (S + 15) & ~15;
     GU_HIP(hipStreamSynchronize(h->stream));
+    h->entry_table_ok = false;  // (other cells, other flags)
     for (void *p : {(void *)h->d_cell, (void *)h->d_cell_raw, (void *)h->d_kind, (void *)h->d_starts, (void *)h->d_nstarts, (void *)h->d_greedy})
         if (p) GU_HIP(hipFree(p));
     h->d_cell = h->d_cell_raw = h->d_kind = h->d_greedy = nullptr;
@@ -606,6 +607,7 @@ int gu_step_device(gu_handle h, int64_t t, uint32_t flags)
 int gu_step_graph(gu_handle h, int64_t t0, int64_t T, uint32_t flags)
 {
     GU_ENTER(h);
+    h->entry_table_ok = false;
     GU_NEED_GRID(h);
     GU_REQUIRE(h->d_actions && t0 >= 0 && T > 0 && t0 + T <= h->actions_T, GU_ERR_STATE, "rows [%lld,%lld) not in the uploaded action stream",
                (long long)t0, (long long)(t0 + T));
@@ -1118,6 +1120,7 @@ int gu_get_state(gu_handle h, int32_t *pos, int32_t *done, uint32_t *episode, ui
 int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uint32_t *episode, const uint32_t *tcount)
 {
     GU_ENTER(h);
+    h->entry_table_ok = false;
     GU_NEED_GRID(h);
     const size_t n = (size_t)h->N;
     if (pos)

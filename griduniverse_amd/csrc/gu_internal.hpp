@@ -202,6 +202,7 @@ struct gu_engine {
 
     // done compaction: one ballot word per wave, written by every kernel that writes done[]
     uint64_t *d_done_bits = nullptr;
+    bool entry_table_ok = false;    // the env state was left by a rollout (done flag == TERM bit of the cell, reward == the cell's): gu_rollout_rows.hip
     bool done_bits_valid = false;   // false only after the host installed done[] (gu_set_state)
 
     // scratch for masks / start choices / look_step_ahead

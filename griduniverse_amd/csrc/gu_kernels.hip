@@ -313,6 +313,7 @@ __global__ void __launch_bounds__(1024) gu_done_compact_kernel(const uint64_t *_
 // ------------------------------------------------------------------------------------
 int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice, bool only_done)
 {
+    h->entry_table_ok = false;  // (a reset may land on a terminal start cell: done = 0 on a terminal cell)
     int trail_rc = gu_trail_before_reset(h, d_mask, only_done);  // (reads the done flags the reset is about to clear)
     if (trail_rc != GU_OK) return trail_rc;
     ResetArgs a{h->pos(), h->done(), h->d_episode, h->d_starts, d_mask, d_choice, h->d_done_bits,
@@ -325,6 +326,7 @@ int gu_launch_reset(gu_engine *h, const uint8_t *d_mask, const int32_t *d_choice
 int gu_launch_step(gu_engine *h, const int32_t *d_actions_row, uint32_t flags, int32_t *host_obs, int32_t *host_reward,
                    int32_t *host_done, uint32_t *host_seq, uint32_t seq, uint32_t *host_err)
 {
+    h->entry_table_ok = false;
     StepArgs a{h->d_cell, h->cell_bytes, h->W, h->delta_lut, d_actions_row, h->pos(), h->reward(), h->done(),
                h->d_episode, h->d_tcount, h->d_starts, (uint32_t)h->n_starts, h->seed_prefix, (uint32_t)h->env_id0, h->N, flags,
                gu_grid_sel(h), host_obs, host_reward, host_done, host_seq, seq, h->d_blocks_done, host_err, h->d_done_bits};
@@ -731,6 +733,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.stream_lds_off = 0;
     a.stream_lds_words = 0;
     a.half_waves = 0;
+    a.entry_table = (h->entry_table_ok && gu_opt(h, GU_OPT_ROLLOUT_ENTRY) != 0) ? 1 : 0;
     const int bs = gu_rollout_block(h);
     a.pace = GuPaceArgs{};
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)
@@ -739,6 +742,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     if (gu_rollout_multi(h, a, policy, auto_mode, traj, stats)) {
         GU_HIP(hipGetLastError());
         h->steps_taken += (uint32_t)T;
+        h->entry_table_ok = true;
         return gu_trail_after_rollout(h, T, traj, auto_mode != 0);
     }
     {
@@ -747,6 +751,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
             if (rows_rc != GU_OK) return rows_rc;
             GU_HIP(hipGetLastError());
             h->steps_taken += (uint32_t)T;
+            h->entry_table_ok = true;
             if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
             return gu_trail_after_rollout(h, T, traj, auto_mode != 0);
         }
@@ -767,6 +772,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
     GU_HIP(hipGetLastError());
     h->steps_taken += (uint32_t)T;
+    h->entry_table_ok = true;
     return gu_trail_after_rollout(h, T, traj, auto_mode != 0);
 }
 

@@ -130,6 +130,7 @@ extern "C" int gu_generate_mazes(gu_handle h, int32_t n_grids, int32_t W, int32_
 {
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
+    h->entry_table_ok = false;
     GU_REQUIRE(n_grids > 0 && h->N % n_grids == 0, GU_ERR_INVALID, "n_grids=%d must divide num_envs=%lld", n_grids, (long long)h->N);
     GU_REQUIRE(W > 0 && H > 0 && (W >= 4 || H >= 4), GU_ERR_INVALID, "a %d x %d grid has no room for a corridor (need max(W,H) >= 4)", W, H);
     GU_REQUIRE((int64_t)W * H <= 65535, GU_ERR_UNSUPPORTED, "generated mazes are limited to 65535 cells");

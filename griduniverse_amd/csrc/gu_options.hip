@@ -48,6 +48,7 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_PACE_PROBE_EVERY", 1024, 0, 1 << 24},
     {"GU_PACE_ADAPT", 1, 0, 1},
     {"GU_ROLLOUT_HALF_WAVES", -1, -1, 1},
+    {"GU_ROLLOUT_ENTRY", 1, 0, 1},
 };
 const char *g_spec_x[GU_OPT_X_COUNT] = {"GU_TRAJ_UNCACHED", "GU_TRAJ_POISON", "GU_MC_POISON"};
 

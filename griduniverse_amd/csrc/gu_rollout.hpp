@@ -355,6 +355,7 @@ struct RolloutArgs {
     int32_t row_shift;      // log2(16 * copies) of that table
     int32_t stream_lds_off; // GU_POLICY_STREAM, MAP 1: byte offset in LDS of the staged action words [stream_lds_words][blockDim.x] ...
     int32_t stream_lds_words;  // ... and how many words per lane fit (0: every word is read from HBM when its steps are due)
+    int32_t entry_table;    // transition-row kernel: the state at entry was left by a rollout -- the first step runs on the table too
     int32_t half_waves;     // transition-row kernel: lanes 0 .. 31 of every wave carry an env, twice the waves (gu_rollout_rows.hip)
     int32_t xcd_remap;      // workgroup b works on env block (b % 8) * (blocks / 8) + b / 8: one XCD = one contiguous env range
     GuPaceArgs pace;        // launches that write rows: the waves' schedule (GuPacer), the rate limiter of the store stream

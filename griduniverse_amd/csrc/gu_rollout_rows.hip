@@ -206,23 +206,28 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
         ep = a.episode[ee];
         t_lane = a.tcount[ee];
     };
+    // ... unless the state was left by a rollout (a.entry_table: gu_launch_rollout vouches for it).  Then the done flag IS the TERM bit
+    // of the cell, the table's rows apply to the first step like to any other, and the launch's fixed cost is ONE global round
+    // trip (the state, under the staging) instead of three.
+    const bool entry_table = a.entry_table != 0;
     auto first_a = [&]() {
         asm volatile("" : "+v"(t_lane), "+v"(s), "+v"(d));
         t_lane += a.steps_taken;
+        if (POLICY == GU_POLICY_SAMPLE) first_word = gu_rng_sample_word(prefix, t_lane);
         if (auto_reset && d) {
-            s = start0;
+            if (!entry_table) s = start0;  // (on the table the row of a terminal cell is the row of the start cell)
             ++ep;
         }
-        f0 = a.cell[s];
-        if (POLICY == GU_POLICY_GREEDY) first_x = a.greedy[s];
-        if (POLICY == GU_POLICY_SAMPLE) {
-            first_thr = a.pi_thr[s];
-            first_word = gu_rng_sample_word(prefix, t_lane);
+        if (!entry_table) {
+            f0 = a.cell[s];
+            if (POLICY == GU_POLICY_GREEDY) first_x = a.greedy[s];
+            if (POLICY == GU_POLICY_SAMPLE) first_thr = a.pi_thr[s];
         }
         if (POLICY == GU_POLICY_UNIFORM) first_x = (gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t_lane >> 4) >> (2u * (t_lane & 15u))) & 3u;
         if (POLICY == GU_POLICY_STREAM) first_x = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void *)pa, 0, 0xFFFFFFFFu, 0x00020000), e4, 0, 0) & 3u;
     };
     auto first_b = [&]() {
+        if (entry_table) return;
         asm volatile("" : "+v"(f0));
         const uint32_t act = POLICY == GU_POLICY_SAMPLE ? gu_sample_action(first_word, first_thr) : first_x;
         const int8_t *rew = reinterpret_cast<const int8_t *>(a.cell + a.cell_bytes);
@@ -381,11 +386,12 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
             }
         }
     };
-    // third part of the launch's first step (its loads were issued under the staging, above): the record it ends on
+    // last part of the launch's first step (its loads were issued under the staging, above): the record it ends on -- or, on the
+    // table, the record the state at entry stands for (only its address counts: it is never emitted)
     rec = (((uint32_t)s << shift) + lds_base) | (((f1 >> GU_CELL_TERM_BIT) & 1u) << GU_ROW_DONE_BIT) | (r1 << 24);
     // `x`: the action (uniform / stream), nothing (greedy), the step's RNG word (sample); `between`: work that does not depend
     // on the env state (hashing the next step's RNG word), placed between the issue of the LDS reads and their first use
-    auto step = [&](uint32_t x, uint32_t soff, auto between) {
+    auto step_e = [&](uint32_t x, uint32_t soff, auto between, auto emits) {
         const uint32_t prev = rec;
         if (POLICY == GU_POLICY_SAMPLE) {
             const uint32_t addr = (prev & GU_ROW_ADDR_MASK) | lane_copy;
@@ -418,9 +424,12 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
                 rec = *(lds_u32_ptr)(uintptr_t)addr;
             }
         }
-        emit(prev, soff);
+        if (decltype(emits)::value) emit(prev, soff);
     };
+    auto step = [&](uint32_t x, uint32_t soff, auto between) { step_e(x, soff, between, std::true_type{}); };
     auto nothing = [] {};
+    // the first step on the table (a.entry_table): like any other, but the record it starts from is nobody's row
+    if (entry_table) step_e(POLICY == GU_POLICY_SAMPLE ? first_word : first_x, 0, nothing, std::false_type{});
     pacer.start(a.pace, TRAJ != 0);
     auto step1 = [&](uint32_t x) {
         step(x, 0, nothing);

@@ -1094,6 +1094,7 @@ int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta)
 {
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
+    h->entry_table_ok = false;  // (the fused launches step the envs: their state is consistent too, but only rollouts vouch for it)
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_vi_sweep_step accepts only GU_F_AUTO_RESET");
     GU_REQUIRE(!h->trail_cap, GU_ERR_UNSUPPORTED, "the agent trail is on (gu_trail_enable): the fused sweep + step launches do not feed it");
@@ -1133,6 +1134,7 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
 {
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
+    h->entry_table_ok = false;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_vi_sweep_step_run accepts only GU_F_AUTO_RESET");
     GU_REQUIRE(!h->trail_cap, GU_ERR_UNSUPPORTED, "the agent trail is on (gu_trail_enable): the fused sweep + step launches do not feed it");

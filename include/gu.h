@@ -116,7 +116,10 @@ int gu_device_info(int device_id, char *buf, size_t len);
                                          gu_read_trajectory, gu_mc_evaluate and the host see does not change                   */
 #define GU_OPT_ROLLOUT_HALF_WAVES 28   /* transition-row kernel, launches that write rows: 32 envs per wave and twice the waves; -1 = where
                                          measured faster (triples + pair tables at 8192 .. 16 384 envs; default), 0 never, 1 always   */
-#define GU_OPT_COUNT 29
+#define GU_OPT_ROLLOUT_ENTRY 29        /* transition-row kernel: 1 (default) = a launch that follows another rollout of the same engine takes
+                                         its FIRST step on the staged table too (the state a rollout leaves behind always agrees with its cell);
+                                         0 = always on the per-cell planes, as a launch behind gu_reset / gu_set_state / gu_step must       */
+#define GU_OPT_COUNT 30
 int gu_set_option(gu_handle h, int32_t option, int64_t value);
 int gu_get_option(gu_handle h, int32_t option, int64_t *value);   /* the value in force (own, process default or built-in) */
 

@@ -96,6 +96,65 @@ def test_rows_kernel_first_step_honours_a_stored_state_that_disagrees_with_the_c
                 assert all(np.array_equal(s[k], getattr(st, k)) for k in ('pos', 'done', 'episode', 'tcount'))
 
 
+@pytest.mark.parametrize('policy', ['uniform', 'stream', 'greedy', 'sample'])
+def test_the_first_step_runs_on_the_table_behind_a_rollout_and_on_the_planes_behind_anything_else(force_rows, gu_option, policy):
+    """A launch that follows another rollout takes its first step on the staged table (option rollout_entry, the default): the state
+    a rollout leaves behind always agrees with its cell.  Behind a reset (here: onto a TERMINAL start cell), gu_set_state with flags
+    that disagree with the cells, or a step call, it must not.  Every launch of such a sequence against the oracle, with the option on
+    and off; both runs also equal each other in every row."""
+    meta, _ = G.load_traj('c4_lava32')
+    N, T = 777, 37
+    S = meta['W'] * meta['H']
+    rows = {}
+    for entry in (1, 0):
+        gu_option('rollout_entry', entry)
+        m = dict(meta, starts=[16])  # a lava cell: every reset lands on a terminal start
+        grid, st, eng = _oracle_and_engine(m, N, 11)
+        out = []
+        with eng:
+            eng.reserve_trajectory(T)
+            table = np.random.RandomState(3).dirichlet(np.ones(4), S)
+            if policy == 'greedy':
+                table = np.eye(4)[np.random.RandomState(3).randint(0, 4, S)]
+            if policy in ('greedy', 'sample'):
+                eng.vi_set(np.zeros(S), table)
+            rs = np.random.RandomState(4)
+
+            def launch(auto):
+                acts = rs.randint(0, 4, (T, N)).astype(np.int32) if policy == 'stream' else None
+                if acts is not None:
+                    eng.upload_actions(acts)
+                eng.rollout(T, policy, auto, True, stats=True)
+                kw = dict(actions=acts) if policy == 'stream' else dict(pi=table) if policy != 'uniform' else {}
+                want = C.rollout(grid, 11, st, T, auto, stats=True, **kw)
+                got = eng.read_trajectory(0, T)
+                assert all(np.array_equal(got[k], want[k]) for k in got), (policy, entry, len(out))
+                s = eng.get_state()
+                assert all(np.array_equal(s[k], getattr(st, k)) for k in ('pos', 'done', 'episode', 'tcount')), (policy, entry, len(out))
+                out.append(got)
+
+            launch(True)    # behind the reset onto a terminal start: planes
+            launch(True)    # behind a rollout: table
+            launch(False)   # ... without auto-reset: the absorbing rows
+            launch(True)
+            assert np.array_equal(eng.reset(), C.reset(grid, 11, st))
+            launch(True)
+            free = np.setdiff1d(np.arange(S), meta['walls'])
+            st.pos[:] = rs.choice(free, N)
+            st.done[:] = rs.randint(0, 2, N)  # flags that disagree with the cells
+            eng.set_state(pos=st.pos, done=st.done)
+            launch(True)
+            launch(True)
+            a = rs.randint(0, 4, N).astype(np.int32)
+            obs, rew, done = eng.step(a)
+            want = C.rollout(grid, 11, st, 1, False, actions=a[None, :])
+            assert np.array_equal(obs, want['obs'][0]) and np.array_equal(done, want['done'][0])
+            launch(True)
+            launch(True)
+        rows[entry] = out
+    assert all(np.array_equal(x[k], y[k]) for x, y in zip(rows[0], rows[1]) for k in x)
+
+
 def test_rows_and_general_kernel_agree_at_config_sizes(gu_option):
     """Config 3 at full size (65 536 envs x 1000 steps) through both kernels: identical trajectory digest, stats and state;
     and the default dispatch (rows for stats-only / packed, general for int32 rows) reproduces the reference's digest."""

@@ -174,7 +174,11 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
     const int32_t copies_log2 = shift - RowBytes<POLICY>::log2;
     // LDS address of the staged table: folded into every record (0 in practice: this kernel has no static LDS), so that a
     // record's address bits are the raw ds_read address and no base is added on the dependent chain
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    // (This kernel has no static LDS: its dynamic block starts at LDS address 0 and a record's address bits ARE the ds_read address.
+    // The compiler does not know that -- the block's address is a link-time constant to it -- and spent one vector instruction per
+    // emitted record on `rec - base`, a fifth of config 2's per-step vector work.  The launcher checks it: rows_dispatch refuses an
+    // instantiation that reports static LDS.)
+    constexpr uint32_t lds_base = 0u;
     // ---- The launch's fixed cost (round 5: 8.6 us of a 60 us config-4 shard, profiles/r05r_rows_intercept.txt) is LATENCY: the table
     // came in through four dependent rounds of global loads (every copy of a row fetched separately, eight loads in flight), and
     // the first step's three dependent global reads (state -> the cell's flags -> the next cell's flags and reward) started behind
@@ -615,13 +619,20 @@ static int rows_max_copies(const gu_engine *h, int32_t policy)
 static int rows_mode(const gu_engine *h) { return (int)gu_opt(h, GU_OPT_ROLLOUT_ROWS); }
 
 template <int POLICY, bool PAIR = false>
-static void rows_dispatch(const gu_engine *h, const RolloutArgs &a, int traj, bool stats, int auto_reset, dim3 grid, dim3 block, size_t lds, hipStream_t stream)
+static bool rows_dispatch(const gu_engine *h, const RolloutArgs &a, int traj, bool stats, int auto_reset, dim3 grid, dim3 block, size_t lds, hipStream_t stream)
 {
 #define GU_ROWS_LAUNCH(TR, ST)                                                                                           \
     do {                                                                                                                 \
         auto kern = gu_rollout_rows_kernel<POLICY, TR, ST, PAIR>;                                                        \
         static std::atomic<uint64_t> raised{0}; /* per instantiation and per device: raise the dynamic-LDS limit once */ \
         gu_allow_lds(kern, raised, h->device, lds, (size_t)h->lds_per_cu);                                               \
+        static std::atomic<int> base_zero{0}; /* 1: no static LDS, the dynamic block starts at 0 (the kernel relies on it) */ \
+        if (!base_zero.load(std::memory_order_relaxed)) {                                                                \
+            hipFuncAttributes fa{};                                                                                      \
+            const bool got = hipFuncGetAttributes(&fa, (const void *)kern) == hipSuccess;                                \
+            base_zero.store(got && fa.sharedSizeBytes == 0 ? 1 : 2, std::memory_order_relaxed);                          \
+        }                                                                                                                \
+        if (base_zero.load(std::memory_order_relaxed) != 1) return false;                                                \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, a, auto_reset);                                               \
     } while (0)
     if (traj == 1) {
@@ -633,6 +644,7 @@ static void rows_dispatch(const gu_engine *h, const RolloutArgs &a, int traj, bo
     } else {
         if (stats) GU_ROWS_LAUNCH(0, true); else GU_ROWS_LAUNCH(0, false);
     }
+    return true;
 #undef GU_ROWS_LAUNCH
 }
 
@@ -761,18 +773,19 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     a.half_waves = half ? 1 : 0;
     const dim3 grid(gu_blocks(h->N, half ? bs / 2 : bs)), block(bs);
     a.xcd_remap = a.xcd_remap && grid.x % 8 == 0;
+    bool launched = true;  // (false: an instantiation with static LDS below its table -- not this build; the launch fails loudly)
     auto launch = [&](const RolloutArgs &args) {
         switch (policy) {
         case GU_POLICY_UNIFORM:
-            if (pair) rows_dispatch<GU_POLICY_UNIFORM, true>(h, args, traj, stats, which, grid, block, lds, h->stream);
-            else rows_dispatch<GU_POLICY_UNIFORM>(h, args, traj, stats, which, grid, block, lds, h->stream);
+            launched = pair ? rows_dispatch<GU_POLICY_UNIFORM, true>(h, args, traj, stats, which, grid, block, lds, h->stream)
+                            : rows_dispatch<GU_POLICY_UNIFORM>(h, args, traj, stats, which, grid, block, lds, h->stream);
             break;
         case GU_POLICY_STREAM:
-            if (pair) rows_dispatch<GU_POLICY_STREAM, true>(h, args, traj, stats, which, grid, block, lds, h->stream);
-            else rows_dispatch<GU_POLICY_STREAM>(h, args, traj, stats, which, grid, block, lds, h->stream);
+            launched = pair ? rows_dispatch<GU_POLICY_STREAM, true>(h, args, traj, stats, which, grid, block, lds, h->stream)
+                            : rows_dispatch<GU_POLICY_STREAM>(h, args, traj, stats, which, grid, block, lds, h->stream);
             break;
-        case GU_POLICY_GREEDY: rows_dispatch<GU_POLICY_GREEDY>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
-        default: rows_dispatch<GU_POLICY_SAMPLE>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
+        case GU_POLICY_GREEDY: launched = rows_dispatch<GU_POLICY_GREEDY>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
+        default: launched = rows_dispatch<GU_POLICY_SAMPLE>(h, args, traj, stats, which, grid, block, lds, h->stream); break;
         }
     };
     if (traj) {  // rows to write: the store stream is rate-limited here too (gu_rollout.hpp: GuPacer)
@@ -785,5 +798,6 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         if (*rc != GU_OK) return true;
     }
     launch(a);
+    if (!launched) *rc = gu_fail(GU_ERR_HIP, "gu_rollout_rows_kernel reports static LDS: its table must start at LDS address 0");
     return true;
 }

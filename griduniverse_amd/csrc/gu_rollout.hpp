@@ -307,6 +307,11 @@ struct GuPacer {
         }
         report_at = 0;
     }
+    // a launch that keeps no schedule and reports nothing: after() does nothing for it.  (The transition-row kernel runs such a launch
+    // on a copy of its loops WITHOUT the call: config 2 and the packed rows at one wave per SIMD are bound by the issue of their own
+    // instructions, one per four clocks, and the test alone -- a taken branch around the schedule's code -- cost them ~60 clocks per
+    // group of sixteen steps.)
+    __device__ __forceinline__ bool idle() const { return ticks == 0u && slot == nullptr; }
     // `steps` steps have just been done (rows stored): wait until their time is up
     __device__ __forceinline__ void after(uint32_t steps)
     {

@@ -435,6 +435,7 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
     // the first step on the table (a.entry_table): like any other, but the record it starts from is nobody's row
     if (entry_table) step_e(POLICY == GU_POLICY_SAMPLE ? first_word : first_x, 0, nothing, std::false_type{});
     pacer.start(a.pace, TRAJ != 0);
+    const int32_t T32 = (int32_t)a.T;
     auto step1 = [&](uint32_t x) {
         step(x, 0, nothing);
         if (TRAJ) rebase(1);
@@ -475,28 +476,32 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
         uint32_t t = t_lane;
         uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);  // (the first step is taken: first_a / first_b)
         ++t;
-        int64_t i = 1;
+        int32_t i = 1;  // (32-bit counters: gu_rollout caps T at 1e8; the 64-bit ones cost the loop three scalar instructions per group)
         const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);
         if (__all(t == t_first)) {  // every lane at the same step count: the 16-actions-per-word schedule is wave-uniform
             t = t_first;
             if (t & 15u) {  // head: finish the current word
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
-                for (; i < a.T && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
+                for (; i < T32 && (t & 15u); ++i, ++t) step1((word >> (2u * (t & 15u))) & 3u);
                 pacer.after((uint32_t)i);
             }
-            for (; i + 16 <= a.T; i += 16, t += 16) {
+            auto groups = [&](auto paced) {  // (two copies: GuPacer::idle)
+                for (; i + 16 <= T32; i += 16, t += 16) {
+                    word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+                    word16(word);
+                    if (TRAJ) rebase(16);
+                    if (decltype(paced)::value && i + 16 < T32) pacer.after(16);  // (gu_rollout.hpp: GuPacer)
+                }
+            };
+            if (TRAJ == 0 || pacer.idle()) groups(std::false_type{});
+            else groups(std::true_type{});
+            if (i < T32) {
                 word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
-                word16(word);
-                if (TRAJ) rebase(16);
-                if (i + 16 < a.T) pacer.after(16);  // (gu_rollout.hpp: GuPacer)
-            }
-            if (i < a.T) {
-                word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
-                for (uint32_t j = 0; i < a.T; ++i, ++j) step1((word >> (2u * j)) & 3u);
+                for (uint32_t j = 0; i < T32; ++i, ++j) step1((word >> (2u * j)) & 3u);
             }
         } else {
             if ((t & 15u) == 0u) word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
-            for (; i < a.T; ++i) {
+            for (; i < T32; ++i) {
                 step1((word >> (2u * (t & 15u))) & 3u);
                 ++t;
                 if ((t & 15u) == 0u) word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
@@ -508,7 +513,7 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
         uint32_t word = first_word;  // (the first step is taken: first_a / first_b)
         if (POLICY == GU_POLICY_SAMPLE) word = gu_rng_sample_advance(prefix, t, word);
         ++t;
-        int64_t i = 1;
+        int32_t i = 1;  // (32-bit counters: gu_rollout caps T at 1e8; the 64-bit ones cost the loop three scalar instructions per group)
         auto pstep = [&](uint32_t soff) {  // the word of the NEXT step is hashed while this step's reads are in flight
             uint32_t next_word = 0u;
             step(word, soff, [&] {
@@ -522,34 +527,42 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
         const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);
         if (POLICY == GU_POLICY_SAMPLE && __all(t == t_first)) {
             t = t_first;
-            for (; i < a.T && (t & GU_RNG_SAMPLE_MASK); ++i) {
+            for (; i < T32 && (t & GU_RNG_SAMPLE_MASK); ++i) {
                 pstep(0);
                 if (TRAJ) rebase(1);
             }
             if (i > 1) pacer.after((uint32_t)i);
             constexpr uint32_t G = GU_RNG_SAMPLE_MASK + 1u < 8u ? 8u : GU_RNG_SAMPLE_MASK + 1u;  // steps per unrolled group
-            for (; i + G <= a.T; i += G) {
+            auto groups = [&](auto paced) {  // (two copies: GuPacer::idle)
+                for (; i + G <= T32; i += G) {
 #pragma unroll
-                for (uint32_t j = 0; j < G; ++j) {
-                    uint32_t next_word = 0u;
-                    step(word, j * trow32, [&] {
-                        next_word = (j & GU_RNG_SAMPLE_MASK) == GU_RNG_SAMPLE_MASK ? gu_rng_sample_advance_at<true>(prefix, t, word) : gu_rng_sample_advance_at<false>(prefix, t, word);
-                    });
-                    word = next_word;
-                    ++t;
+                    for (uint32_t j = 0; j < G; ++j) {
+                        uint32_t next_word = 0u;
+                        step(word, j * trow32, [&] {
+                            next_word = (j & GU_RNG_SAMPLE_MASK) == GU_RNG_SAMPLE_MASK ? gu_rng_sample_advance_at<true>(prefix, t, word) : gu_rng_sample_advance_at<false>(prefix, t, word);
+                        });
+                        word = next_word;
+                        ++t;
+                    }
+                    if (TRAJ) rebase(G);
+                    if (decltype(paced)::value && i + G < T32) pacer.after(G);
                 }
-                if (TRAJ) rebase(G);
-                if (i + G < a.T) pacer.after(G);
-            }
+            };
+            if (TRAJ == 0 || pacer.idle()) groups(std::false_type{});
+            else groups(std::true_type{});
         } else {
-            for (; i + 8 <= a.T; i += 8) {
+            auto groups = [&](auto paced) {  // (two copies: GuPacer::idle)
+                for (; i + 8 <= T32; i += 8) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) pstep(j * trow32);
-                if (TRAJ) rebase(8);
-                if (i + 8 < a.T) pacer.after(8);
-            }
+                    for (uint32_t j = 0; j < 8; ++j) pstep(j * trow32);
+                    if (TRAJ) rebase(8);
+                    if (decltype(paced)::value && i + 8 < T32) pacer.after(8);
+                }
+            };
+            if (TRAJ == 0 || pacer.idle()) groups(std::false_type{});
+            else groups(std::true_type{});
         }
-        for (; i < a.T; ++i) {
+        for (; i < T32; ++i) {
             pstep(0);
             if (TRAJ) rebase(1);
         }

@@ -177,7 +177,7 @@ struct GuPacer {
             next->period_q = p_q, next->seq = pa.seq + 1u, next->t_start = 0, next->unpaced = 1u;
             next->phase = GU_PACE_OFF, next->left = left, next->ema_paced = c_ema_p, next->ema_unpaced = ema_u;
             next->verdict = 0, next->waves = 0, next->elapsed = 0, next->ended_late = 0, next->max_behind = 0, next->report_steps = 0, next->groups = 0;
-            next->dec_q = pa.dec_q, next->block_left = GU_PACE_BLOCK, next->block_sum = 0, next->block_n = 0, next->last_mean = 0, next->up = 1;
+            next->dec_q = pa.dec_q, next->block_left = GU_PACE_BLOCK, next->block_sum = 0, next->block_n = 0, next->last_mean = 0, next->up = 0;
             next->quiet = left > 1u ? 1u : 0u;  // (the launch that ends the phase is a full one: it sets the probe up)
         }
     }
@@ -223,7 +223,7 @@ struct GuPacer {
             const uint32_t waves = counts >> 16, far = counts & 0xFFFFu;
             GuPaceEntry *next = pa.ring + ((pa.seq + 1u) & (GU_PACE_RING - 1u));
             uint32_t n_q = p_q, phase = GU_PACE_NORMAL, left = pa.probe_every ? (pa.probe_every < 128u ? pa.probe_every : 128u) : 0u, ema_p = 0, ema_u = 0;
-            uint32_t dec_q = pa.dec_q, block_left = GU_PACE_BLOCK, block_sum = 0, block_n = 0, last_mean = 0, up = 1;
+            uint32_t dec_q = pa.dec_q, block_left = GU_PACE_BLOCK, block_sum = 0, block_n = 0, last_mean = 0, up = 0;
             if (!fresh) {
                 phase = c_phase, left = c_left, ema_p = c_ema_p, ema_u = c_ema_u;
                 dec_q = c_dec_q, block_left = c_block_left, block_sum = c_block_sum, block_n = c_block_n, last_mean = c_last_mean, up = c_up;
@@ -256,8 +256,11 @@ struct GuPacer {
                     // (how often a launch falls behind at a given distance from the cliff, and what that costs: on one allocation
                     // the rule's 6 % held the period 8 ticks = 3 % above the best one, profiles/r05f_pytest_slow_buffer.txt).  What
                     // counts is the time from one launch's start to the next one's, and the first wave sees it: blocks of 192
-                    // launches (the last 128 counted), each with its own aim -- dec_q moves by a factor of 3/2 per block, in the
+                    // launches (the last 128 counted), each with its own aim -- dec_q moves by a factor of 4/3 per block, in the
                     // direction of the last move while the block's mean interval got shorter, the other way when it got longer.
+                    // The first move is DOWN, towards the longer period: the launch time rises by 0.6 us per two ticks above the best
+                    // period and by 2 .. 7 us per two ticks below it (profiles/r05y_pace_aim.txt; until late in round 5 the first move
+                    // was up, by 3/2, and the launches 192 .. 384 of a kind -- a benchmark's -- ran with 10 % of their waves behind).
                     if (phase == GU_PACE_NORMAL && !pa.fixed && pa.adapt) {
                         if (block_left <= GU_PACE_BLOCK - GU_PACE_BLOCK_SKIP && plausible) block_sum += took, ++block_n;
                         if (block_left) --block_left;
@@ -265,9 +268,9 @@ struct GuPacer {
                             const uint32_t mean = block_n ? block_sum / block_n : 0u;
                             if (mean && last_mean && mean > last_mean) up ^= 1u;
                             if (mean) last_mean = mean;
-                            dec_q = up ? (dec_q * 3u + 1u) / 2u : (dec_q * 2u) / 3u;
+                            dec_q = up ? (dec_q * 4u + 2u) / 3u : (dec_q * 3u) / 4u;
                             dec_q = dec_q < 4u ? 4u : dec_q;
-                            dec_q = dec_q > pa.gain_q / 4u ? pa.gain_q / 4u : dec_q;  // (aims of 4 / gain .. 25 %)
+                            dec_q = dec_q > pa.gain_q / 8u ? pa.gain_q / 8u : dec_q;  // (aims of 4 / gain .. 12.5 %)
                             block_left = GU_PACE_BLOCK, block_sum = 0, block_n = 0;
                         }
                     }

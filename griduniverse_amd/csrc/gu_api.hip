@@ -173,6 +173,7 @@ int gu_destroy(gu_handle h)
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_seq) (void)hipHostFree(h->h_seq);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+    if (h->h_tables) (void)hipHostFree(h->h_tables);
     if (h->h_up) (void)hipHostFree(h->h_up);
     if (h->d_blocks_done) (void)hipFree(h->d_blocks_done);
     for (hipEvent_t ev : h->ev_marks) (void)hipEventDestroy(ev);

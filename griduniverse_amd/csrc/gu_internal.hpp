@@ -211,6 +211,9 @@ struct gu_engine {
 
     // pinned host staging (4*N int32)
     int32_t *h_pin = nullptr;
+    double *h_tables = nullptr;     // page-locked copy of the DP tables [S] + [S][4]: the per-XCD launches of the tables alone write their results here too
+    size_t h_tables_bytes = 0;      //   (gu_vi_xcd.hip), and a gu_vi_get behind such a call is two memcpys -- no launch, no wait
+    bool h_tables_valid = false;    //   ... while nothing else has touched the tables since (every gu_vi_* call that may write them withdraws it)
     unsigned long long *h_ctl = nullptr;  // page-locked landing area of small results (gu_read_back): GU_CTL_WORDS 64-bit words
     char *h_up = nullptr;                 // page-locked staging of small uploads (GU_UP_BYTES): a copy from it is one DMA the stream orders,
                                           // a copy from the caller's pageable array is staged and waited for by the runtime

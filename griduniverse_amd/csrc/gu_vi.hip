@@ -814,6 +814,7 @@ int gu_vi_set(gu_handle h, const double *v, const double *pi)
 {
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
+    h->h_tables_valid = false;  // (the call may write the tables: the host's copy of them, gu_vi_xcd.hip, is withdrawn; the per-XCD launch of the tables alone renews it)
     GU_REQUIRE(h->has_grid, GU_ERR_STATE, "no grid set: call gu_set_grid first");
     GU_REQUIRE(h->n_grids == 1, GU_ERR_UNSUPPORTED, "value / policy tables need a single-grid engine");
     GU_REQUIRE(v && pi, GU_ERR_INVALID, "v or pi is NULL");
@@ -847,6 +848,11 @@ int gu_vi_get(gu_handle h, double *v, double *pi)
     if (rc != GU_OK) return rc;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     const size_t vb = (size_t)h->S * sizeof(double);
+    if (h->h_tables_valid && h->h_tables) {  // the launch that wrote the tables last left a copy on the host (and has been waited for)
+        if (v) memcpy(v, h->h_tables, vb);
+        if (pi) memcpy(pi, h->h_tables + h->S, 4 * vb);
+        return GU_OK;
+    }
     if (v && pi && h->h_ctl && 5 * vb <= GU_CTL_WORDS * sizeof(unsigned long long)) {  // both tables: two DMAs into the landing area, ONE wait
         char *land = (char *)h->h_ctl;
         GuSegments down;  // ONE launch writes both tables into the page-locked landing area, one wait
@@ -868,6 +874,7 @@ int gu_vi_sweep(gu_handle h, double gamma, int32_t iters, int32_t greedy_update,
 {
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
+    h->h_tables_valid = false;  // (the call may write the tables: the host's copy of them, gu_vi_xcd.hip, is withdrawn; the per-XCD launch of the tables alone renews it)
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(iters > 0 && iters <= 4096, GU_ERR_INVALID, "iters must be in 1..4096 per call");
     if (vi_xcd_preferred(h, iters)) {  // one launch of one XCD's workgroups, nothing leaves that XCD's L2 (gu_vi_xcd.hip)
@@ -924,6 +931,7 @@ int gu_vi_run(gu_handle h, double gamma, double threshold, int32_t max_steps, in
 {
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
+    h->h_tables_valid = false;  // (the call may write the tables: the host's copy of them, gu_vi_xcd.hip, is withdrawn; the per-XCD launch of the tables alone renews it)
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
     if (vi_xcd_preferred(h, max_steps)) {
@@ -998,6 +1006,7 @@ int gu_vi_eval_run(gu_handle h, double gamma, double threshold, int32_t max_step
 {
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
+    h->h_tables_valid = false;  // (the call may write the tables: the host's copy of them, gu_vi_xcd.hip, is withdrawn; the per-XCD launch of the tables alone renews it)
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE(max_steps >= 0 && steps_done, GU_ERR_INVALID, "max_steps < 0 or steps_done is NULL");
     if (vi_xcd_preferred(h, max_steps)) {
@@ -1074,6 +1083,7 @@ int gu_vi_greedy(gu_handle h, double gamma)
 {
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
+    h->h_tables_valid = false;  // (the call may write the tables: the host's copy of them, gu_vi_xcd.hip, is withdrawn; the per-XCD launch of the tables alone renews it)
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     ViArgs a = vi_args(h, gamma, nullptr);
     a.v_new = h->d_v[h->vi_cur];  // V2 reads the CURRENT value table ...
@@ -1094,6 +1104,7 @@ int gu_vi_sweep_step(gu_handle h, double gamma, uint32_t flags, double *delta)
 {
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
+    h->h_tables_valid = false;  // (the call may write the tables: the host's copy of them, gu_vi_xcd.hip, is withdrawn; the per-XCD launch of the tables alone renews it)
     h->entry_table_ok = false;  // (the fused launches step the envs: their state is consistent too, but only rollouts vouch for it)
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_vi_sweep_step accepts only GU_F_AUTO_RESET");
@@ -1134,6 +1145,7 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
 {
     int rc = gu_use_device(h);
     if (rc != GU_OK) return rc;
+    h->h_tables_valid = false;  // (the call may write the tables: the host's copy of them, gu_vi_xcd.hip, is withdrawn; the per-XCD launch of the tables alone renews it)
     h->entry_table_ok = false;
     GU_REQUIRE(h->has_vi, GU_ERR_STATE, "no value/policy tables: call gu_vi_set first");
     GU_REQUIRE((flags & ~GU_F_AUTO_RESET) == 0, GU_ERR_INVALID, "gu_vi_sweep_step_run accepts only GU_F_AUTO_RESET");

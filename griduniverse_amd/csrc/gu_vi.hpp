@@ -185,6 +185,8 @@ struct ViStepXcdArgs : ViStepClusterArgs {
     // the other halves of the engine's double buffers --, which the host makes current only when the launch did not give up; no
     // snapshot, no restore.  nullptr: in place, as before (config 5: the envs' state is not double-buffered, its launch keeps a snapshot)
     double *v_out, *pi_out;
+    // ... and, the tables alone, to a page-locked copy on the host as well (nullptr: no copy): gu_vi_get behind the call needs no launch
+    double *v_host, *pi_host;
     // ... and so does config 5's fused launch since the engine keeps a second set of env-state arrays for it: the envs' final
     // positions, rewards, done flags, episode counters and done ballots go to these (nullptr: in place)
     int32_t *pos_out, *reward_out, *done_out;

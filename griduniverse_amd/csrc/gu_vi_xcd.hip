@@ -701,6 +701,10 @@ __global__ void __launch_bounds__(1024) gu_vi_xcd_kernel(const ViStepXcdArgs a)
             if (s >= 0) {
                 vf[s] = v_new[j];
                 if (GREEDY) *reinterpret_cast<double4 *>(pf + 4 * (int64_t)s) = make_double4(p[j][0], p[j][1], p[j][2], p[j][3]);
+                if (!AGENTS && a.v_host) {  // (the policy rows too when they did not change: the copy is of BOTH tables)
+                    a.v_host[s] = v_new[j];
+                    *reinterpret_cast<double4 *>(a.pi_host + 4 * (int64_t)s) = make_double4(p[j][0], p[j][1], p[j][2], p[j][3]);
+                }
             }
         }
     }
@@ -890,6 +894,22 @@ static int vi_xcd_dp_launch(gu_engine *h, double gamma, double threshold, bool u
     a.hdr_next = (uint32_t *)(ctl + 64 * (size_t)((slot_i + 1u) & 15u));
     a.v_out = h->d_v[h->vi_cur ^ 1];
     a.pi_out = greedy ? h->d_pi[h->vi_cur ^ 1] : nullptr;
+    // the final tables also land in a page-locked copy on the host (40 KB at 32 x 32: a few us of stores at the end of the launch),
+    // so that the gu_vi_get that follows a gu_vi_run / gu_vi_sweep / gu_vi_eval_run is two memcpys instead of a launch and a wait
+    const size_t tables_bytes = 5 * (size_t)h->S * sizeof(double);
+    if (!h->h_tables || h->h_tables_bytes < tables_bytes) {
+        if (h->h_tables) (void)hipHostFree(h->h_tables);
+        h->h_tables = nullptr;
+        if (hipHostMalloc((void **)&h->h_tables, tables_bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h->h_tables = nullptr;
+        }
+        h->h_tables_bytes = h->h_tables ? tables_bytes : 0;
+    }
+    const bool copy_was_valid = h->h_tables_valid;
+    h->h_tables_valid = false;
+    a.v_host = h->h_tables;
+    a.pi_host = h->h_tables ? h->h_tables + h->S : nullptr;
     if ((rc = gu_vi_xcd_launch(h, xp, a, false, greedy)) != GU_OK) return rc;
     ++h->vi_xcd_epoch;
     // (the sixteen headers and the first delta keys lie side by side: ONE copy back and one wait)
@@ -921,6 +941,7 @@ static int vi_xcd_dp_launch(gu_engine *h, double gamma, double threshold, bool u
         std::swap(h->d_v[0], h->d_v[1]);
         if (greedy) std::swap(h->d_pi[0], h->d_pi[1]);
     }
+    h->h_tables_valid = h->h_tables != nullptr && (done > 0 || copy_was_valid);  // (no round: nothing was written, anywhere)
     *rounds_done = done;
     h->greedy_valid = false;
     return GU_OK;

@@ -437,6 +437,47 @@ def test_the_tables_alone_take_the_per_xcd_launch_wherever_it_fits(W, H, vi_path
         assert eng.vi_last_dp_form() == 1
 
 
+@pytest.mark.parametrize('W,H', [(32, 32), (64, 64), (100, 40), (7, 3)])
+def test_the_tables_a_dp_call_leaves_on_the_host_are_the_tables_on_the_device(W, H):
+    """The per-XCD launch of gu_vi_run / gu_vi_sweep / gu_vi_eval_run writes its final tables to a page-locked copy on the host as well,
+    and the gu_vi_get behind it is two memcpys (no launch, no wait).  That copy must BE the device's tables -- read here through a
+    call that withdraws the copy without changing a table (gu_vi_run with max_steps = 0) -- after every kind of DP call, and it must be
+    withdrawn by everything that writes a table: gu_vi_set, gu_vi_greedy, the fused sweep + step launches."""
+    S = W * H
+    spec = GridSpec(W, H, [0], [S - 1], [S // 2], [])
+    rs = np.random.RandomState(W)
+    with Engine(64, spec) as eng:
+        eng.reset()
+
+        def device_tables():
+            eng.vi_run(0.9, 1e-3, 0)  # (no round: nothing changes, but the call withdraws the host's copy)
+            return eng.vi_get()
+
+        def same(a, b):
+            return a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+
+        eng.vi_set(rs.rand(S), rs.dirichlet(np.ones(4), S))
+        for call in (lambda: eng.vi_run(0.9, 1e-3, 25), lambda: eng.vi_sweep(0.9, 3, greedy_update=True), lambda: eng.vi_sweep(0.9, 2, greedy_update=False),
+                     lambda: eng.vi_eval_run(0.9, 1e-2, 7), lambda: eng.vi_run(0.9, 1e-9, 1)):
+            call()
+            from_copy = eng.vi_get()
+            assert same(from_copy, eng.vi_get())       # (twice from the copy)
+            assert same(from_copy, device_tables()), (W, H)
+        # ... and what writes a table behind such a call is seen by the next gu_vi_get
+        eng.vi_run(0.9, 1e-3, 5)
+        v2, pi2 = rs.rand(S), rs.dirichlet(np.ones(4), S)
+        eng.vi_set(v2, pi2)
+        assert same(eng.vi_get(), (v2, pi2))
+        eng.vi_run(0.9, 1e-3, 5)
+        before = eng.vi_get()
+        eng.vi_greedy(0.9)
+        after = eng.vi_get()
+        assert after[0].tobytes() == before[0].tobytes() and same(after, device_tables())
+        eng.vi_run(0.9, 1e-3, 5)
+        eng.vi_sweep_step_run(0.9, 3, True)
+        assert same(eng.vi_get(), device_tables())
+
+
 @pytest.mark.parametrize('name,N,auto', [('maze64_s5', 65536, True), ('maze64_s5_g097', 4096, False), ('rect6x5_g1', 100, True),
                                          ('lava4x4_g095', 3, True), ('maze32_s1', 20000, True), ('maze64_s5', 262144, True)])
 def test_sweep_step_run_is_iters_fused_launches_in_one(name, N, auto, vi_path, gu_option):

@@ -409,6 +409,8 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
             // states behind it -- twelve issue slots on the step's dependent chain instead of six.
             const bool c0 = x >= q.x, c1 = x >= q.y, c2 = x >= q.z;
             __builtin_amdgcn_sched_barrier(0);  // (statistics only 68.2 -> 65.0 us, packed rows 76.0 -> 73.7 at config 3; int32 rows, bound by their stores: 114 either way)
+            // (A tree two selects deep -- lo = c0 ? y : x, hi = c2 ? w : z, rec = c1 ? hi : lo, which the sorted thresholds allow -- was
+            // measured SLOWER than the chain of three: 55.4 against 54.7 us statistics only, 114 .. 115.5 against 113 with rows, round 5.)
             uint32_t sel = c0 ? nx.y : nx.x;
             sel = c1 ? nx.z : sel;
             rec = c2 ? nx.w : sel;

@@ -14,7 +14,8 @@
 // `rec` beside the chain.  The 16-byte rows are replicated `copies` (<= 8) times so that the lanes of a half-wave spread
 // over the LDS banks (bank = copy * 4 + action).  The invariant the table relies on -- "the env is done exactly when its
 // cell is terminal" -- holds after any step but not for an arbitrary stored state (gu_set_state, a reset onto a terminal
-// start), so every lane takes its FIRST step of a launch on the per-cell planes, like the general kernel.
+// start), so a launch takes its FIRST step on the per-cell planes, like the general kernel -- unless it follows a rollout of
+// the same engine (RolloutArgs::entry_table, round 5: the state a rollout leaves behind always agrees with its cell).
 //
 // Table policies use the same idea with policy-dependent rows, rebuilt by every launch (the policy table may have changed):
 //   GU_POLICY_GREEDY  row[s]    = the one record reached by the greedy action of the (post-reset) cell: 4 bytes, up to 32
@@ -172,19 +173,18 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
     pacer.fetch(a.pace, TRAJ != 0);  // (asked for ahead of the staging: gu_rollout.hpp)
     const int32_t shift = PAIR ? GU_PAIR_SHIFT : a.row_shift;  // log2(row bytes * copies)
     const int32_t copies_log2 = shift - RowBytes<POLICY>::log2;
-    // LDS address of the staged table: folded into every record (0 in practice: this kernel has no static LDS), so that a
-    // record's address bits are the raw ds_read address and no base is added on the dependent chain
-    // (This kernel has no static LDS: its dynamic block starts at LDS address 0 and a record's address bits ARE the ds_read address.
-    // The compiler does not know that -- the block's address is a link-time constant to it -- and spent one vector instruction per
-    // emitted record on `rec - base`, a fifth of config 2's per-step vector work.  The launcher checks it: rows_dispatch refuses an
-    // instantiation that reports static LDS.)
+    // LDS address of the staged table.  This kernel has no static LDS: its dynamic block starts at LDS address 0 and a record's
+    // address bits ARE the ds_read address -- no base is added on the dependent chain.  (Until late in round 5 the block's address
+    // was folded into every record; the compiler cannot know that it is 0 -- a link-time constant to it -- and spent one vector
+    // instruction per emitted record on `rec - base`, a seventh of config 2's per-step vector work.  The launcher checks it:
+    // rows_dispatch refuses an instantiation that reports static LDS.)
     constexpr uint32_t lds_base = 0u;
     // ---- The launch's fixed cost (round 5: 8.6 us of a 60 us config-4 shard, profiles/r05r_rows_intercept.txt) is LATENCY: the table
     // came in through four dependent rounds of global loads (every copy of a row fetched separately, eight loads in flight), and
     // the first step's three dependent global reads (state -> the cell's flags -> the next cell's flags and reward) started behind
-    // the staging barrier.  Now: the env's state is asked for before anything else; every SOURCE row is loaded once, all of a
-    // thread's loads in flight together, and written to its `copies` places from registers; and the first step's reads are issued
-    // between the stages of that, so that their round trips pass under it.
+    // the staging barrier.  Now: every SOURCE row is loaded once, all of a thread's loads in flight together, and written to its
+    // `copies` places from registers; the env's state is asked for right behind the table's first loads; and the first step's reads
+    // are issued between the stages of that, so that their round trips pass under it.
     const uint32_t half = (uint32_t)a.half_waves;
     const uint32_t slot_in_block = half ? ((threadIdx.x >> 6) << 5) | (threadIdx.x & 31u) : threadIdx.x;
     const int64_t e64 = (int64_t)gu_env_block(a.xcd_remap) * (blockDim.x >> half) + slot_in_block;

@@ -1,4 +1,4 @@
 # scratch session for gpurun (edited per experiment)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python tools/pace_aim.py --loop 3000
+python tools/sample_copies.py

@@ -288,7 +288,9 @@ int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int3
  *               (Grids of up to 4096 states run gu_vi_run / gu_vi_eval_run / gu_vi_sweep as ONE launch of one
  *               workgroup with v in LDS; larger grids take one launch per round.)
  * gu_vi_greedy: V2 alone on the current v (policy improvement without an evaluation sweep)
- * gu_vi_get   : download v / pi (either may be NULL)
+ * gu_vi_get   : download v / pi (either may be NULL).  Behind a gu_vi_run / gu_vi_sweep / gu_vi_eval_run that ran as the one
+ *               launch of one XCD's workgroups this is two memcpys: that launch leaves its final tables in a page-locked copy
+ *               on the host, valid until the next call that may write a table.
  * gu_vi_sweep_step : config 5 -- ONE launch that performs one V1+V2 sweep AND one env
  *               step in which every agent acts greedily on the updated policy.
  * gu_vi_sweep_step_run : `iters` such rounds.  Three forms, fastest first: (1) ONE launch synchronised per XCD -- every XCD

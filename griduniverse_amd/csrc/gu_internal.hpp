@@ -104,7 +104,7 @@ struct gu_engine {
     int64_t opt[GU_OPT_COUNT];       // gu_set_option values of this engine (GU_OPT_UNSET: the process default applies)
     int64_t opt_x[GU_OPT_X_COUNT];   // experiment switches (only a -DGU_EXPERIMENTS build ever sets them)
     hipStream_t stream = nullptr;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_sync = nullptr;  // ev_sync: gu_sync's marker (no timing)
     std::vector<hipEvent_t> ev_marks;  // gu_timer_mark pool (grows on demand, reused)
     size_t n_marks = 0;
 

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_multi_kernel(const Ro
         rec = (((uint32_t)s << 4) + base1) | (dn << GU_MROW_DCOUNT_SHIFT) | (dn << GU_MROW_DONE_BIT) | (r << 24);
         ++t;
     }
-    int64_t rem = a.T - 1;
+    int32_t rem = (int32_t)a.T - 1;  // (32-bit: gu_rollout caps T at 1e8; a 64-bit count costs the loop's scalar unit two instructions per group)
     const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);
     if (POLICY == GU_POLICY_STREAM) {
         // the caller's stream: row i of the stream is step i of the launch, so groups are aligned to the launch, and every

@@ -59,7 +59,7 @@ def main():
     # bench.py's multi-rank flow (blocks, max-over-ranks, gathered-view check, strong-scaling config 4) on the stub engine
     import bench
     args = bench.parse_args(['--gpus', str(world), '--envs', '512', '--T', '40', '--steps', '2', '--warmup', '1',
-                             '--min-seconds', '0.02', '--c4-envs', '2048'])
+                             '--min-seconds', '0.02', '--c4-envs', '2048', '--detail', os.path.join(out_dir, 'bench_detail.json')])
     lines = []
     bench.run(args, engine_cls=OracleEngine, emit=lines.append)
     assert len(lines) == (1 if rank == 0 else 0)

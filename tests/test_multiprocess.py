@@ -48,31 +48,39 @@ def test_two_rank_shards_and_gathered_view_under_torch_distributed_run(tmp_path)
     for r in results:
         assert r['world'] == 2 and r['ok_shard'] and r['ok_view'] and r['ok_max'], r
     # the JSON line of bench.py's N = 2 flow (same script, oracle-backed stub engine, the host channel instead of RCCL)
-    line = json.load(open(os.path.join(str(tmp_path), 'bench_line.json')))
+    text = open(os.path.join(str(tmp_path), 'bench_line.json')).read()
+    assert len(text) < 4096  # the driver parses ONE line and keeps only a few KB of stdout
+    line = json.loads(text)
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['engine'] == 'tests._oracle_engine.OracleEngine'
     assert line['config']['global_envs'] == 1024 and line['steps'] == 2 and line['timing']['blocks'] >= 3
     assert line['timing']['ms_per_step_min'] <= line['ms_per_step'] <= line['timing']['ms_per_step_max']
-    assert abs(line['value'] - 1024 * 40 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-6 * line['value']
+    assert abs(line['value'] - 1024 * 40 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-5 * line['value']
     assert line['rccl']['nranks'] == 2 and line['rccl']['view_equals_shards'] is True and line['rccl']['view_envs'] == 1024
     c4 = line['strong_c4']
     assert c4['scaling'] == 'strong' and c4['total_envs'] == 2048 and c4['envs_per_gpu'] == 1024 and c4['shards_equal_oracle'] is True
     assert len(line['per_rank']['value']) == 2 and line['roofline']['traffic_measured_by_child_runs'] is False
-    assert 'device' in line and 'trajectory_placement' in line['roofline']
+    assert line['roofline']['traffic'] is None  # (the committed PMC profile is of the default launch size only)
     assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
     assert line['bit_exact_vs_reference_digest'] is None  # 512 envs x 40 steps is not the captured run
     other = line['other_modes']['stats_only']
     assert other['returns_vs_oracle'] is True and other['value'] > 0 and 'packed_rows' not in line['other_modes']  # (the stub has no packed rows)
+    # everything that is not on the line: the side file, full precision
+    detail = json.load(open(os.path.join(str(tmp_path), line['detail'])))
+    assert abs(detail['value'] - line['value']) < 1e-5 * line['value'] and detail['metric'] == line['metric']
+    assert 'device' in detail and 'trajectory_placement' in detail['roofline'] and 'topology' in detail
+    assert detail['timing']['launches_per_block'] == 2 and len(detail['per_rank']['ms_per_step']) == 2
 
 
 BENCH_ON_STUB = os.path.join(ROOT, 'tests', '_bench_stub.py')  # bench.main(..., engine_cls=OracleEngine)
 STUB = ['--envs', '512', '--T', '40', '--steps', '2', '--warmup', '1',
-        '--min-seconds', '0.02', '--c4-envs', '2048']
+        '--min-seconds', '0.02', '--c4-envs', '2048', '--detail', '']
 
 
 def _one_json_line(proc):
     assert proc.returncode == 0, proc.stderr.decode()[-3000:]
     lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
+    assert len(lines[0]) < 4096, len(lines[0])
     return json.loads(lines[0])
 
 
@@ -93,7 +101,7 @@ def test_bench_started_plainly_with_gpus_2_spawns_its_ranks_and_prints_one_line(
     assert line['rccl']['nranks'] == 2 and line['rccl']['view_equals_shards'] is True and line['rccl']['view_envs'] == 1024
     assert line['strong_c4']['n_gpus'] == 2 and line['strong_c4']['envs_per_gpu'] == 1024 and line['strong_c4']['shards_equal_oracle'] is True
     assert line['config']['global_envs'] == 1024 and line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
-    assert abs(line['value'] - 1024 * 40 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-6 * line['value']
+    assert abs(line['value'] - 1024 * 40 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-5 * line['value']
 
 
 def test_bench_single_process_form_drives_two_engines_and_prints_one_line():
@@ -107,7 +115,7 @@ def test_bench_single_process_form_drives_two_engines_and_prints_one_line():
     assert line['rccl']['nranks'] == 2 and line['rccl']['view_equals_shards'] is True and line['rccl']['view_envs'] == 1024
     assert line['strong_c4']['n_gpus'] == 2 and line['strong_c4']['total_envs'] == 2048 and line['strong_c4']['shards_equal_oracle'] is True
     assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
-    assert abs(line['value'] - 1024 * 40 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-6 * line['value']
+    assert abs(line['value'] - 1024 * 40 * 2 / (line['ms_per_step'] * 2 / 1e3)) < 1e-5 * line['value']
 
 
 def test_bench_and_the_sharded_product_path_import_no_torch():
@@ -198,17 +206,15 @@ def test_eight_gpu_preflight_on_the_stub_engine(form):
     rendezvous) and with --single-process, config 4 at its full 262 144 envs = 32 768 per rank."""
     extra = ['--single-process'] if form == 'single-process' else []
     proc = subprocess.run([sys.executable, BENCH_ON_STUB, '--gpus', '8'] + extra + ['--envs', '256', '--T', '24', '--steps', '2', '--warmup', '1',
-                                                                                    '--min-seconds', '0.02', '--c4-envs', '262144'],
+                                                                                    '--min-seconds', '0.02', '--c4-envs', '262144', '--detail', ''],
                           env=_scrubbed_env(), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     line = _one_json_line(proc)
-    assert line['n_gpus'] == 8 and len(line['per_rank']['value']) == 8 and len(line['per_rank']['ms_per_step']) == 8
+    assert line['n_gpus'] == 8 and len(line['per_rank']['value']) == 8
     assert line['config']['global_envs'] == 8 * 256 and line['scaling'] == 'weak'
     assert line['strong_c4']['envs_per_gpu'] == 32768 and line['strong_c4']['total_envs'] == 262144 and line['strong_c4']['n_gpus'] == 8
     assert line['strong_c4']['shards_equal_oracle'] is True
     assert line['rccl']['nranks'] == 8 and line['rccl']['view_equals_shards'] is True and line['rccl']['view_envs'] == 8 * 256
     assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
-    if form == 'ranks':
-        assert line['topology']['rccl_library'] is None or line['topology']['rccl_library'].endswith('.so') or '.so.' in line['topology']['rccl_library']
 
 
 def test_a_rank_that_dies_takes_the_launch_down_at_once():

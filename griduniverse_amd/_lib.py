@@ -31,6 +31,7 @@ OPTIONS = {'rollout_block': 1, 'rollout_rows': 2, 'rows_copies': 3, 'rollout_mul
            'mc_global_walk': 11, 'step_sync': 12, 'traj_candidates': 13, 'traj_far_candidates': 14, 'traj_stride_mib': 15,
            'traj_far_mib': 16, 'traj_probe_all': 17, 'rollout_pace': 18, 'vi_xcd_block': 19, 'pace_target': 20, 'pace_bar_num': 21,
            'pace_gain_q': 22, 'pace_dec_q': 23, 'traj_layout': 24, 'pace_record': 25, 'pace_probe_every': 26, 'pace_adapt': 27, 'rollout_half_waves': 28, 'rollout_entry': 29,
+           'sync_spin_us': 30,
            # experiments: refused by libgu.so, accepted by libgu_exp.so only
            'x_traj_uncached': 100, 'x_traj_poison': 101, 'x_mc_poison': 102}
 

@@ -82,6 +82,9 @@ def reference_rng_episodes(policy, env, num_episodes, max_steps_per_episode=1000
     nxt, _, don = env._transition_table(True)
     nxt_l, don_l = nxt.tolist(), don.tolist()
     p = np.asarray(policy, dtype=np.float64)
+    if p.ndim != 2:
+        raise IndexError('policy must be a table of one row of 4 action probabilities per state')
+    wrong_width = p.shape[1] != 4  # np.random.choice(4, p=row): "'a' and 'p' must have same size", at the first draw
     with np.errstate(invalid='ignore', divide='ignore'):
         cdf = p.cumsum(axis=1)
         cdf /= cdf[:, -1:]
@@ -100,6 +103,12 @@ def reference_rng_episodes(policy, env, num_episodes, max_steps_per_episode=1000
         error = None
         done = False
         for t in range(cap):
+            if s >= len(cdf_l):
+                np.random.set_state(before)
+                raise IndexError('index {} is out of bounds for axis 0 with size {}'.format(s, len(cdf_l)))  # policy[obs]
+            if wrong_width:
+                error = "'a' and 'p' must have same size"
+                break
             if bad is not None and bad[s] is not None:
                 error = bad[s]  # (np.random.choice validates p BEFORE it draws)
                 break
@@ -130,8 +139,10 @@ def reference_rng_offsets(policy, env, eng, num_episodes, max_steps_per_episode=
     in bulk; the device walks the episode that would begin at EVERY offset of a block of uniforms (gu_mc_walk_lengths), the host
     follows the chain offset -> offset + length, one table look-up per episode, drawing further blocks while episodes are left; the
     global stream ends exactly where the reference leaves it.  Returns (first_state, offsets, lengths, uniforms, cdf), or None when
-    a policy row is no distribution (np.random.choice raises for it the moment an episode draws from it: the host walk knows how)."""
+    the policy is not an (S, 4) table or a policy row is no distribution (np.random.choice raises for it the moment an episode draws from it: the host walk knows how)."""
     p = np.asarray(policy, dtype=np.float64)
+    if p.shape != (env.world.size, 4):
+        return None  # (the host walk indexes the rows it visits, and raises where the reference's policy[obs] would)
     if not (np.isfinite(p).all() and (p >= 0).all() and (np.abs(p.sum(axis=1) - 1.0) <= 1e-9).all()):
         return None
     cdf = p.cumsum(axis=1)

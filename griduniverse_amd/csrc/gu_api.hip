@@ -1004,8 +1004,7 @@ int gu_rollout_pace_waves(gu_handle h, int32_t policy_kind, uint32_t flags, int3
     const int slot = gu_pace_slot_in_use(h, policy_kind, flags);
     GU_REQUIRE(slot >= 0, GU_ERR_STATE, "this launch kind keeps no schedule on the current trajectory buffer");
     const gu_engine::PaceKind &k = h->pace[slot];
-    const int64_t waves = (h->N + 63) / 64;
-    const int64_t n = std::min<int64_t>(waves, capacity > 0 ? capacity : 0);
+    const int64_t n = std::min<int64_t>(k.n_waves, capacity > 0 ? capacity : 0);  // (half-wave launches: N / 32 of them)
     std::vector<uint64_t> words((size_t)n);
     GU_HIP(hipStreamSynchronize(h->stream));
     // the set the LAST launch of the kind reported into (nobody has summed -- and cleared -- it yet)
@@ -1217,22 +1216,22 @@ int gu_host_free(void *ptr)
 }
 
 // ---------------------------------------------------------------------------------- stream / timing
-// Wait for an event that has been recorded on the engine's stream: polled for up to 5 ms, then the runtime's own (interrupt-driven)
-// wait.  hipEventSynchronize / hipStreamSynchronize hand a wait of more than a few tens of microseconds to an interrupt, and the
-// host then learns of the end 10 .. 20 us late -- 1 % of a 2 ms block of launches between two waits (what `bench.py` times, and what a
-// caller who collects a trajectory per call sees).  A poll sees it within a microsecond; it is bounded so that a long wait does
-// not hold a core.
-static int gu_wait_event(hipEvent_t ev)
+// Wait for an event that has been recorded on the engine's stream: polled for up to GU_OPT_SYNC_SPIN_US (5 ms), then the runtime's
+// own interrupt-driven wait.  hipEventSynchronize learns of the end 10 .. 20 us late (1 % of a 2 ms block of launches); a poll sees it
+// within a microsecond.  Bounded so that a long wait does not hold a core; 0 = no poll (more ranks or engines than host cores).
+static int gu_wait_event(const gu_engine *h, hipEvent_t ev)
 {
+    const int64_t spin_us = gu_opt(h, GU_OPT_SYNC_SPIN_US);
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t turn = 0;; ++turn) {
+    for (uint32_t turn = 0; spin_us > 0; ++turn) {
         const hipError_t q = hipEventQuery(ev);
         if (q == hipSuccess) return GU_OK;
         if (q != hipErrorNotReady) {
             (void)hipGetLastError();
             break;
         }
-        if ((turn & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        __builtin_ia32_pause();
+        if ((turn & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
     }
     GU_HIP(hipEventSynchronize(ev));
     return GU_OK;
@@ -1243,7 +1242,7 @@ int gu_sync(gu_handle h)
     GU_ENTER(h);
     if (h->ev_sync) {
         GU_HIP(hipEventRecord(h->ev_sync, h->stream));
-        return gu_wait_event(h->ev_sync);
+        return gu_wait_event(h, h->ev_sync);
     }
     GU_HIP(hipStreamSynchronize(h->stream));
     return GU_OK;
@@ -1261,7 +1260,7 @@ int gu_timer_end(gu_handle h, float *milliseconds)
     GU_ENTER(h);
     GU_REQUIRE(milliseconds != nullptr, GU_ERR_INVALID, "milliseconds is NULL");
     GU_HIP(hipEventRecord(h->ev_end, h->stream));
-    int rc = gu_wait_event(h->ev_end);
+    int rc = gu_wait_event(h, h->ev_end);
     if (rc != GU_OK) return rc;
     GU_HIP(hipEventElapsedTime(milliseconds, h->ev_begin, h->ev_end));
     return GU_OK;

@@ -173,6 +173,7 @@ struct gu_engine {
         int row_bytes = 0;
         uint32_t seq = 0;              // launches of the kind recorded in the ring so far
         uint32_t model = 0;            // the period its first launch started from
+        uint32_t n_waves = 0;          // waves of the kind's last launch (its reports: one word per wave)
     } pace[36];
     GuPaceEntry *d_pace_ring = nullptr;  // [36][GU_PACE_RING]
     uint64_t *d_pace_slots = nullptr;    // [36][2][pace_slot_stride] the waves' reports (allocated with the ring)

@@ -628,6 +628,7 @@ static int gu_pace_ring_for(gu_engine *h, int slot, int64_t T, unsigned blocks, 
     pace->report_at = (uint32_t)std::min<int64_t>(T > 160 ? T - 96 : std::max<int64_t>(T - 32, 1), 0x7FFFFFFF);
     pace->n_waves = (uint32_t)std::min<int64_t>((int64_t)blocks * (block_size / 64), (int64_t)h->pace_slot_stride);  // the waves of THIS launch
     pace->slot_stride = (uint32_t)h->pace_slot_stride;
+    k.n_waves = pace->n_waves;
     pace->bar_num = (uint16_t)gu_opt(h, GU_OPT_PACE_BAR_NUM);
     pace->gain_q = (uint32_t)gu_opt(h, GU_OPT_PACE_GAIN_Q);
     pace->dec_q = (uint32_t)gu_opt(h, GU_OPT_PACE_DEC_Q);

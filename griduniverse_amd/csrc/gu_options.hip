@@ -49,6 +49,7 @@ const OptSpec g_spec[GU_OPT_COUNT] = {
     {"GU_PACE_ADAPT", 1, 0, 1},
     {"GU_ROLLOUT_HALF_WAVES", -1, -1, 1},
     {"GU_ROLLOUT_ENTRY", 1, 0, 1},
+    {"GU_SYNC_SPIN_US", 5000, 0, 1000000},
 };
 const char *g_spec_x[GU_OPT_X_COUNT] = {"GU_TRAJ_UNCACHED", "GU_TRAJ_POISON", "GU_MC_POISON"};
 
@@ -138,7 +139,7 @@ int gu_set_option(gu_handle h, int32_t option, int64_t value)
     if (h) {
         h->opt[option] = value;
         // a launch-shape option may change which kernel a launch kind runs on: the store pacing of every kind starts over
-        if (option != GU_OPT_ROLLOUT_PACE)
+        if (option != GU_OPT_ROLLOUT_PACE && option != GU_OPT_SYNC_SPIN_US)
             for (gu_engine::PaceKind &k : h->pace) k.active = false;
     } else {
         g_default[option].store(value, std::memory_order_relaxed);

@@ -906,7 +906,6 @@ static int vi_xcd_dp_launch(gu_engine *h, double gamma, double threshold, bool u
         }
         h->h_tables_bytes = h->h_tables ? tables_bytes : 0;
     }
-    const bool copy_was_valid = h->h_tables_valid;
     h->h_tables_valid = false;
     a.v_host = h->h_tables;
     a.pi_host = h->h_tables ? h->h_tables + h->S : nullptr;
@@ -941,7 +940,7 @@ static int vi_xcd_dp_launch(gu_engine *h, double gamma, double threshold, bool u
         std::swap(h->d_v[0], h->d_v[1]);
         if (greedy) std::swap(h->d_pi[0], h->d_pi[1]);
     }
-    h->h_tables_valid = h->h_tables != nullptr && (done > 0 || copy_was_valid);  // (no round: nothing was written, anywhere)
+    h->h_tables_valid = h->h_tables != nullptr && done > 0;  // (no round: nothing was written, anywhere)
     *rounds_done = done;
     h->greedy_valid = false;
     return GU_OK;
@@ -955,10 +954,21 @@ int gu_vi_xcd_fused_run(gu_engine *h, const GuXcdPlan &xp, double gamma, int32_t
 {
     const int64_t path = gu_opt(h, GU_OPT_VI_PATH);
     const size_t n4 = (size_t)h->N * 4, bits_bytes = (((size_t)h->N + 63) / 64) * 8;
-    if (!h->d_out3_alt) {
-        GU_HIP(hipMalloc((void **)&h->d_out3_alt, 3 * n4));
-        GU_HIP(hipMalloc((void **)&h->d_episode_alt, n4));
-        GU_HIP(hipMalloc((void **)&h->d_done_bits_alt, bits_bytes));
+    if (!h->d_out3_alt) {  // all three or none: a half-made set would make the launch write two of them in place
+        int32_t *out3 = nullptr;
+        uint32_t *episode = nullptr;
+        uint64_t *bits = nullptr;
+        if (hipMalloc((void **)&out3, 3 * n4) != hipSuccess || hipMalloc((void **)&episode, n4) != hipSuccess ||
+            hipMalloc((void **)&bits, bits_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (out3) (void)hipFree(out3);
+            if (episode) (void)hipFree(episode);
+            if (bits) (void)hipFree(bits);
+            return gu_fail(GU_ERR_NOMEM, "gu_vi_sweep_step_run: no device memory for the second set of env-state arrays");
+        }
+        h->d_out3_alt = out3;
+        h->d_episode_alt = episode;
+        h->d_done_bits_alt = bits;
     }
     int32_t total = 0;
     while (total < iters) {

@@ -269,7 +269,7 @@ class Engine(object):
     def rollout_pace_waves(self, policy='uniform', auto_reset=True, packed=False):
         """MEASUREMENT AID: what every wave of this kind's last launch reported: int64[waves] ticks (10 ns) from the wave's start to
         its report a few groups before the end of the launch (0 = did not report).  None when the kind keeps no schedule."""
-        cap = (self.N + 63) // 64
+        cap = (self.N + 31) // 32  # (the most a launch can have: the transition-row kernel's half waves)
         buf = np.zeros(cap, dtype=np.uint32)
         n = ctypes.c_int32(0)
         rc = self.lib.gu_rollout_pace_waves(self._h, _POLICIES[policy], (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_PACKED if packed else 0), cap,
@@ -428,7 +428,7 @@ class Engine(object):
         i of `u` in start cell start_states[c] (0xFFFF: the uniforms ran out before it ended)."""
         u = _lib.as_array(u, np.float64, None, 'u')
         starts = _lib.as_array(start_states, np.int32, None, 'start_states')
-        cdf = _lib.as_array(cdf, np.float64, None, 'cdf')
+        cdf = _lib.as_array(cdf, np.float64, (self.spec.S, 4), 'cdf')  # (the library copies S * 32 bytes from it)
         out = np.empty((starts.size, int(n_offsets)), np.uint16)
         check(self.lib.gu_mc_walk_lengths(self._h, u.size, ptr(u), int(n_offsets), starts.size, ptr(starts), int(cap), ptr(cdf), ptr(out)))
         return out
@@ -436,7 +436,7 @@ class Engine(object):
     def mc_walk_episodes(self, u, cdf, offsets, first_state, cap, T):
         """include/gu.h: gu_mc_walk_episodes: episode e from uniform offsets[e] and cell first_state[e] into rows 0 .. T-1 of the trajectory."""
         u = _lib.as_array(u, np.float64, None, 'u')
-        cdf = _lib.as_array(cdf, np.float64, None, 'cdf')
+        cdf = _lib.as_array(cdf, np.float64, (self.spec.S, 4), 'cdf')
         off = _lib.as_array(offsets, np.int64, (self.N,), 'offsets')
         first = _lib.as_array(first_state, np.int32, (self.N,), 'first_state')
         check(self.lib.gu_mc_walk_episodes(self._h, u.size, ptr(u), ptr(cdf), ptr(off), ptr(first), int(cap), int(T)))

@@ -119,7 +119,9 @@ int gu_device_info(int device_id, char *buf, size_t len);
 #define GU_OPT_ROLLOUT_ENTRY 29        /* transition-row kernel: 1 (default) = a launch that follows another rollout of the same engine takes
                                          its FIRST step on the staged table too (the state a rollout leaves behind always agrees with its cell);
                                          0 = always on the per-cell planes, as a launch behind gu_reset / gu_set_state / gu_step must       */
-#define GU_OPT_COUNT 30
+#define GU_OPT_SYNC_SPIN_US 30         /* gu_sync / gu_timer_end poll the event for up to this many microseconds (5000) before the runtime's
+                                         blocking wait; 0 = blocking at once (ranks or engines that outnumber the host cores)             */
+#define GU_OPT_COUNT 31
 int gu_set_option(gu_handle h, int32_t option, int64_t value);
 int gu_get_option(gu_handle h, int32_t option, int64_t *value);   /* the value in force (own, process default or built-in) */
 

@@ -117,7 +117,7 @@ def test_options_have_defaults_ranges_and_process_wide_values(lib):
     for name, builtin in (('rollout_block', 256), ('rollout_rows', -1), ('rollout_multi', -1), ('vi_path', 0), ('mc_scratch_mb', 2048),
                           ('traj_candidates', 4), ('traj_far_candidates', 0), ('rollout_pace', -1), ('traj_stride_mib', 3072), ('traj_far_mib', 49152),
                           ('step_sync', 0), ('rollout_xcd', 0), ('traj_probe_all', 0), ('vi_xcd_block', 0), ('pace_target', 7200), ('pace_bar_num', 20),
-                          ('pace_gain_q', 128), ('pace_dec_q', 8), ('traj_layout', -1), ('pace_record', 1), ('pace_probe_every', 1024), ('pace_adapt', 1), ('rollout_half_waves', -1), ('rollout_entry', 1)):
+                          ('pace_gain_q', 128), ('pace_dec_q', 8), ('traj_layout', -1), ('pace_record', 1), ('pace_probe_every', 1024), ('pace_adapt', 1), ('rollout_half_waves', -1), ('rollout_entry', 1), ('sync_spin_us', 5000)):
         assert _lib.get_default_option(name) == builtin, name
     _lib.set_default_option('rollout_block', 512)
     try:
@@ -128,7 +128,7 @@ def test_options_have_defaults_ranges_and_process_wide_values(lib):
     for name, bad in (('rollout_block', 100), ('rows_copies', 3), ('rollout_multi_k', 3), ('vi_path', 9), ('traj_candidates', 0), ('vi_xcd_block', 128)):
         with pytest.raises(_lib.GuError):
             _lib.set_default_option(name, bad)
-    assert sorted(v for v in _lib.OPTIONS.values() if v < 100) == list(range(1, 30))
+    assert sorted(v for v in _lib.OPTIONS.values() if v < 100) == list(range(1, 31))
 
 
 def test_the_product_library_has_no_code_for_the_unsafe_experiments(lib, monkeypatch):

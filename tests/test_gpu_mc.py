@@ -391,4 +391,18 @@ def test_reference_rng_mode_raises_like_np_random_choice():
         mc.monte_carlo_evaluation(pi, env, num_episodes=20, rng='numpy')
     with pytest.raises(ValueError):
         mc.monte_carlo_evaluation(np.ones((4, 4)) / 4, env, num_episodes=2, rng='mt')
+    # a table with fewer rows than the grid has cells, or rows that are not 4 wide: never handed to the device walk (which copies
+    # S * 32 bytes of it); the host walk raises where the reference's policy[obs] / np.random.choice(4, p=row) would
+    with pytest.raises(IndexError, match='out of bounds'):
+        mc.monte_carlo_evaluation(np.ones((2, 4)) / 4, env, num_episodes=50, rng='numpy')
+    with pytest.raises(ValueError, match='same size'):
+        mc.monte_carlo_evaluation(np.ones((4, 3)) / 3, env, num_episodes=2, rng='numpy')
+    eng = gua.Engine(8, gua.GridSpec.from_env(env))
+    try:
+        with pytest.raises(ValueError, match='cdf must have shape'):
+            eng.mc_walk_lengths(np.zeros(64), 8, [0], 8, np.ones((2, 4)))
+        with pytest.raises(ValueError, match='cdf must have shape'):
+            eng.mc_walk_episodes(np.zeros(64), np.ones((4, 3)), np.zeros(8, np.int64), np.zeros(8, np.int32), 8, 8)
+    finally:
+        eng.close()
     env.close()

@@ -377,6 +377,7 @@ int gu_seed(gu_handle h, uint64_t seed)
     h->seed = seed;
     h->seed_prefix = gu_rng_seed_prefix(seed);
     h->steps_taken = 0;
+    h->off_lo = h->off_hi = 0;
     if (h->graph_exec) {  // captured step launches carry the old seed in their arguments
         (void)hipGraphExecDestroy(h->graph_exec);
         h->graph_exec = nullptr;
@@ -491,6 +492,7 @@ static int gu_require_pinned(const void *p, size_t bytes, const char *what)
 static int gu_step_action_error(gu_engine *h, const int32_t *actions)
 {
     __atomic_store_n(h->h_seq + GU_HOST_ERR_WORD, 0u, __ATOMIC_RELAXED);
+    h->off_lo -= 1;  // (the rejected envs did not step: their offsets to the lock-step counter went down by one)
     for (int64_t i = 0; i < h->N; ++i)
         if ((uint32_t)actions[i] > 3u)
             return gu_fail(GU_ERR_INVALID, "action %d of env %lld outside 0..3 (that env did not step; envs with valid actions did)", actions[i], (long long)i);
@@ -620,7 +622,7 @@ int gu_step_graph(gu_handle h, int64_t t0, int64_t T, uint32_t flags)
             (void)hipGraphExecDestroy(h->graph_exec);
             h->graph_exec = nullptr;
         }
-        const uint32_t saved = h->steps_taken;
+        const uint64_t saved = h->steps_taken;
         hipGraph_t graph = nullptr;
         GU_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         int rc = GU_OK;
@@ -637,7 +639,7 @@ int gu_step_graph(gu_handle h, int64_t t0, int64_t T, uint32_t flags)
         h->graph_flags = flags;
     }
     GU_HIP(hipGraphLaunch(h->graph_exec, h->stream));
-    h->steps_taken += (uint32_t)T;
+    h->steps_taken += (uint64_t)T;
     return GU_OK;
 }
 
@@ -1104,7 +1106,7 @@ int gu_read_stats(gu_handle h, int64_t *reward_sum, int32_t *episodes)
 }
 
 // ---------------------------------------------------------------------------------- state
-int gu_get_state(gu_handle h, int32_t *pos, int32_t *done, uint32_t *episode, uint32_t *tcount)
+int gu_get_state(gu_handle h, int32_t *pos, int32_t *done, uint32_t *episode, uint64_t *tcount)
 {
     GU_ENTER(h);
     const size_t n = (size_t)h->N;
@@ -1113,13 +1115,14 @@ int gu_get_state(gu_handle h, int32_t *pos, int32_t *done, uint32_t *episode, ui
     if (done) GU_HIP(hipMemcpy(done, h->done(), n * 4, hipMemcpyDeviceToHost));
     if (episode) GU_HIP(hipMemcpy(episode, h->d_episode, n * 4, hipMemcpyDeviceToHost));
     if (tcount) {
-        GU_HIP(hipMemcpy(tcount, h->d_tcount, n * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) tcount[i] += h->steps_taken;
+        std::vector<int32_t> off(n);
+        GU_HIP(hipMemcpy(off.data(), h->d_tcount, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) tcount[i] = (uint64_t)((int64_t)h->steps_taken + (int64_t)off[i]);
     }
     return GU_OK;
 }
 
-int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uint32_t *episode, const uint32_t *tcount)
+int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uint32_t *episode, const uint64_t *tcount)
 {
     GU_ENTER(h);
     h->entry_table_ok = false;
@@ -1128,6 +1131,16 @@ int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uin
     if (pos)
         for (size_t i = 0; i < n; ++i)
             GU_REQUIRE(pos[i] >= 0 && pos[i] < h->S, GU_ERR_INVALID, "pos[%zu]=%d outside the grid", i, pos[i]);
+    uint64_t t_min = 0, t_max = 0;
+    if (tcount && n) {
+        t_min = t_max = tcount[0];
+        for (size_t i = 1; i < n; ++i) {
+            t_min = tcount[i] < t_min ? tcount[i] : t_min;
+            t_max = tcount[i] > t_max ? tcount[i] : t_max;
+        }
+        GU_REQUIRE(t_max - t_min < ((uint64_t)1 << 31) && t_max < ((uint64_t)1 << 63), GU_ERR_INVALID,
+                   "tcount: the step counts of one engine must lie within 2^31 of each other (%llu .. %llu)", (unsigned long long)t_min, (unsigned long long)t_max);
+    }
     GU_HIP(hipStreamSynchronize(h->stream));
     if (pos) GU_HIP(hipMemcpy(h->pos(), pos, n * 4, hipMemcpyHostToDevice));
     if (done) {
@@ -1137,10 +1150,17 @@ int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uin
         h->done_bits_valid = false;  // gu_done_indices re-ballots a done[] that came from the host
     }
     if (episode) GU_HIP(hipMemcpy(h->d_episode, episode, n * 4, hipMemcpyHostToDevice));
-    if (tcount) {
-        std::vector<uint32_t> t(tcount, tcount + n);
-        for (auto &x : t) x -= h->steps_taken;  // stored as an offset to the lock-step counter
-        GU_HIP(hipMemcpy(h->d_tcount, t.data(), n * 4, hipMemcpyHostToDevice));
+    if (tcount) {  // the lock-step counter moves to the smallest count; every env keeps its (non-negative) offset to it
+        std::vector<int32_t> off(n);
+        for (size_t i = 0; i < n; ++i) off[i] = (int32_t)(tcount[i] - t_min);
+        GU_HIP(hipMemcpy(h->d_tcount, off.data(), n * 4, hipMemcpyHostToDevice));
+        h->steps_taken = t_min;
+        h->off_lo = 0;
+        h->off_hi = (int64_t)(t_max - t_min);
+        if (h->graph_exec) {  // (captured rollout-free step launches carry no count, but a stale graph is not worth the doubt)
+            (void)hipGraphExecDestroy(h->graph_exec);
+            h->graph_exec = nullptr;
+        }
     }
     return gu_trail_after_set_state(h, pos != nullptr, done != nullptr);
 }

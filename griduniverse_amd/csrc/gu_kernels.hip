@@ -722,9 +722,18 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.episodes_fin = h->d_episodes_fin;
     a.done_bits = h->d_done_bits;
     a.n_starts = (uint32_t)h->n_starts;
-    a.seed_prefix = h->seed_prefix;
     a.env_id0 = (uint32_t)h->env_id0;
-    a.steps_taken = h->steps_taken;
+    a.steps_taken = (uint32_t)h->steps_taken;
+    a.steps_hi = (uint32_t)(h->steps_taken >> 32);
+    a.seed_prefix0 = h->seed_prefix;
+    {   // The epoch (step count >> 32) of RNG streams 0 and 2, csrc/gu_rng.hpp: folded into the seed prefix when every env stays in
+        // ONE epoch for the whole launch (the kernels then count in 32 bits, as ever); else -- once in 2^32 steps -- the launch goes
+        // to the general kernel, which asks per lane and step.  The stream and greedy policies draw nothing from those streams.
+        const int64_t lo = std::max<int64_t>((int64_t)h->steps_taken + h->off_lo, 0), hi = (int64_t)h->steps_taken + h->off_hi + T - 1;
+        const bool draws = policy == GU_POLICY_UNIFORM || policy == GU_POLICY_SAMPLE;
+        a.straddle = draws && (lo >> 32) != (hi >> 32) ? 1 : 0;
+        a.seed_prefix = a.straddle ? h->seed_prefix : gu_rng_seed_prefix_epoch(h->seed_prefix, (uint32_t)(lo >> 32));
+    }
     a.N = h->N;
     a.T = T;
     a.gs = gu_grid_sel(h);
@@ -740,18 +749,18 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)
     if (policy == GU_POLICY_SAMPLE)
         hipLaunchKernelGGL(gu_pi_threshold_kernel, dim3(gu_blocks(h->S, 256)), dim3(256), 0, h->stream, h->d_pi[h->vi_cur], h->S, h->d_pi_thr);
-    if (gu_rollout_multi(h, a, policy, auto_mode, traj, stats)) {
+    if (!a.straddle && gu_rollout_multi(h, a, policy, auto_mode, traj, stats)) {
         GU_HIP(hipGetLastError());
-        h->steps_taken += (uint32_t)T;
+        h->steps_taken += (uint64_t)T;
         h->entry_table_ok = true;
         return gu_trail_after_rollout(h, T, traj, auto_mode != 0);
     }
     {
         int rows_rc = GU_OK;
-        if (gu_rollout_rows(h, a, policy, auto_mode, traj, stats, &rows_rc)) {
+        if (!a.straddle && gu_rollout_rows(h, a, policy, auto_mode, traj, stats, &rows_rc)) {
             if (rows_rc != GU_OK) return rows_rc;
             GU_HIP(hipGetLastError());
-            h->steps_taken += (uint32_t)T;
+            h->steps_taken += (uint64_t)T;
             h->entry_table_ok = true;
             if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
             return gu_trail_after_rollout(h, T, traj, auto_mode != 0);
@@ -772,7 +781,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     }
     if (h->device >= 0 && h->device < 64) g_last_rollout_ms[h->device] = gu_wall_ms();
     GU_HIP(hipGetLastError());
-    h->steps_taken += (uint32_t)T;
+    h->steps_taken += (uint64_t)T;
     h->entry_table_ok = true;
     return gu_trail_after_rollout(h, T, traj, auto_mode != 0);
 }

@@ -3,7 +3,9 @@
 // Specification: oracle/gu_rng.py (MurmurHash3_x86_32 over the four words
 // [seed_lo, seed_hi, global_env_id, (stream << 28) | (counter & 0x0FFFFFFF)], hash seed 0x9747B28C;
 // a counter of 2^28 or more appends a fifth word, counter >> 28, so the streams do not repeat
-// before 2^32 draws).
+// before 2^32 draws).  Streams 0 and 2 are keyed by the env's 64-bit STEP COUNT t: counter = (t >> 4) & 0x0FFFFFFF, and the
+// EPOCH t >> 32, when it is not zero, is hashed as one more word right behind the seed (gu_rng_seed_prefix_epoch; the length
+// word stays 16) -- the launcher folds it into the seed prefix it hands to the kernels, whose loops keep a 32-bit count.
 // The reference has no per-env RNG (core/envs/griduniverse_env.py:64,189 use the
 // process-global stdlib RNG), so this is build-defined and
 // restated on the CPU by the oracle.
@@ -41,6 +43,13 @@ __host__ __device__ __forceinline__ uint32_t gu_rng_seed_prefix(uint64_t seed)
     uint32_t h = 0x9747B28Cu;
     h = gu_mm3_block(h, (uint32_t)seed);
     return gu_mm3_block(h, (uint32_t)(seed >> 32));
+}
+
+// ... and after the epoch (step count >> 32) of streams 0 and 2, where it is not zero (host side, once per launch; per lane and
+// step only in a launch during which some env passes a multiple of 2^32 steps)
+__host__ __device__ __forceinline__ uint32_t gu_rng_seed_prefix_epoch(uint32_t seed_prefix, uint32_t epoch)
+{
+    return epoch ? gu_mm3_block(seed_prefix, epoch) : seed_prefix;
 }
 
 // state after additionally hashing the global env id (once per lane per launch)

@@ -355,7 +355,9 @@ struct RolloutArgs {
     int32_t *tr_obs, *tr_reward, *tr_done;  // [T][N] each
     int32_t *ret, *episodes_fin;
     uint64_t *done_bits;  // [ceil(N/64)] wave ballots of the final done flags (episode-done compaction)
-    uint32_t n_starts, seed_prefix, env_id0, steps_taken;
+    uint32_t n_starts, seed_prefix, env_id0, steps_taken;  // seed_prefix: the epoch of this launch folded in; steps_taken: low word
+    uint32_t seed_prefix0, steps_hi;  // the seed prefix without an epoch (start choices; straddling launches); high word of the lock-step count
+    int32_t straddle;       // some env passes a multiple of 2^32 steps during this launch: the general kernel asks per lane and step
     int64_t N, T;
     GridSel gs;
     const uint32_t *rows;   // transition-row table [S][4] (gu_rollout_rows.hip)
@@ -507,6 +509,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
 
     const uint32_t t_lane = tcount0 + a.steps_taken;
     const uint32_t prefix = gu_rng_prefix(a.seed_prefix, a.env_id0 + e);
+    // start choices (stream 1) are keyed by the episode count alone: no epoch in their prefix
+    const uint32_t prefix0 = AUTO == 2 ? gu_rng_prefix(a.seed_prefix0, a.env_id0 + e) : prefix;
+    // a launch during which an env passes a multiple of 2^32 steps (once in 2^32 steps; the launcher sends it here, whatever its
+    // shape): the words of streams 0 and 2 come from the prefix of the epoch of THEIR step, asked per lane and step
+    const uint32_t epoch0 = (uint32_t)((uint64_t)((int64_t)(((uint64_t)a.steps_hi << 32) | a.steps_taken) + (int64_t)(int32_t)tcount0) >> 32);
+    auto prefix_at = [&](uint32_t t) {  // (t: the low word of the step count; a launch is shorter than 2^32 steps)
+        return gu_rng_prefix(gu_rng_seed_prefix_epoch(a.seed_prefix0, epoch0 + (t < t_lane ? 1u : 0u)), a.env_id0 + e);
+    };
     uint32_t flags = m.f[s];
     int32_t ret = 0, fin = 0;
     const int32_t W = a.W;
@@ -561,7 +571,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         } else {
             if (AUTO == 2) {
                 if (d) {
-                    s = lg.starts[gu_rng_start_index(prefix, ep, lg.n_starts)];
+                    s = lg.starts[gu_rng_start_index(prefix0, ep, lg.n_starts)];
                     ++ep;
                     flags = m.f[s];
                 }
@@ -592,7 +602,11 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     };
 
     pacer.start(a.pace, TRAJ == 1 || TRAJ == 3);
-    if (POLICY == GU_POLICY_UNIFORM) {
+    if (POLICY == GU_POLICY_UNIFORM && a.straddle) {
+        uint32_t t = t_lane;
+#pragma nounroll
+        for (int64_t i = 0; i < a.T; ++i, ++t) step1((gu_rng_word(prefix_at(t), GU_RNG_STREAM_ACTION, t >> 4) >> (2u * (t & 15u))) & 3u);
+    } else if (POLICY == GU_POLICY_UNIFORM) {
         // Fast path: every lane of the wave is at the same step count (always true unless
         // gu_set_state installed per-env counters), so the 16-actions-per-word schedule is
         // wave-uniform: constant bit-field offsets, one hash per 16 steps.
@@ -711,7 +725,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                     d = 0;
                 } else if (AUTO == 2) {
                     if (d) {
-                        s = lg.starts[gu_rng_start_index(prefix, ep, lg.n_starts)];
+                        s = lg.starts[gu_rng_start_index(prefix0, ep, lg.n_starts)];
                         ++ep;
                         flags = m.f[s];
                         d = 0;
@@ -736,6 +750,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             const std::integral_constant<int, 1> new_word{};
             const std::integral_constant<int, 2> ask{};
             int64_t i = 0;
+            if (POLICY == GU_POLICY_SAMPLE && a.straddle) {  // (see prefix_at: every step's word from the prefix of its own epoch)
+#pragma nounroll
+                for (; i < a.T; ++i) {
+                    word = gu_rng_sample_word(prefix_at(t), t);
+                    tstep(0, ask);
+                    if (TRAJ) rebase(1);
+                }
+            }
             const uint32_t t_first = __builtin_amdgcn_readfirstlane(t);
             if (POLICY == GU_POLICY_SAMPLE && __all(t == t_first)) {
                 // every lane at the same step count: single steps up to a multiple of four, then groups of eight in which the

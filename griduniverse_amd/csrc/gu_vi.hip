@@ -1245,7 +1245,7 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
                     h->d_v[1] = t;
                 }
                 h->greedy_valid = false;
-                h->steps_taken += (uint32_t)iters;
+                h->steps_taken += (uint64_t)iters;
                 h->vi_run_form = form == 0 ? 1 : 2;
                 return GU_OK;
             }

@@ -1045,7 +1045,7 @@ int gu_vi_xcd_fused_run(gu_engine *h, const GuXcdPlan &xp, double gamma, int32_t
             h->graph_exec = nullptr;
         }
         h->greedy_valid = false;
-        h->steps_taken += (uint32_t)n;
+        h->steps_taken += (uint64_t)n;
         total += n;
     }
     return GU_OK;

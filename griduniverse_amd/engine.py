@@ -324,7 +324,7 @@ class Engine(object):
     # ------------------------------------------------------------------ state
     def get_state(self):
         pos, don = np.empty(self.N, np.int32), np.empty(self.N, np.int32)
-        ep, tc = np.empty(self.N, np.uint32), np.empty(self.N, np.uint32)
+        ep, tc = np.empty(self.N, np.uint32), np.empty(self.N, np.uint64)  # (step counts have 64 bits: include/gu.h, state)
         check(self.lib.gu_get_state(self._h, ptr(pos), ptr(don), ptr(ep), ptr(tc)))
         return dict(pos=pos, done=don, episode=ep, tcount=tc)
 
@@ -332,7 +332,7 @@ class Engine(object):
         pos = None if pos is None else _lib.as_array(pos, np.int32, (self.N,), 'pos')
         done = None if done is None else _lib.as_array(done, np.int32, (self.N,), 'done')
         episode = None if episode is None else _lib.as_array(episode, np.uint32, (self.N,), 'episode')
-        tcount = None if tcount is None else _lib.as_array(tcount, np.uint32, (self.N,), 'tcount')
+        tcount = None if tcount is None else _lib.as_array(tcount, np.uint64, (self.N,), 'tcount')
         check(self.lib.gu_set_state(self._h, ptr(pos), ptr(done), ptr(episode), ptr(tcount)))
 
     def done_indices(self):

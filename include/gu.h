@@ -261,9 +261,11 @@ int gu_read_trajectory_packed(gu_handle h, int64_t t0, int64_t T, uint32_t *pack
 int gu_read_stats(gu_handle h, int64_t *reward_sum, int32_t *episodes);
 
 /* ---- state (checkpoint / parity harness) --------------------------------------
- * Any pointer may be NULL.  pos/done int32[N], episode/tcount uint32[N]. */
-int gu_get_state(gu_handle h, int32_t *pos, int32_t *done, uint32_t *episode, uint32_t *tcount);
-int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uint32_t *episode, const uint32_t *tcount);
+ * Any pointer may be NULL.  pos/done int32[N], episode uint32[N], tcount uint64[N]: the steps every env has taken since gu_seed
+ * (64 bits: at 4e7 steps per second and env a 32-bit count would wrap, and the action stream repeat, after 97 s; the step counts
+ * of one engine must lie within 2^31 of each other -- envs step in lock step, apart only by gu_set_state and rejected actions). */
+int gu_get_state(gu_handle h, int32_t *pos, int32_t *done, uint32_t *episode, uint64_t *tcount);
+int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uint32_t *episode, const uint64_t *tcount);
 
 /* Ascending indices of envs whose done flag is set.  Every kernel that writes done[] (step, rollout, reset,
  * sweep-step) also writes its waves' 64-bit ballot of the new flags -- 8 KB at 65 536 envs -- so this call is ONE

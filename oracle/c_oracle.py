@@ -35,9 +35,9 @@ def lib():
         _lib.gu_oracle_rng_word.restype = ctypes.c_uint32
         _lib.gu_oracle_rng_word.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
         _lib.gu_oracle_rng_sample_word.restype = ctypes.c_uint32
-        _lib.gu_oracle_rng_sample_word.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
+        _lib.gu_oracle_rng_sample_word.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
         _lib.gu_oracle_rng_action.restype = ctypes.c_int32
-        _lib.gu_oracle_rng_action.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
+        _lib.gu_oracle_rng_action.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
         _lib.gu_oracle_rng_start.restype = ctypes.c_int32
         _lib.gu_oracle_rng_start.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int32]
         _lib.gu_oracle_value_iteration_step.restype = ctypes.c_double
@@ -99,7 +99,7 @@ class State(object):
         self.pos = np.zeros(n, np.int32)
         self.done = np.zeros(n, np.int32)
         self.episode = np.zeros(n, np.uint32)
-        self.tcount = np.zeros(n, np.uint32)
+        self.tcount = np.zeros(n, np.uint64)  # steps since seeding (64 bits: oracle/gu_rng.py, the epoch of streams 0 and 2)
 
 
 def reset(grid, seed, state, mask=None):

@@ -46,11 +46,13 @@ static uint32_t mm3_block(uint32_t h, uint32_t k)
     return h * 5u + 0xE6546B64u;
 }
 
-uint32_t gu_oracle_rng_word(uint64_t seed, uint32_t env, uint32_t stream, uint32_t ctr)
+/* epoch: step count >> 32 of streams 0 and 2 -- hashed right behind the seed when it is not zero; the length word stays 16 */
+static uint32_t rng_word_epoch(uint64_t seed, uint32_t epoch, uint32_t env, uint32_t stream, uint32_t ctr)
 {
     uint32_t h = 0x9747B28Cu;
     h = mm3_block(h, (uint32_t)seed);
     h = mm3_block(h, (uint32_t)(seed >> 32));
+    if (epoch) h = mm3_block(h, epoch);
     h = mm3_block(h, env);
     h = mm3_block(h, ((stream & 0xFu) << 28) | (ctr & 0x0FFFFFFFu));
     if (ctr >> 28) {   /* counters of 2^28 and more: fifth key word, hashed length 20 (oracle/gu_rng.py) */
@@ -63,9 +65,20 @@ uint32_t gu_oracle_rng_word(uint64_t seed, uint32_t env, uint32_t stream, uint32
     return h;
 }
 
-int32_t gu_oracle_rng_action(uint64_t seed, uint32_t env, uint32_t t)
+uint32_t gu_oracle_rng_word(uint64_t seed, uint32_t env, uint32_t stream, uint32_t ctr)
 {
-    return (int32_t)((gu_oracle_rng_word(seed, env, 0, t >> 4) >> (2 * (t & 15))) & 3u);
+    return rng_word_epoch(seed, 0u, env, stream, ctr);
+}
+
+/* the word of stream 0 or 2 that covers step t (a 64-bit step count): counter = bits 4 .. 31 of t, epoch = t >> 32 */
+static uint32_t rng_word_at_step(uint64_t seed, uint32_t env, uint32_t stream, uint64_t t)
+{
+    return rng_word_epoch(seed, (uint32_t)(t >> 32), env, stream, (uint32_t)(t >> 4) & 0x0FFFFFFFu);
+}
+
+int32_t gu_oracle_rng_action(uint64_t seed, uint32_t env, uint64_t t)
+{
+    return (int32_t)((rng_word_at_step(seed, env, 0, t) >> (2 * (t & 15))) & 3u);
 }
 
 int32_t gu_oracle_rng_start(uint64_t seed, uint32_t env, uint32_t episode, int32_t n_starts)
@@ -131,9 +144,9 @@ void gu_oracle_reset(const gu_oracle_grid *g, uint64_t seed, int64_t env_id0, in
 
 /* the word behind the sampled action of step t (oracle/gu_rng.py: sample_word): one hashed word of stream 2 per sixteen steps,
  * the fifteen behind it by xorshift32 + a Weyl increment */
-uint32_t gu_oracle_rng_sample_word(uint64_t seed, uint32_t env, uint32_t t)
+uint32_t gu_oracle_rng_sample_word(uint64_t seed, uint32_t env, uint64_t t)
 {
-    uint32_t w = gu_oracle_rng_word(seed, env, 2, t >> 4);
+    uint32_t w = rng_word_at_step(seed, env, 2, t);
     for (uint32_t i = 0; i < (t & 15u); ++i) {
         w ^= w << 13;
         w ^= w >> 17;
@@ -144,7 +157,7 @@ uint32_t gu_oracle_rng_sample_word(uint64_t seed, uint32_t env, uint32_t t)
 }
 
 /* inverse-CDF sample of pi[s][0..3] on RNG stream 2 (oracle/gu_rng.py: sampled_action) */
-int32_t gu_oracle_rng_sample(uint64_t seed, uint32_t env, uint32_t t, const double *p)
+int32_t gu_oracle_rng_sample(uint64_t seed, uint32_t env, uint64_t t, const double *p)
 {
     double u = (double)gu_oracle_rng_sample_word(seed, env, t) / 4294967296.0;
     volatile double c0 = p[0];
@@ -161,7 +174,7 @@ int32_t gu_oracle_rng_sample(uint64_t seed, uint32_t env, uint32_t t, const doub
  *   ret_out/len... : per-env sum of rewards over the T steps and number of finished episodes, or NULL */
 void gu_oracle_rollout(const gu_oracle_grid *g, uint64_t seed, int64_t env_id0, int64_t n, int64_t T,
                        int32_t auto_reset, const int32_t *actions, const double *pi,
-                       int32_t *pos, int32_t *done, uint32_t *episode, uint32_t *tcount,
+                       int32_t *pos, int32_t *done, uint32_t *episode, uint64_t *tcount,
                        int32_t *obs_out, int32_t *reward_out, int32_t *done_out,
                        int64_t *ret_out, int32_t *episodes_out)
 {

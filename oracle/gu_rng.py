@@ -13,9 +13,15 @@ is sharded, so the build defines one and this file is its specification:
         fifth word, ctr >> 28, is appended (hashed length 20 instead of 16 bytes), so no
         stream repeats before 2**32 draws
 
-    action(seed, env, t)      = (word(seed, env, 0, t >> 4) >> (2 * (t & 15))) & 3
-    start_index(seed, env, e) = (word(seed, env, 1, e) * n_starts) >> 32
-    sample_word(seed, env, t) = next^(t & 15)(word(seed, env, 2, t >> 4)):  ONE hashed word per SIXTEEN steps; the words of
+    Streams 0 and 2 are keyed by the env's STEP COUNT t, a 64-bit number: their counter is bits 4 .. 31 of t
+    ((t >> 4) & 0x0FFFFFFF), and the EPOCH t >> 32, when it is not zero, is hashed as one more word right behind the seed
+    words -- [seed_lo, seed_hi, epoch, env, ...] -- with the length word left at 16 (word_at_step).  Epoch 0 is the plain
+    four-word hash, so every draw of the first 2**32 steps is what it was when the count had 32 bits (and wrapped: at
+    4.4e7 steps per second and env the action stream repeated after 97 s); beyond, no stream repeats before 2**64 steps.
+
+    action(seed, env, t)      = (word_at_step(seed, env, 0, t) >> (2 * (t & 15))) & 3
+    start_index(seed, env, e) = (word(seed, env, 1, e) * n_starts) >> 32          (keyed by the episode count: no epoch)
+    sample_word(seed, env, t) = next^(t & 15)(word_at_step(seed, env, 2, t)):  ONE hashed word per SIXTEEN steps; the words of
                                 the fifteen steps behind it by a multiply-free bijection of 32 bits,
                                 next(x): x ^= x << 13; x ^= x >> 17; x ^= x << 5; x += 0x9E3779B9   (mod 2**32)
                                 (Marsaglia's xorshift32 step followed by a Weyl increment).  Every word is a bijective
@@ -67,13 +73,13 @@ def _fmix(h):
     return h
 
 
-def word(seed, env, stream, ctr):
-    """Scalar 32-bit output for (seed:uint64, env:uint32, stream:0..15, ctr:uint32)."""
+def word(seed, env, stream, ctr, epoch=0):
+    """Scalar 32-bit output for (seed:uint64, env:uint32, stream:0..15, ctr:uint32[, epoch:uint32])."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     ctr = int(ctr) & M32
+    epoch = int(epoch) & M32
     h = H0
-    for k in (seed & M32, seed >> 32, int(env) & M32,
-              ((int(stream) & 0xF) << 28) | (ctr & CTR_MASK)):
+    for k in (seed & M32, seed >> 32) + ((epoch,) if epoch else ()) + (int(env) & M32, ((int(stream) & 0xF) << 28) | (ctr & CTR_MASK)):
         h = _block(h, k)
     length = 16  # bytes hashed
     if ctr >> 28:
@@ -83,8 +89,14 @@ def word(seed, env, stream, ctr):
     return _fmix(h)
 
 
+def word_at_step(seed, env, stream, t):
+    """The word of stream 0 or 2 that covers step t (a 64-bit step count)."""
+    t = int(t) & 0xFFFFFFFFFFFFFFFF
+    return word(seed, env, stream, (t >> 4) & CTR_MASK, epoch=t >> 32)
+
+
 def action(seed, env, t):
-    return (word(seed, env, STREAM_ACTION, t >> 4) >> (2 * (t & 15))) & 3
+    return (word_at_step(seed, env, STREAM_ACTION, t) >> (2 * (int(t) & 15))) & 3
 
 
 def start_index(seed, env, episode, n_starts):
@@ -105,8 +117,8 @@ def sample_next(x):
 
 def sample_word(seed, env, t):
     """The 32-bit word behind the sampled action of step t (stream 2): one hash per sixteen steps."""
-    t = int(t) & M32
-    w = word(seed, env, STREAM_SAMPLE, t >> SAMPLE_GROUP_LOG2)
+    t = int(t) & 0xFFFFFFFFFFFFFFFF
+    w = word_at_step(seed, env, STREAM_SAMPLE, t)
     for _ in range(t & (SAMPLE_GROUP - 1)):
         w = sample_next(w)
     return w
@@ -143,15 +155,18 @@ def _vfmix(h):
     return h
 
 
-def word_v(seed, env, stream, ctr):
-    """Vectorised `word`: env and ctr broadcast; returns uint32 array."""
+def word_v(seed, env, stream, ctr, epoch=None):
+    """Vectorised `word`: env, ctr (and epoch) broadcast; returns uint32 array."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     env = np.asarray(env, dtype=np.uint64) & np.uint64(M32)
     ctr = np.asarray(ctr, dtype=np.uint64) & np.uint64(M32)
-    env, ctr = np.broadcast_arrays(env, ctr)
+    epoch = np.zeros((), np.uint64) if epoch is None else np.asarray(epoch, dtype=np.uint64) & np.uint64(M32)
+    env, ctr, epoch = np.broadcast_arrays(env, ctr, epoch)
     h = np.full(env.shape, H0, dtype=np.uint64)
     h = _vblock(h, np.uint64(seed & M32))
     h = _vblock(h, np.uint64(seed >> 32))
+    if epoch.any():
+        h = np.where(epoch != 0, _vblock(h, epoch), h)
     h = _vblock(h, env)
     h = _vblock(h, (np.uint64((int(stream) & 0xF) << 28)) | (ctr & np.uint64(CTR_MASK)))
     high = ctr >> np.uint64(28)
@@ -162,7 +177,7 @@ def word_v(seed, env, stream, ctr):
 def actions_v(seed, env, t):
     """Vectorised `action`; env, t broadcast.  Returns int32 array in 0..3."""
     t = np.asarray(t, dtype=np.uint64)
-    w = word_v(seed, env, STREAM_ACTION, t >> np.uint64(4)).astype(np.uint64)
+    w = word_v(seed, env, STREAM_ACTION, (t >> np.uint64(4)) & np.uint64(CTR_MASK), epoch=t >> np.uint64(32)).astype(np.uint64)
     return ((w >> (np.uint64(2) * (t & np.uint64(15)))) & np.uint64(3)).astype(np.int32)
 
 

@@ -28,7 +28,7 @@ class NumpyBatchEnv(object):
         self.pos = np.full(self.n, self.starts[0], np.int32)
         self.done = np.zeros(self.n, bool)
         self.episode = np.zeros(self.n, np.uint32)
-        self.tcount = np.zeros(self.n, np.uint32)
+        self.tcount = np.zeros(self.n, np.uint64)
 
     @classmethod
     def from_env(cls, env, n, seed=0, env_id0=0):

@@ -23,7 +23,7 @@ void gu_oracle_reset(const gu_oracle_grid *g, uint64_t seed, int64_t env_id0, in
                      int32_t *pos, int32_t *done, uint32_t *episode);
 void gu_oracle_rollout(const gu_oracle_grid *g, uint64_t seed, int64_t env_id0, int64_t n, int64_t T, int32_t auto_reset,
                        const int32_t *actions, const double *pi, int32_t *pos, int32_t *done, uint32_t *episode,
-                       uint32_t *tcount, int32_t *obs_out, int32_t *reward_out, int32_t *done_out, int64_t *ret_out,
+                       uint64_t *tcount, int32_t *obs_out, int32_t *reward_out, int32_t *done_out, int64_t *ret_out,
                        int32_t *episodes_out);
 
 #define CHECK(call)                                                        \
@@ -62,7 +62,8 @@ int main(void)
     int32_t *obs = malloc(sizeof(int32_t) * N * T), *rew = malloc(sizeof(int32_t) * N * T), *don = malloc(sizeof(int32_t) * N * T);
     int32_t *o_obs = malloc(sizeof(int32_t) * N * T), *o_rew = malloc(sizeof(int32_t) * N * T), *o_don = malloc(sizeof(int32_t) * N * T);
     static int32_t pos[N], done[N], first[N], acts[N], s_obs[N], s_rew[N], s_don[N];
-    static uint32_t episode[N], tcount[N];
+    static uint32_t episode[N];
+    static uint64_t tcount[N];
 
     CHECK(gu_reset(h, NULL, NULL, first));
     gu_oracle_reset(&og, seed, env_id0, N, NULL, pos, done, episode);
@@ -89,12 +90,14 @@ int main(void)
     if (gu_step(h, acts, 0, NULL, NULL, NULL) != GU_ERR_INVALID) { fprintf(stderr, "bad action accepted\n"); return 1; }
     {
         const int32_t keep_pos = pos[7], keep_done = done[7];
-        const uint32_t keep_ep = episode[7], keep_t = tcount[7];
+        const uint32_t keep_ep = episode[7];
+        const uint64_t keep_t = tcount[7];
         acts[7] = 0;
         gu_oracle_rollout(&og, seed, env_id0, N, 1, 0, acts, NULL, pos, done, episode, tcount, o_obs, o_rew, o_don, NULL, NULL);
         pos[7] = keep_pos, done[7] = keep_done, episode[7] = keep_ep, tcount[7] = keep_t;
         static int32_t g_pos[N], g_done[N];
-        static uint32_t g_ep[N], g_t[N];
+        static uint32_t g_ep[N];
+        static uint64_t g_t[N];
         CHECK(gu_get_state(h, g_pos, g_done, g_ep, g_t));
         if (memcmp(g_pos, pos, sizeof pos) || memcmp(g_done, done, sizeof done) || memcmp(g_ep, episode, sizeof episode) ||
             memcmp(g_t, tcount, sizeof tcount)) { fprintf(stderr, "state after a rejected action differs\n"); return 1; }

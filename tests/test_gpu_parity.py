@@ -237,7 +237,7 @@ def test_set_state_round_trip_and_absorbing_terminals():
     pos = rs.choice(free, N).astype(np.int32)
     with Engine(N, spec_of(meta), seed=8) as eng:
         eng.set_state(pos=pos, done=np.zeros(N, np.int32), episode=np.arange(N, dtype=np.uint32),
-                      tcount=np.full(N, 160, np.uint32))
+                      tcount=np.full(N, 160, np.uint64))
         s = eng.get_state()
         assert np.array_equal(s['pos'], pos) and np.all(s['tcount'] == 160) and np.array_equal(s['episode'], np.arange(N))
         lava = np.array(meta['lava'][:N // 2] * 40, np.int32)[:N]

@@ -208,6 +208,92 @@ def test_sampled_stream_does_not_repeat_beyond_2_pow_28_steps():
     assert not np.array_equal(rows[5], rows[(1 << 28) + 5]) and not np.array_equal(rows[(1 << 28) + 5], rows[(3 << 28) + 5])
 
 
+@pytest.mark.parametrize('name,N', [('c3_maze32', 4096), ('c2_open8x8', 512), ('multistart_test_env', 640)])
+def test_step_counts_have_64_bits_a_rollout_across_2_pow_32_steps_equals_the_oracle(name, N):
+    """Round 5's count had 32 bits and the action stream repeated after 2^32 steps per env (97 s at the statistics-only rate).
+    Now: every env at 2^32 - 500 steps, 1000 steps rolled -- the launch in which the count passes 2^32 runs on the general kernel,
+    every step asking for the prefix of its own epoch -- then launches that lie wholly in epoch 1 (the epoch folded into the seed
+    prefix by the launcher: the transition-row and K-step kernels as they are), all equal to the oracle; the steps behind the
+    boundary are NOT steps 0 .. 499 over again; get_state reports counts beyond 2^32."""
+    meta, _ = G.load_traj(name)
+    grid = C.Grid.from_lists(**meta)
+    S = meta['W'] * meta['H']
+    pi = np.random.RandomState(4).dirichlet(np.ones(4), S)
+    T = 1000
+    for policy, kw in (('uniform', {}), ('sample', dict(pi=pi))):
+        with Engine(N, spec_of(meta), seed=21) as eng:
+            eng.vi_set(np.zeros(S), pi)
+            eng.reserve_trajectory(T)
+            fresh = C.State(N)
+            assert np.array_equal(eng.reset(), C.reset(grid, 21, fresh))
+            eng.rollout(500, policy, True)
+            from_zero = eng.read_trajectory(0, 500)  # steps 0 .. 499 of every env
+            assert all(np.array_equal(from_zero[k], v) for k, v in C.rollout(grid, 21, fresh, 500, True, **kw).items() if k in from_zero)
+            # the same engine put back to its reset state, 500 steps short of 2^32
+            eng.seed(21)
+            st = C.State(N)
+            assert np.array_equal(eng.reset(), C.reset(grid, 21, st))
+            st.tcount[:] = 2 ** 32 - 500
+            eng.set_state(tcount=st.tcount)
+            eng.rollout(T, policy, True)
+            got = eng.read_trajectory(0, T)
+            want = C.rollout(grid, 21, st, T, True, **kw)
+            assert all(np.array_equal(got[k], want[k]) for k in got), (policy, 'across the boundary')
+            assert not np.array_equal(got['obs'][500:], from_zero['obs']), policy  # a 32-bit count would replay steps 0 .. 499 here
+            state = eng.get_state()
+            assert state['tcount'].dtype == np.uint64 and np.all(state['tcount'] == 2 ** 32 + 500) and np.array_equal(state['pos'], st.pos)
+            # wholly inside epoch 1: rows, packed rows, statistics only -- whichever kernel the launch shape selects
+            for traj, stats in ((True, False), ('packed', False), (False, True), (True, True)):
+                eng.rollout(T, policy, True, trajectory=traj, stats=stats)
+                want = C.rollout(grid, 21, st, T, True, stats=stats, **kw)
+                if traj == 'packed':
+                    packed = eng.read_trajectory_packed(0, T)
+                    assert np.array_equal(packed & 0xFFFF, want['obs']) and np.array_equal(packed >> 24, want['done']), (policy, 'packed')
+                elif traj:
+                    got = eng.read_trajectory(0, T)
+                    assert all(np.array_equal(got[k], want[k]) for k in got), (policy, traj, stats)
+                if stats:
+                    ret, fin = eng.read_stats()
+                    assert np.array_equal(ret, want['ret']) and np.array_equal(fin, want['episodes']), (policy, 'stats')
+                s = eng.get_state()
+                assert all(np.array_equal(s[k], getattr(st, k)) for k in ('pos', 'done', 'episode', 'tcount')), (policy, traj, stats)
+
+
+def test_envs_that_pass_2_pow_32_steps_at_different_moments():
+    """Ragged step counts around the boundary (gu_set_state), and an env held back by a rejected action: every env changes epoch at
+    its own step; launches straddle the boundary for as long as some env has not passed it."""
+    meta, _ = G.load_traj('c4_lava32')
+    grid = C.Grid.from_lists(**meta)
+    N, S = 1024, 1024
+    rs = np.random.RandomState(8)
+    pi = rs.dirichlet(np.ones(4), S)
+    with Engine(N, spec_of(meta), seed=5) as eng:
+        eng.vi_set(np.zeros(S), pi)
+        eng.reserve_trajectory(300)
+        st = C.State(N)
+        assert np.array_equal(eng.reset(), C.reset(grid, 5, st))
+        st.tcount[:] = 2 ** 32 - 400 + rs.randint(0, 700, N)   # some already beyond, most in front of the boundary
+        st.tcount[:64] = 2 ** 32 - 17                           # one wave at a common count (the unrolled schedule's entry test)
+        eng.set_state(tcount=st.tcount)
+        acts = rs.randint(0, 4, N).astype(np.int32)
+        acts[5] = 7                                            # rejected: env 5 does not step, its count stays behind
+        with pytest.raises(_lib.GuError):
+            eng.step(acts, auto_reset=True)
+        keep = (st.pos[5], st.done[5], st.episode[5], st.tcount[5])
+        acts[5] = 0
+        C.rollout(grid, 5, st, 1, True, actions=acts[None, :])
+        st.pos[5], st.done[5], st.episode[5], st.tcount[5] = keep
+        for policy, kw, T in (('uniform', {}, 300), ('sample', dict(pi=pi), 150), ('uniform', {}, 77), ('sample', dict(pi=pi), 300), ('uniform', {}, 300)):
+            eng.rollout(T, policy, True)
+            got = eng.read_trajectory(0, T)
+            want = C.rollout(grid, 5, st, T, True, **kw)
+            assert all(np.array_equal(got[k], want[k]) for k in got), (policy, T)
+        s = eng.get_state()
+        assert all(np.array_equal(s[k], getattr(st, k)) for k in ('pos', 'done', 'episode', 'tcount')) and s['tcount'].min() > 2 ** 32
+        with pytest.raises(_lib.GuError, match='within 2\\^31'):
+            eng.set_state(tcount=np.where(np.arange(N) % 2, 5, 2 ** 33).astype(np.uint64))
+
+
 def test_get_cells_with_a_start_list_longer_than_the_grid():
     spec = GridSpec(2, 1, [0, 0, 0, 1, 0], [1], [], [])
     with Engine(8, spec) as eng:

@@ -78,6 +78,57 @@ def test_rng_is_murmurhash3_incl_counters_beyond_2_pow_28():
     assert gu_rng.word(7, 3, 2, 5) != gu_rng.word(7, 3, 2, 5 + 2 ** 28) != gu_rng.word(7, 3, 2, 5 + 2 ** 29)
 
 
+def test_step_counts_have_64_bits_and_the_epoch_keys_streams_0_and_2():
+    """oracle/gu_rng.py: streams 0 and 2 are keyed by a 64-bit step count t -- counter = bits 4 .. 31, epoch = t >> 32 hashed
+    right behind the seed words when it is not zero (length word 16).  Epoch 0 is the four-word hash of before; beyond 2^32 steps
+    nothing repeats; scalar Python, vectorised Python and C agree everywhere."""
+    lib = C.lib()
+    rs = np.random.RandomState(11)
+    for i in range(200):
+        seed = int(rs.randint(0, 2 ** 63 - 1)) * 2 + 1
+        env = int(rs.randint(0, 2 ** 32, dtype=np.uint64))
+        t = int(rs.randint(0, 2 ** 63, dtype=np.uint64)) * 2 + (i & 1) if i % 4 else int(rs.randint(0, 2 ** 32, dtype=np.uint64))
+        epoch, ctr = t >> 32, (t >> 4) & 0x0FFFFFFF
+        for stream in (0, 2):
+            keys = [seed & 0xFFFFFFFF, seed >> 32] + ([epoch] if epoch else []) + [env, (stream << 28) | ctr]
+            h = 0x9747B28C  # written out once more, independently of gu_rng._block
+            for k in keys:
+                k = (k * 0xCC9E2D51) & 0xFFFFFFFF
+                k = ((k << 15) | (k >> 17)) & 0xFFFFFFFF
+                k = (k * 0x1B873593) & 0xFFFFFFFF
+                h ^= k
+                h = ((h << 13) | (h >> 19)) & 0xFFFFFFFF
+                h = (h * 5 + 0xE6546B64) & 0xFFFFFFFF
+            h ^= 16
+            h ^= h >> 16
+            h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+            h ^= h >> 13
+            h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+            h ^= h >> 16
+            assert gu_rng.word_at_step(seed, env, stream, t) == h
+            if not epoch:
+                assert h == _murmur3_x86_32(b''.join(w.to_bytes(4, 'little') for w in keys), 0x9747B28C)  # the plain hash
+        assert gu_rng.action(seed, env, t) == lib.gu_oracle_rng_action(seed, env, t) == int(gu_rng.actions_v(seed, [env], np.array([t], np.uint64))[0])
+        assert gu_rng.sample_word(seed, env, t) == lib.gu_oracle_rng_sample_word(seed, env, t)
+    # a stream of actions across the first epoch boundary: what a 32-bit count would have replayed is not replayed
+    first = gu_rng.action_stream(3, range(64), 0, 512)
+    across = gu_rng.action_stream(3, range(64), 2 ** 32 - 256, 512)
+    assert np.array_equal(across[:256], gu_rng.action_stream(3, range(64), 2 ** 32 - 256, 256))
+    assert not np.array_equal(across[256:], first[:256])
+    assert [gu_rng.action(3, 5, 2 ** 32 + k) for k in range(64)] == across[256:320, 5].tolist()
+    # the C rollout counts in 64 bits
+    grid = C.Grid.from_lists(8, 8)
+    st = C.State(16)
+    C.reset(grid, 3, st)
+    st.tcount[:] = 2 ** 32 - 100
+    out = C.rollout(grid, 3, st, 200, True)
+    assert st.tcount.dtype == np.uint64 and np.all(st.tcount == 2 ** 32 + 100)
+    ref = C.State(16)
+    C.reset(grid, 3, ref)
+    again = C.rollout(grid, 3, ref, 200, True, actions=gu_rng.action_stream(3, range(16), 2 ** 32 - 100, 200))
+    assert all(np.array_equal(out[k], again[k]) for k in ('obs', 'reward', 'done'))
+
+
 @pytest.mark.parametrize('name', G.traj_names())
 def test_trajectories_c_oracle(name):
     meta, z = G.load_traj(name)

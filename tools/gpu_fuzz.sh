@@ -1,9 +1,10 @@
-# Long random-grid soak of the property tests (rollouts, table policies, DP, Monte-Carlo) under both rollout dispatches.
-# Usage (through gpurun): bash tools/gpu_fuzz.sh <tag> <trials>
+# Long random-grid soak of the property tests (rollouts, table policies, DP, Monte-Carlo) under several dispatches
+# (GU_TEST_OPTIONS: see tools/gpu_soak_switches.sh).  Usage (through gpurun): bash tools/gpu_fuzz.sh <tag> <trials>
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r02d}
+TAG=${1:-r06}
 TRIALS=${2:-1500}
-for sw in "GU_FUZZ_SEED=11" "GU_FUZZ_SEED=12 GU_ROLLOUT_ROWS=1 GU_ROLLOUT_MULTI=1" "GU_FUZZ_SEED=13 GU_VI_CLUSTER=0" "GU_FUZZ_SEED=14 GU_ROLLOUT_ROWS=0" "GU_FUZZ_SEED=15 GU_ROLLOUT_ROWS=1 GU_ROLLOUT_ENTRY=0" "GU_FUZZ_SEED=16 GU_ROLLOUT_ROWS=3 GU_TRAJ_LAYOUT=1"; do
-  echo "== GU_FUZZ_TRIALS=$TRIALS $sw"
-  env GU_FUZZ_TRIALS=$TRIALS $sw timeout 3000 python -m pytest tests -m gpu -q -k "property" 2>&1 | grep -E "passed|failed|rror|^FAILED|^E  |assert" | tail -14
+for sw in "11 " "12 rollout_rows=1,rollout_multi=1" "13 vi_path=1" "14 rollout_rows=0,rollout_multi=0" "15 rollout_rows=1,rollout_entry=0" "16 rollout_rows=1,traj_layout=1"; do
+  set -- $sw
+  echo "== GU_FUZZ_TRIALS=$TRIALS GU_FUZZ_SEED=$1 GU_TEST_OPTIONS=$2"
+  GU_FUZZ_TRIALS=$TRIALS GU_FUZZ_SEED=$1 GU_TEST_OPTIONS="$2" timeout 3000 python -m pytest tests -m gpu -q -k "property" 2>&1 | grep -E "GU_TEST_OPTIONS|passed|failed|rror|^FAILED|^E  |assert" | tail -14
 done 2>&1 | tee gpurun_out/${TAG}_fuzz_${TRIALS}_trials.txt

@@ -1,10 +1,20 @@
-# The whole -m gpu suite under every launch-shape switch of the rollout kernels (each is read per launch, so forcing it
-# routes every eligible launch of every parity test through that variant).  Usage (through gpurun): bash tools/gpu_soak_switches.sh <tag>
+# The whole -m gpu suite under several sets of launch-shape options of the rollout kernels.  tests/conftest.py turns
+# GU_TEST_OPTIONS into process-wide gu_set_option defaults at session start and prints what gu_get_option reports for each;
+# every eligible launch of every parity test then goes through that variant.  (Rounds 3-5 exported GU_ROLLOUT_ROWS=... here, which
+# the product library had stopped reading in round 3: those logs are the default dispatch, see profiles/README.)
+# Usage (through gpurun): bash tools/gpu_soak_switches.sh <tag> [sets...]
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r02b}
-for sw in "GU_ROLLOUT_ROWS=1" "GU_ROLLOUT_MULTI=1" "GU_ROLLOUT_MULTI=0 GU_ROLLOUT_ROWS=1" "GU_ROLLOUT_ROWS=0" "GU_ROLLOUT_XCD=1" "GU_ROLLOUT_BLOCK=1024" "GU_ROLLOUT_BLOCK=64 GU_ROLLOUT_XCD=1 GU_ROLLOUT_ROWS=1" \
-          "GU_ROLLOUT_ROWS=1 GU_ROLLOUT_ENTRY=0" "GU_ROLLOUT_ROWS=1 GU_TRAJ_LAYOUT=1" "GU_ROLLOUT_ROWS=3 GU_TRAJ_LAYOUT=1 GU_ROLLOUT_HALF_WAVES=1" "GU_ROLLOUT_ROWS=1 GU_ROWS_COPIES=1" "GU_ROLLOUT_ROWS=1 GU_ROWS_COPIES=2" "GU_ROLLOUT_ROWS=1 GU_ROWS_COPIES=32 GU_TRAJ_LAYOUT=0" "GU_ROLLOUT_ROWS=2 GU_ROLLOUT_PACE=150 GU_SOAK_SKIP_PACING_TESTS=1"; do
-  echo "== $sw"
-  skip=""; case "$sw" in *GU_SOAK_SKIP_PACING_TESTS*) skip="--deselect tests/test_gpu_store_pacing.py";; esac  # (those tests are about the DEFAULT pacing)
-  env $sw timeout 1500 python -m pytest tests -m gpu -q -x $skip 2>&1 | grep -E "passed|failed|rror|^FAILED|assert" | tail -8
+TAG=${1:-r06}
+shift
+SETS=("$@")
+if [ ${#SETS[@]} -eq 0 ]; then
+  SETS=("rollout_rows=1" "rollout_multi=1" "rollout_multi=0,rollout_rows=1" "rollout_rows=0,rollout_multi=0" "rollout_xcd=1" "rollout_block=1024"
+        "rollout_block=64,rollout_xcd=1,rollout_rows=1" "rollout_rows=1,rollout_entry=0" "rollout_rows=1,traj_layout=1"
+        "rollout_rows=1,traj_layout=1,rollout_half_waves=1" "rollout_rows=1,rows_copies=2" "rollout_rows=1,rows_copies=32,traj_layout=0"
+        "rollout_rows=2,rollout_pace=150")
+fi
+for sw in "${SETS[@]}"; do
+  echo "== GU_TEST_OPTIONS=$sw"
+  skip=""; case "$sw" in *rollout_pace*) skip="--deselect tests/test_gpu_store_pacing.py";; esac  # (those tests are about the DEFAULT pacing)
+  GU_TEST_OPTIONS="$sw" timeout 1500 python -m pytest tests -m gpu -q -x $skip 2>&1 | grep -E "GU_TEST_OPTIONS|passed|failed|rror|^FAILED|assert" | tail -8
 done 2>&1 | tee gpurun_out/${TAG}_soak_switches.txt

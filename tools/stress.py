@@ -76,18 +76,14 @@ eng.reset()
 ref.reset()
 eng.reserve_trajectory(256)
 ref.reserve_trajectory(256)
-os.environ['GU_ROLLOUT_ROWS'] = '0'
-os.environ['GU_ROLLOUT_MULTI'] = '0'
+ref.set_option('rollout_rows', 0)   # `ref`: always the general kernel (an option of THAT engine; the library reads no environment)
+ref.set_option('rollout_multi', 0)
 modes = [dict(trajectory=True), dict(trajectory=False, stats=True), dict(trajectory='packed'), dict(trajectory=False)]
 launches, t0 = 0, time.time()
 while time.time() - t0 < budget:
     for i, T in enumerate((256, 97, 64, 1, 200, 33)):
         kw = modes[(launches + i) % len(modes)]
-        for k in ('GU_ROLLOUT_ROWS', 'GU_ROLLOUT_MULTI'):
-            os.environ.pop(k, None)
         eng.rollout(T, 'uniform', True, **kw)          # default dispatch: whichever kernel is preferred
-        os.environ['GU_ROLLOUT_ROWS'] = '0'
-        os.environ['GU_ROLLOUT_MULTI'] = '0'
         ref.rollout(T, 'uniform', True, **kw)          # always the general kernel
     launches += 6
     a, b = eng.get_state(), ref.get_state()

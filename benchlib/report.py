@@ -182,6 +182,8 @@ def compact_line(detail, detail_path=None):
     line['per_rank'] = _pick(detail.get('per_rank'), ('value',))
     if detail.get('rccl') is not None:
         line['rccl'] = _pick(detail['rccl'], ('nranks', 'comm_init_ms', 'allgather_ms', 'view_envs', 'view_equals_shards', 'error'))
+        if line['rccl'].get('error'):
+            line['rccl']['error'] = str(line['rccl']['error'])[:240]
     c4 = detail.get('strong_c4')
     if c4 is not None:
         line['strong_c4'] = _pick(c4, ('value', 'scaling', 'total_envs', 'envs_per_gpu', 'n_gpus', 'ms_per_step', 'launch_ms', 'hbm_gbps_per_gpu',

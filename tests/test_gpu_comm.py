@@ -17,16 +17,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args):
+def _bench(tmp_path, *args):
+    """Returns (the ONE line of stdout, under 4 KB; the side file)."""
     env = dict(os.environ)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), cwd=ROOT, env=env, stdout=subprocess.PIPE,
+    side = os.path.join(str(tmp_path), 'bench_detail.json')
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--detail', side] + list(args), cwd=ROOT, env=env, stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, timeout=1200)
     assert proc.returncode == 0, proc.stderr.decode()[-3000:]
     lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    return json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 4096, lines
+    return json.loads(lines[0]), json.load(open(side))
 
 
 SMALL = ['--envs', '16384', '--T', '200', '--steps', '3', '--warmup', '1', '--min-seconds', '0.05', '--c4-envs', '16384', '--no-cpu-baseline', '--no-live-traffic']
@@ -122,24 +124,28 @@ print('VIEW-OK')
     assert out.returncode == 0 and b'VIEW-OK' in out.stdout, out.stdout.decode()[-3000:]
 
 
-def test_bench_started_plainly_with_two_ranks_on_the_one_gpu():
+def test_bench_started_plainly_with_two_ranks_on_the_one_gpu(tmp_path):
     """`python bench.py --gpus 2`, no launcher: two rank processes (sharing device 0 here), rank 0's one line; RCCL itself refuses
     two ranks on one device, which the line reports instead of dying."""
-    line = _bench('--gpus', '2', *SMALL)
+    line, detail = _bench(tmp_path, '--gpus', '2', *SMALL)
     assert line['n_gpus'] == 2 and len(line['per_rank']['value']) == 2 and line['engine'] == 'griduniverse_amd.engine.Engine'
     assert line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
     assert line['rccl']['nranks'] == 2 and (line['rccl'].get('view_equals_shards') is True or 'error' in line['rccl'])
     assert line['strong_c4']['n_gpus'] == 2 and line['strong_c4']['shards_equal_oracle'] is True
-    assert line['device']['arch'].startswith('gfx950') and line['roofline']['trajectory_placement'] is not None
+    assert detail['device']['arch'].startswith('gfx950') and detail['roofline']['trajectory_placement'] is not None
+    if 'error' in line['rccl']:  # (what the real RCCL says to two ranks on one device: kept for profiles/)
+        print('RCCL with 2 ranks on one device: ' + line['rccl']['error'])
 
 
-def test_bench_single_process_form_on_the_one_gpu():
+def test_bench_single_process_form_on_the_one_gpu(tmp_path):
     """--single-process --gpus 2: one process, two engines (both on device 0 here), launches enqueued engine after engine; the
     gu_comm_init_all view needs one device per engine and is reported as refused on this box."""
-    line = _bench('--gpus', '2', '--single-process', *SMALL)
+    line, detail = _bench(tmp_path, '--gpus', '2', '--single-process', *SMALL)
     assert line['n_gpus'] == 2 and line['mode'] == 'single-process' and line['config']['devices'] == [0, 0]
     assert len(line['per_rank']['value']) == 2 and line['bit_exact_vs_oracle'] is True and line['final_state_vs_oracle']['equal'] is True
     assert line['rccl']['nranks'] == 2 and ('error' in line['rccl'] or line['rccl']['view_equals_shards'] is True)
-    assert line['strong_c4']['shards_equal_oracle'] is True and len(line['roofline']['trajectory_placement']) == 2
-    line = _bench('--gpus', '1', '--single-process', '--gather-view', *SMALL)
+    assert line['strong_c4']['shards_equal_oracle'] is True and len(detail['roofline']['trajectory_placement']) == 2
+    if 'error' in line['rccl']:
+        print('ncclCommInitAll with the same device twice: ' + line['rccl']['error'])
+    line, _ = _bench(tmp_path, '--gpus', '1', '--single-process', '--gather-view', *SMALL)
     assert line['n_gpus'] == 1 and line['rccl']['view_equals_shards'] is True and line['rccl']['nranks'] == 1

@@ -167,7 +167,7 @@ int gu_destroy(gu_handle h)
     gu_trail_free(h);
     gu_placement_release(h);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    void *bufs[] = {h->d_kind, h->d_rows[0], h->d_rows[1], h->d_rows2[0], h->d_rows2[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
+    void *bufs[] = {h->d_kind, h->d_rows[0], h->d_rows[1], h->d_rows2[0], h->d_rows2[1], h->d_mrows[0], h->d_mrows[1], h->d_mrows1[0], h->d_mrows1[1], h->d_prow, h->d_cell, h->d_cell_raw, h->d_nib, h->d_starts, h->d_nstarts, h->d_out3, h->d_episode, h->d_tcount, h->d_actions, h->d_actions_packed,
                     h->d_traj, h->d_ret, h->d_episodes_fin, h->d_done_bits, h->d_scratch, h->d_greedy, h->d_pace_ring, h->d_pace_slots, h->d_out3_alt, h->d_episode_alt, h->d_done_bits_alt};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -236,6 +236,9 @@ int gu_install_grids(gu_engine *h, int32_t n_grids, int32_t W, int32_t H, const 
     const int32_t cell_bytes = (S + 15) & ~15;
     GU_HIP(hipStreamSynchronize(h->stream));
     h->entry_table_ok = false;  // (other cells, other flags)
+    h->nib_valid = false;
+    if (h->d_nib) GU_HIP(hipFree(h->d_nib));
+    h->d_nib = nullptr;
     for (void *p : {(void *)h->d_cell, (void *)h->d_cell_raw, (void *)h->d_kind, (void *)h->d_starts, (void *)h->d_nstarts, (void *)h->d_greedy})
         if (p) GU_HIP(hipFree(p));
     h->d_cell = h->d_cell_raw = h->d_kind = h->d_greedy = nullptr;

@@ -138,6 +138,8 @@ struct gu_engine {
     int32_t *d_out3_alt = nullptr;      // a second set of the env-state arrays: config 5's per-XCD launch writes its results there and
     uint32_t *d_episode_alt = nullptr;  // the sets change places when it did not give up (gu_vi_xcd.hip: gu_vi_xcd_fused_run)
     uint64_t *d_done_bits_alt = nullptr;
+    uint32_t *d_nib = nullptr;     // [ceil(N / 64)][nib_dwords][64]: every env's grid at four bits per cell (gu_nibble_planes; rollout MAP 5)
+    bool nib_valid = false;
     uint32_t *d_tcount = nullptr;  // per-env step-count OFFSET (read as int32); effective 64-bit count = steps_taken + offset
     uint64_t steps_taken = 0;      // lock-step counter since gu_seed (all envs step together)
     int64_t off_lo = 0, off_hi = 0;  // what the host knows of the offsets: off_lo <= every offset <= off_hi (gu_set_state, rejected actions)

@@ -675,6 +675,41 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int block_si
     return GU_OK;
 }
 
+// Rollout MAP 5 (gu_rollout.hpp): every env's grid at four bits per cell -- the upper half of its cell records: TERM, RPLUS, RMINUS,
+// WALL -- laid out per wave of 64 envs as [dword][lane], so that a wave stages its image with one contiguous copy and its gathers
+// are free of bank conflicts.  Built once per grid installation, on the device, from the cell planes.
+__global__ void __launch_bounds__(256) gu_nibble_planes_kernel(const uint8_t *__restrict__ cell, GridSel gs, int32_t S, int32_t dwords, int64_t N,
+                                                               uint32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (wave, dword, lane)
+    const int64_t total = ((N + 63) / 64) * dwords * 64;
+    if (i >= total) return;
+    const int64_t lane = i & 63, j = (i >> 6) % dwords, wave = (i >> 6) / dwords, e = wave * 64 + lane;
+    uint32_t word = 0x88888888u;  // (cells past the grid, envs past the batch: walls)
+    if (e < N) {
+        const uint8_t *f = cell + (e / gs.group) * gs.grid_stride;
+        word = 0;
+        for (int32_t k = 0; k < 8; ++k) {
+            const int64_t c = j * 8 + k;
+            const uint32_t four = c < S ? (uint32_t)(f[c] >> 4) : 0x8u;
+            word |= four << (4 * k);
+        }
+    }
+    out[i] = word;
+}
+
+int gu_nibble_planes(gu_engine *h)
+{
+    if (h->nib_valid) return GU_OK;
+    const int32_t dwords = gu_nibble_dwords(h);
+    const int64_t total = ((h->N + 63) / 64) * dwords * 64;
+    if (!h->d_nib) GU_HIP(hipMalloc((void **)&h->d_nib, (size_t)total * sizeof(uint32_t)));
+    hipLaunchKernelGGL(gu_nibble_planes_kernel, dim3(gu_blocks(total, 256)), dim3(256), 0, h->stream, h->d_cell, gu_grid_sel(h), h->S, dwords, h->N, h->d_nib);
+    GU_HIP(hipGetLastError());
+    h->nib_valid = true;
+    return GU_OK;
+}
+
 int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
 {
     // int32 rows: three planes [T][N], or one plane of (obs, reward, done) triples [T][N][3] -- the same words, one 12-byte store
@@ -745,6 +780,15 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     a.half_waves = 0;
     a.entry_table = (h->entry_table_ok && gu_opt(h, GU_OPT_ROLLOUT_ENTRY) != 0) ? 1 : 0;
     const int bs = gu_rollout_block(h);
+    a.nib = nullptr;
+    a.nib_dwords = 0;
+    if (h->n_grids > 1 && (policy == GU_POLICY_UNIFORM || policy == GU_POLICY_STREAM) && !gu_lds_block(h, bs, 2) && h->W <= 32767 &&
+        gu_nibble_bytes_per_wave(h) <= (size_t)h->lds_per_cu - 512) {  // groups that do not align with blocks (one maze per env): MAP 5
+        const int rc = gu_nibble_planes(h);
+        if (rc != GU_OK) return rc;
+        a.nib = h->d_nib;
+        a.nib_dwords = gu_nibble_dwords(h);
+    }
     a.pace = GuPaceArgs{};
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)
     if (policy == GU_POLICY_SAMPLE)

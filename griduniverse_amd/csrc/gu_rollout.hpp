@@ -357,6 +357,8 @@ struct RolloutArgs {
     uint64_t *done_bits;  // [ceil(N/64)] wave ballots of the final done flags (episode-done compaction)
     uint32_t n_starts, seed_prefix, env_id0, steps_taken;  // seed_prefix: the epoch of this launch folded in; steps_taken: low word
     uint32_t seed_prefix0, steps_hi;  // the seed prefix without an epoch (start choices; straddling launches); high word of the lock-step count
+    const uint32_t *nib;    // MAP 5: [waves][nib_dwords][64] four bits per cell, per env (gu_nibble_planes)
+    int32_t nib_dwords;     // dwords per env of that image (a multiple of four)
     int32_t straddle;       // some env passes a multiple of 2^32 steps during this launch: the general kernel asks per lane and step
     int64_t N, T;
     GridSel gs;
@@ -430,8 +432,14 @@ __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint3
 //       register copy of flags); 2 = auto-reset, several start cells (RNG stream 1, rare divergent branch)
 // MAP : 0 = records read from L2 (any grid size, any grid-per-env assignment)
 //       1 = the block's grid staged in LDS, shared by its lanes
-//       2 = every lane keeps a PRIVATE copy of its own grid's flags plane in LDS (multi-grid engines whose groups
-//           do not align with blocks, e.g. one maze per env; 64-lane blocks, S16 + 16 bytes per lane)
+//       5 = every lane keeps its own grid in LDS as FOUR BITS PER CELL -- {terminal, reward +10, reward -10, wall}, the upper half
+//           of the cell record -- for multi-grid engines whose groups do not align with blocks, e.g. one maze per env: S / 2 bytes
+//           per env (512 at 32 x 32: a wave's 32 KB, four waves per CU, the occupancy of the single-grid launch), dword j of
+//           lane l at word j * 64 + l, so that the 64 lanes of a gather hit 64 different banks whatever cells they ask for.  The
+//           step tests the CANDIDATE cell (inside the grid? a wall?) instead of reading open bits of the current one
+//           (env:136-155 literally); one LDS round trip per step as in the other variants.  Staged from a per-wave image of
+//           the grids that gu_nibble_planes builds once per grid installation (gu_kernels.hip).  Replaces round 2's private
+//           BYTE plane per lane (MAP 2: 66.5 KB per wave, two waves per CU, 0.53 of the HBM peak).
 //       3 = like 1 with the flags plane only (it carries the reward code): grids of 32 768 .. ~160 000 cells, one
 //           block per CU.  A global read per step would wait for every trajectory store in flight (vmcnt counts both).
 //       (a fifth variant -- one dword record per cell replicated 32 times, so that the per-step gather is free of LDS bank
@@ -439,7 +447,6 @@ __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint3
 //       stats-only launch of config 3: the conflicts (SQ_LDS_BANK_CONFLICT ~ 7 cycles per gather) are not what bounds the
 //       latency-bound modes, the length of the dependent chain is; profiles/archive/r02b_map_ab.txt.  What shortens the chain is the
 //       transition-row table of gu_rollout_rows.hip.)
-#define GU_PRIVATE_PAD 16
 // Cache-policy bits of the trajectory stores (buffer_store aux: 1 = sc0, 2 = nt, 16 = sc1).  The int32 rows go out with sc1 + nt:
 // written through at device scope instead of staying dirty in the L2 until they are evicted, and marked as streaming -- the rows
 // are never read again by the launch, and the memory then sees them in the order the waves issue them, not in the L2's eviction
@@ -482,6 +489,13 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         tcount0 = a.tcount[e];
     }
     CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem, a.gs, MAP == 3 ? 1 : 2);
+    const uint32_t *nib = reinterpret_cast<const uint32_t *>(smem) + (threadIdx.x & 63u);  // MAP 5: this lane's column of its wave's image
+    if (MAP == 5) {  // (blocks of one wave; the image of wave b is one contiguous piece)
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.nib + (size_t)blockIdx.x * (size_t)a.nib_dwords * 64u);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (int32_t i = threadIdx.x; i < a.nib_dwords * 16; i += 64) dst[i] = src[i];
+        __syncthreads();
+    }
     const uint8_t *greedy = a.greedy;
     if (MAP == 1 && POLICY == GU_POLICY_GREEDY) {
         uint8_t *dst = smem + 2 * a.cell_bytes;
@@ -500,12 +514,6 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     }
     if (!live) return;
     LaneGrid lg = gu_lane_grid<LDS>(a.gs, a.starts, a.n_starts, e, m);
-    if (MAP == 2) {  // copy this lane's own flags plane (which also carries the reward code) into its LDS slice
-        uint8_t *mine = smem + threadIdx.x * (a.cell_bytes + GU_PRIVATE_PAD);
-        for (int32_t i = 0; i < a.cell_bytes; i += 16)
-            *reinterpret_cast<uint4 *>(mine + i) = *reinterpret_cast<const uint4 *>(m.f + i);
-        m.f = mine;
-    }
 
     const uint32_t t_lane = tcount0 + a.steps_taken;
     const uint32_t prefix = gu_rng_prefix(a.seed_prefix, a.env_id0 + e);
@@ -517,12 +525,35 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     auto prefix_at = [&](uint32_t t) {  // (t: the low word of the step count; a launch is shorter than 2^32 steps)
         return gu_rng_prefix(gu_rng_seed_prefix_epoch(a.seed_prefix0, epoch0 + (t < t_lane ? 1u : 0u)), a.env_id0 + e);
     };
-    uint32_t flags = m.f[s];
+    // MAP 5 keeps the upper half of the cell record in `flags` (TERM, RPLUS, RMINUS, WALL: what the four bits per cell hold) and the
+    // cell's own TERM bit once more in bit 0: the TERM bit proper follows the done flag at entry (AUTO == 1), bit 0 is what makes a
+    // terminal cell absorbing (env:145-146)
+    auto flags5 = [](uint32_t b) { return (b & 0xF0u) | ((b >> GU_CELL_TERM_BIT) & 1u); };
+    uint32_t flags = MAP == 5 ? flags5(m.f[s]) : m.f[s];
     int32_t ret = 0, fin = 0;
     const int32_t W = a.W;
     const uint64_t lut = a.lut;
     const int32_t start0 = lg.starts[0];
-    const uint32_t start0_flags = m.f[start0];
+    const uint32_t start0_flags = MAP == 5 ? flags5(m.f[start0]) : m.f[start0];
+    int32_t x = MAP == 5 ? s % W : 0;  // MAP 5: the column, for the RIGHT / LEFT edge tests
+    const int32_t start0_x = MAP == 5 ? start0 % W : 0;
+    auto cell5 = [&](int32_t c) {  // the record of cell c from the four-bit image
+        const uint32_t four = __builtin_amdgcn_ubfe(nib[(c >> 3) * 64], (uint32_t)(c & 7) * 4u, 4);
+        return (four << 4) | (four & 1u);
+    };
+    // one move on the four-bit image: candidate cell, inside the grid?, ONE gather, a wall?  (env:136-155)
+    auto move5 = [&](uint32_t act, int32_t delta) {
+        const int32_t cand = s + delta;
+        const int32_t xc = x + __builtin_amdgcn_sbfe(0xF010, (int32_t)(act * 4u), 4);  // UP 0, RIGHT +1, DOWN 0, LEFT -1
+        const bool inside = (uint32_t)cand < (uint32_t)a.S && (uint32_t)xc < (uint32_t)W;
+        const int32_t c = inside ? cand : s;
+        const uint32_t four = __builtin_amdgcn_ubfe(nib[(c >> 3) * 64], (uint32_t)(c & 7) * 4u, 4);
+        const uint32_t stay = (flags & ~GU_CELL_TERM) | ((flags & 1u) << GU_CELL_TERM_BIT);  // (done = TERM of the cell the agent is on)
+        const bool go = inside && !(four & (GU_CELL_WALL >> 4)) && !(flags & 1u);
+        s = go ? cand : s;
+        x = go ? xc : x;
+        flags = go ? ((four << 4) | (four & 1u)) : stay;
+    };
     // Trajectory rows are addressed as buffer resource (wave-uniform base, rebuilt per 16-step chunk)
     // + lane byte offset e4 (VGPR) + scalar row offset (SGPR): buffer_store_dword ... offen, so that
     // advancing a row costs SALU only and no per-lane 64-bit address arithmetic.
@@ -567,18 +598,21 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             ep += was_done;
             s = was_done ? start0 : s;
             flags = was_done ? start0_flags : flags;
-            s = gu_move(s, flags, act, delta);
-        } else {
-            if (AUTO == 2) {
-                if (d) {
-                    s = lg.starts[gu_rng_start_index(prefix0, ep, lg.n_starts)];
-                    ++ep;
-                    flags = m.f[s];
-                }
+            if (MAP == 5) x = was_done ? start0_x : x;
+        } else if (AUTO == 2) {
+            if (d) {
+                s = lg.starts[gu_rng_start_index(prefix0, ep, lg.n_starts)];
+                ++ep;
+                flags = MAP == 5 ? cell5(s) : m.f[s];  // (no global read inside the loop: it would wait for every row store in flight)
+                if (MAP == 5) x = s % W;
             }
-            s = gu_move(s, flags, act, delta);
         }
-        flags = m.f[s];
+        if (MAP == 5) {
+            move5(act, delta);
+        } else {
+            s = gu_move(s, flags, act, delta);
+            flags = m.f[s];
+        }
         r = (MAP >= 2) ? gu_reward_packed(flags) : (int32_t)m.r[s];
         d = __builtin_amdgcn_ubfe(flags, GU_CELL_TERM_BIT, 1);
         if (STATS) {
@@ -826,6 +860,11 @@ static inline int gu_lds_block(const gu_engine *h, int preferred, int planes)
 
 static inline int gu_rollout_block(const gu_engine *h) { return (int)gu_opt(h, GU_OPT_ROLLOUT_BLOCK); }
 
+// MAP 5: dwords per env of the four-bits-per-cell image (eight cells per dword, rounded up to whole uint4 per lane), bytes per wave
+static inline int32_t gu_nibble_dwords(const gu_engine *h) { return (((h->S + 7) / 8) + 3) & ~3; }
+static inline size_t gu_nibble_bytes_per_wave(const gu_engine *h) { return (size_t)gu_nibble_dwords(h) * 256u; }
+int gu_nibble_planes(gu_engine *h);  // builds h->d_nib if the installed grids have none yet (gu_kernels.hip)
+
 template <int POLICY, int AUTO, int TRAJ, bool STATS>
 static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
 {
@@ -867,12 +906,12 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
             hipLaunchKernelGGL(kern, dim3(n_blocks(bs)), dim3(bs), (size_t)h->cell_bytes, h->stream, a);
             return;
         }
-        // misaligned multi-grid engine (e.g. one maze per env): private per-lane copies in LDS if 64 of them fit
-        const size_t priv = 64 * ((size_t)h->cell_bytes + GU_PRIVATE_PAD);
-        if (h->n_grids > 1 && h->W <= 32767 && (int64_t)priv <= h->lds_per_cu) {
-            auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 2>;
-            if (priv > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)priv);
-            hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, 64)), dim3(64), priv, h->stream, a);
+        // misaligned multi-grid engine (e.g. one maze per env): every lane's grid at four bits per cell in LDS, if a wave's 64 fit
+        if (h->n_grids > 1 && h->W <= 32767 && gu_nibble_bytes_per_wave(h) <= (size_t)h->lds_per_cu - 512 && a.nib) {
+            const size_t lds = gu_nibble_bytes_per_wave(h);
+            auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 5>;
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, 64)), dim3(64), lds, h->stream, a);
             return;
         }
     }

@@ -59,6 +59,57 @@ def test_multi_grid_engine_equals_per_grid_oracle(group):
         assert np.array_equal(final['pos'][sl], st.pos) and np.array_equal(final['episode'][sl], st.episode)
 
 
+@pytest.mark.parametrize('W,H', [(32, 32), (5, 3), (40, 12), (1, 7)])
+def test_one_grid_per_env_on_the_four_bit_image(W, H):
+    """One distinct grid PER ENV (the N x GridUniverseEnv(random_maze=True) shape, griduniverse_env.py:318-321): the rollout keeps
+    every lane's grid in LDS at four bits per cell and tests the candidate cell (gu_rollout.hpp, MAP 5).  Grids with every quirk
+    of SURVEY 8(a): starts on terminal cells and on walls, goals that are walls, cells both goal and lava, several starts; uniform
+    and caller-supplied actions, with and without auto-reset, int32 / packed rows and statistics."""
+    rs = np.random.RandomState(W * 100 + H)
+    S, N, T, seed = W * H, 192, 200, 23
+    specs = random_specs(rs, N, W, H) if S > 8 else [GridSpec(W, H, [int(rs.randint(S))], [int(rs.randint(S))], [], []) for _ in range(N)]
+    for i, sp in enumerate(specs[:64]):  # the quirks, on purpose
+        cells = [int(c) for c in rs.choice(S, size=min(S, 4), replace=False)]
+        goals, lava, walls = (np.flatnonzero(m).tolist() for m in (sp.goal, sp.lava, sp.wall))
+        kind = i % 4
+        if kind == 0:
+            specs[i] = GridSpec(W, H, [cells[0]], [cells[0]], lava, walls)                                   # start on a goal: absorbing at once
+        elif kind == 1:
+            specs[i] = GridSpec(W, H, [cells[0]], goals, [], sorted(set(walls) | {cells[0]}))               # start on a wall
+        elif kind == 2:
+            specs[i] = GridSpec(W, H, list(sp.starts), [cells[-1]], [cells[-1]], sorted(set(walls) | {cells[-1]}))  # goal = lava = wall
+    with Engine(N, specs[0], seed=seed) as eng:
+        eng.set_grids(specs)
+        eng.reserve_trajectory(T)
+        acts = rs.randint(0, 4, (T, N)).astype(np.int32)
+        eng.upload_actions(acts)
+        runs = []
+        for auto in (True, False):
+            eng.seed(seed)
+            first = eng.reset()
+            for policy, traj, stats in (('uniform', True, True), ('stream', True, False), ('uniform', 'packed', False), ('uniform', False, True)):
+                eng.rollout(T, policy, auto_reset=auto, trajectory=traj, stats=stats)
+                rows = eng.read_trajectory_packed(0, T) if traj == 'packed' else eng.read_trajectory(0, T) if traj else None
+                runs.append((auto, policy, traj, stats, first, rows, eng.read_stats() if stats else None, eng.get_state()))
+    for g, spec in enumerate(specs):
+        grid = oracle_grid(spec)
+        st = None
+        for auto, policy, traj, stats, first, rows, st_out, state in runs:
+            if policy == 'uniform' and traj is True and stats:  # (the first run of an `auto` setting: from seed + reset)
+                st = C.State(1, g)
+                assert C.reset(grid, seed, st)[0] == first[g], g
+            want = C.rollout(grid, seed, st, T, auto, actions=acts[:, g:g + 1] if policy == 'stream' else None, stats=stats)
+            if traj == 'packed':
+                assert np.array_equal(rows[:, g] & 0xFFFF, want['obs'][:, 0]) and np.array_equal(rows[:, g] >> 24, want['done'][:, 0]), (g, auto, 'packed')
+                assert np.array_equal(((rows[:, g] >> 16) & 0xFF).astype(np.int8), want['reward'][:, 0].astype(np.int8)), (g, auto, 'packed reward')
+            elif traj:
+                for k in ('obs', 'reward', 'done'):
+                    assert np.array_equal(rows[k][:, g], want[k][:, 0]), (g, auto, policy, k)
+            if stats:
+                assert st_out[0][g] == want['ret'][0] and st_out[1][g] == want['episodes'][0], (g, auto, policy)
+            assert state['pos'][g] == st.pos[0] and state['done'][g] == st.done[0] and state['episode'][g] == st.episode[0], (g, auto, policy)
+
+
 def test_multi_grid_restrictions():
     specs = random_specs(np.random.RandomState(0), 3, 8, 8)
     with Engine(30, specs[0]) as eng:

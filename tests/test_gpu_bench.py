@@ -62,15 +62,17 @@ def test_default_workload_line_carries_the_contract_and_its_own_checks(tmp_path)
     assert abs(roof['frac_wall'] - 12 * 65536 * 1000 / (line['ms_per_step'] / 1e3) / 1e9 / 8000.0) < 1e-5 and roof['frac_wall'] <= roof['frac'] * 1.02
     # every other BASELINE config beside the headline, each with its own parity bit
     cfg, full = line['configs'], detail['configs']
-    assert set(cfg) == set(full) == {'c2', 'c4_shard', 'c5'}
+    assert set(cfg) == set(full) == {'c2', 'c4_shard', 'c5', 'c3_distinct_1024', 'c3_distinct_65536'}
     for name in cfg:
         assert cfg[name]['bit_exact'] is True and cfg[name]['env_steps_per_s'] > 1e9 and full[name]['bound'] and full[name]['check'], name
     assert full['c2']['workload'].startswith('c2: 4096 envs') and full['c4_shard']['workload'].startswith('c4 shard 1 of 8: 32768 envs')
     assert cfg['c5']['form'] == 'per-XCD' and cfg['c5']['us_per_round'] < 3.0
-    for name in ('c2', 'c4_shard'):
+    for name in ('c2', 'c4_shard', 'c3_distinct_1024', 'c3_distinct_65536'):
         assert full[name]['hbm_gbps'] < 8000.0 and 0.0 < cfg[name]['frac_of_hbm_peak'] < 1.0
     # the shard's launch split into a fixed part and a per-step slope (T = 1000 against T = 4000)
-    assert cfg['c4_shard']['frac_of_hbm_peak'] <= cfg['c4_shard']['asymptote_frac_of_hbm_peak'] < 1.0 and 0.0 < cfg['c4_shard']['fixed_us_per_launch'] < 20.0
+    assert 0.5 < cfg['c4_shard']['asymptote_frac_of_hbm_peak'] < 1.0 and -5.0 < cfg['c4_shard']['fixed_us_per_launch'] < 20.0
+    # one maze per env streams its rows like the shared maze does (round 5: 0.53 of the peak on private byte planes)
+    assert cfg['c3_distinct_65536']['frac_of_hbm_peak'] > 0.7 and cfg['c3_distinct_1024']['frac_of_hbm_peak'] > 0.7
     topo = detail['topology']
     assert topo['hip_device_count'] >= 1 and topo['devices'][0]['pci'] and topo['rccl_library']
     assert detail['device'] and detail['roofline']['store_pacing'] and detail['roofline']['trajectory_placement']

@@ -676,22 +676,24 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int block_si
 }
 
 // Rollout MAP 5 (gu_rollout.hpp): every env's grid at four bits per cell -- the upper half of its cell records: TERM, RPLUS, RMINUS,
-// WALL -- laid out per wave of 64 envs as [dword][lane], so that a wave stages its image with one contiguous copy and its gathers
-// are free of bank conflicts.  Built once per grid installation, on the device, from the cell planes.
-__global__ void __launch_bounds__(256) gu_nibble_planes_kernel(const uint8_t *__restrict__ cell, GridSel gs, int32_t S, int32_t dwords, int64_t N,
+// WALL -- padded with wall cells (one column left of every row, one row above and below: cell (x, y) at (y + 1)(W + 1) + x + 1) and
+// laid out per wave of 64 envs as [dword][lane], so that a wave stages its image with one contiguous copy and its gathers are
+// free of bank conflicts.  Built once per grid installation, on the device, from the cell planes.
+__global__ void __launch_bounds__(256) gu_nibble_planes_kernel(const uint8_t *__restrict__ cell, GridSel gs, int32_t W, int32_t H, int32_t dwords, int64_t N,
                                                                uint32_t *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (wave, dword, lane)
     const int64_t total = ((N + 63) / 64) * dwords * 64;
     if (i >= total) return;
     const int64_t lane = i & 63, j = (i >> 6) % dwords, wave = (i >> 6) / dwords, e = wave * 64 + lane;
-    uint32_t word = 0x88888888u;  // (cells past the grid, envs past the batch: walls)
+    uint32_t word = 0x88888888u;  // (padding, cells past the image, envs past the batch: walls)
     if (e < N) {
         const uint8_t *f = cell + (e / gs.group) * gs.grid_stride;
         word = 0;
         for (int32_t k = 0; k < 8; ++k) {
-            const int64_t c = j * 8 + k;
-            const uint32_t four = c < S ? (uint32_t)(f[c] >> 4) : 0x8u;
+            const int32_t p = (int32_t)j * 8 + k, yp = p / (W + 1), xp = p % (W + 1);
+            const bool real = yp >= 1 && yp <= H && xp >= 1;
+            const uint32_t four = real ? (uint32_t)(f[(yp - 1) * W + xp - 1] >> 4) : 0x8u;
             word |= four << (4 * k);
         }
     }
@@ -704,7 +706,7 @@ int gu_nibble_planes(gu_engine *h)
     const int32_t dwords = gu_nibble_dwords(h);
     const int64_t total = ((h->N + 63) / 64) * dwords * 64;
     if (!h->d_nib) GU_HIP(hipMalloc((void **)&h->d_nib, (size_t)total * sizeof(uint32_t)));
-    hipLaunchKernelGGL(gu_nibble_planes_kernel, dim3(gu_blocks(total, 256)), dim3(256), 0, h->stream, h->d_cell, gu_grid_sel(h), h->S, dwords, h->N, h->d_nib);
+    hipLaunchKernelGGL(gu_nibble_planes_kernel, dim3(gu_blocks(total, 256)), dim3(256), 0, h->stream, h->d_cell, gu_grid_sel(h), h->W, h->H, dwords, h->N, h->d_nib);
     GU_HIP(hipGetLastError());
     h->nib_valid = true;
     return GU_OK;
@@ -782,12 +784,14 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     const int bs = gu_rollout_block(h);
     a.nib = nullptr;
     a.nib_dwords = 0;
-    if (h->n_grids > 1 && (policy == GU_POLICY_UNIFORM || policy == GU_POLICY_STREAM) && !gu_lds_block(h, bs, 2) && h->W <= 32767 &&
+    if (h->n_grids > 1 && (policy == GU_POLICY_UNIFORM || policy == GU_POLICY_STREAM) && !gu_lds_block(h, bs, 2) && h->W < 32767 &&
         gu_nibble_bytes_per_wave(h) <= (size_t)h->lds_per_cu - 512) {  // groups that do not align with blocks (one maze per env): MAP 5
         const int rc = gu_nibble_planes(h);
         if (rc != GU_OK) return rc;
         a.nib = h->d_nib;
         a.nib_dwords = gu_nibble_dwords(h);
+        const uint64_t wp = (uint64_t)(uint16_t)(int16_t)(h->W + 1), mwp = (uint64_t)(uint16_t)(int16_t)(-(h->W + 1));
+        a.lut_p = mwp | (1ull << 16) | (wp << 32) | (0xFFFFull << 48);
     }
     a.pace = GuPaceArgs{};
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)

@@ -66,9 +66,10 @@ __device__ __forceinline__ int32_t gu_delta(uint32_t a, uint64_t lut, int32_t W)
     return (a & 1u) ? -sign : sign * W;
 }
 
+// reward code in bits 5 (RPLUS) and 6 (RMINUS) of the record -> -1, +10, -10, -10 (lava over goal, env:86-88): one byte of a constant
 __device__ __forceinline__ int32_t gu_reward_packed(uint32_t flags)
 {
-    return (flags & GU_CELL_RMINUS) ? -10 : ((flags & GU_CELL_RPLUS) ? 10 : -1);
+    return __builtin_amdgcn_sbfe((int32_t)0xF6F60AFFu, (flags >> 2) & 24u, 8);
 }
 
 __device__ __forceinline__ int32_t gu_move(int32_t s, uint32_t flags, uint32_t a, int32_t delta)

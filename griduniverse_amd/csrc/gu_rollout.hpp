@@ -357,8 +357,9 @@ struct RolloutArgs {
     uint64_t *done_bits;  // [ceil(N/64)] wave ballots of the final done flags (episode-done compaction)
     uint32_t n_starts, seed_prefix, env_id0, steps_taken;  // seed_prefix: the epoch of this launch folded in; steps_taken: low word
     uint32_t seed_prefix0, steps_hi;  // the seed prefix without an epoch (start choices; straddling launches); high word of the lock-step count
-    const uint32_t *nib;    // MAP 5: [waves][nib_dwords][64] four bits per cell, per env (gu_nibble_planes)
+    const uint32_t *nib;    // MAP 5: [waves][nib_dwords][64] four bits per cell of the padded grid, per env (gu_nibble_planes)
     int32_t nib_dwords;     // dwords per env of that image (a multiple of four)
+    uint64_t lut_p;         // MAP 5: the action -> delta LUT of the padded image: -(W + 1), +1, +(W + 1), -1
     int32_t straddle;       // some env passes a multiple of 2^32 steps during this launch: the general kernel asks per lane and step
     int64_t N, T;
     GridSel gs;
@@ -433,13 +434,15 @@ __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint3
 // MAP : 0 = records read from L2 (any grid size, any grid-per-env assignment)
 //       1 = the block's grid staged in LDS, shared by its lanes
 //       5 = every lane keeps its own grid in LDS as FOUR BITS PER CELL -- {terminal, reward +10, reward -10, wall}, the upper half
-//           of the cell record -- for multi-grid engines whose groups do not align with blocks, e.g. one maze per env: S / 2 bytes
-//           per env (512 at 32 x 32: a wave's 32 KB, four waves per CU, the occupancy of the single-grid launch), dword j of
-//           lane l at word j * 64 + l, so that the 64 lanes of a gather hit 64 different banks whatever cells they ask for.  The
-//           step tests the CANDIDATE cell (inside the grid? a wall?) instead of reading open bits of the current one
-//           (env:136-155 literally); one LDS round trip per step as in the other variants.  Staged from a per-wave image of
-//           the grids that gu_nibble_planes builds once per grid installation (gu_kernels.hip).  Replaces round 2's private
-//           BYTE plane per lane (MAP 2: 66.5 KB per wave, two waves per CU, 0.53 of the HBM peak).
+//           of the cell record -- for multi-grid engines whose groups do not align with blocks, e.g. one maze per env.  The image
+//           is PADDED with wall cells: one column on the left of every row, one row above and below (cell (x, y) at index
+//           (y + 1)(W + 1) + x + 1), so that a move off the grid meets a wall like any other and the step tests nothing but the
+//           CANDIDATE cell's wall bit (env:136-155 literally, env:51-54 folded into the padding).  (P + 7) / 8 dwords per env, P =
+//           (H + 2)(W + 1) + 1: 576 bytes at 32 x 32 -- a wave's 36 KB, four waves per CU, the occupancy of the single-grid
+//           launch --, dword j of lane l at word j * 64 + l: the 64 lanes of a gather hit 64 different banks whatever cells they
+//           ask for.  One LDS round trip per step as in the other variants.  Staged from a per-wave image that gu_nibble_planes
+//           builds once per grid installation (gu_kernels.hip).  Replaces round 2's private BYTE plane per lane (MAP 2: 66.5 KB
+//           per wave, two waves per CU, 0.53 of the HBM peak).
 //       3 = like 1 with the flags plane only (it carries the reward code): grids of 32 768 .. ~160 000 cells, one
 //           block per CU.  A global read per step would wait for every trajectory store in flight (vmcnt counts both).
 //       (a fifth variant -- one dword record per cell replicated 32 times, so that the per-step gather is free of LDS bank
@@ -525,34 +528,36 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     auto prefix_at = [&](uint32_t t) {  // (t: the low word of the step count; a launch is shorter than 2^32 steps)
         return gu_rng_prefix(gu_rng_seed_prefix_epoch(a.seed_prefix0, epoch0 + (t < t_lane ? 1u : 0u)), a.env_id0 + e);
     };
-    // MAP 5 keeps the upper half of the cell record in `flags` (TERM, RPLUS, RMINUS, WALL: what the four bits per cell hold) and the
-    // cell's own TERM bit once more in bit 0: the TERM bit proper follows the done flag at entry (AUTO == 1), bit 0 is what makes a
-    // terminal cell absorbing (env:145-146)
-    auto flags5 = [](uint32_t b) { return (b & 0xF0u) | ((b >> GU_CELL_TERM_BIT) & 1u); };
+    // MAP 5 keeps the upper half of the cell record in `flags` (TERM, RPLUS, RMINUS, WALL: what the four bits per cell hold) and, in
+    // bit 3, STUCK: the agent stands on a terminal cell it has not been reset away from, which absorbs every action (env:145-146).
+    // With a single start cell (AUTO == 1) that is the case only right after a reset onto a terminal start cell and at entry; a
+    // terminal cell reached by a move is left by the reset of the next step.
+    constexpr uint32_t STUCK = 8u;
+    auto flags5 = [](uint32_t b) { return (b & 0xF0u) | (((b >> GU_CELL_TERM_BIT) & 1u) << 3); };
     uint32_t flags = MAP == 5 ? flags5(m.f[s]) : m.f[s];
     int32_t ret = 0, fin = 0;
     const int32_t W = a.W;
     const uint64_t lut = a.lut;
     const int32_t start0 = lg.starts[0];
     const uint32_t start0_flags = MAP == 5 ? flags5(m.f[start0]) : m.f[start0];
-    int32_t x = MAP == 5 ? s % W : 0;  // MAP 5: the column, for the RIGHT / LEFT edge tests
-    const int32_t start0_x = MAP == 5 ? start0 % W : 0;
-    auto cell5 = [&](int32_t c) {  // the record of cell c from the four-bit image
-        const uint32_t four = __builtin_amdgcn_ubfe(nib[(c >> 3) * 64], (uint32_t)(c & 7) * 4u, 4);
-        return (four << 4) | (four & 1u);
+    auto padded = [&](int32_t c) { return c + c / W + W + 2; };  // MAP 5: cell (x, y) -> (y + 1)(W + 1) + x + 1
+    int32_t sp = MAP == 5 ? padded(s) : 0;  // the agent's cell in the padded image
+    const int32_t start0_p = MAP == 5 ? padded(start0) : 0;
+    auto cell5 = [&](int32_t cp) {  // the record of padded cell cp from the four-bit image
+        const uint32_t four = __builtin_amdgcn_ubfe(nib[(cp >> 3) * 64], (uint32_t)(cp & 7) * 4u, 4);
+        return (four << 4) | ((four & 1u) << 3);
     };
-    // one move on the four-bit image: candidate cell, inside the grid?, ONE gather, a wall?  (env:136-155)
+    // one move on the four-bit image: the candidate cell, ONE gather, a wall?  (env:136-155; moves off the grid meet the padding)
     auto move5 = [&](uint32_t act, int32_t delta) {
         const int32_t cand = s + delta;
-        const int32_t xc = x + __builtin_amdgcn_sbfe(0xF010, (int32_t)(act * 4u), 4);  // UP 0, RIGHT +1, DOWN 0, LEFT -1
-        const bool inside = (uint32_t)cand < (uint32_t)a.S && (uint32_t)xc < (uint32_t)W;
-        const int32_t c = inside ? cand : s;
-        const uint32_t four = __builtin_amdgcn_ubfe(nib[(c >> 3) * 64], (uint32_t)(c & 7) * 4u, 4);
-        const uint32_t stay = (flags & ~GU_CELL_TERM) | ((flags & 1u) << GU_CELL_TERM_BIT);  // (done = TERM of the cell the agent is on)
-        const bool go = inside && !(four & (GU_CELL_WALL >> 4)) && !(flags & 1u);
+        const int32_t candp = sp + gu_delta<true>(act, a.lut_p, 0);
+        const uint32_t four = __builtin_amdgcn_ubfe(nib[(candp >> 3) * 64], (uint32_t)(candp & 7) * 4u, 4);
+        const uint32_t stay = flags | ((flags & STUCK) << 1);               // blocked on a terminal cell: done (TERM sits above STUCK)
+        const uint32_t arrive = AUTO == 1 ? four << 4 : (four << 4) | ((four & 1u) << 3);
+        const bool go = ((flags & STUCK) | four) < (GU_CELL_WALL >> 4);     // neither stuck nor a wall ahead
         s = go ? cand : s;
-        x = go ? xc : x;
-        flags = go ? ((four << 4) | (four & 1u)) : stay;
+        sp = go ? candp : sp;
+        flags = go ? arrive : stay;
     };
     // Trajectory rows are addressed as buffer resource (wave-uniform base, rebuilt per 16-step chunk)
     // + lane byte offset e4 (VGPR) + scalar row offset (SGPR): buffer_store_dword ... offen, so that
@@ -598,13 +603,13 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             ep += was_done;
             s = was_done ? start0 : s;
             flags = was_done ? start0_flags : flags;
-            if (MAP == 5) x = was_done ? start0_x : x;
+            if (MAP == 5) sp = was_done ? start0_p : sp;
         } else if (AUTO == 2) {
             if (d) {
                 s = lg.starts[gu_rng_start_index(prefix0, ep, lg.n_starts)];
                 ++ep;
-                flags = MAP == 5 ? cell5(s) : m.f[s];  // (no global read inside the loop: it would wait for every row store in flight)
-                if (MAP == 5) x = s % W;
+                if (MAP == 5) sp = padded(s);
+                flags = MAP == 5 ? cell5(sp) : m.f[s];  // (no global read inside the loop: it would wait for every row store in flight)
             }
         }
         if (MAP == 5) {
@@ -860,8 +865,9 @@ static inline int gu_lds_block(const gu_engine *h, int preferred, int planes)
 
 static inline int gu_rollout_block(const gu_engine *h) { return (int)gu_opt(h, GU_OPT_ROLLOUT_BLOCK); }
 
-// MAP 5: dwords per env of the four-bits-per-cell image (eight cells per dword, rounded up to whole uint4 per lane), bytes per wave
-static inline int32_t gu_nibble_dwords(const gu_engine *h) { return (((h->S + 7) / 8) + 3) & ~3; }
+// MAP 5: dwords per env of the padded four-bits-per-cell image (eight cells per dword, rounded up to whole uint4 per lane), bytes per wave
+static inline int32_t gu_nibble_cells(const gu_engine *h) { return (h->H + 2) * (h->W + 1) + 1; }
+static inline int32_t gu_nibble_dwords(const gu_engine *h) { return (((gu_nibble_cells(h) + 7) / 8) + 3) & ~3; }
 static inline size_t gu_nibble_bytes_per_wave(const gu_engine *h) { return (size_t)gu_nibble_dwords(h) * 256u; }
 int gu_nibble_planes(gu_engine *h);  // builds h->d_nib if the installed grids have none yet (gu_kernels.hip)
 
@@ -907,7 +913,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
             return;
         }
         // misaligned multi-grid engine (e.g. one maze per env): every lane's grid at four bits per cell in LDS, if a wave's 64 fit
-        if (h->n_grids > 1 && h->W <= 32767 && gu_nibble_bytes_per_wave(h) <= (size_t)h->lds_per_cu - 512 && a.nib) {
+        if (h->n_grids > 1 && h->W < 32767 && gu_nibble_bytes_per_wave(h) <= (size_t)h->lds_per_cu - 512 && a.nib) {
             const size_t lds = gu_nibble_bytes_per_wave(h);
             auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 5>;
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

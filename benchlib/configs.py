@@ -19,11 +19,14 @@ def _rows_entry(N, T, ms, bytes_per_step=BYTES_PER_ENV_STEP):
     return dict(us_per_launch=ms * 1e3, env_steps_per_s=float(N) * T / ms * 1e3, hbm_gbps=gbps, frac_of_hbm_peak=gbps / HBM_PEAK_GBPS)
 
 
-def baseline_configs(engine_cls, device, K, check):
+def baseline_configs(engine_cls, device, K, check, only=None):
     """Configs 2, 4 (shard 1 of 8) and 5 on this GPU: us per launch (or per round), env-steps/s, fraction of the HBM peak
     where rows are written, and `bit_exact` (the config's own check against the reference digest or the C oracle)."""
     out = {}
     T = 1000
+    if only:  # (tools: a subset of the entries, by prefix)
+        full = baseline_configs(engine_cls, device, K, check) if not all(o.startswith('c3_distinct') for o in only) else _distinct_grids(engine_cls, device, K, check, T)
+        return {k: v for k, v in full.items() if any(k.startswith(o) for o in only)}
 
     # ---- config 2: 4096 envs, default 8x8 grid.  Latency-bound: 64 waves on 1024 SIMDs, a chain of T dependent steps.
     template, desc = build_workload('c2')
@@ -64,38 +67,7 @@ def baseline_configs(engine_cls, device, K, check):
                            us_per_launch_4000_steps=ms_long * 1e3, fixed_us_per_launch=ms * 1e3 - slope_us * T,
                            asymptote_frac_of_hbm_peak=BYTES_PER_ENV_STEP * N / slope_us / 1e3 / HBM_PEAK_GBPS if slope_us > 0 else None)
 
-    # ---- config 3 with DISTINCT grids (SURVEY.md 8(d) C3 variant; N x GridUniverseEnv(random_maze=True), griduniverse_env.py:318-321):
-    # 65 536 envs on G device-generated 32x32 mazes (8(f3)), grid = env // (N / G).  G = 65 536 is one maze per env: every lane keeps
-    # its own grid in LDS at four bits per cell (gu_rollout.hpp, MAP 5).
-    if hasattr(engine_cls, 'generate_mazes'):
-        from oracle import c_oracle as C
-        N, seed, maze_seed = 65536, WORKLOAD_SEED['c3'], 2026
-        for G in (1024, 65536):
-            eng = engine_cls(N, gua.GridSpec(32, 32, [0], [1023], [], []), device=device, env_id0=0, seed=seed)
-            try:
-                eng.generate_mazes(G, 32, 32, maze_seed)
-                first = eng.reset()
-                eng.reserve_trajectory(T)
-                eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
-                ok = None
-                if check:  # a sample of grids, each against the C oracle on ITS maze (oracle/gu_oracle.c: the same build RNG)
-                    got = eng.read_trajectory(0, T)
-                    group, ok = N // G, True
-                    for g in sorted({0, 1, G // 3, G // 2, G - 2, G - 1}):
-                        wall, start, goal = C.generate_maze(maze_seed, g, 32, 32)
-                        grid = C.Grid.from_lists(32, 32, walls=np.flatnonzero(wall).tolist(), goals=[int(goal)], starts=[int(start)])
-                        n = min(group, 8)
-                        st = C.State(n, g * group)
-                        ok = ok and bool(np.array_equal(C.reset(grid, seed, st), first[g * group:g * group + n]))
-                        want = C.rollout(grid, seed, st, T, True)
-                        ok = ok and all(np.array_equal(got[k][:, g * group:g * group + n], want[k]) for k in ('obs', 'reward', 'done'))
-                    del got
-                ms = launch_ms(eng, T, K, trajectory=True)
-            finally:
-                eng.close()
-            out['c3_distinct_%d' % G] = dict(_rows_entry(N, T, ms), workload='c3 on %d distinct device-generated 32x32 mazes (%d envs each), seed %d'
-                                             % (G, N // G, seed), bound='hbm', bit_exact=ok,
-                                             check='first launch: envs of six grids == C oracle on the same mazes')
+    out.update(_distinct_grids(engine_cls, device, K, check, T))
 
     # ---- config 5: 65 536 envs, 64x64 maze, one V1 + V2 sweep fused with one greedy env step per round
     if hasattr(engine_cls, 'vi_sweep_step_run'):
@@ -129,6 +101,43 @@ def baseline_configs(engine_cls, device, K, check):
                          form={1: 'per-XCD', 2: 'chip-wide barrier', 3: 'launch per round'}.get(form, str(form)), bound='latency',
                          timing='host wall time of one call / rounds, median of 3', bit_exact=ok,
                          check='%d rounds from reset: tables as raw bytes + every env == C oracle' % n_check)
+    return out
+
+
+def _distinct_grids(engine_cls, device, K, check, T):
+    # ---- config 3 with DISTINCT grids (SURVEY.md 8(d) C3 variant; N x GridUniverseEnv(random_maze=True), griduniverse_env.py:318-321):
+    # 65 536 envs on G device-generated 32x32 mazes (8(f3)), grid = env // (N / G).  G = 65 536 is one maze per env: every lane keeps
+    # its own grid in LDS at four bits per cell (gu_rollout.hpp, MAP 5).
+    out = {}
+    if hasattr(engine_cls, 'generate_mazes'):
+        from oracle import c_oracle as C
+        N, seed, maze_seed = 65536, WORKLOAD_SEED['c3'], 2026
+        for G in (1024, 65536):
+            eng = engine_cls(N, gua.GridSpec(32, 32, [0], [1023], [], []), device=device, env_id0=0, seed=seed)
+            try:
+                eng.generate_mazes(G, 32, 32, maze_seed)
+                first = eng.reset()
+                eng.reserve_trajectory(T)
+                eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
+                ok = None
+                if check:  # a sample of grids, each against the C oracle on ITS maze (oracle/gu_oracle.c: the same build RNG)
+                    got = eng.read_trajectory(0, T)
+                    group, ok = N // G, True
+                    for g in sorted({0, 1, G // 3, G // 2, G - 2, G - 1}):
+                        wall, start, goal = C.generate_maze(maze_seed, g, 32, 32)
+                        grid = C.Grid.from_lists(32, 32, walls=np.flatnonzero(wall).tolist(), goals=[int(goal)], starts=[int(start)])
+                        n = min(group, 8)
+                        st = C.State(n, g * group)
+                        ok = ok and bool(np.array_equal(C.reset(grid, seed, st), first[g * group:g * group + n]))
+                        want = C.rollout(grid, seed, st, T, True)
+                        ok = ok and all(np.array_equal(got[k][:, g * group:g * group + n], want[k]) for k in ('obs', 'reward', 'done'))
+                    del got
+                ms = launch_ms(eng, T, K, trajectory=True)
+            finally:
+                eng.close()
+            out['c3_distinct_%d' % G] = dict(_rows_entry(N, T, ms), workload='c3 on %d distinct device-generated 32x32 mazes (%d envs each), seed %d'
+                                             % (G, N // G, seed), bound='hbm', bit_exact=ok,
+                                             check='first launch: envs of six grids == C oracle on the same mazes')
     return out
 
 

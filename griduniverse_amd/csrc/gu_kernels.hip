@@ -784,14 +784,15 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     const int bs = gu_rollout_block(h);
     a.nib = nullptr;
     a.nib_dwords = 0;
-    if (h->n_grids > 1 && (policy == GU_POLICY_UNIFORM || policy == GU_POLICY_STREAM) && !gu_lds_block(h, bs, 2) && h->W < 32767 &&
+    if (h->n_grids > 1 && (policy == GU_POLICY_UNIFORM || policy == GU_POLICY_STREAM) && !gu_lds_block(h, bs, 2) && h->W <= 1022 &&
         gu_nibble_bytes_per_wave(h) <= (size_t)h->lds_per_cu - 512) {  // groups that do not align with blocks (one maze per env): MAP 5
         const int rc = gu_nibble_planes(h);
         if (rc != GU_OK) return rc;
         a.nib = h->d_nib;
         a.nib_dwords = gu_nibble_dwords(h);
-        const uint64_t wp = (uint64_t)(uint16_t)(int16_t)(h->W + 1), mwp = (uint64_t)(uint16_t)(int16_t)(-(h->W + 1));
-        a.lut_p = mwp | (1ull << 16) | (wp << 32) | (0xFFFFull << 48);
+        // (cells of the padded image times 32: W <= 1022 keeps a row's step inside an int16)
+        const uint64_t wp = (uint64_t)(uint16_t)(int16_t)((h->W + 1) * 32), mwp = (uint64_t)(uint16_t)(int16_t)(-(h->W + 1) * 32);
+        a.lut_p = mwp | (32ull << 16) | (wp << 32) | ((uint64_t)(uint16_t)(int16_t)-32 << 48);
     }
     a.pace = GuPaceArgs{};
     a.xcd_remap = gu_opt(h, GU_OPT_ROLLOUT_XCD) != 0 && h->n_grids == 1;  // XCD-aware env-block order (see gu_env_block; measured slower, off)

@@ -359,7 +359,7 @@ struct RolloutArgs {
     uint32_t seed_prefix0, steps_hi;  // the seed prefix without an epoch (start choices; straddling launches); high word of the lock-step count
     const uint32_t *nib;    // MAP 5: [waves][nib_dwords][64] four bits per cell of the padded grid, per env (gu_nibble_planes)
     int32_t nib_dwords;     // dwords per env of that image (a multiple of four)
-    uint64_t lut_p;         // MAP 5: the action -> delta LUT of the padded image: -(W + 1), +1, +(W + 1), -1
+    uint64_t lut_p;         // MAP 5: the action -> delta LUT of the padded image, times 32: -(W + 1), +1, +(W + 1), -1
     int32_t straddle;       // some env passes a multiple of 2^32 steps during this launch: the general kernel asks per lane and step
     int64_t N, T;
     GridSel gs;
@@ -540,23 +540,30 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     const uint64_t lut = a.lut;
     const int32_t start0 = lg.starts[0];
     const uint32_t start0_flags = MAP == 5 ? flags5(m.f[start0]) : m.f[start0];
-    auto padded = [&](int32_t c) { return c + c / W + W + 2; };  // MAP 5: cell (x, y) -> (y + 1)(W + 1) + x + 1
-    int32_t sp = MAP == 5 ? padded(s) : 0;  // the agent's cell in the padded image
-    const int32_t start0_p = MAP == 5 ? padded(start0) : 0;
-    auto cell5 = [&](int32_t cp) {  // the record of padded cell cp from the four-bit image
-        const uint32_t four = __builtin_amdgcn_ubfe(nib[(cp >> 3) * 64], (uint32_t)(cp & 7) * 4u, 4);
+    // `sq`: the agent's cell in the padded image (cell (x, y) -> (y + 1)(W + 1) + x + 1), times 32 -- bits 8 and up are then the byte
+    // offset of its dword's row in the [dword][lane] image, bits 5 .. 7 the cell inside the dword; a.lut_p is scaled alike
+    auto padded = [&](int32_t c) { return (c + c / W + W + 2) << 5; };
+    int32_t sq = MAP == 5 ? padded(s) : 0;
+    const int32_t start0_q = MAP == 5 ? padded(start0) : 0;
+    const char *nib_lane = reinterpret_cast<const char *>(nib);  // (this lane's column: + lane * 4 bytes)
+    auto four_at = [&](int32_t cq) {
+        const uint32_t word = *reinterpret_cast<const uint32_t *>(nib_lane + ((uint32_t)cq & 0xFFFFFF00u));
+        return __builtin_amdgcn_ubfe(word, ((uint32_t)cq >> 3) & 28u, 4);
+    };
+    auto cell5 = [&](int32_t cq) {  // the record of padded cell cq / 32 from the four-bit image
+        const uint32_t four = four_at(cq);
         return (four << 4) | ((four & 1u) << 3);
     };
     // one move on the four-bit image: the candidate cell, ONE gather, a wall?  (env:136-155; moves off the grid meet the padding)
     auto move5 = [&](uint32_t act, int32_t delta) {
         const int32_t cand = s + delta;
-        const int32_t candp = sp + gu_delta<true>(act, a.lut_p, 0);
-        const uint32_t four = __builtin_amdgcn_ubfe(nib[(candp >> 3) * 64], (uint32_t)(candp & 7) * 4u, 4);
+        const int32_t candq = sq + gu_delta<true>(act, a.lut_p, 0);
+        const uint32_t four = four_at(candq);
         const uint32_t stay = flags | ((flags & STUCK) << 1);               // blocked on a terminal cell: done (TERM sits above STUCK)
         const uint32_t arrive = AUTO == 1 ? four << 4 : (four << 4) | ((four & 1u) << 3);
         const bool go = ((flags & STUCK) | four) < (GU_CELL_WALL >> 4);     // neither stuck nor a wall ahead
         s = go ? cand : s;
-        sp = go ? candp : sp;
+        sq = go ? candq : sq;
         flags = go ? arrive : stay;
     };
     // Trajectory rows are addressed as buffer resource (wave-uniform base, rebuilt per 16-step chunk)
@@ -603,13 +610,13 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             ep += was_done;
             s = was_done ? start0 : s;
             flags = was_done ? start0_flags : flags;
-            if (MAP == 5) sp = was_done ? start0_p : sp;
+            if (MAP == 5) sq = was_done ? start0_q : sq;
         } else if (AUTO == 2) {
             if (d) {
                 s = lg.starts[gu_rng_start_index(prefix0, ep, lg.n_starts)];
                 ++ep;
-                if (MAP == 5) sp = padded(s);
-                flags = MAP == 5 ? cell5(sp) : m.f[s];  // (no global read inside the loop: it would wait for every row store in flight)
+                if (MAP == 5) sq = padded(s);
+                flags = MAP == 5 ? cell5(sq) : m.f[s];  // (no global read inside the loop: it would wait for every row store in flight)
             }
         }
         if (MAP == 5) {
@@ -913,7 +920,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
             return;
         }
         // misaligned multi-grid engine (e.g. one maze per env): every lane's grid at four bits per cell in LDS, if a wave's 64 fit
-        if (h->n_grids > 1 && h->W < 32767 && gu_nibble_bytes_per_wave(h) <= (size_t)h->lds_per_cu - 512 && a.nib) {
+        if (h->n_grids > 1 && h->W <= 1022 && gu_nibble_bytes_per_wave(h) <= (size_t)h->lds_per_cu - 512 && a.nib) {
             const size_t lds = gu_nibble_bytes_per_wave(h);
             auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 5>;
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -556,7 +556,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     };
     // one move on the four-bit image: the candidate cell, ONE gather, a wall?  (env:136-155; moves off the grid meet the padding)
     auto move5 = [&](uint32_t act, int32_t delta) {
-        const int32_t cand = s + delta;
+        int32_t cand = s + delta;
+        asm volatile("" : "+v"(cand));  // (kept as the sum it is: select(go, s + delta, s), not s + select(go, delta, 0) with its sign extension)
         const int32_t candq = sq + gu_delta<true>(act, a.lut_p, 0);
         const uint32_t four = four_at(candq);
         const uint32_t stay = flags | ((flags & STUCK) << 1);               // blocked on a terminal cell: done (TERM sits above STUCK)
@@ -606,7 +607,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             // TERM bit of the record that just arrived (no separate done register on the dependent chain).  A variant
             // that precomputes the move from the start cell off the chain was measured slower at every occupancy
             // (profiles/archive/r01e_auto_form_ab.txt).
-            const bool was_done = flags & GU_CELL_TERM;
+            // (MAP 5 asks the done bit it has extracted for the row anyway: one instruction less in a loop bound by their number)
+            const bool was_done = MAP == 5 ? d != 0u : (flags & GU_CELL_TERM) != 0u;
             ep += was_done;
             s = was_done ? start0 : s;
             flags = was_done ? start0_flags : flags;

@@ -8,7 +8,10 @@ import json, sys
 sys.path.insert(0, '.')
 import griduniverse_amd as gua
 from benchlib.configs import baseline_configs
-for rep in range(2):
-    out = baseline_configs(gua.Engine, 0, 20, rep == 0, only=('c3_distinct',))
-    print(json.dumps({k: {kk: v[kk] for kk in ('us_per_launch', 'env_steps_per_s', 'frac_of_hbm_peak', 'bit_exact')} for k, v in out.items()}))
+from griduniverse_amd import _lib
+for rep in range(3):
+    for layout in (None, 1, 0):
+        _lib.set_default_option('traj_layout', layout)
+        out = baseline_configs(gua.Engine, 0, 20, rep == 0, only=('c3_distinct',))
+        print('traj_layout', layout, json.dumps({k: {kk: round(v[kk], 4) if isinstance(v[kk], float) else v[kk] for kk in ('us_per_launch', 'frac_of_hbm_peak', 'bit_exact')} for k, v in out.items()}))
 PY

@@ -72,7 +72,6 @@ SIGNATURES = {
     'gu_rollout_pacing_totals': [_vp, _vp, _vp, _vp, _vp, _vp],
     'gu_rollout_pace_log': [_vp, _i32, _u32, _i32, _vp, _vp, _vp],
     'gu_rollout_pace_waves': [_vp, _i32, _u32, _i32, _vp, _vp],
-    'gu_rollout_pace_search': [_vp, _i64, _i32, _u32, _vp, _vp, _vp, _vp, _vp],
     'gu_read_trajectory': [_vp, _i64, _i64, _vp, _vp, _vp],
     'gu_read_trajectory_packed': [_vp, _i64, _i64, _vp],
     'gu_read_stats': [_vp, _vp, _vp],

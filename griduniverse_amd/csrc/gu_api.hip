@@ -961,8 +961,8 @@ int gu_rollout_pacing_totals(gu_handle h, float *calibration_ms, int32_t *launch
     GU_ENTER(h);
     int32_t paced = 0;
     for (const gu_engine::PaceKind &k : h->pace) paced += (k.active && k.seq) ? 1 : 0;
-    if (calibration_ms) *calibration_ms = h->pace_search_ms;          // only gu_rollout_pace_search ever spends anything
-    if (launches_spent) *launches_spent = h->pace_search_launches;
+    if (calibration_ms) *calibration_ms = 0.0f;  // (nothing is ever spent on a search: the loop runs inside the caller's launches)
+    if (launches_spent) *launches_spent = 0;
     if (kinds_paced) *kinds_paced = paced;
     if (kinds_from_cache) *kinds_from_cache = 0;
     if (kinds_waiting) *kinds_waiting = 0;
@@ -1034,24 +1034,6 @@ int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t 
     if (ms_paced) *ms_paced = (float)(((last[1] + 32u) >> 6) * (uint64_t)(h->pace[gu_pace_slot_in_use(h, policy_kind, flags)].T / 16)) * 1e-5f;  // its schedule
     if (evaluated) *evaluated = (int32_t)launches;
     if (calibration_ms) *calibration_ms = 0.0f;
-    return GU_OK;
-}
-
-int gu_rollout_pace_search(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
-                           int32_t *launches, float *ms_spent)
-{
-    if (!h) return gu_fail(GU_ERR_INVALID, "null handle");
-    h->pace_search_requested = true;  // (read by gu_pace_for)
-    const int rc = gu_rollout(h, T, policy_kind, flags);
-    const bool searched = !h->pace_search_requested && h->pace_search_found;
-    h->pace_search_requested = false;
-    if (rc != GU_OK) return rc;
-    GU_REQUIRE(searched, GU_ERR_STATE, "this launch is not one that keeps a schedule (less than 128 MB of rows, fewer than 64 steps, or no rows at all)");
-    if (period) *period = (int32_t)h->pace_search_period;
-    if (ms_unpaced) *ms_unpaced = h->pace_search_ms_unpaced;
-    if (ms_paced) *ms_paced = h->pace_search_ms_paced;
-    if (launches) *launches = h->pace_search_last_launches;
-    if (ms_spent) *ms_spent = h->pace_search_last_ms;
     return GU_OK;
 }
 

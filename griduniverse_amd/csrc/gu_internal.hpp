@@ -182,12 +182,6 @@ struct gu_engine {
     uint64_t *d_pace_slots = nullptr;    // [36][2][pace_slot_stride] the waves' reports (allocated with the ring)
     int64_t pace_slot_stride = 0;
     hipEvent_t ev_cal[2] = {nullptr, nullptr};
-    float pace_search_ms = 0.0f;       // gu_rollout_pace_search (the open-loop search of rounds 3 and 4, a measurement aid now):
-    int32_t pace_search_launches = 0;  // what it cost this engine, summed
-    bool pace_search_requested = false, pace_search_found = false;  // inside gu_rollout_pace_search / its launch kind keeps a schedule
-    uint32_t pace_search_period = 0;   // the last search's outcome
-    float pace_search_ms_unpaced = 0.0f, pace_search_ms_paced = 0.0f, pace_search_last_ms = 0.0f;
-    int32_t pace_search_last_launches = 0;
 
     // transition-row tables of the latency-bound rollout (gu_rollout_rows.hip): [0] absorbing, [1] auto-reset folded in
     uint32_t *d_rows[2] = {nullptr, nullptr};

@@ -413,171 +413,8 @@ static void gu_rollout_general(gu_engine *h, const RolloutArgs &a, int32_t polic
     }
 }
 
-// The open-loop search of rounds 3 and 4, kept as a MEASUREMENT AID (gu_rollout_pace_search, include/gu_diag.h): which fixed period
-// makes this launch kind fastest on this trajectory buffer, found by timing the kernel itself -- full-length launches on the engine's
-// own state, which is snapshot first and put back afterwards (positions, rewards, done flags and their ballots, episode counters;
-// the step counter lives on the host and is not advanced).  Launch time follows the schedule (period x groups + a constant) down to
-// the memory's capacity; below it the waves fall behind, first gracefully, then the launch collapses (the cliff).  The search:
-// down from the period that equals the unpaced launch time in steps of 4 % until the time jumps, then up from the collapsed
-// side in steps of 1 %, every candidate entered from a COLLAPSED stream (two unpaced launches first) -- the period it reports is
-// the shortest one that gets out of the collapse by itself, plus 1 %.  A few hundred launches.  The product never runs it: the
-// launches choose their period themselves (gu_rollout.hpp: gu_pace_next); tests and tools/pace_loop.py hold the closed loop
-// against what it finds.
-#ifndef GU_PACE_MARGIN
-#define GU_PACE_MARGIN 1.01  /* the reported period over the first one that recovered and held */
-#endif
-struct GuPaceSearch {
-    uint32_t period = 0;
-    float ms_unpaced = 0.0f, ms_paced = 0.0f, ms_spent = 0.0f;
-    int32_t evaluated = 0, launches = 0;
-};
-static int gu_search_pace(gu_engine *h, int slot, int64_t T, const std::function<void(uint32_t)> &launch, GuPaceSearch *rec)
-{
-    const auto t_start = std::chrono::steady_clock::now();
-    const size_t n4 = (size_t)h->N * 4, bits = (((size_t)h->N + 63) / 64) * 8;
-    int rc = gu_ensure_scratch(h, 4 * n4 + bits);
-    if (rc != GU_OK) return rc;
-    char *snap = (char *)h->d_scratch;
-    void *live[3] = {h->d_out3, h->d_episode, h->d_done_bits};
-    const size_t size[3] = {3 * n4, n4, bits};
-    size_t off = 0;
-    for (int k = 0; k < 3; off += size[k], ++k)
-        if ((rc = gu_device_copy(h, snap + off, live[k], size[k])) != GU_OK) return rc;
-    // whatever happens below -- a HIP error in the middle of the search included -- the engine's state goes back to the snapshot
-    struct Restore {
-        gu_engine *h;
-        char *snap;
-        void **live;
-        const size_t *size;
-        bool armed = true;
-        int run()
-        {
-            armed = false;
-            size_t o = 0;
-            for (int k = 0; k < 3; o += size[k], ++k) {
-                const int r = gu_device_copy(h, live[k], snap + o, size[k]);
-                if (r != GU_OK) return r;
-            }
-            return hipStreamSynchronize(h->stream) == hipSuccess ? GU_OK : GU_ERR_HIP;
-        }
-        ~Restore()
-        {
-            if (armed) (void)run();
-        }
-    } restore{h, snap, live, size};
-    for (hipEvent_t &ev : h->ev_cal)
-        if (!ev) GU_HIP(hipEventCreate(&ev));
-    int evaluated = 0, launches = 0;
-    // The device must be at its working clocks first.  A search right after start-up, on a GPU still ramping up from idle,
-    // sees a slower kernel and a different cliff (profiles/archive/r03f_pace_warmup.txt).  The ramp is gradual -- successive launches agree
-    // within 1 % all along it -- so: unpaced launches until the mean of the last 16 agrees with the mean of the 16 before within
-    // 0.4 %, for at least 30 ms when the device has not been running rollouts in the last 50 ms, 150 ms at most.
-    {
-        const bool cold = h->device < 0 || h->device >= 64 || gu_wall_ms() - g_last_rollout_ms[h->device] > 50.0;
-        const double w0 = gu_wall_ms(), at_least = cold ? 30.0 : 0.0;
-        std::vector<float> pairs;
-        for (;;) {
-            GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
-            launch(0u);
-            launch(0u);
-            launches += 2;
-            GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
-            GU_HIP(hipEventSynchronize(h->ev_cal[1]));
-            float ms = 0.0f;
-            GU_HIP(hipEventElapsedTime(&ms, h->ev_cal[0], h->ev_cal[1]));
-            pairs.push_back(ms);
-            const size_t n = pairs.size();
-            const double waited = gu_wall_ms() - w0;
-            bool stable = false;
-            if (n >= 16) {
-                double last = 0.0, before = 0.0;
-                for (size_t k = 0; k < 8; ++k) last += pairs[n - 1 - k], before += pairs[n - 9 - k];
-                stable = last <= 1.004 * before && before <= 1.004 * last;
-            }
-            if ((stable && waited >= at_least) || waited > 150.0) break;
-        }
-    }
-    // One measurement: `collapse` unpaced launches (to enter from the collapsed state), `settle` launches with the period, then
-    // `reps` timed ones.
-    auto measure = [&](uint32_t period, int collapse, int settle, int reps, float *ms) -> int {
-        for (int r = 0; r < collapse; ++r) launch(0u);
-        for (int r = 0; r < settle; ++r) launch(period);
-        GU_HIP(hipEventRecord(h->ev_cal[0], h->stream));
-        for (int r = 0; r < reps; ++r) launch(period);
-        GU_HIP(hipEventRecord(h->ev_cal[1], h->stream));
-        GU_HIP(hipEventSynchronize(h->ev_cal[1]));
-        GU_HIP(hipGetLastError());
-        GU_HIP(hipEventElapsedTime(ms, h->ev_cal[0], h->ev_cal[1]));
-        *ms /= (float)reps;
-        ++evaluated;
-        launches += collapse + settle + reps;
-        return GU_OK;
-    };
-    float unpaced = 0.0f, t = 0.0f;
-    if ((rc = measure(0u, 0, 1, 4, &unpaced)) != GU_OK) return rc;
-    const double groups = (double)T / 16.0;
-    // down: the period whose schedule equals the unpaced launch, then 4 % less each time, until two points in a row lie 5 % above
-    // the best one (the cliff is behind us) or the schedule is down to half the unpaced time (this launch is not bound by the
-    // write path)
-    std::vector<uint32_t> tried;
-    std::vector<float> tried_ms;
-    float best = unpaced;
-    int above = 0;
-    for (double period = (double)unpaced * 1e5 / groups; period >= 1.0 && period * groups > 0.5e5 * (double)unpaced; period *= 0.96) {
-        const uint32_t p = (uint32_t)(period + 0.5);
-        if (!tried.empty() && p >= tried.back()) continue;
-        if ((rc = measure(p, 0, 1, 3, &t)) != GU_OK) return rc;
-        tried.push_back(p);
-        tried_ms.push_back(t);
-        if (gu_debug() > 1) fprintf(stderr, "[gu]   period %u: %.4f ms\n", p, t);
-        if (t < best) best = t, above = 0;
-        else if (t > 1.05f * best && ++above >= 2) break;
-    }
-    // up from the collapsed side in steps of 1 %: the first period that recovers to within 2 % of the best launch seen and HOLDS it
-    // over 12 launches is kept, plus 1 % (four launches after the recovery say little: at the edge the stream holds for a few
-    // launches and is collapsed again within twenty -- 108 us in the calibration, 115 .. 122 in the 50 launches that followed)
-    uint32_t pick = 0;
-    float pick_ms = unpaced;
-    if (!tried.empty()) {
-        size_t k_best = 0;
-        for (size_t k = 0; k < tried.size(); ++k)
-            if (tried_ms[k] < tried_ms[k_best]) k_best = k;
-        const size_t k_low = std::min(tried.size() - 1, k_best + 1);  // one step below the best point: in the cliff or at its edge
-        const double lo = (double)tried[k_low], hi = k_best > 0 ? (double)tried[k_best - 1] : (double)tried[k_best] * 1.05;
-        for (double period = lo * 1.01; period <= hi * 1.0001; period *= 1.01) {
-            const uint32_t p = (uint32_t)(period + 0.5);
-            if ((rc = measure(p, 2, 2, 12, &t)) != GU_OK) return rc;
-            if (gu_debug() > 1) fprintf(stderr, "[gu]   period %u from the collapsed state: %.4f ms (best %.4f)\n", p, t, best);
-            if (t <= 1.02f * best) {
-                pick = (uint32_t)(period * GU_PACE_MARGIN + 0.5), pick_ms = t;
-                break;
-            }
-        }
-        if (!pick) pick = k_best > 0 ? tried[k_best - 1] : tried[k_best], pick_ms = k_best > 0 ? tried_ms[k_best - 1] : tried_ms[k_best];
-    }
-    if (pick) {  // against no limiter at all, measured the same way
-        if ((rc = measure(0u, 0, 1, 4, &t)) != GU_OK) return rc;
-        unpaced = std::min(unpaced, t);
-        if (unpaced <= 1.01f * pick_ms) pick = 0, pick_ms = unpaced;
-    }
-    if ((rc = restore.run()) != GU_OK) return rc;
-    rec->period = pick;
-    rec->ms_unpaced = unpaced;
-    rec->ms_paced = pick_ms;
-    rec->evaluated = evaluated;
-    rec->launches = launches;
-    rec->ms_spent = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-    h->pace_search_ms += rec->ms_spent;
-    h->pace_search_launches += launches;
-    if (gu_debug())
-        fprintf(stderr, "[gu] store pacing search (%s kernel, policy %d, auto %d, %lld x %lld): %u ticks of 10 ns per 16 steps, %.4f -> %.4f ms per launch, %d candidates in %.1f ms\n",
-                slot >= 24 ? "row-table (packed rows)" : slot >= 12 ? "row-table" : "general", (slot % 12) / 3, slot % 3, (long long)h->N, (long long)T, pick, unpaced, pick_ms, evaluated,
-                rec->ms_spent);
-    return GU_OK;
-}
-
 // The schedule of this launch.  `slot` = policy * 3 + auto mode (+ 12 for the transition-row kernel's int32 rows, + 24 for its packed
-// rows, `row_bytes` = 12 / 4 per env-step); `launch(period)` enqueues the launch with that FIXED period (the search above only).
+// rows, `row_bytes` = 12 / 4 per env-step).  (The open-loop period search of rounds 3 and 4 is gone from the library: docs/HISTORY.md.)
 //   GU_OPT_ROLLOUT_PACE = 0: no limiter.  n > 0: that period, fixed.  -1 (the default): the launches of a kind choose their period
 //   themselves, closed loop, from the first one on (GuPacer / gu_pace_next): no search, no dedicated launch, nothing on the host.
 // Launches that cannot be bound by the HBM write path (less than 128 MB of rows, or fewer workgroups than half the CUs), launches of
@@ -643,24 +480,9 @@ static bool gu_pace_eligible(const gu_engine *h, int64_t T, unsigned blocks, int
     return !((double)h->N * (double)T * (double)row_bytes < 128e6 || (int64_t)blocks * 2 < h->n_cu || T < 64 || h->N > (int64_t)h->n_cu * 1024);
 }
 
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int block_size, int row_bytes, const std::function<void(uint32_t)> &launch, GuPaceArgs *pace)
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int block_size, int row_bytes, GuPaceArgs *pace)
 {
     *pace = GuPaceArgs{};
-    if (h->pace_search_requested) {  // gu_rollout_pace_search: the search first, then this launch without a limiter
-        h->pace_search_requested = false;
-        h->pace_search_found = false;
-        if (!gu_pace_eligible(h, T, blocks, row_bytes)) return GU_OK;
-        GuPaceSearch found;
-        const int rc = gu_search_pace(h, slot, T, launch, &found);
-        if (rc != GU_OK) return rc;
-        h->pace_search_found = true;
-        h->pace_search_period = found.period;
-        h->pace_search_ms_unpaced = found.ms_unpaced;
-        h->pace_search_ms_paced = found.ms_paced;
-        h->pace_search_last_launches = found.launches;
-        h->pace_search_last_ms = found.ms_spent;
-        return GU_OK;
-    }
     const int64_t opt = gu_opt(h, GU_OPT_ROLLOUT_PACE);
     if (opt == 0) return GU_OK;
     const bool eligible = gu_pace_eligible(h, T, blocks, row_bytes);
@@ -817,12 +639,7 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     }
     if (policy < GU_POLICY_UNIFORM || policy > GU_POLICY_SAMPLE) return gu_fail(GU_ERR_INVALID, "unknown policy kind %d", policy);
     if (traj == 1 || traj == 3) {  // int32 rows on the general kernel: the store stream is rate-limited (gu_rollout.hpp: GuPacer)
-        RolloutArgs c = a;
-        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, gu_blocks(h->N, bs), bs, 12, [&](uint32_t period) {
-            c.pace = GuPaceArgs{};
-            c.pace.period = period;
-            gu_rollout_general(h, c, policy, auto_mode, traj, stats, bs);
-        }, &a.pace);
+        int rc = gu_pace_for(h, policy * 3 + auto_mode, T, gu_blocks(h->N, bs), bs, 12, &a.pace);
         if (rc != GU_OK) return rc;
         gu_rollout_general(h, a, policy, auto_mode, traj, stats, bs);
     } else {

@@ -971,6 +971,6 @@ void gu_rollout_sample(gu_engine *h, const RolloutArgs &a, int auto_mode, int tr
 bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats, int *rc);
 bool gu_rows_pairs_fit(const gu_engine *h);  // its pair tables fit this engine's grid (and GU_OPT_ROLLOUT_ROWS does not forbid them)
 // store pacing (gu_kernels.hip): the schedule of a launch that writes rows -- the launch kind's ring of records, or a fixed period
-int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int block_size, int row_bytes, const std::function<void(uint32_t)> &launch, GuPaceArgs *pace);
+int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int block_size, int row_bytes, GuPaceArgs *pace);
 // the K-step kernel (gu_rollout_multi.hip; uniform policy, no trajectory): true when it took the launch
 bool gu_rollout_multi(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode, int traj, bool stats);

@@ -804,12 +804,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
         }
     };
     if (traj) {  // rows to write: the store stream is rate-limited here too (gu_rollout.hpp: GuPacer)
-        RolloutArgs c = a;
-        *rc = gu_pace_for(h, (traj != 2 ? 12 : 24) + policy * 3 + auto_mode, a.T, grid.x, bs, traj != 2 ? 12 : 4, [&](uint32_t period) {
-            c.pace = GuPaceArgs{};
-            c.pace.period = period;
-            launch(c);
-        }, &a.pace);
+        *rc = gu_pace_for(h, (traj != 2 ? 12 : 24) + policy * 3 + auto_mode, a.T, grid.x, bs, traj != 2 ? 12 : 4, &a.pace);
         if (*rc != GU_OK) return true;
     }
     launch(a);

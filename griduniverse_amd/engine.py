@@ -230,7 +230,7 @@ class Engine(object):
 
     def rollout_pacing_totals(self):
         """Over all launch kinds of this engine: dict(calibration_ms, launches_spent, kinds_paced, kinds_from_cache, kinds_waiting) --
-        ms and launches are what rollout_pace_search spent (0 unless a tool asked for one)."""
+        calibration_ms and launches_spent are 0: no launch is ever spent on a search."""
         ms = ctypes.c_float(0.0)
         n = [ctypes.c_int32(0) for _ in range(4)]
         check(self.lib.gu_rollout_pacing_totals(self._h, ctypes.byref(ms), *[ctypes.byref(x) for x in n]))
@@ -278,21 +278,6 @@ class Engine(object):
             return None
         check(rc)
         return buf[:n.value].astype(np.int64)
-
-    def rollout_pace_search(self, T, policy='uniform', auto_reset=True, trajectory=True, stats=False):
-        """MEASUREMENT AID (include/gu.h: gu_rollout_pace_search): the open-loop period search of rounds 3 and 4 on a snapshot of the
-        engine's state, then the rollout itself without a limiter.  dict(period, ms_unpaced, ms_paced, launches, ms_spent), or None
-        for a launch that keeps no schedule (the rollout has still run)."""
-        flags = (_lib.F_AUTO_RESET if auto_reset else 0) | (_lib.F_STATS if stats else 0)
-        flags |= _lib.F_PACKED if trajectory == 'packed' else (_lib.F_TRAJECTORY if trajectory else 0)
-        period, n = ctypes.c_int32(0), ctypes.c_int32(0)
-        a, b, c = ctypes.c_float(0.0), ctypes.c_float(0.0), ctypes.c_float(0.0)
-        rc = self.lib.gu_rollout_pace_search(self._h, int(T), _POLICIES[policy], flags, ctypes.byref(period), ctypes.byref(a), ctypes.byref(b), ctypes.byref(n),
-                                             ctypes.byref(c))
-        if rc == -4:
-            return None
-        check(rc)
-        return dict(period=period.value, ms_unpaced=a.value, ms_paced=b.value, launches=n.value, ms_spent=c.value)
 
     def read_trajectory(self, t0, T, pinned=False):
         """Rows t0..t0+T-1 of the trajectory as obs/reward/done int32[T, N].  pinned=True returns views of

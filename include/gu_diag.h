@@ -26,8 +26,8 @@ int gu_probe_trajectory(gu_handle h, float *milliseconds);
 /* ---- store pacing: where the closed loop stands (include/gu.h, "Store pacing") ---------
  * gu_rollout_pacing reports a launch kind's current period, the length of its schedule (ms_paced; ms_unpaced and
  * calibration_ms are 0), and how many launches of the kind have run on the current shape (`evaluated`); GU_ERR_STATE when the kind
- * keeps no schedule.  gu_rollout_pacing_totals: kinds with a schedule; ms and launches are what gu_rollout_pace_search
- * spent, i.e. 0 unless a tool asked for a search. */
+ * keeps no schedule.  gu_rollout_pacing_totals: kinds with a schedule; calibration_ms and launches_spent are 0 (no launch
+ * is ever spent on a search; the open-loop search of rounds 3 and 4 left the library in round 6). */
 int gu_rollout_pacing_totals(gu_handle h, float *calibration_ms, int32_t *launches_spent, int32_t *kinds_paced, int32_t *kinds_from_cache,
                              int32_t *kinds_waiting);
 int gu_rollout_pacing(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
@@ -42,11 +42,6 @@ int gu_rollout_pace_log(gu_handle h, int32_t policy_kind, uint32_t flags, int32_
 /* MEASUREMENT AID: what every wave of the kind's LAST launch reported -- ticks (10 ns) from the wave's start to its report, a few
  * groups before the end of the launch (0: the wave did not report) -- before the next launch sums and clears it. */
 int gu_rollout_pace_waves(gu_handle h, int32_t policy_kind, uint32_t flags, int32_t capacity, uint32_t *elapsed, int32_t *count);
-/* MEASUREMENT AID: the open-loop search of rounds 3 and 4 (a few hundred full-size launches on a snapshot of the engine's state,
- * which is put back), followed by the rollout itself without a limiter.  Reports the period it would have installed; installs
- * nothing.  tests/test_gpu_store_pacing.py and tools/pace_loop.py hold the closed loop against it. */
-int gu_rollout_pace_search(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags, int32_t *period, float *ms_unpaced, float *ms_paced,
-                           int32_t *launches, float *ms_spent);
 
 /* ---- tabular DP: which form ran ----------------------------------------------------
  * gu_vi_last_form : which of its three forms the last gu_vi_sweep_step_run of this engine took (1 per XCD, 2 chip-wide cluster,

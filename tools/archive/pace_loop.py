@@ -174,36 +174,7 @@ if args.sweep:
     eng.set_option('rollout_pace', None)
     out['sweep'] = rows
 
-# ---- search: the open-loop search on the same buffer, and launches held at what it found -----------------
-if not args.no_search:
-    found = eng.rollout_pace_search(T, policy, True, traj)
-    print('== search:', found)
-    out['search'] = found
-    if found and found['period']:
-        eng.set_option('rollout_pace', found['period'])
-        go(eng, 20)
-        res = [round(chunk(eng, 58)[0], 2) for _ in range(5)]
-        print('   held at %d: wall us per launch, 5 x 60 launches: %s' % (found['period'], res))
-        out['held'] = res
-        eng.set_option('pace_record', 0)  # the same period without the launch records: what they cost
-        go(eng, 20)
-        res = []
-        for _ in range(5):
-            eng.sync()
-            eng.timer_begin()
-            go(eng, 60)
-            res.append(round(eng.timer_end() / 60 * 1e3, 2))
-        print('   held at %d WITHOUT records: wall us per launch, 5 x 60 launches: %s' % (found['period'], res))
-        out['held_no_records'] = res
-        eng.set_option('pace_record', None)
-        eng.set_option('rollout_pace', None)
-        go(eng, 300)  # the closed loop again on this (now warm) engine
-        res = []
-        for _ in range(5):
-            wall, lg = chunk(eng, 58)
-            res.append((round(wall, 2), round(float(np.median(lg['period'][-58:])), 1)))
-        print('   closed loop after it (300 launches later): (wall us, period median) per 60 launches: %s' % res)
-        out['loop_after'] = res
+# (the open-loop search of rounds 3 and 4, which this tool held the loop against until round 5, left the library in round 6)
 eng.close()
 if args.json:
     os.makedirs(os.path.dirname(args.json) or '.', exist_ok=True)

@@ -221,40 +221,18 @@ int gu_step_graph(gu_handle h, int64_t t0, int64_t T, uint32_t flags);
 int gu_read_outputs(gu_handle h, int32_t *obs, int32_t *reward, int32_t *done);
 
 /* ---- rollout: the caller loop of core/algorithms/monte_carlo.py:7-26 fused -----
- * T env-steps per env in ONE launch (async).  With GU_F_TRAJECTORY the
- * (obs,reward,done) of step i of this call land in row i of the trajectory buffer
- * (gu_reserve_trajectory(T) first: room for at least T rows; a buffer that is already large enough is kept); with GU_F_STATS the per-env reward sum and the
- * number of episodes finished during this call are kept for gu_read_stats. */
+ * T env-steps per env in ONE launch (async).  GU_F_TRAJECTORY: the (obs, reward, done) of step i of this call land in row i of the
+ * trajectory buffer (gu_reserve_trajectory(T) first; a buffer that is already large enough is kept).  GU_F_STATS: the per-env
+ * reward sum and the number of episodes finished during this call are kept for gu_read_stats. */
+/* Placement: where a buffer lands in HBM changes its write rate by a few per cent, so buffers of 64 MB and more are CHOSEN: up to
+ * GU_OPT_TRAJ_CANDIDATES (4) allocations are written once in the rollout's store shape and the fastest is kept; never more than
+ * a tenth of the free memory is held.  (what the search did: gu_trajectory_placement*, include/gu_diag.h.) */
 int gu_reserve_trajectory(gu_handle h, int64_t T);
-/* Where an allocation lands in HBM changes how fast it can be written (round 2: 5.7 .. 6.9 TB/s for 786 MB buffers of one process
- * with an unthrottled store stream; since the rollout kernel rate-limits its stores -- see gu_rollout_pacing -- 7.2 .. 7.3 against
- * 7.4 .. 7.5), so gu_reserve_trajectory CHOOSES a buffer of 64 MB and more: it allocates candidates one after
- * the other, writes each once in the rollout's own store shape, and keeps the fastest.  The search
- *   - stops at the first clearly fast candidate (14 % quicker than the slowest seen; on gfx950 also: 6.5 TB/s or more);
- *   - looks at GU_OPT_TRAJ_CANDIDATES (4) back-to-back candidates; only when GU_OPT_TRAJ_FAR_CANDIDATES (0) is set and those were
- *     at least 6 % apart does it continue -- buffers of 256 MiB and more -- with that many more, each behind a spacer of
- *     GU_OPT_TRAJ_STRIDE_MIB (3072) that is held until the choice is made;
- *   - never holds more than a tenth of the device's free memory nor GU_OPT_TRAJ_FAR_MIB (48 GiB) at once, everything but the
- *     kept buffer is freed before the call returns;
- *   - is per-process aware: once an engine of the process owns a chosen trajectory buffer on the device, later engines
- *     probe at most 4 back-to-back candidates, hold at most a sixteenth of the free memory, and stop at the first
- *     candidate within 3 % of the rate the first search ended on.
- * (What the search did, and the probe itself: gu_trajectory_placement* and gu_probe_trajectory, include/gu_diag.h.) */
 int gu_rollout(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
-/* Store pacing.  The HBM write path shows congestion collapse: lanes that hand their rows to the memory system as fast as it will
- * take them are served at 5.7 TB/s on most allocations, the same stores offered just below the memory's capacity at 7.2 .. 7.5 on
- * every one.  Launches with GU_F_TRAJECTORY (and GU_F_PACKED launches on the transition-row kernel) of 128 MB of rows
- * and 64 steps and more (up to four waves per SIMD) keep a SCHEDULE: a wave begins its next 16 steps no earlier than `period` ticks
- * of the 100 MHz clock (10 ns) after the last ones were due, and never waits when it is late.  THE LAUNCHES CHOOSE THE PERIOD
- * THEMSELVES, closed loop, on the device (round 5): every wave counts the groups it began behind its schedule, the next launch of
- * the kind (policy, auto-reset, kernel, row bytes) reads the sum and moves the period -- one tick down while the launch before it
- * was on schedule, back up when it was not, and a period that failed is tried again only after 2, 4 .. 1024 launches on schedule.
- * The first launch of a kind starts from a model (its rows at GU_OPT_PACE_TARGET GB/s).  There is no search, no dedicated launch,
- * no snapshot, nothing on the host: an engine that is simply used gets the paced rate from its first launches on, and a
- * neighbour on the device or a change of clocks moves the period instead of collapsing the stream for good.  Results never depend
- * on any of it.  GU_OPT_ROLLOUT_PACE = 0: no limiter; n > 0: that period, fixed.
- * gu_rollout_calibrate is gu_rollout (rounds 3 and 4 searched the period there; kept for callers that call it).
- * (Where the loop stands, its records, and the open-loop search of rounds 3 and 4 as a measurement aid: include/gu_diag.h.) */
+/* Store pacing: launches that write 128 MB of rows and more keep a schedule -- a wave begins its next 16 steps no earlier than
+ * `period` ticks of 10 ns after the last ones were due.  The launches choose the period themselves, closed loop, on the device;
+ * results never depend on it.  GU_OPT_ROLLOUT_PACE = 0: no limiter; n > 0: that period, fixed.  (where the
+ * loop stands: gu_rollout_pacing, include/gu_diag.h.)  gu_rollout_calibrate is gu_rollout, kept for callers of rounds 3 and 4. */
 int gu_rollout_calibrate(gu_handle h, int64_t T, int32_t policy_kind, uint32_t flags);
 int gu_read_trajectory(gu_handle h, int64_t t0, int64_t T, int32_t *obs, int32_t *reward, int32_t *done);
 int gu_read_trajectory_packed(gu_handle h, int64_t t0, int64_t T, uint32_t *packed);   /* [T][N] after GU_F_PACKED */

@@ -492,7 +492,6 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         tcount0 = a.tcount[e];
     }
     CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem, a.gs, MAP == 3 ? 1 : 2);
-    const uint32_t *nib = reinterpret_cast<const uint32_t *>(smem) + (threadIdx.x & 63u);  // MAP 5: this lane's column of its wave's image
     if (MAP == 5) {  // (blocks of one wave; the image of wave b is one contiguous piece)
         const uint4 *src = reinterpret_cast<const uint4 *>(a.nib + (size_t)blockIdx.x * (size_t)a.nib_dwords * 64u);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -545,9 +544,12 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     auto padded = [&](int32_t c) { return (c + c / W + W + 2) << 5; };
     int32_t sq = MAP == 5 ? padded(s) : 0;
     const int32_t start0_q = MAP == 5 ? padded(start0) : 0;
-    const char *nib_lane = reinterpret_cast<const char *>(nib);  // (this lane's column: + lane * 4 bytes)
+    // The image sits at the START of the workgroup's LDS (this kernel has no static LDS; the launcher checks it and takes another
+    // map otherwise), in rows of 256 bytes: the address of a gather is row offset | lane * 4 -- ONE v_and_or_b32.
+    typedef __attribute__((address_space(3))) const uint32_t *lds_word_ptr;
+    const uint32_t lane4 = (threadIdx.x & 63u) << 2;
     auto four_at = [&](int32_t cq) {
-        const uint32_t word = *reinterpret_cast<const uint32_t *>(nib_lane + ((uint32_t)cq & 0xFFFFFF00u));
+        const uint32_t word = *(lds_word_ptr)(uintptr_t)(((uint32_t)cq & 0xFFFFFF00u) | lane4);
         return __builtin_amdgcn_ubfe(word, ((uint32_t)cq >> 3) & 28u, 4);
     };
     auto cell5 = [&](int32_t cq) {  // the record of padded cell cq / 32 from the four-bit image
@@ -675,7 +677,10 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
                 pacer.after((uint32_t)i);
             }
             for (; i + 16 <= a.T; i += 16, t += 16) {  // body: 16 steps per word, fully unrolled
-                const uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+                uint32_t word = gu_rng_word(prefix, GU_RNG_STREAM_ACTION, t >> 4);
+                // (MAP 5 is bound by the NUMBER of its instructions: the word is kept as it is -- the compiler would otherwise redo the
+                // hash's last multiply in every step whose bits it can take from the product)
+                if (MAP == 5) asm volatile("" : "+v"(word));
 #pragma unroll
                 for (uint32_t j = 0; j < 16; ++j) step(__builtin_amdgcn_ubfe(word, 2 * j, 2), j * trow32);
                 if (TRAJ) rebase(16);
@@ -925,9 +930,17 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
         if (h->n_grids > 1 && h->W <= 1022 && gu_nibble_bytes_per_wave(h) <= (size_t)h->lds_per_cu - 512 && a.nib) {
             const size_t lds = gu_nibble_bytes_per_wave(h);
             auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 5>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, 64)), dim3(64), lds, h->stream, a);
-            return;
+            static std::atomic<int> base_zero{0};  // 1: no static LDS, the image starts at LDS address 0 (the kernel relies on it)
+            if (!base_zero.load(std::memory_order_relaxed)) {
+                hipFuncAttributes fa{};
+                const bool got = hipFuncGetAttributes(&fa, (const void *)kern) == hipSuccess;
+                base_zero.store(got && fa.sharedSizeBytes == 0 ? 1 : 2, std::memory_order_relaxed);
+            }
+            if (base_zero.load(std::memory_order_relaxed) == 1) {
+                if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, 64)), dim3(64), lds, h->stream, a);
+                return;
+            }
         }
     }
     a.xcd_remap = a.xcd_remap && h->n_grids == 1 && blocks_ok(bs);

@@ -497,8 +497,8 @@ int gu_pace_for(gu_engine *h, int slot, int64_t T, unsigned blocks, int block_si
     return GU_OK;
 }
 
-// Rollout MAP 5 (gu_rollout.hpp): every env's grid at four bits per cell -- the upper half of its cell records: TERM, RPLUS, RMINUS,
-// WALL -- padded with wall cells (one column left of every row, one row above and below: cell (x, y) at (y + 1)(W + 1) + x + 1) and
+// Rollout MAP 5 (gu_rollout.hpp): every env's grid at four bits per cell -- RPLUS, RMINUS, TERM, WALL from bit 0 up: the upper half of
+// its cell records with the reward code first -- padded with wall cells (one column left of every row, one row above and below: cell (x, y) at (y + 1)(W + 1) + x + 1) and
 // laid out per wave of 64 envs as [dword][lane], so that a wave stages its image with one contiguous copy and its gathers are
 // free of bank conflicts.  Built once per grid installation, on the device, from the cell planes.
 __global__ void __launch_bounds__(256) gu_nibble_planes_kernel(const uint8_t *__restrict__ cell, GridSel gs, int32_t W, int32_t H, int32_t dwords, int64_t N,
@@ -515,7 +515,8 @@ __global__ void __launch_bounds__(256) gu_nibble_planes_kernel(const uint8_t *__
         for (int32_t k = 0; k < 8; ++k) {
             const int32_t p = (int32_t)j * 8 + k, yp = p / (W + 1), xp = p % (W + 1);
             const bool real = yp >= 1 && yp <= H && xp >= 1;
-            const uint32_t four = real ? (uint32_t)(f[(yp - 1) * W + xp - 1] >> 4) : 0x8u;
+            const uint32_t b = real ? f[(yp - 1) * W + xp - 1] : GU_CELL_WALL;
+            const uint32_t four = ((b >> 5) & 3u) | (((b >> GU_CELL_TERM_BIT) & 1u) << 2) | ((b >> 7) << 3);
             word |= four << (4 * k);
         }
     }

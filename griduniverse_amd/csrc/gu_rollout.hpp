@@ -433,8 +433,8 @@ __device__ __forceinline__ void gu_stream_run(const char *pa, int64_t row, uint3
 //       register copy of flags); 2 = auto-reset, several start cells (RNG stream 1, rare divergent branch)
 // MAP : 0 = records read from L2 (any grid size, any grid-per-env assignment)
 //       1 = the block's grid staged in LDS, shared by its lanes
-//       5 = every lane keeps its own grid in LDS as FOUR BITS PER CELL -- {terminal, reward +10, reward -10, wall}, the upper half
-//           of the cell record -- for multi-grid engines whose groups do not align with blocks, e.g. one maze per env.  The image
+//       5 = every lane keeps its own grid in LDS as FOUR BITS PER CELL -- {reward +10, reward -10, terminal, wall}: the upper half
+//           of the cell record, reward code first -- for multi-grid engines whose groups do not align with blocks, e.g. one maze per env.  The image
 //           is PADDED with wall cells: one column on the left of every row, one row above and below (cell (x, y) at index
 //           (y + 1)(W + 1) + x + 1), so that a move off the grid meets a wall like any other and the step tests nothing but the
 //           CANDIDATE cell's wall bit (env:136-155 literally, env:51-54 folded into the padding).  (P + 7) / 8 dwords per env, P =
@@ -527,12 +527,12 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     auto prefix_at = [&](uint32_t t) {  // (t: the low word of the step count; a launch is shorter than 2^32 steps)
         return gu_rng_prefix(gu_rng_seed_prefix_epoch(a.seed_prefix0, epoch0 + (t < t_lane ? 1u : 0u)), a.env_id0 + e);
     };
-    // MAP 5 keeps the upper half of the cell record in `flags` (TERM, RPLUS, RMINUS, WALL: what the four bits per cell hold) and, in
-    // bit 3, STUCK: the agent stands on a terminal cell it has not been reset away from, which absorbs every action (env:145-146).
-    // With a single start cell (AUTO == 1) that is the case only right after a reset onto a terminal start cell and at entry; a
-    // terminal cell reached by a move is left by the reset of the next step.
-    constexpr uint32_t STUCK = 8u;
-    auto flags5 = [](uint32_t b) { return (b & 0xF0u) | (((b >> GU_CELL_TERM_BIT) & 1u) << 3); };
+    // MAP 5 keeps in `flags` what the four bits of the agent's cell say, shifted up by three: RPLUS 0x08, RMINUS 0x10 -- so that the
+    // register itself is the bit offset of the cell's reward in a constant (v_bfe_i32 reads the low five bits of its offset) --, TERM
+    // 0x20, WALL 0x40.  A terminal cell absorbs every action (env:145-146): the move asks the TERM bit of the cell the agent is on, the
+    // lazy reset asks the done flag `d` -- so the register's TERM bit is never overwritten at entry, as the other maps do.
+    constexpr uint32_t TERM5 = 0x20u, TERM5_BIT = 5u;
+    auto flags5 = [](uint32_t b) { return (((b >> 5) & 3u) << 3) | (((b >> GU_CELL_TERM_BIT) & 1u) << TERM5_BIT) | ((b >> 7) << 6); };
     uint32_t flags = MAP == 5 ? flags5(m.f[s]) : m.f[s];
     int32_t ret = 0, fin = 0;
     const int32_t W = a.W;
@@ -550,24 +550,19 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     const uint32_t lane4 = (threadIdx.x & 63u) << 2;
     auto four_at = [&](int32_t cq) {
         const uint32_t word = *(lds_word_ptr)(uintptr_t)(((uint32_t)cq & 0xFFFFFF00u) | lane4);
-        return __builtin_amdgcn_ubfe(word, ((uint32_t)cq >> 3) & 28u, 4);
+        return __builtin_amdgcn_ubfe(word, (uint32_t)cq >> 3, 4);  // (the low five bits of the offset count: (cell & 7) * 4, cq being a multiple of 32)
     };
-    auto cell5 = [&](int32_t cq) {  // the record of padded cell cq / 32 from the four-bit image
-        const uint32_t four = four_at(cq);
-        return (four << 4) | ((four & 1u) << 3);
-    };
+    auto cell5 = [&](int32_t cq) { return four_at(cq) << 3; };  // the record of padded cell cq / 32 from the four-bit image
     // one move on the four-bit image: the candidate cell, ONE gather, a wall?  (env:136-155; moves off the grid meet the padding)
     auto move5 = [&](uint32_t act, int32_t delta) {
         int32_t cand = s + delta;
         asm volatile("" : "+v"(cand));  // (kept as the sum it is: select(go, s + delta, s), not s + select(go, delta, 0) with its sign extension)
         const int32_t candq = sq + gu_delta<true>(act, a.lut_p, 0);
         const uint32_t four = four_at(candq);
-        const uint32_t stay = flags | ((flags & STUCK) << 1);               // blocked on a terminal cell: done (TERM sits above STUCK)
-        const uint32_t arrive = AUTO == 1 ? four << 4 : (four << 4) | ((four & 1u) << 3);
-        const bool go = ((flags & STUCK) | four) < (GU_CELL_WALL >> 4);     // neither stuck nor a wall ahead
+        const bool go = ((flags & TERM5) | four) < 8u;  // the agent's cell is not terminal and the candidate (bit 3: WALL) is no wall
         s = go ? cand : s;
         sq = go ? candq : sq;
-        flags = go ? arrive : stay;
+        flags = go ? four << 3 : flags;
     };
     // Trajectory rows are addressed as buffer resource (wave-uniform base, rebuilt per 16-step chunk)
     // + lane byte offset e4 (VGPR) + scalar row offset (SGPR): buffer_store_dword ... offen, so that
@@ -599,7 +594,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     // AUTO == 1 keeps the invariant "d == TERM bit of the REGISTER copy of flags", so the lazy reset needs no
     // separate test on the dependent chain; at entry the stored done flag may disagree with the cell (fresh reset
     // onto a terminal start, gu_set_state), so the register copy takes its TERM bit from the stored flag.
-    if (AUTO == 1) flags = (flags & ~GU_CELL_TERM) | (d << GU_CELL_TERM_BIT);
+    if (AUTO == 1 && MAP != 5) flags = (flags & ~GU_CELL_TERM) | (d << GU_CELL_TERM_BIT);
 
     // `soff`: wave-uniform byte offset of this step's row from the resource base
     auto step = [&](uint32_t act, uint32_t soff) {
@@ -629,8 +624,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             s = gu_move(s, flags, act, delta);
             flags = m.f[s];
         }
-        r = (MAP >= 2) ? gu_reward_packed(flags) : (int32_t)m.r[s];
-        d = __builtin_amdgcn_ubfe(flags, GU_CELL_TERM_BIT, 1);
+        r = MAP == 5 ? __builtin_amdgcn_sbfe((int32_t)0xF6F60AFFu, flags, 8) : (MAP >= 2) ? gu_reward_packed(flags) : (int32_t)m.r[s];
+        d = __builtin_amdgcn_ubfe(flags, MAP == 5 ? TERM5_BIT : GU_CELL_TERM_BIT, 1);
         if (STATS) {
             ret += r;
             fin += (int32_t)d;

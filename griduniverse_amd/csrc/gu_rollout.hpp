@@ -548,17 +548,19 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     // map otherwise), in rows of 256 bytes: the address of a gather is row offset | lane * 4 -- ONE v_and_or_b32.
     typedef __attribute__((address_space(3))) const uint32_t *lds_word_ptr;
     const uint32_t lane4 = (threadIdx.x & 63u) << 2;
-    auto four_at = [&](int32_t cq) {
-        const uint32_t word = *(lds_word_ptr)(uintptr_t)(((uint32_t)cq & 0xFFFFFF00u) | lane4);
-        return __builtin_amdgcn_ubfe(word, (uint32_t)cq >> 3, 4);  // (the low five bits of the offset count: (cell & 7) * 4, cq being a multiple of 32)
-    };
+    auto word_at = [&](int32_t cq) { return *(lds_word_ptr)(uintptr_t)(((uint32_t)cq & 0xFFFFFF00u) | lane4); };
+    // (the low five bits of a bit-field offset count: (cell & 7) * 4, cq being a multiple of 32)
+    auto four_of = [](uint32_t word, int32_t cq) { return __builtin_amdgcn_ubfe(word, (uint32_t)cq >> 3, 4); };
+    auto four_at = [&](int32_t cq) { return four_of(word_at(cq), cq); };
     auto cell5 = [&](int32_t cq) { return four_at(cq) << 3; };  // the record of padded cell cq / 32 from the four-bit image
     // one move on the four-bit image: the candidate cell, ONE gather, a wall?  (env:136-155; moves off the grid meet the padding)
-    auto move5 = [&](uint32_t act, int32_t delta) {
+    auto move5 = [&](uint32_t act, int32_t delta, auto &&in_the_shadow) {
         int32_t cand = s + delta;
         asm volatile("" : "+v"(cand));  // (kept as the sum it is: select(go, s + delta, s), not s + select(go, delta, 0) with its sign extension)
         const int32_t candq = sq + gu_delta<true>(act, a.lut_p, 0);
-        const uint32_t four = four_at(candq);
+        const uint32_t word = word_at(candq);
+        in_the_shadow();  // (what the caller has to issue that does not depend on the gather: the row stores of the step before)
+        const uint32_t four = four_of(word, candq);
         const bool go = ((flags & TERM5) | four) < 8u;  // the agent's cell is not terminal and the candidate (bit 3: WALL) is no wall
         s = go ? cand : s;
         sq = go ? candq : sq;
@@ -580,7 +582,31 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0xFFFFFFFFu, 0x00020000);
     __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(pr, 0, 0xFFFFFFFFu, 0x00020000);
     __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(pd, 0, 0xFFFFFFFFu, 0x00020000);
+    // the row of one step (`soff`: wave-uniform byte offset of the row from the resource base)
+    auto emit = [&](int32_t s_, int32_t r_, uint32_t d_, uint32_t soff) {
+        if (TRAJ == 1) {
+            __builtin_amdgcn_raw_buffer_store_b32(s_, ro, e4, soff, GU_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(r_, rr, e4, soff, GU_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32((int32_t)d_, rd, e4, soff, GU_STORE_AUX);
+        } else if (TRAJ == 2) {
+            __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)s_ | (((uint32_t)r_ & 0xFFu) << 16) | (d_ << 24)), ro, e4, soff, GU_STORE_AUX_PACKED);
+        } else if (TRAJ == 3) {  // one 12-byte store per lane and step: the wave's 768 bytes are contiguous
+            const gu_v3u triple = {(uint32_t)s_, (uint32_t)r_, d_};
+            __builtin_amdgcn_raw_buffer_store_b96(triple, ro, te, soff, GU_STORE_AUX);
+        }
+    };
+    // MAP 5 holds a step's row back until the NEXT step's gather has been issued: LDS and vector-memory instructions of a wave go
+    // out through one port, in order, and a gather queued behind three row stores waits for them (~25 clocks each) on top of its own
+    // latency -- on the dependent chain of a loop that has its SIMD alone.  Issued behind the gather, the stores fill its shadow.
+    bool held = false;
+    int32_t held_s = 0, held_r = 0;
+    uint32_t held_d = 0, held_soff = 0;
+    auto release = [&]() {
+        if (MAP == 5 && TRAJ && held) emit(held_s, held_r, held_d, held_soff);
+        held = false;
+    };
     auto rebase = [&](int64_t rows) {
+        release();  // (its row offset counts from the base that is about to move)
         po += rows * trow;
         ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0xFFFFFFFFu, 0x00020000);
         if (TRAJ == 1) {
@@ -619,7 +645,13 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             }
         }
         if (MAP == 5) {
-            move5(act, delta);
+            move5(act, delta, [&]() {
+                if (TRAJ && held) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    emit(held_s, held_r, held_d, held_soff);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
         } else {
             s = gu_move(s, flags, act, delta);
             flags = m.f[s];
@@ -630,16 +662,8 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
             ret += r;
             fin += (int32_t)d;
         }
-        if (TRAJ == 1) {
-            __builtin_amdgcn_raw_buffer_store_b32(s, ro, e4, soff, GU_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b32(r, rr, e4, soff, GU_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b32((int32_t)d, rd, e4, soff, GU_STORE_AUX);
-        } else if (TRAJ == 2) {
-            __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)s | (((uint32_t)r & 0xFFu) << 16) | (d << 24)), ro, e4, soff, GU_STORE_AUX_PACKED);
-        } else if (TRAJ == 3) {  // one 12-byte store per lane and step: the wave's 768 bytes are contiguous
-            const gu_v3u triple = {(uint32_t)s, (uint32_t)r, d};
-            __builtin_amdgcn_raw_buffer_store_b96(triple, ro, te, soff, GU_STORE_AUX);
-        }
+        if (MAP == 5 && TRAJ) held = true, held_s = s, held_r = r, held_d = d, held_soff = soff;
+        else emit(s, r, d, soff);
     };
     auto step1 = [&](uint32_t act) {  // one step, then advance the resource base by one row
         step(act, 0);
@@ -842,6 +866,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         if (thr_in_lds) run([thr_lds](int32_t at) { return thr_lds[at]; });
         else run([&a](int32_t at) { return a.pi_thr[at]; });
     }
+    release();
     pacer.finish();
     a.pos[e] = s;
     a.reward[e] = r;

@@ -492,10 +492,14 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         tcount0 = a.tcount[e];
     }
     CellMap m = gu_stage_map<LDS>(a.cell, a.cell_bytes, smem, a.gs, MAP == 3 ? 1 : 2);
-    if (MAP == 5) {  // (blocks of one wave; the image of wave b is one contiguous piece)
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.nib + (size_t)blockIdx.x * (size_t)a.nib_dwords * 64u);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (int32_t i = threadIdx.x; i < a.nib_dwords * 16; i += 64) dst[i] = src[i];
+    // MAP 5: every wave of the block stages the image of ITS 64 envs (one contiguous piece) into its own region of the block's LDS
+    const uint32_t nib_region = MAP == 5 ? (threadIdx.x >> 6) * (uint32_t)a.nib_dwords * 256u : 0u;  // byte offset of that region
+    if (MAP == 5) {
+        const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.nib + wave * (size_t)a.nib_dwords * 64u);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem + nib_region);
+        if (wave * 64u < (size_t)a.N)
+            for (int32_t i = threadIdx.x & 63; i < a.nib_dwords * 16; i += 64) dst[i] = src[i];
         __syncthreads();
     }
     const uint8_t *greedy = a.greedy;
@@ -540,8 +544,9 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
     const int32_t start0 = lg.starts[0];
     const uint32_t start0_flags = MAP == 5 ? flags5(m.f[start0]) : m.f[start0];
     // `sq`: the agent's cell in the padded image (cell (x, y) -> (y + 1)(W + 1) + x + 1), times 32 -- bits 8 and up are then the byte
-    // offset of its dword's row in the [dword][lane] image, bits 5 .. 7 the cell inside the dword; a.lut_p is scaled alike
-    auto padded = [&](int32_t c) { return (c + c / W + W + 2) << 5; };
+    // offset of its dword's row in the [dword][lane] image, bits 5 .. 7 the cell inside the dword; a.lut_p is scaled alike -- plus the
+    // byte offset of the wave's region in the block's LDS (a multiple of 256: it moves the row, nothing else)
+    auto padded = [&](int32_t c) { return (int32_t)(((uint32_t)(c + c / W + W + 2) << 5) + nib_region); };  // (+ the wave's region: whole rows)
     int32_t sq = MAP == 5 ? padded(s) : 0;
     const int32_t start0_q = MAP == 5 ? padded(start0) : 0;
     // The image sits at the START of the workgroup's LDS (this kernel has no static LDS; the launcher checks it and takes another
@@ -948,7 +953,11 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
         }
         // misaligned multi-grid engine (e.g. one maze per env): every lane's grid at four bits per cell in LDS, if a wave's 64 fit
         if (h->n_grids > 1 && h->W <= 1022 && gu_nibble_bytes_per_wave(h) <= (size_t)h->lds_per_cu - 512 && a.nib) {
-            const size_t lds = gu_nibble_bytes_per_wave(h);
+            // workgroups of four waves where four images fit a CU's LDS (32 x 32: 144 KB): the launch shape of the shared-grid kernel,
+            // whose store stream the memory takes at a shorter period than that of 1024 one-wave workgroups (profiles/r06m_multigrid_ab.txt)
+            int mbs = 256;
+            while (mbs > 64 && (size_t)(mbs / 64) * gu_nibble_bytes_per_wave(h) > (size_t)h->lds_per_cu - 512) mbs >>= 1;
+            const size_t lds = (size_t)(mbs / 64) * gu_nibble_bytes_per_wave(h);
             auto kern = gu_rollout_kernel<POLICY, AUTO, TRAJ, STATS, 5>;
             static std::atomic<int> base_zero{0};  // 1: no static LDS, the image starts at LDS address 0 (the kernel relies on it)
             if (!base_zero.load(std::memory_order_relaxed)) {
@@ -958,7 +967,7 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
             }
             if (base_zero.load(std::memory_order_relaxed) == 1) {
                 if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, 64)), dim3(64), lds, h->stream, a);
+                hipLaunchKernelGGL(kern, dim3(gu_blocks(h->N, mbs)), dim3(mbs), lds, h->stream, a);
                 return;
             }
         }

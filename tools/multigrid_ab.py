@@ -35,7 +35,9 @@ for G in (65536, 1024, 1):
         row['rows, closed loop'] = timed(eng, trajectory=True)
         eng.set_option('rollout_pace', 0)
         row['rows, no limiter'] = timed(eng, 3, trajectory=True)
-        for period in (200, 220, 240, 260):
+        info = eng.rollout_pacing('uniform', True)
+        row['(loop period %s)' % (None if info is None else info['period'])] = 0.0
+        for period in (150, 160, 170, 180, 190, 200):
             eng.set_option('rollout_pace', period)
             row['rows, period %d' % period] = timed(eng, 3, trajectory=True)
         eng.set_option('rollout_pace', None)

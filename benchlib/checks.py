@@ -98,3 +98,19 @@ def cpu_baseline_check_c5(template, seed, gamma, rounds, v, pi, state, rewards):
                 and np.array_equal(state['done'], st.done) and np.array_equal(state['episode'], st.episode)
                 and np.array_equal(rewards, want['reward'][0]))
 
+
+
+def cpu_baseline_check_distinct_grids(got, first, N, G, T, seed, maze_seed):
+    """Config 3 on G device-generated 32x32 mazes: the envs of six grids (up to eight each), reset state and the whole first launch,
+    against the C oracle stepping on ITS restatement of the same mazes (oracle/gu_oracle.c: gu_oracle_generate_maze)."""
+    from oracle import c_oracle as C
+    group, ok = N // G, True
+    for g in sorted({0, 1, G // 3, G // 2, G - 2, G - 1}):
+        wall, start, goal = C.generate_maze(maze_seed, g, 32, 32)
+        grid = C.Grid.from_lists(32, 32, walls=np.flatnonzero(wall).tolist(), goals=[int(goal)], starts=[int(start)])
+        n = min(group, 8)
+        st = C.State(n, g * group)
+        ok = ok and bool(np.array_equal(C.reset(grid, seed, st), first[g * group:g * group + n]))
+        want = C.rollout(grid, seed, st, T, True)
+        ok = ok and all(np.array_equal(got[k][:, g * group:g * group + n], want[k]) for k in ('obs', 'reward', 'done'))
+    return bool(ok)

@@ -110,7 +110,6 @@ def _distinct_grids(engine_cls, device, K, check, T):
     # its own grid in LDS at four bits per cell (gu_rollout.hpp, MAP 5).
     out = {}
     if hasattr(engine_cls, 'generate_mazes'):
-        from oracle import c_oracle as C
         N, seed, maze_seed = 65536, WORKLOAD_SEED['c3'], 2026
         for G in (1024, 65536):
             eng = engine_cls(N, gua.GridSpec(32, 32, [0], [1023], [], []), device=device, env_id0=0, seed=seed)
@@ -121,17 +120,7 @@ def _distinct_grids(engine_cls, device, K, check, T):
                 eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
                 ok = None
                 if check:  # a sample of grids, each against the C oracle on ITS maze (oracle/gu_oracle.c: the same build RNG)
-                    got = eng.read_trajectory(0, T)
-                    group, ok = N // G, True
-                    for g in sorted({0, 1, G // 3, G // 2, G - 2, G - 1}):
-                        wall, start, goal = C.generate_maze(maze_seed, g, 32, 32)
-                        grid = C.Grid.from_lists(32, 32, walls=np.flatnonzero(wall).tolist(), goals=[int(goal)], starts=[int(start)])
-                        n = min(group, 8)
-                        st = C.State(n, g * group)
-                        ok = ok and bool(np.array_equal(C.reset(grid, seed, st), first[g * group:g * group + n]))
-                        want = C.rollout(grid, seed, st, T, True)
-                        ok = ok and all(np.array_equal(got[k][:, g * group:g * group + n], want[k]) for k in ('obs', 'reward', 'done'))
-                    del got
+                    ok = checks.cpu_baseline_check_distinct_grids(eng.read_trajectory(0, T), first, N, G, T, seed, maze_seed)
                 ms = launch_ms(eng, T, K, trajectory=True)
             finally:
                 eng.close()

@@ -23,6 +23,7 @@ MODES = {
     'rollout_sample_policy_traj': lambda name, grid: 'gu_rollout_rows_kernel<3, 1,' in name and grid == 65536,  # <sampled, int32 rows, ...>
     'rollout_sample_policy_stats_only': lambda name, grid: 'gu_rollout_rows_kernel<3, 0,' in name and grid == 65536,
     'c5_rounds_in_one_launch': lambda name, grid: 'gu_vi_xcd_kernel<' in name or 'gu_vi_sweep_step_xcd_kernel<' in name,
+    'c3_distinct_65536': lambda name, grid: 'gu_rollout_kernel<' in name and name.rstrip().endswith(', 5>(RolloutArgs)') and grid == 65536,
 }
 
 
@@ -102,11 +103,16 @@ def main():
                 names['c5_rounds_in_one_launch'] = n
                 seq['c5_rounds_in_one_launch'].append((g, v))
             elif 'gu_rollout_kernel<' in n:
+                if n.rstrip().endswith(', 5>(RolloutArgs)'):  # MAP 5: one grid per env (bench.py: configs.c3_distinct_65536)
+                    names['c3_distinct_65536'] = n
+                    if g == 65536:
+                        seq['c3_distinct_65536'].append((g, v))
+                    continue
                 names.setdefault('general', n)
                 if marker is None or i < marker:
                     if g == 65536:
                         seq['headline'].append((g, v))
-                elif g and C4_ENVS % g == 0 and g >= 65536:
+                elif g == C4_ENVS:  # (the distinct-grid configs also run 65 536 lanes on this kernel, after the marker)
                     seq['strong_c4'].append((g, v))
         out = {}
         for mode, items in seq.items():

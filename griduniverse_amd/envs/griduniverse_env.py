@@ -39,6 +39,53 @@ def _grid_coordinates(n_cols, n_rows):
     return world
 
 
+class _WatchedList(list):
+    """A list that tells its env when it is edited IN PLACE: the reference consults goal_states / lava_states / starting_states
+    on every step (env:157-174, 187-193), so an edit takes effect at once; here the grid is compiled into the engine, and the
+    edit drops the compiled form.  Compares, prints, pickles and serialises as the list it is."""
+
+    def __init__(self, items, on_change):
+        super().__init__(items)
+        self._on_change = on_change
+
+    def __reduce__(self):
+        return (list, (list(self),))
+
+
+def _watch(name):
+    def method(self, *args, **kwargs):
+        out = getattr(list, name)(self, *args, **kwargs)
+        self._on_change()
+        return out
+    method.__name__ = name
+    return method
+
+
+for _name in ('append', 'extend', 'insert', 'remove', 'pop', 'clear', 'sort', 'reverse', '__setitem__', '__delitem__', '__iadd__', '__imul__'):
+    setattr(_WatchedList, _name, _watch(_name))
+
+
+class _WatchedArray(np.ndarray):
+    """wall_grid / reward_matrix: an assignment into the array (`env.wall_grid[5] = 1`) drops the compiled grid, as above.
+    Arrays derived from it (slices, comparisons, copies) are plain in behaviour: they carry no env."""
+
+    def __new__(cls, array, on_change):
+        obj = np.asarray(array).view(cls)
+        obj._on_change = on_change
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._on_change = None
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        if self._on_change is not None:
+            self._on_change()
+
+    def __reduce__(self):
+        return np.asarray(self).__reduce__()
+
+
 def _require_list(value, name):
     if value is not None and not isinstance(value, list):
         raise TypeError("{} parameter must be a list of integer indices".format(name))
@@ -48,6 +95,24 @@ class GridUniverseEnv(object):
     # 'rgb_array' is an addition of this build (frames rendered on the GPU); the other three are the reference's
     metadata = {'render.modes': ['human', 'ansi', 'graphic', 'rgb_array']}
     reward_range = (-float('inf'), float('inf'))
+
+    # the attributes the reference re-reads on every step: replacing one, or editing it in place, drops the compiled grid
+    _GRID_LISTS = ('goal_states', 'lava_states', 'starting_states', 'wall_indices')
+    _GRID_ARRAYS = ('wall_grid', 'reward_matrix')
+
+    def __setattr__(self, name, value):
+        if name in self._GRID_LISTS and isinstance(value, list):
+            value = _WatchedList(value, self._grid_edited)
+        elif name in self._GRID_ARRAYS and isinstance(value, np.ndarray):
+            value = _WatchedArray(value, self._grid_edited)
+        else:
+            return object.__setattr__(self, name, value)
+        object.__setattr__(self, name, value)
+        self._grid_edited()
+
+    def _grid_edited(self):
+        if self.__dict__.get('_engine_obj') is not None or self.__dict__.get('_tables') or self.__dict__.get('_step_tab') is not None:
+            self._drop_engine()
 
     def __init__(self, grid_shape=(4, 4), *, initial_state=0, goal_states=None, lava_states=None, walls=None,
                  custom_world_fp=None, random_maze=False, device=0):
@@ -142,10 +207,10 @@ class GridUniverseEnv(object):
         self._pos_dirty = True
 
     def invalidate(self):
-        """Call after mutating goal_states / lava_states / wall_grid / reward_matrix / starting_states IN PLACE: the
-        grid is compiled into the engine (and the transition table cached) when first needed, so -- unlike the
-        reference, which re-reads those attributes on every step -- later edits are not seen until this is called.
-        (The constructor, the level loader and the maze generator call it themselves.)"""
+        """Drops the compiled grid (engine, cached transition table).  Since round 6 the env does this itself whenever goal_states /
+        lava_states / starting_states / wall_indices are replaced or edited in place and whenever wall_grid / reward_matrix are
+        assigned into -- the reference re-reads them on every step (env:157-174), so an edit takes effect at the next step here
+        too.  Still needed after writing through a VIEW of one of the two arrays (`v = env.wall_grid[2:]; v[0] = 1`)."""
         self._drop_engine()
 
     def _engine(self):

@@ -397,7 +397,7 @@ class GridUniverseEnv(object):
         """Level text -> grid (env:253-316).  'o' floor, '#' wall, 'G' goal, 'L' lava, 'x' start."""
         width = len(text_world_lines[0])
         cells = {'G': [], 'L': [], '#': [], 'x': []}
-        self.goal_states, self.lava_states, self.starting_states = cells['G'], cells['L'], cells['x']
+        self.goal_states, self.lava_states, self.starting_states = [], [], []  # (what a parse error leaves behind, as in the reference)
         for y, line in enumerate(text_world_lines):
             if len(line) != width:
                 raise ValueError("Input text file is not a rectangle")
@@ -405,7 +405,9 @@ class GridUniverseEnv(object):
                 if ch in cells:
                     cells[ch].append(y * width + x)
                 elif ch != 'o':
+                    self.goal_states, self.lava_states, self.starting_states = cells['G'], cells['L'], cells['x']
                     raise ValueError('Invalid Character "{}". Returning'.format(ch))
+        self.goal_states, self.lava_states, self.starting_states = cells['G'], cells['L'], cells['x']
         if not self.starting_states:
             raise ValueError("No starting states set in text file. Place \"x\" within grid. ")
         if not self.goal_states:

@@ -497,7 +497,7 @@ static int gu_step_action_error(gu_engine *h, const int32_t *actions)
     __atomic_store_n(h->h_seq + GU_HOST_ERR_WORD, 0u, __ATOMIC_RELAXED);
     h->off_lo -= 1;  // (the rejected envs did not step: their offsets to the lock-step counter went down by one)
     for (int64_t i = 0; i < h->N; ++i)
-        if ((uint32_t)actions[i] > 3u)
+        if (!GU_ACTION_OK(actions[i]))
             return gu_fail(GU_ERR_INVALID, "action %d of env %lld outside 0..3 (that env did not step; envs with valid actions did)", actions[i], (long long)i);
     return gu_fail(GU_ERR_INVALID, "an action outside 0..3 was seen by the step kernel (the action buffer changed during the call)");
 }
@@ -596,7 +596,7 @@ int gu_upload_actions(gu_handle h, const int32_t *actions, int64_t T)
         __atomic_store_n(h->h_seq + GU_HOST_ERR_WORD, 0u, __ATOMIC_RELAXED);
         // the rejected stream is not usable (the buffers themselves are kept for the next upload)
         for (size_t i = 0; i < count; ++i)
-            if ((uint32_t)actions[i] > 3u) return gu_fail(GU_ERR_INVALID, "action %d at flat index %zu outside 0..3", actions[i], i);
+            if (!GU_ACTION_OK(actions[i])) return gu_fail(GU_ERR_INVALID, "action %d at flat index %zu outside 0..3", actions[i], i);
         return gu_fail(GU_ERR_INVALID, "an action outside 0..3 was uploaded");
     }
     h->actions_T = T;
@@ -1184,7 +1184,7 @@ int gu_look_step_ahead(gu_handle h, int64_t n, const int32_t *states, const int3
         __atomic_store_n(h->h_seq + GU_HOST_ERR_WORD, 0u, __ATOMIC_RELAXED);
         for (int64_t i = 0; i < n; ++i) {
             GU_REQUIRE(states[i] >= 0 && states[i] < h->S, GU_ERR_INVALID, "state %d outside the grid", states[i]);
-            GU_REQUIRE((uint32_t)actions[i] < 4u, GU_ERR_INVALID, "action %d outside 0..3", actions[i]);
+            GU_REQUIRE(GU_ACTION_OK(actions[i]), GU_ERR_INVALID, "action %d outside 0..3", actions[i]);
         }
         return gu_fail(GU_ERR_INVALID, "a state outside the grid or an action outside 0..3 was passed");
     }

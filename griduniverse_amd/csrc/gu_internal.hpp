@@ -27,6 +27,9 @@
 #define GU_CELL_TERM_BIT 4
 #define GU_CELL_RPLUS 0x20u
 #define GU_CELL_RMINUS 0x40u
+// Actions: 0..3 = UP, RIGHT, DOWN, LEFT (env:56); -4..-1 address the same list from its end (env:148 indexes a Python list: -1 is
+// LEFT), i.e. action & 3; anything else is an IndexError in the reference and rejected here.
+#define GU_ACTION_OK(raw) ((uint32_t)((int32_t)(raw) + 4) < 8u)
 #define GU_CELL_WALL 0x80u  /* the cell itself is a wall (only the path search needs it: wall nodes have no edges) */
 
 #define GU_MAX_LDS_CELLS 32767 /* both planes of grids up to 32 767 cells (64 KiB) are LDS-resident; larger read L2 */

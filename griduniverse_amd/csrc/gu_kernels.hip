@@ -124,8 +124,8 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
         const uint32_t raw = (uint32_t)a.actions[e];
         const uint32_t act = raw & 3u;
         int32_t s = a.pos[e], r;
-        if (a.host_err && raw > 3u) {
-            // Action outside 0..3 (env:148 raises IndexError before it touches the instance): this env does not
+        if (a.host_err && !GU_ACTION_OK(raw)) {
+            // Action outside -4..3 (env:148 raises IndexError before it touches the instance): this env does not
             // step -- position, flags, pending lazy reset and step count stay as they were -- and the host is told
             // through the page-locked error word (any offender may write it; the host finds the first one itself).
             __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -170,13 +170,13 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_step_kernel(const StepArgs a)
     }
 }
 
-// Validation of a caller-supplied action stream on the device (gu_upload_actions): any value outside 0..3 raises the
+// Validation of a caller-supplied action stream on the device (gu_upload_actions): any value outside -4..3 raises the
 // page-locked error word.  Replaces a serial host loop over T x N values.
 __global__ void __launch_bounds__(256) gu_validate_actions_kernel(const int32_t *__restrict__ actions, int64_t count, uint32_t *host_err)
 {
     bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
-        bad |= (uint32_t)actions[i] > 3u;
+        bad |= !GU_ACTION_OK(actions[i]);
     if (__ballot(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) gu_pack_actions_kernel(const int32_t *__r
         uint32_t word = 0;
         for (int64_t j = 0; j < 16 && 16 * k + j < T; ++j) {
             const uint32_t act = (uint32_t)actions[(16 * k + j) * N + e];
-            bad |= act > 3u;
+            bad |= !GU_ACTION_OK(act);
             word |= (act & 3u) << (2 * j);
         }
         packed[i] = word;
@@ -252,11 +252,11 @@ __global__ void __launch_bounds__(GU_BLOCK) gu_lookahead_kernel(const LookArgs a
     if (i >= a.n) return;
     int32_t s = a.states[i];
     const uint32_t raw = (uint32_t)a.actions[i];
-    if ((uint32_t)s >= (uint32_t)a.S || raw > 3u) {  // validated here instead of in a serial host loop
+    if ((uint32_t)s >= (uint32_t)a.S || !GU_ACTION_OK(raw)) {  // validated here instead of in a serial host loop
         __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
-    const uint32_t act = raw;
+    const uint32_t act = raw & 3u;  // (-4 .. -1: the list's negative indices)
     s = gu_move(s, m.f[s], act, gu_delta<LDS>(act, a.lut, a.W));
     a.next[i] = s;
     a.reward[i] = m.r[s];  // reward / terminal bits are identical in both maps

@@ -19,9 +19,10 @@
  *     enqueue work on the handle's stream (gu_sync() waits for it).
  *   - env state is struct-of-arrays in HBM: pos[N] | reward[N] | done[N] (one
  *     contiguous int32[3N] block, so the gathered view is one collective),
- *     episode[N], tcount[N] (uint32).  Actions are 0..3 = UP,RIGHT,DOWN,LEFT
- *     (env:56); anything else is rejected (the reference's negative-index quirk is
- *     not part of the contract).  Caller-supplied actions and
+ *     episode[N] (uint32), a 64-bit step count per env.  Actions are 0..3 =
+ *     UP,RIGHT,DOWN,LEFT (env:56); -4..-1 are the same list addressed from its end, as
+ *     in the reference (env:148: -1 is LEFT); anything else is
+ *     rejected (the reference raises IndexError).  Caller-supplied actions and
  *     states are validated by the kernels that consume them (an error word in
  *     page-locked memory), not by host loops.
  */
@@ -198,7 +199,7 @@ int gu_reset_done(gu_handle h);
  * 8192 envs return as soon as the kernel has published a completion word in page-locked
  * memory -- the results are in place, the stream may still be draining; every later call on
  * the handle is ordered behind it as usual.
- * An action outside 0..3 is detected BY THE KERNEL (env:148 raises IndexError before it touches the
+ * An action outside -4..3 is detected BY THE KERNEL (env:148 raises IndexError before it touches the
  * instance): that env does not step -- position, reward, done flag, pending lazy reset and step
  * count stay as they were, its outputs repeat its current state -- every env with a valid action
  * steps, and the call returns GU_ERR_INVALID naming the first offender.
@@ -208,7 +209,7 @@ int gu_step(gu_handle h, const int32_t *actions, uint32_t flags,
             int32_t *obs, int32_t *reward, int32_t *done);
 
 /* Device-resident action stream [T][N] for gu_step_device / GU_POLICY_STREAM.  Values are validated on the
- * device after the copy; a stream holding anything outside 0..3 is rejected as a whole (GU_ERR_INVALID).
+ * device after the copy; a stream holding anything outside -4..3 is rejected as a whole (GU_ERR_INVALID).
  * The upload REPLACES the stream: afterwards it holds exactly rows 0 .. T-1 (a rejected upload leaves none).
  * Besides the int32 rows (read by the single-step launches) the device keeps the stream packed to two bits
  * per action, 16 steps per word and env; gu_rollout(GU_POLICY_STREAM) reads that: 0.25 B, not 4 B, per env-step. */

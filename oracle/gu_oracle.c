@@ -105,6 +105,7 @@ void gu_oracle_look_step_ahead(const gu_oracle_grid *g, int32_t s, int32_t a, in
                                int32_t *next, int32_t *reward, int32_t *done)
 {
     int32_t n;
+    if (a < 0) a += 4;   /* env:148 indexes a Python list of four moves: -1 is LEFT ... -4 is UP */
     if (care_about_terminal && is_terminal(g, s)) {
         n = s;
     } else {

@@ -32,7 +32,7 @@ def test_invalid_action_is_caught_by_the_kernel_and_only_that_env_stays(N, pinne
         rew_before = eng.read_outputs()[1]
         acts = rs.randint(0, 4, N).astype(np.int32)
         bad = np.array([7, N // 2, N - 1])
-        acts[bad] = [4, -1, 1 << 20]
+        acts[bad] = [4, -5, 1 << 20]  # (-4 .. -1 are valid: the reference indexes a Python list, see the next test)
 
         def call():
             if pinned:
@@ -64,6 +64,47 @@ def test_invalid_action_is_caught_by_the_kernel_and_only_that_env_stays(N, pinne
         assert np.array_equal(obs[good], want2['obs'][0][good])
         # done ballots stay current through all of this
         assert np.array_equal(eng.done_indices(), np.flatnonzero(eng.get_state()['done']))
+
+
+def test_negative_actions_address_the_move_list_from_its_end_like_the_reference():
+    """env:148 indexes a Python list of four moves, so -1 is LEFT, -2 DOWN, -3 RIGHT, -4 UP; round 5's
+    batched calls rejected them.  gu_step, an uploaded stream (single steps and the rollout that reads it packed) and
+    gu_look_step_ahead take them; -5 and 4 are still refused."""
+    meta, _ = G.load_traj('c4_lava32')
+    grid = C.Grid.from_lists(**meta)
+    N, T = 777, 64
+    rs = np.random.RandomState(2)
+    acts = rs.randint(-4, 4, (T, N)).astype(np.int32)
+    for use in ('step', 'step_device', 'stream'):
+        st = C.State(N)
+        with Engine(N, spec_of(meta), seed=3) as eng:
+            assert np.array_equal(eng.reset(), C.reset(grid, 3, st))
+            want = C.rollout(grid, 3, st, T, True, actions=acts)
+            same = C.State(N)
+            C.reset(grid, 3, same)
+            again = C.rollout(grid, 3, same, T, True, actions=acts & 3)
+            assert all(np.array_equal(want[k], again[k]) for k in ('obs', 'reward', 'done'))  # the oracle: -k is 4 - k
+            if use == 'step':
+                got = [eng.step(acts[t], auto_reset=True) for t in range(T)]
+                assert all(np.array_equal(got[t][0], want['obs'][t]) and np.array_equal(got[t][1], want['reward'][t]) for t in range(T))
+            else:
+                eng.upload_actions(acts)
+                if use == 'step_device':
+                    for t in range(T):
+                        eng.step_device(t, auto_reset=True)
+                else:
+                    eng.reserve_trajectory(T)
+                    eng.rollout(T, 'stream', True)
+                    got = eng.read_trajectory(0, T)
+                    assert all(np.array_equal(got[k], want[k]) for k in got)
+            s = eng.get_state()
+            assert np.array_equal(s['pos'], st.pos) and np.array_equal(s['done'], st.done) and np.array_equal(s['episode'], st.episode), use
+            nxt, rew, don = eng.look_step_ahead(np.arange(64), np.full(64, -1))
+            nx3, rw3, dn3 = eng.look_step_ahead(np.arange(64), np.full(64, 3))
+            assert np.array_equal(nxt, nx3) and np.array_equal(rew, rw3) and np.array_equal(don, dn3)
+            for bad in (-5, 4):
+                with pytest.raises(gua.GuError):
+                    eng.step(np.full(N, bad, np.int32))
 
 
 def test_uploaded_action_stream_is_validated_on_the_device():

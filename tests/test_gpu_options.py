@@ -18,6 +18,8 @@ def test_options_are_per_engine_with_a_process_default(gu_option):
     that), identical results; an engine's own value wins over the process default, None hands it back."""
     meta, _ = G.load_traj('c3_maze32')
     N, T = 4096, 300
+    for name in ('rollout_rows', 'rollout_block', 'rollout_multi'):
+        gu_option(name, None)  # (a GU_TEST_OPTIONS session may have set them: this test is about the built-in defaults)
     with Engine(N, spec_of(meta), seed=11) as a, Engine(N, spec_of(meta), seed=11) as b:
         assert a.get_option('rollout_rows') == -1 and a.get_option('rollout_block') == 256
         a.set_option('rollout_rows', 0)

@@ -250,7 +250,7 @@ def test_set_state_round_trip_and_absorbing_terminals():
         with pytest.raises(gua.GuError):
             eng.step(np.full(N, 4, np.int32))
         with pytest.raises(gua.GuError):
-            eng.step(np.full(N, -1, np.int32))
+            eng.step(np.full(N, -5, np.int32))  # (-4 .. -1 are the move list from its end, env:148)
 
 
 def test_look_step_ahead_tables():

@@ -107,6 +107,33 @@ def test_one_grid_per_env_on_the_four_bit_image(W, H):
             assert state['pos'][g] == st.pos[0] and state['done'][g] == st.done[0] and state['episode'][g] == st.episode[0], (g, auto, policy)
 
 
+def test_one_grid_per_env_across_2_pow_32_steps():
+    """The four-bit image (MAP 5) in the launch during which the step counts pass 2^32 (every step asks for the RNG prefix of its
+    own epoch, gu_rollout.hpp: prefix_at) and in launches that lie wholly in epoch 1."""
+    rs = np.random.RandomState(77)
+    W, H, N, T, seed = 9, 7, 128, 120, 31
+    specs = random_specs(rs, N, W, H)
+    with Engine(N, specs[0], seed=seed) as eng:
+        eng.set_grids(specs)
+        first = eng.reset()
+        tc = (2 ** 32 - 50 + rs.randint(0, 30, N)).astype(np.uint64)
+        eng.set_state(tcount=tc)
+        eng.reserve_trajectory(T)
+        runs = []
+        for _ in range(3):
+            eng.rollout(T, 'uniform', auto_reset=True, trajectory=True)
+            runs.append(eng.read_trajectory(0, T))
+        final = eng.get_state()
+    for g, spec in enumerate(specs):
+        grid, st = oracle_grid(spec), C.State(1, g)
+        assert C.reset(grid, seed, st)[0] == first[g]
+        st.tcount[:] = tc[g]
+        for got in runs:
+            want = C.rollout(grid, seed, st, T, True)
+            assert all(np.array_equal(got[k][:, g], want[k][:, 0]) for k in ('obs', 'reward', 'done')), g
+        assert final['pos'][g] == st.pos[0] and final['tcount'][g] == st.tcount[0] == tc[g] + 3 * T
+
+
 def test_multi_grid_restrictions():
     specs = random_specs(np.random.RandomState(0), 3, 8, 8)
     with Engine(30, specs[0]) as eng:

@@ -59,7 +59,7 @@ def test_multi_grid_engine_equals_per_grid_oracle(group):
         assert np.array_equal(final['pos'][sl], st.pos) and np.array_equal(final['episode'][sl], st.episode)
 
 
-@pytest.mark.parametrize('W,H', [(32, 32), (5, 3), (40, 12), (1, 7)])
+@pytest.mark.parametrize('W,H', [(32, 32), (5, 3), (40, 12), (1, 7), (64, 64), (90, 80)])  # (64 x 64: one wave per workgroup; 90 x 80: too big for LDS, records from L2)
 def test_one_grid_per_env_on_the_four_bit_image(W, H):
     """One distinct grid PER ENV (the N x GridUniverseEnv(random_maze=True) shape, griduniverse_env.py:318-321): the rollout keeps
     every lane's grid in LDS at four bits per cell and tests the candidate cell (gu_rollout.hpp, MAP 5).  Grids with every quirk

@@ -738,7 +738,7 @@ static int gu_alloc_trajectory(gu_engine *h, size_t bytes, int64_t T, int32_t **
     // ranks of one process group, share it).  What the search is still worth under the closed-loop store pacing: the first
     // allocation an engine gets runs the headline launch at 105.9 .. 110.2 us (ten buffers of one process, median 107.5), the
     // searched one at 105.2 -- 2 % in the median, 4 % at worst; the probe time ranks them in the same order
-    // (profiles/r05f_placement_loop.txt).  Why buffers differ is still not known (tools/archive/micro/placement_*.hip).
+    // (profiles/archive/r05f_placement_loop.txt).  Why buffers differ is still not known (tools/archive/micro/placement_*.hip).
     size_t budget = others ? free_b / 16 : free_b / 10;
     if (others) {
         want = want < 4 ? want : 4;

@@ -80,7 +80,7 @@ static_assert(sizeof(GuPaceEntry) == 128, "GuPaceEntry is two cache lines' halve
 // (NOT atomics.  Round 5's first version had every wave add its counts to one word of its launch's record: the 3072 agent-scope
 // atomics of a launch were executed one after the other at ~11 ns each and added 34 us to every 105 us launch.  Spread over 32
 // neighbouring cache lines they still cost 6 .. 9 us per launch -- the lines share a memory channel, and that is where device-scope
-// atomics are executed; profiles/r05a_pace_c3.txt, r05c_pace_c3.txt "held ... WITHOUT records".)
+// atomics are executed; profiles/archive/r05a_pace_c3.txt, r05c_pace_c3.txt "held ... WITHOUT records".)
 #define GU_PACE_RING 64u  /* entries per launch kind: the last 61 launches can be read back (gu_rollout_pace_log) */
 struct GuPaceArgs {
     GuPaceEntry *ring;      // nullptr: `period` as it is (0 = no limiter), nothing recorded

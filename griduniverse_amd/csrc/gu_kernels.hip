@@ -540,13 +540,13 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     // int32 rows: three planes [T][N], or one plane of (obs, reward, done) triples [T][N][3] -- the same words, one 12-byte store
     // per lane and step (gu_rollout.hpp: TRAJ == 3; the readers take them apart again: gu_read_trajectory, gu_mc_evaluate).
     // GU_OPT_TRAJ_LAYOUT: 0 = planes, 1 = triples wherever possible, -1 (default) = triples where they are faster.  Measured
-    // (profiles/r05b_layout_ab.txt, r05c_layout_sizes.txt, five variants interleaved in one process): a launch bound by the HBM write path is
+    // (profiles/archive/r05b_layout_ab.txt, r05c_layout_sizes.txt, five variants interleaved in one process): a launch bound by the HBM write path is
     // SLOWER with triples -- 65 536 envs: 117 against 112 us, a config-4 shard of 32 768: 68 against 63 -- and so is every table
     // policy; a launch of a few waves, bound by the ISSUE of its stores (~25 clocks per 256-byte store of a wave that has its SIMD
     // alone), gains little from the triple alone (config 2, 4096 envs: 49.4 against 49.9 us) but 25 % together with the pair tables
     // (two steps per LDS round trip, two stores per pair instead of six: 37.3 us), up to 8192 envs = one workgroup per eight
     // CUs; at 16 384 the two are level -- unless the batch is spread over twice the waves (32 envs each: 43.6 against 53.3 us,
-    // profiles/r05m_half_sizes.txt) --, beyond it the planes win.  So: triples for the uniform policy on the transition-row
+    // profiles/archive/r05m_half_sizes.txt) --, beyond it the planes win.  So: triples for the uniform policy on the transition-row
     // kernel with pair tables, up to n_cu / 4 workgroups of 256 (half waves for the upper half of that range).  Batches of more than 2^24 envs (lane offset + 15 rows must stay
     // below 2^32 bytes) and engines with the agent trail on always keep the planes.
     int traj = (flags & GU_F_PACKED) ? 2 : ((flags & GU_F_TRAJECTORY) ? 1 : 0);

@@ -102,7 +102,7 @@ __host__ __device__ __forceinline__ uint32_t gu_rng_word(uint32_t prefix, uint32
 // SIXTEEN steps, the words of the fifteen steps behind it by a multiply-free bijection (xorshift32 step + Weyl increment).  A
 // hash per step was what bound the sampled rollout (five quarter-rate 32-bit multiplies, ~80 clocks of issue time per step
 // against the ~30 of the rest of the step); one per four steps still left it 9 of a step's 34 instructions, and the sampled
-// rollout with int32 rows at 0.80 of the HBM peak; one per sixteen: 0.87 (profiles/r04z_sample_rollout.json).
+// rollout with int32 rows at 0.80 of the HBM peak; one per sixteen: 0.87 (profiles/archive/r04z_sample_rollout.json).
 __host__ __device__ __forceinline__ uint32_t gu_rng_sample_next(uint32_t x)
 {
     x ^= x << 13;

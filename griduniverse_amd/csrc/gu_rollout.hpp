@@ -54,9 +54,9 @@ __device__ __forceinline__ uint32_t gu_sample_action(uint32_t word, const uint4 
 //    few per cent of them even 10 ticks above it, a workgroup or two each time, 4 .. 8 us late (0.5 % of the waves on average) --
 //    while below it most waves of every launch do; the mean share rises from 0.5 % to 3 % to > 50 % within ten ticks, so 6 % is
 //    reached within a tick or two of the period at which the mean launch time is shortest, on every allocation, and five times the
-//    background keeps the loop from creeping up on a noisy device (profiles/r05c_pace_c3.txt).  The first launches come down
+//    background keeps the loop from creeping up on a noisy device (profiles/archive/r05c_pace_c3.txt).  The first launches come down
 //    faster: dec is at least 8 / (8 + seq) tick.  And the loop keeps asking whether the limiter pays at all (decide()).
-// (History, all in profiles/r05*_pace_*.txt.  Version 1 moved one whole tick per launch and kept a "period known to fail" with
+// (History, all in profiles/archive/r05*_pace_*.txt.  Version 1 moved one whole tick per launch and kept a "period known to fail" with
 // exponential back-off: two unlucky launches in a row doubled the back-off twice, and the period drifted up by 8 ticks in 300
 // launches and stayed there.  Version 2 stepped up by two ticks per launch behind and down by 1/32 tick: 4 ticks = 2.3 % above
 // the best fixed period, because a launch behind costs 8 us here, not the 35 us that ratio was chosen for.  Version 3 stepped up
@@ -254,12 +254,12 @@ struct GuPacer {
                     n_q = n_q > dec ? n_q - dec : n_q;
                     // THE SLOW LOOP AROUND IT: which share of waves behind is the best one to AIM for differs from buffer to buffer
                     // (how often a launch falls behind at a given distance from the cliff, and what that costs: on one allocation
-                    // the rule's 6 % held the period 8 ticks = 3 % above the best one, profiles/r05f_pytest_slow_buffer.txt).  What
+                    // the rule's 6 % held the period 8 ticks = 3 % above the best one, profiles/archive/r05f_pytest_slow_buffer.txt).  What
                     // counts is the time from one launch's start to the next one's, and the first wave sees it: blocks of 192
                     // launches (the last 128 counted), each with its own aim -- dec_q moves by a factor of 4/3 per block, in the
                     // direction of the last move while the block's mean interval got shorter, the other way when it got longer.
                     // The first move is DOWN, towards the longer period: the launch time rises by 0.6 us per two ticks above the best
-                    // period and by 2 .. 7 us per two ticks below it (profiles/r05y_pace_aim.txt; until late in round 5 the first move
+                    // period and by 2 .. 7 us per two ticks below it (profiles/archive/r05y_pace_aim.txt; until late in round 5 the first move
                     // was up, by 3/2, and the launches 192 .. 384 of a kind -- a benchmark's -- ran with 10 % of their waves behind).
                     if (phase == GU_PACE_NORMAL && !pa.fixed && pa.adapt) {
                         if (block_left <= GU_PACE_BLOCK - GU_PACE_BLOCK_SKIP && plausible) block_sum += took, ++block_n;

@@ -29,7 +29,7 @@
 // waves' in-order instruction stream carries neither the stores nor their stalls -- were built in round 4 and measured SLOWER for
 // every launch whose chain is short (uniform / greedy at 4096 .. 32 768 envs: 75 against 50 .. 60 us per 1000 steps: the hand-over
 // itself, a produced / consumed count pair per wave and eight records per group, costs ~180 clocks per step) and no faster where the
-// chain is long (sampled policy at 65 536 envs: 130 against 128; 110 against 117 at 32 768): profiles/r04s_rows_store_waves_ab.json.
+// chain is long (sampled policy at 65 536 envs: 130 against 128; 110 against 117 at 32 768): profiles/archive/r04s_rows_store_waves_ab.json.
 // Removed again; the sampled launch with int32 rows stays bound by its one wave per SIMD issuing chain and stores in order.
 //
 // Results are bit-identical to the general kernel (tests/test_gpu_rows_kernel.py runs both on the same seeds); the launcher
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
     // instruction per emitted record on `rec - base`, a seventh of config 2's per-step vector work.  The launcher checks it:
     // rows_dispatch refuses an instantiation that reports static LDS.)
     constexpr uint32_t lds_base = 0u;
-    // ---- The launch's fixed cost (round 5: 8.6 us of a 60 us config-4 shard, profiles/r05r_rows_intercept.txt) is LATENCY: the table
+    // ---- The launch's fixed cost (round 5: 8.6 us of a 60 us config-4 shard, profiles/archive/r05r_rows_intercept.txt) is LATENCY: the table
     // came in through four dependent rounds of global loads (every copy of a row fetched separately, eight loads in flight), and
     // the first step's three dependent global reads (state -> the cell's flags -> the next cell's flags and reward) started behind
     // the staging barrier.  Now: every SOURCE row is loaded once, all of a thread's loads in flight together, and written to its
@@ -777,7 +777,7 @@ bool gu_rollout_rows(gu_engine *h, RolloutArgs a, int32_t policy, int auto_mode,
     }
     a.row_shift = shift;
     const size_t lds = pair ? (size_t)h->S * 144 : ((size_t)h->S << row_log2) << (shift - row_log2);
-    // Half waves (see the kernel).  Measured (profiles/r05m_half_sizes.txt, r05m_half_ab.txt): the stores of a wave do NOT get cheaper
+    // Half waves (see the kernel).  Measured (profiles/archive/r05m_half_sizes.txt, r05m_half_ab.txt): the stores of a wave do NOT get cheaper
     // with fewer lanes -- planes at 4096 .. 8192 envs: 52.3 us either way, 55.4 against 53.3 at 16 384, and 223 against 126 us
     // where two half waves share a SIMD -- so this is no cure for the issue-bound launches.  It pays in ONE place: triples with
     // the pair tables between 8192 and 16 384 envs (43.6 against 47.6 us; the planes: 53.3), where a workgroup per four CUs

@@ -656,7 +656,7 @@ static ViArgs vi_args(gu_engine *h, double gamma, unsigned long long *delta_key)
 // The per-XCD launch (gu_vi_xcd.hip) runs a round in ~1.06 us WHATEVER the grid's size (1.02 at 8x8, 1.06 at 64x64), against 1.35
 // (8x8) .. 1.9 (32x32) .. 5 us (64x64) in one workgroup and ~4 us behind the chip-wide barrier, and since its snapshot and its
 // zeroed buffers are ONE launch and its results one copy back, a call of it is no dearer either: 39 us for one round, 145 for a
-// hundred at 32x32, against 46 and 240 of the single-workgroup kernel (profiles/r04z_dp_calls.txt).  It is taken first on every
+// hundred at 32x32, against 46 and 240 of the single-workgroup kernel (profiles/archive/r04z_dp_calls.txt).  It is taken first on every
 // grid it fits; the other paths are what it falls back to (a grid that does not fit a workgroup's LDS, workgroups that cannot all
 // be resident, GU_OPT_VI_PATH).
 static bool vi_xcd_preferred(const gu_engine *h, int32_t rounds)
@@ -1159,7 +1159,7 @@ int gu_vi_sweep_step_run(gu_handle h, double gamma, int32_t iters, uint32_t flag
     // leaves half-advanced state, which is put back before the next form runs.
     GuXcdPlan xp{};
     // (a call of ONE round: the one-launch forms cost ~10 us more to start -- the registration wait, the snapshot, the zeroed
-    // exchange buffers -- than they save; profiles/r04z_c5_forms.json, xcd_default_us_per_call_by_rounds.  GU_OPT_VI_PATH = 6: always)
+    // exchange buffers -- than they save; profiles/archive/r04z_c5_forms.json, xcd_default_us_per_call_by_rounds.  GU_OPT_VI_PATH = 6: always)
     const bool short_call = path == 0 && iters <= 1;
     const bool try_xcd = !short_call && (path == 0 || path == 5 || path == 6) && gu_vi_xcd_plan(h, true, &xp);
     const bool try_cluster = h->n_grids == 1 && h->S <= GU_MAX_LDS_CELLS && G <= (h->n_cu < VI_CL_MAX_WGS ? h->n_cu : VI_CL_MAX_WGS) &&

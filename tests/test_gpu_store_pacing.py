@@ -113,7 +113,7 @@ def test_an_engine_that_is_simply_used_gets_the_paced_rate(kind, gu_option):
     """Rounds 3 and 4 needed gu_rollout_calibrate (a search of a few hundred launches, 40 .. 60 ms) to reach the paced rate; an engine
     left alone ran without a limiter for 1024 launches and then stalled for the search.  Now: no launch of a fresh engine is ever
     spent on anything but the caller's work (launches_spent stays 0, the first launch costs a kernel), no launch takes more than
-    twice the median, and launches 200 .. 400 of the fresh engine run within 4 % (int32 rows; measured: -2 .. +3 %, profiles/r05h_matrix.txt,
+    twice the median, and launches 200 .. 400 of the fresh engine run within 4 % (int32 rows; measured: -2 .. +3 %, profiles/archive/r05h_matrix.txt,
     r06*_pace_quality.txt; packed rows: 10 %, see below) of the best of (a) no limiter and (b) FIVE FIXED PERIODS around the model (0.92 .. 1.08 x the rows of 16
     steps at 7.2 TB/s), each held on the same engine and buffer -- for the headline launch, where the limiter is worth 10 %, and
     for packed rows at one wave per SIMD, where it is worth nothing and the loop must find that out and switch it off."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The sampled-policy rollout at config 3 with 4 / 2 / 1 copies of the transition rows in LDS (option rows_copies), statistics only and with
-int32 rows: do LDS bank conflicts matter to it?  (They do not: 55.6 .. 56.7 us either way, profiles/r05zz_sample_copies.txt.)
+int32 rows: do LDS bank conflicts matter to it?  (They do not: 55.6 .. 56.7 us either way, profiles/archive/r05zz_sample_copies.txt.)
     python tools/sample_copies.py"""
 import sys, random, numpy as np
 sys.path.insert(0, '.')

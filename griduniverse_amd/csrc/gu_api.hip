@@ -381,6 +381,7 @@ int gu_seed(gu_handle h, uint64_t seed)
     h->seed_prefix = gu_rng_seed_prefix(seed);
     h->steps_taken = 0;
     h->off_lo = h->off_hi = 0;
+    h->off_exact = true;
     if (h->graph_exec) {  // captured step launches carry the old seed in their arguments
         (void)hipGraphExecDestroy(h->graph_exec);
         h->graph_exec = nullptr;
@@ -496,6 +497,7 @@ static int gu_step_action_error(gu_engine *h, const int32_t *actions)
 {
     __atomic_store_n(h->h_seq + GU_HOST_ERR_WORD, 0u, __ATOMIC_RELAXED);
     h->off_lo -= 1;  // (the rejected envs did not step: their offsets to the lock-step counter went down by one)
+    h->off_exact = false;
     for (int64_t i = 0; i < h->N; ++i)
         if (!GU_ACTION_OK(actions[i]))
             return gu_fail(GU_ERR_INVALID, "action %d of env %lld outside 0..3 (that env did not step; envs with valid actions did)", actions[i], (long long)i);
@@ -1142,6 +1144,7 @@ int gu_set_state(gu_handle h, const int32_t *pos, const int32_t *done, const uin
         h->steps_taken = t_min;
         h->off_lo = 0;
         h->off_hi = (int64_t)(t_max - t_min);
+        h->off_exact = true;
         if (h->graph_exec) {  // (captured rollout-free step launches carry no count, but a stale graph is not worth the doubt)
             (void)hipGraphExecDestroy(h->graph_exec);
             h->graph_exec = nullptr;

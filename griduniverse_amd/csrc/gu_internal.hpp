@@ -146,6 +146,7 @@ struct gu_engine {
     uint32_t *d_tcount = nullptr;  // per-env step-count OFFSET (read as int32); effective 64-bit count = steps_taken + offset
     uint64_t steps_taken = 0;      // lock-step counter since gu_seed (all envs step together)
     int64_t off_lo = 0, off_hi = 0;  // what the host knows of the offsets: off_lo <= every offset <= off_hi (gu_set_state, rejected actions)
+    bool off_exact = true;           // ... and whether both bounds are attained (false behind a rejected action: read back when it matters)
     uint64_t seed = 0;
     uint32_t seed_prefix = 0;
 

@@ -589,8 +589,18 @@ int gu_launch_rollout(gu_engine *h, int64_t T, int32_t policy, uint32_t flags)
     {   // The epoch (step count >> 32) of RNG streams 0 and 2, csrc/gu_rng.hpp: folded into the seed prefix when every env stays in
         // ONE epoch for the whole launch (the kernels then count in 32 bits, as ever); else -- once in 2^32 steps -- the launch goes
         // to the general kernel, which asks per lane and step.  The stream and greedy policies draw nothing from those streams.
-        const int64_t lo = std::max<int64_t>((int64_t)h->steps_taken + h->off_lo, 0), hi = (int64_t)h->steps_taken + h->off_hi + T - 1;
         const bool draws = policy == GU_POLICY_UNIFORM || policy == GU_POLICY_SAMPLE;
+        int64_t lo = std::max<int64_t>((int64_t)h->steps_taken + h->off_lo, 0), hi = (int64_t)h->steps_taken + h->off_hi + T - 1;
+        if (draws && (lo >> 32) != (hi >> 32) && !h->off_exact) {
+            // the bounds are only bounds (envs were held back by rejected actions since the host last knew): read the offsets once,
+            // so that launches do not take the slow path for longer than the envs really are on both sides of the boundary
+            std::vector<int32_t> off((size_t)h->N);
+            GU_HIP(hipMemcpyAsync(off.data(), h->d_tcount, (size_t)h->N * 4, hipMemcpyDeviceToHost, h->stream));
+            GU_HIP(hipStreamSynchronize(h->stream));
+            const auto mm = std::minmax_element(off.begin(), off.end());
+            h->off_lo = *mm.first, h->off_hi = *mm.second, h->off_exact = true;
+            lo = std::max<int64_t>((int64_t)h->steps_taken + h->off_lo, 0), hi = (int64_t)h->steps_taken + h->off_hi + T - 1;
+        }
         a.straddle = draws && (lo >> 32) != (hi >> 32) ? 1 : 0;
         a.seed_prefix = a.straddle ? h->seed_prefix : gu_rng_seed_prefix_epoch(h->seed_prefix, (uint32_t)(lo >> 32));
     }

@@ -598,6 +598,7 @@ __global__ void __launch_bounds__(GU_MAX_BLOCK) gu_rollout_kernel(const RolloutA
         } else if (TRAJ == 3) {  // one 12-byte store per lane and step: the wave's 768 bytes are contiguous
             const gu_v3u triple = {(uint32_t)s_, (uint32_t)r_, d_};
             __builtin_amdgcn_raw_buffer_store_b96(triple, ro, te, soff, GU_STORE_AUX);
+            GU_WIDE_STORE_PAD();
         }
     };
     // MAP 5 holds a step's row back until the NEXT step's gather has been issued: LDS and vector-memory instructions of a wave go

@@ -385,6 +385,7 @@ __global__ void __launch_bounds__(GU_ROWS_MAX_BLOCK) gu_rollout_rows_kernel(cons
             } else if (TRAJ == 3) {
                 const gu_v3u triple = {(uint32_t)cell, (uint32_t)r, dn};
                 __builtin_amdgcn_raw_buffer_store_b96(triple, ro, te, soff, GU_STORE_AUX);
+            GU_WIDE_STORE_PAD();
             } else {
                 __builtin_amdgcn_raw_buffer_store_b32((int32_t)((uint32_t)cell | (((uint32_t)r & 0xFFu) << 16) | (dn << 24)), ro, e4, soff, GU_STORE_AUX_PACKED);
             }

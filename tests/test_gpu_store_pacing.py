@@ -10,7 +10,10 @@ from griduniverse_amd import Engine, GridSpec
 from oracle import c_oracle as C
 from tests import _golden as G
 
-pytestmark = pytest.mark.gpu
+import os
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(bool(os.environ.get('GU_TEST_OPTIONS')), reason='about the DEFAULT dispatch and pacing: not under forced launch-shape options')]
 
 
 def spec_of(meta):

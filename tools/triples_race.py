@@ -8,10 +8,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from griduniverse_amd import Engine, GridSpec, _lib  # noqa: E402
-from tests import _golden as G  # noqa: E402
+from benchlib.workloads import build_workload  # noqa: E402
 
-meta, _ = G.load_traj('c3_maze32')
-spec = GridSpec(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'])
+spec = GridSpec.from_env(build_workload('c3')[0])
 N, T = 65536, 120
 
 

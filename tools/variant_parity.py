@@ -14,7 +14,7 @@ if '--root' in args:
     del args[args.index('--root'):args.index('--root') + 2]
 sys.path.insert(0, root)
 from griduniverse_amd import Engine, GridSpec, _lib  # noqa: E402
-from tests import _golden as G  # noqa: E402
+from benchlib.workloads import build_workload  # noqa: E402
 
 for item in args:
     k, v = item.split('=')
@@ -22,19 +22,18 @@ for item in args:
 print('root', root, 'options', args)
 
 
-def spec_of(meta):
-    return GridSpec(meta['W'], meta['H'], meta['starts'], meta['goals'], meta['lava'], meta['walls'], meta['reward'])
+def spec_of(name):
+    return GridSpec.from_env(build_workload(name)[0])
 
 
-for name, N, T in (('c2_open8x8', 4096, 300), ('c4_lava32', 32768, 160), ('c3_maze32', 65536, 120)):
+for name, N, T in (('c2', 4096, 300), ('c4', 32768, 160), ('c3', 65536, 120)):
     for policy in ('uniform', 'greedy'):
-        meta, _ = G.load_traj(name)
-        S = meta['W'] * meta['H']
+        S = spec_of(name).S
         outs = {}
         for layout, rows in ((0, None), (1, None), (-1, None), (1, 0), (1, 3), (0, 0)):
             _lib.set_default_option('traj_layout', layout)
             _lib.set_default_option('rollout_rows', rows)
-            with Engine(N, spec_of(meta), seed=11, env_id0=5) as eng:
+            with Engine(N, spec_of(name), seed=11, env_id0=5) as eng:
                 eng.reset()
                 eng.reserve_trajectory(T)
                 if policy == 'greedy':

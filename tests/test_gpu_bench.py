@@ -70,9 +70,10 @@ def test_default_workload_line_carries_the_contract_and_its_own_checks(tmp_path)
     for name in ('c2', 'c4_shard', 'c3_distinct_1024', 'c3_distinct_65536'):
         assert full[name]['hbm_gbps'] < 8000.0 and 0.0 < cfg[name]['frac_of_hbm_peak'] < 1.0
     # the shard's launch split into a fixed part and a per-step slope (T = 1000 against T = 4000)
-    assert 0.5 < cfg['c4_shard']['asymptote_frac_of_hbm_peak'] < 1.0 and -5.0 < cfg['c4_shard']['fixed_us_per_launch'] < 20.0
+    # (a slope from two noisy launch times: 0.84 .. 0.96 on the boxes of round 6; the bounds only catch nonsense)
+    assert 0.5 < cfg['c4_shard']['asymptote_frac_of_hbm_peak'] < 1.25 and -10.0 < cfg['c4_shard']['fixed_us_per_launch'] < 25.0
     # one maze per env streams its rows like the shared maze does (round 5: 0.53 of the peak on private byte planes)
-    assert cfg['c3_distinct_65536']['frac_of_hbm_peak'] > 0.7 and cfg['c3_distinct_1024']['frac_of_hbm_peak'] > 0.7
+    assert cfg['c3_distinct_65536']['frac_of_hbm_peak'] > 0.65 and cfg['c3_distinct_1024']['frac_of_hbm_peak'] > 0.65  # (measured 0.78 .. 0.82 / 0.84 .. 0.91)
     topo = detail['topology']
     assert topo['hip_device_count'] >= 1 and topo['devices'][0]['pci'] and topo['rccl_library']
     assert detail['device'] and detail['roofline']['store_pacing'] and detail['roofline']['trajectory_placement']

@@ -182,6 +182,9 @@ def run(args, engine_cls=None, emit=print):
                          'traffic': hbm_bytes, 'traffic_measured_by_child_runs': bool(measured),
                          'traffic_over_algorithmic': hbm_bytes / float(BYTES_PER_ENV_STEP * N * T) if hbm_bytes else None,
                          'kernel': 'gu_rollout_kernel<UNIFORM,TRAJ,LDS>', 'launch_ms': launch_s * 1e3,
+                         # the same kernel's average duration in the committed rocprofv3 --kernel-trace summary (profiles/), for comparison
+                         'kernel_avg_us': None if traffic is None else traffic.get('kernel_avg_us'),
+                         'kernel_avg_us_profile': None if traffic is None else traffic.get('tag'),
                          'algorithmic_bytes_per_launch': BYTES_PER_ENV_STEP * N * T,
                          'traffic_source': measured['source'] if measured else None if traffic is None else traffic.get('source'),
                          'traffic_live': measured,

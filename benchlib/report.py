@@ -162,7 +162,7 @@ def compact_line(detail, detail_path=None):
     line = {k: detail[k] for k in CONTRACT}
     line['config'] = _pick(detail['config'], ('workload', 'envs_per_gpu', 'env_steps_per_launch', 'global_envs', 'parallelism', 'devices'))
     line['roofline'] = _pick(detail['roofline'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_wall', 'traffic', 'traffic_over_algorithmic',
-                                                  'traffic_measured_by_child_runs', 'kernel', 'launch_ms', 'algorithmic_bytes_per_launch',
+                                                  'traffic_measured_by_child_runs', 'kernel', 'launch_ms', 'kernel_avg_us', 'kernel_avg_us_profile', 'algorithmic_bytes_per_launch',
                                                   'vs_measured_copy_rate'))
     if 'cpu_baseline' in detail:
         cpu = _pick(detail['cpu_baseline'], ('value', 'unit', 'cores', 'kind', 'sample', 'host_cpu_model', 'host_cpu_count', 'host_usable_cores',

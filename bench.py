@@ -37,6 +37,7 @@ and config 4 -- 262 144 envs on the lava grid in total, split over the ranks -- 
 import argparse
 import os
 import sys
+import threading
 
 import numpy as np
 
@@ -130,17 +131,9 @@ def run(args, engine_cls=None, emit=print):
     if not args.no_other_modes and hasattr(eng, 'read_stats'):
         others = other_modes(eng, template, seed, rank * N, N, T, K, rank == 0 and not args.no_checks)
 
-    rccl = None
-    if world > 1 or args.gather_view:
-        try:
-            with native_stdout_to_stderr():
-                rccl = rccl_view_check(eng, engine_cls, ranks)
-        except gua.GuError as err:  # reported, not fatal: the throughput line above does not depend on the collective
-            rccl = dict(nranks=world, view_equals_shards=None, error=str(err))
     per_rank = ranks.gather([float(np.median(own_wall))])
     placement = placement_block(eng, post_probe_ms, float(np.median(kern)) / K)
     pacing = pacing_block(eng)
-    eng.close()
     c4 = None if args.no_strong_c4 else strong_c4(args, ranks, engine_cls, device, pacing_block)
     configs = None
     if world == 1 and not args.no_configs:
@@ -197,7 +190,7 @@ def run(args, engine_cls=None, emit=print):
             'engine': engine_cls.__module__ + '.' + engine_cls.__name__,
             # every rank's own median block (the N = 1 run of this script reports exactly this figure as `value`)
             'per_rank': {'ms_per_step': [v[0] / K * 1e3 for v in per_rank], 'value': [float(N) * T * K / v[0] for v in per_rank]},
-            'rccl': rccl, 'strong_c4': c4, 'other_modes': others, 'configs': configs,
+            'rccl': None, 'strong_c4': c4, 'other_modes': others, 'configs': configs,
             'topology': topology_block(engine_cls),
         }
         detail.update(found)
@@ -205,7 +198,36 @@ def run(args, engine_cls=None, emit=print):
             base = cpu_baseline(template, seed, T)
             base['all_cores'] = all_cores
             detail['cpu_baseline'] = base
+    # ---- LAST: the RCCL gathered view (never run with more than one rank before the driver's own multi-GPU run).  Nothing follows
+    # it but the line, and a watchdog stands behind it: a collective that does not come back costs the `rccl` object, not the line.
+    if world > 1 or args.gather_view:
+        box = {}
+
+        def check():
+            try:
+                with native_stdout_to_stderr():
+                    box['rccl'] = rccl_view_check(eng, engine_cls, ranks)
+            except gua.GuError as err:  # reported, not fatal: the throughput line does not depend on the collective
+                box['rccl'] = dict(nranks=world, view_equals_shards=None, error=str(err))
+            except Exception as err:  # noqa: BLE001 -- (a peer that left the host channel while this rank was still in the check)
+                box['rccl'] = dict(nranks=world, view_equals_shards=None, error='%s: %s' % (type(err).__name__, err))
+
+        limit = float(os.environ.get('GU_RCCL_CHECK_TIMEOUT', '180'))
+        worker = threading.Thread(target=check, daemon=True)
+        worker.start()
+        worker.join(limit)
+        if worker.is_alive():  # the thread sits in native code: this process can only report and leave
+            if rank == 0:
+                detail['rccl'] = dict(nranks=world, view_equals_shards=None, error='the RCCL view check did not come back within %.0f s' % limit)
+                emit_report(detail, emit, args.detail)
+            sys.stdout.flush()
+            sys.stderr.write('bench.py: rank %d: the RCCL view check did not come back within %.0f s; leaving\n' % (rank, limit))
+            os._exit(0)
+        if rank == 0:
+            detail['rccl'] = box.get('rccl')
+    if rank == 0:
         emit_report(detail, emit, args.detail)
+    eng.close()
     ranks.close()
 
 

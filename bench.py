@@ -205,8 +205,7 @@ def run(args, engine_cls=None, emit=print):
 
         def check():
             try:
-                with native_stdout_to_stderr():
-                    box['rccl'] = rccl_view_check(eng, engine_cls, ranks)
+                box['rccl'] = rccl_view_check(eng, engine_cls, ranks)
             except gua.GuError as err:  # reported, not fatal: the throughput line does not depend on the collective
                 box['rccl'] = dict(nranks=world, view_equals_shards=None, error=str(err))
             except Exception as err:  # noqa: BLE001 -- (a peer that left the host channel while this rank was still in the check)
@@ -214,8 +213,9 @@ def run(args, engine_cls=None, emit=print):
 
         limit = float(os.environ.get('GU_RCCL_CHECK_TIMEOUT', '180'))
         worker = threading.Thread(target=check, daemon=True)
-        worker.start()
-        worker.join(limit)
+        with native_stdout_to_stderr():  # (RCCL's banner; restored HERE, by this thread, whatever becomes of the worker)
+            worker.start()
+            worker.join(limit)
         if worker.is_alive():  # the thread sits in native code: this process can only report and leave
             if rank == 0:
                 detail['rccl'] = dict(nranks=world, view_equals_shards=None, error='the RCCL view check did not come back within %.0f s' % limit)

@@ -82,6 +82,9 @@ class OracleEngine(object):
         return os.urandom(128)
 
     def comm_init(self, nranks, rank, unique_id):
+        if os.environ.get('GU_TEST_HANG_RCCL'):  # (tests/test_multiprocess.py: a collective that never comes back)
+            import time
+            time.sleep(3600)
         self.nranks, self.rank, self.uid = nranks, rank, bytes(unique_id)
         everyone = type(self).host_channel.allgather_bytes(self.uid) if nranks > 1 else [self.uid]
         assert len(everyone) == nranks and all(u == self.uid for u in everyone), 'ranks disagree on the unique id'

@@ -227,3 +227,18 @@ def test_a_rank_that_dies_takes_the_launch_down_at_once():
                           timeout=120)
     assert proc.returncode == 3 and time.time() - t0 < 60, (proc.returncode, time.time() - t0)
     assert proc.stdout.strip() == b'' and b'rank 1 exited with code 3' in proc.stderr
+
+
+def test_a_collective_that_never_comes_back_costs_the_rccl_object_not_the_line():
+    """RCCL with more than one rank has never run before the driver's own multi-GPU run.  The view check is the LAST thing bench.py
+    does, behind a watchdog: if it hangs, rank 0 still prints its line (with the refusal in `rccl.error`) and every rank leaves with
+    exit code 0."""
+    import time
+    env = dict(_scrubbed_env(), GU_TEST_HANG_RCCL='1', GU_RCCL_CHECK_TIMEOUT='3')
+    t0 = time.time()
+    proc = subprocess.run([sys.executable, BENCH_ON_STUB, '--gpus', '2'] + STUB, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=300)
+    line = _one_json_line(proc)
+    assert time.time() - t0 < 120
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['strong_c4']['shards_equal_oracle'] is True
+    assert line['rccl']['view_equals_shards'] is None and 'did not come back' in line['rccl']['error']

@@ -280,11 +280,13 @@ struct GridSel {
     int64_t grid_stride;     // bytes between consecutive grids' plane pairs (2 * cell_bytes)
     const int32_t *n_starts; // [n_grids]
     int32_t n_grids, max_starts;
+    int32_t per_wave;        // LDS variants: every WAVE of a workgroup stages the planes of its own grid (groups of 64 .. 192 envs under
+                             // workgroups of 256: the launch shape of the shared grid); 0: one grid per workgroup
 };
 
 inline GridSel gu_grid_sel(const gu_engine *h)
 {
-    return GridSel{h->group, 2 * (int64_t)h->cell_bytes, h->d_nstarts, h->n_grids, h->max_starts};
+    return GridSel{h->group, 2 * (int64_t)h->cell_bytes, h->d_nstarts, h->n_grids, h->max_starts, 0};
 }
 
 // ---- error plumbing --------------------------------------------------------------

@@ -247,7 +247,7 @@ template <bool LDS>
 __global__ void __launch_bounds__(GU_BLOCK) gu_lookahead_kernel(const LookArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const CellMap m = gu_stage_map<LDS>(a.cell_move, a.cell_bytes, smem, GridSel{0, 0, nullptr, 1, 0});
+    const CellMap m = gu_stage_map<LDS>(a.cell_move, a.cell_bytes, smem, GridSel{0, 0, nullptr, 1, 0, 0});
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     int32_t s = a.states[i];

@@ -18,7 +18,10 @@ struct CellMap {
 // multiple of the block size -- the launcher guarantees it), whose planes are staged into LDS.
 __device__ __forceinline__ uint32_t gu_block_grid(const GridSel &gs)
 {
-    return gs.n_grids > 1 ? (uint32_t)(((int64_t)blockIdx.x * blockDim.x) / gs.group) : 0u;
+    if (gs.n_grids <= 1) return 0u;
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + (gs.per_wave ? (int64_t)(threadIdx.x & ~63u) : 0);  // the workgroup's / the wave's first env
+    const int64_t grid = first / gs.group;
+    return (uint32_t)(grid < gs.n_grids ? grid : gs.n_grids - 1);  // (a wave past the batch stages the last grid: its lanes leave right after)
 }
 
 template <bool LDS>
@@ -27,8 +30,14 @@ __device__ __forceinline__ CellMap gu_stage_map(const uint8_t *__restrict__ g, i
 {
     if (LDS) {
         g += (int64_t)gu_block_grid(gs) * gs.grid_stride;
-        for (int32_t i = threadIdx.x * 16; i < planes * cell_bytes; i += blockDim.x * 16)
-            *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(g + i);
+        if (gs.per_wave) {  // every wave its own grid, in its own region of the workgroup's LDS
+            smem += (threadIdx.x >> 6) * (uint32_t)(planes * cell_bytes);
+            for (int32_t i = (threadIdx.x & 63) * 16; i < planes * cell_bytes; i += 64 * 16)
+                *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(g + i);
+        } else {
+            for (int32_t i = threadIdx.x * 16; i < planes * cell_bytes; i += blockDim.x * 16)
+                *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(g + i);
+        }
         __syncthreads();
         return CellMap{smem, reinterpret_cast<const int8_t *>(smem + cell_bytes)};
     }

@@ -918,10 +918,18 @@ static void gu_rollout_launch(gu_engine *h, const RolloutArgs &a_in, int bs)
     auto blocks_ok = [&](int block) { return gu_blocks(h->N, block) % 8 == 0; };
     auto n_blocks = [&](int block) { return gu_blocks(h->N, block); };
     const int planes = POLICY == GU_POLICY_GREEDY ? 3 : 2;
-    const int lds_bs = gu_lds_block(h, bs, planes);
+    int lds_bs = gu_lds_block(h, bs, planes);
+    // Groups of 64 .. 192 envs (a multiple of 64, smaller than the workgroup): every wave stages its own grid's planes, so the launch
+    // keeps the workgroup size of the shared-grid launch -- whose store stream the memory takes at a shorter period than that of
+    // one-wave workgroups (profiles/r06m_multigrid_ab.txt).  Uniform and stream policies (the table policies keep one grid anyway).
+    bool per_wave = false;
+    if ((POLICY == GU_POLICY_UNIFORM || POLICY == GU_POLICY_STREAM) && lds_bs && lds_bs < bs && h->n_grids > 1 && h->group % 64 == 0 &&
+        (size_t)(bs / 64) * planes * h->cell_bytes <= 32768)
+        per_wave = true, lds_bs = bs;
     if (lds_bs) {
-        size_t lds = (size_t)planes * h->cell_bytes;
+        size_t lds = (size_t)planes * h->cell_bytes * (per_wave ? (size_t)(bs / 64) : 1);
         RolloutArgs b = a;
+        b.gs.per_wave = per_wave ? 1 : 0;
         b.xcd_remap = a.xcd_remap && blocks_ok(lds_bs);
         if (POLICY == GU_POLICY_SAMPLE && lds + (size_t)h->S * sizeof(uint4) <= 65536) {
             b.pi_lds = 1;
